@@ -1,0 +1,165 @@
+/* pfd.h — C-ABI of libpfd_hip.so: MI355X-native D8 flow-accumulation hot path.
+ *
+ * This is the drop-in boundary for the path
+ *     D8 raster -> downstream graph -> cell ordering -> accuflux / upstream_area,
+ *     Strahler order, basins, HAND
+ * of Deltares/pyflwdir (reference v0.5.12).  The reference has no FFI of its own: its seam
+ * is "method on FlwdirRaster validates & flattens, then calls a free function on flat
+ * C-contiguous numpy arrays" (reference pyflwdir/flwdir.py:567-602, pyflwdir/pyflwdir.py:
+ * 770-801, :564-599, :1485-1511).  Each entry point below replaces one of those free
+ * functions and cites it.  Plain C: opaque handle, plain pointers and sizes, int status.
+ *
+ * Conventions
+ *   - Every function returns PFD_OK (0) or a negative PFD_E* code; pfd_last_error() gives
+ *     the message of the last failure on the calling thread.
+ *   - Rasters are row-major (C order), linear cell index i = r*ncol + c.
+ *   - `memspace` says where the caller's buffers live: PFD_HOST (the library stages them
+ *     through HBM) or PFD_DEVICE (pointers into the HBM of the handle's GPU; nothing is
+ *     copied).  Inputs are never modified; outputs are caller-allocated and fully written.
+ *   - A handle owns all device state (normalised D8 codes, level structure, scratch) of one
+ *     raster (or one row block of a raster in a multi-GPU job) on one GPU.  Handles are not
+ *     thread-safe; use one per host thread / process.
+ */
+#ifndef PFD_H_
+#define PFD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFD_ABI_VERSION 1
+
+/* status codes */
+#define PFD_OK 0
+#define PFD_EINVAL (-1)      /* bad argument (shape, dtype code, NULL pointer, ...) */
+#define PFD_ENODEVICE (-2)   /* no usable HIP device / device index out of range */
+#define PFD_EHIP (-3)        /* a HIP runtime call failed (message has the HIP error) */
+#define PFD_ENOMEM (-4)      /* device or host allocation failed */
+#define PFD_EBADCODE (-5)    /* raster holds a value that is not a D8 code (core_d8._all) */
+#define PFD_ENOPITS (-6)     /* raster has no pit: reference raises "no pits found" */
+#define PFD_EUNSUPPORTED (-7)/* valid request outside what the HIP path implements */
+#define PFD_ECOMM (-8)       /* RCCL call failed (multi-GPU) */
+
+/* memory spaces */
+#define PFD_HOST 0
+#define PFD_DEVICE 1
+
+/* element dtype codes (payloads and index exports) */
+#define PFD_I32 1
+#define PFD_U32 2
+#define PFD_I64 3
+#define PFD_F32 4
+#define PFD_F64 5
+
+/* accumulation direction: streams.accuflux (up) / streams.accuflux_ds (down) */
+#define PFD_UP 0
+#define PFD_DOWN 1
+
+typedef struct pfd_raster pfd_raster;
+
+/* ---- library / device --------------------------------------------------------------- */
+int pfd_abi_version(void);
+const char *pfd_last_error(void);
+int pfd_device_count(int *count);
+/* device memory helpers so that a ctypes caller can keep rasters resident in HBM without
+ * any other GPU library (bench.py uses these). */
+int pfd_malloc(int device, size_t bytes, void **ptr);
+int pfd_free(int device, void *ptr);
+int pfd_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+int pfd_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
+int pfd_device_synchronize(int device);
+
+/* ---- raster handle -------------------------------------------------------------------
+ * pfd_raster_create: replaces core_d8.from_array (reference pyflwdir/core_d8.py:42-67) as the
+ * constructor of the device-side graph.  `d8` holds nrow*ncol uint8 D8 codes (1 E, 2 SE,
+ * 4 S, 8 SW, 16 W, 32 NW, 64 N, 128 NE, 0/255 pit, 247 nodata; core_d8.py:14-19).  Cells
+ * whose target lies outside the raster or on a nodata cell become pits (core_d8.py:57-63).
+ * Any other value -> PFD_EBADCODE (the reference only accepts such rasters with
+ * check_ftype=False and then decodes them with log2 arithmetic the device path does not
+ * imitate).  Fails with PFD_ENOPITS when no pit exists (reference pyflwdir/flwdir.py:126).
+ * Limit: nrow*ncol <= 4294967294 per handle (32-bit device indices). */
+int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, int memspace, int device,
+                      pfd_raster **out);
+int pfd_raster_destroy(pfd_raster *h);
+
+/* info[0]=nrow [1]=ncol [2]=n_valid [3]=n_pits [4]=n_seq (cells draining to a pit; -1 until
+ * the cells are ordered) [5]=n_levels (max rank + 1; -1 until ordered) [6]=device
+ * [7]=bytes of HBM held by the handle */
+int pfd_raster_info(pfd_raster *h, int64_t info[8]);
+
+/* FlwdirRaster.add_pits (reference pyflwdir/flwdir.py:261-279): turn the given cells into
+ * pits and invalidate the ordering.  Indices must address valid cells. */
+int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k);
+
+/* ---- index exports (public attributes of FlwdirRaster) ------------------------------- */
+/* idxs_ds in the reference's index dtype (PFD_I32/PFD_U32/PFD_I64; pyflwdir.py:105-127):
+ * -1 (cast) on nodata, own index on pits.  core_d8.from_array, core_d8.py:42-67. */
+int pfd_idxs_ds(pfd_raster *h, int idx_dtype, void *out, int memspace);
+/* pit indices ascending; out has n_pits entries.  core_d8.py:62 / core.pit_indices */
+int pfd_idxs_pit(pfd_raster *h, int idx_dtype, void *out, int memspace);
+/* core.upstream_count (reference pyflwdir/core.py:50-61): int8 in-degree, -9 on nodata;
+ * `mask` (uint8, may be NULL) restricts the contributing cells. */
+int pfd_upstream_count(pfd_raster *h, const uint8_t *mask, int8_t *out, int memspace);
+/* Flwdir.order_cells("walk") (reference pyflwdir/flwdir.py:231-250): build the level
+ * structure (cells grouped by rank) that every sweep below uses.  Called implicitly. */
+int pfd_order_cells(pfd_raster *h);
+/* core.idxs_seq (reference pyflwdir/core.py:87-117): the exact breadth-first order of the
+ * reference (pits ascending, then each dequeued cell's upstream cells ascending); out has
+ * n_seq entries. */
+int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace);
+/* core.rank (reference pyflwdir/core.py:17-47): int32 distance to the pit, -1 for cells that
+ * do not drain to a pit, -9999 on nodata. */
+int pfd_rank(pfd_raster *h, int32_t *out, int memspace);
+
+/* ---- sweeps ---------------------------------------------------------------------------- */
+/* FlwdirRaster.upstream_area(unit="cell") (reference pyflwdir/pyflwdir.py:770-801): int32
+ * upstream cell count incl. the cell itself, -9999 on nodata cells, cells that do not drain
+ * to a pit keep 1.  Fused fast path (no weight array is read). */
+int pfd_upstream_area_cell(pfd_raster *h, int32_t *out, int memspace);
+/* same result through the generic level-by-level engine (kept for cross-checking) */
+int pfd_upstream_area_cell_levels(pfd_raster *h, int32_t *out, int memspace);
+/* streams.accuflux / streams.accuflux_ds (reference pyflwdir/streams.py:15-41, :44-70).
+ * dtype in {PFD_I32, PFD_I64, PFD_F32, PFD_F64}; `nodata_i` is used for the integer types,
+ * `nodata_f` for the float types; has_nodata=0 disables the nodata test (the Python
+ * comparison can never match, e.g. NaN).  Children are added in the reference's order
+ * (descending linear index), so float results are bit-identical to the serial loop.
+ * If mask_invalid != 0 nodata cells of the raster are set to `nodata` afterwards
+ * (FlwdirRaster.upstream_area, pyflwdir.py:800). */
+int pfd_accuflux(pfd_raster *h, int dtype, const void *data, int64_t nodata_i, double nodata_f,
+                 int has_nodata, int direction, int mask_invalid, void *out, int memspace);
+/* streams.strahler_order (reference pyflwdir/streams.py:228-269); mask uint8 or NULL. */
+int pfd_strahler(pfd_raster *h, const uint8_t *mask, uint8_t *out, int memspace);
+/* basins.basins + core.fillnodata_upstream (reference pyflwdir/basins.py:12-18,
+ * pyflwdir/core.py:120-146): `outlets` are k linear indices (host memory, always), `ids`
+ * their k labels of `id_size` bytes each (1, 2, 4 or 8; no zeros).  out: n labels. */
+int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k, int id_size,
+               void *out, int memspace);
+/* dem.height_above_nearest_drain (reference pyflwdir/dem.py:299-330): drain uint8 (==1 is
+ * drain), elevtn PFD_F32 or PFD_F64, out float64 (-9999 off the sequence). */
+int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, double *out,
+             int memspace);
+
+/* ---- instrumentation ---------------------------------------------------------------------
+ * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST
+ * sweep/ordering call on the handle.  Enable with pfd_set_profiling(h, 1).  Up to max_seg
+ * segments are returned: ms[i] GPU milliseconds, launches[i] kernel launches in the segment,
+ * names = segment names joined by ';' (e.g. "order_cells;init;sweep_count_up"). */
+int pfd_set_profiling(pfd_raster *h, int enable);
+int pfd_last_timing(pfd_raster *h, int max_seg, double *ms, int64_t *launches, char *names,
+                    size_t names_len, int *nseg);
+
+/* ---- synthetic rasters (bench / tests; device twin of oracle/pfd_oracle.c orc_synth_*) ---- */
+/* writes rows [row0, row0+nrows) of the nrow x ncol synthetic raster to device memory */
+int pfd_synth_d8(int device, uint64_t seed, int64_t nrow, int64_t ncol, int64_t tilt, int64_t white,
+                 int32_t nodata_pct, int64_t row0, int64_t nrows, uint8_t *out_dev);
+int pfd_synth_elev_f32(int device, uint64_t seed, int64_t nrow, int64_t ncol, int64_t tilt,
+                       int64_t white, int32_t nodata_pct, int64_t row0, int64_t nrows, float *out_dev);
+int pfd_synth_weights_f32(int device, uint64_t seed, int64_t i0, int64_t n, float *out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFD_H_ */

@@ -1,0 +1,282 @@
+"""ctypes binding of libpfd_hip.so — the C-ABI declared in include/pfd.h.
+
+There is deliberately NO fallback: if the shared library is missing, or no MI355X/HIP device
+is visible, every entry point raises.  The CPU oracle under oracle/ is test infrastructure and
+is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpfd_hip.so")
+
+PFD_HOST, PFD_DEVICE = 0, 1
+PFD_I32, PFD_U32, PFD_I64, PFD_F32, PFD_F64 = 1, 2, 3, 4, 5
+PFD_UP, PFD_DOWN = 0, 1
+
+IDX_CODE = {np.dtype(np.int32): PFD_I32, np.dtype(np.uint32): PFD_U32, np.dtype(np.int64): PFD_I64}
+
+# status code -> Python exception (messages come from pfd_last_error()).  PFD_ENOPITS and
+# PFD_EBADCODE map to the ValueErrors the reference raises for the same conditions
+# (reference pyflwdir/flwdir.py:126-127, pyflwdir/pyflwdir.py:181-182).
+_ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, -5: ValueError,
+           -6: ValueError, -7: NotImplementedError, -8: RuntimeError}
+
+# every symbol include/pfd.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "pfd_abi_version", "pfd_last_error", "pfd_device_count", "pfd_malloc", "pfd_free", "pfd_memcpy_h2d",
+    "pfd_memcpy_d2h", "pfd_device_synchronize", "pfd_raster_create", "pfd_raster_destroy", "pfd_raster_info",
+    "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
+    "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
+    "pfd_basins", "pfd_hand", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
+    "pfd_synth_weights_f32",
+]
+
+_lib = None
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libpfd_hip.so (once).  Raises HipLibraryMissing when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build the HIP extension first (python -m pyflwdir_amd.build, "
+                "needs hipcc/ROCm).  pyflwdir_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.pfd_last_error.restype = C.c_char_p
+        for name in SYMBOLS:
+            if name != "pfd_last_error":
+                getattr(L, name).restype = C.c_int
+        L.pfd_raster_create.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pfd_raster_destroy.argtypes = [C.c_void_p]
+        L.pfd_raster_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.pfd_add_pits.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.pfd_idxs_ds.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.pfd_idxs_pit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.pfd_idxs_seq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.pfd_upstream_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_order_cells.argtypes = [C.c_void_p]
+        L.pfd_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_upstream_area_cell.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_upstream_area_cell_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_accuflux.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_int]
+        L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
+        L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
+                                      C.POINTER(C.c_int)]
+        L.pfd_malloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.pfd_free.argtypes = [C.c_int, C.c_void_p]
+        L.pfd_memcpy_h2d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.pfd_memcpy_d2h.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.pfd_device_synchronize.argtypes = [C.c_int]
+        L.pfd_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.pfd_synth_d8.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                   C.c_int64, C.c_int64, C.c_void_p]
+        L.pfd_synth_elev_f32.argtypes = L.pfd_synth_d8.argtypes
+        L.pfd_synth_weights_f32.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().pfd_last_error().decode("utf-8", "replace")
+        raise _ERRORS.get(rc, RuntimeError)(msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().pfd_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def ptr(a):
+    """void* of a numpy array (None -> NULL) or pass-through for raw device addresses."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, DeviceBuffer):
+        return C.c_void_p(a.addr)
+    return C.c_void_p(int(a))
+
+
+class DeviceBuffer:
+    """A plain HBM allocation owned by Python (no torch): bench.py keeps the D8 raster and the
+    result resident with these and passes them with memspace=PFD_DEVICE."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        check(lib().pfd_malloc(device, C.c_size_t(self.nbytes), C.byref(p)))
+        self.addr = p.value
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(lib().pfd_memcpy_h2d(self.device, C.c_void_p(self.addr), ptr(arr), C.c_size_t(arr.nbytes)))
+        return self
+
+    def download(self, dtype, shape, offset_bytes: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes + offset_bytes <= self.nbytes
+        check(lib().pfd_memcpy_d2h(self.device, ptr(out), C.c_void_p(self.addr + offset_bytes), C.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.addr:
+            check(lib().pfd_free(self.device, C.c_void_p(self.addr)))
+            self.addr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class RasterHandle:
+    """Owner of one ``pfd_raster`` (device-side graph of one raster on one GPU)."""
+
+    def __init__(self, d8, nrow: int, ncol: int, device: int = 0, memspace: int = PFD_HOST):
+        self._h = C.c_void_p()
+        self.nrow, self.ncol, self.n = int(nrow), int(ncol), int(nrow) * int(ncol)
+        self.device = device
+        if isinstance(d8, np.ndarray):
+            d8 = np.ascontiguousarray(d8, dtype=np.uint8)
+            assert d8.size == self.n
+        check(lib().pfd_raster_create(ptr(d8), self.nrow, self.ncol, memspace, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().pfd_raster_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- info -------------------------------------------------------------------------------
+    def info(self) -> dict:
+        a = (C.c_int64 * 8)()
+        check(lib().pfd_raster_info(self._h, a))
+        keys = ["nrow", "ncol", "n_valid", "n_pits", "n_seq", "n_levels", "device", "bytes_held"]
+        return dict(zip(keys, [int(v) for v in a]))
+
+    def set_profiling(self, on: bool = True):
+        check(lib().pfd_set_profiling(self._h, int(on)))
+
+    def last_timing(self):
+        ms = (C.c_double * 16)()
+        ln = (C.c_int64 * 16)()
+        names = C.create_string_buffer(512)
+        k = C.c_int(0)
+        check(lib().pfd_last_timing(self._h, 16, ms, ln, names, 512, C.byref(k)))
+        nm = names.value.decode().split(";") if k.value else []
+        return [dict(name=nm[i], ms=ms[i], launches=int(ln[i])) for i in range(k.value)]
+
+    # -- graph exports ----------------------------------------------------------------------
+    def idxs_ds(self, dtype) -> np.ndarray:
+        out = np.empty(self.n, dtype)
+        check(lib().pfd_idxs_ds(self._h, IDX_CODE[np.dtype(dtype)], ptr(out), PFD_HOST))
+        return out
+
+    def idxs_pit(self, dtype) -> np.ndarray:
+        out = np.empty(self.info()["n_pits"], dtype)
+        check(lib().pfd_idxs_pit(self._h, IDX_CODE[np.dtype(dtype)], ptr(out), PFD_HOST))
+        return out
+
+    def order_cells(self):
+        check(lib().pfd_order_cells(self._h))
+
+    def idxs_seq(self, dtype) -> np.ndarray:
+        self.order_cells()
+        out = np.empty(self.info()["n_seq"], dtype)
+        check(lib().pfd_idxs_seq(self._h, IDX_CODE[np.dtype(dtype)], ptr(out), PFD_HOST))
+        return out
+
+    def rank(self) -> np.ndarray:
+        out = np.empty(self.n, np.int32)
+        check(lib().pfd_rank(self._h, ptr(out), PFD_HOST))
+        return out
+
+    def upstream_count(self, mask=None) -> np.ndarray:
+        out = np.empty(self.n, np.int8)
+        m = None if mask is None else np.ascontiguousarray(mask).astype(np.uint8, copy=False).ravel()
+        check(lib().pfd_upstream_count(self._h, ptr(m), ptr(out), PFD_HOST))
+        return out
+
+    def add_pits(self, idxs):
+        idxs = np.ascontiguousarray(idxs, dtype=np.int64).ravel()
+        check(lib().pfd_add_pits(self._h, ptr(idxs), idxs.size))
+
+    # -- sweeps -----------------------------------------------------------------------------
+    def upstream_area_cell(self, out=None, memspace=PFD_HOST, engine="auto"):
+        f = lib().pfd_upstream_area_cell if engine == "auto" else lib().pfd_upstream_area_cell_levels
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, np.int32)
+        check(f(self._h, ptr(out), memspace))
+        return out
+
+    def accuflux(self, data, dtype_code, nodata_i=0, nodata_f=0.0, has_nodata=1, direction=PFD_UP,
+                 mask_invalid=0, out=None, memspace=PFD_HOST):
+        if memspace == PFD_HOST:
+            out = np.empty_like(data)
+        check(lib().pfd_accuflux(self._h, dtype_code, ptr(data), int(nodata_i), float(nodata_f), int(has_nodata),
+                                 direction, int(mask_invalid), ptr(out), memspace))
+        return out
+
+    def strahler(self, mask=None, out=None, memspace=PFD_HOST):
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, np.uint8)
+        check(lib().pfd_strahler(self._h, ptr(mask), ptr(out), memspace))
+        return out
+
+    def basins(self, outlets, ids, out=None, memspace=PFD_HOST):
+        outlets = np.ascontiguousarray(outlets, dtype=np.int64).ravel()
+        ids = np.ascontiguousarray(ids).ravel()
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, ids.dtype)
+        check(lib().pfd_basins(self._h, ptr(outlets), ptr(ids), outlets.size, ids.dtype.itemsize, ptr(out), memspace))
+        return out
+
+    def hand(self, drain, elevtn, elev_code, out=None, memspace=PFD_HOST):
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, np.float64)
+        check(lib().pfd_hand(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(out), memspace))
+        return out
+
+
+# -- synthetic rasters generated in HBM ---------------------------------------------------------
+def synth_d8_device(nrow, ncol, seed=0, tilt=1 << 26, white=2, nodata_pct=0, row0=0, nrows=None, device=0):
+    nrows = nrow - row0 if nrows is None else nrows
+    buf = DeviceBuffer(nrows * ncol, device)
+    check(lib().pfd_synth_d8(device, seed, nrow, ncol, tilt, white, nodata_pct, row0, nrows, C.c_void_p(buf.addr)))
+    return buf
+
+
+def synth_elev_device(nrow, ncol, seed=0, tilt=1 << 26, white=2, nodata_pct=0, row0=0, nrows=None, device=0):
+    nrows = nrow - row0 if nrows is None else nrows
+    buf = DeviceBuffer(nrows * ncol * 4, device)
+    check(lib().pfd_synth_elev_f32(device, seed, nrow, ncol, tilt, white, nodata_pct, row0, nrows, C.c_void_p(buf.addr)))
+    return buf
+
+
+def synth_weights_device(n, seed=1, i0=0, device=0):
+    buf = DeviceBuffer(n * 4, device)
+    check(lib().pfd_synth_weights_f32(device, seed, i0, n, C.c_void_p(buf.addr)))
+    return buf

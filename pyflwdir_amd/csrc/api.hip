@@ -1,0 +1,319 @@
+// api.hip — C-ABI plumbing of libpfd_hip: errors, device memory helpers, handle life cycle,
+// index exports.  See include/pfd.h for the contract of every entry point.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void pfd_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *pfd_last_error(void) { return g_err; }
+extern "C" int pfd_abi_version(void) { return PFD_ABI_VERSION; }
+
+extern "C" int pfd_device_count(int *count) {
+  if (!count) {
+    pfd_set_error("pfd_device_count: NULL argument");
+    return PFD_EINVAL;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    pfd_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return PFD_ENODEVICE;
+  }
+  *count = n;
+  return PFD_OK;
+}
+
+static int select_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    pfd_set_error("no HIP device available (%s); the MI355X path has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return PFD_ENODEVICE;
+  }
+  if (device < 0 || device >= n) {
+    pfd_set_error("device index %d out of range [0,%d)", device, n);
+    return PFD_ENODEVICE;
+  }
+  HIPCHK(hipSetDevice(device));
+  return PFD_OK;
+}
+
+extern "C" int pfd_malloc(int device, size_t bytes, void **ptr) {
+  if (!ptr) {
+    pfd_set_error("pfd_malloc: NULL ptr");
+    return PFD_EINVAL;
+  }
+  PFDCHK(select_device(device));
+  HIPCHK(hipMalloc(ptr, bytes ? bytes : 16));
+  return PFD_OK;
+}
+extern "C" int pfd_free(int device, void *ptr) {
+  PFDCHK(select_device(device));
+  if (ptr) HIPCHK(hipFree(ptr));
+  return PFD_OK;
+}
+extern "C" int pfd_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes) {
+  PFDCHK(select_device(device));
+  HIPCHK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return PFD_OK;
+}
+extern "C" int pfd_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes) {
+  PFDCHK(select_device(device));
+  HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return PFD_OK;
+}
+extern "C" int pfd_device_synchronize(int device) {
+  PFDCHK(select_device(device));
+  HIPCHK(hipDeviceSynchronize());
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+int pfd_check_handle(pfd_raster *h) {
+  if (!h) {
+    pfd_set_error("NULL raster handle");
+    return PFD_EINVAL;
+  }
+  HIPCHK(hipSetDevice(h->device));
+  return PFD_OK;
+}
+
+static void free_handle(pfd_raster *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (auto &s : h->segs) {
+    (void)hipEventDestroy(s.e0);
+    (void)hipEventDestroy(s.e1);
+  }
+  if (h->ncode) (void)hipFree(h->ncode);
+  if (h->seq) (void)hipFree(h->seq);
+  if (h->ctrl) (void)hipFree(h->ctrl);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, int memspace, int device,
+                                 pfd_raster **out) {
+  if (!out) {
+    pfd_set_error("pfd_raster_create: NULL out");
+    return PFD_EINVAL;
+  }
+  *out = nullptr;
+  if (!d8 || nrow <= 0 || ncol <= 0) {
+    pfd_set_error("pfd_raster_create: invalid raster (ptr=%p, shape=%lld x %lld)", (const void *)d8,
+                  (long long)nrow, (long long)ncol);
+    return PFD_EINVAL;
+  }
+  const unsigned __int128 n128 = (unsigned __int128)nrow * (unsigned __int128)ncol;
+  if (n128 > 4294967294ull) {
+    pfd_set_error("pfd_raster_create: %lld x %lld cells exceed the 4294967294 cells a single handle "
+                  "indexes with 32 bits; split the raster into row blocks (one handle per GPU)",
+                  (long long)nrow, (long long)ncol);
+    return PFD_EUNSUPPORTED;
+  }
+  if (memspace != PFD_HOST && memspace != PFD_DEVICE) {
+    pfd_set_error("pfd_raster_create: bad memspace %d", memspace);
+    return PFD_EINVAL;
+  }
+  PFDCHK(select_device(device));
+  pfd_raster *h = new pfd_raster();
+  h->device = device;
+  h->nrow = nrow;
+  h->ncol = ncol;
+  h->n = nrow * ncol;
+  h->geo = make_geo(nrow, ncol);
+  int rc = PFD_OK;
+  do {
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->ncode, (size_t)h->n)) != hipSuccess ||
+        (e = hipMalloc((void **)&h->ctrl, 64 * sizeof(u64))) != hipSuccess) {
+      pfd_set_error("pfd_raster_create: device allocation failed: %s", hipGetErrorString(e));
+      rc = (e == hipErrorOutOfMemory) ? PFD_ENOMEM : PFD_EHIP;
+      break;
+    }
+    h->bytes_held = (size_t)h->n + 64 * sizeof(u64);
+    InArg in;
+    if ((rc = in.bind(d8, (size_t)h->n, memspace, h->stream)) != PFD_OK) break;
+    if ((rc = pfd_normalise_and_count(h, (const u8 *)in.dev)) != PFD_OK) break;
+  } while (0);
+  if (rc != PFD_OK) {
+    free_handle(h);
+    return rc;
+  }
+  *out = h;
+  return PFD_OK;
+}
+
+extern "C" int pfd_raster_destroy(pfd_raster *h) {
+  free_handle(h);
+  return PFD_OK;
+}
+
+extern "C" int pfd_raster_info(pfd_raster *h, int64_t info[8]) {
+  PFDCHK(pfd_check_handle(h));
+  if (!info) {
+    pfd_set_error("pfd_raster_info: NULL info");
+    return PFD_EINVAL;
+  }
+  info[0] = h->nrow;
+  info[1] = h->ncol;
+  info[2] = h->n_valid;
+  info[3] = h->n_pits;
+  info[4] = h->ordered ? h->n_seq : -1;
+  info[5] = h->ordered ? h->n_levels : -1;
+  info[6] = h->device;
+  info[7] = (int64_t)h->bytes_held;
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling segments
+// ---------------------------------------------------------------------------------------------
+void pfd_seg_clear(pfd_raster *h) {
+  for (auto &s : h->segs) {
+    (void)hipEventDestroy(s.e0);
+    (void)hipEventDestroy(s.e1);
+  }
+  h->segs.clear();
+}
+void pfd_seg_begin(pfd_raster *h, const char *name) {
+  if (!h->profiling) return;
+  PfdSegment s;
+  s.name = name;
+  s.launches = 0;
+  (void)hipEventCreate(&s.e0);
+  (void)hipEventCreate(&s.e1);
+  (void)hipEventRecord(s.e0, h->stream);
+  h->segs.push_back(s);
+}
+void pfd_seg_end(pfd_raster *h, i64 launches) {
+  if (!h->profiling || h->segs.empty()) return;
+  PfdSegment &s = h->segs.back();
+  s.launches = launches;
+  (void)hipEventRecord(s.e1, h->stream);
+}
+
+extern "C" int pfd_set_profiling(pfd_raster *h, int enable) {
+  PFDCHK(pfd_check_handle(h));
+  h->profiling = enable != 0;
+  if (!enable) pfd_seg_clear(h);
+  return PFD_OK;
+}
+
+extern "C" int pfd_last_timing(pfd_raster *h, int max_seg, double *ms, int64_t *launches, char *names,
+                               size_t names_len, int *nseg) {
+  PFDCHK(pfd_check_handle(h));
+  if (!nseg) {
+    pfd_set_error("pfd_last_timing: NULL nseg");
+    return PFD_EINVAL;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::string joined;
+  int k = 0;
+  for (auto &s : h->segs) {
+    if (k >= max_seg) break;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, s.e0, s.e1) != hipSuccess) t = -1.f;
+    if (ms) ms[k] = (double)t;
+    if (launches) launches[k] = s.launches;
+    if (k) joined += ";";
+    joined += s.name;
+    ++k;
+  }
+  *nseg = k;
+  if (names && names_len) {
+    strncpy(names, joined.c_str(), names_len - 1);
+    names[names_len - 1] = 0;
+  }
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index exports
+// ---------------------------------------------------------------------------------------------
+template <class IDX>
+__global__ void k_export_idxs_ds(const u8 *__restrict__ ncode, Geo g, IDX *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.n) return;
+  const u32 code = ncode[i];
+  IDX v;
+  if (code == D8_MV)
+    v = (IDX)-1;
+  else
+    v = (IDX)d8_down(g, i, code);
+  out[i] = v;
+}
+
+template <class IDX>
+__global__ void k_export_u32(const u32 *__restrict__ src, u32 m, IDX *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) out[i] = (IDX)src[i];
+}
+
+static size_t idx_size(int idx_dtype) {
+  switch (idx_dtype) {
+    case PFD_I32:
+    case PFD_U32:
+      return 4;
+    case PFD_I64:
+      return 8;
+    default:
+      return 0;
+  }
+}
+
+extern "C" int pfd_idxs_ds(pfd_raster *h, int idx_dtype, void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  const size_t es = idx_size(idx_dtype);
+  if (!es || !out) {
+    pfd_set_error("pfd_idxs_ds: bad index dtype %d or NULL out", idx_dtype);
+    return PFD_EINVAL;
+  }
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * es, memspace));
+  const u32 grid = cdiv_u32((u64)h->n, 256);
+  if (idx_dtype == PFD_I32)
+    k_export_idxs_ds<i32><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (i32 *)o.dev);
+  else if (idx_dtype == PFD_U32)
+    k_export_idxs_ds<u32><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (u32 *)o.dev);
+  else
+    k_export_idxs_ds<i64><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (i64 *)o.dev);
+  KCHK();
+  return o.finish(h->stream);
+}
+
+int pfd_export_u32(pfd_raster *h, const u32 *src, i64 m, int idx_dtype, void *out, int memspace) {
+  const size_t es = idx_size(idx_dtype);
+  if (!es || !out) {
+    pfd_set_error("index export: bad index dtype %d or NULL out", idx_dtype);
+    return PFD_EINVAL;
+  }
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)m * es, memspace));
+  if (m > 0) {
+    const u32 grid = cdiv_u32((u64)m, 256);
+    if (idx_dtype == PFD_I32)
+      k_export_u32<i32><<<grid, 256, 0, h->stream>>>(src, (u32)m, (i32 *)o.dev);
+    else if (idx_dtype == PFD_U32)
+      k_export_u32<u32><<<grid, 256, 0, h->stream>>>(src, (u32)m, (u32 *)o.dev);
+    else
+      k_export_u32<i64><<<grid, 256, 0, h->stream>>>(src, (u32)m, (i64 *)o.dev);
+    KCHK();
+  }
+  return o.finish(h->stream);
+}

@@ -1,0 +1,217 @@
+// common.h — shared declarations of libpfd_hip (gfx950 / MI355X only).
+//
+// Device-side representation of a D8 raster:
+//   ncode  u8[n]   "normalised" D8 code per cell: one of the eight direction codes for a cell
+//                  whose downstream neighbour is a valid in-raster cell, 0 for EVERY pit (pit
+//                  code 0/255, target outside, or target nodata — reference
+//                  pyflwdir/core_d8.py:57-63), 247 for nodata.  1 byte/cell is the whole graph:
+//                  the downstream index and the upstream cells are decoded on the fly from
+//                  the cell's own byte and its 8 neighbours' bytes.
+//   seq    u32[n_seq]  cells grouped by rank (level l = cells l steps away from their pit),
+//                  level 0 = pits ascending; lvl_off[l] .. lvl_off[l+1] delimits level l.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pfd.h"
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+#define D8_MV 247u
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+void pfd_set_error(const char *fmt, ...);
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      pfd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
+      return (e_ == hipErrorOutOfMemory) ? PFD_ENOMEM : PFD_EHIP;                                 \
+    }                                                                                             \
+  } while (0)
+#define PFDCHK(expr)                 \
+  do {                               \
+    int rc_ = (expr);                \
+    if (rc_ != PFD_OK) return rc_;   \
+  } while (0)
+#define KCHK() HIPCHK(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+// raster geometry + exact u32 division by ncol (Granlund-Montgomery round-up method), so that
+// kernels working from a linear cell index get (row, col) without a hardware divide.
+// ---------------------------------------------------------------------------------------------
+struct Geo {
+  u32 nrow, ncol;
+  u32 n;           // nrow*ncol (<= 4294967294)
+  u32 dm, ds1, ds2;  // magic for / ncol
+};
+static inline Geo make_geo(i64 nrow, i64 ncol) {
+  Geo g;
+  g.nrow = (u32)nrow;
+  g.ncol = (u32)ncol;
+  g.n = (u32)(nrow * ncol);
+  u32 d = g.ncol, l = 0;
+  while ((1ull << l) < d) ++l;
+  g.dm = (u32)((((1ull << l) - d) << 32) / d + 1);
+  g.ds1 = l < 1 ? l : 1;
+  g.ds2 = l > 0 ? l - 1 : 0;
+  return g;
+}
+__device__ __forceinline__ u32 geo_row(const Geo &g, u32 i) {
+  const u32 t = __umulhi(g.dm, i);
+  return (t + ((i - t) >> g.ds1)) >> g.ds2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// D8 code helpers.  Direction slot k = log2(code): 0 E, 1 SE, 2 S, 3 SW, 4 W, 5 NW, 6 N, 7 NE
+// (reference pyflwdir/core_d8.py:15 `_ds`).  The neighbour located in slot k of a cell drains
+// INTO that cell iff its code is the opposite slot, 1 << ((k+4)&7) (core_d8.py:16 `_us`).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d8_dr(int k) { return (k >= 1 && k <= 3) ? 1 : (k >= 5 ? -1 : 0); }
+__device__ __forceinline__ int d8_dc(int k) { return (k == 0 || k == 1 || k == 7) ? 1 : ((k >= 3 && k <= 5) ? -1 : 0); }
+__device__ __forceinline__ bool d8_is_dir(u32 code) { return code != 0 && code != D8_MV && code != 255u; }
+__device__ __forceinline__ int d8_slot(u32 code) { return __ffs((int)code) - 1; }
+
+// children visiting orders: slots of the neighbours in DESCENDING linear index (the order in
+// which the reference's serial loop adds children into a parent: SE,S,SW,E,W,NE,N,NW) and in
+// ASCENDING linear index (order of a cell's upstream cells in core.idxs_seq).
+__device__ __constant__ const int PFD_SLOT_DESC[8] = {1, 2, 3, 0, 4, 7, 6, 5};
+__device__ __constant__ const int PFD_SLOT_ASC[8] = {5, 6, 7, 4, 0, 3, 2, 1};
+
+// true if the neighbour in slot k of (r,c) exists and drains into (r,c); *nb = its index
+__device__ __forceinline__ bool d8_child(const u8 *__restrict__ ncode, const Geo &g, u32 i, u32 r, u32 c,
+                                         int k, u32 *nb) {
+  const int dr = d8_dr(k), dc = d8_dc(k);
+  const u32 rr = r + (u32)dr, cc = c + (u32)dc;  // wraps to >= nrow/ncol when negative
+  if (rr >= g.nrow || cc >= g.ncol) return false;
+  const u32 j = (u32)((i64)i + (i64)dr * (i64)g.ncol + dc);
+  *nb = j;
+  return ncode[j] == (1u << ((k + 4) & 7));
+}
+// downstream index of a cell with normalised code `code` (self for pits)
+__device__ __forceinline__ u32 d8_down(const Geo &g, u32 i, u32 code) {
+  if (!d8_is_dir(code)) return i;
+  const int k = d8_slot(code);
+  return (u32)((i64)i + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k));
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling segments (HIP events on the handle's stream)
+// ---------------------------------------------------------------------------------------------
+struct PfdSegment {
+  std::string name;
+  hipEvent_t e0, e1;
+  i64 launches;
+};
+
+// ---------------------------------------------------------------------------------------------
+// the handle
+// ---------------------------------------------------------------------------------------------
+struct pfd_raster {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  i64 nrow = 0, ncol = 0, n = 0;
+  Geo geo{};
+  u8 *ncode = nullptr;  // device
+  i64 n_valid = 0, n_pits = 0;
+  // ordering
+  bool ordered = false;
+  u32 *seq = nullptr;  // device, capacity n_valid
+  i64 n_seq = -1, n_levels = -1;
+  std::vector<i64> lvl_off;  // host copy, n_levels+1 entries
+  // small device control block (counters), 64 x u64
+  u64 *ctrl = nullptr;
+  size_t bytes_held = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<PfdSegment> segs;
+};
+
+// scoped device selection + temp buffers ---------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  int rc = PFD_OK;
+  DevBuf() {}
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (p) {
+      (void)hipFree(p);
+      p = nullptr;
+    }
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      p = nullptr;
+      pfd_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+      return PFD_ENOMEM;
+    }
+    return PFD_OK;
+  }
+  template <class T>
+  T *as() { return (T *)p; }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// An input that may live on the host (staged through a temp buffer) or on the device (used as is).
+struct InArg {
+  DevBuf tmp;
+  const void *dev = nullptr;
+  int bind(const void *src, size_t bytes, int memspace, hipStream_t s) {
+    if (src == nullptr) {
+      dev = nullptr;
+      return PFD_OK;
+    }
+    if (memspace == PFD_DEVICE) {
+      dev = src;
+      return PFD_OK;
+    }
+    PFDCHK(tmp.alloc(bytes));
+    HIPCHK(hipMemcpyAsync(tmp.p, src, bytes, hipMemcpyHostToDevice, s));
+    dev = tmp.p;
+    return PFD_OK;
+  }
+};
+// An output that is produced in HBM and, for host callers, copied back at the end.
+struct OutArg {
+  DevBuf tmp;
+  void *dev = nullptr;
+  void *host = nullptr;
+  size_t bytes = 0;
+  int bind(void *dst, size_t nbytes, int memspace) {
+    bytes = nbytes;
+    if (memspace == PFD_DEVICE) {
+      dev = dst;
+      return PFD_OK;
+    }
+    host = dst;
+    PFDCHK(tmp.alloc(nbytes));
+    dev = tmp.p;
+    return PFD_OK;
+  }
+  int finish(hipStream_t s) {
+    if (host) HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return PFD_OK;
+  }
+};
+
+// internal entry points shared between translation units -----------------------------------------
+int pfd_check_handle(pfd_raster *h);
+void pfd_seg_clear(pfd_raster *h);
+void pfd_seg_begin(pfd_raster *h, const char *name);
+void pfd_seg_end(pfd_raster *h, i64 launches);
+int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev);  // order.hip
+int pfd_order_cells_impl(pfd_raster *h);                        // order.hip
+
+static inline u32 cdiv_u32(u64 a, u32 b) { return (u32)((a + b - 1) / b); }

@@ -1,0 +1,578 @@
+// order.hip — decode / normalise a D8 raster on the GPU and build the level structure
+// (cells grouped by rank) that replaces the reference's serial ordering.
+//
+// Reference functions replaced (all single-threaded numba loops):
+//   core_d8.from_array        pyflwdir/core_d8.py:42-67   -> k_normalise (+ pit compaction)
+//   core.upstream_count       pyflwdir/core.py:50-61      -> k_upstream_count
+//   core.upstream_matrix      pyflwdir/core.py:67-84      -> never materialised (decoded on the fly)
+//   core.idxs_seq             pyflwdir/core.py:87-117     -> k_bfs_level (level sets) and
+//                                                            k_oseq_* (exact BFS order on request)
+//   core.rank                 pyflwdir/core.py:17-47      -> k_rank_from_levels
+#include "common.h"
+
+int pfd_export_u32(pfd_raster *h, const u32 *src, i64 m, int idx_dtype, void *out, int memspace);
+
+// ctrl block slots (u64 each)
+enum { C_NVALID = 0, C_NPITS = 1, C_BAD = 2, C_TAIL = 3, C_DONE = 4, C_AUX = 5 };
+
+// ---------------------------------------------------------------------------------------------
+// normalise: one thread per cell, 2-D indexing (no division).  Writes ncode, counts valid cells
+// and pits, flags values outside the D8 alphabet (core_d8._all, pyflwdir/core_d8.py:19).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_normalise(const u8 *__restrict__ d8, Geo g, u8 *__restrict__ ncode,
+                                                   u64 *__restrict__ ctrl) {
+  const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const u32 r = blockIdx.y * 4 + (threadIdx.x >> 6);
+  u32 valid = 0, pit = 0, bad = 0;
+  if (r < g.nrow && c < g.ncol) {
+    const u32 i = r * g.ncol + c;
+    const u32 code = d8[i];
+    u32 out = code;
+    if (code == D8_MV) {
+      out = D8_MV;
+    } else if (code == 0u || code == 255u) {
+      out = 0;
+      valid = 1;
+      pit = 1;
+    } else if ((code & (code - 1)) == 0u) {  // one of the eight direction codes
+      valid = 1;
+      const int k = d8_slot(code);
+      const u32 rr = r + (u32)d8_dr(k), cc = c + (u32)d8_dc(k);
+      if (rr >= g.nrow || cc >= g.ncol || d8[rr * g.ncol + cc] == D8_MV) {
+        out = 0;  // drains off the raster or into nodata -> pit (core_d8.py:57-63)
+        pit = 1;
+      }
+    } else {
+      bad = 1;
+      out = D8_MV;
+    }
+    ncode[i] = (u8)out;
+  }
+  // block reduction -> 3 atomics per block
+  __shared__ u32 s_valid, s_pit, s_bad;
+  if (threadIdx.x == 0) s_valid = s_pit = s_bad = 0;
+  __syncthreads();
+  const u64 bv = __ballot(valid), bp = __ballot(pit), bb = __ballot(bad);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&s_valid, (u32)__popcll(bv));
+    atomicAdd(&s_pit, (u32)__popcll(bp));
+    atomicAdd(&s_bad, (u32)__popcll(bb));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_valid) atomicAdd((unsigned long long *)&ctrl[C_NVALID], (unsigned long long)s_valid);
+    if (s_pit) atomicAdd((unsigned long long *)&ctrl[C_NPITS], (unsigned long long)s_pit);
+    if (s_bad) atomicAdd((unsigned long long *)&ctrl[C_BAD], (unsigned long long)s_bad);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ordered compaction of the pit cells (ascending linear index) into seq[0 .. n_pits):
+// per-chunk counts -> single-block exclusive scan of the chunk counts -> ordered scatter.
+// ---------------------------------------------------------------------------------------------
+#define PIT_CHUNK 4096u  // cells per block (256 threads x 16)
+
+__global__ void __launch_bounds__(256) k_pit_count(const u8 *__restrict__ ncode, u32 n, u32 *__restrict__ counts) {
+  const u32 base = blockIdx.x * PIT_CHUNK;
+  u32 cnt = 0;
+  for (u32 t = threadIdx.x; t < PIT_CHUNK; t += 256) {
+    const u32 i = base + t;
+    if (i < n && ncode[i] == 0) ++cnt;
+  }
+  __shared__ u32 s;
+  if (threadIdx.x == 0) s = 0;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s, cnt);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s;
+}
+
+// in-place exclusive scan of m u32 values by ONE block of 1024 threads
+__global__ void __launch_bounds__(1024) k_scan_u32_1block(u32 *__restrict__ v, u32 m) {
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (u32 base = 0; base < m; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    const u32 x = i < m ? v[i] : 0;
+    u32 incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+      const u32 y = __shfl_up(incl, o);
+      if (lane >= (u32)o) incl += y;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 w = 0; w < wid; ++w) woff += wsum[w];
+    u32 total = 0;
+    for (u32 w = 0; w < 16; ++w) total += wsum[w];
+    const u32 excl = carry + woff + incl - x;
+    if (i < m) v[i] = excl;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_pit_scatter(const u8 *__restrict__ ncode, u32 n,
+                                                     const u32 *__restrict__ offs, u32 *__restrict__ seq) {
+  // each thread owns 16 CONSECUTIVE cells so that the in-block order is the linear order
+  const u32 base = blockIdx.x * PIT_CHUNK + threadIdx.x * 16;
+  u32 mask = 0;
+  for (u32 t = 0; t < 16; ++t) {
+    const u32 i = base + t;
+    if (i < n && ncode[i] == 0) mask |= 1u << t;
+  }
+  const u32 cnt = __popc(mask);
+  // block exclusive scan over the 256 thread counts
+  __shared__ u32 wsum[4];
+  const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  u32 incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 y = __shfl_up(incl, o);
+    if (lane >= (u32)o) incl += y;
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  u32 woff = 0;
+  for (u32 w = 0; w < wid; ++w) woff += wsum[w];
+  u32 pos = offs[blockIdx.x] + woff + incl - cnt;
+  while (mask) {
+    const u32 t = __ffs((int)mask) - 1;
+    mask &= mask - 1;
+    seq[pos++] = base + t;
+  }
+}
+
+static int compact_pits(pfd_raster *h) {
+  const u32 n = h->geo.n;
+  const u32 nchunk = cdiv_u32((u64)n, PIT_CHUNK);
+  DevBuf counts;
+  PFDCHK(counts.alloc((size_t)nchunk * sizeof(u32)));
+  k_pit_count<<<nchunk, 256, 0, h->stream>>>(h->ncode, n, counts.as<u32>());
+  KCHK();
+  k_scan_u32_1block<<<1, 1024, 0, h->stream>>>(counts.as<u32>(), nchunk);
+  KCHK();
+  k_pit_scatter<<<nchunk, 256, 0, h->stream>>>(h->ncode, n, counts.as<u32>(), h->seq);
+  KCHK();
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}
+
+int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
+  HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
+  dim3 grid(cdiv_u32((u64)h->ncol, 64), cdiv_u32((u64)h->nrow, 4));
+  k_normalise<<<grid, 256, 0, h->stream>>>(d8_dev, h->geo, h->ncode, h->ctrl);
+  KCHK();
+  u64 c[3];
+  HIPCHK(hipMemcpyAsync(c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (c[C_BAD]) {
+    pfd_set_error("raster holds %llu value(s) that are not D8 codes (allowed: 1,2,4,8,16,32,64,128,0,255,247)",
+                  (unsigned long long)c[C_BAD]);
+    return PFD_EBADCODE;
+  }
+  h->n_valid = (i64)c[C_NVALID];
+  h->n_pits = (i64)c[C_NPITS];
+  if (h->n_pits == 0) {
+    pfd_set_error("Invalid FlwdirRaster: no pits found");
+    return PFD_ENOPITS;
+  }
+  HIPCHK(hipMalloc((void **)&h->seq, (size_t)h->n_valid * sizeof(u32)));
+  h->bytes_held += (size_t)h->n_valid * sizeof(u32);
+  h->ordered = false;
+  return compact_pits(h);
+}
+
+extern "C" int pfd_idxs_pit(pfd_raster *h, int idx_dtype, void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  return pfd_export_u32(h, h->seq, h->n_pits, idx_dtype, out, memspace);
+}
+
+// ---------------------------------------------------------------------------------------------
+// add_pits (reference pyflwdir/flwdir.py:261-279)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_add_pits(u8 *__restrict__ ncode, const i64 *__restrict__ idxs, u32 k, u32 n, u64 *ctrl) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k) return;
+  const i64 i = idxs[t];
+  if (i < 0 || i >= (i64)n || ncode[i] == D8_MV) {
+    atomicAdd((unsigned long long *)&ctrl[C_BAD], 1ull);
+    return;
+  }
+  ncode[i] = 0;
+}
+__global__ void __launch_bounds__(256) k_count_pits(const u8 *__restrict__ ncode, u32 n, u64 *ctrl) {
+  u32 cnt = 0;
+  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) cnt += ncode[i] == 0;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd((unsigned long long *)&ctrl[C_NPITS], (unsigned long long)cnt);
+}
+
+extern "C" int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k) {
+  PFDCHK(pfd_check_handle(h));
+  if (k < 0 || (k > 0 && !idxs)) {
+    pfd_set_error("pfd_add_pits: bad arguments");
+    return PFD_EINVAL;
+  }
+  if (k == 0) return PFD_OK;
+  InArg in;
+  PFDCHK(in.bind(idxs, (size_t)k * sizeof(i64), PFD_HOST, h->stream));
+  HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
+  k_add_pits<<<cdiv_u32((u64)k, 256), 256, 0, h->stream>>>(h->ncode, (const i64 *)in.dev, (u32)k, h->geo.n, h->ctrl);
+  KCHK();
+  k_count_pits<<<1024, 256, 0, h->stream>>>(h->ncode, h->geo.n, h->ctrl);
+  KCHK();
+  u64 c[3];
+  HIPCHK(hipMemcpyAsync(c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->n_pits = (i64)c[C_NPITS];
+  h->ordered = false;
+  h->n_seq = h->n_levels = -1;
+  h->lvl_off.clear();
+  PFDCHK(compact_pits(h));
+  if (c[C_BAD]) {
+    pfd_set_error("pfd_add_pits: %llu index(es) outside the raster or on nodata cells were ignored",
+                  (unsigned long long)c[C_BAD]);
+    return PFD_EINVAL;
+  }
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// upstream_count (reference pyflwdir/core.py:50-61): pull form, one thread per cell.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_upstream_count(const u8 *__restrict__ ncode, Geo g,
+                                                        const u8 *__restrict__ mask, int8_t *__restrict__ out) {
+  const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const u32 r = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (r >= g.nrow || c >= g.ncol) return;
+  const u32 i = r * g.ncol + c;
+  if (ncode[i] == D8_MV) {
+    out[i] = -9;
+    return;
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    u32 nb;
+    if (d8_child(ncode, g, i, r, c, k, &nb) && (mask == nullptr || mask[nb])) ++cnt;
+  }
+  out[i] = (int8_t)cnt;
+}
+
+extern "C" int pfd_upstream_count(pfd_raster *h, const uint8_t *mask, int8_t *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!out) {
+    pfd_set_error("pfd_upstream_count: NULL out");
+    return PFD_EINVAL;
+  }
+  InArg m;
+  PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n, memspace));
+  dim3 grid(cdiv_u32((u64)h->ncol, 64), cdiv_u32((u64)h->nrow, 4));
+  k_upstream_count<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const u8 *)m.dev, (int8_t *)o.dev);
+  KCHK();
+  return o.finish(h->stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// level build: top-down breadth-first expansion from the pits.  Level l+1 = all cells draining
+// into a cell of level l.  One launch per level; each wave aggregates its children counts and
+// reserves output space with ONE atomicAdd (order inside a level is irrelevant to the pull
+// sweeps; the exact reference order is produced separately by pfd_idxs_seq).  The last block
+// to finish publishes the end offset of the new level, so the next launch needs no host
+// round trip.
+// ---------------------------------------------------------------------------------------------
+#define BFS_GRID 1024
+
+__global__ void __launch_bounds__(256) k_bfs_level(const u8 *__restrict__ ncode, Geo g, u32 *__restrict__ seq,
+                                                   u64 *__restrict__ ctrl, i64 *__restrict__ lvl_off, int lvl) {
+  const u32 begin = (u32)lvl_off[lvl], end = (u32)lvl_off[lvl + 1];
+  const u32 lane = threadIdx.x & 63;
+  const u32 nthreads = gridDim.x * blockDim.x;
+  // wave-uniform trip count
+  for (u32 j0 = begin + (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)); j0 < end; j0 += nthreads) {
+    const u32 j = j0 + lane;
+    u32 kids[8];
+    u32 cnt = 0;
+    if (j < end) {
+      const u32 x = seq[j];
+      const u32 r = geo_row(g, x), c = x - r * g.ncol;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        u32 nb;
+        if (d8_child(ncode, g, x, r, c, PFD_SLOT_ASC[q], &nb)) kids[cnt++] = nb;
+      }
+    }
+    u32 incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const u32 y = __shfl_up(incl, o);
+      if (lane >= (u32)o) incl += y;
+    }
+    const u32 total = __shfl(incl, 63);
+    u32 base = 0;
+    if (total) {
+      if (lane == 0) base = (u32)atomicAdd((unsigned long long *)&ctrl[C_TAIL], (unsigned long long)total);
+      base = __shfl(base, 0);
+      u32 pos = base + incl - cnt;
+      for (u32 q = 0; q < cnt; ++q) seq[pos + q] = kids[q];
+    }
+  }
+  // last block publishes the end of level lvl+1
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned long long prev = atomicAdd((unsigned long long *)&ctrl[C_DONE], 1ull);
+    if (prev == (unsigned long long)gridDim.x - 1) {
+      const unsigned long long tail = atomicAdd((unsigned long long *)&ctrl[C_TAIL], 0ull);
+      lvl_off[lvl + 2] = (i64)tail;
+      ctrl[C_DONE] = 0;
+    }
+  }
+}
+
+int pfd_order_cells_impl(pfd_raster *h) {
+  if (h->ordered) return PFD_OK;
+  pfd_seg_begin(h, "order_cells");
+  const int BATCH = 256;
+  size_t cap = (size_t)(2 * (h->nrow + h->ncol) + 4 * BATCH + 64);
+  DevBuf lvl;
+  PFDCHK(lvl.alloc(cap * sizeof(i64)));
+  HIPCHK(hipMemsetAsync(lvl.p, 0, cap * sizeof(i64), h->stream));
+  const i64 first[2] = {0, h->n_pits};
+  HIPCHK(hipMemcpyAsync(lvl.p, first, sizeof(first), hipMemcpyHostToDevice, h->stream));
+  u64 ctrl0[8] = {0};
+  ctrl0[C_TAIL] = (u64)h->n_pits;
+  HIPCHK(hipMemcpyAsync(h->ctrl, ctrl0, sizeof(ctrl0), hipMemcpyHostToDevice, h->stream));
+  std::vector<i64> off;
+  off.push_back(0);
+  off.push_back(h->n_pits);
+  int lvl_next = 0;  // next level to expand
+  i64 launches = 0;
+  bool done = false;
+  std::vector<i64> tmp(BATCH);
+  while (!done) {
+    if ((size_t)(lvl_next + BATCH + 2) > cap) {  // grow the device offsets array
+      const size_t ncap = cap * 2 + BATCH;
+      DevBuf bigger;
+      PFDCHK(bigger.alloc(ncap * sizeof(i64)));
+      HIPCHK(hipMemsetAsync(bigger.p, 0, ncap * sizeof(i64), h->stream));
+      HIPCHK(hipMemcpyAsync(bigger.p, lvl.p, cap * sizeof(i64), hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      std::swap(lvl.p, bigger.p);
+      cap = ncap;
+    }
+    for (int b = 0; b < BATCH; ++b) {
+      k_bfs_level<<<BFS_GRID, 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, h->ctrl, lvl.as<i64>(), lvl_next + b);
+      ++launches;
+    }
+    KCHK();
+    // offsets lvl_next+2 .. lvl_next+BATCH+1 were produced by this batch
+    HIPCHK(hipMemcpyAsync(tmp.data(), lvl.as<i64>() + lvl_next + 2, BATCH * sizeof(i64), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < BATCH; ++b) {
+      if (tmp[b] == off.back()) {  // level lvl_next+b+1 is empty -> finished
+        done = true;
+        break;
+      }
+      off.push_back(tmp[b]);
+    }
+    lvl_next += BATCH;
+  }
+  h->lvl_off = off;
+  h->n_levels = (i64)off.size() - 1;
+  h->n_seq = off.back();
+  h->ordered = true;
+  pfd_seg_end(h, launches);
+  return PFD_OK;
+}
+
+extern "C" int pfd_order_cells(pfd_raster *h) {
+  PFDCHK(pfd_check_handle(h));
+  return pfd_order_cells_impl(h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rank (reference pyflwdir/core.py:17-47): level id of every ordered cell, -1 for valid cells
+// outside the sequence (loops), -9999 on nodata.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rank_init(const u8 *__restrict__ ncode, u32 n, i32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ncode[i] == D8_MV ? -9999 : -1;
+}
+__global__ void k_rank_from_levels(const u32 *__restrict__ seq, const i64 *__restrict__ lvl_off, u32 nlev,
+                                   u32 nseq, i32 *__restrict__ out) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nseq) return;
+  u32 lo = 0, hi = nlev;  // find l with lvl_off[l] <= j < lvl_off[l+1]
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if ((u32)lvl_off[mid] <= j)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  out[seq[j]] = (i32)lo;
+}
+
+extern "C" int pfd_rank(pfd_raster *h, int32_t *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!out) {
+    pfd_set_error("pfd_rank: NULL out");
+    return PFD_EINVAL;
+  }
+  PFDCHK(pfd_order_cells_impl(h));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
+  InArg lo;
+  PFDCHK(lo.bind(h->lvl_off.data(), h->lvl_off.size() * sizeof(i64), PFD_HOST, h->stream));
+  k_rank_init<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, (i32 *)o.dev);
+  KCHK();
+  if (h->n_seq > 0) {
+    k_rank_from_levels<<<cdiv_u32((u64)h->n_seq, 256), 256, 0, h->stream>>>(h->seq, (const i64 *)lo.dev,
+                                                                           (u32)h->n_levels, (u32)h->n_seq, (i32 *)o.dev);
+    KCHK();
+  }
+  return o.finish(h->stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact core.idxs_seq order (reference pyflwdir/core.py:103-116).  The reference's queue is
+// "pits, then for every dequeued cell its upstream cells ascending".  Position of the k-th
+// upstream cell of the cell dequeued at position j is  n_pits + S(j) + k  with S the exclusive
+// prefix sum of the in-degrees in dequeue order.  The sum is local to a level, so level l+1 is
+// laid out from level l with: (A) in-degree per position + per-chunk sums, (B) scan of the chunk
+// sums, (C) ordered scatter.  Small levels run A-C fused in a single block.
+// ---------------------------------------------------------------------------------------------
+#define OSEQ_CHUNK 1024u  // positions per block (256 threads x 4 consecutive)
+
+__device__ __forceinline__ u32 count_children(const u8 *__restrict__ ncode, const Geo &g, u32 x) {
+  const u32 r = geo_row(g, x), c = x - r * g.ncol;
+  u32 cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    u32 nb;
+    cnt += d8_child(ncode, g, x, r, c, k, &nb) ? 1u : 0u;
+  }
+  return cnt;
+}
+__device__ __forceinline__ void write_children_asc(const u8 *__restrict__ ncode, const Geo &g, u32 x, u32 *dst) {
+  const u32 r = geo_row(g, x), c = x - r * g.ncol;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    u32 nb;
+    if (d8_child(ncode, g, x, r, c, PFD_SLOT_ASC[q], &nb)) *dst++ = nb;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_oseq_count(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ oseq,
+                                                    u32 begin, u32 end, u32 *__restrict__ chunk_sums) {
+  const u32 j0 = begin + blockIdx.x * OSEQ_CHUNK + threadIdx.x * 4;
+  u32 cnt = 0;
+  for (u32 t = 0; t < 4; ++t)
+    if (j0 + t < end) cnt += count_children(ncode, g, oseq[j0 + t]);
+  __shared__ u32 s;
+  if (threadIdx.x == 0) s = 0;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s, cnt);
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_sums[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_oseq_scatter(const u8 *__restrict__ ncode, Geo g, u32 *__restrict__ oseq,
+                                                      u32 begin, u32 end, const u32 *__restrict__ chunk_offs) {
+  const u32 j0 = begin + blockIdx.x * OSEQ_CHUNK + threadIdx.x * 4;
+  u32 c4[4], cnt = 0;
+  for (u32 t = 0; t < 4; ++t) {
+    c4[t] = (j0 + t < end) ? count_children(ncode, g, oseq[j0 + t]) : 0;
+    cnt += c4[t];
+  }
+  __shared__ u32 wsum[4];
+  const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  u32 incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 y = __shfl_up(incl, o);
+    if (lane >= (u32)o) incl += y;
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  u32 woff = 0;
+  for (u32 w = 0; w < wid; ++w) woff += wsum[w];
+  u32 pos = end + chunk_offs[blockIdx.x] + woff + incl - cnt;
+  for (u32 t = 0; t < 4; ++t) {
+    if (c4[t]) write_children_asc(ncode, g, oseq[j0 + t], oseq + pos);
+    pos += c4[t];
+  }
+}
+
+// fused single-block version for levels of at most `OSEQ_SMALL` cells, looping over as many
+// consecutive small levels as possible (lvl_sizes known on the host).
+__global__ void __launch_bounds__(1024) k_oseq_small(const u8 *__restrict__ ncode, Geo g, u32 *__restrict__ oseq,
+                                                     u32 begin, u32 end) {
+  __shared__ u32 wsum[16];
+  __shared__ u32 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (u32 base = begin; base < end; base += 1024) {
+    const u32 j = base + threadIdx.x;
+    const u32 x = j < end ? oseq[j] : 0;
+    const u32 cnt = j < end ? count_children(ncode, g, x) : 0;
+    u32 incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const u32 y = __shfl_up(incl, o);
+      if (lane >= (u32)o) incl += y;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    u32 woff = 0, total = 0;
+    for (u32 w = 0; w < 16; ++w) {
+      if (w < wid) woff += wsum[w];
+      total += wsum[w];
+    }
+    if (cnt) write_children_asc(ncode, g, x, oseq + end + carry + woff + incl - cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+}
+
+extern "C" int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_order_cells_impl(h));
+  pfd_seg_begin(h, "idxs_seq_exact_order");
+  DevBuf oseq;
+  PFDCHK(oseq.alloc((size_t)h->n_seq * sizeof(u32)));
+  HIPCHK(hipMemcpyAsync(oseq.p, h->seq, (size_t)h->n_pits * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
+  i64 maxlev = 0;
+  for (i64 l = 0; l < h->n_levels; ++l) maxlev = std::max(maxlev, h->lvl_off[l + 1] - h->lvl_off[l]);
+  const u32 maxchunks = cdiv_u32((u64)maxlev, OSEQ_CHUNK);
+  DevBuf sums;
+  PFDCHK(sums.alloc((size_t)maxchunks * sizeof(u32)));
+  i64 launches = 0;
+  for (i64 l = 0; l + 1 < h->n_levels; ++l) {
+    const u32 begin = (u32)h->lvl_off[l], end = (u32)h->lvl_off[l + 1];
+    const u32 m = end - begin;
+    if (m <= 8192) {
+      k_oseq_small<<<1, 1024, 0, h->stream>>>(h->ncode, h->geo, oseq.as<u32>(), begin, end);
+      ++launches;
+    } else {
+      const u32 nchunk = cdiv_u32((u64)m, OSEQ_CHUNK);
+      k_oseq_count<<<nchunk, 256, 0, h->stream>>>(h->ncode, h->geo, oseq.as<u32>(), begin, end, sums.as<u32>());
+      k_scan_u32_1block<<<1, 1024, 0, h->stream>>>(sums.as<u32>(), nchunk);
+      k_oseq_scatter<<<nchunk, 256, 0, h->stream>>>(h->ncode, h->geo, oseq.as<u32>(), begin, end, sums.as<u32>());
+      launches += 3;
+    }
+  }
+  KCHK();
+  pfd_seg_end(h, launches);
+  return pfd_export_u32(h, oseq.as<u32>(), h->n_seq, idx_dtype, out, memspace);
+}

@@ -1,0 +1,406 @@
+// sweeps.hip — level-by-level sweeps over the ordered cells, all in PULL form.
+//
+// The reference walks `seq` serially (up- to downstream for accumulations, down- to upstream
+// for labels/HAND) and read-modify-writes the downstream cell.  Here every cell of one level
+// (= one rank) is final before the next level is launched, and each thread computes the value
+// of ITS OWN cell from its upstream cells (decoded from the 8 neighbour codes) or from its
+// downstream cell.  No atomics, no write conflicts, and the children are combined in the
+// exact order of the serial loop (descending linear index), so float32/float64 results are
+// bit-identical to the reference, not merely within tolerance.
+//
+// Reference functions replaced:
+//   streams.accuflux          pyflwdir/streams.py:15-41    AccuUp
+//   streams.accuflux_ds       pyflwdir/streams.py:44-70    AccuDown
+//   streams.strahler_order    pyflwdir/streams.py:228-269  Strahler
+//   core.fillnodata_upstream  pyflwdir/core.py:120-146     Labels (basins.basins, basins.py:12-18)
+//   dem.height_above_nearest_drain  pyflwdir/dem.py:299-330  Hand
+#include <algorithm>
+#include <unordered_set>
+
+#include "common.h"
+
+template <class Op>
+__global__ void __launch_bounds__(256) k_sweep(Op op, const u32 *__restrict__ seq, u32 begin, u32 count) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) op(seq[begin + t]);
+}
+
+// up- to downstream: deepest level first (children final before their parent's level runs)
+template <class Op>
+static int run_up(pfd_raster *h, const Op &op, const char *name) {
+  pfd_seg_begin(h, name);
+  i64 launches = 0;
+  for (i64 l = h->n_levels - 1; l >= 0; --l) {
+    const u32 begin = (u32)h->lvl_off[l], cnt = (u32)(h->lvl_off[l + 1] - h->lvl_off[l]);
+    if (!cnt) continue;
+    k_sweep<Op><<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(op, h->seq, begin, cnt);
+    ++launches;
+  }
+  KCHK();
+  pfd_seg_end(h, launches);
+  return PFD_OK;
+}
+// down- to upstream: level 1 first (level 0 = pits are seeded by the init step)
+template <class Op>
+static int run_down(pfd_raster *h, const Op &op, const char *name, i64 first_level) {
+  pfd_seg_begin(h, name);
+  i64 launches = 0;
+  for (i64 l = first_level; l < h->n_levels; ++l) {
+    const u32 begin = (u32)h->lvl_off[l], cnt = (u32)(h->lvl_off[l + 1] - h->lvl_off[l]);
+    if (!cnt) continue;
+    k_sweep<Op><<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(op, h->seq, begin, cnt);
+    ++launches;
+  }
+  KCHK();
+  pfd_seg_end(h, launches);
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// payload arithmetic: integers wrap like numba's fixed-width ints, floats are plain IEEE adds
+// ---------------------------------------------------------------------------------------------
+template <class T> struct Num;
+template <> struct Num<i32> {
+  static __device__ __forceinline__ i32 add(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
+};
+template <> struct Num<i64> {
+  static __device__ __forceinline__ i64 add(i64 a, i64 b) { return (i64)((u64)a + (u64)b); }
+};
+template <> struct Num<float> {
+  static __device__ __forceinline__ float add(float a, float b) { return a + b; }
+};
+template <> struct Num<double> {
+  static __device__ __forceinline__ double add(double a, double b) { return a + b; }
+};
+
+template <class T>
+struct AccuUp {
+  const u8 *ncode;
+  Geo g;
+  const T *data;
+  T *out;
+  T nodata;
+  int has_nodata;
+  __device__ __forceinline__ void operator()(u32 x) const {
+    const u32 r = geo_row(g, x), c = x - r * g.ncol;
+    T acc = data[x];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      u32 nb;
+      if (d8_child(ncode, g, x, r, c, PFD_SLOT_DESC[q], &nb)) {
+        const T a = out[nb];
+        if (!has_nodata || (acc != nodata && a != nodata)) acc = Num<T>::add(acc, a);
+      }
+    }
+    out[x] = acc;
+  }
+};
+
+template <class T>
+struct AccuDown {
+  const u8 *ncode;
+  Geo g;
+  const T *data;
+  T *out;
+  T nodata;
+  int has_nodata;
+  __device__ __forceinline__ void operator()(u32 x) const {
+    const u32 p = d8_down(g, x, ncode[x]);
+    if (p == x) return;  // pit keeps its own value (copied by the init step)
+    T a = data[x];
+    const T b = out[p];
+    if (!has_nodata || (b != nodata && a != nodata)) a = Num<T>::add(a, b);
+    out[x] = a;
+  }
+};
+
+// FlwdirRaster.upstream_area(unit="cell"): unit weights, nothing read but the codes
+struct CountUp {
+  const u8 *ncode;
+  Geo g;
+  u32 *out;
+  __device__ __forceinline__ void operator()(u32 x) const {
+    const u32 r = geo_row(g, x), c = x - r * g.ncol;
+    u32 acc = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      u32 nb;
+      if (d8_child(ncode, g, x, r, c, k, &nb)) acc += out[nb];
+    }
+    out[x] = acc;
+  }
+};
+
+// Strahler order, order-independent closed form of the reference's two-array update
+// (pyflwdir/streams.py:252-268): among the upstream cells that are inside the mask, let m be
+// the largest order; the cell gets m+1 if at least two of them have order m, else m; with no
+// such upstream cell it is a headwater: 1 if the cell itself is inside the mask, else 0.
+struct Strahler {
+  const u8 *ncode;
+  Geo g;
+  const u8 *mask;  // may be null
+  u8 *out;
+  __device__ __forceinline__ void operator()(u32 x) const {
+    const u32 r = geo_row(g, x), c = x - r * g.ncol;
+    u32 m = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      u32 nb;
+      if (d8_child(ncode, g, x, r, c, k, &nb) && (mask == nullptr || mask[nb])) {
+        const u32 v = out[nb];
+        if (v > m) {
+          m = v;
+          cnt = 1;
+        } else if (v == m) {
+          ++cnt;
+        }
+      }
+    }
+    u32 val;
+    if (cnt == 0)
+      val = (mask == nullptr || mask[x]) ? 1u : 0u;
+    else
+      val = cnt >= 2 ? m + 1 : m;
+    out[x] = (u8)val;
+  }
+};
+
+template <class L>
+struct Labels {
+  const u8 *ncode;
+  Geo g;
+  L *out;
+  __device__ __forceinline__ void operator()(u32 x) const {
+    if (out[x] != 0) return;  // seeded cells are never overwritten
+    const u32 p = d8_down(g, x, ncode[x]);
+    const L v = out[p];
+    if (v != 0) out[x] = v;
+  }
+};
+
+template <class E>
+struct Hand {
+  const u8 *ncode;
+  Geo g;
+  const u8 *drain;
+  const E *elev;
+  double *out;
+  __device__ __forceinline__ void operator()(u32 x) const {
+    if (drain[x] == 1) {
+      out[x] = 0.0;
+      return;
+    }
+    const u32 p = d8_down(g, x, ncode[x]);
+    const E dz = elev[x] - elev[p];  // difference in the elevation dtype (dem.py:328)
+    const double base = (p == x) ? 0.0 : out[p];
+    out[x] = base + (double)dz;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// small streaming helpers
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void k_fill(T *__restrict__ out, u32 n, T v) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+template <class T>
+__global__ void k_mask_invalid(const u8 *__restrict__ ncode, u32 n, T *__restrict__ out, T v) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && ncode[i] == D8_MV) out[i] = v;
+}
+__global__ void k_init_cell(const u8 *__restrict__ ncode, u32 n, i32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ncode[i] == D8_MV ? -9999 : 1;
+}
+template <class L>
+__global__ void k_seed_labels(const i64 *__restrict__ idx, const L *__restrict__ ids, u32 k, L *__restrict__ out) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < k) out[idx[t]] = ids[t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int pfd_upstream_area_cell_levels(pfd_raster *h, int32_t *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!out) {
+    pfd_set_error("pfd_upstream_area_cell: NULL out");
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  PFDCHK(pfd_order_cells_impl(h));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
+  pfd_seg_begin(h, "init");
+  k_init_cell<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, (i32 *)o.dev);
+  KCHK();
+  pfd_seg_end(h, 1);
+  CountUp op{h->ncode, h->geo, (u32 *)o.dev};
+  PFDCHK(run_up(h, op, "sweep_count_up"));
+  return o.finish(h->stream);
+}
+
+extern "C" int pfd_upstream_area_cell(pfd_raster *h, int32_t *out, int memspace) {
+  return pfd_upstream_area_cell_levels(h, out, memspace);
+}
+
+template <class T>
+static int accuflux_t(pfd_raster *h, const void *data, T nodata, int has_nodata, int direction,
+                      int mask_invalid, void *out, int memspace) {
+  InArg d;
+  PFDCHK(d.bind(data, (size_t)h->n * sizeof(T), memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * sizeof(T), memspace));
+  pfd_seg_begin(h, "init");
+  HIPCHK(hipMemcpyAsync(o.dev, d.dev, (size_t)h->n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+  pfd_seg_end(h, 1);
+  if (direction == PFD_UP) {
+    AccuUp<T> op{h->ncode, h->geo, (const T *)d.dev, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(run_up(h, op, "sweep_accuflux_up"));
+  } else {
+    AccuDown<T> op{h->ncode, h->geo, (const T *)d.dev, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(run_down(h, op, "sweep_accuflux_down", 1));
+  }
+  if (mask_invalid) {
+    k_mask_invalid<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, (T *)o.dev, nodata);
+    KCHK();
+  }
+  return o.finish(h->stream);
+}
+
+extern "C" int pfd_accuflux(pfd_raster *h, int dtype, const void *data, int64_t nodata_i, double nodata_f,
+                            int has_nodata, int direction, int mask_invalid, void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!data || !out || (direction != PFD_UP && direction != PFD_DOWN)) {
+    pfd_set_error("pfd_accuflux: bad arguments");
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  PFDCHK(pfd_order_cells_impl(h));
+  switch (dtype) {
+    case PFD_I32:
+      return accuflux_t<i32>(h, data, (i32)nodata_i, has_nodata, direction, mask_invalid, out, memspace);
+    case PFD_I64:
+      return accuflux_t<i64>(h, data, (i64)nodata_i, has_nodata, direction, mask_invalid, out, memspace);
+    case PFD_F32:
+      return accuflux_t<float>(h, data, (float)nodata_f, has_nodata, direction, mask_invalid, out, memspace);
+    case PFD_F64:
+      return accuflux_t<double>(h, data, nodata_f, has_nodata, direction, mask_invalid, out, memspace);
+    default:
+      pfd_set_error("pfd_accuflux: unsupported payload dtype code %d", dtype);
+      return PFD_EUNSUPPORTED;
+  }
+}
+
+extern "C" int pfd_strahler(pfd_raster *h, const uint8_t *mask, uint8_t *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!out) {
+    pfd_set_error("pfd_strahler: NULL out");
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  PFDCHK(pfd_order_cells_impl(h));
+  InArg m;
+  PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n, memspace));
+  pfd_seg_begin(h, "init");
+  HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
+  pfd_seg_end(h, 1);
+  Strahler op{h->ncode, h->geo, (const u8 *)m.dev, (u8 *)o.dev};
+  PFDCHK(run_up(h, op, "sweep_strahler"));
+  return o.finish(h->stream);
+}
+
+template <class L>
+static int basins_t(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, void *out_dev) {
+  pfd_seg_begin(h, "init");
+  HIPCHK(hipMemsetAsync(out_dev, 0, (size_t)h->n * sizeof(L), h->stream));
+  if (k) {
+    k_seed_labels<L><<<cdiv_u32(k, 256), 256, 0, h->stream>>>(idx_dev, (const L *)ids_dev, k, (L *)out_dev);
+    KCHK();
+  }
+  pfd_seg_end(h, 2);
+  Labels<L> op{h->ncode, h->geo, (L *)out_dev};
+  return run_down(h, op, "sweep_labels", 0);
+}
+
+extern "C" int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k, int id_size,
+                          void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!out || k < 0 || (k > 0 && (!outlets || !ids)) ||
+      (id_size != 1 && id_size != 2 && id_size != 4 && id_size != 8)) {
+    pfd_set_error("pfd_basins: bad arguments (k=%lld, id_size=%d)", (long long)k, id_size);
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  // numpy's `basins[idxs] = ids` keeps the LAST id of a repeated index: dedupe on the host so
+  // that the device scatter has no write conflict.
+  std::vector<i64> uidx;
+  std::vector<unsigned char> uids;
+  {
+    std::unordered_set<i64> seen;
+    uidx.reserve((size_t)k);
+    uids.reserve((size_t)k * id_size);
+    for (i64 j = k - 1; j >= 0; --j) {
+      const i64 i = outlets[j];
+      if (i < 0 || i >= h->n) {
+        pfd_set_error("pfd_basins: outlet index %lld outside the raster", (long long)i);
+        return PFD_EINVAL;
+      }
+      if (!seen.insert(i).second) continue;
+      uidx.push_back(i);
+      const unsigned char *src = (const unsigned char *)ids + (size_t)j * id_size;
+      uids.insert(uids.end(), src, src + id_size);
+    }
+  }
+  PFDCHK(pfd_order_cells_impl(h));
+  const u32 ku = (u32)uidx.size();
+  InArg di, dl;
+  PFDCHK(di.bind(ku ? uidx.data() : nullptr, (size_t)ku * sizeof(i64), PFD_HOST, h->stream));
+  PFDCHK(dl.bind(ku ? uids.data() : nullptr, (size_t)ku * id_size, PFD_HOST, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * id_size, memspace));
+  int rc;
+  switch (id_size) {
+    case 1: rc = basins_t<u8>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+    case 2: rc = basins_t<uint16_t>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+    case 4: rc = basins_t<u32>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+    default: rc = basins_t<u64>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+  }
+  PFDCHK(rc);
+  return o.finish(h->stream);
+}
+
+template <class E>
+static int hand_t(pfd_raster *h, const u8 *drain_dev, const void *elev_dev, double *out_dev) {
+  pfd_seg_begin(h, "init");
+  k_fill<double><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(out_dev, h->geo.n, -9999.0);
+  KCHK();
+  pfd_seg_end(h, 1);
+  Hand<E> op{h->ncode, h->geo, drain_dev, (const E *)elev_dev, out_dev};
+  return run_down(h, op, "sweep_hand", 0);
+}
+
+extern "C" int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, double *out,
+                        int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!drain || !elevtn || !out || (elev_dtype != PFD_F32 && elev_dtype != PFD_F64)) {
+    pfd_set_error("pfd_hand: bad arguments (elevation dtype code %d)", elev_dtype);
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  PFDCHK(pfd_order_cells_impl(h));
+  InArg dr, el;
+  PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
+  PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * sizeof(double), memspace));
+  if (elev_dtype == PFD_F32)
+    PFDCHK(hand_t<float>(h, (const u8 *)dr.dev, el.dev, (double *)o.dev));
+  else
+    PFDCHK(hand_t<double>(h, (const u8 *)dr.dev, el.dev, (double *)o.dev));
+  return o.finish(h->stream);
+}

@@ -1,0 +1,485 @@
+"""``FlwdirRaster`` for the MI355X hot path: the call surface of the reference's raster object
+for D8 decode -> cell ordering -> accumulation / stream order / basins / HAND, with every
+O(n) loop executed by hand-written HIP kernels behind the C-ABI in ``include/pfd.h``.
+
+Mirrors (names, argument meaning, return conventions, error messages):
+
+* ``from_array``                       reference pyflwdir/pyflwdir.py:130-205
+* ``FlwdirRaster.__init__``            reference pyflwdir/pyflwdir.py:211-273, pyflwdir/flwdir.py:72-127
+* ``upstream_area``                    reference pyflwdir/pyflwdir.py:770-801
+* ``accuflux``                         reference pyflwdir/flwdir.py:567-602
+* ``stream_order``                     reference pyflwdir/flwdir.py:508-547
+* ``basins``                           reference pyflwdir/pyflwdir.py:564-599
+* ``hand``                             reference pyflwdir/pyflwdir.py:1485-1511
+* ``add_pits`` / ``order_cells``       reference pyflwdir/flwdir.py:231-279, pyflwdir/pyflwdir.py:299-315
+* ``_check_data`` / ``_check_idxs_xy`` reference pyflwdir/flwdir.py:782-811, pyflwdir/pyflwdir.py:1548-1566
+
+The host keeps the uint8 D8 raster (1 byte/cell); ``idxs_ds`` / ``idxs_seq`` (4-8 bytes/cell)
+are public attributes of the reference and are materialised lazily, on request, by the GPU.
+There is no CPU fallback: without the HIP library or a device the methods raise.
+"""
+from __future__ import annotations
+
+import pickle
+
+import numpy as np
+
+from . import _hip
+from . import gis
+from ._affine import get_affine
+
+Affine = get_affine()
+
+__all__ = ["FlwdirRaster", "from_array", "FTYPES"]
+
+# D8 alphabet, reference pyflwdir/core_d8.py:14-19
+D8_DS = np.array([[32, 64, 128], [16, 0, 1], [8, 4, 2]], dtype=np.uint8)
+D8_MV = np.uint8(247)
+D8_PV = np.array([0, 255], dtype=np.uint8)
+D8_ALL = np.array([32, 64, 128, 16, 0, 1, 8, 4, 2, 247, 255], dtype=np.uint8)
+FTYPES = ("d8", "ldd", "nextxy")  # names known to the reference; only "d8" runs on the GPU
+
+_PAYLOAD = {np.dtype(np.int32): _hip.PFD_I32, np.dtype(np.int64): _hip.PFD_I64,
+            np.dtype(np.float32): _hip.PFD_F32, np.dtype(np.float64): _hip.PFD_F64}
+
+
+def _get_idxs_dtype(n):
+    """Smallest index dtype for ``n`` cells; reference pyflwdir/pyflwdir.py:105-127."""
+    if n < 2147483647:
+        return np.int32
+    elif n < 4294967294:
+        return np.uint32
+    return np.int64
+
+
+def d8_isvalid(flwdir) -> bool:
+    """True if ``flwdir`` is a 2-D uint8 raster of D8 values; reference pyflwdir/core_d8.py:105-122."""
+    if not (isinstance(flwdir, np.ndarray) and flwdir.dtype == np.uint8 and flwdir.ndim == 2):
+        return False
+    present = np.zeros(256, dtype=bool)
+    present[np.unique(flwdir)] = True
+    present[D8_ALL] = False
+    return not present.any()
+
+
+def _infer_ftype(flwdir):
+    """reference pyflwdir/pyflwdir.py:39-48 (only D8 can be inferred here)."""
+    if d8_isvalid(flwdir):
+        return "d8"
+    raise ValueError("The flow direction type could not be inferred.")
+
+
+def _d8_from_idxs_ds(idxs_ds, shape, mv):
+    """D8 codes from downstream indices (the inverse decode, reference core_d8.to_array,
+    pyflwdir/core_d8.py:86-102), vectorised; links outside the 8 neighbours raise."""
+    nrow, ncol = shape
+    idx0 = np.arange(idxs_ds.size, dtype=np.int64)
+    ds = idxs_ds.astype(np.int64)
+    valid = idxs_ds != mv
+    dr = np.where(valid, ds // ncol - idx0 // ncol, 0)
+    dc = np.where(valid, ds % ncol - idx0 % ncol, 0)
+    if np.any(np.abs(dr) > 1) or np.any(np.abs(dc) > 1):
+        raise ValueError("Invalid data downstream index outside 8 neighbors.")
+    d8 = D8_DS[dr + 1, dc + 1]
+    d8[~valid] = D8_MV
+    return d8.reshape(shape)
+
+
+def from_array(data, ftype="infer", check_ftype=True, mask=None, transform=gis.IDENTITY, latlon=False, **kwargs):
+    """Flow direction raster parsed to an actionable (device-resident) format.
+
+    Same signature and checks as the reference's ``from_array`` (pyflwdir/pyflwdir.py:130-205).
+    Only ``ftype="d8"`` (or ``"infer"`` on D8 data) is implemented on the GPU path."""
+    if ftype == "infer":
+        ftype = _infer_ftype(data)
+        check_ftype = False
+    if ftype not in FTYPES:
+        raise ValueError(f'Unknown flow direction type: "{ftype}", select from {", ".join(FTYPES)}')
+    if ftype != "d8":
+        raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path; only "d8" is implemented')
+    data = np.asarray(data)
+    if data.ndim != 2:
+        raise ValueError("The FlwdirRaster should be 2 dimensional")
+    if check_ftype and not d8_isvalid(data):
+        raise ValueError(f'The flow direction data with type "{ftype}" is invalid.')
+    if mask is not None:
+        if mask.shape != data.shape:
+            raise ValueError('"mask" shape does not match with data shape')
+        data = np.where(mask != 0, data, D8_MV)
+    return FlwdirRaster._from_d8(np.ascontiguousarray(data, dtype=np.uint8), transform=transform, latlon=latlon,
+                                 **kwargs)
+
+
+class FlwdirRaster(object):
+    """Flow direction raster parsed to a device-resident graph (see module docstring)."""
+
+    # -- construction -----------------------------------------------------------------------
+    def __init__(self, idxs_ds, shape, ftype, idxs_pit=None, idxs_outlet=None, idxs_seq=None, nnodes=None,
+                 transform=gis.IDENTITY, latlon=False, cache=True, device=0):
+        idxs_ds = np.asarray(idxs_ds)
+        if idxs_ds.size <= 1:
+            raise ValueError(f"Invalid FlwdirRaster: size {idxs_ds.size}")
+        if ftype not in FTYPES:
+            raise ValueError(f'Unknown flow direction type: "{ftype}", select from {", ".join(FTYPES)}')
+        if ftype != "d8":
+            raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path; only "d8" is implemented')
+        if np.multiply(*np.array(shape, np.uint64)) != idxs_ds.size:
+            raise ValueError(f"Invalid FlwdirRaster: shape {shape} does not match size {idxs_ds.size}")
+        mv = self._mv_for(idxs_ds.dtype)
+        d8 = _d8_from_idxs_ds(idxs_ds.ravel(), tuple(shape), mv)
+        self._setup(d8, transform, latlon, cache, device)
+        self._idxs_ds = idxs_ds.ravel()
+        self._idx_dtype = idxs_ds.dtype
+        self._mv = mv
+        if idxs_pit is not None:
+            self._pit = np.asarray(idxs_pit)
+        if idxs_outlet is not None:
+            self.idxs_outlet = np.asarray(idxs_outlet)
+
+    @classmethod
+    def _from_d8(cls, d8, transform=gis.IDENTITY, latlon=False, cache=True, device=0, **kwargs):
+        if kwargs:
+            raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
+        if d8.size <= 1:
+            raise ValueError(f"Invalid FlwdirRaster: size {d8.size}")
+        self = cls.__new__(cls)
+        self._setup(d8, transform, latlon, cache, device)
+        return self
+
+    @staticmethod
+    def _mv_for(dtype):
+        # -1 for signed, 4294967295 for uint32, ... ; reference pyflwdir/flwdir.py:112-117
+        dtype = np.dtype(dtype)
+        if dtype.kind == "u":
+            return dtype.type(np.iinfo(dtype).max)
+        return np.intp(-1)
+
+    def _setup(self, d8, transform, latlon, cache, device):
+        self._d8 = d8
+        self.shape = tuple(int(s) for s in d8.shape)
+        self.size = int(d8.size)
+        self.ftype = "d8"
+        self.device = device
+        self._idx_dtype = np.dtype(_get_idxs_dtype(self.size))
+        self._mv = self._mv_for(self._idx_dtype)
+        self.cache = cache
+        self._cached = dict()
+        self._idxs_ds = None
+        self._pit = None
+        self._seq = None
+        self._nnodes = None
+        # device graph: raises ValueError("... no pits found") like the reference (flwdir.py:126)
+        self._h = _hip.RasterHandle(d8, self.shape[0], self.shape[1], device=device)
+        # outlets exclude the pits created at the raster edge / next to nodata (pyflwdir.py:193)
+        pits = self.idxs_pit
+        self.idxs_outlet = pits[np.isin(self._d8.flat[pits], D8_PV)]
+        self.set_transform(transform, latlon)
+
+    # -- representation / io ----------------------------------------------------------------
+    @property
+    def _dict(self):
+        return {"ftype": self.ftype, "shape": self.shape, "nnodes": self.nnodes, "transform": self.transform,
+                "latlon": self.latlon, "idxs_ds": self.idxs_ds, "idxs_seq": self._seq, "idxs_pit": self._pit}
+
+    def __getitem__(self, idx):
+        return self.idxs_ds[idx]
+
+    def dump(self, fn):
+        """Serialize to file with pickle (same dictionary layout as the reference,
+        pyflwdir/pyflwdir.py:275-286, pyflwdir/flwdir.py:290-293)."""
+        with open(fn, "wb") as handle:
+            pickle.dump(self._dict, handle, protocol=-1)
+
+    @staticmethod
+    def load(fn):
+        with open(fn, "rb") as handle:
+            kwargs = pickle.load(handle)
+        return FlwdirRaster(**kwargs)
+
+    # -- properties -------------------------------------------------------------------------
+    @property
+    def idxs_ds(self):
+        """Linear indices of the downstream cell (GPU decode, reference core_d8.from_array)."""
+        if self._idxs_ds is None:
+            self._idxs_ds = self._h.idxs_ds(self._idx_dtype)
+        return self._idxs_ds
+
+    @property
+    def idxs_pit(self):
+        """Linear indices of pits/outlets, ascending."""
+        if self._pit is None:
+            self._pit = self._h.idxs_pit(self._idx_dtype)
+        return self._pit
+
+    @property
+    def idxs_seq(self):
+        """Linear indices of valid cells ordered from down- to upstream, in the exact order of
+        the reference's ``core.idxs_seq`` (pyflwdir/core.py:87-117)."""
+        if self._seq is None:
+            self.order_cells(method="walk")
+        return self._seq
+
+    @property
+    def nnodes(self):
+        if self._nnodes is None:
+            self._h.order_cells()
+            self._nnodes = self._h.info()["n_seq"]
+        return self._nnodes
+
+    @property
+    def ncells(self):
+        return self.nnodes
+
+    @property
+    def mask(self):
+        """Boolean array of valid cells (flattened like the reference, pyflwdir/flwdir.py:201-204)."""
+        return self._d8.ravel() != D8_MV
+
+    @property
+    def rank(self):
+        """Cell rank: distance to the outlet in cells, -1 off the sequence, -9999 on nodata."""
+        if "rank" in self._cached:
+            return self._cached["rank"]
+        rank = self._h.rank().reshape(self.shape)
+        if self.cache:
+            self._cached.update(rank=rank)
+        return rank
+
+    @property
+    def isvalid(self):
+        """True if no valid cell is part of (or drains to) a loop."""
+        self._cached.pop("rank", None)
+        return bool(np.all(self.rank != -1))
+
+    @property
+    def n_upstream(self):
+        return self._h.upstream_count().reshape(self.shape)
+
+    @property
+    def area(self):
+        """Cell area [m2]; reference pyflwdir/pyflwdir.py:430-440."""
+        if "area" in self._cached:
+            return self._cached["area"]
+        area = gis.area_grid(self.transform, self.shape, self.latlon, unit="m2")
+        if self.cache:
+            self._cached.update(area=area)
+        return area
+
+    @property
+    def bounds(self):
+        w, n = self.transform.xoff, self.transform.yoff
+        e, s = self.transform * (self.shape[1], self.shape[0])
+        return np.array([w, s, e, n], dtype=np.float64)
+
+    # -- set / modify -----------------------------------------------------------------------
+    def set_transform(self, transform, latlon=False):
+        """reference pyflwdir/pyflwdir.py:317-337"""
+        if not (hasattr(transform, "a") and hasattr(transform, "f") and len(transform) >= 6):
+            try:
+                transform = Affine(*transform)
+            except TypeError:
+                raise ValueError("Invalid transform.")
+        self.transform = transform
+        self.latlon = latlon
+
+    def order_cells(self, method="walk"):
+        """Order cells from down- to upstream; reference pyflwdir/flwdir.py:231-250.  "walk"
+        reproduces the reference's breadth-first order exactly; "sort" orders by rank."""
+        if method == "walk":
+            self._seq = self._h.idxs_seq(self._idx_dtype)
+        elif method == "sort":
+            rnk = self._h.rank()
+            n = int(np.sum(rnk >= 0))
+            self._seq = np.argsort(rnk)[-n:].astype(self._idx_dtype)
+        else:
+            raise ValueError(f'Invalid method {method}, select from ["walk", "sort"]')
+        self._nnodes = self._seq.size
+
+    def add_pits(self, idxs=None, xy=None, streams=None):
+        """Add pits to the flow direction raster; reference pyflwdir/pyflwdir.py:299-315,
+        pyflwdir/flwdir.py:261-279."""
+        idxs1 = self._check_idxs_xy(idxs, xy, streams)
+        self._h.add_pits(idxs1)
+        self._d8 = self._d8.copy()
+        self._d8.flat[idxs1] = 0
+        self._idxs_ds = None
+        self._pit = None
+        self._seq = None
+        self._nnodes = None
+        self._cached.clear()
+        pits = self.idxs_pit
+        self.idxs_outlet = pits[np.isin(self._d8.flat[pits], D8_PV)]
+
+    def to_array(self, ftype=None):
+        """2-D flow direction raster (D8 only)."""
+        if ftype is None:
+            ftype = self.ftype
+        if ftype != "d8":
+            if ftype in FTYPES:
+                raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path')
+            raise ValueError(f'ftype "{ftype}" unknown')
+        # cells that decode to pits but carry a direction code keep the code of the input,
+        # like the reference which re-encodes idxs_ds: a pit is written as 0
+        d8 = self._d8.copy()
+        d8.flat[self.idxs_pit] = 0
+        return d8
+
+    # -- spatial ----------------------------------------------------------------------------
+    def index(self, xs, ys, **kwargs):
+        return gis.coords_to_idxs(xs, ys, self.transform, self.shape, **kwargs)
+
+    def xy(self, idxs, **kwargs):
+        return gis.idxs_to_coords(idxs, self.transform, self.shape, **kwargs)
+
+    # -- the hot path -------------------------------------------------------------------------
+    def upstream_area(self, unit="cell"):
+        """Upstream area map; reference pyflwdir/pyflwdir.py:770-801.  ``unit="cell"`` returns the
+        int32 upstream cell count; other units accumulate the cell-area grid (float64 for
+        lat/lon grids, float32 for projected ones).  -9999 on nodata cells."""
+        unit = str(unit).lower()
+        if unit not in gis.AREA_FACTORS:
+            fstr = '", "'.join(gis.AREA_FACTORS.keys())
+            raise ValueError(f'Unknown unit: {unit}, select from "{fstr}".')
+        if unit == "cell":
+            return self._h.upstream_area_cell().reshape(self.shape)
+        area = np.ascontiguousarray(self.area.ravel() / gis.AREA_FACTORS[unit])
+        out = self._h.accuflux(area, _PAYLOAD[area.dtype], nodata_i=-9999, nodata_f=-9999.0, has_nodata=1,
+                               direction=_hip.PFD_UP, mask_invalid=1)
+        return out.reshape(self.shape)
+
+    def accuflux(self, data, nodata=-9999, direction="up"):
+        """Accumulate ``data`` along the flow directions; reference pyflwdir/flwdir.py:567-602."""
+        if direction not in ("up", "down"):
+            raise ValueError(f'Unknown flow direction: {direction}, select from ["up", "down"].')
+        data = np.asarray(data)
+        flat = self._check_data(data, "data")
+        view, code, nd_i, nd_f, has_nd = _payload_args(flat, nodata)
+        out = self._h.accuflux(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd,
+                               direction=_hip.PFD_UP if direction == "up" else _hip.PFD_DOWN)
+        return out.view(flat.dtype).reshape(data.shape)
+
+    def stream_order(self, type="strahler", mask=None):
+        """Strahler stream order map (uint8); reference pyflwdir/flwdir.py:508-547.  Like the
+        reference, the result is cached under "strord" when ``cache=True`` regardless of mask."""
+        mask = self._check_data(mask, "mask", optional=True)
+        if type.lower() == "strahler":
+            if "strord" in self._cached:
+                strord = self._cached["strord"]
+            else:
+                m = None if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
+                strord = self._h.strahler(m)
+                if self.cache:
+                    self._cached.update(strord=strord)
+        elif type.lower() == "classic":
+            raise NotImplementedError('stream_order(type="classic") is a "next" row of the scope table '
+                                      "(SURVEY.md §8f-1) and not on the GPU path yet")
+        else:
+            # the reference falls through to an UnboundLocalError here; be explicit instead
+            raise ValueError(f'Unknown stream order type: {type}, select from ["strahler", "classic"].')
+        return strord.reshape(self.shape)
+
+    def basins(self, idxs=None, xy=None, ids=None, **kwargs):
+        """(Sub)basin map with a unique ID per (sub)basin; reference pyflwdir/pyflwdir.py:564-599."""
+        if idxs is None and xy is None:
+            idxs = self.idxs_pit
+        else:
+            idxs = self._check_idxs_xy(idxs, xy, **kwargs)
+        idxs = np.asarray(idxs)
+        if ids is not None:
+            ids = np.atleast_1d(ids).ravel()
+            if ids.size != idxs.size:
+                raise ValueError("IDs size does not match size of idxs.")
+            elif np.any(ids == 0):
+                raise ValueError("IDs cannot contain a value zero.")
+        else:
+            ids = np.arange(1, idxs.size + 1, dtype=np.uint32)  # reference basins.py:14-15
+        if ids.dtype.kind not in "iu" or ids.dtype.itemsize not in (1, 2, 4, 8):
+            raise NotImplementedError(f"basin ids of dtype {ids.dtype} are not supported on the HIP path")
+        idxs64 = idxs.astype(np.int64)
+        if np.any(idxs64 < 0) or np.any(idxs64 >= self.size):
+            raise IndexError("idxs outside domain")
+        return self._h.basins(idxs64, ids).reshape(self.shape)
+
+    def hand(self, drain, elevtn):
+        """Height above the nearest drain (float64); reference pyflwdir/pyflwdir.py:1485-1511."""
+        drain = self._check_data(drain, "drain")
+        elevtn = self._check_data(elevtn, "elevtn")
+        drain_u8 = np.ascontiguousarray(drain == 1).view(np.uint8)
+        if elevtn.dtype == np.float32:
+            code = _hip.PFD_F32
+        elif elevtn.dtype == np.float64 or elevtn.dtype.kind in "iub":
+            code, elevtn = _hip.PFD_F64, elevtn.astype(np.float64, copy=False)
+        else:
+            raise NotImplementedError(f"elevation dtype {elevtn.dtype} is not supported on the HIP path")
+        return self._h.hand(drain_u8, np.ascontiguousarray(elevtn), code).reshape(self.shape)
+
+    # -- shortcuts ------------------------------------------------------------------------------
+    def _check_data(self, data, name, optional=False, flatten=True, **kwargs):
+        """Check data shape and size, return the flattened array; reference
+        pyflwdir/flwdir.py:782-803 and pyflwdir/pyflwdir.py:1548-1559."""
+        if data is None and optional:
+            return
+        if data is None:
+            if name == "uparea":
+                data = self.upstream_area(**kwargs)
+            elif name == "basins":
+                data = self.basins(**kwargs)
+            elif name == "strord":
+                data = self.stream_order(**kwargs)
+        data = np.atleast_1d(data)
+        if flatten:
+            if data.size == 1:
+                data = np.full(self.size, data, dtype=data.dtype)
+            elif data.size != self.size:
+                raise ValueError(f'"{name}" size does not match.')
+            return data.ravel()
+        if data.size == 1:
+            data = np.full(self.shape, data, dtype=data.dtype)
+        elif data.shape != self.shape:
+            raise ValueError(f'"{name}" shape does not match.')
+        return data
+
+    def _check_idxs_xy(self, idxs=None, xy=None, streams=None):
+        """reference pyflwdir/pyflwdir.py:1561-1566 and pyflwdir/flwdir.py:805-811"""
+        if (xy is not None and idxs is not None) or (xy is None and idxs is None):
+            raise ValueError("Either idxs or xy should be provided.")
+        elif xy is not None:
+            idxs = self.index(*xy)
+        idxs = np.atleast_1d(idxs).ravel()
+        if streams is not None:
+            raise NotImplementedError("snapping outlets to a stream mask (core.snap) is outside the GPU hot path")
+        return idxs
+
+
+def _payload_args(flat, nodata):
+    """Map a flattened payload + Python nodata to the device dtype code and nodata arguments.
+    `has_nodata` is False when the reference's comparison ``accu != nodata`` can never be False
+    (NaN, out-of-range or non-integral nodata for integer data, negative nodata for unsigned)."""
+    dt = flat.dtype
+    if dt == np.uint32:
+        view, info = flat.view(np.int32), np.iinfo(np.uint32)
+    elif dt == np.uint64:
+        view, info = flat.view(np.int64), np.iinfo(np.uint64)
+    elif dt in _PAYLOAD:
+        view, info = flat, (np.iinfo(dt) if dt.kind == "i" else None)
+    else:
+        raise NotImplementedError(f"payload dtype {dt} is not supported on the HIP path "
+                                  "(supported: int32, int64, uint32, uint64, float32, float64)")
+    view = np.ascontiguousarray(view)
+    code = _PAYLOAD[view.dtype]
+    if dt.kind == "f":
+        nd = float(nodata)
+        if nd != nd:
+            return view, code, 0, 0.0, 0
+        return view, code, 0, float(dt.type(nd)), 1
+    # integer payloads: equality with a python number holds only for an integral in-range value
+    try:
+        integral = float(nodata) == int(nodata)
+    except (OverflowError, ValueError):
+        integral = False
+    if not integral or not (info.min <= int(nodata) <= info.max):
+        return view, code, 0, 0.0, 0
+    nd = int(nodata)
+    if dt.kind == "u":  # reinterpret as the signed kernel type
+        nd = int(np.array([nd], dtype=dt).view(view.dtype)[0])
+    return view, code, nd, 0.0, 1

@@ -1,0 +1,47 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure only)."""
+    from oracle import oracle as O
+
+    O.build()
+    return O
+
+
+def case_names():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        m = json.load(f)
+    return sorted(k for k in m if not k.startswith("_"))
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """libpfd_hip with a visible device; GPU tests fail (not skip) without it."""
+    from pyflwdir_amd import _hip
+
+    lib = _hip.lib()
+    assert _hip.device_count() >= 1, "no HIP device visible: -m gpu tests need an MI355X"
+    return lib
