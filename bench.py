@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Mcells/s of FlwdirRaster.upstream_area("cell") on a synthetic
+D8 raster (BASELINE.json configs[1]: 10000 x 10000, 1 MI355X), with the HBM-roofline fraction of
+the dominant kernel and the single-thread CPU baseline (the oracle restatement of the
+reference's serial algorithm) timed on the same host.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu-baseline]
+
+A "step" is one complete pass of the hot path on one raster: device-resident uint8 D8 codes in
+-> device-resident int32 upstream cell counts out, INCLUDING the decode/normalisation of the
+raster and the construction of whatever ordering structure the kernels need (a fresh raster
+handle is created every step; nothing is cached between steps).  Inputs are generated in HBM
+by the device twin of the oracle's synthetic generator and are resident before the timed
+region starts; the result stays in HBM.
+
+N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
+the raster is row-tiled over the N GPUs (weak scaling: every rank owns `size` rows); see
+DESIGN.md §Multi-GPU.  torch.distributed is used only for rendezvous/barrier/max-reduce.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pyflwdir_amd import _hip  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic bytes per cell of upstream_area("cell"): 29 B/cell in total,
+# split over the phases of the level engine as documented in DESIGN.md §Roofline
+B_ALG_TOTAL = 29.0
+B_ALG_PHASE = {"order_cells": 8.0, "init": 4.0, "sweep_count_up": 17.0,
+               "tile_local": 8.0, "tile_exits": 4.0, "tile_final": 17.0}
+SYNTH = dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0)  # "river" regime: max_rank = nrow-1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=10000, help="raster is size x size per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the raster given to the CPU baseline (0=auto)")
+    return ap.parse_args()
+
+
+def one_step(d8_buf, out_buf, nrow, ncol, device, profile=False):
+    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE)
+    if profile:
+        h.set_profiling(True)
+    h.upstream_area_cell(out=out_buf, memspace=_hip.PFD_DEVICE)
+    res = (h.last_timing(), h.info()) if profile else None
+    h.close()
+    return res
+
+
+def cpu_baseline(d8_host, rows):
+    """Single-thread oracle (restatement of the reference's serial pipeline) on a bounded sample:
+    the first `rows` rows of the same raster (a self-contained raster: flow is southwards, the
+    cut edge simply becomes an outlet row)."""
+    from oracle import oracle as O
+
+    sample = np.ascontiguousarray(d8_host[:rows])
+    t0 = time.perf_counter()
+    upa, tim, st = O.upstream_area_cell(sample)
+    dt = time.perf_counter() - t0
+    return dict(value=round(sample.size / dt / 1e6, 3), unit="Mcells/s", cores=1, kind="port",
+                sample=f"first {rows} of {d8_host.shape[0]} rows x {d8_host.shape[1]} cols of the same raster "
+                       f"({sample.size / 1e6:.0f} Mcells, {dt:.1f} s; decode {tim['decode_s']:.2f} s, idxs_seq "
+                       f"{tim['idxs_seq_s']:.2f} s, accuflux {tim['accuflux_s']:.2f} s)",
+                host_cpus=os.cpu_count()), upa
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world > 1:
+        raise SystemExit("multi-GPU bench path is added with pyflwdir_amd.dist (see DESIGN.md §Multi-GPU)")
+
+    device = local
+    nrow = ncol = a.size
+    n = nrow * ncol
+    d8_buf = _hip.synth_d8_device(nrow, ncol, device=device, **SYNTH)
+    out_buf = _hip.DeviceBuffer(n * 4, device)
+
+    for _ in range(a.warmup):
+        one_step(d8_buf, out_buf, nrow, ncol, device)
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step(d8_buf, out_buf, nrow, ncol, device)
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    dt = time.perf_counter() - t0
+    ms_per_step = dt / a.steps * 1e3
+    value = n * a.steps / dt / 1e6
+
+    # one extra, profiled step: HIP events on the library's own stream around each phase
+    segs, info = one_step(d8_buf, out_buf, nrow, ncol, device, profile=True)
+    dom = max(segs, key=lambda s: s["ms"])
+    b_alg = B_ALG_PHASE.get(dom["name"], B_ALG_TOTAL)
+    launches = max(1, dom["launches"])
+    avg_ms = dom["ms"] / launches
+    achieved = (b_alg * n / launches) / (avg_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=round(achieved / PEAK_HBM_GBS, 5), traffic=None, kernel=dom["name"],
+                    launches=dom["launches"], avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
+                    whole_pass=dict(alg_bytes_per_cell=B_ALG_TOTAL,
+                                    achieved=round(B_ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9, 2),
+                                    frac=round(B_ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)),
+                    phases_ms={s["name"]: round(s["ms"], 3) for s in segs})
+
+    out = dict(metric="Mcells/s upstream_area on D8 raster", value=round(value, 2), unit="Mcells/s", n_gpus=1,
+               steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
+               config=dict(workload=f"{nrow}x{ncol} synthetic D8 (river regime, seed 0), "
+                                    "upstream_area(unit='cell') int32, decode+order+sweep per step",
+                           n_valid=info["n_valid"], n_pits=info["n_pits"], n_levels=info["n_levels"],
+                           parallelism="1 GPU"),
+               roofline=roofline)
+
+    if not a.no_cpu_baseline:
+        d8_host = d8_buf.download(np.uint8, (nrow, ncol))
+        rows = a.cpu_rows or min(nrow, max(1, int(1.2e8 // ncol)))
+        cpu, upa_cpu = cpu_baseline(d8_host, rows)
+        out["cpu_baseline"] = cpu
+        # parity spot check of the benchmarked result against the oracle on the sample's interior:
+        # rows whose whole upstream area lies inside the sample are identical in both rasters
+        got = out_buf.download(np.int32, (rows, ncol))
+        if rows == nrow:
+            out["parity_vs_oracle"] = bool(np.array_equal(got, upa_cpu))
+        else:
+            out["parity_vs_oracle"] = bool(np.array_equal(got, upa_cpu))  # flow is southwards: upstream = rows above
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

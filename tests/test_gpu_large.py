@@ -1,0 +1,82 @@
+"""GPU-vs-oracle parity on rasters too large for the interpreted reference, plus
+size-independent invariants (reference tests/test_streams_basins.py:14-50: pit sums == number
+of cells, basin sizes == upstream area at the pits) and device-generator == host-generator."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,seed,kw", [
+    ((1500, 2100), 3, dict(tilt=1 << 26, white=2, nodata_pct=0)),
+    ((2048, 2048), 4, dict(tilt=100000, white=2, nodata_pct=30)),
+    ((3000, 1000), 5, dict(tilt=1 << 26, white=2, nodata_pct=20)),
+])
+def test_vs_oracle(gpu_lib, oracle, shape, seed, kw):
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd import _hip
+
+    O = oracle
+    d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+    # device generator is the bit-exact twin of the host generator
+    buf = _hip.synth_d8_device(shape[0], shape[1], seed=seed, **kw)
+    assert np.array_equal(buf.download(np.uint8, shape), d8)
+    ebuf = _hip.synth_elev_device(shape[0], shape[1], seed=seed, **kw)
+    elev = O.synth_elev_f32(shape[0], shape[1], seed=seed, **kw)
+    assert np.array_equal(ebuf.download(np.float32, shape), elev)
+    w = O.synth_weights_f32(d8.size, seed=1)
+    assert np.array_equal(_hip.synth_weights_device(d8.size, seed=1).download(np.float32, (d8.size,)), w)
+
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    idxs_ds, idxs_pit, nvalid = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    assert np.array_equal(flw.idxs_ds, idxs_ds) and np.array_equal(flw.idxs_pit, idxs_pit)
+    assert np.array_equal(flw.idxs_seq, seq)
+    upa_o, _, _ = O.upstream_area_cell(d8)
+    upa = flw.upstream_area()
+    assert np.array_equal(upa, upa_o)
+    # invariants
+    assert upa.flat[idxs_pit].astype(np.int64).sum() == seq.size
+    bas = flw.basins()
+    assert np.array_equal(bas.ravel(), O.basins(idxs_ds, idxs_pit, seq))
+    sizes = np.bincount(bas.ravel(), minlength=idxs_pit.size + 1)[1:]
+    assert np.array_equal(sizes, upa.flat[idxs_pit])
+    # float32 accumulation: bit-exact (tolerance of the north star: 1e-6 relative)
+    acc = flw.accuflux(w.reshape(shape))
+    acc_o = O.accuflux(idxs_ds, seq, w).reshape(shape)
+    assert np.array_equal(acc, acc_o)
+    sto = flw.stream_order()
+    assert np.array_equal(sto.ravel(), O.strahler_order(idxs_ds, seq))
+    drain = upa > 500
+    hand = flw.hand(drain, elev)
+    assert np.array_equal(hand.ravel(), O.height_above_nearest_drain(idxs_ds, seq, drain.ravel(), elev.ravel()))
+    assert np.array_equal(flw.rank.ravel(), O.rank(idxs_ds)[0])
+
+
+def test_add_pits(gpu_lib, oracle):
+    """add_pits turns cells into pits and invalidates the order (reference flwdir.py:261-279)."""
+    import pyflwdir_amd as pyflwdir
+
+    O = oracle
+    d8 = O.synth_d8(300, 400, seed=9)
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    upa = flw.upstream_area()
+    new = np.argsort(upa.ravel())[-5:-2]
+    flw.add_pits(idxs=new)
+    d8b = d8.copy()
+    d8b.flat[new] = 0
+    idxs_ds, idxs_pit, _ = O.from_array(d8b)
+    assert np.array_equal(flw.idxs_pit, idxs_pit) and np.array_equal(flw.idxs_ds, idxs_ds)
+    assert np.array_equal(flw.upstream_area(), O.upstream_area_cell(d8b)[0])
+    assert np.array_equal(flw.idxs_seq, O.idxs_seq(idxs_ds, idxs_pit))
+
+
+def test_invalid_rasters(gpu_lib):
+    import pyflwdir_amd as pyflwdir
+
+    with pytest.raises(ValueError, match="no pits found"):
+        pyflwdir.from_array(np.array([[1, 16], [1, 16]], dtype=np.uint8), ftype="d8")  # two 2-cycles
+    with pytest.raises(ValueError, match="is invalid"):
+        pyflwdir.from_array(np.array([[3, 0], [0, 0]], dtype=np.uint8), ftype="d8")
+    with pytest.raises(ValueError, match="not D8 codes|invalid"):
+        pyflwdir.from_array(np.array([[3, 0], [0, 0]], dtype=np.uint8), ftype="d8", check_ftype=False)

@@ -1,0 +1,129 @@
+"""GPU parity: the HIP path, called through the FlwdirRaster front end and the C-ABI, must
+reproduce the reference bit for bit on every golden case (ints, labels, Strahler, the exact
+idxs_seq order AND the float32/float64 accumulations and HAND — the pull sweeps add children
+in the reference's order, so no tolerance is needed; the north-star tolerance for float32
+accuflux is 1e-6 relative, asserted here as exact equality).
+
+Mirrors reference tests/test_pyflwdir.py:218-289,390-407 and tests/test_streams_basins.py.
+"""
+import numpy as np
+import pytest
+
+from conftest import case_names
+from golden_util import Case, derived_inputs
+from oracle import golden_inputs as GI
+
+pytestmark = pytest.mark.gpu
+
+CASES = case_names()
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request, manifest):
+    return Case(request.param, manifest)
+
+
+@pytest.fixture(scope="module")
+def flw(case, gpu_lib):
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd._affine import Affine
+
+    return pyflwdir.from_array(case.d8, ftype="d8", transform=Affine(*case.transform), latlon=case.latlon, cache=False)
+
+
+def test_graph_exports(case, flw):
+    st = case.entry["stats"]
+    info = flw._h.info()
+    assert info["n_valid"] == st["n_valid"] and info["n_pits"] == st["n_pits"]
+    case.check("idxs_ds_int32", flw.idxs_ds)
+    case.check("idxs_pit_int32", flw.idxs_pit)
+    case.check("idxs_outlet", flw.idxs_outlet)
+    case.check("n_upstream", flw.n_upstream.ravel())
+    case.check("idxs_seq_int32", flw.idxs_seq)
+    case.check("rank", flw.rank.ravel())
+    assert flw.nnodes == st["n_seq"] == flw.ncells
+    assert flw._h.info()["n_levels"] == st["max_rank"] + 1
+    assert flw.isvalid == (st["n_loop_cells"] == 0)
+    # other index dtypes of the reference's ladder (pyflwdir.py:105-127)
+    for dt in (np.uint32, np.int64):
+        sfx = np.dtype(dt).name
+        if f"idxs_ds_{sfx}" in case.digests:
+            case.check(f"idxs_ds_{sfx}", flw._h.idxs_ds(dt))
+            case.check(f"idxs_pit_{sfx}", flw._h.idxs_pit(dt))
+            case.check(f"idxs_seq_{sfx}", flw._h.idxs_seq(dt))
+
+
+def test_upstream_area(case, flw):
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd._affine import Affine
+
+    upa = flw.upstream_area()
+    case.check("uparea_cell", upa)
+    # the generic level engine must agree with the fused path
+    assert np.array_equal(flw._h.upstream_area_cell(engine="levels").reshape(case.shape), upa)
+    case.check("uparea_km2_latlon", flw.upstream_area("km2"))
+    flw_proj = pyflwdir.from_array(case.d8, ftype="d8", transform=Affine(*GI.PROJ_TRANSFORM), latlon=False, cache=False)
+    case.check("uparea_ha_proj", flw_proj.upstream_area("ha"))
+    # reference test_uparea (tests/test_pyflwdir.py:259-270)
+    assert upa.dtype == np.int32 and upa.shape == case.shape
+    if (~flw.mask).any():
+        assert upa.min() == -9999
+    assert upa[upa != -9999].min() == 1
+    acc = flw.accuflux(np.ones(flw.shape))
+    assert np.all(acc.flat[flw.mask] == upa.flat[flw.mask])
+
+
+def test_accuflux(case, flw):
+    P = GI.payloads(case.shape)
+    case.check("accuflux_f32", flw.accuflux(P["w32"]))
+    case.check("accuflux_f64", flw.accuflux(P["w64"]))
+    case.check("accuflux_ds_f32", flw.accuflux(P["w32"], direction="down"))
+    case.check("accuflux_i32_nodata", flw.accuflux(P["wi32_nodata"], nodata=-9999))
+    case.check("accuflux_ds_i32_nodata", flw.accuflux(P["wi32_nodata"], nodata=-9999, direction="down"))
+    case.check("accuflux_f32_nodata_m1", flw.accuflux(P["wf32_nodata_m1"], nodata=-1))
+    case.check("accuflux_i64", flw.accuflux(P["wi64"]))
+
+
+def test_strahler_basins_hand(case, flw):
+    upa = flw.upstream_area()
+    D = derived_inputs(case, upa, flw.idxs_pit)
+    sto = flw.stream_order()
+    case.check("strahler", sto)
+    case.check("strahler_mask_upa", flw.stream_order(mask=D["mask_upa"]))
+    case.check("strahler_mask_rand", flw.stream_order(mask=D["mask_rand"]))
+    assert sto.dtype == np.uint8 and sto.flat[flw.mask].min() >= 0
+    bas = flw.basins()
+    case.check("basins", bas)
+    assert bas.dtype == np.uint32 and bas.max() <= flw.idxs_pit.size
+    case.check("basins_sub_i16", flw.basins(idxs=D["basins_idxs"], ids=D["basins_ids"]))
+    case.check("hand_f32", flw.hand(D["drain"], D["elevtn"]))
+    case.check("hand_f64", flw.hand(D["drain"], D["elevtn"].astype(np.float64) * 1.000001))
+
+
+def test_constructor_from_idxs_ds(case, flw):
+    """FlwdirRaster(idxs_ds, shape, "d8") like reference tests/conftest.py:49-54."""
+    import pyflwdir_amd as pyflwdir
+
+    if case.n <= 1:
+        pytest.skip("single cell")
+    flw2 = pyflwdir.FlwdirRaster(flw.idxs_ds.copy(), case.shape, "d8", idxs_pit=flw.idxs_pit.copy(), cache=False)
+    case.check("uparea_cell", flw2.upstream_area())
+    case.check("idxs_seq_int32", flw2.idxs_seq)
+
+
+def test_errors(case, flw):
+    """Error behaviour of the wrappers (reference tests/test_pyflwdir.py:230-235,271-278,403-407)."""
+    with pytest.raises(ValueError, match="Unknown unit"):
+        flw.upstream_area(unit="km")
+    with pytest.raises(ValueError, match="size does not match"):
+        flw.accuflux(np.ones((2, 1)) if case.n != 2 else np.ones((3, 1)))
+    with pytest.raises(ValueError, match="Unknown flow direction"):
+        flw.accuflux(np.ones((1, 1)), direction="???")
+    k = flw.idxs_pit.size
+    if k > 1:
+        with pytest.raises(ValueError, match="size does not match"):
+            flw.basins(ids=np.arange(k - 1))
+    with pytest.raises(ValueError, match="IDs cannot contain a value zero"):
+        flw.basins(ids=np.zeros(k, dtype=np.int16))
+    with pytest.raises(ValueError, match="size does not match"):
+        flw.hand(np.ones(case.shape, bool), np.ones((case.shape[0] + 1, 1)))
