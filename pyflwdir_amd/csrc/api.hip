@@ -101,6 +101,7 @@ static void free_handle(pfd_raster *h) {
   }
   if (h->ncode) (void)hipFree(h->ncode);
   if (h->seq) (void)hipFree(h->seq);
+  if (h->pits) (void)hipFree(h->pits);
   if (h->ctrl) (void)hipFree(h->ctrl);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

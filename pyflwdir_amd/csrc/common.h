@@ -124,7 +124,8 @@ struct pfd_raster {
   i64 n_valid = 0, n_pits = 0;
   // ordering
   bool ordered = false;
-  u32 *seq = nullptr;  // device, capacity n_valid
+  u32 *pits = nullptr;  // device, n_pits entries, ascending
+  u32 *seq = nullptr;   // device, capacity n_valid, allocated by the first ordering
   i64 n_seq = -1, n_levels = -1;
   std::vector<i64> lvl_off;  // host copy, n_levels+1 entries
   // small device control block (counters), 64 x u64
@@ -213,5 +214,6 @@ void pfd_seg_begin(pfd_raster *h, const char *name);
 void pfd_seg_end(pfd_raster *h, i64 launches);
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev);  // order.hip
 int pfd_order_cells_impl(pfd_raster *h);                        // order.hip
+int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete);  // tiled.hip
 
 static inline u32 cdiv_u32(u64 a, u32 b) { return (u32)((a + b - 1) / b); }

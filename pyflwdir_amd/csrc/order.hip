@@ -8,6 +8,8 @@
 //   core.idxs_seq             pyflwdir/core.py:87-117     -> k_bfs_level (level sets) and
 //                                                            k_oseq_* (exact BFS order on request)
 //   core.rank                 pyflwdir/core.py:17-47      -> k_rank_from_levels
+#include <algorithm>
+
 #include "common.h"
 
 int pfd_export_u32(pfd_raster *h, const u32 *src, i64 m, int idx_dtype, void *out, int memspace);
@@ -21,47 +23,55 @@ enum { C_NVALID = 0, C_NPITS = 1, C_BAD = 2, C_TAIL = 3, C_DONE = 4, C_AUX = 5 }
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_normalise(const u8 *__restrict__ d8, Geo g, u8 *__restrict__ ncode,
                                                    u64 *__restrict__ ctrl) {
+  // one block = a 64-column x 64-row patch, 4 rows per pass
   const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const u32 r = blockIdx.y * 4 + (threadIdx.x >> 6);
   u32 valid = 0, pit = 0, bad = 0;
-  if (r < g.nrow && c < g.ncol) {
-    const u32 i = r * g.ncol + c;
-    const u32 code = d8[i];
-    u32 out = code;
-    if (code == D8_MV) {
-      out = D8_MV;
-    } else if (code == 0u || code == 255u) {
-      out = 0;
-      valid = 1;
-      pit = 1;
-    } else if ((code & (code - 1)) == 0u) {  // one of the eight direction codes
-      valid = 1;
-      const int k = d8_slot(code);
-      const u32 rr = r + (u32)d8_dr(k), cc = c + (u32)d8_dc(k);
-      if (rr >= g.nrow || cc >= g.ncol || d8[rr * g.ncol + cc] == D8_MV) {
-        out = 0;  // drains off the raster or into nodata -> pit (core_d8.py:57-63)
-        pit = 1;
+  for (u32 pass = 0; pass < 16; ++pass) {
+    const u32 r = blockIdx.y * 64 + pass * 4 + (threadIdx.x >> 6);
+    if (r < g.nrow && c < g.ncol) {
+      const size_t i = (size_t)r * g.ncol + c;
+      const u32 code = d8[i];
+      u32 out = code;
+      if (code == D8_MV) {
+        out = D8_MV;
+      } else if (code == 0u || code == 255u) {
+        out = 0;
+        ++valid;
+        ++pit;
+      } else if ((code & (code - 1)) == 0u) {  // one of the eight direction codes
+        ++valid;
+        const int k = d8_slot(code);
+        const u32 rr = r + (u32)d8_dr(k), cc = c + (u32)d8_dc(k);
+        if (rr >= g.nrow || cc >= g.ncol || d8[(size_t)rr * g.ncol + cc] == D8_MV) {
+          out = 0;  // drains off the raster or into nodata -> pit (core_d8.py:57-63)
+          ++pit;
+        }
+      } else {
+        ++bad;
+        out = D8_MV;
       }
-    } else {
-      bad = 1;
-      out = D8_MV;
+      ncode[i] = (u8)out;
     }
-    ncode[i] = (u8)out;
   }
-  // block reduction -> 3 atomics per block
+  // block reduction -> at most 3 atomics per block, spread over 16 counter copies
   __shared__ u32 s_valid, s_pit, s_bad;
   if (threadIdx.x == 0) s_valid = s_pit = s_bad = 0;
   __syncthreads();
-  const u64 bv = __ballot(valid), bp = __ballot(pit), bb = __ballot(bad);
+  for (int o = 32; o > 0; o >>= 1) {
+    valid += __shfl_down(valid, o);
+    pit += __shfl_down(pit, o);
+    bad += __shfl_down(bad, o);
+  }
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&s_valid, (u32)__popcll(bv));
-    atomicAdd(&s_pit, (u32)__popcll(bp));
-    atomicAdd(&s_bad, (u32)__popcll(bb));
+    if (valid) atomicAdd(&s_valid, valid);
+    if (pit) atomicAdd(&s_pit, pit);
+    if (bad) atomicAdd(&s_bad, bad);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (s_valid) atomicAdd((unsigned long long *)&ctrl[C_NVALID], (unsigned long long)s_valid);
-    if (s_pit) atomicAdd((unsigned long long *)&ctrl[C_NPITS], (unsigned long long)s_pit);
+    const u32 copy = (blockIdx.x + blockIdx.y) & 15u;
+    if (s_valid) atomicAdd((unsigned long long *)&ctrl[16 + copy], (unsigned long long)s_valid);
+    if (s_pit) atomicAdd((unsigned long long *)&ctrl[32 + copy], (unsigned long long)s_pit);
     if (s_bad) atomicAdd((unsigned long long *)&ctrl[C_BAD], (unsigned long long)s_bad);
   }
 }
@@ -156,18 +166,31 @@ static int compact_pits(pfd_raster *h) {
   KCHK();
   k_scan_u32_1block<<<1, 1024, 0, h->stream>>>(counts.as<u32>(), nchunk);
   KCHK();
-  k_pit_scatter<<<nchunk, 256, 0, h->stream>>>(h->ncode, n, counts.as<u32>(), h->seq);
+  k_pit_scatter<<<nchunk, 256, 0, h->stream>>>(h->ncode, n, counts.as<u32>(), h->pits);
   KCHK();
   HIPCHK(hipStreamSynchronize(h->stream));
   return PFD_OK;
 }
 
+static int alloc_pits(pfd_raster *h) {
+  if (h->pits) {
+    HIPCHK(hipFree(h->pits));
+    h->pits = nullptr;
+  }
+  HIPCHK(hipMalloc((void **)&h->pits, (size_t)std::max<i64>(h->n_pits, 1) * sizeof(u32)));
+  return PFD_OK;
+}
+
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
+  if (cdiv_u32((u64)h->nrow, 64) > 65535u) {
+    pfd_set_error("rasters with more than %d rows per handle are not supported", 65535 * 64);
+    return PFD_EUNSUPPORTED;
+  }
   HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
-  dim3 grid(cdiv_u32((u64)h->ncol, 64), cdiv_u32((u64)h->nrow, 4));
+  dim3 grid(cdiv_u32((u64)h->ncol, 64), cdiv_u32((u64)h->nrow, 64));
   k_normalise<<<grid, 256, 0, h->stream>>>(d8_dev, h->geo, h->ncode, h->ctrl);
   KCHK();
-  u64 c[3];
+  u64 c[48];
   HIPCHK(hipMemcpyAsync(c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (c[C_BAD]) {
@@ -175,21 +198,24 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
                   (unsigned long long)c[C_BAD]);
     return PFD_EBADCODE;
   }
-  h->n_valid = (i64)c[C_NVALID];
-  h->n_pits = (i64)c[C_NPITS];
+  h->n_valid = h->n_pits = 0;
+  for (int k = 0; k < 16; ++k) {
+    h->n_valid += (i64)c[16 + k];
+    h->n_pits += (i64)c[32 + k];
+  }
   if (h->n_pits == 0) {
     pfd_set_error("Invalid FlwdirRaster: no pits found");
     return PFD_ENOPITS;
   }
-  HIPCHK(hipMalloc((void **)&h->seq, (size_t)h->n_valid * sizeof(u32)));
-  h->bytes_held += (size_t)h->n_valid * sizeof(u32);
+  PFDCHK(alloc_pits(h));
+  h->bytes_held += (size_t)h->n_pits * sizeof(u32);
   h->ordered = false;
   return compact_pits(h);
 }
 
 extern "C" int pfd_idxs_pit(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
-  return pfd_export_u32(h, h->seq, h->n_pits, idx_dtype, out, memspace);
+  return pfd_export_u32(h, h->pits, h->n_pits, idx_dtype, out, memspace);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,6 +259,7 @@ extern "C" int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k) {
   h->ordered = false;
   h->n_seq = h->n_levels = -1;
   h->lvl_off.clear();
+  PFDCHK(alloc_pits(h));
   PFDCHK(compact_pits(h));
   if (c[C_BAD]) {
     pfd_set_error("pfd_add_pits: %llu index(es) outside the raster or on nodata cells were ignored",
@@ -339,7 +366,12 @@ __global__ void __launch_bounds__(256) k_bfs_level(const u8 *__restrict__ ncode,
 
 int pfd_order_cells_impl(pfd_raster *h) {
   if (h->ordered) return PFD_OK;
+  if (!h->seq) {
+    HIPCHK(hipMalloc((void **)&h->seq, (size_t)h->n_valid * sizeof(u32)));
+    h->bytes_held += (size_t)h->n_valid * sizeof(u32);
+  }
   pfd_seg_begin(h, "order_cells");
+  HIPCHK(hipMemcpyAsync(h->seq, h->pits, (size_t)h->n_pits * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
   const int BATCH = 256;
   size_t cap = (size_t)(2 * (h->nrow + h->ncol) + 4 * BATCH + 64);
   DevBuf lvl;

@@ -223,6 +223,16 @@ __global__ void k_seed_labels(const i64 *__restrict__ idx, const L *__restrict__
 // ---------------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------------
+static int upstream_area_cell_levels_dev(pfd_raster *h, i32 *out_dev) {
+  PFDCHK(pfd_order_cells_impl(h));
+  pfd_seg_begin(h, "init");
+  k_init_cell<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, out_dev);
+  KCHK();
+  pfd_seg_end(h, 1);
+  CountUp op{h->ncode, h->geo, (u32 *)out_dev};
+  return run_up(h, op, "sweep_count_up");
+}
+
 extern "C" int pfd_upstream_area_cell_levels(pfd_raster *h, int32_t *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
   if (!out) {
@@ -230,20 +240,28 @@ extern "C" int pfd_upstream_area_cell_levels(pfd_raster *h, int32_t *out, int me
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  PFDCHK(pfd_order_cells_impl(h));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
-  pfd_seg_begin(h, "init");
-  k_init_cell<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, (i32 *)o.dev);
-  KCHK();
-  pfd_seg_end(h, 1);
-  CountUp op{h->ncode, h->geo, (u32 *)o.dev};
-  PFDCHK(run_up(h, op, "sweep_count_up"));
+  PFDCHK(upstream_area_cell_levels_dev(h, (i32 *)o.dev));
   return o.finish(h->stream);
 }
 
+// Fast path: LDS-tiled sweep (tiled.hip).  A raster with cycles (cells that never reach a pit)
+// cannot be finished by it; those rasters are recomputed by the level engine, whose semantics
+// for such cells are the reference's (they keep their own weight).
 extern "C" int pfd_upstream_area_cell(pfd_raster *h, int32_t *out, int memspace) {
-  return pfd_upstream_area_cell_levels(h, out, memspace);
+  PFDCHK(pfd_check_handle(h));
+  if (!out) {
+    pfd_set_error("pfd_upstream_area_cell: NULL out");
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
+  int complete = 0;
+  PFDCHK(pfd_upstream_area_cell_tiled(h, (i32 *)o.dev, &complete));
+  if (!complete) PFDCHK(upstream_area_cell_levels_dev(h, (i32 *)o.dev));
+  return o.finish(h->stream);
 }
 
 template <class T>
