@@ -71,6 +71,9 @@ int pfd_free(int device, void *ptr);
 int pfd_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
 int pfd_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
 int pfd_device_synchronize(int device);
+/* the library caches freed HBM blocks for reuse; pfd_trim returns them to the driver
+ * (device < 0: all devices) */
+int pfd_trim(int device);
 
 /* ---- raster handle -------------------------------------------------------------------
  * pfd_raster_create: replaces core_d8.from_array (reference pyflwdir/core_d8.py:42-67) as the

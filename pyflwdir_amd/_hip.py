@@ -29,7 +29,7 @@ _ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, 
 # every symbol include/pfd.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "pfd_abi_version", "pfd_last_error", "pfd_device_count", "pfd_malloc", "pfd_free", "pfd_memcpy_h2d",
-    "pfd_memcpy_d2h", "pfd_device_synchronize", "pfd_raster_create", "pfd_raster_destroy", "pfd_raster_info",
+    "pfd_memcpy_d2h", "pfd_device_synchronize", "pfd_trim", "pfd_raster_create", "pfd_raster_destroy", "pfd_raster_info",
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_basins", "pfd_hand", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         L.pfd_memcpy_h2d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.pfd_memcpy_d2h.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.pfd_device_synchronize.argtypes = [C.c_int]
+        L.pfd_trim.argtypes = [C.c_int]
         L.pfd_device_count.argtypes = [C.POINTER(C.c_int)]
         L.pfd_synth_d8.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                    C.c_int64, C.c_int64, C.c_void_p]

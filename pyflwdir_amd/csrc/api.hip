@@ -4,6 +4,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 static thread_local char g_err[1024] = "";
@@ -31,6 +35,95 @@ extern "C" int pfd_device_count(int *count) {
     return PFD_ENODEVICE;
   }
   *count = n;
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// caching device allocator
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DevCache {
+  std::mutex mu;
+  std::unordered_map<void *, std::pair<int, size_t>> live;       // ptr -> (device, class bytes)
+  std::map<std::pair<int, size_t>, std::vector<void *>> idle;    // (device, class bytes) -> blocks
+  size_t idle_bytes = 0;
+};
+DevCache &cache() {
+  static DevCache c;
+  return c;
+}
+size_t size_class(size_t bytes) {
+  if (bytes < 256) return 256;
+  if (bytes >= (1u << 20)) return (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);  // 2 MiB steps
+  size_t c = 256;
+  while (c < bytes) c <<= 1;
+  return c;
+}
+const size_t IDLE_CAP = (size_t)96 << 30;  // keep at most 96 GiB of idle blocks per process
+}  // namespace
+
+int pfd_dmalloc(void **p, size_t bytes) {
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  const size_t cls = size_class(bytes);
+  DevCache &c = cache();
+  {
+    std::lock_guard<std::mutex> g(c.mu);
+    auto it = c.idle.find({dev, cls});
+    if (it != c.idle.end() && !it->second.empty()) {
+      *p = it->second.back();
+      it->second.pop_back();
+      c.idle_bytes -= cls;
+      c.live[*p] = {dev, cls};
+      return PFD_OK;
+    }
+  }
+  hipError_t e = hipMalloc(p, cls);
+  if (e != hipSuccess) {  // give the cached blocks back and retry once
+    (void)hipGetLastError();
+    pfd_trim(dev);
+    e = hipMalloc(p, cls);
+  }
+  if (e != hipSuccess) {
+    *p = nullptr;
+    pfd_set_error("hipMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e));
+    return PFD_ENOMEM;
+  }
+  std::lock_guard<std::mutex> g(c.mu);
+  c.live[*p] = {dev, cls};
+  return PFD_OK;
+}
+
+void pfd_dfree(void *p) {
+  if (!p) return;
+  DevCache &c = cache();
+  std::lock_guard<std::mutex> g(c.mu);
+  auto it = c.live.find(p);
+  if (it == c.live.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  const auto key = it->second;
+  c.live.erase(it);
+  if (c.idle_bytes + key.second > IDLE_CAP) {
+    (void)hipFree(p);
+    return;
+  }
+  c.idle[key].push_back(p);
+  c.idle_bytes += key.second;
+}
+
+extern "C" int pfd_trim(int device) {
+  DevCache &c = cache();
+  std::lock_guard<std::mutex> g(c.mu);
+  for (auto &kv : c.idle) {
+    if (device >= 0 && kv.first.first != device) continue;
+    for (void *p : kv.second) {
+      (void)hipFree(p);
+      c.idle_bytes -= kv.first.second;
+    }
+    kv.second.clear();
+  }
   return PFD_OK;
 }
 
@@ -99,10 +192,11 @@ static void free_handle(pfd_raster *h) {
     (void)hipEventDestroy(s.e0);
     (void)hipEventDestroy(s.e1);
   }
-  if (h->ncode) (void)hipFree(h->ncode);
-  if (h->seq) (void)hipFree(h->seq);
-  if (h->pits) (void)hipFree(h->pits);
-  if (h->ctrl) (void)hipFree(h->ctrl);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  pfd_dfree(h->ncode);
+  pfd_dfree(h->seq);
+  pfd_dfree(h->pits);
+  pfd_dfree(h->ctrl);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -140,13 +234,13 @@ extern "C" int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, 
   int rc = PFD_OK;
   do {
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc((void **)&h->ncode, (size_t)h->n)) != hipSuccess ||
-        (e = hipMalloc((void **)&h->ctrl, 64 * sizeof(u64))) != hipSuccess) {
-      pfd_set_error("pfd_raster_create: device allocation failed: %s", hipGetErrorString(e));
-      rc = (e == hipErrorOutOfMemory) ? PFD_ENOMEM : PFD_EHIP;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+      pfd_set_error("pfd_raster_create: hipStreamCreate failed: %s", hipGetErrorString(e));
+      rc = PFD_EHIP;
       break;
     }
+    if ((rc = pfd_dmalloc((void **)&h->ncode, (size_t)h->n)) != PFD_OK) break;
+    if ((rc = pfd_dmalloc((void **)&h->ctrl, 64 * sizeof(u64))) != PFD_OK) break;
     h->bytes_held = (size_t)h->n + 64 * sizeof(u64);
     InArg in;
     if ((rc = in.bind(d8, (size_t)h->n, memspace, h->stream)) != PFD_OK) break;

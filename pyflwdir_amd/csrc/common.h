@@ -124,7 +124,8 @@ struct pfd_raster {
   i64 n_valid = 0, n_pits = 0;
   // ordering
   bool ordered = false;
-  u32 *pits = nullptr;  // device, n_pits entries, ascending
+  u32 *pits = nullptr;  // device, n_pits entries, ascending (compacted on first use)
+  bool pits_ready = false;
   u32 *seq = nullptr;   // device, capacity n_valid, allocated by the first ordering
   i64 n_seq = -1, n_levels = -1;
   std::vector<i64> lvl_off;  // host copy, n_levels+1 entries
@@ -136,27 +137,27 @@ struct pfd_raster {
   std::vector<PfdSegment> segs;
 };
 
+// Caching device allocator (api.hip): hipMalloc/hipFree cost milliseconds for the 0.1-30 GB
+// buffers of this path, so freed blocks are kept per device and size class and handed out
+// again.  Every API call synchronises its stream before it returns, hence a block is idle
+// when it is released.  pfd_trim() returns the cache to the driver.
+int pfd_dmalloc(void **p, size_t bytes);
+void pfd_dfree(void *p);
+
 // scoped device selection + temp buffers ---------------------------------------------------------
 struct DevBuf {
   void *p = nullptr;
   int rc = PFD_OK;
   DevBuf() {}
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) pfd_dfree(p);
   }
   int alloc(size_t bytes) {
     if (p) {
-      (void)hipFree(p);
+      pfd_dfree(p);
       p = nullptr;
     }
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) {
-      p = nullptr;
-      pfd_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-      return PFD_ENOMEM;
-    }
-    return PFD_OK;
+    return pfd_dmalloc(&p, bytes);
   }
   template <class T>
   T *as() { return (T *)p; }
@@ -214,6 +215,7 @@ void pfd_seg_begin(pfd_raster *h, const char *name);
 void pfd_seg_end(pfd_raster *h, i64 launches);
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev);  // order.hip
 int pfd_order_cells_impl(pfd_raster *h);                        // order.hip
+int pfd_ensure_pits(pfd_raster *h);                             // order.hip
 int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete);  // tiled.hip
 
 static inline u32 cdiv_u32(u64 a, u32 b) { return (u32)((a + b - 1) / b); }

@@ -174,11 +174,10 @@ static int compact_pits(pfd_raster *h) {
 
 static int alloc_pits(pfd_raster *h) {
   if (h->pits) {
-    HIPCHK(hipFree(h->pits));
+    pfd_dfree(h->pits);
     h->pits = nullptr;
   }
-  HIPCHK(hipMalloc((void **)&h->pits, (size_t)std::max<i64>(h->n_pits, 1) * sizeof(u32)));
-  return PFD_OK;
+  return pfd_dmalloc((void **)&h->pits, (size_t)std::max<i64>(h->n_pits, 1) * sizeof(u32));
 }
 
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
@@ -207,14 +206,23 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
     pfd_set_error("Invalid FlwdirRaster: no pits found");
     return PFD_ENOPITS;
   }
+  h->ordered = false;
+  h->pits_ready = false;  // the ascending pit list is compacted on first use
+  return PFD_OK;
+}
+
+int pfd_ensure_pits(pfd_raster *h) {
+  if (h->pits_ready) return PFD_OK;
   PFDCHK(alloc_pits(h));
   h->bytes_held += (size_t)h->n_pits * sizeof(u32);
-  h->ordered = false;
-  return compact_pits(h);
+  PFDCHK(compact_pits(h));
+  h->pits_ready = true;
+  return PFD_OK;
 }
 
 extern "C" int pfd_idxs_pit(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_ensure_pits(h));
   return pfd_export_u32(h, h->pits, h->n_pits, idx_dtype, out, memspace);
 }
 
@@ -259,8 +267,7 @@ extern "C" int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k) {
   h->ordered = false;
   h->n_seq = h->n_levels = -1;
   h->lvl_off.clear();
-  PFDCHK(alloc_pits(h));
-  PFDCHK(compact_pits(h));
+  h->pits_ready = false;
   if (c[C_BAD]) {
     pfd_set_error("pfd_add_pits: %llu index(es) outside the raster or on nodata cells were ignored",
                   (unsigned long long)c[C_BAD]);
@@ -366,8 +373,9 @@ __global__ void __launch_bounds__(256) k_bfs_level(const u8 *__restrict__ ncode,
 
 int pfd_order_cells_impl(pfd_raster *h) {
   if (h->ordered) return PFD_OK;
+  PFDCHK(pfd_ensure_pits(h));
   if (!h->seq) {
-    HIPCHK(hipMalloc((void **)&h->seq, (size_t)h->n_valid * sizeof(u32)));
+    PFDCHK(pfd_dmalloc((void **)&h->seq, (size_t)h->n_valid * sizeof(u32)));
     h->bytes_held += (size_t)h->n_valid * sizeof(u32);
   }
   pfd_seg_begin(h, "order_cells");

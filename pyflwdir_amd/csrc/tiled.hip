@@ -22,6 +22,9 @@
 // HBM traffic: 2 x 1 B/cell (codes) + 4 B/cell (result) + ~0.4 B/cell of perimeter records.
 // Cells on or upstream of a cycle are never finalised; the run counts finalised cells and
 // exits, and pfd_upstream_area_cell falls back to the level engine when a count is short.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 #define TS 64               // tile edge (cells)
@@ -36,12 +39,13 @@ struct TileArgs {
   const u8 *ncode;
   u32 nrow, ncol, ntr, ntc;
   u64 *xtot;      // [ntiles*PSL] coarse state: total<<32 | expected<<16 | arrived
-  u32 *xtarget;   // [ntiles*PSL] global slot an exit drains into, NONE32 if the slot is no exit
-  u32 *xnext;     // [ntiles*PSL] next exit on the path (slot), NONE32 at the end
+  u64 *xrec;      // [ntiles*PSL] next exit on the path (slot) << 32 | slot the exit drains into;
+                  //              low half NONE32 if the slot is no exit, high half NONE32 at a path end
   u32 *elink;     // [ntiles*PSL] perimeter slot (0..251) of the exit an entry's path reaches
   u32 *inflow;    // [ntiles*PSL] sum of the totals of the exits draining into this slot
   u64 *ctrl;
   i32 *out;
+  int ablate;  // debugging/profiling knob (env PFD_TILE_ABLATE): bit0 skip sweep, bit1 skip scatter
 };
 
 __device__ __forceinline__ int pslot(int lr, int lc) {
@@ -67,25 +71,37 @@ __device__ __forceinline__ void pslot_inv(int p, int *lr, int *lc) {
   }
 }
 
+#define TSTAMP(slot)                                                                            \
+  if (a.ablate & 16) {                                                                          \
+    __syncthreads();                                                                            \
+    if (tid == 0) {                                                                             \
+      const u64 t_ = __builtin_readcyclecounter();                                              \
+      atomicAdd((unsigned long long *)&a.ctrl[(FINAL ? 40 : 24) + slot], (unsigned long long)(t_ - tprev)); \
+      tprev = t_;                                                                               \
+    }                                                                                           \
+  }
+
 template <bool FINAL>
 __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
+  u64 tprev = __builtin_readcyclecounter();
   __shared__ u64 state[TCELLS];  // total<<32 | expected_children<<16 | arrived_children
   __shared__ u8 code[HW * HW];
-  __shared__ u32 s_proc, s_exits;
+  __shared__ u32 s_proc, s_exits, s_next;
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
   const u32 tile = tr * a.ntc + tc;
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
-  if (tid == 0) s_proc = s_exits = 0;
+  if (tid == 0) s_proc = s_exits = s_next = 0;
 
   // ---- stage the tile's codes (+1-cell halo) in LDS --------------------------------------
   for (u32 idx = tid; idx < HW * HW; idx += 256) {
     const i64 gr = r0 + (i64)(idx / HW) - 1, gc = c0 + (i64)(idx % HW) - 1;
     u8 v = (u8)D8_MV;
-    if (gr >= 0 && gc >= 0 && gr < (i64)a.nrow && gc < (i64)a.ncol) v = a.ncode[(size_t)gr * a.ncol + (size_t)gc];
+    if (gr >= 0 && gc >= 0 && gr < (i64)a.nrow && gc < (i64)a.ncol) v = (a.ablate & 4) ? (u8)1 : a.ncode[(size_t)gr * a.ncol + (size_t)gc];
     code[idx] = v;
   }
   __syncthreads();
+  TSTAMP(0)
 
   // ---- initial weights: 1 per valid cell (+ inflow from other tiles in the final pass) -----
   u32 anyvalid = 0;
@@ -115,15 +131,16 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     } else if (tid < PSL) {
       const size_t s = (size_t)tile * PSL + tid;
       a.xtot[s] = 0;
-      a.xtarget[s] = NONE32;
+      a.xrec[s] = ~0ull;
       a.elink[s] = NONE32;
     }
     return;
   }
 
+  TSTAMP(1)
   // ---- expected children per cell: every cell with an in-tile target bumps that target ------
 #pragma unroll 4
-  for (u32 j = 0; j < TCELLS / 256; ++j) {
+  for (u32 j = 0; j < ((a.ablate & 2) ? 0u : TCELLS / 256); ++j) {
     const u32 l = tid + 256 * j;
     const int lr = l >> 6, lc = l & 63;
     const u32 c = code[(lr + 1) * HW + lc + 1];
@@ -134,35 +151,77 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     }
   }
   __syncthreads();
+  TSTAMP(2)
 
-  // ---- dependency-driven up-sweep: start at cells without in-tile children ------------------
-  u32 proc = 0;
-  for (u32 j = 0; j < TCELLS / 256; ++j) {
-    const u32 l = tid + 256 * j;
-    u32 c = code[((l >> 6) + 1) * HW + (l & 63) + 1];
-    if (c == D8_MV) continue;
-    const u64 s0 = state[l];
-    if ((s0 >> 16) & 0xFFFFu) continue;  // has in-tile children: someone else finishes it
-    u32 v = (u32)(s0 >> 32);
-    int lr = l >> 6, lc = l & 63;
-    ++proc;
-    while (d8_is_dir(c)) {
-      const int k = d8_slot(c);
-      lr += d8_dr(k);
-      lc += d8_dc(k);
-      if ((unsigned)lr >= TS || (unsigned)lc >= TS) break;  // leaves the tile: an exit
-      const u64 old = atomicAdd((unsigned long long *)&state[lr * TS + lc], ((u64)v << 32) | 1ull);
-      if (((old & 0xFFFFu) + 1) != ((old >> 16) & 0xFFFFu)) break;  // siblings still pending
-      v += (u32)(old >> 32);
-      c = code[(lr + 1) * HW + lc + 1];
-      ++proc;
+  // ---- dependency-driven up-sweep --------------------------------------------------------------
+  // Lanes claim cells in chunks of 4 from a tile-wide counter; a claimed cell without in-tile
+  // children starts a chain: deliver the finished total to the downstream cell with ONE 64-bit
+  // LDS atomic and, if that was the last missing child, carry on with that cell.  A lane whose
+  // chain stops (siblings pending, pit, tile edge) claims the next cell at once, so the wave's
+  // time is the longest single chain plus its share of the tile, not the sum of per-cell maxima.
+  u32 proc = 0, iters = 0;
+  if (!(a.ablate & 1)) {
+    u32 cbase = 0, cpos = 4, v = 0, c = 0;
+    int lr = 0, lc = 0;
+    bool active = false, nomore = false;
+    for (;;) {
+      if (!active && !nomore) {
+        if (cpos == 4) {
+          cbase = atomicAdd(&s_next, 4u);
+          cpos = 0;
+          if (cbase >= TCELLS) nomore = true;
+        }
+        if (!nomore) {
+          const u32 l = cbase + cpos;
+          ++cpos;
+          const u32 cc = code[((l >> 6) + 1) * HW + (l & 63) + 1];
+          if (cc != D8_MV) {
+            const u64 s0 = state[l];
+            if (((s0 >> 16) & 0xFFFFu) == 0) {  // no in-tile children: a chain starts here
+              active = true;
+              v = (u32)(s0 >> 32);
+              lr = l >> 6;
+              lc = l & 63;
+              c = cc;
+              ++proc;
+            }
+          }
+        }
+      }
+      if (active) {
+        active = false;
+        if (d8_is_dir(c)) {
+          const int k = d8_slot(c);
+          lr += d8_dr(k);
+          lc += d8_dc(k);
+          if ((unsigned)lr < TS && (unsigned)lc < TS) {  // else: leaves the tile (an exit)
+            const u32 cn = code[(lr + 1) * HW + lc + 1];
+            const u64 old = atomicAdd((unsigned long long *)&state[lr * TS + lc], ((u64)v << 32) | 1ull);
+            if (((old & 0xFFFFu) + 1) == ((old >> 16) & 0xFFFFu)) {  // last missing child
+              v += (u32)(old >> 32);
+              c = cn;
+              active = true;
+              ++proc;
+            }
+          }
+        }
+      }
+      ++iters;
+      if (!__any(active || !nomore)) break;
     }
   }
+  if ((a.ablate & 16) && (tid & 63) == 0) {
+    atomicAdd((unsigned long long *)&a.ctrl[(FINAL ? 40 : 24) + 8], (unsigned long long)iters);
+    atomicMax((unsigned long long *)&a.ctrl[(FINAL ? 40 : 24) + 9], (unsigned long long)iters);
+  }
+  TSTAMP(3)
   // block-reduce the number of finalised cells
   for (int o = 32; o > 0; o >>= 1) proc += __shfl_down(proc, o);
   if ((tid & 63) == 0 && proc) atomicAdd(&s_proc, proc);
   __syncthreads();
 
+  TSTAMP(4)
+  if (a.ablate & 8) return;
   if (FINAL) {
     // ---- write the finished tile, one 256-B row segment per wave instruction ---------------
 #pragma unroll 4
@@ -176,6 +235,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       }
     }
     if (tid == 0 && s_proc) atomicAdd((unsigned long long *)&a.ctrl[T_PROC], (unsigned long long)s_proc);
+    TSTAMP(5)
     return;
   }
 
@@ -226,15 +286,16 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       }
     }
     a.xtot[slot] = xt;
-    a.xtarget[slot] = tgt;
+    a.xrec[slot] = ((u64)NONE32 << 32) | tgt;
     a.elink[slot] = link;
   } else if (tid < PSL) {
     const size_t slot = (size_t)tile * PSL + tid;
     a.xtot[slot] = 0;
-    a.xtarget[slot] = NONE32;
+    a.xrec[slot] = ~0ull;
     a.elink[slot] = NONE32;
   }
   __syncthreads();
+  TSTAMP(5)
   if (tid == 0) {
     if (s_proc) atomicAdd((unsigned long long *)&a.ctrl[T_PROC], (unsigned long long)s_proc);
     if (s_exits) atomicAdd((unsigned long long *)&a.ctrl[T_NEXITS], (unsigned long long)s_exits);
@@ -245,35 +306,39 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
 __global__ void __launch_bounds__(256) k_coarse_link(TileArgs a, u32 nslots) {
   const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
-  const u32 tgt = a.xtarget[s];
+  const u32 tgt = (u32)a.xrec[s];
   if (tgt == NONE32) return;
   const u32 l = a.elink[tgt];
-  u32 nx = NONE32;
   if (l != NONE32) {
-    nx = (tgt & ~(u32)(PSL - 1)) + l;
+    const u32 nx = (tgt & ~(u32)(PSL - 1)) + l;
     atomicAdd((unsigned long long *)&a.xtot[nx], 1ull << 16);
+    a.xrec[s] = ((u64)nx << 32) | tgt;
   }
-  a.xnext[s] = nx;
 }
 
 // dependency-driven sweep over the exit forest; delivers every final total to the entry slot
-// of the neighbouring tile (inflow) on the way
+// of the neighbouring tile (inflow) on the way.  One dependent memory round trip per hop: the
+// record of the next exit is fetched while the returning atomic on its state is in flight.
 __global__ void __launch_bounds__(256) k_coarse_chase(TileArgs a, u32 nslots) {
   const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
   u32 done = 0;
-  if (s < nslots && a.xtarget[s] != NONE32) {
-    const u64 s0 = a.xtot[s];
-    if (((s0 >> 16) & 0xFFFFu) == 0) {
-      u32 cur = s, v = (u32)(s0 >> 32);
-      for (;;) {
-        ++done;
-        atomicAdd(&a.inflow[a.xtarget[cur]], v);
-        const u32 nx = a.xnext[cur];
-        if (nx == NONE32) break;
-        const u64 old = atomicAdd((unsigned long long *)&a.xtot[nx], ((u64)v << 32) | 1ull);
-        if (((old & 0xFFFFu) + 1) != ((old >> 16) & 0xFFFFu)) break;
-        v += (u32)(old >> 32);
-        cur = nx;
+  if (s < nslots) {
+    u64 rec = a.xrec[s];
+    if ((u32)rec != NONE32) {
+      const u64 s0 = a.xtot[s];
+      if (((s0 >> 16) & 0xFFFFu) == 0) {
+        u32 v = (u32)(s0 >> 32);
+        for (;;) {
+          ++done;
+          atomicAdd(&a.inflow[(u32)rec], v);
+          const u32 nx = (u32)(rec >> 32);
+          if (nx == NONE32) break;
+          const u64 rec_nx = a.xrec[nx];
+          const u64 old = atomicAdd((unsigned long long *)&a.xtot[nx], ((u64)v << 32) | 1ull);
+          if (((old & 0xFFFFu) + 1) != ((old >> 16) & 0xFFFFu)) break;
+          v += (u32)(old >> 32);
+          rec = rec_nx;
+        }
       }
     }
   }
@@ -289,15 +354,15 @@ int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
     *complete = 0;  // slot ids are 32 bit; such rasters go through the level engine
     return PFD_OK;
   }
-  DevBuf xtot, xtarget, xnext, elink, inflow;
+  DevBuf xtot, xrec, elink, inflow;
   PFDCHK(xtot.alloc(nslots * sizeof(u64)));
-  PFDCHK(xtarget.alloc(nslots * sizeof(u32)));
-  PFDCHK(xnext.alloc(nslots * sizeof(u32)));
+  PFDCHK(xrec.alloc(nslots * sizeof(u64)));
   PFDCHK(elink.alloc(nslots * sizeof(u32)));
   PFDCHK(inflow.alloc(nslots * sizeof(u32)));
-  TileArgs a{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, xtot.as<u64>(), xtarget.as<u32>(),
-             xnext.as<u32>(), elink.as<u32>(), inflow.as<u32>(), h->ctrl, out_dev};
-  HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 8 * sizeof(u64), h->stream));
+  TileArgs a{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, xtot.as<u64>(), xrec.as<u64>(),
+             elink.as<u32>(), inflow.as<u32>(), h->ctrl, out_dev, 0};
+  if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
+  HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 56 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(inflow.p, 0, nslots * sizeof(u32), h->stream));
   const dim3 grid(ntc, ntr);
   pfd_seg_begin(h, "tile_local");
@@ -316,6 +381,16 @@ int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
   u64 c[3];
   HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (a.ablate & 16) {
+    u64 t[32];
+    HIPCHK(hipMemcpy(t, h->ctrl + 24, sizeof(t), hipMemcpyDeviceToHost));
+    const double nt = (double)ntr * ntc;
+    for (int ph = 0; ph < 2; ++ph) {
+      const u64 *q = t + 16 * ph;
+      fprintf(stderr, "[k_tile<%d>] cycles/tile: load %.0f init %.0f scatter %.0f sweep %.0f red %.0f out %.0f | iters/wave avg %.1f max %llu\n",
+              ph, q[0] / nt, q[1] / nt, q[2] / nt, q[3] / nt, q[4] / nt, q[5] / nt, q[8] / (nt * 4), (unsigned long long)q[9]);
+    }
+  }
   // T_PROC counted both tile passes
   *complete = (c[0] == 2ull * (u64)h->n_valid) && (c[1] == c[2]);
   return PFD_OK;
