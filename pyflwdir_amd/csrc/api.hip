@@ -127,6 +127,37 @@ extern "C" int pfd_trim(int device) {
   return PFD_OK;
 }
 
+// hipStreamCreate/Destroy cost ~1 ms each: streams are pooled per device and reused
+namespace {
+struct StreamPool {
+  std::mutex mu;
+  std::map<int, std::vector<hipStream_t>> idle;
+};
+StreamPool &streams() {
+  static StreamPool p;
+  return p;
+}
+}  // namespace
+static int acquire_stream(int device, hipStream_t *out) {
+  StreamPool &p = streams();
+  {
+    std::lock_guard<std::mutex> g(p.mu);
+    auto &v = p.idle[device];
+    if (!v.empty()) {
+      *out = v.back();
+      v.pop_back();
+      return PFD_OK;
+    }
+  }
+  HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  return PFD_OK;
+}
+static void release_stream(int device, hipStream_t s) {
+  StreamPool &p = streams();
+  std::lock_guard<std::mutex> g(p.mu);
+  p.idle[device].push_back(s);
+}
+
 static int select_device(int device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -197,7 +228,7 @@ static void free_handle(pfd_raster *h) {
   pfd_dfree(h->seq);
   pfd_dfree(h->pits);
   pfd_dfree(h->ctrl);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream) release_stream(h->device, h->stream);
   delete h;
 }
 
@@ -233,12 +264,7 @@ extern "C" int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, 
   h->geo = make_geo(nrow, ncol);
   int rc = PFD_OK;
   do {
-    hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
-      pfd_set_error("pfd_raster_create: hipStreamCreate failed: %s", hipGetErrorString(e));
-      rc = PFD_EHIP;
-      break;
-    }
+    if ((rc = acquire_stream(device, &h->stream)) != PFD_OK) break;
     if ((rc = pfd_dmalloc((void **)&h->ncode, (size_t)h->n)) != PFD_OK) break;
     if ((rc = pfd_dmalloc((void **)&h->ctrl, 64 * sizeof(u64))) != PFD_OK) break;
     h->bytes_held = (size_t)h->n + 64 * sizeof(u64);
