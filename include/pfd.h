@@ -87,6 +87,12 @@ int pfd_trim(int device);
 int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, int memspace, int device,
                       pfd_raster **out);
 int pfd_raster_destroy(pfd_raster *h);
+/* One row block of a raster that is tiled over several GPUs (Multi-GPU): `d8` holds
+ * halo_top + own_rows + halo_bot rows; the halo rows (0 or 1 each) are copies of the adjacent
+ * rows of the neighbouring blocks and are only used to decide where flow leaves the block.
+ * Block handles support pfd_upstream_area_cell_blocks / pfd_upstream_area_cell_dist only. */
+int pfd_raster_create_block(const uint8_t *d8, int64_t own_rows, int64_t ncol, int halo_top, int halo_bot,
+                            int memspace, int device, pfd_raster **out);
 
 /* info[0]=nrow [1]=ncol [2]=n_valid [3]=n_pits [4]=n_seq (cells draining to a pit; -1 until
  * the cells are ordered) [5]=n_levels (max rank + 1; -1 until ordered) [6]=device
@@ -144,6 +150,19 @@ int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k
  * drain), elevtn PFD_F32 or PFD_F64, out float64 (-9999 off the sequence). */
 int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, double *out,
              int memspace);
+
+/* ---- multi-GPU: upstream_area(unit="cell") on a raster row-tiled over several GPUs -----------
+ * In-process form: `hs` are the nblocks row-block handles (top to bottom) of ONE process,
+ * outs[b] receives own_rows(b)*ncol int32. */
+int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32_t **outs, int memspace);
+/* One-process-per-GPU form over RCCL.  Rank 0 obtains a unique id (128 bytes) and ships it to
+ * the other ranks by any host-side means; every rank then creates its communicator and calls
+ * pfd_upstream_area_cell_dist collectively with its own block (rank r holds block r). */
+typedef struct pfd_comm pfd_comm;
+int pfd_comm_unique_id(void *id_out, size_t len);
+int pfd_comm_create(const void *id, size_t len, int rank, int world, int device, pfd_comm **out);
+int pfd_comm_destroy(pfd_comm *c);
+int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int memspace);
 
 /* ---- instrumentation ---------------------------------------------------------------------
  * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST

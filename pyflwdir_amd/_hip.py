@@ -29,7 +29,9 @@ _ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, 
 # every symbol include/pfd.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "pfd_abi_version", "pfd_last_error", "pfd_device_count", "pfd_malloc", "pfd_free", "pfd_memcpy_h2d",
-    "pfd_memcpy_d2h", "pfd_device_synchronize", "pfd_trim", "pfd_raster_create", "pfd_raster_destroy", "pfd_raster_info",
+    "pfd_memcpy_d2h", "pfd_device_synchronize", "pfd_trim", "pfd_raster_create", "pfd_raster_create_block",
+    "pfd_raster_destroy", "pfd_raster_info", "pfd_upstream_area_cell_blocks", "pfd_comm_unique_id", "pfd_comm_create",
+    "pfd_comm_destroy", "pfd_upstream_area_cell_dist",
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_basins", "pfd_hand", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
@@ -57,6 +59,13 @@ def lib() -> C.CDLL:
             if name != "pfd_last_error":
                 getattr(L, name).restype = C.c_int
         L.pfd_raster_create.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pfd_raster_create_block.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_void_p)]
+        L.pfd_upstream_area_cell_blocks.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int]
+        L.pfd_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+        L.pfd_comm_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pfd_comm_destroy.argtypes = [C.c_void_p]
+        L.pfd_upstream_area_cell_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_raster_destroy.argtypes = [C.c_void_p]
         L.pfd_raster_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.pfd_add_pits.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -151,14 +160,21 @@ class DeviceBuffer:
 class RasterHandle:
     """Owner of one ``pfd_raster`` (device-side graph of one raster on one GPU)."""
 
-    def __init__(self, d8, nrow: int, ncol: int, device: int = 0, memspace: int = PFD_HOST):
+    def __init__(self, d8, nrow: int, ncol: int, device: int = 0, memspace: int = PFD_HOST, halo=(0, 0)):
+        """``nrow`` counts the OWNED rows; with ``halo=(top, bottom)`` (row block of a multi-GPU job) ``d8``
+        holds top + nrow + bottom rows."""
         self._h = C.c_void_p()
         self.nrow, self.ncol, self.n = int(nrow), int(ncol), int(nrow) * int(ncol)
         self.device = device
+        self.halo = (int(halo[0]), int(halo[1]))
         if isinstance(d8, np.ndarray):
             d8 = np.ascontiguousarray(d8, dtype=np.uint8)
-            assert d8.size == self.n
-        check(lib().pfd_raster_create(ptr(d8), self.nrow, self.ncol, memspace, device, C.byref(self._h)))
+            assert d8.size == (self.nrow + sum(self.halo)) * self.ncol
+        if self.halo == (0, 0):
+            check(lib().pfd_raster_create(ptr(d8), self.nrow, self.ncol, memspace, device, C.byref(self._h)))
+        else:
+            check(lib().pfd_raster_create_block(ptr(d8), self.nrow, self.ncol, self.halo[0], self.halo[1], memspace,
+                                                device, C.byref(self._h)))
 
     def close(self):
         if self._h:
@@ -260,6 +276,46 @@ class RasterHandle:
             out = np.empty(self.n, np.float64)
         check(lib().pfd_hand(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(out), memspace))
         return out
+
+
+def upstream_area_cell_blocks(handles, outs=None, memspace=PFD_HOST):
+    """upstream_area("cell") of a raster held as row blocks by the handles of THIS process."""
+    k = len(handles)
+    if memspace == PFD_HOST:
+        outs = [np.empty(h.n, np.int32) for h in handles]
+    hs = (C.c_void_p * k)(*[h._h for h in handles])
+    ps = (C.c_void_p * k)(*[ptr(o) for o in outs])
+    check(lib().pfd_upstream_area_cell_blocks(hs, k, ps, memspace))
+    return outs
+
+
+class Communicator:
+    """RCCL communicator (one rank per GPU/process).  ``uid`` = 128 bytes from ``unique_id()`` of rank 0."""
+
+    UID_BYTES = 128
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int):
+        self._c = C.c_void_p()
+        buf = C.create_string_buffer(bytes(uid), self.UID_BYTES)
+        check(lib().pfd_comm_create(buf, self.UID_BYTES, rank, world, device, C.byref(self._c)))
+        self.rank, self.world, self.device = rank, world, device
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Communicator.UID_BYTES)
+        check(lib().pfd_comm_unique_id(buf, Communicator.UID_BYTES))
+        return buf.raw
+
+    def upstream_area_cell(self, handle, out=None, memspace=PFD_HOST):
+        if memspace == PFD_HOST:
+            out = np.empty(handle.n, np.int32)
+        check(lib().pfd_upstream_area_cell_dist(handle._h, self._c, ptr(out), memspace))
+        return out
+
+    def close(self):
+        if self._c:
+            lib().pfd_comm_destroy(self._c)
+            self._c = C.c_void_p()
 
 
 # -- synthetic rasters generated in HBM ---------------------------------------------------------

@@ -232,18 +232,19 @@ static void free_handle(pfd_raster *h) {
   delete h;
 }
 
-extern "C" int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, int memspace, int device,
-                                 pfd_raster **out) {
+static int raster_create_impl(const uint8_t *d8, int64_t own_rows, int64_t ncol, int halo_top, int halo_bot,
+                              int memspace, int device, pfd_raster **out) {
   if (!out) {
     pfd_set_error("pfd_raster_create: NULL out");
     return PFD_EINVAL;
   }
   *out = nullptr;
-  if (!d8 || nrow <= 0 || ncol <= 0) {
-    pfd_set_error("pfd_raster_create: invalid raster (ptr=%p, shape=%lld x %lld)", (const void *)d8,
-                  (long long)nrow, (long long)ncol);
+  if (!d8 || own_rows <= 0 || ncol <= 0 || halo_top < 0 || halo_top > 1 || halo_bot < 0 || halo_bot > 1) {
+    pfd_set_error("pfd_raster_create: invalid raster (ptr=%p, shape=%lld x %lld, halo %d/%d)", (const void *)d8,
+                  (long long)own_rows, (long long)ncol, halo_top, halo_bot);
     return PFD_EINVAL;
   }
+  const int64_t nrow = own_rows + halo_top + halo_bot;
   const unsigned __int128 n128 = (unsigned __int128)nrow * (unsigned __int128)ncol;
   if (n128 > 4294967294ull) {
     pfd_set_error("pfd_raster_create: %lld x %lld cells exceed the 4294967294 cells a single handle "
@@ -261,6 +262,9 @@ extern "C" int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, 
   h->nrow = nrow;
   h->ncol = ncol;
   h->n = nrow * ncol;
+  h->halo_top = halo_top;
+  h->halo_bot = halo_bot;
+  h->own_rows = own_rows;
   h->geo = make_geo(nrow, ncol);
   int rc = PFD_OK;
   do {
@@ -278,6 +282,16 @@ extern "C" int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, 
   }
   *out = h;
   return PFD_OK;
+}
+
+extern "C" int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, int memspace, int device,
+                                 pfd_raster **out) {
+  return raster_create_impl(d8, nrow, ncol, 0, 0, memspace, device, out);
+}
+
+extern "C" int pfd_raster_create_block(const uint8_t *d8, int64_t own_rows, int64_t ncol, int halo_top, int halo_bot,
+                                       int memspace, int device, pfd_raster **out) {
+  return raster_create_impl(d8, own_rows, ncol, halo_top, halo_bot, memspace, device, out);
 }
 
 extern "C" int pfd_raster_destroy(pfd_raster *h) {
@@ -400,6 +414,7 @@ static size_t idx_size(int idx_dtype) {
 
 extern "C" int pfd_idxs_ds(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_require_whole(h, "idxs_ds"));
   const size_t es = idx_size(idx_dtype);
   if (!es || !out) {
     pfd_set_error("pfd_idxs_ds: bad index dtype %d or NULL out", idx_dtype);

@@ -24,6 +24,7 @@ typedef int32_t i32;
 typedef int64_t i64;
 
 #define D8_MV 247u
+#define D8_HALO 254u  // valid cell of a halo row (owned by the neighbouring row block): a weightless sink
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing
@@ -77,7 +78,7 @@ __device__ __forceinline__ u32 geo_row(const Geo &g, u32 i) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int d8_dr(int k) { return (k >= 1 && k <= 3) ? 1 : (k >= 5 ? -1 : 0); }
 __device__ __forceinline__ int d8_dc(int k) { return (k == 0 || k == 1 || k == 7) ? 1 : ((k >= 3 && k <= 5) ? -1 : 0); }
-__device__ __forceinline__ bool d8_is_dir(u32 code) { return code != 0 && code != D8_MV && code != 255u; }
+__device__ __forceinline__ bool d8_is_dir(u32 code) { return code != 0 && (code & (code - 1)) == 0; }  // power of two
 __device__ __forceinline__ int d8_slot(u32 code) { return __ffs((int)code) - 1; }
 
 // children visiting orders: slots of the neighbours in DESCENDING linear index (the order in
@@ -118,7 +119,8 @@ struct PfdSegment {
 struct pfd_raster {
   int device = 0;
   hipStream_t stream = nullptr;
-  i64 nrow = 0, ncol = 0, n = 0;
+  i64 nrow = 0, ncol = 0, n = 0;  // device raster incl. halo rows (row blocks of a multi-GPU job)
+  i64 halo_top = 0, halo_bot = 0, own_rows = 0;  // owned rows = [halo_top, halo_top + own_rows)
   Geo geo{};
   u8 *ncode = nullptr;  // device
   i64 n_valid = 0, n_pits = 0;
@@ -216,6 +218,7 @@ void pfd_seg_end(pfd_raster *h, i64 launches);
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev);  // order.hip
 int pfd_order_cells_impl(pfd_raster *h);                        // order.hip
 int pfd_ensure_pits(pfd_raster *h);                             // order.hip
+int pfd_require_whole(pfd_raster *h, const char *what);          // order.hip
 int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete);  // tiled.hip
 
 static inline u32 cdiv_u32(u64 a, u32 b) { return (u32)((a + b - 1) / b); }

@@ -1,0 +1,277 @@
+// dist.hip — multi-GPU driver of the tiled accumulation: one row block (+1 halo row per inner
+// edge) per GPU, one process per GPU, ONE small all-gather over RCCL/xGMI per pass.
+//
+// A D8 edge changes the row by at most one, so the only cross-GPU edges connect the last row
+// of block k with the first row of block k+1.  Per pass:
+//
+//   phase A (local, all GPUs in parallel)   tile pass + exit-graph solve with zero outside flow.
+//       Each halo cell (a weightless sink standing for the neighbour's boundary cell) ends up
+//       with L = flow that leaves the block through it; each own boundary-row cell gets
+//       sink = the halo cell where flow entering THERE would leave the block again.
+//   exchange                                 all-gather of the 4*ncol-word boundary record
+//       {L_top, L_bottom, sink_first_row, sink_last_row} of every block (<= 1.4 MB per GPU for
+//       90000 columns): ncclAllGather, nothing else crosses xGMI.
+//   interface solve (redundant on every GPU) the interface cells form a forest
+//       F(h) = L(h) + sum of F over the interface cells whose flow leaves through h
+//       (2*N*ncol nodes); same pointer doubling as everywhere else.
+//   phase B (local, parallel)                F of the own boundary rows is pushed down the local
+//       exit paths, then the final tile pass writes the block's result.
+//
+// The in-process variant (pfd_upstream_area_cell_blocks) runs the identical phases for several
+// blocks that live on the GPUs of ONE process and "gathers" with device copies; it is what the
+// single-GPU test box exercises, and it differs from the RCCL path only in the transport.
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "tiled.h"
+
+struct pfd_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+};
+
+#define NCCLCHK(expr)                                                                       \
+  do {                                                                                      \
+    ncclResult_t r_ = (expr);                                                               \
+    if (r_ != ncclSuccess) {                                                                \
+      pfd_set_error("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); \
+      return PFD_ECOMM;                                                                     \
+    }                                                                                       \
+  } while (0)
+
+extern "C" int pfd_comm_unique_id(void *id_out, size_t len) {
+  if (!id_out || len < sizeof(ncclUniqueId)) {
+    pfd_set_error("pfd_comm_unique_id: buffer must hold %zu bytes", sizeof(ncclUniqueId));
+    return PFD_EINVAL;
+  }
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return PFD_OK;
+}
+
+extern "C" int pfd_comm_create(const void *id, size_t len, int rank, int world, int device, pfd_comm **out) {
+  if (!id || len < sizeof(ncclUniqueId) || !out || world < 1 || rank < 0 || rank >= world) {
+    pfd_set_error("pfd_comm_create: bad arguments");
+    return PFD_EINVAL;
+  }
+  HIPCHK(hipSetDevice(device));
+  pfd_comm *c = new pfd_comm();
+  c->rank = rank;
+  c->world = world;
+  c->device = device;
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
+  if (r != ncclSuccess) {
+    pfd_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    delete c;
+    return PFD_ECOMM;
+  }
+  *out = c;
+  return PFD_OK;
+}
+
+extern "C" int pfd_comm_destroy(pfd_comm *c) {
+  if (c) {
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+  }
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// interface graph.  Node id = (block*2 + side)*ncol + col stands for the halo cell `col` on
+// `side` (0 top, 1 bottom) of `block`; rec = the gathered records, 4*ncol words per block.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_iface_build(const u32 *__restrict__ rec, u32 nblocks, u32 ncol,
+                                                     u32 *__restrict__ T, u32 *__restrict__ J, u64 *ctrl) {
+  const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= nblocks * 2 * ncol) return;
+  const u32 col = id % ncol, bs = id / ncol, side = bs & 1, blk = bs >> 1;
+  T[id] = rec[(size_t)blk * 4 * ncol + side * ncol + col];  // L: flow leaving `blk` through this cell
+  u32 j = id | XDONE;
+  // the cell belongs to the neighbouring block, where it is a boundary-row cell on the other side
+  const int owner = (int)blk + (side ? 1 : -1);
+  if (owner >= 0 && owner < (int)nblocks) {
+    const u32 s = rec[(size_t)owner * 4 * ncol + (2 + (1 - side)) * ncol + col];  // where that flow leaves `owner`
+    if (s != NONE32) j = ((u32)owner * 2 + ((s & ENC_SIDE1) ? 1u : 0u)) * ncol + (s & ENC_COL);
+  }
+  J[id] = j;
+  if (!(j & XDONE)) {
+    if (__hip_atomic_load(&ctrl[T_XACTIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+      __hip_atomic_store(&ctrl[T_XACTIVE], (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// flow entering the own boundary rows: first row <- bottom halo of block-1, last row <- top halo of block+1
+__global__ void __launch_bounds__(256) k_iface_inflow(const u32 *__restrict__ F, u32 nblocks, u32 ncol, u32 blk,
+                                                      u32 *__restrict__ brow_inflow) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncol) return;
+  const u32 side = t / ncol, col = t % ncol;
+  const int src = (int)blk + (side ? 1 : -1);
+  u32 v = 0;
+  if (src >= 0 && src < (int)nblocks) v = F[((u32)src * 2 + (1 - side)) * ncol + col];
+  brow_inflow[t] = v;
+}
+__global__ void k_pack_record(const u32 *__restrict__ haloL, const u32 *__restrict__ brow_sink, u32 ncol,
+                              u32 *__restrict__ rec) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncol) return;
+  rec[t] = haloL[t];
+  rec[2 * ncol + t] = brow_sink[t];
+}
+
+// solve the interface forest from the gathered records (on the handle's device/stream) and
+// leave the inflow of block `blk` in run.brow_inflow
+static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u32 blk) {
+  pfd_raster *h = run.h;
+  const u32 ncol = (u32)h->ncol;
+  const u32 nn = nblocks * 2 * ncol;
+  DevBuf T0, T1, J0, J1;
+  PFDCHK(T0.alloc((size_t)nn * sizeof(u32)));
+  PFDCHK(T1.alloc((size_t)nn * sizeof(u32)));
+  PFDCHK(J0.alloc((size_t)nn * sizeof(u32)));
+  PFDCHK(J1.alloc((size_t)nn * sizeof(u32)));
+  u32 *Tc = T0.as<u32>(), *Tn = T1.as<u32>(), *Jc = J0.as<u32>(), *Jn = J1.as<u32>();
+  pfd_seg_begin(h, "interface_solve");
+  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+  k_iface_build<<<cdiv_u32(nn, 256), 256, 0, h->stream>>>(allrec_dev, nblocks, ncol, Tc, Jc, h->ctrl);
+  KCHK();
+  bool done = false;
+  i64 launches = 1;
+  PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nn, 3, &done, &launches));
+  k_iface_inflow<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(Tc, nblocks, ncol, blk, run.brow_inflow);
+  KCHK();
+  HIPCHK(hipStreamSynchronize(h->stream));
+  pfd_seg_end(h, launches + 1);
+  if (!done) run.coarse_done = false;  // a cycle through several blocks
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-process: all blocks of the raster are handles of THIS process (any devices)
+// ---------------------------------------------------------------------------------------------
+extern "C" int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32_t **outs, int memspace) {
+  if (!hs || !outs || nblocks < 1) {
+    pfd_set_error("pfd_upstream_area_cell_blocks: bad arguments");
+    return PFD_EINVAL;
+  }
+  const i64 ncol = hs[0]->ncol;
+  for (int b = 0; b < nblocks; ++b) {
+    if (!hs[b] || !outs[b] || hs[b]->ncol != ncol || hs[b]->halo_top != (b > 0) ||
+        hs[b]->halo_bot != (b + 1 < nblocks)) {
+      pfd_set_error("pfd_upstream_area_cell_blocks: block %d must have %d top / %d bottom halo rows and %lld columns",
+                    b, b > 0, b + 1 < nblocks, (long long)ncol);
+      return PFD_EINVAL;
+    }
+  }
+  std::vector<TiledRun> runs(nblocks);
+  std::vector<OutArg> o(nblocks);
+  const size_t recw = 4 * (size_t)ncol;
+  std::vector<u32> allrec_host((size_t)nblocks * recw);
+  for (int b = 0; b < nblocks; ++b) {  // phase A on every block
+    pfd_raster *h = hs[b];
+    PFDCHK(pfd_check_handle(h));
+    pfd_seg_clear(h);
+    PFDCHK(o[b].bind(outs[b], (size_t)h->own_rows * ncol * sizeof(i32), memspace));
+    PFDCHK(runs[b].init(h, (i32 *)o[b].dev));
+    if (!runs[b].supported) {
+      pfd_set_error("pfd_upstream_area_cell_blocks: block %d is too large for the tiled engine", b);
+      return PFD_EUNSUPPORTED;
+    }
+    PFDCHK(runs[b].phase_a());
+    DevBuf rec;
+    PFDCHK(rec.alloc(recw * sizeof(u32)));
+    k_pack_record<<<cdiv_u32(2 * (u32)ncol, 256), 256, 0, h->stream>>>(runs[b].haloL, runs[b].brow_sink, (u32)ncol,
+                                                                     rec.as<u32>());
+    KCHK();
+    HIPCHK(hipMemcpyAsync(allrec_host.data() + (size_t)b * recw, rec.p, recw * sizeof(u32), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  int all_complete = 1;
+  for (int b = 0; b < nblocks; ++b) {  // "all-gather" = every block gets all records; then phase B
+    pfd_raster *h = hs[b];
+    PFDCHK(pfd_check_handle(h));
+    if (nblocks > 1) {
+      DevBuf allrec;
+      PFDCHK(allrec.alloc(allrec_host.size() * sizeof(u32)));
+      HIPCHK(hipMemcpyAsync(allrec.p, allrec_host.data(), allrec_host.size() * sizeof(u32), hipMemcpyHostToDevice,
+                            h->stream));
+      PFDCHK(interface_solve(runs[b], allrec.as<u32>(), (u32)nblocks, (u32)b));
+    }
+    int complete = 0;
+    PFDCHK(runs[b].phase_b(&complete));
+    all_complete &= complete;
+    PFDCHK(o[b].finish(h->stream));
+  }
+  if (!all_complete) {
+    pfd_set_error("the raster holds cells that never reach a pit (cycles); the multi-block path requires a "
+                  "valid flow direction raster (FlwdirRaster.isvalid)");
+    return PFD_EUNSUPPORTED;
+  }
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one process per GPU: collective call, every rank passes its own block
+// ---------------------------------------------------------------------------------------------
+extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!comm || !out) {
+    pfd_set_error("pfd_upstream_area_cell_dist: bad arguments");
+    return PFD_EINVAL;
+  }
+  const int rank = comm->rank, world = comm->world;
+  if (h->halo_top != (rank > 0) || h->halo_bot != (rank + 1 < world)) {
+    pfd_set_error("pfd_upstream_area_cell_dist: rank %d of %d must hold %d top / %d bottom halo rows", rank, world,
+                  rank > 0, rank + 1 < world);
+    return PFD_EINVAL;
+  }
+  const u32 ncol = (u32)h->ncol;
+  const size_t recw = 4 * (size_t)ncol;
+  pfd_seg_clear(h);
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->own_rows * ncol * sizeof(i32), memspace));
+  TiledRun run;
+  PFDCHK(run.init(h, (i32 *)o.dev));
+  if (!run.supported) {
+    pfd_set_error("pfd_upstream_area_cell_dist: the block is too large for the tiled engine");
+    return PFD_EUNSUPPORTED;
+  }
+  PFDCHK(run.phase_a());
+  if (world > 1) {
+    DevBuf rec, allrec;
+    PFDCHK(rec.alloc(recw * sizeof(u32)));
+    PFDCHK(allrec.alloc((size_t)world * recw * sizeof(u32)));
+    pfd_seg_begin(h, "allgather");
+    k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(run.haloL, run.brow_sink, ncol, rec.as<u32>());
+    KCHK();
+    NCCLCHK(ncclAllGather(rec.p, allrec.p, recw, ncclUint32, comm->comm, h->stream));
+    pfd_seg_end(h, 2);
+    PFDCHK(interface_solve(run, allrec.as<u32>(), (u32)world, (u32)rank));
+  }
+  int complete = 0;
+  PFDCHK(run.phase_b(&complete));
+  PFDCHK(o.finish(h->stream));
+  // every rank must agree on success: a cycle anywhere invalidates downstream blocks as well
+  int ok_local = complete ? 1 : 0, ok_all = ok_local;
+  if (world > 1) {
+    DevBuf flag;
+    PFDCHK(flag.alloc(sizeof(int)));
+    HIPCHK(hipMemcpyAsync(flag.p, &ok_local, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(ncclAllReduce(flag.p, flag.p, 1, ncclInt32, ncclMin, comm->comm, h->stream));
+    HIPCHK(hipMemcpyAsync(&ok_all, flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  if (!ok_all) {
+    pfd_set_error("the raster holds cells that never reach a pit (cycles); the multi-GPU path requires a "
+                  "valid flow direction raster (FlwdirRaster.isvalid)");
+    return PFD_EUNSUPPORTED;
+  }
+  return PFD_OK;
+}

@@ -22,7 +22,7 @@ enum { C_NVALID = 0, C_NPITS = 1, C_BAD = 2, C_TAIL = 3, C_DONE = 4, C_AUX = 5 }
 // and pits, flags values outside the D8 alphabet (core_d8._all, pyflwdir/core_d8.py:19).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_normalise(const u8 *__restrict__ d8, Geo g, u8 *__restrict__ ncode,
-                                                   u64 *__restrict__ ctrl) {
+                                                   u64 *__restrict__ ctrl, u32 row_first, u32 row_last) {
   // one block = a 64-column x 64-row patch, 4 rows per pass
   const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
   u32 valid = 0, pit = 0, bad = 0;
@@ -34,6 +34,11 @@ __global__ void __launch_bounds__(256) k_normalise(const u8 *__restrict__ d8, Ge
       u32 out = code;
       if (code == D8_MV) {
         out = D8_MV;
+      } else if (r < row_first || r > row_last) {
+        // halo row of a row block: the cell belongs to the neighbouring block; here it is a
+        // weightless sink that collects the flow leaving this block
+        out = ((code & (code - 1)) == 0u || code == 255u) ? D8_HALO : D8_MV;
+        if (out == D8_MV) ++bad;
       } else if (code == 0u || code == 255u) {
         out = 0;
         ++valid;
@@ -187,7 +192,8 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
   }
   HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
   dim3 grid(cdiv_u32((u64)h->ncol, 64), cdiv_u32((u64)h->nrow, 64));
-  k_normalise<<<grid, 256, 0, h->stream>>>(d8_dev, h->geo, h->ncode, h->ctrl);
+  k_normalise<<<grid, 256, 0, h->stream>>>(d8_dev, h->geo, h->ncode, h->ctrl, (u32)h->halo_top,
+                                           (u32)(h->halo_top + h->own_rows - 1));
   KCHK();
   u64 c[48];
   HIPCHK(hipMemcpyAsync(c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
@@ -202,7 +208,7 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
     h->n_valid += (i64)c[16 + k];
     h->n_pits += (i64)c[32 + k];
   }
-  if (h->n_pits == 0) {
+  if (h->n_pits == 0 && !(h->halo_top || h->halo_bot)) {
     pfd_set_error("Invalid FlwdirRaster: no pits found");
     return PFD_ENOPITS;
   }
@@ -211,8 +217,18 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
   return PFD_OK;
 }
 
+int pfd_require_whole(pfd_raster *h, const char *what) {
+  if (h->halo_top || h->halo_bot) {
+    pfd_set_error("%s is not available on a row-block handle (multi-GPU blocks only support "
+                  "pfd_upstream_area_cell_blocks / _dist)", what);
+    return PFD_EUNSUPPORTED;
+  }
+  return PFD_OK;
+}
+
 int pfd_ensure_pits(pfd_raster *h) {
   if (h->pits_ready) return PFD_OK;
+  PFDCHK(pfd_require_whole(h, "the pit list"));
   PFDCHK(alloc_pits(h));
   h->bytes_held += (size_t)h->n_pits * sizeof(u32);
   PFDCHK(compact_pits(h));
@@ -300,6 +316,7 @@ __global__ void __launch_bounds__(256) k_upstream_count(const u8 *__restrict__ n
 
 extern "C" int pfd_upstream_count(pfd_raster *h, const uint8_t *mask, int8_t *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_require_whole(h, "upstream_count"));
   if (!out) {
     pfd_set_error("pfd_upstream_count: NULL out");
     return PFD_EINVAL;

@@ -36,32 +36,17 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "tiled.h"
 
-#define TS 64               // tile edge (cells)
-#define TCELLS (TS * TS)    // 4096
-#define HW (TS + 2)         // halo'd row pitch in LDS
-#define PSL 256             // perimeter slots per tile (252 used)
-#define NPERIM (2 * TS + 2 * (TS - 2))
-#define NONE32 0xFFFFFFFFu
-#define PDONE 0x8000u       // in-tile pointer saturated at its root
-#define XDONE 0x80000000u   // coarse pointer saturated
-#define MAXROUNDS_TILE 13   // 2^13 > 4096 cells: more rounds mean a cycle
-#define CPT (TCELLS / 256)  // cells per thread
-
-enum { T_PROC = 8, T_NEXITS = 9, T_XACTIVE = 10 };  // ctrl slots (u64)
-
-struct TileArgs {
-  const u8 *ncode;
-  u32 nrow, ncol, ntr, ntc;
-  u32 *xid;       // [nslots] dense id of the exit sitting on this perimeter slot, NONE32 if none
-  u32 *eT;        // [nexits] local count of an exit (dense exit id)
-  u32 *etgt;      // [nexits] global perimeter slot the exit drains into
-  u32 *elink;     // [nslots] perimeter slot (0..251) of the exit an entry's path reaches
-  u32 *inflow;    // [nslots] sum of the totals of the exits draining into this slot
-  u64 *ctrl;
-  i32 *out;
-  int ablate;     // profiling knob (env PFD_TILE_ABLATE): bit0 skip doubling, bit4 cycle stamps
-};
+#define TSTAMP(slot)                                                                                        \
+  if (a.ablate & 16) {                                                                                      \
+    __syncthreads();                                                                                        \
+    if (tid == 0) {                                                                                         \
+      const u64 t_ = __builtin_readcyclecounter();                                                          \
+      atomicAdd((unsigned long long *)&a.ctrl[(FINAL ? 40 : 24) + slot], (unsigned long long)(t_ - tprev)); \
+      tprev = t_;                                                                                           \
+    }                                                                                                       \
+  }
 
 __device__ __forceinline__ int pslot(int lr, int lc) {
   if (lr == 0) return lc;
@@ -86,21 +71,12 @@ __device__ __forceinline__ void pslot_inv(int p, int *lr, int *lc) {
   }
 }
 
-#define TSTAMP(slot)                                                                                        \
-  if (a.ablate & 16) {                                                                                      \
-    __syncthreads();                                                                                        \
-    if (tid == 0) {                                                                                         \
-      const u64 t_ = __builtin_readcyclecounter();                                                          \
-      atomicAdd((unsigned long long *)&a.ctrl[(FINAL ? 40 : 24) + slot], (unsigned long long)(t_ - tprev)); \
-      tprev = t_;                                                                                           \
-    }                                                                                                       \
-  }
-
 template <bool FINAL>
 __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   __shared__ u32 A[TCELLS];       // running subtree count of the cell
   __shared__ uint16_t P[TCELLS];  // 2^k-th ancestor (local index) | PDONE once saturated
   __shared__ u8 code[HW * HW];    // normalised codes with a 1-cell halo
+  __shared__ u32 s_xid[PSL];      // dense exit id per perimeter slot (phase 1)
   __shared__ u32 s_proc, s_exits, s_xbase;
   u64 tprev = __builtin_readcyclecounter();
   const u32 tid = threadIdx.x;
@@ -141,13 +117,19 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       const u32 l = tid + 256u * j;
       const int lr = l >> 6, lc = l & 63;
       const u32 c = code[(lr + 1) * HW + lc + 1];
-      u32 p = l | PDONE;  // nodata, pit, or flow leaves the tile: the cell is its own root
+      u32 p = l | PDONE;  // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
       if (d8_is_dir(c)) {
         const int k = d8_slot(c);
         const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
         if ((unsigned)nr < TS && (unsigned)nc < TS) p = (u32)(nr * TS + nc);
       }
-      A[l] = (c != D8_MV) ? 1u : 0u;
+      u32 w = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
+      if (FINAL && w) {  // flow entering this row block from the neighbouring GPUs
+        const u32 gr = (u32)r0 + (u32)lr, gc = (u32)c0 + (u32)lc;
+        if (gr == a.row_first) w += a.brow_inflow[gc];
+        if (gr == a.row_last) w += a.brow_inflow[a.ncol + gc];
+      }
+      A[l] = w;
       P[l] = (uint16_t)p;
     }
     if (FINAL) {
@@ -172,7 +154,8 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     const u32 p = P[l];
     y[j] = p & 0xFFFu;
     if (!(p & PDONE)) live |= 1u << j;
-    nvalid += code[((l >> 6) + 1) * HW + (l & 63) + 1] != D8_MV;
+    const u32 c = code[((l >> 6) + 1) * HW + (l & 63) + 1];
+    nvalid += (c != D8_MV && c != D8_HALO);
   }
   if (!(a.ablate & 1)) {
     for (int round = 0; round < MAXROUNDS_TILE; ++round) {
@@ -205,15 +188,15 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   __syncthreads();
 
   if (FINAL) {
-    // ---- write the finished tile, one 256-B row segment per wave instruction ---------------
+    // ---- write the owned rows of the finished tile, one 256-B row segment per wave ----------
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
       const u32 l = tid + 256u * j;
       const int lr = l >> 6, lc = l & 63;
       const i64 gr = r0 + lr, gc = c0 + lc;
-      if (gr < (i64)a.nrow && gc < (i64)a.ncol) {
+      if (gr >= (i64)a.row_first && gr <= (i64)a.row_last && gc < (i64)a.ncol) {
         const u32 c = code[(lr + 1) * HW + lc + 1];
-        a.out[(size_t)gr * a.ncol + (size_t)gc] = (c == D8_MV) ? -9999 : (i32)A[l];
+        a.out[(size_t)(gr - a.row_first) * a.ncol + (size_t)gc] = (c == D8_MV) ? -9999 : (i32)A[l];
       }
     }
     if (tid == 0 && s_proc) atomicAdd((unsigned long long *)&a.ctrl[T_PROC], (unsigned long long)s_proc);
@@ -222,40 +205,31 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   }
 
   // ---- perimeter records for the coarse graph ------------------------------------------------
-  u32 xt = 0, tgt = NONE32, link = NONE32, xrank = 0;
+  u32 xt = 0, tgt = NONE32, xrank = 0;
+  bool entry = false;
+  int plr = 0, plc = 0;
   if (tid < NPERIM) {
-    int lr, lc;
-    pslot_inv((int)tid, &lr, &lc);
-    const u32 c = code[(lr + 1) * HW + lc + 1];
-    if (c != D8_MV) {
+    pslot_inv((int)tid, &plr, &plc);
+    const u32 c = code[(plr + 1) * HW + plc + 1];
+    if (c != D8_MV && c != D8_HALO) {
       if (d8_is_dir(c)) {  // exit?
         const int k = d8_slot(c);
-        const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
+        const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
         if ((unsigned)nr >= TS || (unsigned)nc >= TS) {
           const i64 gr = r0 + nr, gc = c0 + nc;  // inside the raster and valid (normalised codes)
           const u32 ttile = (u32)(gr >> 6) * a.ntc + (u32)(gc >> 6);
           tgt = ttile * PSL + (u32)pslot((int)(gr & 63), (int)(gc & 63));
-          xt = A[lr * TS + lc];
+          xt = A[plr * TS + plc];
           xrank = atomicAdd(&s_exits, 1u);
         }
       }
-      // entry?  (a neighbour outside the tile drains into this cell)
-      bool entry = false;
+    }
+    if (c != D8_MV) {  // entry?  (a neighbour outside the tile drains into this cell; may be a halo sink)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
+        const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
         if (((unsigned)nr >= TS || (unsigned)nc >= TS) && code[(nr + 1) * HW + nc + 1] == (1u << ((k + 4) & 7)))
           entry = true;
-      }
-      if (entry) {  // the root of the in-tile path is an exit or a pit
-        const u32 root = P[lr * TS + lc] & 0xFFFu;
-        const int rr = root >> 6, rc = root & 63;
-        const u32 cr = code[(rr + 1) * HW + rc + 1];
-        if (d8_is_dir(cr)) {
-          const int k = d8_slot(cr);
-          const int nr = rr + d8_dr(k), nc = rc + d8_dc(k);
-          if ((unsigned)nr >= TS || (unsigned)nc >= TS) link = (u32)pslot(rr, rc);
-        }
       }
     }
   }
@@ -266,15 +240,56 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   }
   __syncthreads();
   if (tid < PSL) {
-    const size_t slot = (size_t)tile * PSL + tid;
     u32 id = NONE32;
     if (tgt != NONE32) {
       id = s_xbase + xrank;
       a.eT[id] = xt;
       a.etgt[id] = tgt;
     }
-    a.xid[slot] = id;
-    a.elink[slot] = link;
+    s_xid[tid] = id;
+    a.xid[(size_t)tile * PSL + tid] = id;
+  }
+  __syncthreads();
+  // where does the in-tile path of a cell end?  -> exit id, halo sink (row block), or nothing
+  auto path_end = [&](u32 l) -> u32 {
+    const u32 root = P[l] & 0xFFFu;
+    const int rr = root >> 6, rc = root & 63;
+    const u32 cr = code[(rr + 1) * HW + rc + 1];
+    if (cr == D8_HALO) return ENC_SINK | (((u32)r0 + (u32)rr > a.row_last) ? ENC_SIDE1 : 0u) | ((u32)c0 + (u32)rc);
+    if (d8_is_dir(cr)) {
+      const int k = d8_slot(cr);
+      const int nr = rr + d8_dr(k), nc = rc + d8_dc(k);
+      if ((unsigned)nr >= TS || (unsigned)nc >= TS) return s_xid[pslot(rr, rc)];
+    }
+    return NONE32;
+  };
+  if (tid < PSL) {
+    u32 link = NONE32, esink = NONE32;
+    if (entry) {
+      const u32 e = path_end((u32)(plr * TS + plc));
+      if (e != NONE32 && (e & ENC_SINK))
+        esink = e;
+      else if (e != NONE32)
+        link = e;  // dense id of the exit the entry's path reaches
+    }
+    a.elink[(size_t)tile * PSL + tid] = link;
+    if (tr == 0) a.esink[(size_t)tc * PSL + tid] = esink;
+    if (tr == a.ntr - 1 && a.ntr > 1) a.esink[((size_t)a.ntc + tc) * PSL + tid] = esink;
+  }
+  // row-block bookkeeping: flow collected by the halo sinks, first hop of the boundary rows
+  if (a.row_first > 0 || a.row_last + 1 < a.nrow) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const u32 l = tid + 256u * j;
+      const u32 gr = (u32)r0 + (l >> 6), gc = (u32)c0 + (l & 63);
+      if (gr >= a.nrow || gc >= a.ncol) continue;
+      const u32 c = code[((l >> 6) + 1) * HW + (l & 63) + 1];
+      if (c == D8_HALO) a.haloA[(gr > a.row_last ? a.ncol : 0u) + gc] = A[l];
+      if (c != D8_MV && c != D8_HALO) {
+        if (gr == a.row_first) a.brow_first[gc] = path_end(l);
+        if (gr == a.row_last) a.brow_first[a.ncol + gc] = path_end(l);
+      }
+    }
   }
   TSTAMP(3)
 }
@@ -294,15 +309,14 @@ __device__ __forceinline__ void flag_active(u64 *ctrl) {
 }
 
 __global__ void __launch_bounds__(256) k_coarse_link(const u32 *__restrict__ etgt, const u32 *__restrict__ elink,
-                                                     const u32 *__restrict__ xid, u32 *__restrict__ J, u32 nexits,
+                                                     u32 *__restrict__ J, u32 *__restrict__ Jlink, u32 nexits,
                                                      u64 *ctrl) {
   const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nexits) return;
-  const u32 tgt = etgt[e];
-  const u32 l = elink[tgt];
-  u32 j = e | XDONE;
-  if (l != NONE32) j = xid[(tgt & ~(u32)(PSL - 1)) + l];
+  const u32 l = elink[etgt[e]];
+  const u32 j = (l != NONE32) ? l : (e | XDONE);
   J[e] = j;
+  Jlink[e] = j;
   if (!(j & XDONE)) flag_active(ctrl);
 }
 
@@ -336,29 +350,133 @@ __global__ void __launch_bounds__(256) k_coarse_inflow(const u32 *__restrict__ e
   if (e < nexits) atomicAdd(&inflow[etgt[e]], T[e]);
 }
 
-// returns PFD_OK and *complete = 1 when every valid cell was finalised (no cycles)
-int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
-  const u32 ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
-  const size_t nslots = (size_t)ntr * ntc * PSL;
-  *complete = 0;
-  if (nslots >= 0x7FFFFFFFull || ntr > 65535u) return PFD_OK;  // slot ids are 31 bit: level engine
+// generic pointer doubling driver on (T, J) ping-pong buffers; rounds are idempotent once every
+// pointer is saturated, so they are issued in batches and the "still active" flag is read only
+// between batches (one host round trip per batch).  On return *Tc / *Jc hold the result.
+int pfd_doubling_rounds(pfd_raster *h, u32 **Tc, u32 **Tn, u32 **Jc, u32 **Jn, u32 n, int first_batch,
+                        bool *done, i64 *launches) {
+  const u32 grid = cdiv_u32(n, 256);
+  *done = false;
+  int batch = first_batch;
+  for (int rounds = 0; rounds < 40 && !*done;) {
+    for (int b = 0; b < batch; ++b, ++rounds) {
+      k_coarse_prep<<<grid, 256, 0, h->stream>>>(*Tc, *Tn, n, h->ctrl);
+      k_coarse_round<<<grid, 256, 0, h->stream>>>(*Tc, *Tn, *Jc, *Jn, n, h->ctrl);
+      *launches += 2;
+      std::swap(*Tc, *Tn);
+      std::swap(*Jc, *Jn);
+    }
+    KCHK();
+    u64 active = 0;
+    HIPCHK(hipMemcpyAsync(&active, h->ctrl + T_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *done = active == 0;
+    batch = 2;
+  }
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-block (multi-GPU) helpers
+// ---------------------------------------------------------------------------------------------
+// flow collected by a halo sink = what reached it inside its tile (haloA) + the inflow of the
+// tile entries whose in-tile path ends on it
+__global__ void __launch_bounds__(256) k_halo_collect(const u32 *__restrict__ esink, const u32 *__restrict__ inflow,
+                                                      u32 ntc, u32 ntr, u32 ncol, u32 *__restrict__ haloL, u32 n) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const u32 e = esink[t];
+  if (e == NONE32) return;
+  // region 0 = tile row 0, region 1 = last tile row
+  const size_t slot = (t < ntc * PSL) ? (size_t)t : (size_t)(ntr - 1) * ntc * PSL + (t - ntc * PSL);
+  const u32 v = inflow[slot];
+  if (v) atomicAdd(&haloL[((e & ENC_SIDE1) ? ncol : 0u) + (e & ENC_COL)], v);
+}
+// where does the flow entering at a boundary-row cell leave the block?  (halo sink or nowhere)
+__global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, const u32 *__restrict__ Jfinal,
+                                                   const u32 *__restrict__ etgt, const u32 *__restrict__ esink,
+                                                   u32 ntc, u32 ntr, u32 ncol, u32 *__restrict__ brow_sink) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncol) return;
+  u32 f = brow_first[t];
+  if (f != NONE32 && !(f & ENC_SINK)) {  // an exit id: jump to the last exit of its path
+    const u32 last = Jfinal[f] & ~XDONE;
+    const u32 slot = etgt[last];
+    const u32 tile = slot / PSL, tr = tile / ntc, tc = tile % ntc;
+    f = NONE32;
+    if (tr == 0)
+      f = esink[(size_t)tc * PSL + (slot & (PSL - 1))];
+    else if (tr == ntr - 1)
+      f = esink[((size_t)ntc + tc) * PSL + (slot & (PSL - 1))];
+  }
+  brow_sink[t] = f;
+}
+// push the flow that enters at the boundary rows along the coarse paths: every exit on the path
+// delivers that much more to the tile entry it drains into
+__global__ void __launch_bounds__(256) k_brow_push(const u32 *__restrict__ brow_first, const u32 *__restrict__ brow_inflow,
+                                                   const u32 *__restrict__ Jlink, const u32 *__restrict__ etgt,
+                                                   u32 ncol, u32 *__restrict__ inflow) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncol) return;
+  const u32 v = brow_inflow[t];
+  u32 e = brow_first[t];
+  if (!v || e == NONE32 || (e & ENC_SINK)) return;
+  for (;;) {
+    atomicAdd(&inflow[etgt[e]], v);
+    const u32 j = Jlink[e];
+    if (j & XDONE) break;
+    e = j;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------
+int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
+  h = hh;
+  ntr = cdiv_u32((u64)h->nrow, TS);
+  ntc = cdiv_u32((u64)h->ncol, TS);
+  nslots = (size_t)ntr * ntc * PSL;
+  supported = !(nslots >= 0x3FFFFFFFull || ntr > 65535u || (u64)h->ncol >= ENC_SIDE1);
+  if (!supported) return PFD_OK;  // ids are 30 bit: such rasters go through the level engine
   const size_t xcap = (size_t)ntr * ntc * NPERIM;  // upper bound of the number of exits
-  DevBuf T0, T1, J0, J1, etgt, xid, elink, inflow;
+  const size_t nb = 2 * (size_t)h->ncol;
   PFDCHK(T0.alloc(xcap * sizeof(u32)));
   PFDCHK(T1.alloc(xcap * sizeof(u32)));
   PFDCHK(J0.alloc(xcap * sizeof(u32)));
   PFDCHK(J1.alloc(xcap * sizeof(u32)));
+  PFDCHK(Jlink.alloc(xcap * sizeof(u32)));
   PFDCHK(etgt.alloc(xcap * sizeof(u32)));
   PFDCHK(xid.alloc(nslots * sizeof(u32)));
   PFDCHK(elink.alloc(nslots * sizeof(u32)));
   PFDCHK(inflow.alloc(nslots * sizeof(u32)));
-  TileArgs a{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, xid.as<u32>(), T0.as<u32>(), etgt.as<u32>(),
-             elink.as<u32>(), inflow.as<u32>(), h->ctrl, out_dev, 0};
+  PFDCHK(esink.alloc(2 * (size_t)ntc * PSL * sizeof(u32)));
+  PFDCHK(bnd.alloc(5 * nb * sizeof(u32)));  // brow_first | haloA | haloL | brow_sink | brow_inflow
+  u32 *b = bnd.as<u32>();
+  brow_first = b;
+  haloA = b + nb;
+  haloL = b + 2 * nb;
+  brow_sink = b + 3 * nb;
+  brow_inflow = b + 4 * nb;
+  a = TileArgs{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
+               (u32)(h->halo_top + h->own_rows - 1), xid.as<u32>(), T0.as<u32>(), etgt.as<u32>(),
+               elink.as<u32>(), inflow.as<u32>(), esink.as<u32>(), brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
+  is_block = h->halo_top || h->halo_bot;
+  return PFD_OK;
+}
+
+// phase A: local tile pass + coarse solve with zero flow from other row blocks
+int TiledRun::phase_a() {
+  const size_t nb = 2 * (size_t)h->ncol;
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 56 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(inflow.p, 0, nslots * sizeof(u32), h->stream));
+  // brow_first / brow_sink = NONE, haloA / brow_inflow = 0
+  HIPCHK(hipMemsetAsync(brow_first, 0xFF, nb * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(haloA, 0, 2 * nb * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(brow_sink, 0xFF, nb * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));
   const dim3 grid(ntc, ntr);
-
   pfd_seg_begin(h, "tile_local");
   k_tile<false><<<grid, 256, 0, h->stream>>>(a);
   KCHK();
@@ -368,43 +486,52 @@ int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
   u64 c[3];
   HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  const u32 nexits = (u32)c[1];
+  nexits = (u32)c[1];
   i64 launches = 0;
-  bool coarse_done = true;
-  u32 *Tc = T0.as<u32>(), *Tn = T1.as<u32>(), *Jc = J0.as<u32>(), *Jn = J1.as<u32>();
+  coarse_done = true;
+  Tc = T0.as<u32>(), Tn = T1.as<u32>(), Jc = J0.as<u32>(), Jn = J1.as<u32>();
   if (nexits) {
     const u32 egrid = cdiv_u32(nexits, 256);
-    k_coarse_link<<<egrid, 256, 0, h->stream>>>(etgt.as<u32>(), elink.as<u32>(), xid.as<u32>(), Jc, nexits, h->ctrl);
+    k_coarse_link<<<egrid, 256, 0, h->stream>>>(etgt.as<u32>(), elink.as<u32>(), Jc, Jlink.as<u32>(), nexits, h->ctrl);
     ++launches;
-    // rounds are idempotent once every pointer is saturated: issue them in batches and look at
-    // the "still active" flag only between batches (one host round trip per batch)
-    coarse_done = false;
     int batch = 1;
     for (u32 span = 1; span < ntr + ntc; span <<= 1) ++batch;  // ~log2 of a typical path (in tiles)
-    for (int rounds = 0; rounds < 40 && !coarse_done;) {
-      for (int b = 0; b < batch; ++b, ++rounds) {
-        k_coarse_prep<<<egrid, 256, 0, h->stream>>>(Tc, Tn, nexits, h->ctrl);
-        k_coarse_round<<<egrid, 256, 0, h->stream>>>(Tc, Tn, Jc, Jn, nexits, h->ctrl);
-        launches += 2;
-        std::swap(Tc, Tn);
-        std::swap(Jc, Jn);
-      }
-      u64 active = 0;
-      HIPCHK(hipMemcpyAsync(&active, h->ctrl + T_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      coarse_done = active == 0;
-      batch = 2;
-    }
+    PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nexits, batch, &coarse_done, &launches));
     k_coarse_inflow<<<egrid, 256, 0, h->stream>>>(etgt.as<u32>(), Tc, inflow.as<u32>(), nexits);
     ++launches;
     KCHK();
   }
+  if (is_block) {  // what leaves through the halo rows, and where boundary-row inflow would leave
+    HIPCHK(hipMemcpyAsync(haloL, haloA, nb * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
+    const u32 ne = (ntr > 1 ? 2u : 1u) * ntc * PSL;
+    k_halo_collect<<<cdiv_u32(ne, 256), 256, 0, h->stream>>>(esink.as<u32>(), inflow.as<u32>(), ntc, ntr, (u32)h->ncol,
+                                                            haloL, ne);
+    k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, Jc, etgt.as<u32>(), esink.as<u32>(), ntc, ntr,
+                                                         (u32)h->ncol, brow_sink);
+    launches += 3;
+    KCHK();
+  }
   pfd_seg_end(h, launches);
+  return PFD_OK;
+}
 
+// phase B: add the flow arriving from the other row blocks (brow_inflow, already on the device),
+// final tile pass, completeness check
+int TiledRun::phase_b(int *complete) {
+  const size_t nb = 2 * (size_t)h->ncol;
+  if (is_block && nexits) {
+    pfd_seg_begin(h, "block_inflow");
+    k_brow_push<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, Jlink.as<u32>(), etgt.as<u32>(),
+                                                         (u32)h->ncol, inflow.as<u32>());
+    KCHK();
+    pfd_seg_end(h, 1);
+  }
+  const dim3 grid(ntc, ntr);
   pfd_seg_begin(h, "tile_final");
   k_tile<true><<<grid, 256, 0, h->stream>>>(a);
   KCHK();
   pfd_seg_end(h, 1);
+  u64 c[3];
   HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (a.ablate & 16) {
@@ -420,4 +547,14 @@ int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
   // T_PROC counted both tile passes
   *complete = coarse_done && (c[0] == 2ull * (u64)h->n_valid);
   return PFD_OK;
+}
+
+// returns PFD_OK and *complete = 1 when every valid cell was finalised (no cycles)
+int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
+  *complete = 0;
+  TiledRun run;
+  PFDCHK(run.init(h, out_dev));
+  if (!run.supported) return PFD_OK;
+  PFDCHK(run.phase_a());
+  return run.phase_b(complete);
 }
