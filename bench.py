@@ -37,7 +37,8 @@ PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # split over the phases of the level engine as documented in DESIGN.md §Roofline
 B_ALG_TOTAL = 29.0
 B_ALG_PHASE = {"order_cells": 8.0, "init": 4.0, "sweep_count_up": 17.0,
-               "tile_local": 8.0, "tile_exits": 4.0, "tile_final": 17.0}
+               "tile_local": 8.0, "tile_exits": 4.0, "tile_final": 17.0, "interface_solve": 4.0, "allgather": 4.0,
+               "block_inflow": 4.0}
 SYNTH = dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0)  # "river" regime: max_rank = nrow-1
 
 
@@ -79,6 +80,74 @@ def cpu_baseline(d8_host, rows):
                 host_cpus=os.cpu_count()), upa
 
 
+def run_distributed(a, rank, world, local):
+    """N > 1: one rank per GPU, weak scaling — every rank owns a size x size row block of the
+    (N*size) x size raster (+ one halo row per inner edge), generated directly in its HBM."""
+    import torch
+    import torch.distributed as dist
+
+    from pyflwdir_amd import dist as pdist
+
+    dist.init_process_group(backend="gloo")  # rendezvous / barrier / max-reduce only (CPU, 128-byte id)
+    device = local
+    ncol = a.size
+    nrow_total = a.size * world
+    r0, r1 = rank * a.size, (rank + 1) * a.size
+    top, bot = pdist.halo_of(rank, world)
+    d8_buf = _hip.synth_d8_device(nrow_total, ncol, row0=r0 - top, nrows=(r1 - r0) + top + bot, device=device, **SYNTH)
+    out_buf = _hip.DeviceBuffer(a.size * ncol * 4, device)
+    comm = _hip.Communicator(pdist.exchange_unique_id(rank, world), rank, world, device)
+
+    def step(profile=False):
+        h = _hip.RasterHandle(d8_buf, a.size, ncol, device=device, memspace=_hip.PFD_DEVICE, halo=(top, bot))
+        if profile:
+            h.set_profiling(True)
+        comm.upstream_area_cell(h, out=out_buf, memspace=_hip.PFD_DEVICE)
+        res = (h.last_timing(), h.info()) if profile else None
+        h.close()
+        return res
+
+    for _ in range(a.warmup):
+        step()
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt[0])
+    segs, info = step(profile=True)
+    # cross-rank invariant: the cells draining off the last row of the raster carry every cell
+    stats = torch.tensor([info["n_valid"]], dtype=torch.int64)
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        n = nrow_total * ncol
+        ms_per_step = dt / a.steps * 1e3
+        dom = max(segs, key=lambda s: s["ms"])
+        b_alg = B_ALG_PHASE.get(dom["name"], B_ALG_TOTAL)
+        launches = max(1, dom["launches"])
+        avg_ms = dom["ms"] / launches
+        achieved = (b_alg * (n / world) / launches) / (avg_ms * 1e-3) / 1e9
+        out = dict(metric="Mcells/s upstream_area on D8 raster", value=round(n * a.steps / dt / 1e6, 2), unit="Mcells/s",
+                   n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
+                   config=dict(workload=f"{nrow_total}x{ncol} synthetic D8 (river regime, seed 0) row-tiled over {world} "
+                                        f"GPUs ({a.size} rows each + halo), upstream_area(unit='cell') int32, "
+                                        "decode+local solve+RCCL all-gather+final pass per step",
+                               n_valid=int(stats[0]), parallelism=f"{world} row blocks, 1 all-gather/pass"),
+                   roofline=dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                 frac=round(achieved / PEAK_HBM_GBS, 5), traffic=None, kernel=dom["name"],
+                                 launches=dom["launches"], avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
+                                 per_gpu=True, phases_ms={s["name"]: round(s["ms"], 3) for s in segs}))
+        print(json.dumps(out))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -88,9 +157,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    if world > 1:
-        raise SystemExit("multi-GPU bench path is added with pyflwdir_amd.dist (see DESIGN.md §Multi-GPU)")
-
+    if world > 1 or os.environ.get("PFD_BENCH_FORCE_DIST"):  # the env knob runs the RCCL path with 1 rank
+        return run_distributed(a, rank, world, local)
     device = local
     nrow = ncol = a.size
     n = nrow * ncol

@@ -1,0 +1,160 @@
+"""N > 1 path on CPU: two real processes over the gloo backend.
+
+What can run without a GPU is the host side of the multi-GPU path and the PROTOCOL itself:
+ * row partition / halo bookkeeping (pyflwdir_amd.dist),
+ * the rendezvous of the 128-byte RCCL unique id through torch.distributed,
+ * the block protocol of csrc/dist.hip restated in numpy — local solve with the halo rows as
+   weightless sinks, all-gather of the boundary records {L_top, L_bottom, sink_first, sink_last},
+   redundant interface-forest solve, final local solve with the boundary inflow — with the
+   oracle as the per-block solver and dist.all_gather as the transport.  Its result must equal
+   the oracle on the whole raster.  (The same protocol with the HIP kernels is tested on the GPU
+   box in tests/test_gpu_blocks.py.)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition():
+    from pyflwdir_amd import dist
+
+    assert dist.block_rows(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert dist.block_rows(8, 8) == [(i, i + 1) for i in range(8)]
+    with pytest.raises(ValueError):
+        dist.block_rows(3, 4)
+    assert [dist.halo_of(b, 4) for b in range(4)] == [(0, 1), (1, 1), (1, 1), (1, 0)]
+    assert dist.halo_of(0, 1) == (0, 0)
+    assert [dist.block_slice(10, 3, b) for b in range(3)] == [(0, 5), (3, 8), (6, 10)]
+    rows = dist.block_rows(90000, 8)
+    assert rows[0] == (0, 11250) and rows[-1] == (78750, 90000)
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle as O
+    from pyflwdir_amd import _hip
+    from pyflwdir_amd import dist as pdist
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        # 1) unique-id rendezvous (the id itself comes from RCCL on a GPU box; here a stand-in)
+        _hip.Communicator.unique_id = staticmethod(lambda: bytes(range(128)))
+        uid = pdist.exchange_unique_id(rank, world)
+        assert uid == bytes(range(128))
+
+        # 2) the block protocol, numpy + oracle + gloo all_gather
+        for shape, seed, kw in [((97, 120), 21, dict(tilt=1 << 26, white=2, nodata_pct=0)),
+                                ((64, 75), 22, dict(tilt=100000, white=2, nodata_pct=30))]:
+            d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+            nrow, ncol = d8.shape
+            r0, r1 = pdist.block_rows(nrow, world)[rank]
+            top, bot = pdist.halo_of(rank, world)
+            a, e = pdist.block_slice(nrow, world, rank)
+            blk = d8[a:e].copy()
+            own = np.zeros(blk.shape, bool)
+            own[top:top + (r1 - r0)] = True
+            # halo rows: weightless sinks (valid cells become pits), like k_normalise does
+            halo_valid = (~own) & (blk != 247)
+            blk_local = blk.copy()
+            blk_local[halo_valid] = 0
+            idxs_ds, idxs_pit, _ = O.from_array(blk_local)
+            seq = O.idxs_seq(idxs_ds, idxs_pit)
+            w0 = (own & (blk != 247)).astype(np.int64).ravel()
+            acc0 = O.accuflux(idxs_ds, seq, w0, nodata=-1).reshape(blk.shape)
+            # terminal cell of every cell's path (pointer jumping)
+            end = np.where(idxs_ds >= 0, idxs_ds, np.arange(idxs_ds.size)).astype(np.int64)
+            for _ in range(20):
+                end = end[end]
+            NONE = 0xFFFFFFFF
+            rec = np.zeros(4 * ncol, np.int64)
+            rows_h = ([0] if top else [None]) + ([blk.shape[0] - 1] if bot else [None])
+            for side, hr in enumerate(rows_h):
+                if hr is not None:
+                    rec[side * ncol:(side + 1) * ncol] = np.where(halo_valid[hr], acc0[hr], 0)
+            first, last = top, top + (r1 - r0) - 1
+            for side, br in enumerate((first, last)):
+                for c in range(ncol):
+                    v = NONE
+                    if blk[br, c] != 247:
+                        t = end[br * ncol + c]
+                        tr, tc = divmod(int(t), ncol)
+                        if halo_valid[tr, tc]:
+                            v = (1 << 31) | ((1 << 30) if tr > last else 0) | tc
+                    rec[(2 + side) * ncol + c] = v
+            gathered = [torch.zeros(4 * ncol, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(gathered, torch.from_numpy(rec))
+            allrec = np.stack([g.numpy() for g in gathered])
+            # interface forest, solved redundantly: F(h) = L(h) + sum F(h'') with next(h'') == h
+            nn = world * 2 * ncol
+            L = np.zeros(nn, np.int64)
+            nxt = np.full(nn, -1, np.int64)
+            for b in range(world):
+                for side in range(2):
+                    for c in range(ncol):
+                        nid = (b * 2 + side) * ncol + c
+                        L[nid] = allrec[b, side * ncol + c]
+                        owner = b + (1 if side else -1)
+                        if 0 <= owner < world:
+                            s = int(allrec[owner, (2 + (1 - side)) * ncol + c])
+                            if s != NONE:
+                                nxt[nid] = (owner * 2 + (1 if s & (1 << 30) else 0)) * ncol + (s & 0x3FFFFFFF)
+            F = L.copy()
+            order = []  # topological order by repeated relaxation (tiny graph)
+            indeg = np.zeros(nn, np.int64)
+            for i in range(nn):
+                if nxt[i] >= 0:
+                    indeg[nxt[i]] += 1
+            stack = [i for i in range(nn) if indeg[i] == 0]
+            while stack:
+                i = stack.pop()
+                j = nxt[i]
+                if j >= 0:
+                    F[j] += F[i]
+                    indeg[j] -= 1
+                    if indeg[j] == 0:
+                        stack.append(j)
+            w1 = w0.reshape(blk.shape).copy()
+            if rank > 0:
+                w1[first] += np.where(blk[first] != 247, F[((rank - 1) * 2 + 1) * ncol:((rank - 1) * 2 + 2) * ncol], 0)
+            if rank + 1 < world:
+                w1[last] += np.where(blk[last] != 247, F[((rank + 1) * 2 + 0) * ncol:((rank + 1) * 2 + 1) * ncol], 0)
+            acc1 = O.accuflux(idxs_ds, seq, w1.ravel(), nodata=-1).reshape(blk.shape)[top:top + (r1 - r0)]
+            res = np.where(blk[top:top + (r1 - r0)] == 247, -9999, acc1).astype(np.int32)
+            exp = O.upstream_area_cell(d8)[0][r0:r1]
+            assert np.array_equal(res, exp), f"rank {rank}: block protocol differs from the oracle"
+        # 3) bench-style timing reduction: MAX over ranks
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t[0]) == float(world)
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    for r, p in enumerate(procs):
+        assert p.exitcode == 0, f"rank {r} failed (exit code {p.exitcode})"
+        assert (tmp_path / f"ok{r}").exists()
