@@ -7,6 +7,11 @@
 #define TCELLS (TS * TS)    // 4096
 #define HW (TS + 2)         // halo'd row pitch in LDS
 #define PSL 256             // perimeter slots per tile (252 used)
+#define SG 8                // supertile edge in tiles (supertile = 512 x 512 cells)
+#define SSL (SG * SG * PSL) // slots per supertile (16384)
+#define SSHIFT 14           // log2(SSL)
+#define SDONE 0x8000u       // supertile pointer saturated (local slot ids use 14 bits)
+#define MAXROUNDS_SUPER 15
 #define NPERIM (2 * TS + 2 * (TS - 2))
 #define NONE32 0xFFFFFFFFu
 #define PDONE 0x8000u       // in-tile pointer saturated at its root
@@ -18,16 +23,42 @@
 #define ENC_SIDE1 0x40000000u
 #define ENC_COL 0x3FFFFFFFu
 
-enum { T_PROC = 8, T_NEXITS = 9, T_XACTIVE = 10 };  // ctrl slots (u64)
+enum { T_PROC = 8, T_NEXITS = 9, T_XACTIVE = 10, T_NSUPER = 11, T_SLIVE = 12 };  // ctrl slots (u64)
+
+// slot numbering: [supertile][tile within supertile][perimeter slot] so that the exits of one
+// 8x8-tile supertile are 16384 consecutive ids (the level-2 solve keeps them in LDS)
+__host__ __device__ inline u32 sslot_base(u32 tr, u32 tc, u32 nstc) {
+  return ((((tr >> 3) * nstc + (tc >> 3)) << SSHIFT) | ((((tr & 7) << 3) | (tc & 7)) << 8));
+}
+__host__ __device__ inline void sslot_inv(u32 s, u32 nstc, u32 *tr, u32 *tc, u32 *p) {
+  const u32 st = s >> SSHIFT, tl = (s >> 8) & 63;
+  *tr = (st / nstc) * 8 + (tl >> 3);
+  *tc = (st % nstc) * 8 + (tl & 7);
+  *p = s & 255;
+}
+
+// level-2 (supertile) solve arguments
+struct SuperArgs {
+  u32 nst;          // number of supertiles
+  const u32 *xT, *xtgt, *elink;
+  u32 *xin;         // [nslots] flow entering the supertile at this exit (from other supertiles)
+  u32 *T2;          // [nslots] supertile-local total of the exit
+  u32 *R2;          // [nslots] last exit (slot) of the exit's path inside its supertile
+  u32 *sxid;        // [nslots] dense id of a super-exit (drains into another supertile), else NONE32
+  u32 *sx_slot;     // [nsuper] slot of the super-exit
+  u32 *T3;          // [nsuper] level-3 start value (= T2 of the super-exit)
+  u32 *inflow;      // [nslots] (final pass) flow delivered to the tile entries
+  u64 *ctrl;
+};
 
 struct TileArgs {
   const u8 *ncode;
   u32 nrow, ncol, ntr, ntc;
   u32 row_first, row_last;  // owned rows (inclusive) of the device raster; the rest are halo rows
-  u32 *xid;        // [nslots] dense id of the exit sitting on this perimeter slot, NONE32 if none
-  u32 *eT;         // [nexits] local count of an exit (dense exit id)
-  u32 *etgt;       // [nexits] global perimeter slot the exit drains into
-  u32 *elink;      // [nslots] dense id of the exit an entry's in-tile path reaches, NONE32 if none
+  u32 nstc;        // supertiles per row; slot ids are supertile-major (sslot_base)
+  u32 *xT;         // [nslots] tile-local count of the exit sitting on this perimeter slot
+  u32 *xtgt;       // [nslots] slot the exit drains into, NONE32 if the slot holds no exit
+  u32 *elink;      // [nslots] slot of the exit an entry's in-tile path reaches, NONE32 if none
   u32 *inflow;     // [nslots] sum of the totals of the exits draining into this slot
   u32 *esink;      // [2*ntc*PSL] first/last tile row: halo sink an entry's in-tile path ends on
   u32 *brow_first; // [2*ncol] boundary rows: where the in-tile path of the cell ends (exit id / sink)
@@ -43,7 +74,11 @@ struct TiledRun {
   u32 ntr = 0, ntc = 0, nexits = 0;
   size_t nslots = 0;
   bool supported = false, is_block = false, coarse_done = false;
-  DevBuf T0, T1, J0, J1, Jlink, etgt, xid, elink, inflow, esink, bnd;
+  DevBuf slots, sx, esink, bnd;  // per-slot arrays (8 x nslots), per-super-exit arrays (5 x cap)
+  u32 nst = 0, nstc = 0, nsuper = 0;
+  u32 *xT = nullptr, *xtgt = nullptr, *elink = nullptr, *inflow = nullptr, *xin = nullptr, *T2 = nullptr,
+      *R2 = nullptr, *sxid = nullptr, *sx_slot = nullptr;
+  SuperArgs sa{};
   u32 *brow_first = nullptr, *haloA = nullptr, *haloL = nullptr, *brow_sink = nullptr, *brow_inflow = nullptr;
   u32 *Tc = nullptr, *Tn = nullptr, *Jc = nullptr, *Jn = nullptr;
   TileArgs a{};

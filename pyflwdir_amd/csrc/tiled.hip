@@ -22,10 +22,12 @@
 //                            every cell that drains out of the tile ("exit") and the slot it
 //                            drains into; for every perimeter cell that receives flow from
 //                            outside ("entry") the exit its in-tile path ends at ("link").
-//   phase 2  k_coarse_*      the exits form a forest ~50x smaller than the raster:
-//                            exit e -> link(target(e)).  Same doubling with global atomics
-//                            (ping-pong buffers, one launch per round) gives the TOTAL count
-//                            at every exit and, summed per target, the inflow at every entry.
+//   phase 2  k_super / k_*3  the exits form a forest ~50x smaller than the raster:
+//                            exit e -> link(target(e)).  Solved hierarchically with the same
+//                            doubling: per 8x8-tile supertile in LDS (k_super), then globally
+//                            over the exits that leave their supertile (ping-pong buffers, one
+//                            launch per round), then per supertile again with the flow entering
+//                            it: TOTAL count at every exit, inflow at every tile entry.
 //   phase 3  k_tile<true>    per tile: the doubling again with entries weighted 1 + inflow;
 //                            the finished tile is written to HBM once, coalesced.
 //
@@ -76,12 +78,11 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   __shared__ u32 A[TCELLS];       // running subtree count of the cell
   __shared__ uint16_t P[TCELLS];  // 2^k-th ancestor (local index) | PDONE once saturated
   __shared__ u8 code[HW * HW];    // normalised codes with a 1-cell halo
-  __shared__ u32 s_xid[PSL];      // dense exit id per perimeter slot (phase 1)
-  __shared__ u32 s_proc, s_exits, s_xbase;
+  __shared__ u32 s_proc, s_exits;
   u64 tprev = __builtin_readcyclecounter();
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
-  const u32 tile = tr * a.ntc + tc;
+  const u32 sbase = sslot_base(tr, tc, a.nstc);  // first of this tile's 256 slot ids
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   if (tid == 0) s_proc = s_exits = 0;
 
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       v[k] = inside ? ld : (u8)D8_MV;
     }
     u32 inf = 0;
-    if (FINAL) inf = a.inflow[(size_t)tile * PSL + tid];  // 256 slots per tile: always in bounds
+    if (FINAL) inf = a.inflow[sbase + tid];  // 256 slots per tile: always in bounds
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
       const u32 idx = tid + 256u * k;
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   }
 
   // ---- perimeter records for the coarse graph ------------------------------------------------
-  u32 xt = 0, tgt = NONE32, xrank = 0;
+  u32 xt = 0, tgt = NONE32;
   bool entry = false;
   int plr = 0, plc = 0;
   if (tid < NPERIM) {
@@ -217,10 +218,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
         const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
         if ((unsigned)nr >= TS || (unsigned)nc >= TS) {
           const i64 gr = r0 + nr, gc = c0 + nc;  // inside the raster and valid (normalised codes)
-          const u32 ttile = (u32)(gr >> 6) * a.ntc + (u32)(gc >> 6);
-          tgt = ttile * PSL + (u32)pslot((int)(gr & 63), (int)(gc & 63));
+          tgt = sslot_base((u32)(gr >> 6), (u32)(gc >> 6), a.nstc) + (u32)pslot((int)(gr & 63), (int)(gc & 63));
           xt = A[plr * TS + plc];
-          xrank = atomicAdd(&s_exits, 1u);
+          atomicAdd(&s_exits, 1u);
         }
       }
     }
@@ -234,23 +234,11 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     }
   }
   __syncthreads();
-  if (tid == 0) {  // reserve a dense id range for this tile's exits
-    s_xbase = s_exits ? (u32)atomicAdd((unsigned long long *)&a.ctrl[T_NEXITS], (unsigned long long)s_exits) : 0u;
+  if (tid == 0) {
+    if (s_exits) atomicAdd((unsigned long long *)&a.ctrl[T_NEXITS], (unsigned long long)s_exits);
     if (s_proc) atomicAdd((unsigned long long *)&a.ctrl[T_PROC], (unsigned long long)s_proc);
   }
-  __syncthreads();
-  if (tid < PSL) {
-    u32 id = NONE32;
-    if (tgt != NONE32) {
-      id = s_xbase + xrank;
-      a.eT[id] = xt;
-      a.etgt[id] = tgt;
-    }
-    s_xid[tid] = id;
-    a.xid[(size_t)tile * PSL + tid] = id;
-  }
-  __syncthreads();
-  // where does the in-tile path of a cell end?  -> exit id, halo sink (row block), or nothing
+  // where does the in-tile path of a cell end?  -> exit slot, halo sink (row block), or nothing
   auto path_end = [&](u32 l) -> u32 {
     const u32 root = P[l] & 0xFFFu;
     const int rr = root >> 6, rc = root & 63;
@@ -259,7 +247,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     if (d8_is_dir(cr)) {
       const int k = d8_slot(cr);
       const int nr = rr + d8_dr(k), nc = rc + d8_dc(k);
-      if ((unsigned)nr >= TS || (unsigned)nc >= TS) return s_xid[pslot(rr, rc)];
+      if ((unsigned)nr >= TS || (unsigned)nc >= TS) return sbase + (u32)pslot(rr, rc);
     }
     return NONE32;
   };
@@ -270,9 +258,11 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       if (e != NONE32 && (e & ENC_SINK))
         esink = e;
       else if (e != NONE32)
-        link = e;  // dense id of the exit the entry's path reaches
+        link = e;  // slot of the exit the entry's path reaches
     }
-    a.elink[(size_t)tile * PSL + tid] = link;
+    a.xT[sbase + tid] = xt;
+    a.xtgt[sbase + tid] = tgt;
+    a.elink[sbase + tid] = link;
     if (tr == 0) a.esink[(size_t)tc * PSL + tid] = esink;
     if (tr == a.ntr - 1 && a.ntr > 1) a.esink[((size_t)a.ntc + tc) * PSL + tid] = esink;
   }
@@ -308,16 +298,126 @@ __device__ __forceinline__ void flag_active(u64 *ctrl) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_coarse_link(const u32 *__restrict__ etgt, const u32 *__restrict__ elink,
-                                                     u32 *__restrict__ J, u32 *__restrict__ Jlink, u32 nexits,
-                                                     u64 *ctrl) {
-  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nexits) return;
-  const u32 l = elink[etgt[e]];
-  const u32 j = (l != NONE32) ? l : (e | XDONE);
-  J[e] = j;
-  Jlink[e] = j;
-  if (!(j & XDONE)) flag_active(ctrl);
+// ---------------------------------------------------------------------------------------------
+// level 2: one 1024-thread workgroup per supertile (8x8 tiles) keeps the supertile's 16384 slot
+// records in LDS and runs the same pointer doubling over the exits, restricted to the hops that
+// stay inside the supertile.  Exits that drain into another supertile ("super-exits") are the
+// only nodes left for the global (level-3) solve: ~8x fewer nodes, ~8x shorter paths, and the
+// global atomics of the previous single-level solve become LDS atomics.
+//   FINAL == false: T2 = supertile-local total, R2 = last exit of the path inside the supertile,
+//                   dense ids + start values for the super-exits
+//   FINAL == true : exits start with their tile-local count + the flow entering the supertile
+//                   at them (xin, from level 3); every exit delivers its total to its tile entry
+// ---------------------------------------------------------------------------------------------
+template <bool FINAL>
+__global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
+  __shared__ u32 T[SSL];
+  __shared__ uint16_t P[SSL];
+  __shared__ u32 s_cnt, s_base;
+  const u32 tid = threadIdx.x;
+  const u32 st = blockIdx.x;
+  const u32 base = st << SSHIFT;
+  constexpr int SPT = SSL / 1024;  // slots per thread
+  if (tid == 0) s_cnt = 0;
+  u32 tg[SPT];
+  u32 y[SPT];
+  u32 live = 0;
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const u32 i = tid + 1024u * j;
+    const u32 g = base + i;
+    const u32 tgt = s.xtgt[g];
+    u32 t = s.xT[g];
+    if (FINAL) t += s.xin[g];
+    u32 p = i | SDONE;
+    if (tgt != NONE32 && (tgt >> SSHIFT) == st) {  // drains into a tile of this supertile
+      const u32 l = s.elink[tgt];                  // exit reached from there (same tile => same supertile)
+      if (l != NONE32) p = l & (SSL - 1);
+    }
+    tg[j] = tgt;
+    T[i] = t;
+    P[i] = (uint16_t)p;
+    y[j] = p & (SSL - 1);
+    if (!(p & SDONE)) live |= 1u << j;
+  }
+  __syncthreads();
+  for (int round = 0; round < MAXROUNDS_SUPER; ++round) {
+    u32 av[SPT], q[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      if (live & (1u << j)) {
+        av[j] = T[tid + 1024u * j];
+        q[j] = P[y[j]];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      if (live & (1u << j)) {
+        atomicAdd(&T[y[j]], av[j]);
+        P[tid + 1024u * j] = (uint16_t)q[j];
+        y[j] = q[j] & (SSL - 1);
+        if (q[j] & SDONE) live &= ~(1u << j);
+      }
+    }
+    if (!__syncthreads_or((int)live)) break;
+  }
+  if (live) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the supertile
+  if (FINAL) {
+#pragma unroll
+    for (int j = 0; j < SPT; ++j)
+      if (tg[j] != NONE32) atomicAdd(&s.inflow[tg[j]], T[tid + 1024u * j]);
+    return;
+  }
+  // super-exits get dense ids (order is irrelevant)
+  u32 rank[SPT];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    rank[j] = NONE32;
+    if (tg[j] != NONE32 && (tg[j] >> SSHIFT) != st) rank[j] = atomicAdd(&s_cnt, 1u);
+  }
+  __syncthreads();
+  if (tid == 0) s_base = s_cnt ? (u32)atomicAdd((unsigned long long *)&s.ctrl[T_NSUPER], (unsigned long long)s_cnt) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const u32 i = tid + 1024u * j;
+    const u32 g = base + i;
+    if (tg[j] == NONE32) continue;
+    s.T2[g] = T[i];
+    s.R2[g] = base + (P[i] & (SSL - 1));
+    if (rank[j] != NONE32) {
+      const u32 id = s_base + rank[j];
+      s.sxid[g] = id;
+      s.sx_slot[id] = g;
+      s.T3[id] = T[i];
+    }
+  }
+}
+
+// level 3 links: super-exit -> next super-exit on its path (through the supertile it enters)
+__global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__restrict__ J3) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nsuper) return;
+  const u32 e = s.sx_slot[k];
+  const u32 n1 = s.elink[s.xtgt[e]];
+  u32 j = k | XDONE;
+  if (n1 != NONE32) {
+    const u32 id = s.sxid[s.R2[n1]];
+    if (id != NONE32) j = id;
+  }
+  J3[k] = j;
+  if (!(j & XDONE)) flag_active(s.ctrl);
+}
+// flow through a super-exit enters the next supertile at the exit its target entry leads to
+__global__ void __launch_bounds__(256) k_push3(SuperArgs s, u32 nsuper, const u32 *__restrict__ T3final) {
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nsuper) return;
+  const u32 tgt = s.xtgt[s.sx_slot[k]];
+  const u32 n1 = s.elink[tgt];
+  // (the delivery to the tile entry itself happens in the final supertile pass, where the
+  // super-exit's total is T3final again)
+  if (n1 != NONE32) atomicAdd(&s.xin[n1], T3final[k]);
 }
 
 // round prologue: Tnew = Told (the adds of the round go on top) and reset the activity flag
@@ -342,12 +442,6 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
   atomicAdd(&Tnew[j], Told[e]);
   Jnew[e] = q;
   if (!(q & XDONE)) flag_active(ctrl);
-}
-
-__global__ void __launch_bounds__(256) k_coarse_inflow(const u32 *__restrict__ etgt, const u32 *__restrict__ T,
-                                                       u32 *__restrict__ inflow, u32 nexits) {
-  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < nexits) atomicAdd(&inflow[etgt[e]], T[e]);
 }
 
 // generic pointer doubling driver on (T, J) ping-pong buffers; rounds are idempotent once every
@@ -382,39 +476,47 @@ int pfd_doubling_rounds(pfd_raster *h, u32 **Tc, u32 **Tn, u32 **Jc, u32 **Jn, u
 // flow collected by a halo sink = what reached it inside its tile (haloA) + the inflow of the
 // tile entries whose in-tile path ends on it
 __global__ void __launch_bounds__(256) k_halo_collect(const u32 *__restrict__ esink, const u32 *__restrict__ inflow,
-                                                      u32 ntc, u32 ntr, u32 ncol, u32 *__restrict__ haloL, u32 n) {
+                                                      u32 ntc, u32 ntr, u32 nstc, u32 ncol, u32 *__restrict__ haloL,
+                                                      u32 n) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const u32 e = esink[t];
   if (e == NONE32) return;
   // region 0 = tile row 0, region 1 = last tile row
-  const size_t slot = (t < ntc * PSL) ? (size_t)t : (size_t)(ntr - 1) * ntc * PSL + (t - ntc * PSL);
-  const u32 v = inflow[slot];
+  const u32 reg = t / (ntc * PSL), tc = (t % (ntc * PSL)) / PSL, p = t % PSL;
+  const u32 v = inflow[sslot_base(reg ? ntr - 1 : 0, tc, nstc) + p];
   if (v) atomicAdd(&haloL[((e & ENC_SIDE1) ? ncol : 0u) + (e & ENC_COL)], v);
 }
 // where does the flow entering at a boundary-row cell leave the block?  (halo sink or nowhere)
-__global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, const u32 *__restrict__ Jfinal,
-                                                   const u32 *__restrict__ etgt, const u32 *__restrict__ esink,
-                                                   u32 ntc, u32 ntr, u32 ncol, u32 *__restrict__ brow_sink) {
+// exit -> last exit inside its supertile -> (level 3) last super-exit -> last exit of the path
+__global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, SuperArgs s,
+                                                   const u32 *__restrict__ J3final, const u32 *__restrict__ esink,
+                                                   u32 ntc, u32 ntr, u32 nstc, u32 ncol, u32 *__restrict__ brow_sink) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * ncol) return;
   u32 f = brow_first[t];
-  if (f != NONE32 && !(f & ENC_SINK)) {  // an exit id: jump to the last exit of its path
-    const u32 last = Jfinal[f] & ~XDONE;
-    const u32 slot = etgt[last];
-    const u32 tile = slot / PSL, tr = tile / ntc, tc = tile % ntc;
+  if (f != NONE32 && !(f & ENC_SINK)) {
+    u32 last = s.R2[f];
+    const u32 id = s.sxid[last];
+    if (id != NONE32) {
+      last = s.sx_slot[J3final[id] & ~XDONE];
+      const u32 n1 = s.elink[s.xtgt[last]];
+      if (n1 != NONE32) last = s.R2[n1];
+    }
+    u32 tr, tc, p;
+    sslot_inv(s.xtgt[last], nstc, &tr, &tc, &p);
     f = NONE32;
     if (tr == 0)
-      f = esink[(size_t)tc * PSL + (slot & (PSL - 1))];
+      f = esink[(size_t)tc * PSL + p];
     else if (tr == ntr - 1)
-      f = esink[((size_t)ntc + tc) * PSL + (slot & (PSL - 1))];
+      f = esink[((size_t)ntc + tc) * PSL + p];
   }
   brow_sink[t] = f;
 }
-// push the flow that enters at the boundary rows along the coarse paths: every exit on the path
+// push the flow that enters at the boundary rows along the exit paths: every exit on the path
 // delivers that much more to the tile entry it drains into
 __global__ void __launch_bounds__(256) k_brow_push(const u32 *__restrict__ brow_first, const u32 *__restrict__ brow_inflow,
-                                                   const u32 *__restrict__ Jlink, const u32 *__restrict__ etgt,
+                                                   const u32 *__restrict__ xtgt, const u32 *__restrict__ elink,
                                                    u32 ncol, u32 *__restrict__ inflow) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * ncol) return;
@@ -422,10 +524,10 @@ __global__ void __launch_bounds__(256) k_brow_push(const u32 *__restrict__ brow_
   u32 e = brow_first[t];
   if (!v || e == NONE32 || (e & ENC_SINK)) return;
   for (;;) {
-    atomicAdd(&inflow[etgt[e]], v);
-    const u32 j = Jlink[e];
-    if (j & XDONE) break;
-    e = j;
+    const u32 tgt = xtgt[e];
+    atomicAdd(&inflow[tgt], v);
+    e = elink[tgt];
+    if (e == NONE32) break;
   }
 }
 
@@ -436,22 +538,24 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   h = hh;
   ntr = cdiv_u32((u64)h->nrow, TS);
   ntc = cdiv_u32((u64)h->ncol, TS);
-  nslots = (size_t)ntr * ntc * PSL;
+  nstc = cdiv_u32(ntc, SG);
+  nst = cdiv_u32(ntr, SG) * nstc;
+  nslots = (size_t)nst * SSL;
   supported = !(nslots >= 0x3FFFFFFFull || ntr > 65535u || (u64)h->ncol >= ENC_SIDE1);
   if (!supported) return PFD_OK;  // ids are 30 bit: such rasters go through the level engine
-  const size_t xcap = (size_t)ntr * ntc * NPERIM;  // upper bound of the number of exits
   const size_t nb = 2 * (size_t)h->ncol;
-  PFDCHK(T0.alloc(xcap * sizeof(u32)));
-  PFDCHK(T1.alloc(xcap * sizeof(u32)));
-  PFDCHK(J0.alloc(xcap * sizeof(u32)));
-  PFDCHK(J1.alloc(xcap * sizeof(u32)));
-  PFDCHK(Jlink.alloc(xcap * sizeof(u32)));
-  PFDCHK(etgt.alloc(xcap * sizeof(u32)));
-  PFDCHK(xid.alloc(nslots * sizeof(u32)));
-  PFDCHK(elink.alloc(nslots * sizeof(u32)));
-  PFDCHK(inflow.alloc(nslots * sizeof(u32)));
+  const size_t sxcap = (size_t)nst * 4 * SG * TS;  // super-exits sit on the supertile perimeter
+  PFDCHK(slots.alloc(8 * nslots * sizeof(u32)));
+  PFDCHK(sx.alloc(5 * sxcap * sizeof(u32)));
   PFDCHK(esink.alloc(2 * (size_t)ntc * PSL * sizeof(u32)));
   PFDCHK(bnd.alloc(5 * nb * sizeof(u32)));  // brow_first | haloA | haloL | brow_sink | brow_inflow
+  u32 *q = slots.as<u32>();
+  xtgt = q, elink = q + nslots, sxid = q + 2 * nslots;              // 0xFF-initialised
+  xT = q + 3 * nslots, inflow = q + 4 * nslots, xin = q + 5 * nslots;  // zero-initialised
+  T2 = q + 6 * nslots, R2 = q + 7 * nslots;                          // written before read
+  u32 *x = sx.as<u32>();
+  sx_slot = x;
+  Tc = x + sxcap, Tn = x + 2 * sxcap, Jc = x + 3 * sxcap, Jn = x + 4 * sxcap;
   u32 *b = bnd.as<u32>();
   brow_first = b;
   haloA = b + nb;
@@ -459,19 +563,21 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   brow_sink = b + 3 * nb;
   brow_inflow = b + 4 * nb;
   a = TileArgs{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
-               (u32)(h->halo_top + h->own_rows - 1), xid.as<u32>(), T0.as<u32>(), etgt.as<u32>(),
-               elink.as<u32>(), inflow.as<u32>(), esink.as<u32>(), brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
+               (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
+               brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
+  sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl};
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
   is_block = h->halo_top || h->halo_bot;
   return PFD_OK;
 }
 
-// phase A: local tile pass + coarse solve with zero flow from other row blocks
+// phase A: local tile pass + hierarchical exit-graph solve with zero flow from other row blocks
 int TiledRun::phase_a() {
   const size_t nb = 2 * (size_t)h->ncol;
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 56 * sizeof(u64), h->stream));
-  HIPCHK(hipMemsetAsync(inflow.p, 0, nslots * sizeof(u32), h->stream));
-  // brow_first / brow_sink = NONE, haloA / brow_inflow = 0
+  HIPCHK(hipMemsetAsync(xtgt, 0xFF, 3 * nslots * sizeof(u32), h->stream));  // xtgt, elink, sxid = NONE
+  HIPCHK(hipMemsetAsync(xT, 0, 3 * nslots * sizeof(u32), h->stream));       // xT, inflow, xin = 0
+  // brow_first / brow_sink = NONE, haloA / haloL / brow_inflow = 0
   HIPCHK(hipMemsetAsync(brow_first, 0xFF, nb * sizeof(u32), h->stream));
   HIPCHK(hipMemsetAsync(haloA, 0, 2 * nb * sizeof(u32), h->stream));
   HIPCHK(hipMemsetAsync(brow_sink, 0xFF, nb * sizeof(u32), h->stream));
@@ -482,31 +588,37 @@ int TiledRun::phase_a() {
   KCHK();
   pfd_seg_end(h, 1);
 
-  pfd_seg_begin(h, "tile_exits");
-  u64 c[3];
+  pfd_seg_begin(h, "exit_graph");
+  i64 launches = 1;
+  k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
+  KCHK();
+  u64 c[5];
   HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   nexits = (u32)c[1];
-  i64 launches = 0;
-  coarse_done = true;
-  Tc = T0.as<u32>(), Tn = T1.as<u32>(), Jc = J0.as<u32>(), Jn = J1.as<u32>();
-  if (nexits) {
-    const u32 egrid = cdiv_u32(nexits, 256);
-    k_coarse_link<<<egrid, 256, 0, h->stream>>>(etgt.as<u32>(), elink.as<u32>(), Jc, Jlink.as<u32>(), nexits, h->ctrl);
+  nsuper = (u32)c[3];
+  coarse_done = c[4] == 0;  // no supertile was left with unsaturated pointers
+  if (nsuper) {
+    const u32 g3 = cdiv_u32(nsuper, 256);
+    k_link3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Jc);
     ++launches;
     int batch = 1;
-    for (u32 span = 1; span < ntr + ntc; span <<= 1) ++batch;  // ~log2 of a typical path (in tiles)
-    PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nexits, batch, &coarse_done, &launches));
-    k_coarse_inflow<<<egrid, 256, 0, h->stream>>>(etgt.as<u32>(), Tc, inflow.as<u32>(), nexits);
+    for (u32 span = 1; span < (ntr + ntc) / SG + 2; span <<= 1) ++batch;  // ~log2 of a path in supertiles
+    bool done3 = false;
+    PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nsuper, batch, &done3, &launches));
+    coarse_done = coarse_done && done3;
+    k_push3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Tc);
     ++launches;
-    KCHK();
   }
+  k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
+  ++launches;
+  KCHK();
   if (is_block) {  // what leaves through the halo rows, and where boundary-row inflow would leave
     HIPCHK(hipMemcpyAsync(haloL, haloA, nb * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
     const u32 ne = (ntr > 1 ? 2u : 1u) * ntc * PSL;
-    k_halo_collect<<<cdiv_u32(ne, 256), 256, 0, h->stream>>>(esink.as<u32>(), inflow.as<u32>(), ntc, ntr, (u32)h->ncol,
+    k_halo_collect<<<cdiv_u32(ne, 256), 256, 0, h->stream>>>(esink.as<u32>(), inflow, ntc, ntr, nstc, (u32)h->ncol,
                                                             haloL, ne);
-    k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, Jc, etgt.as<u32>(), esink.as<u32>(), ntc, ntr,
+    k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, sa, Jc, esink.as<u32>(), ntc, ntr, nstc,
                                                          (u32)h->ncol, brow_sink);
     launches += 3;
     KCHK();
@@ -521,8 +633,7 @@ int TiledRun::phase_b(int *complete) {
   const size_t nb = 2 * (size_t)h->ncol;
   if (is_block && nexits) {
     pfd_seg_begin(h, "block_inflow");
-    k_brow_push<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, Jlink.as<u32>(), etgt.as<u32>(),
-                                                         (u32)h->ncol, inflow.as<u32>());
+    k_brow_push<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, xtgt, elink, (u32)h->ncol, inflow);
     KCHK();
     pfd_seg_end(h, 1);
   }
@@ -531,7 +642,7 @@ int TiledRun::phase_b(int *complete) {
   k_tile<true><<<grid, 256, 0, h->stream>>>(a);
   KCHK();
   pfd_seg_end(h, 1);
-  u64 c[3];
+  u64 c[5];
   HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (a.ablate & 16) {
@@ -544,8 +655,8 @@ int TiledRun::phase_b(int *complete) {
               q[1] / nt, q[2] / nt, q[3] / nt);
     }
   }
-  // T_PROC counted both tile passes
-  *complete = coarse_done && (c[0] == 2ull * (u64)h->n_valid);
+  // T_PROC counted both tile passes; T_SLIVE counts supertile solves that did not saturate
+  *complete = coarse_done && c[4] == 0 && (c[0] == 2ull * (u64)h->n_valid);
   return PFD_OK;
 }
 
