@@ -269,7 +269,7 @@ static int raster_create_impl(const uint8_t *d8, int64_t own_rows, int64_t ncol,
   int rc = PFD_OK;
   do {
     if ((rc = acquire_stream(device, &h->stream)) != PFD_OK) break;
-    if ((rc = pfd_dmalloc((void **)&h->ncode, (size_t)h->n)) != PFD_OK) break;
+    if ((rc = pfd_dmalloc((void **)&h->ncode, (size_t)h->n + 64)) != PFD_OK) break;  // +slack: dword halo loads
     if ((rc = pfd_dmalloc((void **)&h->ctrl, 64 * sizeof(u64))) != PFD_OK) break;
     h->bytes_held = (size_t)h->n + 64 * sizeof(u64);
     InArg in;

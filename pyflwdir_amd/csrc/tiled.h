@@ -23,7 +23,7 @@
 #define ENC_SIDE1 0x40000000u
 #define ENC_COL 0x3FFFFFFFu
 
-enum { T_PROC = 8, T_NEXITS = 9, T_XACTIVE = 10, T_NSUPER = 11, T_SLIVE = 12 };  // ctrl slots (u64)
+enum { T_UNSAT = 8, T_XACTIVE = 10, T_NSUPER = 11, T_SLIVE = 12 };  // ctrl slots (u64)
 
 // slot numbering: [supertile][tile within supertile][perimeter slot] so that the exits of one
 // 8x8-tile supertile are 16384 consecutive ids (the level-2 solve keeps them in LDS)

@@ -73,65 +73,87 @@ __device__ __forceinline__ void pslot_inv(int p, int *lr, int *lc) {
   }
 }
 
+// LDS layout of the staged codes: 66 rows (1-cell halo) x 72 bytes; column lc in [-1, 64] lives
+// at byte lc + 4 of its row, so that the 64 own columns start on a dword boundary and the halo'd
+// row is exactly 18 dwords [c0-4, c0+68) of the raster row.
+#define CP 72
+#define CODE(lr, lc) code[((lr) + 1) * CP + (lc) + 4]
+#define QPT (TCELLS / 4 / 256)  // quads (4 consecutive cells) per thread
+
 template <bool FINAL>
 __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
-  __shared__ u32 A[TCELLS];       // running subtree count of the cell
-  __shared__ uint16_t P[TCELLS];  // 2^k-th ancestor (local index) | PDONE once saturated
-  __shared__ u8 code[HW * HW];    // normalised codes with a 1-cell halo
-  __shared__ u32 s_proc, s_exits;
+  __shared__ __attribute__((aligned(16))) u32 A[TCELLS];       // running subtree count of the cell
+  __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2^k-th ancestor | PDONE once saturated
+  __shared__ __attribute__((aligned(16))) u8 code[HW * CP];    // normalised codes with a 1-cell halo
   u64 tprev = __builtin_readcyclecounter();
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
   const u32 sbase = sslot_base(tr, tc, a.nstc);  // first of this tile's 256 slot ids
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
-  if (tid == 0) s_proc = s_exits = 0;
 
-  // ---- stage the tile's codes (+1-cell halo): all loads in flight before the first store -----
+  // ---- stage the tile's codes (+halo) as dwords: all loads in flight before the first store ----
   {
-    u8 v[18];
+    u32 v[5];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) {
-      const u32 idx = tid + 256u * k;
-      const i64 gr = r0 + (i64)(idx / HW) - 1, gc = c0 + (i64)(idx % HW) - 1;
-      // unconditional load from a clamped address (a load inside a branch would be waited for
-      // on the spot and the 18 loads would serialise), nodata selected afterwards
-      const bool inside = idx < HW * HW && gr >= 0 && gc >= 0 && gr < (i64)a.nrow && gc < (i64)a.ncol;
-      const i64 cr = gr < 0 ? 0 : (gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr);
-      const i64 cc = gc < 0 ? 0 : (gc >= (i64)a.ncol ? (i64)a.ncol - 1 : gc);
-      const u8 ld = a.ncode[(size_t)cr * a.ncol + (size_t)cc];
-      v[k] = inside ? ld : (u8)D8_MV;
+    for (int k = 0; k < 5; ++k) {
+      const u32 idx = tid + 256u * k;  // dword idx of the 66 x 18 staging area (1188 used)
+      const u32 hr = idx / 18u, d = idx - hr * 18u;
+      const i64 gr = r0 + (i64)hr - 1;
+      const i64 cs = c0 - 4 + 4 * (i64)d;  // first raster column of this dword
+      // unconditional (possibly unaligned) dword load from a clamped address; a load inside a
+      // branch would be waited for on the spot.  Reading up to 3 bytes past a row end is fine:
+      // the bytes are masked below and the allocation carries slack.
+      const i64 crr = gr < 0 ? 0 : (gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr);
+      const i64 ccs = cs < 0 ? 0 : (cs >= (i64)a.ncol ? (i64)a.ncol - 1 : cs);
+      u32 w;
+      __builtin_memcpy(&w, a.ncode + (size_t)crr * a.ncol + (size_t)ccs, 4);
+      const bool rowok = idx < HW * 18u && gr >= 0 && gr < (i64)a.nrow;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const i64 col = cs + b;
+        if (!rowok || col < 0 || col >= (i64)a.ncol) w = (w & ~(0xFFu << (8 * b))) | (D8_MV << (8 * b));
+      }
+      v[k] = w;
     }
     u32 inf = 0;
     if (FINAL) inf = a.inflow[sbase + tid];  // 256 slots per tile: always in bounds
 #pragma unroll
-    for (int k = 0; k < 18; ++k) {
+    for (int k = 0; k < 5; ++k) {
       const u32 idx = tid + 256u * k;
-      if (idx < HW * HW) code[idx] = v[k];
+      if (idx < HW * 18u) ((u32 *)code)[idx] = v[k];
     }
     __syncthreads();
     TSTAMP(0)
 
     // ---- initial weights and downstream pointers -------------------------------------------
-    // thread owns cells l = tid + 256*j (a wave = one 64-cell row segment: conflict-free LDS)
+    // a thread owns QPT quads of 4 consecutive cells: l0 = 4*tid + 1024*j (16 lanes = one row)
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      const u32 l = tid + 256u * j;
-      const int lr = l >> 6, lc = l & 63;
-      const u32 c = code[(lr + 1) * HW + lc + 1];
-      u32 p = l | PDONE;  // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
-      if (d8_is_dir(c)) {
-        const int k = d8_slot(c);
-        const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
-        if ((unsigned)nr < TS && (unsigned)nc < TS) p = (u32)(nr * TS + nc);
+    for (int j = 0; j < QPT; ++j) {
+      const u32 l0 = 4u * tid + 1024u * j;
+      const int lr = l0 >> 6, lc0 = l0 & 63;
+      const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+      u32 w4[4], p4[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const u32 c = (c4 >> (8 * b)) & 0xFFu;
+        const u32 l = l0 + b;
+        u32 p = l | PDONE;  // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
+        if (d8_is_dir(c)) {
+          const int k = d8_slot(c);
+          const int nr = lr + d8_dr(k), nc = lc0 + b + d8_dc(k);
+          if ((unsigned)nr < TS && (unsigned)nc < TS) p = (u32)(nr * TS + nc);
+        }
+        u32 w = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
+        if (FINAL && w) {  // flow entering this row block from the neighbouring GPUs
+          const u32 gr = (u32)r0 + (u32)lr, gc = (u32)c0 + (u32)lc0 + b;
+          if (gr == a.row_first) w += a.brow_inflow[gc];
+          if (gr == a.row_last) w += a.brow_inflow[a.ncol + gc];
+        }
+        w4[b] = w;
+        p4[b] = p;
       }
-      u32 w = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
-      if (FINAL && w) {  // flow entering this row block from the neighbouring GPUs
-        const u32 gr = (u32)r0 + (u32)lr, gc = (u32)c0 + (u32)lc;
-        if (gr == a.row_first) w += a.brow_inflow[gc];
-        if (gr == a.row_last) w += a.brow_inflow[a.ncol + gc];
-      }
-      A[l] = w;
-      P[l] = (uint16_t)p;
+      *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+      *(uint2 *)&P[l0] = make_uint2(p4[0] | (p4[1] << 16), p4[2] | (p4[3] << 16));
     }
     if (FINAL) {
       __syncthreads();
@@ -146,72 +168,97 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   TSTAMP(1)
 
   // ---- pointer doubling ------------------------------------------------------------------------
-  u32 y[CPT];        // current 2^k-th ancestor of own cell j (valid while its bit in `live` is set)
-  u32 live = 0;      // bit j: own cell j still has an unsaturated pointer
-  u32 nvalid = 0;
+  u32 pc[QPT * 4];   // current pointer word (ancestor | PDONE) of own cell 4*j+b
+  u32 live = 0;      // bit 4*j+b: own cell still has an unsaturated pointer
 #pragma unroll
-  for (int j = 0; j < CPT; ++j) {
-    const u32 l = tid + 256u * j;
-    const u32 p = P[l];
-    y[j] = p & 0xFFFu;
-    if (!(p & PDONE)) live |= 1u << j;
-    const u32 c = code[((l >> 6) + 1) * HW + (l & 63) + 1];
-    nvalid += (c != D8_MV && c != D8_HALO);
+  for (int j = 0; j < QPT; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const uint2 pp = *(const uint2 *)&P[l0];
+    pc[4 * j + 0] = pp.x & 0xFFFFu;
+    pc[4 * j + 1] = pp.x >> 16;
+    pc[4 * j + 2] = pp.y & 0xFFFFu;
+    pc[4 * j + 3] = pp.y >> 16;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (!(pc[4 * j + b] & PDONE)) live |= 1u << (4 * j + b);
+    }
   }
   if (!(a.ablate & 1)) {
     for (int round = 0; round < MAXROUNDS_TILE; ++round) {
-      u32 av[CPT], q[CPT];
+      u32 av[QPT * 4], q[QPT * 4];
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) {
-        if (live & (1u << j)) {
-          av[j] = A[tid + 256u * j];
-          q[j] = P[y[j]];
+      for (int j = 0; j < QPT; ++j) {
+        if (live & (0xFu << (4 * j))) {
+          const uint4 a4 = *(const uint4 *)&A[4u * tid + 1024u * j];
+          av[4 * j + 0] = a4.x;
+          av[4 * j + 1] = a4.y;
+          av[4 * j + 2] = a4.z;
+          av[4 * j + 3] = a4.w;
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (live & (1u << (4 * j + b))) q[4 * j + b] = P[pc[4 * j + b]];
         }
       }
       __syncthreads();  // every read of this round precedes every write of this round
 #pragma unroll
-      for (int j = 0; j < CPT; ++j) {
-        if (live & (1u << j)) {
-          atomicAdd(&A[y[j]], av[j]);
-          P[tid + 256u * j] = (uint16_t)q[j];
-          y[j] = q[j] & 0xFFFu;
-          if (q[j] & PDONE) live &= ~(1u << j);
+      for (int j = 0; j < QPT; ++j) {
+        if (live & (0xFu << (4 * j))) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (live & (1u << (4 * j + b))) {
+              atomicAdd(&A[pc[4 * j + b]], av[4 * j + b]);
+              pc[4 * j + b] = q[4 * j + b];
+              if (q[4 * j + b] & PDONE) live &= ~(1u << (4 * j + b));
+            }
+          }
+          *(uint2 *)&P[4u * tid + 1024u * j] =
+              make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
         }
       }
       if (!__syncthreads_or((int)live)) break;
     }
   }
   TSTAMP(2)
-  // saturated valid cells (a cell on or upstream of a cycle never saturates)
-  u32 proc = nvalid - (u32)__popc(live);
-  for (int o = 32; o > 0; o >>= 1) proc += __shfl_down(proc, o);
-  if ((tid & 63) == 0 && proc) atomicAdd(&s_proc, proc);
+  // a cell on or upstream of a cycle never saturates: count them (normally zero, so that no
+  // same-address global atomic is issued at all — 25k of them would cost ~0.3 ms)
+  if (live) atomicAdd((unsigned long long *)&a.ctrl[T_UNSAT], (unsigned long long)__popc(live));
   __syncthreads();
 
   if (FINAL) {
-    // ---- write the owned rows of the finished tile, one 256-B row segment per wave ----------
+    // ---- write the owned rows of the finished tile (16 B per lane) ---------------------------
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      const u32 l = tid + 256u * j;
-      const int lr = l >> 6, lc = l & 63;
-      const i64 gr = r0 + lr, gc = c0 + lc;
-      if (gr >= (i64)a.row_first && gr <= (i64)a.row_last && gc < (i64)a.ncol) {
-        const u32 c = code[(lr + 1) * HW + lc + 1];
-        a.out[(size_t)(gr - a.row_first) * a.ncol + (size_t)gc] = (c == D8_MV) ? -9999 : (i32)A[l];
+    for (int j = 0; j < QPT; ++j) {
+      const u32 l0 = 4u * tid + 1024u * j;
+      const int lr = l0 >> 6, lc0 = l0 & 63;
+      const i64 gr = r0 + lr, gc0 = c0 + lc0;
+      if (gr < (i64)a.row_first || gr > (i64)a.row_last || gc0 >= (i64)a.ncol) continue;
+      const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+      const uint4 a4 = *(const uint4 *)&A[l0];
+      i32 o4[4] = {(i32)a4.x, (i32)a4.y, (i32)a4.z, (i32)a4.w};
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (((c4 >> (8 * b)) & 0xFFu) == D8_MV) o4[b] = -9999;
+      i32 *dst = a.out + (size_t)(gr - a.row_first) * a.ncol + (size_t)gc0;
+      if (gc0 + 3 < (i64)a.ncol && (((size_t)dst) & 15) == 0) {
+        *(int4 *)dst = make_int4(o4[0], o4[1], o4[2], o4[3]);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (gc0 + b < (i64)a.ncol) dst[b] = o4[b];
       }
     }
-    if (tid == 0 && s_proc) atomicAdd((unsigned long long *)&a.ctrl[T_PROC], (unsigned long long)s_proc);
     TSTAMP(3)
     return;
   }
 
+  if (a.ablate & 8) return;
   // ---- perimeter records for the coarse graph ------------------------------------------------
   u32 xt = 0, tgt = NONE32;
   bool entry = false;
   int plr = 0, plc = 0;
   if (tid < NPERIM) {
     pslot_inv((int)tid, &plr, &plc);
-    const u32 c = code[(plr + 1) * HW + plc + 1];
+    const u32 c = CODE(plr, plc);
     if (c != D8_MV && c != D8_HALO) {
       if (d8_is_dir(c)) {  // exit?
         const int k = d8_slot(c);
@@ -220,7 +267,6 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
           const i64 gr = r0 + nr, gc = c0 + nc;  // inside the raster and valid (normalised codes)
           tgt = sslot_base((u32)(gr >> 6), (u32)(gc >> 6), a.nstc) + (u32)pslot((int)(gr & 63), (int)(gc & 63));
           xt = A[plr * TS + plc];
-          atomicAdd(&s_exits, 1u);
         }
       }
     }
@@ -228,21 +274,17 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
-        if (((unsigned)nr >= TS || (unsigned)nc >= TS) && code[(nr + 1) * HW + nc + 1] == (1u << ((k + 4) & 7)))
+        if (((unsigned)nr >= TS || (unsigned)nc >= TS) && CODE(nr, nc) == (1u << ((k + 4) & 7)))
           entry = true;
       }
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    if (s_exits) atomicAdd((unsigned long long *)&a.ctrl[T_NEXITS], (unsigned long long)s_exits);
-    if (s_proc) atomicAdd((unsigned long long *)&a.ctrl[T_PROC], (unsigned long long)s_proc);
-  }
   // where does the in-tile path of a cell end?  -> exit slot, halo sink (row block), or nothing
   auto path_end = [&](u32 l) -> u32 {
     const u32 root = P[l] & 0xFFFu;
     const int rr = root >> 6, rc = root & 63;
-    const u32 cr = code[(rr + 1) * HW + rc + 1];
+    const u32 cr = CODE(rr, rc);
     if (cr == D8_HALO) return ENC_SINK | (((u32)r0 + (u32)rr > a.row_last) ? ENC_SIDE1 : 0u) | ((u32)c0 + (u32)rc);
     if (d8_is_dir(cr)) {
       const int k = d8_slot(cr);
@@ -273,7 +315,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       const u32 l = tid + 256u * j;
       const u32 gr = (u32)r0 + (l >> 6), gc = (u32)c0 + (l & 63);
       if (gr >= a.nrow || gc >= a.ncol) continue;
-      const u32 c = code[((l >> 6) + 1) * HW + (l & 63) + 1];
+      const u32 c = CODE((int)(l >> 6), (int)(l & 63));
       if (c == D8_HALO) a.haloA[(gr > a.row_last ? a.ncol : 0u) + gc] = A[l];
       if (c != D8_MV && c != D8_HALO) {
         if (gr == a.row_first) a.brow_first[gc] = path_end(l);
@@ -595,7 +637,6 @@ int TiledRun::phase_a() {
   u64 c[5];
   HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  nexits = (u32)c[1];
   nsuper = (u32)c[3];
   coarse_done = c[4] == 0;  // no supertile was left with unsaturated pointers
   if (nsuper) {
@@ -631,7 +672,7 @@ int TiledRun::phase_a() {
 // final tile pass, completeness check
 int TiledRun::phase_b(int *complete) {
   const size_t nb = 2 * (size_t)h->ncol;
-  if (is_block && nexits) {
+  if (is_block) {
     pfd_seg_begin(h, "block_inflow");
     k_brow_push<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, xtgt, elink, (u32)h->ncol, inflow);
     KCHK();
@@ -655,8 +696,8 @@ int TiledRun::phase_b(int *complete) {
               q[1] / nt, q[2] / nt, q[3] / nt);
     }
   }
-  // T_PROC counted both tile passes; T_SLIVE counts supertile solves that did not saturate
-  *complete = coarse_done && c[4] == 0 && (c[0] == 2ull * (u64)h->n_valid);
+  // T_UNSAT: cells left unsaturated by a tile pass; T_SLIVE: supertile solves that did not saturate
+  *complete = coarse_done && c[4] == 0 && c[0] == 0;
   return PFD_OK;
 }
 
