@@ -83,7 +83,8 @@ int pfd_trim(int device);
  * Any other value -> PFD_EBADCODE (the reference only accepts such rasters with
  * check_ftype=False and then decodes them with log2 arithmetic the device path does not
  * imitate).  Fails with PFD_ENOPITS when no pit exists (reference pyflwdir/flwdir.py:126).
- * Limit: nrow*ncol <= 4294967294 per handle (32-bit device indices). */
+ * Rasters of more than 4294967294 cells (32-bit device indices) are accepted for
+ * pfd_upstream_area_cell only (LDS-tiled path, e.g. 90000 x 90000 on one 288 GB GPU). */
 int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, int memspace, int device,
                       pfd_raster **out);
 int pfd_raster_destroy(pfd_raster *h);

@@ -245,11 +245,15 @@ static int raster_create_impl(const uint8_t *d8, int64_t own_rows, int64_t ncol,
     return PFD_EINVAL;
   }
   const int64_t nrow = own_rows + halo_top + halo_bot;
+  // Rasters beyond 4294967294 cells cannot use the level engine (32-bit cell indices) but the
+  // LDS-tiled path addresses cells as (tile, local index): accept them as long as the tile
+  // bookkeeping fits its 30-bit slot ids (e.g. 90000 x 90000 = 8.1e9 cells on one 288 GB GPU).
   const unsigned __int128 n128 = (unsigned __int128)nrow * (unsigned __int128)ncol;
-  if (n128 > 4294967294ull) {
-    pfd_set_error("pfd_raster_create: %lld x %lld cells exceed the 4294967294 cells a single handle "
-                  "indexes with 32 bits; split the raster into row blocks (one handle per GPU)",
-                  (long long)nrow, (long long)ncol);
+  const uint64_t ntr = ((uint64_t)nrow + 63) / 64, ntc = ((uint64_t)ncol + 63) / 64;
+  const uint64_t nslots = ((ntr + 7) / 8) * ((ntc + 7) / 8) * 16384ull;
+  if (n128 > 4294967294ull && (nslots >= 0x3FFFFFFFull || ntr > 65535ull || (uint64_t)ncol >= 0x40000000ull)) {
+    pfd_set_error("pfd_raster_create: %lld x %lld cells are more than one handle can address; split the "
+                  "raster into row blocks (one handle per GPU)", (long long)nrow, (long long)ncol);
     return PFD_EUNSUPPORTED;
   }
   if (memspace != PFD_HOST && memspace != PFD_DEVICE) {

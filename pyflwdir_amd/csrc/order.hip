@@ -223,6 +223,11 @@ int pfd_require_whole(pfd_raster *h, const char *what) {
                   "pfd_upstream_area_cell_blocks / _dist)", what);
     return PFD_EUNSUPPORTED;
   }
+  if (h->n > 4294967294ll) {
+    pfd_set_error("%s needs 32-bit cell indices and is not available for a raster of %lld cells (only "
+                  "upstream_area(unit=\"cell\") runs on rasters this large)", what, (long long)h->n);
+    return PFD_EUNSUPPORTED;
+  }
   return PFD_OK;
 }
 
@@ -339,7 +344,6 @@ extern "C" int pfd_upstream_count(pfd_raster *h, const uint8_t *mask, int8_t *ou
 // to finish publishes the end offset of the new level, so the next launch needs no host
 // round trip.
 // ---------------------------------------------------------------------------------------------
-#define BFS_GRID 1024
 
 __global__ void __launch_bounds__(256) k_bfs_level(const u8 *__restrict__ ncode, Geo g, u32 *__restrict__ seq,
                                                    u64 *__restrict__ ctrl, i64 *__restrict__ lvl_off, int lvl) {
@@ -397,7 +401,7 @@ int pfd_order_cells_impl(pfd_raster *h) {
   }
   pfd_seg_begin(h, "order_cells");
   HIPCHK(hipMemcpyAsync(h->seq, h->pits, (size_t)h->n_pits * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
-  const int BATCH = 256;
+  const int BATCH = 128;
   size_t cap = (size_t)(2 * (h->nrow + h->ncol) + 4 * BATCH + 64);
   DevBuf lvl;
   PFDCHK(lvl.alloc(cap * sizeof(i64)));
@@ -413,6 +417,7 @@ int pfd_order_cells_impl(pfd_raster *h) {
   int lvl_next = 0;  // next level to expand
   i64 launches = 0;
   bool done = false;
+  i64 recent_max = h->n_pits;
   std::vector<i64> tmp(BATCH);
   while (!done) {
     if ((size_t)(lvl_next + BATCH + 2) > cap) {  // grow the device offsets array
@@ -425,8 +430,11 @@ int pfd_order_cells_impl(pfd_raster *h) {
       std::swap(lvl.p, bigger.p);
       cap = ncap;
     }
+    // grid sized from the largest recent level (every block ends with one same-address atomic,
+    // so an oversized grid costs ~12 ns per block; an undersized one just grid-strides)
+    const u32 bfs_grid = (u32)std::min<i64>(2048, std::max<i64>(32, (4 * recent_max + 255) / 256));
     for (int b = 0; b < BATCH; ++b) {
-      k_bfs_level<<<BFS_GRID, 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, h->ctrl, lvl.as<i64>(), lvl_next + b);
+      k_bfs_level<<<bfs_grid, 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, h->ctrl, lvl.as<i64>(), lvl_next + b);
       ++launches;
     }
     KCHK();
@@ -434,11 +442,13 @@ int pfd_order_cells_impl(pfd_raster *h) {
     HIPCHK(hipMemcpyAsync(tmp.data(), lvl.as<i64>() + lvl_next + 2, BATCH * sizeof(i64), hipMemcpyDeviceToHost,
                           h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    recent_max = 0;
     for (int b = 0; b < BATCH; ++b) {
       if (tmp[b] == off.back()) {  // level lvl_next+b+1 is empty -> finished
         done = true;
         break;
       }
+      recent_max = std::max(recent_max, tmp[b] - off.back());
       off.push_back(tmp[b]);
     }
     lvl_next += BATCH;
