@@ -37,8 +37,35 @@ PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # split over the phases of the level engine as documented in DESIGN.md §Roofline
 B_ALG_TOTAL = 29.0
 B_ALG_PHASE = {"order_cells": 8.0, "init": 4.0, "sweep_count_up": 17.0,
-               "tile_local": 8.0, "tile_exits": 4.0, "tile_final": 17.0, "interface_solve": 4.0, "allgather": 4.0,
-               "block_inflow": 4.0}
+               "tile_local": 8.0, "exit_graph": 4.0, "tile_final": 17.0}
+# segment -> the kernel it times (names as rocprofv3 prints them); single-launch segments only
+KERNEL_OF = {"tile_local": "void k_tile<false>(TileArgs)", "tile_final": "void k_tile<true>(TileArgs)",
+             "order_cells": "k_bfs_level(...)", "sweep_count_up": "void k_sweep<CountUp>(...)"}
+# HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3
+# --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of this same command, 10000 x 10000):
+# bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024, raw counter values (calibration in DESIGN.md)
+PMC_TRAFFIC = {("void k_tile<true>(TileArgs)", 10000): (185267.325 + 391395.281) * 1024,
+               ("void k_tile<false>(TileArgs)", 10000): (172864.663 + 75801.5) * 1024}
+
+
+def roofline_of(segs, n, size, ms_per_step):
+    """Roofline object for the dominant KERNEL (the tile pass that takes longest; multi-launch
+    segments such as the exit graph are reported in phases_ms but are not one kernel)."""
+    cand = [s for s in segs if s["name"] in KERNEL_OF] or segs
+    dom = max(cand, key=lambda s: s["ms"])
+    b_alg = B_ALG_PHASE.get(dom["name"], B_ALG_TOTAL)
+    launches = max(1, dom["launches"])
+    avg_ms = dom["ms"] / launches
+    achieved = (b_alg * n / launches) / (avg_ms * 1e-3) / 1e9
+    kname = KERNEL_OF.get(dom["name"], dom["name"])
+    traffic = PMC_TRAFFIC.get((kname, size))
+    whole = B_ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                frac=round(achieved / PEAK_HBM_GBS, 5), traffic=traffic, kernel=kname, launches=dom["launches"],
+                avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
+                whole_pass=dict(alg_bytes_per_cell=B_ALG_TOTAL, achieved=round(whole, 2),
+                                frac=round(whole / PEAK_HBM_GBS, 5)),
+                phases_ms={s["name"]: round(s["ms"], 3) for s in segs})
 SYNTH = dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0)  # "river" regime: max_rank = nrow-1
 
 
@@ -54,6 +81,8 @@ def parse():
 
 
 def one_step(d8_buf, out_buf, nrow, ncol, device, profile=False):
+    """One pass of the hot path.  With profile=True the library brackets every phase with HIP
+    events on its own stream (6 events per pass) and the phase times are returned."""
     h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE)
     if profile:
         h.set_profiling(True)
@@ -61,6 +90,16 @@ def one_step(d8_buf, out_buf, nrow, ncol, device, profile=False):
     res = (h.last_timing(), h.info()) if profile else None
     h.close()
     return res
+
+
+def mean_segments(all_segs):
+    """Average the per-phase HIP-event times over the timed steps."""
+    acc = {}
+    for segs in all_segs:
+        for s in segs:
+            a = acc.setdefault(s["name"], dict(name=s["name"], ms=0.0, launches=s["launches"]))
+            a["ms"] += s["ms"] / len(all_segs)
+    return list(acc.values())
 
 
 def cpu_baseline(d8_host, rows):
@@ -112,25 +151,21 @@ def run_distributed(a, rank, world, local):
     _hip.check(_hip.lib().pfd_device_synchronize(device))
     dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    timed = [step(profile=True) for _ in range(a.steps)]
     _hip.check(_hip.lib().pfd_device_synchronize(device))
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt[0])
-    segs, info = step(profile=True)
+    segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
     # cross-rank invariant: the cells draining off the last row of the raster carry every cell
     stats = torch.tensor([info["n_valid"]], dtype=torch.int64)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     if rank == 0:
         n = nrow_total * ncol
         ms_per_step = dt / a.steps * 1e3
-        dom = max(segs, key=lambda s: s["ms"])
-        b_alg = B_ALG_PHASE.get(dom["name"], B_ALG_TOTAL)
-        launches = max(1, dom["launches"])
-        avg_ms = dom["ms"] / launches
-        achieved = (b_alg * (n / world) / launches) / (avg_ms * 1e-3) / 1e9
+        roof = roofline_of(segs, n // world, a.size, ms_per_step)
+        roof["per_gpu"] = True
         out = dict(metric="Mcells/s upstream_area on D8 raster", value=round(n * a.steps / dt / 1e6, 2), unit="Mcells/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
@@ -138,10 +173,7 @@ def run_distributed(a, rank, world, local):
                                         f"GPUs ({a.size} rows each + halo), upstream_area(unit='cell') int32, "
                                         "decode+local solve+RCCL all-gather+final pass per step",
                                n_valid=int(stats[0]), parallelism=f"{world} row blocks, 1 all-gather/pass"),
-                   roofline=dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                                 frac=round(achieved / PEAK_HBM_GBS, 5), traffic=None, kernel=dom["name"],
-                                 launches=dom["launches"], avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
-                                 per_gpu=True, phases_ms={s["name"]: round(s["ms"], 3) for s in segs}))
+                   roofline=roof)
         print(json.dumps(out))
     dist.barrier()
     comm.close()
@@ -169,27 +201,14 @@ def main():
         one_step(d8_buf, out_buf, nrow, ncol, device)
     _hip.check(_hip.lib().pfd_device_synchronize(device))
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step(d8_buf, out_buf, nrow, ncol, device)
+    timed = [one_step(d8_buf, out_buf, nrow, ncol, device, profile=True) for _ in range(a.steps)]
     _hip.check(_hip.lib().pfd_device_synchronize(device))
     dt = time.perf_counter() - t0
     ms_per_step = dt / a.steps * 1e3
     value = n * a.steps / dt / 1e6
-
-    # one extra, profiled step: HIP events on the library's own stream around each phase
-    segs, info = one_step(d8_buf, out_buf, nrow, ncol, device, profile=True)
-    dom = max(segs, key=lambda s: s["ms"])
-    b_alg = B_ALG_PHASE.get(dom["name"], B_ALG_TOTAL)
-    launches = max(1, dom["launches"])
-    avg_ms = dom["ms"] / launches
-    achieved = (b_alg * n / launches) / (avg_ms * 1e-3) / 1e9
-    roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                    frac=round(achieved / PEAK_HBM_GBS, 5), traffic=None, kernel=dom["name"],
-                    launches=dom["launches"], avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
-                    whole_pass=dict(alg_bytes_per_cell=B_ALG_TOTAL,
-                                    achieved=round(B_ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9, 2),
-                                    frac=round(B_ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)),
-                    phases_ms={s["name"]: round(s["ms"], 3) for s in segs})
+    # kernel durations: HIP events recorded live, inside the timed region, on the library's stream
+    segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
+    roofline = roofline_of(segs, n, a.size, ms_per_step)
 
     out = dict(metric="Mcells/s upstream_area on D8 raster", value=round(value, 2), unit="Mcells/s", n_gpus=1,
                steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
@@ -199,6 +218,14 @@ def main():
                            n_valid=info["n_valid"], n_pits=info["n_pits"], n_levels=info["n_levels"],
                            parallelism="1 GPU"),
                roofline=roofline)
+
+    # size-independent invariant (reference tests/test_streams_basins.py:24-27): the upstream areas of
+    # the pits add up to the number of valid cells.  In the river regime every pit sits on the last row.
+    last_codes = d8_buf.download(np.uint8, (ncol,), offset_bytes=(nrow - 1) * ncol)
+    last_upa = out_buf.download(np.int32, (ncol,), offset_bytes=(nrow - 1) * ncol * 4)
+    pits = last_codes == 0
+    if int(pits.sum()) == info["n_pits"]:
+        out["invariant_pit_sum_equals_n_valid"] = bool(int(last_upa[pits].astype(np.int64).sum()) == info["n_valid"])
 
     if not a.no_cpu_baseline:
         d8_host = d8_buf.download(np.uint8, (nrow, ncol))
