@@ -135,13 +135,23 @@ def run_distributed(a, rank, world, local):
     top, bot = pdist.halo_of(rank, world)
     d8_buf = _hip.synth_d8_device(nrow_total, ncol, row0=r0 - top, nrows=(r1 - r0) + top + bot, device=device, **SYNTH)
     out_buf = _hip.DeviceBuffer(a.size * ncol * 4, device)
-    comm = _hip.Communicator(pdist.exchange_unique_id(rank, world), rank, world, device)
+    # RCCL communicator (all-gather over xGMI); if it cannot be brought up on every rank the same
+    # protocol runs with the records travelling through torch.distributed (transport named in the output)
+    probe = pdist.DistributedRaster(d8_buf, a.size, ncol, rank, world, device, memspace=_hip.PFD_DEVICE,
+                                    transport=os.environ.get("PFD_DIST_TRANSPORT", "auto"))
+    comm, transport = probe.comm, probe.transport
+    probe.handle.close()
 
     def step(profile=False):
+        # a fresh handle per step, like the single-GPU bench: decode + local solve + exchange + final pass
         h = _hip.RasterHandle(d8_buf, a.size, ncol, device=device, memspace=_hip.PFD_DEVICE, halo=(top, bot))
         if profile:
             h.set_profiling(True)
-        comm.upstream_area_cell(h, out=out_buf, memspace=_hip.PFD_DEVICE)
+        if comm is not None:
+            comm.upstream_area_cell(h, out=out_buf, memspace=_hip.PFD_DEVICE)
+        else:
+            probe.handle = h
+            probe.upstream_area(out=out_buf, memspace=_hip.PFD_DEVICE)
         res = (h.last_timing(), h.info()) if profile else None
         h.close()
         return res
@@ -172,11 +182,12 @@ def run_distributed(a, rank, world, local):
                    config=dict(workload=f"{nrow_total}x{ncol} synthetic D8 (river regime, seed 0) row-tiled over {world} "
                                         f"GPUs ({a.size} rows each + halo), upstream_area(unit='cell') int32, "
                                         "decode+local solve+RCCL all-gather+final pass per step",
-                               n_valid=int(stats[0]), parallelism=f"{world} row blocks, 1 all-gather/pass"),
+                               n_valid=int(stats[0]), parallelism=f"{world} row blocks, 1 all-gather/pass", transport=transport),
                    roofline=roof)
         print(json.dumps(out))
     dist.barrier()
-    comm.close()
+    if comm is not None:
+        comm.close()
     dist.destroy_process_group()
 
 

@@ -164,6 +164,13 @@ int pfd_comm_unique_id(void *id_out, size_t len);
 int pfd_comm_create(const void *id, size_t len, int rank, int world, int device, pfd_comm **out);
 int pfd_comm_destroy(pfd_comm *c);
 int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int memspace);
+/* Split-phase form for callers that move the boundary records themselves (MPI, gloo, shared memory ...):
+ * begin() runs the local phase and returns this block's record (4*ncol uint32, host memory); finish()
+ * takes the records of all blocks in block order (nblocks*4*ncol uint32, host) and completes the pass.
+ * *complete = 0 reports cells that never reach a pit (cycles). */
+int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int memspace, uint32_t *record_host);
+int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_records_host, int nblocks, int block,
+                                  int *complete);
 
 /* ---- instrumentation ---------------------------------------------------------------------
  * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST

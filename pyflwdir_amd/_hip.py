@@ -31,7 +31,7 @@ SYMBOLS = [
     "pfd_abi_version", "pfd_last_error", "pfd_device_count", "pfd_malloc", "pfd_free", "pfd_memcpy_h2d",
     "pfd_memcpy_d2h", "pfd_device_synchronize", "pfd_trim", "pfd_raster_create", "pfd_raster_create_block",
     "pfd_raster_destroy", "pfd_raster_info", "pfd_upstream_area_cell_blocks", "pfd_comm_unique_id", "pfd_comm_create",
-    "pfd_comm_destroy", "pfd_upstream_area_cell_dist",
+    "pfd_comm_destroy", "pfd_upstream_area_cell_dist", "pfd_upstream_area_cell_begin", "pfd_upstream_area_cell_finish",
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_basins", "pfd_hand", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
@@ -66,6 +66,8 @@ def lib() -> C.CDLL:
         L.pfd_comm_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.pfd_comm_destroy.argtypes = [C.c_void_p]
         L.pfd_upstream_area_cell_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_upstream_area_cell_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.pfd_upstream_area_cell_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.pfd_raster_destroy.argtypes = [C.c_void_p]
         L.pfd_raster_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.pfd_add_pits.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -287,6 +289,24 @@ def upstream_area_cell_blocks(handles, outs=None, memspace=PFD_HOST):
     ps = (C.c_void_p * k)(*[ptr(o) for o in outs])
     check(lib().pfd_upstream_area_cell_blocks(hs, k, ps, memspace))
     return outs
+
+
+def upstream_area_cell_begin(handle, out=None, memspace=PFD_HOST):
+    """Local phase of a multi-block pass; returns (out, record) with record = 4*ncol uint32."""
+    if memspace == PFD_HOST:
+        out = np.empty(handle.n, np.int32)
+    rec = np.empty(4 * handle.ncol, np.uint32)
+    check(lib().pfd_upstream_area_cell_begin(handle._h, ptr(out), memspace, ptr(rec)))
+    return out, rec
+
+
+def upstream_area_cell_finish(handle, all_records: np.ndarray, nblocks: int, block: int) -> bool:
+    """Completes the pass with the records of all blocks (shape [nblocks, 4*ncol]); True if acyclic."""
+    all_records = np.ascontiguousarray(all_records, dtype=np.uint32)
+    assert all_records.size == nblocks * 4 * handle.ncol
+    ok = C.c_int(0)
+    check(lib().pfd_upstream_area_cell_finish(handle._h, ptr(all_records), nblocks, block, C.byref(ok)))
+    return bool(ok.value)
 
 
 class Communicator:

@@ -224,6 +224,7 @@ static void free_handle(pfd_raster *h) {
     (void)hipEventDestroy(s.e1);
   }
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  pfd_free_pending(h);
   pfd_dfree(h->ncode);
   pfd_dfree(h->seq);
   pfd_dfree(h->pits);

@@ -134,6 +134,7 @@ struct pfd_raster {
   // small device control block (counters), 64 x u64
   u64 *ctrl = nullptr;
   size_t bytes_held = 0;
+  void *pending = nullptr;  // split-phase multi-block pass in flight (dist.hip)
   // profiling
   bool profiling = false;
   std::vector<PfdSegment> segs;
@@ -219,6 +220,7 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev);  // order.hip
 int pfd_order_cells_impl(pfd_raster *h);                        // order.hip
 int pfd_ensure_pits(pfd_raster *h);                             // order.hip
 int pfd_require_whole(pfd_raster *h, const char *what);          // order.hip
+void pfd_free_pending(pfd_raster *h);                            // dist.hip
 int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete);  // tiled.hip
 
 static inline u32 cdiv_u32(u64 a, u32 b) { return (u32)((a + b - 1) / b); }

@@ -218,6 +218,83 @@ extern "C" int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32
 }
 
 // ---------------------------------------------------------------------------------------------
+// split-phase form: the caller moves the boundary records itself (any transport — MPI, gloo,
+// shared memory).  begin() runs phase A and returns this block's record (4*ncol words, host);
+// finish() takes the records of ALL blocks (nblocks*4*ncol words, host, block order) and runs
+// the interface solve + phase B.  Same kernels as the RCCL path.
+// ---------------------------------------------------------------------------------------------
+struct DistPending {
+  TiledRun run;
+  OutArg out;
+};
+
+void pfd_free_pending(pfd_raster *h) {
+  delete (DistPending *)h->pending;
+  h->pending = nullptr;
+}
+
+extern "C" int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int memspace, uint32_t *record_host) {
+  PFDCHK(pfd_check_handle(h));
+  if (!out || !record_host) {
+    pfd_set_error("pfd_upstream_area_cell_begin: bad arguments");
+    return PFD_EINVAL;
+  }
+  delete (DistPending *)h->pending;
+  h->pending = nullptr;
+  DistPending *p = new DistPending();
+  const u32 ncol = (u32)h->ncol;
+  const size_t recw = 4 * (size_t)ncol;
+  pfd_seg_clear(h);
+  int rc = p->out.bind(out, (size_t)h->own_rows * ncol * sizeof(i32), memspace);
+  if (rc == PFD_OK) rc = p->run.init(h, (i32 *)p->out.dev);
+  if (rc == PFD_OK && !p->run.supported) {
+    pfd_set_error("pfd_upstream_area_cell_begin: the block is too large for the tiled engine");
+    rc = PFD_EUNSUPPORTED;
+  }
+  if (rc == PFD_OK) rc = p->run.phase_a();
+  if (rc != PFD_OK) {
+    delete p;
+    return rc;
+  }
+  h->pending = p;
+  DevBuf rec;
+  PFDCHK(rec.alloc(recw * sizeof(u32)));
+  k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(p->run.haloL, p->run.brow_sink, ncol, rec.as<u32>());
+  KCHK();
+  HIPCHK(hipMemcpyAsync(record_host, rec.p, recw * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}
+
+extern "C" int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_records_host, int nblocks, int block,
+                                             int *complete) {
+  PFDCHK(pfd_check_handle(h));
+  DistPending *p = (DistPending *)h->pending;
+  if (!p || !all_records_host || nblocks < 1 || block < 0 || block >= nblocks || !complete) {
+    pfd_set_error("pfd_upstream_area_cell_finish: no pass in flight on this handle, or bad arguments");
+    return PFD_EINVAL;
+  }
+  int rc = PFD_OK;
+  const size_t recw = 4 * (size_t)h->ncol;
+  if (nblocks > 1) {
+    DevBuf allrec;
+    rc = allrec.alloc((size_t)nblocks * recw * sizeof(u32));
+    if (rc == PFD_OK &&
+        hipMemcpyAsync(allrec.p, all_records_host, (size_t)nblocks * recw * sizeof(u32), hipMemcpyHostToDevice,
+                       h->stream) != hipSuccess) {
+      pfd_set_error("pfd_upstream_area_cell_finish: upload of the boundary records failed");
+      rc = PFD_EHIP;
+    }
+    if (rc == PFD_OK) rc = interface_solve(p->run, allrec.as<u32>(), (u32)nblocks, (u32)block);
+  }
+  if (rc == PFD_OK) rc = p->run.phase_b(complete);
+  if (rc == PFD_OK) rc = p->out.finish(h->stream);
+  delete p;
+  h->pending = nullptr;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // one process per GPU: collective call, every rank passes its own block
 // ---------------------------------------------------------------------------------------------
 extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int memspace) {

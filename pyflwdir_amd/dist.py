@@ -67,20 +67,80 @@ def exchange_unique_id(rank: int, world: int, group=None) -> bytes:
     return bytes(t.numpy().tobytes())
 
 
-class DistributedRaster:
-    """The row block of this rank plus the communicator; ``upstream_area()`` is collective."""
+def _try_rccl(uid, rank, world, device, timeout):
+    """Create the RCCL communicator in a watchdog thread: a bootstrap that cannot reach its peers
+    blocks forever instead of failing."""
+    import threading
 
-    def __init__(self, d8_block, own_rows: int, ncol: int, rank: int, world: int, device: int, uid: bytes,
-                 memspace=_hip.PFD_HOST):
-        self.rank, self.world, self.device = rank, world, device
+    box = {}
+
+    def work():
+        try:
+            box["comm"] = _hip.Communicator(uid, rank, world, device)
+        except Exception as exc:  # noqa: BLE001 - any failure means "use the host transport"
+            box["err"] = exc
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout)
+    return box.get("comm")
+
+
+class DistributedRaster:
+    """The row block of this rank; ``upstream_area()`` is collective over the process group.
+
+    transport="rccl": one ``ncclAllGather`` of the 4*ncol-word boundary record over xGMI (default).
+    transport="host": the same record travels through ``torch.distributed.all_gather`` (any backend);
+    identical kernels on either side of the exchange (split-phase C-ABI).  With transport="auto" RCCL
+    is tried first and every rank falls back to "host" if any rank could not create its communicator.
+    """
+
+    def __init__(self, d8_block, own_rows: int, ncol: int, rank: int, world: int, device: int,
+                 memspace=_hip.PFD_HOST, transport="auto", group=None, rccl_timeout=120.0):
+        import torch
+        import torch.distributed as dist
+
+        self.rank, self.world, self.device, self.group = rank, world, device, group
         self.handle = _hip.RasterHandle(d8_block, own_rows, ncol, device=device, memspace=memspace,
                                         halo=halo_of(rank, world))
-        self.comm = _hip.Communicator(uid, rank, world, device)
+        self.comm = None
+        if transport in ("auto", "rccl") and world >= 1:
+            uid = exchange_unique_id(rank, world, group)
+            self.comm = _try_rccl(uid, rank, world, device, rccl_timeout)
+            ok = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int32)
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok[0]) == 0:
+                if transport == "rccl":
+                    raise RuntimeError("RCCL communicator could not be created on every rank")
+                self.comm = None  # a created communicator is simply not used
+        self.transport = "rccl" if self.comm is not None else "host"
 
     def upstream_area(self, out=None, memspace=_hip.PFD_HOST):
-        res = self.comm.upstream_area_cell(self.handle, out=out, memspace=memspace)
+        if self.comm is not None:
+            res = self.comm.upstream_area_cell(self.handle, out=out, memspace=memspace)
+        else:
+            import torch
+            import torch.distributed as dist
+
+            res, rec = _hip.upstream_area_cell_begin(self.handle, out=out, memspace=memspace)
+            mine = torch.from_numpy(rec.view(np.int32).copy())
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            if self.world > 1:
+                dist.all_gather(parts, mine, group=self.group)
+            else:
+                parts = [mine]
+            allrec = np.stack([p.numpy().view(np.uint32) for p in parts])
+            ok = _hip.upstream_area_cell_finish(self.handle, allrec, self.world, self.rank)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if self.world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if int(flag[0]) == 0:
+                raise NotImplementedError("the raster holds cells that never reach a pit (cycles); the multi-GPU "
+                                          "path requires a valid flow direction raster (FlwdirRaster.isvalid)")
         return res.reshape(self.handle.nrow, self.handle.ncol) if memspace == _hip.PFD_HOST else res
 
     def close(self):
         self.handle.close()
-        self.comm.close()
+        if self.comm is not None:
+            self.comm.close()

@@ -53,3 +53,25 @@ def test_blocks_reject_cycles(gpu_lib, oracle):
     d8[100, 50], d8[100, 51] = 1, 16
     with pytest.raises(NotImplementedError, match="cycles"):
         dist.upstream_area_blocks(d8, 2)
+
+
+def test_split_phase_api(gpu_lib, oracle):
+    """begin()/finish(): the caller moves the boundary records itself (host transport of the multi-GPU path)."""
+    from pyflwdir_amd import _hip, dist
+
+    d8 = oracle.synth_d8(500, 640, seed=17, tilt=100000, white=2, nodata_pct=15)
+    exp, _, _ = oracle.upstream_area_cell(d8)
+    nb = 3
+    handles, outs, recs = [], [], []
+    for b, (r0, r1) in enumerate(dist.block_rows(d8.shape[0], nb)):
+        a, e = dist.block_slice(d8.shape[0], nb, b)
+        handles.append(_hip.RasterHandle(d8[a:e], r1 - r0, d8.shape[1], halo=dist.halo_of(b, nb)))
+    for h in handles:
+        o, r = _hip.upstream_area_cell_begin(h)
+        outs.append(o)
+        recs.append(r)
+    allrec = np.stack(recs)
+    for b, h in enumerate(handles):
+        assert _hip.upstream_area_cell_finish(h, allrec, nb, b)
+    got = np.concatenate([o.reshape(-1, d8.shape[1]) for o in outs])
+    assert np.array_equal(got, exp)
