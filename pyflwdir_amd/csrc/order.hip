@@ -18,44 +18,83 @@ int pfd_export_u32(pfd_raster *h, const u32 *src, i64 m, int idx_dtype, void *ou
 enum { C_NVALID = 0, C_NPITS = 1, C_BAD = 2, C_TAIL = 3, C_DONE = 4, C_AUX = 5 };
 
 // ---------------------------------------------------------------------------------------------
-// normalise: one thread per cell, 2-D indexing (no division).  Writes ncode, counts valid cells
-// and pits, flags values outside the D8 alphabet (core_d8._all, pyflwdir/core_d8.py:19).
+// normalise: decode + pit rule + validation + counts in one streaming pass.  A thread owns 4
+// consecutive cells of a row and works from three unconditional 8-byte window loads (rows r-1,
+// r, r+1, columns c-1 .. c+6; clamped addresses, validity applied afterwards) so that no load
+// depends on another; the 4 normalised codes leave as one dword store.
+// Flags values outside the D8 alphabet (core_d8._all, pyflwdir/core_d8.py:19).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 load_window8(const u8 *__restrict__ p, size_t off, size_t n) {
+  u64 w = 0;
+  if (off + 8 <= n) {
+    __builtin_memcpy(&w, p + off, 8);
+  } else {  // last bytes of the raster: stay inside the caller's buffer
+    for (int b = 0; b < 8; ++b)
+      if (off + b < n) w |= (u64)p[off + b] << (8 * b);
+  }
+  return w;
+}
+
 __global__ void __launch_bounds__(256) k_normalise(const u8 *__restrict__ d8, Geo g, u8 *__restrict__ ncode,
                                                    u64 *__restrict__ ctrl, u32 row_first, u32 row_last) {
-  // one block = a 64-column x 64-row patch, 4 rows per pass
-  const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
+  // one block = 256 columns (64 lanes x 4 cells) x 16 rows (4 waves x 4 passes)
+  const u32 c0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const size_t n = (size_t)g.nrow * g.ncol;
   u32 valid = 0, pit = 0, bad = 0;
-  for (u32 pass = 0; pass < 16; ++pass) {
-    const u32 r = blockIdx.y * 64 + pass * 4 + (threadIdx.x >> 6);
-    if (r < g.nrow && c < g.ncol) {
-      const size_t i = (size_t)r * g.ncol + c;
-      const u32 code = d8[i];
-      u32 out = code;
-      if (code == D8_MV) {
-        out = D8_MV;
-      } else if (r < row_first || r > row_last) {
-        // halo row of a row block: the cell belongs to the neighbouring block; here it is a
-        // weightless sink that collects the flow leaving this block
-        out = ((code & (code - 1)) == 0u || code == 255u) ? D8_HALO : D8_MV;
-        if (out == D8_MV) ++bad;
-      } else if (code == 0u || code == 255u) {
-        out = 0;
-        ++valid;
-        ++pit;
-      } else if ((code & (code - 1)) == 0u) {  // one of the eight direction codes
-        ++valid;
-        const int k = d8_slot(code);
-        const u32 rr = r + (u32)d8_dr(k), cc = c + (u32)d8_dc(k);
-        if (rr >= g.nrow || cc >= g.ncol || d8[(size_t)rr * g.ncol + cc] == D8_MV) {
-          out = 0;  // drains off the raster or into nodata -> pit (core_d8.py:57-63)
+  for (u32 pass = 0; pass < 4; ++pass) {
+    const u32 r = blockIdx.y * 16 + pass * 4 + (threadIdx.x >> 6);
+    if (r >= g.nrow || c0 >= g.ncol) continue;
+    // windows: byte k of win[j] = column c0 - 1 + k of row r - 1 + j
+    const u32 cstart = c0 ? c0 - 1 : 0;
+    u64 win[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const u32 rr = (u32)min(max((int)r - 1 + j, 0), (int)g.nrow - 1);
+      u64 w = load_window8(d8, (size_t)rr * g.ncol + cstart, n);
+      if (!c0) w <<= 8;  // column -1 does not exist: the window started at column 0
+      win[j] = w;
+    }
+    u32 out4 = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const u32 c = c0 + b;
+      u32 out = D8_MV;
+      if (c < g.ncol) {
+        const u32 code = (u32)(win[1] >> (8 * (b + 1))) & 0xFFu;
+        out = code;
+        if (code == D8_MV) {
+          out = D8_MV;
+        } else if (r < row_first || r > row_last) {
+          // halo row of a row block: the cell belongs to the neighbouring block; here it is a
+          // weightless sink that collects the flow leaving this block
+          out = ((code & (code - 1)) == 0u || code == 255u) ? D8_HALO : D8_MV;
+          if (out == D8_MV) ++bad;
+        } else if (code == 0u || code == 255u) {
+          out = 0;
+          ++valid;
           ++pit;
+        } else if ((code & (code - 1)) == 0u) {  // one of the eight direction codes
+          ++valid;
+          const int k = d8_slot(code);
+          const int dr = d8_dr(k), dc = d8_dc(k);
+          const u32 rr = r + (u32)dr, cc = c + (u32)dc;
+          const u32 tcode = (u32)(win[1 + dr] >> (8 * (b + 1 + dc))) & 0xFFu;
+          if (rr >= g.nrow || cc >= g.ncol || tcode == D8_MV) {
+            out = 0;  // drains off the raster or into nodata -> pit (core_d8.py:57-63)
+            ++pit;
+          }
+        } else {
+          ++bad;
+          out = D8_MV;
         }
-      } else {
-        ++bad;
-        out = D8_MV;
       }
-      ncode[i] = (u8)out;
+      out4 |= out << (8 * b);
+    }
+    u8 *dst = ncode + (size_t)r * g.ncol + c0;
+    if (c0 + 3 < g.ncol) {
+      __builtin_memcpy(dst, &out4, 4);  // (possibly unaligned) dword store
+    } else {
+      for (u32 b = 0; b < 4 && c0 + b < g.ncol; ++b) dst[b] = (u8)(out4 >> (8 * b));
     }
   }
   // block reduction -> at most 3 atomics per block, spread over 16 counter copies
@@ -186,12 +225,13 @@ static int alloc_pits(pfd_raster *h) {
 }
 
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
-  if (cdiv_u32((u64)h->nrow, 64) > 65535u) {
-    pfd_set_error("rasters with more than %d rows per handle are not supported", 65535 * 64);
+  if (cdiv_u32((u64)h->nrow, 16) > 65535u) {
+    pfd_set_error("rasters with more than %d rows per handle are not supported", 65535 * 16);
     return PFD_EUNSUPPORTED;
   }
   HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
-  dim3 grid(cdiv_u32((u64)h->ncol, 64), cdiv_u32((u64)h->nrow, 64));
+  const u32 gy = cdiv_u32((u64)h->nrow, 16);
+  dim3 grid(cdiv_u32((u64)h->ncol, 256), gy);
   k_normalise<<<grid, 256, 0, h->stream>>>(d8_dev, h->geo, h->ncode, h->ctrl, (u32)h->halo_top,
                                            (u32)(h->halo_top + h->own_rows - 1));
   KCHK();

@@ -1,21 +1,50 @@
-"""Timing of the other hot-path operations (level engine) on a synthetic raster, device-resident."""
+"""Timing of the other hot-path operations on a synthetic raster, everything device-resident.
+
+    python tools/bench_ops.py NROW NCOL [nodata_pct] [tilt]
+
+Prints one line per operation: wall time of a complete call (HIP work + host launch loop) and
+Mcells/s over all raster cells.  Used for the C3/C5-shaped measurements quoted in DESIGN.md."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
 from pyflwdir_amd import _hip
 L = _hip.lib()
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-d8 = _hip.synth_d8_device(n, n, seed=0)
-w = _hip.synth_weights_device(n * n, seed=1)
-out4 = _hip.DeviceBuffer(n * n * 4)
-out1 = _hip.DeviceBuffer(n * n)
+nrow = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+ncol = int(sys.argv[2]) if len(sys.argv) > 2 else nrow
+nd = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+tilt = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 26
+n = nrow * ncol
+kw = dict(seed=0, tilt=tilt, white=2, nodata_pct=nd)
+d8 = _hip.synth_d8_device(nrow, ncol, **kw)
 def sync(): _hip.check(L.pfd_device_synchronize(0))
-h = _hip.RasterHandle(d8, n, n, device=0, memspace=_hip.PFD_DEVICE)
-h.set_profiling(True)
+def timed(name, fn, reps=2):
+    fn(); sync(); t0 = time.perf_counter()
+    for _ in range(reps - 1): fn()
+    sync(); t1 = time.perf_counter()
+    dt = (t1 - t0) / max(1, reps - 1)
+    print(f"{name:22s} {1e3*dt:10.2f} ms  {n/dt/1e6:10.1f} Mcells/s", flush=True)
+sync(); t0 = time.perf_counter()
+h = _hip.RasterHandle(d8, nrow, ncol, device=0, memspace=_hip.PFD_DEVICE)
+sync(); t1 = time.perf_counter()
+print(f"raster {nrow}x{ncol} nodata_pct={nd} tilt={tilt}: create {1e3*(t1-t0):.2f} ms, {h.info()}")
+out4 = _hip.DeviceBuffer(n * 4)
+timed("upstream_area(cell)", lambda: h.upstream_area_cell(out=out4, memspace=_hip.PFD_DEVICE))
 sync(); t0 = time.perf_counter(); h.order_cells(); sync(); t1 = time.perf_counter()
-print(f"order_cells   {1e3*(t1-t0):9.2f} ms  levels={h.info()['n_levels']}", h.last_timing())
-for name, fn in [("accuflux_f32", lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out4, memspace=_hip.PFD_DEVICE)),
-                 ("strahler", lambda: h.strahler(None, out=out1, memspace=_hip.PFD_DEVICE)),
-                 ("count_levels", lambda: h.upstream_area_cell(out=out4, memspace=_hip.PFD_DEVICE, engine="levels"))]:
-    fn(); sync(); t0 = time.perf_counter(); fn(); sync(); t1 = time.perf_counter()
-    print(f"{name:13s} {1e3*(t1-t0):9.2f} ms  {n*n/(t1-t0)/1e6:9.1f} Mcells/s")
+info = h.info()
+print(f"{'order_cells':22s} {1e3*(t1-t0):10.2f} ms  {n/(t1-t0)/1e6:10.1f} Mcells/s  levels={info['n_levels']} n_seq={info['n_seq']} "
+      f"n_pits={info['n_pits']} bytes_held={info['bytes_held']/1e9:.2f} GB", flush=True)
+w = _hip.synth_weights_device(n, seed=1)
+timed("accuflux f32 (up)", lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out4, memspace=_hip.PFD_DEVICE))
+timed("accuflux f32 (down)", lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, direction=_hip.PFD_DOWN, out=out4, memspace=_hip.PFD_DEVICE))
+out1 = _hip.DeviceBuffer(n)
+timed("strahler", lambda: h.strahler(None, out=out1, memspace=_hip.PFD_DEVICE))
+# basins from 1000 outlets: the pits + evenly spread cells (ids 1..k)
+k = 1000
+idxs = (np.arange(k, dtype=np.int64) * (n // k) + ncol // 2) % n
+ids = np.arange(1, k + 1, dtype=np.uint32)
+timed("basins (1000 outlets)", lambda: h.basins(idxs, ids, out=out4, memspace=_hip.PFD_DEVICE))
+del w
+elev = _hip.synth_elev_device(nrow, ncol, **kw)
+out8 = _hip.DeviceBuffer(n * 8)
+drain = out1  # strahler order as a stand-in stream mask (value 1 = drain: the headwater cells... any uint8 works)
+timed("hand f32->f64", lambda: h.hand(drain, elev, _hip.PFD_F32, out=out8, memspace=_hip.PFD_DEVICE))
