@@ -221,6 +221,9 @@ int pfd_order_cells_impl(pfd_raster *h);                        // order.hip
 int pfd_ensure_pits(pfd_raster *h);                             // order.hip
 int pfd_require_whole(pfd_raster *h, const char *what);          // order.hip
 void pfd_free_pending(pfd_raster *h);                            // dist.hip
+int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
+int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev,
+                     int *ok);                                   // paths.hip
 int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete);  // tiled.hip
 
 static inline u32 cdiv_u32(u64 a, u32 b) { return (u32)((a + b - 1) / b); }

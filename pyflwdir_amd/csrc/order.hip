@@ -8,6 +8,8 @@
 //   core.idxs_seq             pyflwdir/core.py:87-117     -> k_bfs_level (level sets) and
 //                                                            k_oseq_* (exact BFS order on request)
 //   core.rank                 pyflwdir/core.py:17-47      -> k_rank_from_levels
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -434,8 +436,18 @@ __global__ void __launch_bounds__(256) k_bfs_level(const u8 *__restrict__ ncode,
 
 int pfd_order_cells_impl(pfd_raster *h) {
   if (h->ordered) return PFD_OK;
+  PFDCHK(pfd_require_whole(h, "the cell ordering"));
+  if (!getenv("PFD_ORDER_BFS")) {
+    // fast path: ranks by LDS-tiled pointer doubling + one radix sort of the cells by rank
+    // (paths.hip); rasters with cycles fall through to the breadth-first build below
+    int ok = 0;
+    pfd_seg_begin(h, "order_cells_by_rank");
+    PFDCHK(pfd_order_cells_by_rank(h, &ok));
+    pfd_seg_end(h, 4);
+    if (ok) return PFD_OK;
+  }
   PFDCHK(pfd_ensure_pits(h));
-  if (!h->seq) {
+  if (!h->seq) {  // (a buffer left by an abandoned rank-sort attempt holds n >= n_valid entries)
     PFDCHK(pfd_dmalloc((void **)&h->seq, (size_t)h->n_valid * sizeof(u32)));
     h->bytes_held += (size_t)h->n_valid * sizeof(u32);
   }

@@ -1,0 +1,459 @@
+// paths.hip — LDS-tiled PATH queries by pointer doubling: "how far is the pit" (rank) and
+// "which is the first outlet downstream" (basin labels).  Both are properties of the path from
+// a cell to its pit, both are pure integer/copy operations (bit-exact in any order), and both
+// use the two-pass tile scheme of tiled.hip with GATHER-only doubling (no atomics at all):
+//
+//     rank :  V_0(z) = 1 (0 at the path end),  V(z) += V(J(z)),  J(z) = J(J(z))
+//     label:  outlets are absorbing path ends;  after saturation J(z) = first outlet or the end
+//
+//   pass 1  k_path<MODE, false>  per 64x64 tile in LDS; per perimeter slot: the slot an exit drains
+//                                 into, and for an entry the exit its in-tile path reaches plus the
+//                                 hops to it (rank) / the outlet met on the way (label)
+//   exits   k_xinit + k_xround    the exits form chains; the same gather doubling over them gives
+//                                 every exit its rank / its first outlet
+//   pass 2  k_path<MODE, true>    per tile again: every cell = own in-tile part + its exit's value
+//
+// Replaces, on rasters without cycles:
+//   core.rank                 pyflwdir/core.py:17-47   (and, with a radix sort of the cells by rank,
+//   core.idxs_seq             pyflwdir/core.py:87-117   the level structure of the level engine)
+//   basins.basins             pyflwdir/basins.py:12-18 + core.fillnodata_upstream core.py:120-146
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+#include "tiled.h"
+
+enum { MODE_RANK = 0, MODE_LABEL = 1 };
+enum { P_UNSAT = 8, P_XACTIVE = 10, P_MAXRANK = 13 };  // ctrl slots (u64)
+#define KEY_INVALID 0xFFFFFFFFu
+
+struct PathArgs {
+  const u8 *ncode;
+  u32 nrow, ncol, ntr, ntc, nstc;
+  u32 *xtgt;        // [nslots] slot the exit on this slot drains into, NONE32 if no exit
+  u32 *elink;       // [nslots] entry: slot of the exit its in-tile path reaches, NONE32 if it ends in the tile
+  u32 *eval;        // [nslots] entry: hops to the end of its in-tile path (rank) / outlet met there (label)
+  const u32 *xres;  // [nslots] pass 2: rank of the exit cell / outlet the exit finally reaches
+  const u32 *seed;  // [n] label mode: outlet number (1-based) seeded on the cell, 0 = none
+  u32 *out;         // [n] pass 2: rank (KEY_INVALID on nodata) / outlet number per cell
+  u64 *ctrl;
+};
+
+template <int MODE, bool FINAL>
+__global__ void __launch_bounds__(256) k_path(PathArgs a) {
+  __shared__ __attribute__((aligned(16))) u32 V[TCELLS];       // rank: hops so far; label: seed number
+  __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2^k-th ancestor | PDONE once saturated
+  __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
+  const u32 tid = threadIdx.x;
+  const u32 tc = blockIdx.x, tr = blockIdx.y;
+  const u32 sbase = sslot_base(tr, tc, a.nstc);
+  const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
+  {
+    u32 v[5];
+    stage_load(a.ncode, a.nrow, a.ncol, r0, c0, tid, v);
+    stage_store(code, tid, v);
+  }
+  __syncthreads();
+
+  // ---- initial pointers / values -----------------------------------------------------------------
+  u32 pc[QPT * 4];
+  u32 live = 0;
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const int lr = l0 >> 6, lc0 = l0 & 63;
+    const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+    u32 s4[4] = {0, 0, 0, 0};
+    if (MODE == MODE_LABEL) {  // outlets seeded on the cells of this quad (nodata cells may be seeded too)
+      const i64 gr = r0 + lr, gc0 = c0 + lc0;
+      const i64 crr = gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr;
+      const i64 ccs = gc0 >= (i64)a.ncol ? (i64)a.ncol - 1 : gc0;
+      // unconditional 16-byte load from a clamped address (the seed array carries slack past its end)
+      __builtin_memcpy(s4, a.seed + (size_t)crr * a.ncol + (size_t)ccs, 16);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (gr >= (i64)a.nrow || gc0 + b >= (i64)a.ncol) s4[b] = 0;
+    }
+    u32 v4[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const u32 c = (c4 >> (8 * b)) & 0xFFu;
+      const u32 l = l0 + b;
+      u32 p = l | PDONE;
+      if (d8_is_dir(c) && !(MODE == MODE_LABEL && s4[b])) {  // an outlet is the end of its path
+        const int k = d8_slot(c);
+        const int nr = lr + d8_dr(k), nc = lc0 + b + d8_dc(k);
+        if ((unsigned)nr < TS && (unsigned)nc < TS) p = (u32)(nr * TS + nc);
+      }
+      pc[4 * j + b] = p;
+      if (!(p & PDONE)) live |= 1u << (4 * j + b);
+      v4[b] = (MODE == MODE_RANK) ? ((p & PDONE) ? 0u : 1u) : s4[b];
+    }
+    *(uint4 *)&V[l0] = make_uint4(v4[0], v4[1], v4[2], v4[3]);
+    *(uint2 *)&P[l0] = make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
+  }
+  __syncthreads();
+
+  // ---- gather doubling ---------------------------------------------------------------------------
+  for (int round = 0; round < MAXROUNDS_TILE; ++round) {
+    u32 q[QPT * 4], dv[QPT * 4];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (live & (1u << (4 * j + b))) {
+          q[4 * j + b] = P[pc[4 * j + b]];
+          if (MODE == MODE_RANK) dv[4 * j + b] = V[pc[4 * j + b]];
+        }
+      }
+    }
+    __syncthreads();  // every read of this round precedes every write of this round
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+      if (live & (0xFu << (4 * j))) {
+        const u32 l0 = 4u * tid + 1024u * j;
+        uint4 v4;
+        if (MODE == MODE_RANK) v4 = *(const uint4 *)&V[l0];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (live & (1u << (4 * j + b))) {
+            if (MODE == MODE_RANK) ((u32 *)&v4)[b] += dv[4 * j + b];
+            pc[4 * j + b] = q[4 * j + b];
+            if (q[4 * j + b] & PDONE) live &= ~(1u << (4 * j + b));
+          }
+        }
+        if (MODE == MODE_RANK) *(uint4 *)&V[l0] = v4;
+        *(uint2 *)&P[l0] = make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
+      }
+    }
+    if (!__syncthreads_or((int)live)) break;
+  }
+  if (live) atomicAdd((unsigned long long *)&a.ctrl[P_UNSAT], (unsigned long long)__popc(live));  // cycles
+  __syncthreads();
+
+  // is the end of an in-tile path an exit?  -> its slot, else NONE32
+  auto exit_slot_of = [&](u32 root) -> u32 {
+    const int rr = root >> 6, rc = root & 63;
+    const u32 cr = CODE(rr, rc);
+    if (d8_is_dir(cr) && !(MODE == MODE_LABEL && V[root])) {
+      const int k = d8_slot(cr);
+      const int nr = rr + d8_dr(k), nc = rc + d8_dc(k);
+      if ((unsigned)nr >= TS || (unsigned)nc >= TS) return sbase + (u32)pslot(rr, rc);
+    }
+    return NONE32;
+  };
+
+  if (FINAL) {
+    u32 mx = 0;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+      const u32 l0 = 4u * tid + 1024u * j;
+      const int lr = l0 >> 6, lc0 = l0 & 63;
+      const i64 gr = r0 + lr, gc0 = c0 + lc0;
+      if (gr >= (i64)a.nrow || gc0 >= (i64)a.ncol) continue;
+      const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+      u32 o4[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const u32 c = (c4 >> (8 * b)) & 0xFFu;
+        const u32 l = l0 + b;
+        const u32 root = P[l] & 0xFFFu;
+        u32 val;
+        if (MODE == MODE_RANK) {
+          val = KEY_INVALID;
+          if (c != D8_MV) {
+            val = V[l];
+            const u32 xs = exit_slot_of(root);
+            if (xs != NONE32) val += a.xres[xs];
+            mx = max(mx, val);
+          }
+        } else {
+          val = V[root];  // outlet at the end of the in-tile path (also: the cell's own seed)
+          if (!val && c != D8_MV) {
+            const u32 xs = exit_slot_of(root);
+            if (xs != NONE32) val = a.xres[xs];
+          }
+        }
+        o4[b] = val;
+      }
+      u32 *dst = a.out + (size_t)gr * a.ncol + (size_t)gc0;
+      if (gc0 + 3 < (i64)a.ncol && (((size_t)dst) & 15) == 0) {
+        *(uint4 *)dst = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (gc0 + b < (i64)a.ncol) dst[b] = o4[b];
+      }
+    }
+    if (MODE == MODE_RANK) {
+      for (int o = 32; o > 0; o >>= 1) mx = max(mx, (u32)__shfl_down(mx, o));
+      if ((tid & 63) == 0 && mx) atomicMax((unsigned long long *)&a.ctrl[P_MAXRANK], (unsigned long long)mx);
+    }
+    return;
+  }
+
+  // ---- pass 1: perimeter records ------------------------------------------------------------------
+  if (tid < PSL) {
+    u32 tgt = NONE32, link = NONE32, ev = 0;
+    if (tid < NPERIM) {
+      int plr, plc;
+      pslot_inv((int)tid, &plr, &plc);
+      const u32 l = (u32)(plr * TS + plc);
+      const u32 c = CODE(plr, plc);
+      if (c != D8_MV) {
+        if (d8_is_dir(c) && !(MODE == MODE_LABEL && V[l])) {  // exit?
+          const int k = d8_slot(c);
+          const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
+          if ((unsigned)nr >= TS || (unsigned)nc >= TS) {
+            const i64 gr = r0 + nr, gc = c0 + nc;
+            tgt = sslot_base((u32)(gr >> 6), (u32)(gc >> 6), a.nstc) + (u32)pslot((int)(gr & 63), (int)(gc & 63));
+          }
+        }
+        bool entry = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
+          if (((unsigned)nr >= TS || (unsigned)nc >= TS) && CODE(nr, nc) == (1u << ((k + 4) & 7))) entry = true;
+        }
+        if (entry) {
+          const u32 root = P[l] & 0xFFFu;
+          link = exit_slot_of(root);
+          ev = (MODE == MODE_RANK) ? V[l] : V[root];
+        }
+      }
+    }
+    a.xtgt[sbase + tid] = tgt;
+    a.elink[sbase + tid] = link;
+    a.eval[sbase + tid] = ev;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exit chains: W(e) = value accumulated from exit e to the end of its path, J(e) = next exit
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flag_active_p(u64 *ctrl) {
+  const u64 m = __ballot(1);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+    if (__hip_atomic_load(&ctrl[P_XACTIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+      __hip_atomic_store(&ctrl[P_XACTIVE], (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_xinit(const u32 *__restrict__ xtgt, const u32 *__restrict__ elink,
+                                               const u32 *__restrict__ eval, u32 *__restrict__ W,
+                                               u32 *__restrict__ J, u32 nslots, u64 *ctrl) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  const u32 q = xtgt[s];
+  u32 w = 0, j = s | XDONE;
+  if (q != NONE32) {
+    const u32 l = elink[q];
+    if (MODE == MODE_RANK) {
+      w = 1 + eval[q];  // one hop into the next tile + the hops to the end of the path in there
+      if (l != NONE32) j = l;
+    } else {
+      w = eval[q];  // outlet met inside the next tile (0: none)
+      if (!w && l != NONE32) j = l;
+    }
+  }
+  W[s] = w;
+  J[s] = j;
+  if (!(j & XDONE)) flag_active_p(ctrl);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_xround(const u32 *__restrict__ Wo, u32 *__restrict__ Wn,
+                                                const u32 *__restrict__ Jo, u32 *__restrict__ Jn, u32 nslots,
+                                                u64 *ctrl) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  const u32 j = Jo[s];
+  u32 w = Wo[s];
+  if (j & XDONE) {
+    Wn[s] = w;
+    Jn[s] = j;
+    return;
+  }
+  const u32 wj = Wo[j];
+  u32 q = Jo[j];
+  if (MODE == MODE_RANK) {
+    w += wj;
+  } else if (wj) {  // the first outlet on the path wins; the chain ends there
+    w = wj;
+    q = s | XDONE;
+  }
+  Wn[s] = w;
+  Jn[s] = q;
+  if (!(q & XDONE)) flag_active_p(ctrl);
+}
+
+// one complete path query; on return *complete = 0 means cycles were found (caller falls back)
+template <int MODE>
+static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *complete, u32 *maxrank) {
+  *complete = 0;
+  const u32 ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
+  const u32 nstc = cdiv_u32(ntc, SG);
+  const size_t nslots = (size_t)cdiv_u32(ntr, SG) * nstc * SSL;
+  if (nslots >= 0x3FFFFFFFull || ntr > 65535u) return PFD_OK;
+  DevBuf buf;
+  PFDCHK(buf.alloc(7 * nslots * sizeof(u32)));
+  u32 *b = buf.as<u32>();
+  u32 *xtgt = b, *elink = b + nslots, *eval = b + 2 * nslots;
+  u32 *Wc = b + 3 * nslots, *Wn = b + 4 * nslots, *Jc = b + 5 * nslots, *Jn = b + 6 * nslots;
+  HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 8 * sizeof(u64), h->stream));
+  HIPCHK(hipMemsetAsync(xtgt, 0xFF, nslots * sizeof(u32), h->stream));  // slots of tiles that do not exist
+  PathArgs a{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, h->ctrl};
+  const dim3 grid(ntc, ntr);
+  i64 launches = 2;
+  k_path<MODE, false><<<grid, 256, 0, h->stream>>>(a);
+  const u32 sgrid = cdiv_u32(nslots, 256);
+  k_xinit<MODE><<<sgrid, 256, 0, h->stream>>>(xtgt, elink, eval, Wc, Jc, (u32)nslots, h->ctrl);
+  KCHK();
+  bool done = false;
+  int batch = 2;
+  for (u32 span = 1; span < ntr + ntc; span <<= 1) ++batch;
+  for (int rounds = 0; rounds < 40 && !done;) {
+    u64 zero = 0;
+    HIPCHK(hipMemcpyAsync(h->ctrl + P_XACTIVE, &zero, sizeof(u64), hipMemcpyHostToDevice, h->stream));
+    for (int r = 0; r < batch; ++r, ++rounds) {
+      k_xround<MODE><<<sgrid, 256, 0, h->stream>>>(Wc, Wn, Jc, Jn, (u32)nslots, h->ctrl);
+      std::swap(Wc, Wn);
+      std::swap(Jc, Jn);
+      ++launches;
+    }
+    KCHK();
+    // the flag raised by the LAST round of the batch decides; earlier rounds may have raised it too,
+    // which only costs one more (idempotent) batch
+    u64 active = 0;
+    HIPCHK(hipMemcpyAsync(&active, h->ctrl + P_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    done = active == 0;
+    batch = 2;
+  }
+  a.xres = Wc;
+  k_path<MODE, true><<<grid, 256, 0, h->stream>>>(a);
+  KCHK();
+  u64 c[6];
+  HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *complete = done && c[P_UNSAT - 8] == 0;
+  if (maxrank) *maxrank = (u32)c[P_MAXRANK - 8];
+  (void)launches;
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cell ordering from ranks: keys = rank, stable radix sort of the cell indices by key => cells
+// grouped by rank, ascending index inside a rank (level 0 = the pits in ascending order)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_iota(u32 *__restrict__ v, u32 n) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+__global__ void k_clamp_keys(u32 *__restrict__ k, u32 n, u32 inval) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && k[i] > inval) k[i] = inval;
+}
+__global__ void k_level_offsets(const u32 *__restrict__ keys, u32 nseq, i64 *__restrict__ lvl_off) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseq) return;
+  const u32 k = keys[i];
+  if (i == 0 || keys[i - 1] != k) lvl_off[k] = (i64)i;  // ranks are contiguous 0..max
+}
+
+// returns *ok = 1 if the level structure (h->seq, h->lvl_off) was built this way
+int pfd_order_cells_by_rank(pfd_raster *h, int *ok) {
+  *ok = 0;
+  const u32 n = h->geo.n;
+  DevBuf keys, keys2, vals;
+  PFDCHK(keys.alloc((size_t)n * sizeof(u32)));
+  int complete = 0;
+  u32 maxrank = 0;
+  PFDCHK(run_paths<MODE_RANK>(h, nullptr, keys.as<u32>(), &complete, &maxrank));
+  if (!complete) return PFD_OK;  // cycles (or raster too large for the slot ids): breadth-first build instead
+  PFDCHK(keys2.alloc((size_t)n * sizeof(u32)));
+  PFDCHK(vals.alloc((size_t)n * sizeof(u32)));
+  if (h->seq) {  // sorted values need n entries (nodata cells sort to the tail)
+    pfd_dfree(h->seq);
+    h->bytes_held -= (size_t)h->n_valid * sizeof(u32);
+    h->seq = nullptr;
+  }
+  PFDCHK(pfd_dmalloc((void **)&h->seq, (size_t)n * sizeof(u32)));
+  h->bytes_held += (size_t)n * sizeof(u32);
+  k_iota<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(vals.as<u32>(), n);
+  KCHK();
+  // nodata keys (0xFFFFFFFF) become maxrank+1, so that sorting on the low `bits` bits is enough
+  int bits = 1;
+  while ((1ull << bits) <= (u64)maxrank + 1) ++bits;
+  k_clamp_keys<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(keys.as<u32>(), n, maxrank + 1);
+  KCHK();
+  size_t tmp_bytes = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<u32>(), keys2.as<u32>(), vals.as<u32>(), h->seq, (size_t)n,
+                                   0u, (unsigned)bits, h->stream));
+  DevBuf tmp;
+  PFDCHK(tmp.alloc(tmp_bytes));
+  HIPCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<u32>(), keys2.as<u32>(), vals.as<u32>(), h->seq, (size_t)n, 0u,
+                                   (unsigned)bits, h->stream));
+  const i64 nlev = (i64)maxrank + 1;
+  DevBuf lo;
+  PFDCHK(lo.alloc((size_t)(nlev + 1) * sizeof(i64)));
+  k_level_offsets<<<cdiv_u32((u64)h->n_valid, 256), 256, 0, h->stream>>>(keys2.as<u32>(), (u32)h->n_valid, lo.as<i64>());
+  KCHK();
+  h->lvl_off.assign((size_t)nlev + 1, 0);
+  HIPCHK(hipMemcpyAsync(h->lvl_off.data(), lo.p, (size_t)nlev * sizeof(i64), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->lvl_off[nlev] = h->n_valid;
+  h->n_levels = nlev;
+  h->n_seq = h->n_valid;
+  h->ordered = true;
+  *ok = 1;
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// basins through the tiled label query; *ok = 0 -> caller uses the level engine
+// ---------------------------------------------------------------------------------------------
+__global__ void k_seed_numbers(const i64 *__restrict__ idx, u32 k, u32 *__restrict__ seed) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < k) seed[idx[t]] = t + 1;
+}
+template <class L>
+__global__ void k_labels_out(const u32 *__restrict__ num, const L *__restrict__ ids, u32 n, L *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 v = num[i];
+  out[i] = v ? ids[v - 1] : (L)0;
+}
+
+int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev, int *ok) {
+  *ok = 0;
+  if (h->n > 4294967294ll || h->halo_top || h->halo_bot) return PFD_OK;
+  const u32 n = h->geo.n;
+  DevBuf seed, num;
+  PFDCHK(seed.alloc((size_t)n * sizeof(u32) + 64));  // + slack: quads are loaded 16 bytes at a time
+  PFDCHK(num.alloc((size_t)n * sizeof(u32)));
+  HIPCHK(hipMemsetAsync(seed.p, 0, (size_t)n * sizeof(u32), h->stream));
+  if (k) {
+    k_seed_numbers<<<cdiv_u32(k, 256), 256, 0, h->stream>>>(idx_dev, k, seed.as<u32>());
+    KCHK();
+  }
+  int complete = 0;
+  pfd_seg_begin(h, "tile_labels");
+  PFDCHK(run_paths<MODE_LABEL>(h, seed.as<u32>(), num.as<u32>(), &complete, nullptr));
+  pfd_seg_end(h, 2);
+  if (!complete) return PFD_OK;
+  const u32 grid = cdiv_u32(n, 256);
+  switch (id_size) {
+    case 1: k_labels_out<u8><<<grid, 256, 0, h->stream>>>(num.as<u32>(), (const u8 *)ids_dev, n, (u8 *)out_dev); break;
+    case 2: k_labels_out<uint16_t><<<grid, 256, 0, h->stream>>>(num.as<u32>(), (const uint16_t *)ids_dev, n, (uint16_t *)out_dev); break;
+    case 4: k_labels_out<u32><<<grid, 256, 0, h->stream>>>(num.as<u32>(), (const u32 *)ids_dev, n, (u32 *)out_dev); break;
+    default: k_labels_out<u64><<<grid, 256, 0, h->stream>>>(num.as<u32>(), (const u64 *)ids_dev, n, (u64 *)out_dev); break;
+  }
+  KCHK();
+  *ok = 1;
+  return PFD_OK;
+}

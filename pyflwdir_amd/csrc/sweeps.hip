@@ -14,6 +14,8 @@
 //   streams.strahler_order    pyflwdir/streams.py:228-269  Strahler
 //   core.fillnodata_upstream  pyflwdir/core.py:120-146     Labels (basins.basins, basins.py:12-18)
 //   dem.height_above_nearest_drain  pyflwdir/dem.py:299-330  Hand
+#include <stdlib.h>
+
 #include <algorithm>
 #include <unordered_set>
 
@@ -374,21 +376,28 @@ extern "C" int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids
       uids.insert(uids.end(), src, src + id_size);
     }
   }
-  PFDCHK(pfd_order_cells_impl(h));
   const u32 ku = (u32)uidx.size();
   InArg di, dl;
   PFDCHK(di.bind(ku ? uidx.data() : nullptr, (size_t)ku * sizeof(i64), PFD_HOST, h->stream));
   PFDCHK(dl.bind(ku ? uids.data() : nullptr, (size_t)ku * id_size, PFD_HOST, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * id_size, memspace));
-  int rc;
-  switch (id_size) {
-    case 1: rc = basins_t<u8>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
-    case 2: rc = basins_t<uint16_t>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
-    case 4: rc = basins_t<u32>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
-    default: rc = basins_t<u64>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+  // fast path: LDS-tiled "first outlet downstream" query (paths.hip); needs no cell ordering.
+  // Rasters with cycles (and PFD_BASINS_LEVELS=1) go through the level engine.
+  int tiled_ok = 0;
+  if (!getenv("PFD_BASINS_LEVELS"))
+    PFDCHK(pfd_basins_tiled(h, (const i64 *)di.dev, dl.dev, ku, id_size, o.dev, &tiled_ok));
+  if (!tiled_ok) {
+    PFDCHK(pfd_order_cells_impl(h));
+    int rc;
+    switch (id_size) {
+      case 1: rc = basins_t<u8>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+      case 2: rc = basins_t<uint16_t>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+      case 4: rc = basins_t<u32>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+      default: rc = basins_t<u64>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
+    }
+    PFDCHK(rc);
   }
-  PFDCHK(rc);
   return o.finish(h->stream);
 }
 

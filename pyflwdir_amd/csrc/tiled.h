@@ -69,6 +69,74 @@ struct TileArgs {
   int ablate;      // profiling knob (env PFD_TILE_ABLATE): bit0 skip doubling, bit4 cycle stamps
 };
 
+// ---- device helpers shared by the tile kernels (tiled.hip, paths.hip) ---------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int pslot(int lr, int lc) {
+  if (lr == 0) return lc;
+  if (lr == TS - 1) return TS + lc;
+  if (lc == 0) return 2 * TS + (lr - 1);
+  if (lc == TS - 1) return 2 * TS + (TS - 2) + (lr - 1);
+  return -1;
+}
+__device__ __forceinline__ void pslot_inv(int p, int *lr, int *lc) {
+  if (p < TS) {
+    *lr = 0;
+    *lc = p;
+  } else if (p < 2 * TS) {
+    *lr = TS - 1;
+    *lc = p - TS;
+  } else if (p < 2 * TS + (TS - 2)) {
+    *lr = p - 2 * TS + 1;
+    *lc = 0;
+  } else {
+    *lr = p - (2 * TS + (TS - 2)) + 1;
+    *lc = TS - 1;
+  }
+}
+
+// LDS layout of the staged codes: 66 rows (1-cell halo) x 72 bytes; column lc in [-1, 64] lives
+// at byte lc + 4 of its row, so that the 64 own columns start on a dword boundary and the halo'd
+// row is exactly 18 dwords [c0-4, c0+68) of the raster row.
+#define CP 72
+#define CODE(lr, lc) code[((lr) + 1) * CP + (lc) + 4]
+#define QPT (TCELLS / 4 / 256)  // quads (4 consecutive cells) per thread
+
+
+// issue the (<= 5 per thread) unconditional, possibly unaligned dword loads of a tile's halo'd
+// codes; v[k] is dword idx = tid + 256*k of the 66 x 18 staging area, out-of-raster bytes = nodata
+__device__ __forceinline__ void stage_load(const u8 *__restrict__ ncode, u32 nrow, u32 ncol, i64 r0, i64 c0, u32 tid,
+                                           u32 (&v)[5]) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const u32 idx = tid + 256u * k;  // dword idx of the 66 x 18 staging area (1188 used)
+    const u32 hr = idx / 18u, d = idx - hr * 18u;
+    const i64 gr = r0 + (i64)hr - 1;
+    const i64 cs = c0 - 4 + 4 * (i64)d;  // first raster column of this dword
+    // a load inside a branch would be waited for on the spot: load from a clamped address and
+    // mask afterwards.  Reading up to 3 bytes past a row end is fine: the bytes are masked and the
+    // allocation carries slack.
+    const i64 crr = gr < 0 ? 0 : (gr >= (i64)nrow ? (i64)nrow - 1 : gr);
+    const i64 ccs = cs < 0 ? 0 : (cs >= (i64)ncol ? (i64)ncol - 1 : cs);
+    u32 w;
+    __builtin_memcpy(&w, ncode + (size_t)crr * ncol + (size_t)ccs, 4);
+    const bool rowok = idx < HW * 18u && gr >= 0 && gr < (i64)nrow;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const i64 col = cs + b;
+      if (!rowok || col < 0 || col >= (i64)ncol) w = (w & ~(0xFFu << (8 * b))) | (D8_MV << (8 * b));
+    }
+    v[k] = w;
+  }
+}
+__device__ __forceinline__ void stage_store(u8 *code, u32 tid, const u32 (&v)[5]) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const u32 idx = tid + 256u * k;
+    if (idx < HW * 18u) ((u32 *)code)[idx] = v[k];
+  }
+}
+#endif  // __HIPCC__
+
 struct TiledRun {
   pfd_raster *h = nullptr;
   u32 ntr = 0, ntc = 0, nexits = 0;

@@ -50,36 +50,6 @@
     }                                                                                                       \
   }
 
-__device__ __forceinline__ int pslot(int lr, int lc) {
-  if (lr == 0) return lc;
-  if (lr == TS - 1) return TS + lc;
-  if (lc == 0) return 2 * TS + (lr - 1);
-  if (lc == TS - 1) return 2 * TS + (TS - 2) + (lr - 1);
-  return -1;
-}
-__device__ __forceinline__ void pslot_inv(int p, int *lr, int *lc) {
-  if (p < TS) {
-    *lr = 0;
-    *lc = p;
-  } else if (p < 2 * TS) {
-    *lr = TS - 1;
-    *lc = p - TS;
-  } else if (p < 2 * TS + (TS - 2)) {
-    *lr = p - 2 * TS + 1;
-    *lc = 0;
-  } else {
-    *lr = p - (2 * TS + (TS - 2)) + 1;
-    *lc = TS - 1;
-  }
-}
-
-// LDS layout of the staged codes: 66 rows (1-cell halo) x 72 bytes; column lc in [-1, 64] lives
-// at byte lc + 4 of its row, so that the 64 own columns start on a dword boundary and the halo'd
-// row is exactly 18 dwords [c0-4, c0+68) of the raster row.
-#define CP 72
-#define CODE(lr, lc) code[((lr) + 1) * CP + (lc) + 4]
-#define QPT (TCELLS / 4 / 256)  // quads (4 consecutive cells) per thread
-
 template <bool FINAL>
 __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   __shared__ __attribute__((aligned(16))) u32 A[TCELLS];       // running subtree count of the cell
@@ -94,27 +64,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   // ---- stage the tile's codes (+halo) as dwords: all loads in flight before the first store ----
   {
     u32 v[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const u32 idx = tid + 256u * k;  // dword idx of the 66 x 18 staging area (1188 used)
-      const u32 hr = idx / 18u, d = idx - hr * 18u;
-      const i64 gr = r0 + (i64)hr - 1;
-      const i64 cs = c0 - 4 + 4 * (i64)d;  // first raster column of this dword
-      // unconditional (possibly unaligned) dword load from a clamped address; a load inside a
-      // branch would be waited for on the spot.  Reading up to 3 bytes past a row end is fine:
-      // the bytes are masked below and the allocation carries slack.
-      const i64 crr = gr < 0 ? 0 : (gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr);
-      const i64 ccs = cs < 0 ? 0 : (cs >= (i64)a.ncol ? (i64)a.ncol - 1 : cs);
-      u32 w;
-      __builtin_memcpy(&w, a.ncode + (size_t)crr * a.ncol + (size_t)ccs, 4);
-      const bool rowok = idx < HW * 18u && gr >= 0 && gr < (i64)a.nrow;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const i64 col = cs + b;
-        if (!rowok || col < 0 || col >= (i64)a.ncol) w = (w & ~(0xFFu << (8 * b))) | (D8_MV << (8 * b));
-      }
-      v[k] = w;
-    }
+    stage_load(a.ncode, a.nrow, a.ncol, r0, c0, tid, v);
     u32 inf = 0;
     if (FINAL) inf = a.inflow[sbase + tid];  // 256 slots per tile: always in bounds
 #pragma unroll
