@@ -12,6 +12,9 @@
 #define SSHIFT 14           // log2(SSL)
 #define SDONE 0x8000u       // supertile pointer saturated (local slot ids use 14 bits)
 #define MAXROUNDS_SUPER 15
+#define HG 4                // hypertile edge in supertiles (hypertile = 2048 x 2048 cells)
+#define HCAP 24576          // super-exit ids per hypertile kept in LDS (6 B per node = 144 KB)
+#define HDONE 0x8000u       // hypertile pointer saturated (local ids use 15 bits)
 #define NPERIM (2 * TS + 2 * (TS - 2))
 #define NONE32 0xFFFFFFFFu
 #define PDONE 0x8000u       // in-tile pointer saturated at its root
@@ -23,7 +26,7 @@
 #define ENC_SIDE1 0x40000000u
 #define ENC_COL 0x3FFFFFFFu
 
-enum { T_UNSAT = 8, T_XACTIVE = 10, T_NSUPER = 11, T_SLIVE = 12 };  // ctrl slots (u64)
+enum { T_UNSAT = 8, T_XACTIVE = 10, T_NSUPER = 11, T_SLIVE = 12, T_NHYPER = 14, T_OVERFLOW = 15 };  // ctrl slots (u64)
 
 // slot numbering: [supertile][tile within supertile][perimeter slot] so that the exits of one
 // 8x8-tile supertile are 16384 consecutive ids (the level-2 solve keeps them in LDS)
@@ -48,6 +51,24 @@ struct SuperArgs {
   u32 *sx_slot;     // [nsuper] slot of the super-exit
   u32 *T3;          // [nsuper] level-3 start value (= T2 of the super-exit)
   u32 *inflow;      // [nslots] (final pass) flow delivered to the tile entries
+  u64 *ctrl;
+  u32 nstc, nhtc;   // supertiles / hypertiles per row
+  u32 *hcnt;        // [nht] super-exits per hypertile (hmode 1: ids = ht*HCAP + rank)
+  int hmode;        // 1: per-hypertile ids (level 3 solved in LDS), 0: one flat id range
+};
+
+// level-3 (hypertile = 4x4 supertiles) solve arguments; node ids k = ht*HCAP + i, i < hcnt[ht]
+struct HyperArgs {
+  u32 nht;
+  const u32 *hcnt;
+  const u32 *T3;    // [nht*HCAP] start value (supertile-local total of the super-exit)
+  const u32 *J3;    // [nht*HCAP] next super-exit on the path | XDONE
+  const u32 *xin3;  // [nht*HCAP] (final) flow entering the hypertile at this node
+  u32 *T3out;       // [nht*HCAP] hypertile-local total (pass 1) / total (final)
+  u32 *R3;          // [nht*HCAP] last super-exit of the path inside the hypertile
+  u32 *hx_id;       // [nht*HCAP] dense id of a hyper-exit (drains into another hypertile), else NONE32
+  u32 *hx_node;     // [nhyper] node of the hyper-exit
+  u32 *T4;          // [nhyper] level-4 start value
   u64 *ctrl;
 };
 
@@ -143,12 +164,16 @@ struct TiledRun {
   size_t nslots = 0;
   bool supported = false, is_block = false, coarse_done = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (8 x nslots), per-super-exit arrays (5 x cap)
-  u32 nst = 0, nstc = 0, nsuper = 0;
+  u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
+  DevBuf l3, l4, hcntbuf;
   u32 *xT = nullptr, *xtgt = nullptr, *elink = nullptr, *inflow = nullptr, *xin = nullptr, *T2 = nullptr,
       *R2 = nullptr, *sxid = nullptr, *sx_slot = nullptr;
   SuperArgs sa{};
   u32 *brow_first = nullptr, *haloA = nullptr, *haloL = nullptr, *brow_sink = nullptr, *brow_inflow = nullptr;
-  u32 *Tc = nullptr, *Tn = nullptr, *Jc = nullptr, *Jn = nullptr;
+  u32 *Tc = nullptr, *Tn = nullptr, *Jc = nullptr, *Jn = nullptr, *xin3 = nullptr, *R3 = nullptr, *hx_id = nullptr;
+  size_t n3cap = 0, n4cap = 0;
+  int level3_flat(i64 *launches);
+  int level3_hyper(i64 *launches);
   TileArgs a{};
   int init(pfd_raster *hh, i32 *out_dev);
   int phase_a();

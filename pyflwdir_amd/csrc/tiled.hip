@@ -134,6 +134,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     }
   }
   if (!(a.ablate & 1)) {
+    // Branches are per QUAD only: inside a live quad all four cells run the same instruction
+    // stream; a saturated cell re-reads its root's pointer and adds 0 to it (harmless), which is
+    // cheaper than four exec-mask regions per quad and round.
     for (int round = 0; round < MAXROUNDS_TILE; ++round) {
       u32 av[QPT * 4], q[QPT * 4];
 #pragma unroll
@@ -145,8 +148,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
           av[4 * j + 2] = a4.z;
           av[4 * j + 3] = a4.w;
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
-            if (live & (1u << (4 * j + b))) q[4 * j + b] = P[pc[4 * j + b]];
+          for (int b = 0; b < 4; ++b) q[4 * j + b] = P[pc[4 * j + b] & 0xFFFu];
         }
       }
       __syncthreads();  // every read of this round precedes every write of this round
@@ -155,12 +157,14 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
         if (live & (0xFu << (4 * j))) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            if (live & (1u << (4 * j + b))) {
-              atomicAdd(&A[pc[4 * j + b]], av[4 * j + b]);
-              pc[4 * j + b] = q[4 * j + b];
-              if (q[4 * j + b] & PDONE) live &= ~(1u << (4 * j + b));
-            }
+            const u32 p = pc[4 * j + b];
+            const bool done = p & PDONE;
+            atomicAdd(&A[p & 0xFFFu], done ? 0u : av[4 * j + b]);
+            pc[4 * j + b] = done ? p : q[4 * j + b];
           }
+          const u32 d4 = ((pc[4 * j + 0] >> 15) & 1u) | ((pc[4 * j + 1] >> 14) & 2u) | ((pc[4 * j + 2] >> 13) & 4u) |
+                         ((pc[4 * j + 3] >> 12) & 8u);
+          live = (live & ~(0xFu << (4 * j))) | ((~d4 & 0xFu) << (4 * j));
           *(uint2 *)&P[4u * tid + 1024u * j] =
               make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
         }
@@ -369,7 +373,18 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
     if (tg[j] != NONE32 && (tg[j] >> SSHIFT) != st) rank[j] = atomicAdd(&s_cnt, 1u);
   }
   __syncthreads();
-  if (tid == 0) s_base = s_cnt ? (u32)atomicAdd((unsigned long long *)&s.ctrl[T_NSUPER], (unsigned long long)s_cnt) : 0u;
+  const u32 ht = ((st / s.nstc) / HG) * s.nhtc + (st % s.nstc) / HG;
+  if (tid == 0) {
+    if (!s_cnt) {
+      s_base = 0;
+    } else if (s.hmode) {  // ids of one hypertile are consecutive: its level-3 solve runs in LDS
+      const u32 b = atomicAdd(&s.hcnt[ht], s_cnt);
+      if (b + s_cnt > HCAP) s.ctrl[T_OVERFLOW] = 1;  // host falls back to the flat id range
+      s_base = ht * HCAP + (b + s_cnt > HCAP ? 0u : b);
+    } else {
+      s_base = (u32)atomicAdd((unsigned long long *)&s.ctrl[T_NSUPER], (unsigned long long)s_cnt);
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < SPT; ++j) {
@@ -388,9 +403,16 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
 }
 
 // level 3 links: super-exit -> next super-exit on its path (through the supertile it enters)
+__device__ __forceinline__ bool sx_active(const SuperArgs &s, u32 k) {
+  return !s.hmode || (k % HCAP) < s.hcnt[k / HCAP];
+}
 __global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__restrict__ J3) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nsuper) return;
+  if (!sx_active(s, k)) {
+    J3[k] = k | XDONE;
+    return;
+  }
   const u32 e = s.sx_slot[k];
   const u32 n1 = s.elink[s.xtgt[e]];
   u32 j = k | XDONE;
@@ -404,12 +426,118 @@ __global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__r
 // flow through a super-exit enters the next supertile at the exit its target entry leads to
 __global__ void __launch_bounds__(256) k_push3(SuperArgs s, u32 nsuper, const u32 *__restrict__ T3final) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nsuper) return;
+  if (k >= nsuper || !sx_active(s, k)) return;
   const u32 tgt = s.xtgt[s.sx_slot[k]];
   const u32 n1 = s.elink[tgt];
   // (the delivery to the tile entry itself happens in the final supertile pass, where the
   // super-exit's total is T3final again)
   if (n1 != NONE32) atomicAdd(&s.xin[n1], T3final[k]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 3: one 1024-thread workgroup per hypertile (4x4 supertiles = 2048 x 2048 cells) keeps the
+// <= HCAP super-exits of the hypertile in LDS; same doubling restricted to the hops that stay
+// inside the hypertile.  Only the super-exits that leave their hypertile remain for the global
+// (level-4) rounds.  FINAL: start values + flow entering the hypertile -> totals of all nodes.
+// ---------------------------------------------------------------------------------------------
+template <bool FINAL>
+__global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
+  __shared__ u32 T[HCAP];
+  __shared__ uint16_t P[HCAP];
+  __shared__ u32 s_cnt, s_base;
+  const u32 tid = threadIdx.x;
+  const u32 ht = blockIdx.x;
+  const u32 base = ht * HCAP;
+  const u32 n = s.hcnt[ht];
+  constexpr int SPT = HCAP / 1024;
+  if (tid == 0) s_cnt = 0;
+  u32 y[SPT], ext = 0, live = 0;  // ext bit j: node drains into another hypertile
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const u32 i = tid + 1024u * j;
+    u32 p = i | HDONE, t = 0;
+    if (i < n) {
+      const u32 j3 = s.J3[base + i];
+      t = s.T3[base + i];
+      if (FINAL) t += s.xin3[base + i];
+      if (!(j3 & XDONE)) {
+        if (j3 / HCAP == ht)
+          p = j3 % HCAP;
+        else
+          ext |= 1u << j;
+      }
+    }
+    T[i] = t;
+    P[i] = (uint16_t)p;
+    y[j] = p & 0x7FFFu;
+    if (!(p & HDONE)) live |= 1u << j;
+  }
+  __syncthreads();
+  for (int round = 0; round < 16; ++round) {
+    u32 av[SPT], q[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      if (live & (1u << j)) {
+        av[j] = T[tid + 1024u * j];
+        q[j] = P[y[j]];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      if (live & (1u << j)) {
+        atomicAdd(&T[y[j]], av[j]);
+        P[tid + 1024u * j] = (uint16_t)q[j];
+        y[j] = q[j] & 0x7FFFu;
+        if (q[j] & HDONE) live &= ~(1u << j);
+      }
+    }
+    if (!__syncthreads_or((int)live)) break;
+  }
+  if (live) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the hypertile
+  if (FINAL) {
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      const u32 i = tid + 1024u * j;
+      if (i < n) s.T3out[base + i] = T[i];
+    }
+    return;
+  }
+  u32 rank[SPT];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) rank[j] = (ext & (1u << j)) ? atomicAdd(&s_cnt, 1u) : NONE32;
+  __syncthreads();
+  if (tid == 0) s_base = s_cnt ? (u32)atomicAdd((unsigned long long *)&s.ctrl[T_NHYPER], (unsigned long long)s_cnt) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const u32 i = tid + 1024u * j;
+    if (i >= n) continue;
+    s.T3out[base + i] = T[i];
+    s.R3[base + i] = base + (P[i] & 0x7FFFu);
+    u32 id = NONE32;
+    if (rank[j] != NONE32) {
+      id = s_base + rank[j];
+      s.hx_node[id] = base + i;
+      s.T4[id] = T[i];
+    }
+    s.hx_id[base + i] = id;
+  }
+}
+// level-4 links: hyper-exit -> next hyper-exit on its path (through the hypertile it enters)
+__global__ void __launch_bounds__(256) k_link4(HyperArgs s, u32 nhyper, u32 *__restrict__ J4) {
+  const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nhyper) return;
+  const u32 n1 = s.J3[s.hx_node[m]];  // first node inside the entered hypertile
+  const u32 id = s.hx_id[s.R3[n1]];
+  const u32 j = (id != NONE32) ? id : (m | XDONE);
+  J4[m] = j;
+  if (!(j & XDONE)) flag_active(s.ctrl);
+}
+__global__ void __launch_bounds__(256) k_push4(HyperArgs s, u32 nhyper, const u32 *__restrict__ T4final, u32 *xin3) {
+  const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nhyper) return;
+  atomicAdd(&xin3[s.J3[s.hx_node[m]]], T4final[m]);
 }
 
 // round prologue: Tnew = Told (the adds of the round go on top) and reset the activity flag
@@ -479,24 +607,44 @@ __global__ void __launch_bounds__(256) k_halo_collect(const u32 *__restrict__ es
   const u32 v = inflow[sslot_base(reg ? ntr - 1 : 0, tc, nstc) + p];
   if (v) atomicAdd(&haloL[((e & ENC_SIDE1) ? ncol : 0u) + (e & ENC_COL)], v);
 }
+// last exit on the path of every exit: J-only pointer jumping over the slot ids (row blocks only)
+__global__ void __launch_bounds__(256) k_jinit(const u32 *__restrict__ xtgt, const u32 *__restrict__ elink,
+                                               u32 *__restrict__ J, u32 nslots, u64 *ctrl) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  const u32 tgt = xtgt[s];
+  u32 j = s | XDONE;
+  if (tgt != NONE32) {
+    const u32 l = elink[tgt];
+    if (l != NONE32) j = l;
+  }
+  J[s] = j;
+  if (!(j & XDONE)) flag_active(ctrl);
+}
+__global__ void __launch_bounds__(256) k_jround(const u32 *__restrict__ Jo, u32 *__restrict__ Jn, u32 nslots, u64 *ctrl) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  const u32 j = Jo[s];
+  if (j & XDONE) {
+    Jn[s] = j;
+    return;
+  }
+  u32 q = Jo[j];
+  if (q & XDONE) q = (q & ~XDONE) | XDONE;  // saturated: q already names the last exit
+  Jn[s] = q;
+  if (!(q & XDONE)) flag_active(ctrl);
+}
 // where does the flow entering at a boundary-row cell leave the block?  (halo sink or nowhere)
-// exit -> last exit inside its supertile -> (level 3) last super-exit -> last exit of the path
-__global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, SuperArgs s,
-                                                   const u32 *__restrict__ J3final, const u32 *__restrict__ esink,
+__global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, const u32 *__restrict__ Jlast,
+                                                   const u32 *__restrict__ xtgt, const u32 *__restrict__ esink,
                                                    u32 ntc, u32 ntr, u32 nstc, u32 ncol, u32 *__restrict__ brow_sink) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * ncol) return;
   u32 f = brow_first[t];
   if (f != NONE32 && !(f & ENC_SINK)) {
-    u32 last = s.R2[f];
-    const u32 id = s.sxid[last];
-    if (id != NONE32) {
-      last = s.sx_slot[J3final[id] & ~XDONE];
-      const u32 n1 = s.elink[s.xtgt[last]];
-      if (n1 != NONE32) last = s.R2[n1];
-    }
+    const u32 last = Jlast[f] & ~XDONE;  // an exit without successor points at itself
     u32 tr, tc, p;
-    sslot_inv(s.xtgt[last], nstc, &tr, &tc, &p);
+    sslot_inv(xtgt[last], nstc, &tr, &tc, &p);
     f = NONE32;
     if (tr == 0)
       f = esink[(size_t)tc * PSL + p];
@@ -531,23 +679,32 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   ntr = cdiv_u32((u64)h->nrow, TS);
   ntc = cdiv_u32((u64)h->ncol, TS);
   nstc = cdiv_u32(ntc, SG);
-  nst = cdiv_u32(ntr, SG) * nstc;
+  const u32 nstr = cdiv_u32(ntr, SG);
+  nst = nstr * nstc;
+  nhtc = cdiv_u32(nstc, HG);
+  nht = cdiv_u32(nstr, HG) * nhtc;
   nslots = (size_t)nst * SSL;
-  supported = !(nslots >= 0x3FFFFFFFull || ntr > 65535u || (u64)h->ncol >= ENC_SIDE1);
+  supported = !(nslots >= 0x3FFFFFFFull || ntr > 65535u || (u64)h->ncol >= ENC_SIDE1 ||
+                (size_t)nht * HCAP >= 0x7FFFFFFFull);
   if (!supported) return PFD_OK;  // ids are 30 bit: such rasters go through the level engine
   const size_t nb = 2 * (size_t)h->ncol;
   const size_t sxcap = (size_t)nst * 4 * SG * TS;  // super-exits sit on the supertile perimeter
+  n3cap = std::max(sxcap, (size_t)nht * HCAP);
+  n4cap = (size_t)nht * 4 * HG * SG * TS;           // hyper-exits sit on the hypertile perimeter
   PFDCHK(slots.alloc(8 * nslots * sizeof(u32)));
-  PFDCHK(sx.alloc(5 * sxcap * sizeof(u32)));
+  PFDCHK(l3.alloc(8 * n3cap * sizeof(u32)));
+  PFDCHK(l4.alloc(5 * n4cap * sizeof(u32)));
+  PFDCHK(hcntbuf.alloc((size_t)nht * sizeof(u32)));
   PFDCHK(esink.alloc(2 * (size_t)ntc * PSL * sizeof(u32)));
   PFDCHK(bnd.alloc(5 * nb * sizeof(u32)));  // brow_first | haloA | haloL | brow_sink | brow_inflow
   u32 *q = slots.as<u32>();
   xtgt = q, elink = q + nslots, sxid = q + 2 * nslots;              // 0xFF-initialised
   xT = q + 3 * nslots, inflow = q + 4 * nslots, xin = q + 5 * nslots;  // zero-initialised
   T2 = q + 6 * nslots, R2 = q + 7 * nslots;                          // written before read
-  u32 *x = sx.as<u32>();
+  u32 *x = l3.as<u32>();
   sx_slot = x;
-  Tc = x + sxcap, Tn = x + 2 * sxcap, Jc = x + 3 * sxcap, Jn = x + 4 * sxcap;
+  Tc = x + n3cap, Tn = x + 2 * n3cap, Jc = x + 3 * n3cap, Jn = x + 4 * n3cap;
+  xin3 = x + 5 * n3cap, R3 = x + 6 * n3cap, hx_id = x + 7 * n3cap;
   u32 *b = bnd.as<u32>();
   brow_first = b;
   haloA = b + nb;
@@ -557,9 +714,63 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   a = TileArgs{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
-  sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl};
+  sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
+                 hcntbuf.as<u32>(), 0};
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
   is_block = h->halo_top || h->halo_bot;
+  return PFD_OK;
+}
+
+// level 3 over one flat id range: global doubling over all super-exits (small rasters, and the
+// fallback when a hypertile holds more than HCAP super-exits)
+int TiledRun::level3_flat(i64 *launches) {
+  const u32 g3 = cdiv_u32(nsuper, 256);
+  k_link3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Jc);
+  ++*launches;
+  int batch = 1;
+  for (u32 span = 1; span < (ntr + ntc) / SG + 2; span <<= 1) ++batch;  // ~log2 of a path in supertiles
+  bool done3 = false;
+  PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nsuper, batch + 2, &done3, launches));
+  coarse_done = coarse_done && done3;
+  k_push3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Tc);
+  ++*launches;
+  KCHK();
+  return PFD_OK;
+}
+
+// level 3 per hypertile in LDS + level 4 (global doubling over the hyper-exits only)
+int TiledRun::level3_hyper(i64 *launches) {
+  const u32 n3 = nht * HCAP;
+  const u32 g3 = cdiv_u32(n3, 256);
+  u32 *T3 = Tc, *J3 = Jc, *T3out = Tn;  // Jn is free: level 4 has its own buffers
+  u32 *y = l4.as<u32>();
+  u32 *hx_node = y, *T4c = y + n4cap, *T4n = y + 2 * n4cap, *J4c = y + 3 * n4cap, *J4n = y + 4 * n4cap;
+  HIPCHK(hipMemsetAsync(xin3, 0, (size_t)n3 * sizeof(u32), h->stream));
+  k_link3<<<g3, 256, 0, h->stream>>>(sa, n3, J3);
+  HyperArgs ha{nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl};
+  k_hyper<false><<<nht, 1024, 0, h->stream>>>(ha);
+  KCHK();
+  u64 c[8];
+  HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  nhyper = (u32)c[T_NHYPER - 8];
+  *launches += 2;
+  if (nhyper) {
+    const u32 g4 = cdiv_u32(nhyper, 256);
+    HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+    k_link4<<<g4, 256, 0, h->stream>>>(ha, nhyper, J4c);
+    int batch = 3;
+    for (u32 span = 1; span < (ntr + ntc) / (SG * HG) + 2; span <<= 1) ++batch;  // ~log2 of a path in hypertiles
+    bool done4 = false;
+    PFDCHK(pfd_doubling_rounds(h, &T4c, &T4n, &J4c, &J4n, nhyper, batch, &done4, launches));
+    coarse_done = coarse_done && done4;
+    k_push4<<<g4, 256, 0, h->stream>>>(ha, nhyper, T4c, xin3);
+    *launches += 2;
+  }
+  k_hyper<true><<<nht, 1024, 0, h->stream>>>(ha);
+  k_push3<<<g3, 256, 0, h->stream>>>(sa, n3, T3out);
+  *launches += 2;
+  KCHK();
   return PFD_OK;
 }
 
@@ -569,11 +780,13 @@ int TiledRun::phase_a() {
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 56 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(xtgt, 0xFF, 3 * nslots * sizeof(u32), h->stream));  // xtgt, elink, sxid = NONE
   HIPCHK(hipMemsetAsync(xT, 0, 3 * nslots * sizeof(u32), h->stream));       // xT, inflow, xin = 0
-  // brow_first / brow_sink = NONE, haloA / haloL / brow_inflow = 0
-  HIPCHK(hipMemsetAsync(brow_first, 0xFF, nb * sizeof(u32), h->stream));
-  HIPCHK(hipMemsetAsync(haloA, 0, 2 * nb * sizeof(u32), h->stream));
-  HIPCHK(hipMemsetAsync(brow_sink, 0xFF, nb * sizeof(u32), h->stream));
-  HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(hcntbuf.p, 0, (size_t)nht * sizeof(u32), h->stream));
+  if (is_block) {  // brow_first / brow_sink = NONE, haloA / haloL = 0
+    HIPCHK(hipMemsetAsync(brow_first, 0xFF, nb * sizeof(u32), h->stream));
+    HIPCHK(hipMemsetAsync(haloA, 0, 2 * nb * sizeof(u32), h->stream));
+    HIPCHK(hipMemsetAsync(brow_sink, 0xFF, nb * sizeof(u32), h->stream));
+  }
+  HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));  // read by the final tile pass
   const dim3 grid(ntc, ntr);
   pfd_seg_begin(h, "tile_local");
   k_tile<false><<<grid, 256, 0, h->stream>>>(a);
@@ -582,25 +795,30 @@ int TiledRun::phase_a() {
 
   pfd_seg_begin(h, "exit_graph");
   i64 launches = 1;
+  // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
+  sa.hmode = (nht > 1 && !getenv("PFD_FLAT_L3")) ? 1 : 0;
   k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
   KCHK();
-  u64 c[5];
+  u64 c[8];
   HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  nsuper = (u32)c[3];
-  coarse_done = c[4] == 0;  // no supertile was left with unsaturated pointers
-  if (nsuper) {
-    const u32 g3 = cdiv_u32(nsuper, 256);
-    k_link3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Jc);
-    ++launches;
-    int batch = 1;
-    for (u32 span = 1; span < (ntr + ntc) / SG + 2; span <<= 1) ++batch;  // ~log2 of a path in supertiles
-    bool done3 = false;
-    PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nsuper, batch, &done3, &launches));
-    coarse_done = coarse_done && done3;
-    k_push3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Tc);
+  if (sa.hmode && c[T_OVERFLOW - 8]) {  // a hypertile holds more super-exits than fit in LDS: flat ids
+    sa.hmode = 0;
+    HIPCHK(hipMemsetAsync(sxid, 0xFF, nslots * sizeof(u32), h->stream));
+    HIPCHK(hipMemsetAsync(h->ctrl + T_NSUPER, 0, sizeof(u64), h->stream));
+    HIPCHK(hipMemsetAsync(h->ctrl + T_SLIVE, 0, sizeof(u64), h->stream));
+    k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     ++launches;
   }
+  nsuper = (u32)c[T_NSUPER - 8];
+  coarse_done = c[T_SLIVE - 8] == 0;  // no supertile was left with unsaturated pointers
+  if (sa.hmode)
+    PFDCHK(level3_hyper(&launches));
+  else if (nsuper)
+    PFDCHK(level3_flat(&launches));
   k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
   ++launches;
   KCHK();
@@ -609,7 +827,29 @@ int TiledRun::phase_a() {
     const u32 ne = (ntr > 1 ? 2u : 1u) * ntc * PSL;
     k_halo_collect<<<cdiv_u32(ne, 256), 256, 0, h->stream>>>(esink.as<u32>(), inflow, ntc, ntr, nstc, (u32)h->ncol,
                                                             haloL, ne);
-    k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, sa, Jc, esink.as<u32>(), ntc, ntr, nstc,
+    // last exit of every exit's path: pointer jumping over the slot ids (T2/R2 are free again)
+    u32 *Ja = T2, *Jb = R2;
+    const u32 sgrid = cdiv_u32(nslots, 256);
+    HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+    k_jinit<<<sgrid, 256, 0, h->stream>>>(xtgt, elink, Ja, (u32)nslots, h->ctrl);
+    bool jd = false;
+    int batch = 2;
+    for (u32 span = 1; span < ntr + ntc; span <<= 1) ++batch;
+    for (int rounds = 0; rounds < 40 && !jd;) {
+      HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+      for (int r = 0; r < batch; ++r, ++rounds) {
+        k_jround<<<sgrid, 256, 0, h->stream>>>(Ja, Jb, (u32)nslots, h->ctrl);
+        std::swap(Ja, Jb);
+        ++launches;
+      }
+      u64 active = 0;
+      HIPCHK(hipMemcpyAsync(&active, h->ctrl + T_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      jd = active == 0;
+      batch = 2;
+    }
+    coarse_done = coarse_done && jd;
+    k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, Ja, xtgt, esink.as<u32>(), ntc, ntr, nstc,
                                                          (u32)h->ncol, brow_sink);
     launches += 3;
     KCHK();
