@@ -227,6 +227,7 @@ static void free_handle(pfd_raster *h) {
   pfd_free_pending(h);
   pfd_dfree(h->ncode);
   pfd_dfree(h->seq);
+  pfd_dfree(h->seq_kids);
   pfd_dfree(h->pits);
   pfd_dfree(h->ctrl);
   if (h->stream) release_stream(h->device, h->stream);

@@ -129,6 +129,8 @@ struct pfd_raster {
   u32 *pits = nullptr;  // device, n_pits entries, ascending (compacted on first use)
   bool pits_ready = false;
   u32 *seq = nullptr;   // device, capacity n_valid, allocated by the first ordering
+  u8 *seq_kids = nullptr, *seq_own = nullptr;  // per ordered cell: mask of draining neighbours / own code
+  bool aux_ready = false;
   i64 n_seq = -1, n_levels = -1;
   std::vector<i64> lvl_off;  // host copy, n_levels+1 entries
   // small device control block (counters), 64 x u64

@@ -255,6 +255,7 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
     return PFD_ENOPITS;
   }
   h->ordered = false;
+  h->aux_ready = false;
   h->pits_ready = false;  // the ascending pit list is compacted on first use
   return PFD_OK;
 }
@@ -328,6 +329,7 @@ extern "C" int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k) {
   HIPCHK(hipStreamSynchronize(h->stream));
   h->n_pits = (i64)c[C_NPITS];
   h->ordered = false;
+  h->aux_ready = false;
   h->n_seq = h->n_levels = -1;
   h->lvl_off.clear();
   h->pits_ready = false;
@@ -509,6 +511,7 @@ int pfd_order_cells_impl(pfd_raster *h) {
   h->n_levels = (i64)off.size() - 1;
   h->n_seq = off.back();
   h->ordered = true;
+  h->aux_ready = false;
   pfd_seg_end(h, launches);
   return PFD_OK;
 }

@@ -410,6 +410,7 @@ int pfd_order_cells_by_rank(pfd_raster *h, int *ok) {
   h->n_levels = nlev;
   h->n_seq = h->n_valid;
   h->ordered = true;
+  h->aux_ready = false;
   *ok = 1;
   return PFD_OK;
 }

@@ -21,21 +21,64 @@
 
 #include "common.h"
 
+// Every ordered cell carries one byte of pre-decoded graph next to its index (built once per
+// ordering by k_seq_aux): the mask of the neighbour slots that drain into it (up-sweeps) and its
+// own normalised code (down-sweeps).  A level kernel is then two dependent global round trips
+// (seq + aux -> neighbour values) instead of three (seq -> 8 neighbour codes -> values), and needs
+// neither bounds checks nor the row/column of the cell.
 template <class Op>
-__global__ void __launch_bounds__(256) k_sweep(Op op, const u32 *__restrict__ seq, u32 begin, u32 count) {
+__global__ void __launch_bounds__(256) k_sweep(Op op, const u32 *__restrict__ seq, const u8 *__restrict__ aux,
+                                               u32 begin, u32 count) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < count) op(seq[begin + t]);
+  if (t < count) op(seq[begin + t], (u32)aux[begin + t]);
+}
+
+__global__ void __launch_bounds__(256) k_seq_aux(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ seq,
+                                                 u32 nseq, u8 *__restrict__ kids, u8 *__restrict__ own) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nseq) return;
+  const u32 x = seq[j];
+  const u32 r = geo_row(g, x), c = x - r * g.ncol;
+  u32 m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    u32 nb;
+    if (d8_child(ncode, g, x, r, c, k, &nb)) m |= 1u << k;
+  }
+  kids[j] = (u8)m;
+  own[j] = ncode[x];
+}
+
+int pfd_ensure_seq_aux(pfd_raster *h) {
+  if (h->aux_ready) return PFD_OK;
+  if (h->seq_kids) pfd_dfree(h->seq_kids);
+  h->seq_kids = nullptr;
+  PFDCHK(pfd_dmalloc((void **)&h->seq_kids, 2 * (size_t)std::max<i64>(h->n_seq, 1)));
+  h->seq_own = h->seq_kids + h->n_seq;
+  if (h->n_seq) {
+    k_seq_aux<<<cdiv_u32((u64)h->n_seq, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, (u32)h->n_seq,
+                                                                   h->seq_kids, h->seq_own);
+    KCHK();
+  }
+  h->aux_ready = true;
+  return PFD_OK;
+}
+
+// neighbour slot k of cell x (valid by construction of the mask / code)
+__device__ __forceinline__ u32 nb_of(const Geo &g, u32 x, int k) {
+  return (u32)((i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k));
 }
 
 // up- to downstream: deepest level first (children final before their parent's level runs)
 template <class Op>
 static int run_up(pfd_raster *h, const Op &op, const char *name) {
+  PFDCHK(pfd_ensure_seq_aux(h));
   pfd_seg_begin(h, name);
   i64 launches = 0;
   for (i64 l = h->n_levels - 1; l >= 0; --l) {
     const u32 begin = (u32)h->lvl_off[l], cnt = (u32)(h->lvl_off[l + 1] - h->lvl_off[l]);
     if (!cnt) continue;
-    k_sweep<Op><<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(op, h->seq, begin, cnt);
+    k_sweep<Op><<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_kids, begin, cnt);
     ++launches;
   }
   KCHK();
@@ -45,12 +88,13 @@ static int run_up(pfd_raster *h, const Op &op, const char *name) {
 // down- to upstream: level 1 first (level 0 = pits are seeded by the init step)
 template <class Op>
 static int run_down(pfd_raster *h, const Op &op, const char *name, i64 first_level) {
+  PFDCHK(pfd_ensure_seq_aux(h));
   pfd_seg_begin(h, name);
   i64 launches = 0;
   for (i64 l = first_level; l < h->n_levels; ++l) {
     const u32 begin = (u32)h->lvl_off[l], cnt = (u32)(h->lvl_off[l + 1] - h->lvl_off[l]);
     if (!cnt) continue;
-    k_sweep<Op><<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(op, h->seq, begin, cnt);
+    k_sweep<Op><<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_own, begin, cnt);
     ++launches;
   }
   KCHK();
@@ -83,14 +127,13 @@ struct AccuUp {
   T *out;
   T nodata;
   int has_nodata;
-  __device__ __forceinline__ void operator()(u32 x) const {
-    const u32 r = geo_row(g, x), c = x - r * g.ncol;
+  __device__ __forceinline__ void operator()(u32 x, u32 kids) const {
     T acc = data[x];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      u32 nb;
-      if (d8_child(ncode, g, x, r, c, PFD_SLOT_DESC[q], &nb)) {
-        const T a = out[nb];
+    for (int q = 0; q < 8; ++q) {  // children in descending linear index: the serial loop's order
+      const int k = PFD_SLOT_DESC[q];
+      if (kids & (1u << k)) {
+        const T a = out[nb_of(g, x, k)];
         if (!has_nodata || (acc != nodata && a != nodata)) acc = Num<T>::add(acc, a);
       }
     }
@@ -106,8 +149,8 @@ struct AccuDown {
   T *out;
   T nodata;
   int has_nodata;
-  __device__ __forceinline__ void operator()(u32 x) const {
-    const u32 p = d8_down(g, x, ncode[x]);
+  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
+    const u32 p = d8_down(g, x, code);
     if (p == x) return;  // pit keeps its own value (copied by the init step)
     T a = data[x];
     const T b = out[p];
@@ -121,14 +164,11 @@ struct CountUp {
   const u8 *ncode;
   Geo g;
   u32 *out;
-  __device__ __forceinline__ void operator()(u32 x) const {
-    const u32 r = geo_row(g, x), c = x - r * g.ncol;
+  __device__ __forceinline__ void operator()(u32 x, u32 kids) const {
     u32 acc = 1;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      u32 nb;
-      if (d8_child(ncode, g, x, r, c, k, &nb)) acc += out[nb];
-    }
+    for (int k = 0; k < 8; ++k)
+      if (kids & (1u << k)) acc += out[nb_of(g, x, k)];
     out[x] = acc;
   }
 };
@@ -142,13 +182,12 @@ struct Strahler {
   Geo g;
   const u8 *mask;  // may be null
   u8 *out;
-  __device__ __forceinline__ void operator()(u32 x) const {
-    const u32 r = geo_row(g, x), c = x - r * g.ncol;
+  __device__ __forceinline__ void operator()(u32 x, u32 kids) const {
     u32 m = 0, cnt = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      u32 nb;
-      if (d8_child(ncode, g, x, r, c, k, &nb) && (mask == nullptr || mask[nb])) {
+      const u32 nb = nb_of(g, x, k);
+      if ((kids & (1u << k)) && (mask == nullptr || mask[nb])) {
         const u32 v = out[nb];
         if (v > m) {
           m = v;
@@ -172,9 +211,9 @@ struct Labels {
   const u8 *ncode;
   Geo g;
   L *out;
-  __device__ __forceinline__ void operator()(u32 x) const {
+  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
     if (out[x] != 0) return;  // seeded cells are never overwritten
-    const u32 p = d8_down(g, x, ncode[x]);
+    const u32 p = d8_down(g, x, code);
     const L v = out[p];
     if (v != 0) out[x] = v;
   }
@@ -187,12 +226,12 @@ struct Hand {
   const u8 *drain;
   const E *elev;
   double *out;
-  __device__ __forceinline__ void operator()(u32 x) const {
+  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
     if (drain[x] == 1) {
       out[x] = 0.0;
       return;
     }
-    const u32 p = d8_down(g, x, ncode[x]);
+    const u32 p = d8_down(g, x, code);
     const E dz = elev[x] - elev[p];  // difference in the elevation dtype (dem.py:328)
     const double base = (p == x) ? 0.0 : out[p];
     out[x] = base + (double)dz;
