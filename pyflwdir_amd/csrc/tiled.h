@@ -43,7 +43,7 @@ __host__ __device__ inline void sslot_inv(u32 s, u32 nstc, u32 *tr, u32 *tc, u32
 // level-2 (supertile) solve arguments
 struct SuperArgs {
   u32 nst;          // number of supertiles
-  const u32 *xT, *xtgt, *elink;
+  const u32 *xT, *xtgt, *elink;  // xT = start values of the solve
   u32 *xin;         // [nslots] flow entering the supertile at this exit (from other supertiles)
   u32 *T2;          // [nslots] supertile-local total of the exit
   u32 *R2;          // [nslots] last exit (slot) of the exit's path inside its supertile
@@ -55,6 +55,7 @@ struct SuperArgs {
   u32 nstc, nhtc;   // supertiles / hypertiles per row
   u32 *hcnt;        // [nht] super-exits per hypertile (hmode 1: ids = ht*HCAP + rank)
   int hmode;        // 1: per-hypertile ids (level 3 solved in LDS), 0: one flat id range
+  int bonly;        // final pass over the flow entering from other row blocks only (xT ignored)
 };
 
 // level-3 (hypertile = 4x4 supertiles) solve arguments; node ids k = ht*HCAP + i, i < hcnt[ht]
@@ -172,6 +173,8 @@ struct TiledRun {
   u32 *brow_first = nullptr, *haloA = nullptr, *haloL = nullptr, *brow_sink = nullptr, *brow_inflow = nullptr;
   u32 *Tc = nullptr, *Tn = nullptr, *Jc = nullptr, *Jn = nullptr, *xin3 = nullptr, *R3 = nullptr, *hx_id = nullptr;
   size_t n3cap = 0, n4cap = 0;
+  u32 *W2 = nullptr, *J4fin = nullptr;
+  int solve_exits(const u32 *start, i64 *launches);
   int level3_flat(i64 *launches);
   int level3_hyper(i64 *launches);
   TileArgs a{};

@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
     const u32 i = tid + 1024u * j;
     const u32 g = base + i;
     const u32 tgt = s.xtgt[g];
-    u32 t = s.xT[g];
+    u32 t = (FINAL && s.bonly) ? 0u : s.xT[g];
     if (FINAL) t += s.xin[g];
     u32 p = i | SDONE;
     if (tgt != NONE32 && (tgt >> SSHIFT) == st) {  // drains into a tile of this supertile
@@ -607,44 +607,44 @@ __global__ void __launch_bounds__(256) k_halo_collect(const u32 *__restrict__ es
   const u32 v = inflow[sslot_base(reg ? ntr - 1 : 0, tc, nstc) + p];
   if (v) atomicAdd(&haloL[((e & ENC_SIDE1) ? ncol : 0u) + (e & ENC_COL)], v);
 }
-// last exit on the path of every exit: J-only pointer jumping over the slot ids (row blocks only)
-__global__ void __launch_bounds__(256) k_jinit(const u32 *__restrict__ xtgt, const u32 *__restrict__ elink,
-                                               u32 *__restrict__ J, u32 nslots, u64 *ctrl) {
-  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nslots) return;
-  const u32 tgt = xtgt[s];
-  u32 j = s | XDONE;
-  if (tgt != NONE32) {
-    const u32 l = elink[tgt];
-    if (l != NONE32) j = l;
+// last exit on the path of exit f, by O(1) lookups in the hierarchy built by the solve:
+// supertile root -> (level 3) last super-exit [-> (level 4) last hyper-exit -> hypertile root] ->
+// the supertile the path finally enters -> its root
+struct LastExitArgs {
+  const u32 *R2, *sxid, *sx_slot, *xtgt, *elink;
+  const u32 *J3;       // hyper mode: level-3 links; flat mode: saturated level-3 pointers
+  const u32 *R3, *hx_id, *hx_node, *J4fin;  // hyper mode only
+  int hmode;
+};
+__device__ __forceinline__ u32 last_exit(const LastExitArgs &q, u32 f) {
+  const u32 r2 = q.R2[f];
+  const u32 k = q.sxid[r2];
+  if (k == NONE32) return r2;  // the path ends inside this supertile
+  u32 k3;
+  if (q.hmode) {
+    k3 = q.R3[k];  // last super-exit inside the hypertile
+    const u32 m = q.hx_id[k3];
+    if (m != NONE32) {  // the path leaves the hypertile: last hyper-exit, then the root of the hypertile it enters
+      const u32 mlast = q.J4fin[m] & ~XDONE;
+      k3 = q.R3[q.J3[q.hx_node[mlast]] & ~XDONE];
+    }
+  } else {
+    k3 = q.J3[k] & ~XDONE;
   }
-  J[s] = j;
-  if (!(j & XDONE)) flag_active(ctrl);
-}
-__global__ void __launch_bounds__(256) k_jround(const u32 *__restrict__ Jo, u32 *__restrict__ Jn, u32 nslots, u64 *ctrl) {
-  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nslots) return;
-  const u32 j = Jo[s];
-  if (j & XDONE) {
-    Jn[s] = j;
-    return;
-  }
-  u32 q = Jo[j];
-  if (q & XDONE) q = (q & ~XDONE) | XDONE;  // saturated: q already names the last exit
-  Jn[s] = q;
-  if (!(q & XDONE)) flag_active(ctrl);
+  const u32 e = q.sx_slot[k3];
+  const u32 n1 = q.elink[q.xtgt[e]];
+  return (n1 == NONE32) ? e : q.R2[n1];
 }
 // where does the flow entering at a boundary-row cell leave the block?  (halo sink or nowhere)
-__global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, const u32 *__restrict__ Jlast,
-                                                   const u32 *__restrict__ xtgt, const u32 *__restrict__ esink,
-                                                   u32 ntc, u32 ntr, u32 nstc, u32 ncol, u32 *__restrict__ brow_sink) {
+__global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, LastExitArgs q,
+                                                   const u32 *__restrict__ esink, u32 ntc, u32 ntr, u32 nstc, u32 ncol,
+                                                   u32 *__restrict__ brow_sink) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * ncol) return;
   u32 f = brow_first[t];
   if (f != NONE32 && !(f & ENC_SINK)) {
-    const u32 last = Jlast[f] & ~XDONE;  // an exit without successor points at itself
     u32 tr, tc, p;
-    sslot_inv(xtgt[last], nstc, &tr, &tc, &p);
+    sslot_inv(q.xtgt[last_exit(q, f)], nstc, &tr, &tc, &p);
     f = NONE32;
     if (tr == 0)
       f = esink[(size_t)tc * PSL + p];
@@ -653,22 +653,13 @@ __global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_
   }
   brow_sink[t] = f;
 }
-// push the flow that enters at the boundary rows along the exit paths: every exit on the path
-// delivers that much more to the tile entry it drains into
-__global__ void __launch_bounds__(256) k_brow_push(const u32 *__restrict__ brow_first, const u32 *__restrict__ brow_inflow,
-                                                   const u32 *__restrict__ xtgt, const u32 *__restrict__ elink,
-                                                   u32 ncol, u32 *__restrict__ inflow) {
+// flow entering at the boundary rows becomes the start value of the exit it reaches first
+__global__ void __launch_bounds__(256) k_brow_scatter(const u32 *__restrict__ brow_first, const u32 *__restrict__ brow_inflow,
+                                                      u32 ncol, u32 *__restrict__ start) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * ncol) return;
-  const u32 v = brow_inflow[t];
-  u32 e = brow_first[t];
-  if (!v || e == NONE32 || (e & ENC_SINK)) return;
-  for (;;) {
-    const u32 tgt = xtgt[e];
-    atomicAdd(&inflow[tgt], v);
-    e = elink[tgt];
-    if (e == NONE32) break;
-  }
+  const u32 v = brow_inflow[t], e = brow_first[t];
+  if (v && e != NONE32 && !(e & ENC_SINK)) atomicAdd(&start[e], v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -691,7 +682,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   const size_t sxcap = (size_t)nst * 4 * SG * TS;  // super-exits sit on the supertile perimeter
   n3cap = std::max(sxcap, (size_t)nht * HCAP);
   n4cap = (size_t)nht * 4 * HG * SG * TS;           // hyper-exits sit on the hypertile perimeter
-  PFDCHK(slots.alloc(8 * nslots * sizeof(u32)));
+  PFDCHK(slots.alloc(9 * nslots * sizeof(u32)));
   PFDCHK(l3.alloc(8 * n3cap * sizeof(u32)));
   PFDCHK(l4.alloc(5 * n4cap * sizeof(u32)));
   PFDCHK(hcntbuf.alloc((size_t)nht * sizeof(u32)));
@@ -701,6 +692,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   xtgt = q, elink = q + nslots, sxid = q + 2 * nslots;              // 0xFF-initialised
   xT = q + 3 * nslots, inflow = q + 4 * nslots, xin = q + 5 * nslots;  // zero-initialised
   T2 = q + 6 * nslots, R2 = q + 7 * nslots;                          // written before read
+  W2 = q + 8 * nslots;                                                // start values of the second solve (row blocks)
   u32 *x = l3.as<u32>();
   sx_slot = x;
   Tc = x + n3cap, Tn = x + 2 * n3cap, Jc = x + 3 * n3cap, Jn = x + 4 * n3cap;
@@ -715,7 +707,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
-                 hcntbuf.as<u32>(), 0};
+                 hcntbuf.as<u32>(), 0, 0};
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
   is_block = h->halo_top || h->halo_bot;
   return PFD_OK;
@@ -763,6 +755,7 @@ int TiledRun::level3_hyper(i64 *launches) {
     for (u32 span = 1; span < (ntr + ntc) / (SG * HG) + 2; span <<= 1) ++batch;  // ~log2 of a path in hypertiles
     bool done4 = false;
     PFDCHK(pfd_doubling_rounds(h, &T4c, &T4n, &J4c, &J4n, nhyper, batch, &done4, launches));
+    J4fin = J4c;
     coarse_done = coarse_done && done4;
     k_push4<<<g4, 256, 0, h->stream>>>(ha, nhyper, T4c, xin3);
     *launches += 2;
@@ -774,13 +767,55 @@ int TiledRun::level3_hyper(i64 *launches) {
   return PFD_OK;
 }
 
+// hierarchical solve of the exit graph for the start values `start` (one u32 per slot): totals of
+// all exits, delivered (added) to the tile entries they drain into
+int TiledRun::solve_exits(const u32 *start, i64 *launches) {
+  HIPCHK(hipMemsetAsync(sxid, 0xFF, nslots * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(xin, 0, nslots * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(hcntbuf.p, 0, (size_t)nht * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+  HIPCHK(hipMemsetAsync(h->ctrl + T_NSUPER, 0, sizeof(u64), h->stream));
+  HIPCHK(hipMemsetAsync(h->ctrl + T_NHYPER, 0, 2 * sizeof(u64), h->stream));  // T_NHYPER, T_OVERFLOW
+  sa.xT = start;
+  Tc = l3.as<u32>() + n3cap, Tn = Tc + n3cap, Jc = Tn + n3cap, Jn = Jc + n3cap;  // undo earlier ping-pong swaps
+  sa.T3 = Tc;
+  // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
+  sa.hmode = (nht > 1 && !getenv("PFD_FLAT_L3")) ? 1 : 0;
+  k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
+  KCHK();
+  ++*launches;
+  u64 c[8];
+  HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (sa.hmode && c[T_OVERFLOW - 8]) {  // a hypertile holds more super-exits than fit in LDS: flat ids
+    sa.hmode = 0;
+    HIPCHK(hipMemsetAsync(sxid, 0xFF, nslots * sizeof(u32), h->stream));
+    HIPCHK(hipMemsetAsync(h->ctrl + T_NSUPER, 0, sizeof(u64), h->stream));
+    k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ++*launches;
+  }
+  nsuper = (u32)c[T_NSUPER - 8];
+  if (c[T_SLIVE - 8]) coarse_done = false;  // a supertile was left with unsaturated pointers
+  if (sa.hmode)
+    PFDCHK(level3_hyper(launches));
+  else if (nsuper)
+    PFDCHK(level3_flat(launches));
+  k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
+  ++*launches;
+  KCHK();
+  return PFD_OK;
+}
+
 // phase A: local tile pass + hierarchical exit-graph solve with zero flow from other row blocks
 int TiledRun::phase_a() {
+  coarse_done = true;
   const size_t nb = 2 * (size_t)h->ncol;
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 56 * sizeof(u64), h->stream));
-  HIPCHK(hipMemsetAsync(xtgt, 0xFF, 3 * nslots * sizeof(u32), h->stream));  // xtgt, elink, sxid = NONE
-  HIPCHK(hipMemsetAsync(xT, 0, 3 * nslots * sizeof(u32), h->stream));       // xT, inflow, xin = 0
-  HIPCHK(hipMemsetAsync(hcntbuf.p, 0, (size_t)nht * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(xtgt, 0xFF, 2 * nslots * sizeof(u32), h->stream));  // xtgt, elink = NONE
+  HIPCHK(hipMemsetAsync(xT, 0, 2 * nslots * sizeof(u32), h->stream));       // xT, inflow = 0
   if (is_block) {  // brow_first / brow_sink = NONE, haloA / haloL = 0
     HIPCHK(hipMemsetAsync(brow_first, 0xFF, nb * sizeof(u32), h->stream));
     HIPCHK(hipMemsetAsync(haloA, 0, 2 * nb * sizeof(u32), h->stream));
@@ -794,63 +829,16 @@ int TiledRun::phase_a() {
   pfd_seg_end(h, 1);
 
   pfd_seg_begin(h, "exit_graph");
-  i64 launches = 1;
-  // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
-  sa.hmode = (nht > 1 && !getenv("PFD_FLAT_L3")) ? 1 : 0;
-  k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
-  KCHK();
-  u64 c[8];
-  HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (sa.hmode && c[T_OVERFLOW - 8]) {  // a hypertile holds more super-exits than fit in LDS: flat ids
-    sa.hmode = 0;
-    HIPCHK(hipMemsetAsync(sxid, 0xFF, nslots * sizeof(u32), h->stream));
-    HIPCHK(hipMemsetAsync(h->ctrl + T_NSUPER, 0, sizeof(u64), h->stream));
-    HIPCHK(hipMemsetAsync(h->ctrl + T_SLIVE, 0, sizeof(u64), h->stream));
-    k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
-    KCHK();
-    HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    ++launches;
-  }
-  nsuper = (u32)c[T_NSUPER - 8];
-  coarse_done = c[T_SLIVE - 8] == 0;  // no supertile was left with unsaturated pointers
-  if (sa.hmode)
-    PFDCHK(level3_hyper(&launches));
-  else if (nsuper)
-    PFDCHK(level3_flat(&launches));
-  k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
-  ++launches;
-  KCHK();
+  i64 launches = 0;
+  PFDCHK(solve_exits(xT, &launches));
   if (is_block) {  // what leaves through the halo rows, and where boundary-row inflow would leave
     HIPCHK(hipMemcpyAsync(haloL, haloA, nb * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
     const u32 ne = (ntr > 1 ? 2u : 1u) * ntc * PSL;
     k_halo_collect<<<cdiv_u32(ne, 256), 256, 0, h->stream>>>(esink.as<u32>(), inflow, ntc, ntr, nstc, (u32)h->ncol,
                                                             haloL, ne);
-    // last exit of every exit's path: pointer jumping over the slot ids (T2/R2 are free again)
-    u32 *Ja = T2, *Jb = R2;
-    const u32 sgrid = cdiv_u32(nslots, 256);
-    HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
-    k_jinit<<<sgrid, 256, 0, h->stream>>>(xtgt, elink, Ja, (u32)nslots, h->ctrl);
-    bool jd = false;
-    int batch = 2;
-    for (u32 span = 1; span < ntr + ntc; span <<= 1) ++batch;
-    for (int rounds = 0; rounds < 40 && !jd;) {
-      HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
-      for (int r = 0; r < batch; ++r, ++rounds) {
-        k_jround<<<sgrid, 256, 0, h->stream>>>(Ja, Jb, (u32)nslots, h->ctrl);
-        std::swap(Ja, Jb);
-        ++launches;
-      }
-      u64 active = 0;
-      HIPCHK(hipMemcpyAsync(&active, h->ctrl + T_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      jd = active == 0;
-      batch = 2;
-    }
-    coarse_done = coarse_done && jd;
-    k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, Ja, xtgt, esink.as<u32>(), ntc, ntr, nstc,
-                                                         (u32)h->ncol, brow_sink);
+    LastExitArgs le{R2, sxid, sx_slot, xtgt, elink, Jc, R3, hx_id, l4.as<u32>(), J4fin, sa.hmode};
+    k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, le, esink.as<u32>(), ntc, ntr, nstc, (u32)h->ncol,
+                                                         brow_sink);
     launches += 3;
     KCHK();
   }
@@ -863,10 +851,15 @@ int TiledRun::phase_a() {
 int TiledRun::phase_b(int *complete) {
   const size_t nb = 2 * (size_t)h->ncol;
   if (is_block) {
+    // The flow entering from the other row blocks is one more set of start values on the same exit
+    // graph: solve it once more (the solve is linear) — its totals are ADDED to the tile entries.
     pfd_seg_begin(h, "block_inflow");
-    k_brow_push<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, xtgt, elink, (u32)h->ncol, inflow);
+    i64 launches = 2;
+    HIPCHK(hipMemsetAsync(W2, 0, nslots * sizeof(u32), h->stream));
+    k_brow_scatter<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, W2);
     KCHK();
-    pfd_seg_end(h, 1);
+    PFDCHK(solve_exits(W2, &launches));
+    pfd_seg_end(h, launches);
   }
   const dim3 grid(ntc, ntr);
   pfd_seg_begin(h, "tile_final");
