@@ -84,26 +84,37 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       const u32 c4 = *(const u32 *)&CODE(lr, lc0);
       u32 w4[4], p4[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < 4; ++b) {  // branch-free: (dr, dc) from two packed 2-bit tables
         const u32 c = (c4 >> (8 * b)) & 0xFFu;
         const u32 l = l0 + b;
-        u32 p = l | PDONE;  // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
-        if (d8_is_dir(c)) {
-          const int k = d8_slot(c);
-          const int nr = lr + d8_dr(k), nc = lc0 + b + d8_dc(k);
-          if ((unsigned)nr < TS && (unsigned)nc < TS) p = (u32)(nr * TS + nc);
-        }
-        u32 w = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
-        if (FINAL && w) {  // flow entering this row block from the neighbouring GPUs
-          const u32 gr = (u32)r0 + (u32)lr, gc = (u32)c0 + (u32)lc0 + b;
-          if (gr == a.row_first) w += a.brow_inflow[gc];
-          if (gr == a.row_last) w += a.brow_inflow[a.ncol + gc];
-        }
-        w4[b] = w;
-        p4[b] = p;
+        const int k = (int)__builtin_ctz(c | 0x100u);                 // slot of a direction code (8 for 0)
+        const int dr = (int)((0x101A9u >> (2 * k)) & 3u) - 1;         // dr+1 per slot, slot 8 (no direction) -> 0
+        const int dc = (int)((0x1901Au >> (2 * k)) & 3u) - 1;         // dc+1 per slot, slot 8 -> 0
+        const int nr = lr + dr, nc = lc0 + b + dc;
+        const bool go = d8_is_dir(c) && (unsigned)nr < TS && (unsigned)nc < TS;
+        // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
+        p4[b] = go ? (u32)(nr * TS + nc) : (l | PDONE);
+        w4[b] = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
       }
       *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
       *(uint2 *)&P[l0] = make_uint2(p4[0] | (p4[1] << 16), p4[2] | (p4[3] << 16));
+    }
+    if (FINAL && (a.row_first > 0 || a.row_last + 1 < a.nrow)) {
+      // row blocks: flow entering the owned boundary rows from the neighbouring GPUs
+      __syncthreads();
+      if (tid < 2 * TS) {
+        const u32 side = tid >> 6, lc = tid & 63;
+        const i64 gr = side ? (i64)a.row_last : (i64)a.row_first;
+        const i64 lr = gr - r0, gc = c0 + lc;
+        if (lr >= 0 && lr < TS && gc < (i64)a.ncol && !(side && a.row_last == a.row_first)) {
+          const u32 c = CODE((int)lr, (int)lc);
+          if (c != D8_MV && c != D8_HALO) {
+            u32 v = a.brow_inflow[side * a.ncol + gc];
+            if (!side && a.row_last == a.row_first) v += a.brow_inflow[a.ncol + gc];  // one-row block: both sides
+            if (v) A[lr * TS + lc] += v;
+          }
+        }
+      }
     }
     if (FINAL) {
       __syncthreads();
