@@ -183,7 +183,7 @@ extern "C" int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32
       pfd_set_error("pfd_upstream_area_cell_blocks: block %d is too large for the tiled engine", b);
       return PFD_EUNSUPPORTED;
     }
-    PFDCHK(runs[b].phase_a());
+    PFDCHK(runs[b].phase_a_checked());
     DevBuf rec;
     PFDCHK(rec.alloc(recw * sizeof(u32)));
     k_pack_record<<<cdiv_u32(2 * (u32)ncol, 256), 256, 0, h->stream>>>(runs[b].haloL, runs[b].brow_sink, (u32)ncol,
@@ -251,7 +251,7 @@ extern "C" int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int mem
     pfd_set_error("pfd_upstream_area_cell_begin: the block is too large for the tiled engine");
     rc = PFD_EUNSUPPORTED;
   }
-  if (rc == PFD_OK) rc = p->run.phase_a();
+  if (rc == PFD_OK) rc = p->run.phase_a_checked();
   if (rc != PFD_OK) {
     delete p;
     return rc;
@@ -320,7 +320,7 @@ extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_
     pfd_set_error("pfd_upstream_area_cell_dist: the block is too large for the tiled engine");
     return PFD_EUNSUPPORTED;
   }
-  PFDCHK(run.phase_a());
+  PFDCHK(run.phase_a_checked());
   if (world > 1) {
     DevBuf rec, allrec;
     PFDCHK(rec.alloc(recw * sizeof(u32)));

@@ -26,7 +26,8 @@
 #define ENC_SIDE1 0x40000000u
 #define ENC_COL 0x3FFFFFFFu
 
-enum { T_UNSAT = 8, T_XACTIVE = 10, T_NSUPER = 11, T_SLIVE = 12, T_NHYPER = 14, T_OVERFLOW = 15 };  // ctrl slots (u64)
+// ctrl slots (u64): 8..10 live for a whole pass, 12..14 are reset at the start of every exit-graph solve
+enum { T_UNSAT = 8, T_SLIVE = 9, T_OVERFLOW = 10, T_XACTIVE = 12, T_NSUPER = 13, T_NHYPER = 14 };  // ctrl slots (u64)
 
 // slot numbering: [supertile][tile within supertile][perimeter slot] so that the exits of one
 // 8x8-tile supertile are 16384 consecutive ids (the level-2 solve keeps them in LDS)
@@ -56,6 +57,8 @@ struct SuperArgs {
   u32 *hcnt;        // [nht] super-exits per hypertile (hmode 1: ids = ht*HCAP + rank)
   int hmode;        // 1: per-hypertile ids (level 3 solved in LDS), 0: one flat id range
   int bonly;        // final pass over the flow entering from other row blocks only (xT ignored)
+  u32 ntr, ntc;     // tiles per column / row (slots of tiles beyond them do not exist)
+  u32 hcap;         // super-exits per hypertile that fit in LDS (HCAP; lowered by tests via PFD_TEST_HCAP)
 };
 
 // level-3 (hypertile = 4x4 supertiles) solve arguments; node ids k = ht*HCAP + i, i < hcnt[ht]
@@ -163,7 +166,7 @@ struct TiledRun {
   pfd_raster *h = nullptr;
   u32 ntr = 0, ntc = 0, nexits = 0;
   size_t nslots = 0;
-  bool supported = false, is_block = false, coarse_done = false;
+  bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (8 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
   DevBuf l3, l4, hcntbuf;
@@ -179,9 +182,11 @@ struct TiledRun {
   int level3_hyper(i64 *launches);
   TileArgs a{};
   int init(pfd_raster *hh, i32 *out_dev);
+  bool overflowed = false;
   int phase_a();
+  int phase_a_checked();
   int phase_b(int *complete);
 };
 
 int pfd_doubling_rounds(pfd_raster *h, u32 **Tc, u32 **Tn, u32 **Jc, u32 **Jn, u32 n, int first_batch, bool *done,
-                        i64 *launches);
+                        i64 *launches, const u64 *ncnt = nullptr);

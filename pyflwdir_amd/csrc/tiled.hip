@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     a.xT[sbase + tid] = xt;
     a.xtgt[sbase + tid] = tgt;
     a.elink[sbase + tid] = link;
+    a.inflow[sbase + tid] = 0;  // accumulated by the exit-graph solve
     if (tr == 0) a.esink[(size_t)tc * PSL + tid] = esink;
     if (tr == a.ntr - 1 && a.ntr > 1) a.esink[((size_t)a.ntc + tc) * PSL + tid] = esink;
   }
@@ -333,9 +334,16 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
   for (int j = 0; j < SPT; ++j) {
     const u32 i = tid + 1024u * j;
     const u32 g = base + i;
-    const u32 tgt = s.xtgt[g];
-    u32 t = (FINAL && s.bonly) ? 0u : s.xT[g];
-    if (FINAL) t += s.xin[g];
+    // slots of tiles beyond the raster edge (partial supertiles) hold nothing and are never read
+    const u32 tl = i >> 8;
+    const bool exists = (st / s.nstc) * SG + (tl >> 3) < s.ntr && (st % s.nstc) * SG + (tl & 7) < s.ntc;
+    const u32 tgt = exists ? s.xtgt[g] : NONE32;
+    u32 t = (!exists || (FINAL && s.bonly)) ? 0u : s.xT[g];
+    if (FINAL) {
+      t += s.xin[g];
+    } else {
+      s.xin[g] = 0;  // accumulated by k_push3 before the final pass reads it
+    }
     u32 p = i | SDONE;
     if (tgt != NONE32 && (tgt >> SSHIFT) == st) {  // drains into a tile of this supertile
       const u32 l = s.elink[tgt];                  // exit reached from there (same tile => same supertile)
@@ -390,8 +398,8 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
       s_base = 0;
     } else if (s.hmode) {  // ids of one hypertile are consecutive: its level-3 solve runs in LDS
       const u32 b = atomicAdd(&s.hcnt[ht], s_cnt);
-      if (b + s_cnt > HCAP) s.ctrl[T_OVERFLOW] = 1;  // host falls back to the flat id range
-      s_base = ht * HCAP + (b + s_cnt > HCAP ? 0u : b);
+      if (b + s_cnt > s.hcap) s.ctrl[T_OVERFLOW] = 1;  // host falls back to the flat id range
+      s_base = ht * HCAP + (b + s_cnt > s.hcap ? 0u : b);
     } else {
       s_base = (u32)atomicAdd((unsigned long long *)&s.ctrl[T_NSUPER], (unsigned long long)s_cnt);
     }
@@ -401,15 +409,17 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
   for (int j = 0; j < SPT; ++j) {
     const u32 i = tid + 1024u * j;
     const u32 g = base + i;
-    if (tg[j] == NONE32) continue;
-    s.T2[g] = T[i];
-    s.R2[g] = base + (P[i] & (SSL - 1));
-    if (rank[j] != NONE32) {
-      const u32 id = s_base + rank[j];
-      s.sxid[g] = id;
-      s.sx_slot[id] = g;
-      s.T3[id] = T[i];
+    u32 id = NONE32;
+    if (tg[j] != NONE32) {
+      s.T2[g] = T[i];
+      s.R2[g] = base + (P[i] & (SSL - 1));
+      if (rank[j] != NONE32) {
+        id = s_base + rank[j];
+        s.sx_slot[id] = g;
+        s.T3[id] = T[i];
+      }
     }
+    s.sxid[g] = id;
   }
 }
 
@@ -420,6 +430,7 @@ __device__ __forceinline__ bool sx_active(const SuperArgs &s, u32 k) {
 __global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__restrict__ J3) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nsuper) return;
+  if (s.hmode && s.ctrl[T_OVERFLOW]) return;  // ids are invalid: the host redoes the pass flat
   if (!sx_active(s, k)) {
     J3[k] = k | XDONE;
     return;
@@ -437,7 +448,7 @@ __global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__r
 // flow through a super-exit enters the next supertile at the exit its target entry leads to
 __global__ void __launch_bounds__(256) k_push3(SuperArgs s, u32 nsuper, const u32 *__restrict__ T3final) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nsuper || !sx_active(s, k)) return;
+  if (k >= nsuper || (s.hmode && s.ctrl[T_OVERFLOW]) || !sx_active(s, k)) return;
   const u32 tgt = s.xtgt[s.sx_slot[k]];
   const u32 n1 = s.elink[tgt];
   // (the delivery to the tile entry itself happens in the final supertile pass, where the
@@ -459,6 +470,7 @@ __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
   const u32 tid = threadIdx.x;
   const u32 ht = blockIdx.x;
   const u32 base = ht * HCAP;
+  if (s.ctrl[T_OVERFLOW]) return;  // (uniform) ids are invalid: the host redoes the pass flat
   const u32 n = s.hcnt[ht];
   constexpr int SPT = HCAP / 1024;
   if (tid == 0) s_cnt = 0;
@@ -536,33 +548,37 @@ __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
   }
 }
 // level-4 links: hyper-exit -> next hyper-exit on its path (through the hypertile it enters)
-__global__ void __launch_bounds__(256) k_link4(HyperArgs s, u32 nhyper, u32 *__restrict__ J4) {
+__global__ void __launch_bounds__(256) k_link4(HyperArgs s, u32 cap, u32 *__restrict__ J4) {
   const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= nhyper) return;
+  if (m >= min(cap, (u32)s.ctrl[T_NHYPER]) || s.ctrl[T_OVERFLOW]) return;
   const u32 n1 = s.J3[s.hx_node[m]];  // first node inside the entered hypertile
   const u32 id = s.hx_id[s.R3[n1]];
   const u32 j = (id != NONE32) ? id : (m | XDONE);
   J4[m] = j;
   if (!(j & XDONE)) flag_active(s.ctrl);
 }
-__global__ void __launch_bounds__(256) k_push4(HyperArgs s, u32 nhyper, const u32 *__restrict__ T4final, u32 *xin3) {
+__global__ void __launch_bounds__(256) k_push4(HyperArgs s, u32 cap, const u32 *__restrict__ T4final, u32 *xin3) {
   const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= nhyper) return;
+  if (m >= min(cap, (u32)s.ctrl[T_NHYPER]) || s.ctrl[T_OVERFLOW]) return;
   atomicAdd(&xin3[s.J3[s.hx_node[m]]], T4final[m]);
 }
 
 // round prologue: Tnew = Told (the adds of the round go on top) and reset the activity flag
+// (`ncnt`, if given, is the device-side node count: the host launches for the capacity and does
+// not have to wait for the count)
 __global__ void __launch_bounds__(256) k_coarse_prep(const u32 *__restrict__ Told, u32 *__restrict__ Tnew, u32 nexits,
-                                                     u64 *ctrl) {
+                                                     u64 *ctrl, const u64 *__restrict__ ncnt) {
   const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e == 0) ctrl[T_XACTIVE] = 0;
+  if (ncnt) nexits = min(nexits, (u32)*ncnt);
   if (e < nexits) Tnew[e] = Told[e];
 }
 
 __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ Told, u32 *__restrict__ Tnew,
                                                       const u32 *__restrict__ Jold, u32 *__restrict__ Jnew,
-                                                      u32 nexits, u64 *ctrl) {
+                                                      u32 nexits, u64 *ctrl, const u64 *__restrict__ ncnt) {
   const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ncnt) nexits = min(nexits, (u32)*ncnt);
   if (e >= nexits) return;
   const u32 j = Jold[e];
   if (j & XDONE) {
@@ -579,14 +595,14 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
 // pointer is saturated, so they are issued in batches and the "still active" flag is read only
 // between batches (one host round trip per batch).  On return *Tc / *Jc hold the result.
 int pfd_doubling_rounds(pfd_raster *h, u32 **Tc, u32 **Tn, u32 **Jc, u32 **Jn, u32 n, int first_batch,
-                        bool *done, i64 *launches) {
+                        bool *done, i64 *launches, const u64 *ncnt) {
   const u32 grid = cdiv_u32(n, 256);
   *done = false;
   int batch = first_batch;
   for (int rounds = 0; rounds < 40 && !*done;) {
     for (int b = 0; b < batch; ++b, ++rounds) {
-      k_coarse_prep<<<grid, 256, 0, h->stream>>>(*Tc, *Tn, n, h->ctrl);
-      k_coarse_round<<<grid, 256, 0, h->stream>>>(*Tc, *Tn, *Jc, *Jn, n, h->ctrl);
+      k_coarse_prep<<<grid, 256, 0, h->stream>>>(*Tc, *Tn, n, h->ctrl, ncnt);
+      k_coarse_round<<<grid, 256, 0, h->stream>>>(*Tc, *Tn, *Jc, *Jn, n, h->ctrl, ncnt);
       *launches += 2;
       std::swap(*Tc, *Tn);
       std::swap(*Jc, *Jn);
@@ -718,7 +734,8 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
-                 hcntbuf.as<u32>(), 0, 0};
+                 hcntbuf.as<u32>(), 0, 0, ntr, ntc, HCAP};
+  if (const char *e = getenv("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
   is_block = h->halo_top || h->halo_bot;
   return PFD_OK;
@@ -733,7 +750,7 @@ int TiledRun::level3_flat(i64 *launches) {
   int batch = 1;
   for (u32 span = 1; span < (ntr + ntc) / SG + 2; span <<= 1) ++batch;  // ~log2 of a path in supertiles
   bool done3 = false;
-  PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nsuper, batch + 2, &done3, launches));
+  PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nsuper, batch + 2, &done3, launches, nullptr));
   coarse_done = coarse_done && done3;
   k_push3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Tc);
   ++*launches;
@@ -753,22 +770,20 @@ int TiledRun::level3_hyper(i64 *launches) {
   HyperArgs ha{nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl};
   k_hyper<false><<<nht, 1024, 0, h->stream>>>(ha);
   KCHK();
-  u64 c[8];
-  HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  nhyper = (u32)c[T_NHYPER - 8];
   *launches += 2;
-  if (nhyper) {
-    const u32 g4 = cdiv_u32(nhyper, 256);
+  {  // level 4: the number of hyper-exits stays on the device (grids are sized for the capacity)
+    const u32 cap4 = (u32)std::min<size_t>(n4cap, 0x7FFFFFFF);
+    const u32 g4 = cdiv_u32(cap4, 256);
     HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
-    k_link4<<<g4, 256, 0, h->stream>>>(ha, nhyper, J4c);
-    int batch = 3;
+    k_link4<<<g4, 256, 0, h->stream>>>(ha, cap4, J4c);
+    // converged rounds cost ~8 us, a host round trip ~40: start with a generous batch
+    int batch = 6;
     for (u32 span = 1; span < (ntr + ntc) / (SG * HG) + 2; span <<= 1) ++batch;  // ~log2 of a path in hypertiles
     bool done4 = false;
-    PFDCHK(pfd_doubling_rounds(h, &T4c, &T4n, &J4c, &J4n, nhyper, batch, &done4, launches));
+    PFDCHK(pfd_doubling_rounds(h, &T4c, &T4n, &J4c, &J4n, cap4, batch, &done4, launches, h->ctrl + T_NHYPER));
     J4fin = J4c;
     coarse_done = coarse_done && done4;
-    k_push4<<<g4, 256, 0, h->stream>>>(ha, nhyper, T4c, xin3);
+    k_push4<<<g4, 256, 0, h->stream>>>(ha, cap4, T4c, xin3);
     *launches += 2;
   }
   k_hyper<true><<<nht, 1024, 0, h->stream>>>(ha);
@@ -781,35 +796,24 @@ int TiledRun::level3_hyper(i64 *launches) {
 // hierarchical solve of the exit graph for the start values `start` (one u32 per slot): totals of
 // all exits, delivered (added) to the tile entries they drain into
 int TiledRun::solve_exits(const u32 *start, i64 *launches) {
-  HIPCHK(hipMemsetAsync(sxid, 0xFF, nslots * sizeof(u32), h->stream));
-  HIPCHK(hipMemsetAsync(xin, 0, nslots * sizeof(u32), h->stream));
   HIPCHK(hipMemsetAsync(hcntbuf.p, 0, (size_t)nht * sizeof(u32), h->stream));
-  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
-  HIPCHK(hipMemsetAsync(h->ctrl + T_NSUPER, 0, sizeof(u64), h->stream));
-  HIPCHK(hipMemsetAsync(h->ctrl + T_NHYPER, 0, 2 * sizeof(u64), h->stream));  // T_NHYPER, T_OVERFLOW
+  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, 3 * sizeof(u64), h->stream));  // T_XACTIVE, T_NSUPER, T_NHYPER
   sa.xT = start;
   Tc = l3.as<u32>() + n3cap, Tn = Tc + n3cap, Jc = Tn + n3cap, Jn = Jc + n3cap;  // undo earlier ping-pong swaps
   sa.T3 = Tc;
   // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
-  sa.hmode = (nht > 1 && !getenv("PFD_FLAT_L3")) ? 1 : 0;
+  sa.hmode = (nht > 1 && !force_flat && !getenv("PFD_FLAT_L3")) ? 1 : 0;
   k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
   KCHK();
   ++*launches;
-  u64 c[8];
-  HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (sa.hmode && c[T_OVERFLOW - 8]) {  // a hypertile holds more super-exits than fit in LDS: flat ids
-    sa.hmode = 0;
-    HIPCHK(hipMemsetAsync(sxid, 0xFF, nslots * sizeof(u32), h->stream));
-    HIPCHK(hipMemsetAsync(h->ctrl + T_NSUPER, 0, sizeof(u64), h->stream));
-    k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
-    KCHK();
+  if (!sa.hmode) {  // the flat level-3 rounds are sized by the number of super-exits
+    u64 c[8];
     HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    ++*launches;
+    nsuper = (u32)c[T_NSUPER - 8];
   }
-  nsuper = (u32)c[T_NSUPER - 8];
-  if (c[T_SLIVE - 8]) coarse_done = false;  // a supertile was left with unsaturated pointers
+  // (hyper mode runs on without a host round trip; T_OVERFLOW — a hypertile with more super-exits
+  //  than fit in LDS — is looked at when the pass is checked, and the pass is redone flat)
   if (sa.hmode)
     PFDCHK(level3_hyper(launches));
   else if (nsuper)
@@ -825,8 +829,8 @@ int TiledRun::phase_a() {
   coarse_done = true;
   const size_t nb = 2 * (size_t)h->ncol;
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 56 * sizeof(u64), h->stream));
-  HIPCHK(hipMemsetAsync(xtgt, 0xFF, 2 * nslots * sizeof(u32), h->stream));  // xtgt, elink = NONE
-  HIPCHK(hipMemsetAsync(xT, 0, 2 * nslots * sizeof(u32), h->stream));       // xT, inflow = 0
+  // (no slot array needs clearing: every tile writes its 256 slots, slots of tiles beyond the
+  //  raster edge are never read)
   if (is_block) {  // brow_first / brow_sink = NONE, haloA / haloL = 0
     HIPCHK(hipMemsetAsync(brow_first, 0xFF, nb * sizeof(u32), h->stream));
     HIPCHK(hipMemsetAsync(haloA, 0, 2 * nb * sizeof(u32), h->stream));
@@ -890,8 +894,26 @@ int TiledRun::phase_b(int *complete) {
               q[1] / nt, q[2] / nt, q[3] / nt);
     }
   }
-  // T_UNSAT: cells left unsaturated by a tile pass; T_SLIVE: supertile solves that did not saturate
-  *complete = coarse_done && c[4] == 0 && c[0] == 0;
+  // T_UNSAT: cells left unsaturated by a tile pass; T_SLIVE: supertile/hypertile solves that did not
+  // saturate; T_OVERFLOW: a hypertile held more super-exits than fit in LDS (result invalid: redo flat)
+  *complete = coarse_done && c[T_SLIVE - 8] == 0 && c[T_UNSAT - 8] == 0;
+  overflowed = c[T_OVERFLOW - 8] != 0;
+  if (overflowed) *complete = 0;
+  return PFD_OK;
+}
+
+// phase A for row blocks: the boundary records leave the GPU right after it, so an overflow of
+// the per-hypertile id range has to be known (and repaired by a flat re-run) before that
+int TiledRun::phase_a_checked() {
+  PFDCHK(phase_a());
+  if (!sa.hmode) return PFD_OK;
+  u64 ov = 0;
+  HIPCHK(hipMemcpyAsync(&ov, h->ctrl + T_OVERFLOW, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (ov) {
+    force_flat = true;
+    PFDCHK(phase_a());
+  }
   return PFD_OK;
 }
 
@@ -902,5 +924,11 @@ int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
   PFDCHK(run.init(h, out_dev));
   if (!run.supported) return PFD_OK;
   PFDCHK(run.phase_a());
-  return run.phase_b(complete);
+  PFDCHK(run.phase_b(complete));
+  if (run.overflowed) {  // rare: redo the pass with one flat id range for level 3
+    run.force_flat = true;
+    PFDCHK(run.phase_a());
+    PFDCHK(run.phase_b(complete));
+  }
+  return PFD_OK;
 }

@@ -80,3 +80,17 @@ def test_invalid_rasters(gpu_lib):
         pyflwdir.from_array(np.array([[3, 0], [0, 0]], dtype=np.uint8), ftype="d8")
     with pytest.raises(ValueError, match="not D8 codes|invalid"):
         pyflwdir.from_array(np.array([[3, 0], [0, 0]], dtype=np.uint8), ftype="d8", check_ftype=False)
+
+
+def test_hypertile_overflow_fallback(gpu_lib, oracle, monkeypatch):
+    """A hypertile with more super-exits than fit in LDS makes the pass fall back to the flat
+    level-3 id range (forced here by lowering the capacity); single handle and row blocks."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd import dist
+
+    d8 = oracle.synth_d8(2300, 2600, seed=8, tilt=100000, white=2, nodata_pct=10)  # 2 x 2 hypertiles
+    exp, _, _ = oracle.upstream_area_cell(d8)
+    monkeypatch.setenv("PFD_TEST_HCAP", "100")
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    assert np.array_equal(flw.upstream_area(), exp)
+    assert np.array_equal(dist.upstream_area_blocks(d8, 2), exp)
