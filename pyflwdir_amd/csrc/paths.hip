@@ -82,12 +82,12 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
     for (int b = 0; b < 4; ++b) {
       const u32 c = (c4 >> (8 * b)) & 0xFFu;
       const u32 l = l0 + b;
-      u32 p = l | PDONE;
-      if (d8_is_dir(c) && !(MODE == MODE_LABEL && s4[b])) {  // an outlet is the end of its path
-        const int k = d8_slot(c);
-        const int nr = lr + d8_dr(k), nc = lc0 + b + d8_dc(k);
-        if ((unsigned)nr < TS && (unsigned)nc < TS) p = (u32)(nr * TS + nc);
-      }
+      // branch-free decode: (dr, dc) from two packed 2-bit tables; an outlet is the end of its path
+      const int k = (int)__builtin_ctz(c | 0x100u);
+      const int nr = lr + (int)((0x101A9u >> (2 * k)) & 3u) - 1;
+      const int nc = lc0 + b + (int)((0x1901Au >> (2 * k)) & 3u) - 1;
+      const bool go = d8_is_dir(c) && !(MODE == MODE_LABEL && s4[b]) && (unsigned)nr < TS && (unsigned)nc < TS;
+      const u32 p = go ? (u32)(nr * TS + nc) : (l | PDONE);
       pc[4 * j + b] = p;
       if (!(p & PDONE)) live |= 1u << (4 * j + b);
       v4[b] = (MODE == MODE_RANK) ? ((p & PDONE) ? 0u : 1u) : s4[b];
