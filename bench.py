@@ -83,7 +83,7 @@ def parse():
 def one_step(d8_buf, out_buf, nrow, ncol, device, profile=False):
     """One pass of the hot path.  With profile=True the library brackets every phase with HIP
     events on its own stream (6 events per pass) and the phase times are returned."""
-    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE)
+    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE, deferred=True)
     if profile:
         h.set_profiling(True)
     h.upstream_area_cell(out=out_buf, memspace=_hip.PFD_DEVICE)
@@ -144,7 +144,8 @@ def run_distributed(a, rank, world, local):
 
     def step(profile=False):
         # a fresh handle per step, like the single-GPU bench: decode + local solve + exchange + final pass
-        h = _hip.RasterHandle(d8_buf, a.size, ncol, device=device, memspace=_hip.PFD_DEVICE, halo=(top, bot))
+        h = _hip.RasterHandle(d8_buf, a.size, ncol, device=device, memspace=_hip.PFD_DEVICE, halo=(top, bot),
+                              deferred=True)
         if profile:
             h.set_profiling(True)
         if comm is not None:

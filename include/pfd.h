@@ -94,6 +94,19 @@ int pfd_raster_destroy(pfd_raster *h);
  * Block handles support pfd_upstream_area_cell_blocks / pfd_upstream_area_cell_dist only. */
 int pfd_raster_create_block(const uint8_t *d8, int64_t own_rows, int64_t ncol, int halo_top, int halo_bot,
                             int memspace, int device, pfd_raster **out);
+/* Same raster / row block (halo_top = halo_bot = 0: a whole raster), but decoding, the pit rule,
+ * validation and the counts are DEFERRED to the first operation on the handle: fused into the
+ * first tile pass of pfd_upstream_area_cell (and its _blocks/_dist/_begin forms), done by a
+ * separate pass for every other entry point.  PFD_EBADCODE / PFD_ENOPITS are then returned by
+ * that operation instead of by this call, and pfd_raster_info reports n_valid = n_pits = -1
+ * until then.  With PFD_DEVICE the buffer is referenced, not copied: it must stay valid and
+ * unmodified until the first operation on the handle has returned.
+ * Mirrors from_array(..., check_ftype=False) (reference pyflwdir/pyflwdir.py:93-100) in that the
+ * constructor does no validation pass; unlike it, invalid codes are still rejected later. */
+int pfd_raster_create_deferred(const uint8_t *d8, int64_t own_rows, int64_t ncol, int halo_top, int halo_bot,
+                               int memspace, int device, pfd_raster **out);
+/* Normalises and validates a deferred handle now (no-op on any other handle). */
+int pfd_raster_validate(pfd_raster *h);
 
 /* info[0]=nrow [1]=ncol [2]=n_valid [3]=n_pits [4]=n_seq (cells draining to a pit; -1 until
  * the cells are ordered) [5]=n_levels (max rank + 1; -1 until ordered) [6]=device

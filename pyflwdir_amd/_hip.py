@@ -30,6 +30,7 @@ _ERRORS = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: MemoryError, 
 SYMBOLS = [
     "pfd_abi_version", "pfd_last_error", "pfd_device_count", "pfd_malloc", "pfd_free", "pfd_memcpy_h2d",
     "pfd_memcpy_d2h", "pfd_device_synchronize", "pfd_trim", "pfd_raster_create", "pfd_raster_create_block",
+    "pfd_raster_create_deferred", "pfd_raster_validate",
     "pfd_raster_destroy", "pfd_raster_info", "pfd_upstream_area_cell_blocks", "pfd_comm_unique_id", "pfd_comm_create",
     "pfd_comm_destroy", "pfd_upstream_area_cell_dist", "pfd_upstream_area_cell_begin", "pfd_upstream_area_cell_finish",
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
@@ -60,6 +61,8 @@ def lib() -> C.CDLL:
                 getattr(L, name).restype = C.c_int
         L.pfd_raster_create.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.pfd_raster_create_block.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_void_p)]
+        L.pfd_raster_create_deferred.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.POINTER(C.c_void_p)]
         L.pfd_upstream_area_cell_blocks.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int]
         L.pfd_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
@@ -162,9 +165,11 @@ class DeviceBuffer:
 class RasterHandle:
     """Owner of one ``pfd_raster`` (device-side graph of one raster on one GPU)."""
 
-    def __init__(self, d8, nrow: int, ncol: int, device: int = 0, memspace: int = PFD_HOST, halo=(0, 0)):
+    def __init__(self, d8, nrow: int, ncol: int, device: int = 0, memspace: int = PFD_HOST, halo=(0, 0),
+                 deferred: bool = False):
         """``nrow`` counts the OWNED rows; with ``halo=(top, bottom)`` (row block of a multi-GPU job) ``d8``
-        holds top + nrow + bottom rows."""
+        holds top + nrow + bottom rows.  ``deferred``: decode/validate inside the first operation
+        (``pfd_raster_create_deferred``); a device buffer ``d8`` is then referenced until that operation."""
         self._h = C.c_void_p()
         self.nrow, self.ncol, self.n = int(nrow), int(ncol), int(nrow) * int(ncol)
         self.device = device
@@ -172,7 +177,11 @@ class RasterHandle:
         if isinstance(d8, np.ndarray):
             d8 = np.ascontiguousarray(d8, dtype=np.uint8)
             assert d8.size == (self.nrow + sum(self.halo)) * self.ncol
-        if self.halo == (0, 0):
+        self._d8_ref = d8 if deferred else None  # keep a referenced device buffer alive
+        if deferred:
+            check(lib().pfd_raster_create_deferred(ptr(d8), self.nrow, self.ncol, self.halo[0], self.halo[1],
+                                                   memspace, device, C.byref(self._h)))
+        elif self.halo == (0, 0):
             check(lib().pfd_raster_create(ptr(d8), self.nrow, self.ncol, memspace, device, C.byref(self._h)))
         else:
             check(lib().pfd_raster_create_block(ptr(d8), self.nrow, self.ncol, self.halo[0], self.halo[1], memspace,
@@ -190,7 +199,13 @@ class RasterHandle:
             pass
 
     # -- info -------------------------------------------------------------------------------
-    def info(self) -> dict:
+    def validate(self):
+        """Normalise + validate a deferred handle now (counts become available)."""
+        check(lib().pfd_raster_validate(self._h))
+
+    def info(self, counts: bool = False) -> dict:
+        if counts:
+            self.validate()
         a = (C.c_int64 * 8)()
         check(lib().pfd_raster_info(self._h, a))
         keys = ["nrow", "ncol", "n_valid", "n_pits", "n_seq", "n_levels", "device", "bytes_held"]
@@ -215,7 +230,7 @@ class RasterHandle:
         return out
 
     def idxs_pit(self, dtype) -> np.ndarray:
-        out = np.empty(self.info()["n_pits"], dtype)
+        out = np.empty(self.info(counts=True)["n_pits"], dtype)
         check(lib().pfd_idxs_pit(self._h, IDX_CODE[np.dtype(dtype)], ptr(out), PFD_HOST))
         return out
 

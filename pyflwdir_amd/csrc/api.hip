@@ -207,13 +207,17 @@ extern "C" int pfd_device_synchronize(int device) {
 // ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
-int pfd_check_handle(pfd_raster *h) {
+int pfd_check_handle_lazy(pfd_raster *h) {
   if (!h) {
     pfd_set_error("NULL raster handle");
     return PFD_EINVAL;
   }
   HIPCHK(hipSetDevice(h->device));
   return PFD_OK;
+}
+int pfd_check_handle(pfd_raster *h) {
+  PFDCHK(pfd_check_handle_lazy(h));
+  return pfd_ensure_normalised(h);
 }
 
 static void free_handle(pfd_raster *h) {
@@ -226,6 +230,7 @@ static void free_handle(pfd_raster *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   pfd_free_pending(h);
   pfd_dfree(h->ncode);
+  pfd_dfree(h->raw_owned);
   pfd_dfree(h->seq);
   pfd_dfree(h->seq_kids);
   pfd_dfree(h->pits);
@@ -235,7 +240,7 @@ static void free_handle(pfd_raster *h) {
 }
 
 static int raster_create_impl(const uint8_t *d8, int64_t own_rows, int64_t ncol, int halo_top, int halo_bot,
-                              int memspace, int device, pfd_raster **out) {
+                              int memspace, int device, pfd_raster **out, bool deferred = false) {
   if (!out) {
     pfd_set_error("pfd_raster_create: NULL out");
     return PFD_EINVAL;
@@ -278,6 +283,25 @@ static int raster_create_impl(const uint8_t *d8, int64_t own_rows, int64_t ncol,
     if ((rc = pfd_dmalloc((void **)&h->ncode, (size_t)h->n + 64)) != PFD_OK) break;  // +slack: dword halo loads
     if ((rc = pfd_dmalloc((void **)&h->ctrl, 64 * sizeof(u64))) != PFD_OK) break;
     h->bytes_held = (size_t)h->n + 64 * sizeof(u64);
+    if (deferred && h->n >= 4) {
+      // no kernel and no synchronisation here: the codes are normalised, validated and counted by
+      // the first operation.  Device input is referenced, not copied (see include/pfd.h).
+      if (memspace == PFD_HOST) {
+        if ((rc = pfd_dmalloc((void **)&h->raw_owned, (size_t)h->n)) != PFD_OK) break;
+        if (hipMemcpyAsync(h->raw_owned, d8, (size_t)h->n, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+          pfd_set_error("pfd_raster_create_deferred: upload failed");
+          rc = PFD_EHIP;
+          break;
+        }
+        (void)hipStreamSynchronize(h->stream);  // the caller may reuse its host buffer at once
+        h->raw = h->raw_owned;
+      } else {
+        h->raw = d8;
+      }
+      h->normalised = false;
+      h->n_valid = h->n_pits = -1;
+      break;
+    }
     InArg in;
     if ((rc = in.bind(d8, (size_t)h->n, memspace, h->stream)) != PFD_OK) break;
     if ((rc = pfd_normalise_and_count(h, (const u8 *)in.dev)) != PFD_OK) break;
@@ -300,13 +324,20 @@ extern "C" int pfd_raster_create_block(const uint8_t *d8, int64_t own_rows, int6
   return raster_create_impl(d8, own_rows, ncol, halo_top, halo_bot, memspace, device, out);
 }
 
+extern "C" int pfd_raster_create_deferred(const uint8_t *d8, int64_t own_rows, int64_t ncol, int halo_top, int halo_bot,
+                                          int memspace, int device, pfd_raster **out) {
+  return raster_create_impl(d8, own_rows, ncol, halo_top, halo_bot, memspace, device, out, true);
+}
+
+extern "C" int pfd_raster_validate(pfd_raster *h) { return pfd_check_handle(h); }
+
 extern "C" int pfd_raster_destroy(pfd_raster *h) {
   free_handle(h);
   return PFD_OK;
 }
 
 extern "C" int pfd_raster_info(pfd_raster *h, int64_t info[8]) {
-  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_check_handle_lazy(h));  // (a deferred handle reports n_valid = n_pits = -1 until its first operation)
   if (!info) {
     pfd_set_error("pfd_raster_info: NULL info");
     return PFD_EINVAL;
@@ -350,7 +381,7 @@ void pfd_seg_end(pfd_raster *h, i64 launches) {
 }
 
 extern "C" int pfd_set_profiling(pfd_raster *h, int enable) {
-  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_check_handle_lazy(h));
   h->profiling = enable != 0;
   if (!enable) pfd_seg_clear(h);
   return PFD_OK;
@@ -358,7 +389,7 @@ extern "C" int pfd_set_profiling(pfd_raster *h, int enable) {
 
 extern "C" int pfd_last_timing(pfd_raster *h, int max_seg, double *ms, int64_t *launches, char *names,
                                size_t names_len, int *nseg) {
-  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_check_handle_lazy(h));
   if (!nseg) {
     pfd_set_error("pfd_last_timing: NULL nseg");
     return PFD_EINVAL;

@@ -124,6 +124,12 @@ struct pfd_raster {
   Geo geo{};
   u8 *ncode = nullptr;  // device
   i64 n_valid = 0, n_pits = 0;
+  // deferred handles (pfd_raster_create_deferred): the raw codes wait here until the first
+  // operation normalises them — fused into the first tile pass of upstream_area(cell), or by
+  // k_normalise for every other entry point
+  bool normalised = true;
+  const u8 *raw = nullptr;   // device; the caller's buffer (PFD_DEVICE) or raw_owned (PFD_HOST)
+  u8 *raw_owned = nullptr;
   // ordering
   bool ordered = false;
   u32 *pits = nullptr;  // device, n_pits entries, ascending (compacted on first use)
@@ -214,7 +220,10 @@ struct OutArg {
 };
 
 // internal entry points shared between translation units -----------------------------------------
-int pfd_check_handle(pfd_raster *h);
+int pfd_check_handle(pfd_raster *h);       // + normalises a deferred handle
+int pfd_check_handle_lazy(pfd_raster *h);  // leaves a deferred handle raw (tiled count path)
+int pfd_ensure_normalised(pfd_raster *h);
+int pfd_adopt_counts(pfd_raster *h, const u64 *c);  // c = ctrl[0..48) after a normalising pass
 void pfd_seg_clear(pfd_raster *h);
 void pfd_seg_begin(pfd_raster *h, const char *name);
 void pfd_seg_end(pfd_raster *h, i64 launches);

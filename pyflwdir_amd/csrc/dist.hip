@@ -175,7 +175,7 @@ extern "C" int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32
   std::vector<u32> allrec_host((size_t)nblocks * recw);
   for (int b = 0; b < nblocks; ++b) {  // phase A on every block
     pfd_raster *h = hs[b];
-    PFDCHK(pfd_check_handle(h));
+    PFDCHK(pfd_check_handle_lazy(h));
     pfd_seg_clear(h);
     PFDCHK(o[b].bind(outs[b], (size_t)h->own_rows * ncol * sizeof(i32), memspace));
     PFDCHK(runs[b].init(h, (i32 *)o[b].dev));
@@ -196,7 +196,7 @@ extern "C" int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32
   int all_complete = 1;
   for (int b = 0; b < nblocks; ++b) {  // "all-gather" = every block gets all records; then phase B
     pfd_raster *h = hs[b];
-    PFDCHK(pfd_check_handle(h));
+    PFDCHK(pfd_check_handle_lazy(h));
     if (nblocks > 1) {
       DevBuf allrec;
       PFDCHK(allrec.alloc(allrec_host.size() * sizeof(u32)));
@@ -234,7 +234,7 @@ void pfd_free_pending(pfd_raster *h) {
 }
 
 extern "C" int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int memspace, uint32_t *record_host) {
-  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_check_handle_lazy(h));
   if (!out || !record_host) {
     pfd_set_error("pfd_upstream_area_cell_begin: bad arguments");
     return PFD_EINVAL;
@@ -268,7 +268,7 @@ extern "C" int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int mem
 
 extern "C" int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_records_host, int nblocks, int block,
                                              int *complete) {
-  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_check_handle_lazy(h));
   DistPending *p = (DistPending *)h->pending;
   if (!p || !all_records_host || nblocks < 1 || block < 0 || block >= nblocks || !complete) {
     pfd_set_error("pfd_upstream_area_cell_finish: no pass in flight on this handle, or bad arguments");
@@ -298,7 +298,7 @@ extern "C" int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_
 // one process per GPU: collective call, every rank passes its own block
 // ---------------------------------------------------------------------------------------------
 extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int memspace) {
-  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_check_handle_lazy(h));
   if (!comm || !out) {
     pfd_set_error("pfd_upstream_area_cell_dist: bad arguments");
     return PFD_EINVAL;

@@ -240,6 +240,16 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
   u64 c[48];
   HIPCHK(hipMemcpyAsync(c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return pfd_adopt_counts(h, c);
+}
+
+// a deferred handle is normalised by the first entry point that needs the codes
+int pfd_ensure_normalised(pfd_raster *h) {
+  if (h->normalised) return PFD_OK;
+  return pfd_normalise_and_count(h, h->raw);
+}
+
+int pfd_adopt_counts(pfd_raster *h, const u64 *c) {
   if (c[C_BAD]) {
     pfd_set_error("raster holds %llu value(s) that are not D8 codes (allowed: 1,2,4,8,16,32,64,128,0,255,247)",
                   (unsigned long long)c[C_BAD]);
@@ -257,6 +267,12 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
   h->ordered = false;
   h->aux_ready = false;
   h->pits_ready = false;  // the ascending pit list is compacted on first use
+  h->normalised = true;
+  h->raw = nullptr;
+  if (h->raw_owned) {
+    pfd_dfree(h->raw_owned);
+    h->raw_owned = nullptr;
+  }
   return PFD_OK;
 }
 

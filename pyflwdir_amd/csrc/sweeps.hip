@@ -291,7 +291,7 @@ extern "C" int pfd_upstream_area_cell_levels(pfd_raster *h, int32_t *out, int me
 // cannot be finished by it; those rasters are recomputed by the level engine, whose semantics
 // for such cells are the reference's (they keep their own weight).
 extern "C" int pfd_upstream_area_cell(pfd_raster *h, int32_t *out, int memspace) {
-  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_check_handle_lazy(h));  // a deferred handle is normalised inside the first tile pass
   if (!out) {
     pfd_set_error("pfd_upstream_area_cell: NULL out");
     return PFD_EINVAL;
@@ -301,7 +301,10 @@ extern "C" int pfd_upstream_area_cell(pfd_raster *h, int32_t *out, int memspace)
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
   int complete = 0;
   PFDCHK(pfd_upstream_area_cell_tiled(h, (i32 *)o.dev, &complete));
-  if (!complete) PFDCHK(upstream_area_cell_levels_dev(h, (i32 *)o.dev));
+  if (!complete) {
+    PFDCHK(pfd_ensure_normalised(h));
+    PFDCHK(upstream_area_cell_levels_dev(h, (i32 *)o.dev));
+  }
   return o.finish(h->stream);
 }
 

@@ -78,6 +78,10 @@ struct HyperArgs {
 
 struct TileArgs {
   const u8 *ncode;
+  const u8 *raw;   // deferred handle: raw codes; the first tile pass normalises them into ncode_w
+  u8 *ncode_w;
+  u64 *tcnt;       // [ntr*ntc] per tile: valid | pits << 16 | bad << 32 (raw pass only)
+  u64 ntot;        // nrow * ncol
   u32 nrow, ncol, ntr, ntc;
   u32 row_first, row_last;  // owned rows (inclusive) of the device raster; the rest are halo rows
   u32 nstc;        // supertiles per row; slot ids are supertile-major (sslot_base)
@@ -123,14 +127,18 @@ __device__ __forceinline__ void pslot_inv(int p, int *lr, int *lc) {
 // at byte lc + 4 of its row, so that the 64 own columns start on a dword boundary and the halo'd
 // row is exactly 18 dwords [c0-4, c0+68) of the raster row.
 #define CP 72
+// swizzled LDS index of tile cell z (an involution; see k_tile)
+#define PHYS(z) ((z) ^ (((z) >> 5) & 3u))
 #define CODE(lr, lc) code[((lr) + 1) * CP + (lc) + 4]
 #define QPT (TCELLS / 4 / 256)  // quads (4 consecutive cells) per thread
 
 
 // issue the (<= 5 per thread) unconditional, possibly unaligned dword loads of a tile's halo'd
 // codes; v[k] is dword idx = tid + 256*k of the 66 x 18 staging area, out-of-raster bytes = nodata
+// GUARD: the buffer has no slack behind its last byte (a caller's raw raster)
+template <bool GUARD = false>
 __device__ __forceinline__ void stage_load(const u8 *__restrict__ ncode, u32 nrow, u32 ncol, i64 r0, i64 c0, u32 tid,
-                                           u32 (&v)[5]) {
+                                           u32 (&v)[5], u64 ntot = 0) {
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const u32 idx = tid + 256u * k;  // dword idx of the 66 x 18 staging area (1188 used)
@@ -143,7 +151,14 @@ __device__ __forceinline__ void stage_load(const u8 *__restrict__ ncode, u32 nro
     const i64 crr = gr < 0 ? 0 : (gr >= (i64)nrow ? (i64)nrow - 1 : gr);
     const i64 ccs = cs < 0 ? 0 : (cs >= (i64)ncol ? (i64)ncol - 1 : cs);
     u32 w;
-    __builtin_memcpy(&w, ncode + (size_t)crr * ncol + (size_t)ccs, 4);
+    size_t off = (size_t)crr * ncol + (size_t)ccs;
+    u32 sh = 0;
+    if (GUARD && off + 4 > ntot) {  // last bytes of the raster: load the final dword, shift down
+      sh = 8u * (u32)(off + 4 - ntot);
+      off = ntot - 4;
+    }
+    __builtin_memcpy(&w, ncode + off, 4);
+    if (GUARD) w >>= sh;
     const bool rowok = idx < HW * 18u && gr >= 0 && gr < (i64)nrow;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -169,7 +184,8 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (8 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf;
+  DevBuf l3, l4, hcntbuf, tcntbuf;
+  bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   u32 *xT = nullptr, *xtgt = nullptr, *elink = nullptr, *inflow = nullptr, *xin = nullptr, *T2 = nullptr,
       *R2 = nullptr, *sxid = nullptr, *sx_slot = nullptr;
   SuperArgs sa{};

@@ -50,9 +50,15 @@
     }                                                                                                       \
   }
 
-template <bool FINAL>
+// RAW (first pass of a deferred handle): the staged bytes are the caller's raw codes; the tile
+// normalises its own cells on the fly (decode + pit rule + validation + counts = k_normalise,
+// order.hip), keeps the result in LDS and writes it to the handle's ncode for every later pass.
+// A neighbour's raw byte serves wherever a normalised one would: normalisation only ever turns a
+// cell into a pit (0) when its TARGET is nodata, and the halo ring is only asked "are you nodata"
+// and "do you point at this valid cell".
+template <bool FINAL, bool RAW = false>
 __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
-  __shared__ __attribute__((aligned(16))) u32 A[TCELLS];       // running subtree count of the cell
+  __shared__ __attribute__((aligned(16))) u32 A[TCELLS + 64];  // running subtree count of the cell (+64 sink words)
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2^k-th ancestor | PDONE once saturated
   __shared__ __attribute__((aligned(16))) u8 code[HW * CP];    // normalised codes with a 1-cell halo
   u64 tprev = __builtin_readcyclecounter();
@@ -64,7 +70,33 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   // ---- stage the tile's codes (+halo) as dwords: all loads in flight before the first store ----
   {
     u32 v[5];
-    stage_load(a.ncode, a.nrow, a.ncol, r0, c0, tid, v);
+    if (RAW)
+      stage_load<true>(a.raw, a.nrow, a.ncol, r0, c0, tid, v, a.ntot);
+    else
+      stage_load(a.ncode, a.nrow, a.ncol, r0, c0, tid, v);
+    u32 nbad = 0, nvalid = 0, npit = 0;
+    if (RAW && (a.row_first > 0 || a.row_last + 1 < a.nrow)) {
+      // halo rows of a row block: weightless sinks (D8_HALO) wherever they are seen, ring included
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const u32 idx = tid + 256u * k;
+        const u32 hr = idx / 18u, d = idx - hr * 18u;
+        const i64 gr = r0 + (i64)hr - 1;
+        if (idx < HW * 18u && gr >= 0 && gr < (i64)a.nrow && (gr < (i64)a.row_first || gr > (i64)a.row_last)) {
+          const bool own = hr >= 1 && hr <= TS && d >= 1 && d <= 16;
+          u32 w = v[k];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const u32 x = (w >> (8 * b)) & 0xFFu;
+            if (x == D8_MV) continue;
+            const bool ok = (x & (x - 1)) == 0u || x == 255u;
+            if (!ok && own) ++nbad;
+            w = (w & ~(0xFFu << (8 * b))) | ((ok ? D8_HALO : D8_MV) << (8 * b));
+          }
+          v[k] = w;
+        }
+      }
+    }
     u32 inf = 0;
     if (FINAL) inf = a.inflow[sbase + tid];  // 256 slots per tile: always in bounds
 #pragma unroll
@@ -76,28 +108,73 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     TSTAMP(0)
 
     // ---- initial weights and downstream pointers -------------------------------------------
-    // a thread owns QPT quads of 4 consecutive cells: l0 = 4*tid + 1024*j (16 lanes = one row)
+    // a thread owns QPT quads of 4 consecutive cells: l0 = 4*tid + 1024*j (16 lanes = one row).
+    // A and P are stored SWIZZLED (PHYS): with the linear layout the lanes of a half-wave touch
+    // words 4 apart for a given register slot -> 8 banks, 4-way conflicts on every gather and
+    // atomic of the doubling.  PHYS xors the two low index bits with bits 5..6, a per-lane
+    // constant qs for own cells: register slot b holds logical cell l0 + (b ^ qs), the quad is
+    // still one aligned 16-byte vector, and pointers are kept in physical form throughout.
+    const u32 qs = (tid >> 3) & 3u;
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
       const u32 l0 = 4u * tid + 1024u * j;
       const int lr = l0 >> 6, lc0 = l0 & 63;
       const u32 c4 = *(const u32 *)&CODE(lr, lc0);
       u32 w4[4], p4[4];
+      u32 n4 = 0;  // RAW: the normalised codes of the quad
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {  // branch-free: (dr, dc) from two packed 2-bit tables
-        const u32 c = (c4 >> (8 * b)) & 0xFFu;
-        const u32 l = l0 + b;
+      for (int s = 0; s < 4; ++s) {  // branch-free: (dr, dc) from two packed 2-bit tables
+        const u32 b = (u32)s ^ qs;   // logical position in the quad of register slot s
+        u32 c = (c4 >> (8 * b)) & 0xFFu;
+        const u32 l = l0 + (u32)s;   // physical index of that cell
+        if (RAW) {
+          const bool isdir = c != 0u && (c & (c - 1)) == 0u;
+          const bool ispit = c == 0u || c == 255u;
+          const int kk = (int)__builtin_ctz(c | 0x100u);
+          const int tr_ = lr + (int)((0x101A9u >> (2 * kk)) & 3u) - 1;
+          const int tc_ = lc0 + (int)b + (int)((0x1901Au >> (2 * kk)) & 3u) - 1;
+          const u32 t = CODE(isdir ? tr_ : lr, isdir ? tc_ : lc0);  // (halo ring holds nodata off the raster)
+          const bool halorow = (i64)r0 + lr < (i64)a.row_first || (i64)r0 + lr > (i64)a.row_last;
+          const bool special = c == D8_MV || (c == D8_HALO && halorow);  // (254 elsewhere is a bad code)
+          const bool topit = ispit || (isdir && t == D8_MV);
+          const bool isbad = !special && !isdir && !ispit;
+          nvalid += (!special && !isbad) ? 1u : 0u;
+          npit += (!special && topit) ? 1u : 0u;
+          nbad += isbad ? 1u : 0u;
+          c = special ? c : (isbad ? (u32)D8_MV : (topit ? 0u : c));
+          n4 |= c << (8 * b);
+        }
         const int k = (int)__builtin_ctz(c | 0x100u);                 // slot of a direction code (8 for 0)
         const int dr = (int)((0x101A9u >> (2 * k)) & 3u) - 1;         // dr+1 per slot, slot 8 (no direction) -> 0
         const int dc = (int)((0x1901Au >> (2 * k)) & 3u) - 1;         // dc+1 per slot, slot 8 -> 0
-        const int nr = lr + dr, nc = lc0 + b + dc;
+        const int nr = lr + dr, nc = lc0 + (int)b + dc;
         const bool go = d8_is_dir(c) && (unsigned)nr < TS && (unsigned)nc < TS;
         // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
-        p4[b] = go ? (u32)(nr * TS + nc) : (l | PDONE);
-        w4[b] = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
+        p4[s] = go ? PHYS((u32)(nr * TS + nc)) : (l | PDONE);
+        w4[s] = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
       }
       *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
       *(uint2 *)&P[l0] = make_uint2(p4[0] | (p4[1] << 16), p4[2] | (p4[3] << 16));
+      if (RAW) {
+        *(u32 *)&CODE(lr, lc0) = n4;  // (readers of the raw byte only ask "== nodata": unchanged)
+        const i64 gr = r0 + lr, gc0 = c0 + lc0;
+        if (gr < (i64)a.nrow && gc0 < (i64)a.ncol) {
+          u8 *dst = a.ncode_w + (size_t)gr * a.ncol + (size_t)gc0;
+          if (gc0 + 3 < (i64)a.ncol) {
+            __builtin_memcpy(dst, &n4, 4);  // (possibly unaligned) dword store
+          } else {
+            for (int k = 0; k < 4 && gc0 + k < (i64)a.ncol; ++k) dst[k] = (u8)(n4 >> (8 * k));
+          }
+        }
+      }
+    }
+    if (RAW) {  // counts of the tile -> tcnt (summed by k_tile_counts: no same-address atomics)
+      __shared__ u64 s_cnt[4];
+      u64 pk = (u64)nvalid | ((u64)npit << 16) | ((u64)nbad << 32);
+      for (int o = 32; o > 0; o >>= 1) pk += __shfl_down(pk, o);
+      if ((tid & 63u) == 0) s_cnt[tid >> 6] = pk;
+      __syncthreads();
+      if (tid == 0) a.tcnt[(size_t)tr * a.ntc + tc] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
     if (FINAL && (a.row_first > 0 || a.row_last + 1 < a.nrow)) {
       // row blocks: flow entering the owned boundary rows from the neighbouring GPUs
@@ -111,7 +188,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
           if (c != D8_MV && c != D8_HALO) {
             u32 v = a.brow_inflow[side * a.ncol + gc];
             if (!side && a.row_last == a.row_first) v += a.brow_inflow[a.ncol + gc];  // one-row block: both sides
-            if (v) A[lr * TS + lc] += v;
+            if (v) A[PHYS((u32)(lr * TS + lc))] += v;
           }
         }
       }
@@ -121,7 +198,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       if (tid < NPERIM && inf) {  // flow entering the tile from its neighbours
         int lr, lc;
         pslot_inv((int)tid, &lr, &lc);
-        A[lr * TS + lc] += inf;
+        A[PHYS((u32)(lr * TS + lc))] += inf;
       }
     }
   }
@@ -170,7 +247,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
           for (int b = 0; b < 4; ++b) {
             const u32 p = pc[4 * j + b];
             const bool done = p & PDONE;
-            atomicAdd(&A[p & 0xFFFu], done ? 0u : av[4 * j + b]);
+            // a saturated cell adds 0 to a per-lane sink word: adding it to its root would pile
+            // same-address LDS atomics onto the few roots of the tile (n-way bank conflicts)
+            atomicAdd(&A[done ? TCELLS + (tid & 63u) : (p & 0xFFFu)], done ? 0u : av[4 * j + b]);
             pc[4 * j + b] = done ? p : q[4 * j + b];
           }
           const u32 d4 = ((pc[4 * j + 0] >> 15) & 1u) | ((pc[4 * j + 1] >> 14) & 2u) | ((pc[4 * j + 2] >> 13) & 4u) |
@@ -199,7 +278,11 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       if (gr < (i64)a.row_first || gr > (i64)a.row_last || gc0 >= (i64)a.ncol) continue;
       const u32 c4 = *(const u32 *)&CODE(lr, lc0);
       const uint4 a4 = *(const uint4 *)&A[l0];
-      i32 o4[4] = {(i32)a4.x, (i32)a4.y, (i32)a4.z, (i32)a4.w};
+      const u32 qs = (tid >> 3) & 3u;  // undo the swizzle: logical cell k sits in slot k ^ qs
+      const u32 x0 = (qs & 1u) ? a4.y : a4.x, x1 = (qs & 1u) ? a4.x : a4.y;
+      const u32 x2 = (qs & 1u) ? a4.w : a4.z, x3 = (qs & 1u) ? a4.z : a4.w;
+      i32 o4[4] = {(i32)((qs & 2u) ? x2 : x0), (i32)((qs & 2u) ? x3 : x1), (i32)((qs & 2u) ? x0 : x2),
+                   (i32)((qs & 2u) ? x1 : x3)};
 #pragma unroll
       for (int b = 0; b < 4; ++b)
         if (((c4 >> (8 * b)) & 0xFFu) == D8_MV) o4[b] = -9999;
@@ -231,7 +314,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
         if ((unsigned)nr >= TS || (unsigned)nc >= TS) {
           const i64 gr = r0 + nr, gc = c0 + nc;  // inside the raster and valid (normalised codes)
           tgt = sslot_base((u32)(gr >> 6), (u32)(gc >> 6), a.nstc) + (u32)pslot((int)(gr & 63), (int)(gc & 63));
-          xt = A[plr * TS + plc];
+          xt = A[PHYS((u32)(plr * TS + plc))];
         }
       }
     }
@@ -247,7 +330,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   __syncthreads();
   // where does the in-tile path of a cell end?  -> exit slot, halo sink (row block), or nothing
   auto path_end = [&](u32 l) -> u32 {
-    const u32 root = P[l] & 0xFFFu;
+    const u32 root = PHYS(P[PHYS(l)] & 0xFFFu);
     const int rr = root >> 6, rc = root & 63;
     const u32 cr = CODE(rr, rc);
     if (cr == D8_HALO) return ENC_SINK | (((u32)r0 + (u32)rr > a.row_last) ? ENC_SIDE1 : 0u) | ((u32)c0 + (u32)rc);
@@ -282,7 +365,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       const u32 gr = (u32)r0 + (l >> 6), gc = (u32)c0 + (l & 63);
       if (gr >= a.nrow || gc >= a.ncol) continue;
       const u32 c = CODE((int)(l >> 6), (int)(l & 63));
-      if (c == D8_HALO) a.haloA[(gr > a.row_last ? a.ncol : 0u) + gc] = A[l];
+      if (c == D8_HALO) a.haloA[(gr > a.row_last ? a.ncol : 0u) + gc] = A[PHYS(l)];
       if (c != D8_MV && c != D8_HALO) {
         if (gr == a.row_first) a.brow_first[gc] = path_end(l);
         if (gr == a.row_last) a.brow_first[a.ncol + gc] = path_end(l);
@@ -290,6 +373,36 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     }
   }
   TSTAMP(3)
+}
+
+// per-tile counts of a raw pass -> the counters k_normalise would have left in ctrl
+__global__ void __launch_bounds__(1024) k_tile_counts(const u64 *__restrict__ tcnt, u32 ntiles, u64 *ctrl) {
+  __shared__ u64 s[3][16];
+  u64 v = 0, p = 0, b = 0;
+  for (u32 i = threadIdx.x; i < ntiles; i += 1024u) {
+    const u64 x = tcnt[i];
+    v += x & 0xFFFFu;
+    p += (x >> 16) & 0xFFFFu;
+    b += x >> 32;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_down(v, o);
+    p += __shfl_down(p, o);
+    b += __shfl_down(b, o);
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    s[0][threadIdx.x >> 6] = v;
+    s[1][threadIdx.x >> 6] = p;
+    s[2][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    v = p = b = 0;
+    for (int k = 0; k < 16; ++k) v += s[0][k], p += s[1][k], b += s[2][k];
+    ctrl[16] = v;  // (copies 17..31 / 33..47 were cleared with the rest of ctrl)
+    ctrl[32] = p;
+    ctrl[2] = b;   // C_BAD
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -730,7 +843,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   haloL = b + 2 * nb;
   brow_sink = b + 3 * nb;
   brow_inflow = b + 4 * nb;
-  a = TileArgs{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
+  a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
@@ -839,9 +952,20 @@ int TiledRun::phase_a() {
   HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));  // read by the final tile pass
   const dim3 grid(ntc, ntr);
   pfd_seg_begin(h, "tile_local");
-  k_tile<false><<<grid, 256, 0, h->stream>>>(a);
-  KCHK();
-  pfd_seg_end(h, 1);
+  if (!h->normalised) {  // deferred handle: decode + validate + count inside the tile pass
+    if (!tcntbuf.p) PFDCHK(tcntbuf.alloc((size_t)ntr * ntc * sizeof(u64)));
+    a.raw = h->raw;
+    a.tcnt = tcntbuf.as<u64>();
+    k_tile<false, true><<<grid, 256, 0, h->stream>>>(a);
+    k_tile_counts<<<1, 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);
+    fused_norm = true;
+    KCHK();
+    pfd_seg_end(h, 2);
+  } else {
+    k_tile<false><<<grid, 256, 0, h->stream>>>(a);
+    KCHK();
+    pfd_seg_end(h, 1);
+  }
 
   pfd_seg_begin(h, "exit_graph");
   i64 launches = 0;
@@ -881,9 +1005,11 @@ int TiledRun::phase_b(int *complete) {
   k_tile<true><<<grid, 256, 0, h->stream>>>(a);
   KCHK();
   pfd_seg_end(h, 1);
-  u64 c[5];
-  HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  u64 c0[48];
+  HIPCHK(hipMemcpyAsync(c0, h->ctrl, sizeof(c0), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  const u64 *c = c0 + 8;
+  if (fused_norm && !h->normalised) PFDCHK(pfd_adopt_counts(h, c0));  // bad codes / no pits surface here
   if (a.ablate & 16) {
     u64 t[32];
     HIPCHK(hipMemcpy(t, h->ctrl + 24, sizeof(t), hipMemcpyDeviceToHost));

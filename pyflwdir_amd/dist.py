@@ -38,7 +38,7 @@ def block_slice(nrow: int, nblocks: int, block: int):
     return r0 - top, r1 + bot
 
 
-def upstream_area_blocks(d8: np.ndarray, nblocks: int, devices=None) -> np.ndarray:
+def upstream_area_blocks(d8: np.ndarray, nblocks: int, devices=None, deferred: bool = False) -> np.ndarray:
     """``upstream_area("cell")`` of a host raster computed as ``nblocks`` row blocks held by this one
     process (on one or several GPUs).  Same kernels and protocol as the RCCL path."""
     d8 = np.ascontiguousarray(d8, dtype=np.uint8)
@@ -47,7 +47,8 @@ def upstream_area_blocks(d8: np.ndarray, nblocks: int, devices=None) -> np.ndarr
     handles = []
     for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
         a, e = block_slice(nrow, nblocks, b)
-        handles.append(_hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks)))
+        handles.append(_hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks),
+                                          deferred=deferred))
     outs = _hip.upstream_area_cell_blocks(handles)
     for h in handles:
         h.close()
