@@ -83,7 +83,8 @@ def parse():
 def one_step(d8_buf, out_buf, nrow, ncol, device, profile=False):
     """One pass of the hot path.  With profile=True the library brackets every phase with HIP
     events on its own stream (6 events per pass) and the phase times are returned."""
-    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE, deferred=True)
+    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE,
+                          deferred=not os.environ.get("PFD_BENCH_EAGER"))  # (eager create: A/B knob)
     if profile:
         h.set_profiling(True)
     h.upstream_area_cell(out=out_buf, memspace=_hip.PFD_DEVICE)

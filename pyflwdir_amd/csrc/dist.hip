@@ -131,20 +131,20 @@ static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u3
   pfd_raster *h = run.h;
   const u32 ncol = (u32)h->ncol;
   const u32 nn = nblocks * 2 * ncol;
-  DevBuf T0, T1, J0, J1;
-  PFDCHK(T0.alloc((size_t)nn * sizeof(u32)));
-  PFDCHK(T1.alloc((size_t)nn * sizeof(u32)));
-  PFDCHK(J0.alloc((size_t)nn * sizeof(u32)));
-  PFDCHK(J1.alloc((size_t)nn * sizeof(u32)));
-  u32 *Tc = T0.as<u32>(), *Tn = T1.as<u32>(), *Jc = J0.as<u32>(), *Jn = J1.as<u32>();
+  DevBuf buf;
+  PFDCHK(buf.alloc(5 * (size_t)nn * sizeof(u32)));
+  u32 *T[3] = {buf.as<u32>(), buf.as<u32>() + nn, buf.as<u32>() + 2 * (size_t)nn};
+  u32 *J[2] = {buf.as<u32>() + 3 * (size_t)nn, buf.as<u32>() + 4 * (size_t)nn};
+  u32 *Tc = T[0], *Jc = J[0];
   pfd_seg_begin(h, "interface_solve");
   HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
   k_iface_build<<<cdiv_u32(nn, 256), 256, 0, h->stream>>>(allrec_dev, nblocks, ncol, Tc, Jc, h->ctrl);
   KCHK();
   bool done = false;
   i64 launches = 1;
-  PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nn, 3, &done, &launches));
-  k_iface_inflow<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(Tc, nblocks, ncol, blk, run.brow_inflow);
+  int rounds = 0;
+  PFDCHK(pfd_doubling_rounds(h, T, J, nn, 4, true, &done, &rounds, &launches));
+  k_iface_inflow<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(T[0], nblocks, ncol, blk, run.brow_inflow);
   KCHK();
   HIPCHK(hipStreamSynchronize(h->stream));
   pfd_seg_end(h, launches + 1);

@@ -186,6 +186,8 @@ struct TiledRun {
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
   DevBuf l3, l4, hcntbuf, tcntbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
+  int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
+  bool short_of_rounds = false;
   u32 *xT = nullptr, *xtgt = nullptr, *elink = nullptr, *inflow = nullptr, *xin = nullptr, *T2 = nullptr,
       *R2 = nullptr, *sxid = nullptr, *sx_slot = nullptr;
   SuperArgs sa{};
@@ -204,5 +206,5 @@ struct TiledRun {
   int phase_b(int *complete);
 };
 
-int pfd_doubling_rounds(pfd_raster *h, u32 **Tc, u32 **Tn, u32 **Jc, u32 **Jn, u32 n, int first_batch, bool *done,
-                        i64 *launches, const u64 *ncnt = nullptr);
+int pfd_doubling_rounds(pfd_raster *h, u32 *T[3], u32 *J[2], u32 n, int first_batch, bool check, bool *done,
+                        int *rounds_issued, i64 *launches, const u64 *ncnt = nullptr);

@@ -60,7 +60,9 @@ template <bool FINAL, bool RAW = false>
 __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   __shared__ __attribute__((aligned(16))) u32 A[TCELLS + 64];  // running subtree count of the cell (+64 sink words)
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2^k-th ancestor | PDONE once saturated
-  __shared__ __attribute__((aligned(16))) u8 code[HW * CP];    // normalised codes with a 1-cell halo
+  // codes with a 1-cell halo.  The final pass needs neither the halo ring nor lookups of other
+  // cells' codes: it keeps its own quads' codes in registers (cq) and stages nothing.
+  __shared__ __attribute__((aligned(16))) u8 code[FINAL ? 16 : HW * CP];
   u64 tprev = __builtin_readcyclecounter();
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
@@ -68,13 +70,29 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
 
   // ---- stage the tile's codes (+halo) as dwords: all loads in flight before the first store ----
+  u32 cq[QPT];  // FINAL: the codes of the thread's quads
   {
     u32 v[5];
-    if (RAW)
+    if (FINAL) {
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {  // own quads straight from HBM (clamped address, masked afterwards)
+        const u32 l0 = 4u * tid + 1024u * j;
+        const i64 gr = r0 + (l0 >> 6), gc0 = c0 + (l0 & 63);
+        const i64 crr = gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr;
+        const i64 ccs = gc0 >= (i64)a.ncol ? (i64)a.ncol - 1 : gc0;
+        u32 w;
+        __builtin_memcpy(&w, a.ncode + (size_t)crr * a.ncol + (size_t)ccs, 4);  // (ncode carries slack)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (gr >= (i64)a.nrow || gc0 + b >= (i64)a.ncol) w = (w & ~(0xFFu << (8 * b))) | (D8_MV << (8 * b));
+        cq[j] = w;
+      }
+    } else if (RAW) {
       stage_load<true>(a.raw, a.nrow, a.ncol, r0, c0, tid, v, a.ntot);
-    else
+    } else {
       stage_load(a.ncode, a.nrow, a.ncol, r0, c0, tid, v);
-    u32 nbad = 0, nvalid = 0, npit = 0;
+    }
+    u32 nbad = 0, cnt = 0;  // RAW: cnt = valid | pits << 10 | bad << 20 of this thread's 16 cells
     if (RAW && (a.row_first > 0 || a.row_last + 1 < a.nrow)) {
       // halo rows of a row block: weightless sinks (D8_HALO) wherever they are seen, ring included
 #pragma unroll
@@ -99,12 +117,14 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     }
     u32 inf = 0;
     if (FINAL) inf = a.inflow[sbase + tid];  // 256 slots per tile: always in bounds
+    if (!FINAL) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const u32 idx = tid + 256u * k;
-      if (idx < HW * 18u) ((u32 *)code)[idx] = v[k];
+      for (int k = 0; k < 5; ++k) {
+        const u32 idx = tid + 256u * k;
+        if (idx < HW * 18u) ((u32 *)code)[idx] = v[k];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     TSTAMP(0)
 
     // ---- initial weights and downstream pointers -------------------------------------------
@@ -119,36 +139,32 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     for (int j = 0; j < QPT; ++j) {
       const u32 l0 = 4u * tid + 1024u * j;
       const int lr = l0 >> 6, lc0 = l0 & 63;
-      const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+      const u32 c4 = FINAL ? cq[j] : *(const u32 *)&CODE(lr, lc0);
       u32 w4[4], p4[4];
       u32 n4 = 0;  // RAW: the normalised codes of the quad
+      const bool halorow = (i64)r0 + lr < (i64)a.row_first || (i64)r0 + lr > (i64)a.row_last;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {  // branch-free: (dr, dc) from two packed 2-bit tables
         const u32 b = (u32)s ^ qs;   // logical position in the quad of register slot s
         u32 c = (c4 >> (8 * b)) & 0xFFu;
         const u32 l = l0 + (u32)s;   // physical index of that cell
-        if (RAW) {
-          const bool isdir = c != 0u && (c & (c - 1)) == 0u;
-          const bool ispit = c == 0u || c == 255u;
-          const int kk = (int)__builtin_ctz(c | 0x100u);
-          const int tr_ = lr + (int)((0x101A9u >> (2 * kk)) & 3u) - 1;
-          const int tc_ = lc0 + (int)b + (int)((0x1901Au >> (2 * kk)) & 3u) - 1;
-          const u32 t = CODE(isdir ? tr_ : lr, isdir ? tc_ : lc0);  // (halo ring holds nodata off the raster)
-          const bool halorow = (i64)r0 + lr < (i64)a.row_first || (i64)r0 + lr > (i64)a.row_last;
-          const bool special = c == D8_MV || (c == D8_HALO && halorow);  // (254 elsewhere is a bad code)
-          const bool topit = ispit || (isdir && t == D8_MV);
-          const bool isbad = !special && !isdir && !ispit;
-          nvalid += (!special && !isbad) ? 1u : 0u;
-          npit += (!special && topit) ? 1u : 0u;
-          nbad += isbad ? 1u : 0u;
-          c = special ? c : (isbad ? (u32)D8_MV : (topit ? 0u : c));
-          n4 |= c << (8 * b);
-        }
         const int k = (int)__builtin_ctz(c | 0x100u);                 // slot of a direction code (8 for 0)
         const int dr = (int)((0x101A9u >> (2 * k)) & 3u) - 1;         // dr+1 per slot, slot 8 (no direction) -> 0
         const int dc = (int)((0x1901Au >> (2 * k)) & 3u) - 1;         // dc+1 per slot, slot 8 -> 0
         const int nr = lr + dr, nc = lc0 + (int)b + dc;
-        const bool go = d8_is_dir(c) && (unsigned)nr < TS && (unsigned)nc < TS;
+        bool isdir = d8_is_dir(c);
+        if (RAW) {  // normalise (k_normalise, order.hip): pit rule, validation, counts
+          const u32 t = CODE(nr, nc);  // code of the target, the cell itself when c is no direction
+          const bool special = c == D8_MV || (c == D8_HALO && halorow);  // (254 elsewhere is a bad code)
+          const bool ispit = c == 0u || c == 255u;
+          const bool isbad = !special && !isdir && !ispit;
+          isdir = isdir && t != D8_MV;  // flow off the raster / into nodata ends here
+          const bool valid = !special && !isbad;
+          cnt += (valid ? 1u : 0u) + ((valid && !isdir) ? 1u << 10 : 0u) + (isbad ? 1u << 20 : 0u);
+          c = special ? c : (isbad ? (u32)D8_MV : (isdir ? c : 0u));
+          n4 |= c << (8 * b);
+        }
+        const bool go = isdir && (unsigned)nr < TS && (unsigned)nc < TS;
         // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
         p4[s] = go ? PHYS((u32)(nr * TS + nc)) : (l | PDONE);
         w4[s] = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     }
     if (RAW) {  // counts of the tile -> tcnt (summed by k_tile_counts: no same-address atomics)
       __shared__ u64 s_cnt[4];
-      u64 pk = (u64)nvalid | ((u64)npit << 16) | ((u64)nbad << 32);
+      u64 pk = (u64)(cnt & 1023u) | ((u64)((cnt >> 10) & 1023u) << 16) | ((u64)((cnt >> 20) + nbad) << 32);
       for (int o = 32; o > 0; o >>= 1) pk += __shfl_down(pk, o);
       if ((tid & 63u) == 0) s_cnt[tid >> 6] = pk;
       __syncthreads();
@@ -184,7 +200,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
         const i64 gr = side ? (i64)a.row_last : (i64)a.row_first;
         const i64 lr = gr - r0, gc = c0 + lc;
         if (lr >= 0 && lr < TS && gc < (i64)a.ncol && !(side && a.row_last == a.row_first)) {
-          const u32 c = CODE((int)lr, (int)lc);
+          const u32 c = a.ncode[(size_t)gr * a.ncol + (size_t)gc];
           if (c != D8_MV && c != D8_HALO) {
             u32 v = a.brow_inflow[side * a.ncol + gc];
             if (!side && a.row_last == a.row_first) v += a.brow_inflow[a.ncol + gc];  // one-row block: both sides
@@ -276,7 +292,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       const int lr = l0 >> 6, lc0 = l0 & 63;
       const i64 gr = r0 + lr, gc0 = c0 + lc0;
       if (gr < (i64)a.row_first || gr > (i64)a.row_last || gc0 >= (i64)a.ncol) continue;
-      const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+      const u32 c4 = cq[j];
       const uint4 a4 = *(const uint4 *)&A[l0];
       const u32 qs = (tid >> 3) & 3u;  // undo the swizzle: logical cell k sits in slot k ^ qs
       const u32 x0 = (qs & 1u) ? a4.y : a4.x, x1 = (qs & 1u) ? a4.x : a4.y;
@@ -679,54 +695,73 @@ __global__ void __launch_bounds__(256) k_push4(HyperArgs s, u32 cap, const u32 *
 // round prologue: Tnew = Told (the adds of the round go on top) and reset the activity flag
 // (`ncnt`, if given, is the device-side node count: the host launches for the capacity and does
 // not have to wait for the count)
-__global__ void __launch_bounds__(256) k_coarse_prep(const u32 *__restrict__ Told, u32 *__restrict__ Tnew, u32 nexits,
-                                                     u64 *ctrl, const u64 *__restrict__ ncnt) {
-  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e == 0) ctrl[T_XACTIVE] = 0;
-  if (ncnt) nexits = min(nexits, (u32)*ncnt);
-  if (e < nexits) Tnew[e] = Told[e];
-}
-
+// One doubling round, one launch: T_{k+1}[v] = T_k[v] + sum of T_k[e] over the unsaturated e with
+// J_k(e) = v.  Three T buffers rotate: every thread carries its own value into the (zeroed) next
+// buffer with the same atomics that deliver its contribution, and zeroes its word of the buffer
+// after next — no separate copy/clear launch per round.  ctrl[T_XACTIVE] keeps the number of the
+// last round that still moved a pointer.
 __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ Told, u32 *__restrict__ Tnew,
-                                                      const u32 *__restrict__ Jold, u32 *__restrict__ Jnew,
-                                                      u32 nexits, u64 *ctrl, const u64 *__restrict__ ncnt) {
+                                                      u32 *__restrict__ Tzero, const u32 *__restrict__ Jold,
+                                                      u32 *__restrict__ Jnew, u32 nexits, u64 *ctrl,
+                                                      const u64 *__restrict__ ncnt, u32 round) {
   const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ncnt) nexits = min(nexits, (u32)*ncnt);
+  if (ncnt) {
+    // device-side node count (level 4).  After a hypertile overflow the level-4 graph is only
+    // partly built (the pass is about to be redone flat): touch nothing.
+    nexits = ctrl[T_OVERFLOW] ? 0u : min(nexits, (u32)*ncnt);
+  }
   if (e >= nexits) return;
   const u32 j = Jold[e];
+  const u32 t = Told[e];
+  Tzero[e] = 0;
+  if (t) atomicAdd(&Tnew[e], t);
   if (j & XDONE) {
     Jnew[e] = j;
     return;
   }
   const u32 q = Jold[j];
-  atomicAdd(&Tnew[j], Told[e]);
+  if (t) atomicAdd(&Tnew[j], t);
   Jnew[e] = q;
-  if (!(q & XDONE)) flag_active(ctrl);
+  if (!(q & XDONE)) {  // at most one store per wave, none once this round's mark is visible
+    const u64 m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
+      if (__hip_atomic_load(&ctrl[T_XACTIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (u64)round)
+        __hip_atomic_store(&ctrl[T_XACTIVE], (u64)round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
-// generic pointer doubling driver on (T, J) ping-pong buffers; rounds are idempotent once every
-// pointer is saturated, so they are issued in batches and the "still active" flag is read only
-// between batches (one host round trip per batch).  On return *Tc / *Jc hold the result.
-int pfd_doubling_rounds(pfd_raster *h, u32 **Tc, u32 **Tn, u32 **Jc, u32 **Jn, u32 n, int first_batch,
-                        bool *done, i64 *launches, const u64 *ncnt) {
+// generic pointer doubling driver on T[3] / J[2] rotating buffers (T[0], J[0] hold the input; on
+// return T[0] / J[0] hold the result).  Rounds are idempotent once every pointer is saturated, so
+// they are issued in batches.  check == true: the "last active round" mark is read between batches
+// (one host round trip per batch) until a batch ends saturated.  check == false: exactly
+// first_batch rounds are issued and *done is left to the caller, who compares ctrl[T_XACTIVE]
+// with the returned round count at its next synchronisation.
+int pfd_doubling_rounds(pfd_raster *h, u32 *T[3], u32 *J[2], u32 n, int first_batch, bool check, bool *done,
+                        int *rounds_issued, i64 *launches, const u64 *ncnt) {
   const u32 grid = cdiv_u32(n, 256);
   *done = false;
-  int batch = first_batch;
-  for (int rounds = 0; rounds < 40 && !*done;) {
-    for (int b = 0; b < batch; ++b, ++rounds) {
-      k_coarse_prep<<<grid, 256, 0, h->stream>>>(*Tc, *Tn, n, h->ctrl, ncnt);
-      k_coarse_round<<<grid, 256, 0, h->stream>>>(*Tc, *Tn, *Jc, *Jn, n, h->ctrl, ncnt);
-      *launches += 2;
-      std::swap(*Tc, *Tn);
-      std::swap(*Jc, *Jn);
+  HIPCHK(hipMemsetAsync(T[1], 0, (size_t)n * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+  int batch = first_batch, rounds = 0;
+  while (rounds < 48 && !*done) {
+    for (int b = 0; b < batch; ++b) {
+      ++rounds;
+      k_coarse_round<<<grid, 256, 0, h->stream>>>(T[0], T[1], T[2], J[0], J[1], n, h->ctrl, ncnt, (u32)rounds);
+      ++*launches;
+      u32 *t0 = T[0];
+      T[0] = T[1], T[1] = T[2], T[2] = t0;
+      std::swap(J[0], J[1]);
     }
     KCHK();
-    u64 active = 0;
-    HIPCHK(hipMemcpyAsync(&active, h->ctrl + T_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    if (!check) break;
+    u64 last = 0;
+    HIPCHK(hipMemcpyAsync(&last, h->ctrl + T_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    *done = active == 0;
+    *done = last < (u64)rounds;  // the last round issued moved no pointer
     batch = 2;
   }
+  *rounds_issued = rounds;
   return PFD_OK;
 }
 
@@ -778,9 +813,10 @@ __device__ __forceinline__ u32 last_exit(const LastExitArgs &q, u32 f) {
 // where does the flow entering at a boundary-row cell leave the block?  (halo sink or nowhere)
 __global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, LastExitArgs q,
                                                    const u32 *__restrict__ esink, u32 ntc, u32 ntr, u32 nstc, u32 ncol,
-                                                   u32 *__restrict__ brow_sink) {
+                                                   u32 *__restrict__ brow_sink, const u64 *__restrict__ ctrl) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * ncol) return;
+  if (q.hmode && ctrl[T_OVERFLOW]) return;  // the hierarchy is only partly built: the pass is redone flat
   u32 f = brow_first[t];
   if (f != NONE32 && !(f & ENC_SINK)) {
     u32 tr, tc, p;
@@ -824,7 +860,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   n4cap = (size_t)nht * 4 * HG * SG * TS;           // hyper-exits sit on the hypertile perimeter
   PFDCHK(slots.alloc(9 * nslots * sizeof(u32)));
   PFDCHK(l3.alloc(8 * n3cap * sizeof(u32)));
-  PFDCHK(l4.alloc(5 * n4cap * sizeof(u32)));
+  PFDCHK(l4.alloc(6 * n4cap * sizeof(u32)));
   PFDCHK(hcntbuf.alloc((size_t)nht * sizeof(u32)));
   PFDCHK(esink.alloc(2 * (size_t)ntc * PSL * sizeof(u32)));
   PFDCHK(bnd.alloc(5 * nb * sizeof(u32)));  // brow_first | haloA | haloL | brow_sink | brow_inflow
@@ -863,7 +899,10 @@ int TiledRun::level3_flat(i64 *launches) {
   int batch = 1;
   for (u32 span = 1; span < (ntr + ntc) / SG + 2; span <<= 1) ++batch;  // ~log2 of a path in supertiles
   bool done3 = false;
-  PFDCHK(pfd_doubling_rounds(h, &Tc, &Tn, &Jc, &Jn, nsuper, batch + 2, &done3, launches, nullptr));
+  u32 *T[3] = {Tc, Tn, xin3}, *J[2] = {Jc, Jn};  // (xin3 is only used in hyper mode)
+  int rounds = 0;
+  PFDCHK(pfd_doubling_rounds(h, T, J, nsuper, batch + 2, true, &done3, &rounds, launches, nullptr));
+  Tc = T[0], Tn = T[1], Jc = J[0], Jn = J[1];
   coarse_done = coarse_done && done3;
   k_push3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Tc);
   ++*launches;
@@ -877,7 +916,8 @@ int TiledRun::level3_hyper(i64 *launches) {
   const u32 g3 = cdiv_u32(n3, 256);
   u32 *T3 = Tc, *J3 = Jc, *T3out = Tn;  // Jn is free: level 4 has its own buffers
   u32 *y = l4.as<u32>();
-  u32 *hx_node = y, *T4c = y + n4cap, *T4n = y + 2 * n4cap, *J4c = y + 3 * n4cap, *J4n = y + 4 * n4cap;
+  u32 *hx_node = y, *T4c = y + n4cap, *J4c = y + 3 * n4cap;
+  u32 *T4[3] = {y + n4cap, y + 2 * n4cap, y + 5 * n4cap}, *J4[2] = {y + 3 * n4cap, y + 4 * n4cap};
   HIPCHK(hipMemsetAsync(xin3, 0, (size_t)n3 * sizeof(u32), h->stream));
   k_link3<<<g3, 256, 0, h->stream>>>(sa, n3, J3);
   HyperArgs ha{nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl};
@@ -887,16 +927,17 @@ int TiledRun::level3_hyper(i64 *launches) {
   {  // level 4: the number of hyper-exits stays on the device (grids are sized for the capacity)
     const u32 cap4 = (u32)std::min<size_t>(n4cap, 0x7FFFFFFF);
     const u32 g4 = cdiv_u32(cap4, 256);
-    HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
     k_link4<<<g4, 256, 0, h->stream>>>(ha, cap4, J4c);
-    // converged rounds cost ~8 us, a host round trip ~40: start with a generous batch
-    int batch = 6;
+    // No host round trip here: a fixed number of rounds is issued (rounds past saturation are
+    // idempotent) and the "last round that moved a pointer" mark is compared with it at the pass's
+    // final synchronisation; a miss redoes the pass with more rounds.
+    int batch = 5 + extra_rounds;
     for (u32 span = 1; span < (ntr + ntc) / (SG * HG) + 2; span <<= 1) ++batch;  // ~log2 of a path in hypertiles
+    if (const char *e = getenv("PFD_TEST_ROUNDS4")) batch = atoi(e) + extra_rounds;  // (tests: force a miss)
     bool done4 = false;
-    PFDCHK(pfd_doubling_rounds(h, &T4c, &T4n, &J4c, &J4n, cap4, batch, &done4, launches, h->ctrl + T_NHYPER));
-    J4fin = J4c;
-    coarse_done = coarse_done && done4;
-    k_push4<<<g4, 256, 0, h->stream>>>(ha, cap4, T4c, xin3);
+    PFDCHK(pfd_doubling_rounds(h, T4, J4, cap4, batch, false, &done4, &rounds4, launches, h->ctrl + T_NHYPER));
+    J4fin = J4[0];
+    k_push4<<<g4, 256, 0, h->stream>>>(ha, cap4, T4[0], xin3);
     *launches += 2;
   }
   k_hyper<true><<<nht, 1024, 0, h->stream>>>(ha);
@@ -977,7 +1018,7 @@ int TiledRun::phase_a() {
                                                             haloL, ne);
     LastExitArgs le{R2, sxid, sx_slot, xtgt, elink, Jc, R3, hx_id, l4.as<u32>(), J4fin, sa.hmode};
     k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, le, esink.as<u32>(), ntc, ntr, nstc, (u32)h->ncol,
-                                                         brow_sink);
+                                                         brow_sink, h->ctrl);
     launches += 3;
     KCHK();
   }
@@ -1024,7 +1065,9 @@ int TiledRun::phase_b(int *complete) {
   // saturate; T_OVERFLOW: a hypertile held more super-exits than fit in LDS (result invalid: redo flat)
   *complete = coarse_done && c[T_SLIVE - 8] == 0 && c[T_UNSAT - 8] == 0;
   overflowed = c[T_OVERFLOW - 8] != 0;
-  if (overflowed) *complete = 0;
+  // level 4 ran a fixed number of rounds: saturated iff the last one moved no pointer
+  short_of_rounds = sa.hmode && rounds4 > 0 && c[T_XACTIVE - 8] >= (u64)rounds4;
+  if (overflowed || short_of_rounds) *complete = 0;
   return PFD_OK;
 }
 
@@ -1032,12 +1075,17 @@ int TiledRun::phase_b(int *complete) {
 // the per-hypertile id range has to be known (and repaired by a flat re-run) before that
 int TiledRun::phase_a_checked() {
   PFDCHK(phase_a());
-  if (!sa.hmode) return PFD_OK;
-  u64 ov = 0;
-  HIPCHK(hipMemcpyAsync(&ov, h->ctrl + T_OVERFLOW, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (ov) {
-    force_flat = true;
+  for (int tries = 0; sa.hmode && tries < 3; ++tries) {
+    u64 c[8];
+    HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (c[T_OVERFLOW - 8]) {
+      force_flat = true;
+    } else if (rounds4 > 0 && c[T_XACTIVE - 8] >= (u64)rounds4 && tries < 2) {
+      extra_rounds += 8;  // (a cyclic exit graph never saturates: give up after two extensions)
+    } else {
+      break;
+    }
     PFDCHK(phase_a());
   }
   return PFD_OK;
@@ -1051,8 +1099,14 @@ int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
   if (!run.supported) return PFD_OK;
   PFDCHK(run.phase_a());
   PFDCHK(run.phase_b(complete));
-  if (run.overflowed) {  // rare: redo the pass with one flat id range for level 3
-    run.force_flat = true;
+  for (int tries = 0; tries < 3 && (run.overflowed || (run.short_of_rounds && tries < 2)); ++tries) {
+    // rare: a hypertile overflowed its LDS id range (redo with one flat id range for level 3), or
+    // level 4 needed more rounds than were issued (a cyclic exit graph never saturates: two
+    // extensions, then the level engine takes over)
+    if (run.overflowed)
+      run.force_flat = true;
+    else
+      run.extra_rounds += 8;
     PFDCHK(run.phase_a());
     PFDCHK(run.phase_b(complete));
   }

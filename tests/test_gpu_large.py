@@ -94,3 +94,17 @@ def test_hypertile_overflow_fallback(gpu_lib, oracle, monkeypatch):
     flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
     assert np.array_equal(flw.upstream_area(), exp)
     assert np.array_equal(dist.upstream_area_blocks(d8, 2), exp)
+
+
+def test_level4_round_budget_miss(gpu_lib, oracle, monkeypatch):
+    """Level 4 of the exit graph issues a fixed number of doubling rounds without asking the host;
+    too few (forced here) must be noticed at the end of the pass and repaired by a longer re-run."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd import dist
+
+    d8 = oracle.synth_d8(4200, 4300, seed=9, tilt=1 << 26, white=2, nodata_pct=0)  # 3 x 3 hypertiles, long rivers
+    exp, _, _ = oracle.upstream_area_cell(d8)
+    monkeypatch.setenv("PFD_TEST_ROUNDS4", "1")
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    assert np.array_equal(flw.upstream_area(), exp)
+    assert np.array_equal(dist.upstream_area_blocks(d8, 2), exp)

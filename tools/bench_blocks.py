@@ -12,7 +12,7 @@ for b in range(nb):
 outs = [_hip.DeviceBuffer(n * n * 4) for _ in range(nb)]
 for it in range(3):
     _hip.check(L.pfd_device_synchronize(0)); t0 = time.perf_counter()
-    hs = [_hip.RasterHandle(bufs[b], n, n, device=0, memspace=_hip.PFD_DEVICE, halo=dist.halo_of(b, nb)) for b in range(nb)]
+    hs = [_hip.RasterHandle(bufs[b], n, n, device=0, memspace=_hip.PFD_DEVICE, halo=dist.halo_of(b, nb), deferred=True) for b in range(nb)]
     for h in hs: h.set_profiling(True)
     _hip.upstream_area_cell_blocks(hs, outs=outs, memspace=_hip.PFD_DEVICE)
     _hip.check(L.pfd_device_synchronize(0)); t1 = time.perf_counter()
