@@ -39,13 +39,13 @@ B_ALG_TOTAL = 29.0
 B_ALG_PHASE = {"order_cells": 8.0, "init": 4.0, "sweep_count_up": 17.0,
                "tile_local": 8.0, "exit_graph": 4.0, "tile_final": 17.0}
 # segment -> the kernel it times (names as rocprofv3 prints them); single-launch segments only
-KERNEL_OF = {"tile_local": "void k_tile<false>(TileArgs)", "tile_final": "void k_tile<true>(TileArgs)",
+KERNEL_OF = {"tile_local": "void k_tile<false, true>(TileArgs)", "tile_final": "void k_tile<true, false>(TileArgs)",
              "order_cells": "k_bfs_level(...)", "sweep_count_up": "void k_sweep<CountUp>(...)"}
 # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3
 # --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of this same command, 10000 x 10000):
 # bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024, raw counter values (calibration in DESIGN.md)
-PMC_TRAFFIC = {("void k_tile<true>(TileArgs)", 10000): (185267.325 + 391395.281) * 1024,
-               ("void k_tile<false>(TileArgs)", 10000): (172864.663 + 75801.5) * 1024}
+PMC_TRAFFIC = {("void k_tile<true, false>(TileArgs)", 10000): (147187.047 + 390625.000) * 1024,  # profiles/r01e_*
+               ("void k_tile<false, true>(TileArgs)", 10000): (176831.812 + 221867.781) * 1024}
 
 
 def roofline_of(segs, n, size, ms_per_step):

@@ -998,10 +998,10 @@ int TiledRun::phase_a() {
     a.raw = h->raw;
     a.tcnt = tcntbuf.as<u64>();
     k_tile<false, true><<<grid, 256, 0, h->stream>>>(a);
-    k_tile_counts<<<1, 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);
     fused_norm = true;
     KCHK();
-    pfd_seg_end(h, 2);
+    pfd_seg_end(h, 1);
+    k_tile_counts<<<1, 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);  // (10 us, outside the segments)
   } else {
     k_tile<false><<<grid, 256, 0, h->stream>>>(a);
     KCHK();
@@ -1067,6 +1067,7 @@ int TiledRun::phase_b(int *complete) {
   overflowed = c[T_OVERFLOW - 8] != 0;
   // level 4 ran a fixed number of rounds: saturated iff the last one moved no pointer
   short_of_rounds = sa.hmode && rounds4 > 0 && c[T_XACTIVE - 8] >= (u64)rounds4;
+  if (getenv("PFD_DEBUG_ROUNDS")) fprintf(stderr, "[level4] rounds issued %d, last active %llu\n", rounds4, (unsigned long long)c[T_XACTIVE - 8]);
   if (overflowed || short_of_rounds) *complete = 0;
   return PFD_OK;
 }

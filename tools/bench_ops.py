@@ -29,6 +29,9 @@ sync(); t1 = time.perf_counter()
 print(f"raster {nrow}x{ncol} nodata_pct={nd} tilt={tilt}: create {1e3*(t1-t0):.2f} ms, {h.info()}")
 out4 = _hip.DeviceBuffer(n * 4)
 timed("upstream_area(cell)", lambda: h.upstream_area_cell(out=out4, memspace=_hip.PFD_DEVICE))
+# (first use pays hipMalloc of the sort buffers — ~0.4 s at 30000^2; the caching allocator keeps
+#  them, so time the ordering of a second handle)
+h0 = _hip.RasterHandle(d8, nrow, ncol, device=0, memspace=_hip.PFD_DEVICE); h0.order_cells(); h0.close(); del h0
 sync(); t0 = time.perf_counter(); h.order_cells(); sync(); t1 = time.perf_counter()
 info = h.info()
 print(f"{'order_cells':22s} {1e3*(t1-t0):10.2f} ms  {n/(t1-t0)/1e6:10.1f} Mcells/s  levels={info['n_levels']} n_seq={info['n_seq']} "
