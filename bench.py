@@ -129,7 +129,7 @@ def run_distributed(a, rank, world, local):
     from pyflwdir_amd import dist as pdist
 
     dist.init_process_group(backend="gloo")  # rendezvous / barrier / max-reduce only (CPU, 128-byte id)
-    device = local
+    device = local % max(1, _hip.device_count())  # (one rank per GPU; the modulo only matters on test boxes)
     ncol = a.size
     nrow_total = a.size * world
     r0, r1 = rank * a.size, (rank + 1) * a.size

@@ -165,6 +165,29 @@ int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k
 int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, double *out,
              int memspace);
 
+/* ---- SURVEY 8(f)-1 -------------------------------------------------------------------------
+ * core.main_upstream (reference pyflwdir/core.py:191-219; Flwdir.main_upstream flwdir.py:252-258):
+ * per cell the linear index of the upstream cell with the largest `uparea` (payload dtype
+ * PFD_I32 / PFD_I64 / PFD_F32 / PFD_F64; strictly larger than upa_min, cast to that dtype, and
+ * than every upstream cell of lower index), the index dtype's missing value (-1 / 0xFFFFFFFF)
+ * for headwaters and nodata cells.  out: n indices of idx_dtype. */
+int pfd_main_upstream(pfd_raster *h, int dtype, const void *uparea, double upa_min, int idx_dtype, void *out,
+                      int memspace);
+/* streams.stream_order, the classic "bottom up" order (reference pyflwdir/streams.py:191-225;
+ * Flwdir.stream_order(type="classic") flwdir.py:540-543): uint8; pits 1, tributaries (cells that
+ * are not the main upstream cell of a downstream cell with more than one upstream cell inside
+ * `mask`) one more than the cell they drain into, 0 outside `mask` (nullable: all cells). */
+int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void *idxs_us_main, const uint8_t *mask,
+                             uint8_t *out, int memspace);
+/* streams.stream_distance (reference pyflwdir/streams.py:272-315; FlwdirRaster.stream_distance
+ * pyflwdir.py:837-863): distance to the outlet or to the next downstream cell with mask != 0
+ * (nullable), -9999 for cells that do not drain to a pit.  real_length == 0: int32 cell counts.
+ * real_length != 0: float32; `step_lengths` (HOST pointer, 3 * (2*nrow - 1) floats) holds the
+ * length of one step by row sum r0 + r1 and kind {vertical, horizontal, diagonal} — the host
+ * evaluates gis_utils.distance (gis_utils.py:452-486), the device only adds in float32. */
+int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_length, const float *step_lengths, void *out,
+                        int memspace);
+
 /* ---- multi-GPU: upstream_area(unit="cell") on a raster row-tiled over several GPUs -----------
  * In-process form: `hs` are the nblocks row-block handles (top to bottom) of ONE process,
  * outs[b] receives own_rows(b)*ncol int32. */

@@ -8,7 +8,8 @@ reference's own test-suite forces with NUMBA_DISABLE_JIT=1, reference
 tests/conftest.py:7) and records its outputs for the hot path:
 
     core_d8.from_array / core.upstream_count / core.idxs_seq / core.rank and the
-    FlwdirRaster methods upstream_area, accuflux (up & down), stream_order, basins, hand.
+    FlwdirRaster methods upstream_area, accuflux (up & down), stream_order (Strahler and classic),
+    basins, hand, main_upstream / idxs_us_main, stream_distance.
 
 Inputs are the reference's own test rasters (tests/data/flwdir.asc, flwdir1.asc, the seeded
 from_dem raster of tests/conftest.py:57-60, examples/rhine_d8.tif + rhine_elv0.tif) and
@@ -169,6 +170,16 @@ def run_case(name, case):
     res["hand_f32"] = flw.hand(drain, elevtn)
     res["hand_f64"] = flw.hand(drain, elevtn.astype(np.float64) * 1.000001)
     res["hand_thr"] = np.int64(thr)
+    # ---- main upstream cell, classic stream order, stream distance ----------
+    res["idxs_us_main"] = flw.idxs_us_main                                   # uparea = upstream_area() int32
+    res["idxs_us_main_km2"] = flw.main_upstream(uparea=res["uparea_km2_latlon"])  # float64 areas
+    res["strord_classic"] = flw.stream_order(type="classic")
+    res["strord_classic_mask"] = flw.stream_order(type="classic", mask=upa > thr)
+    res["strdist_cell"] = flw.stream_distance(unit="cell")
+    res["strdist_cell_mask"] = flw.stream_distance(mask=upa > thr, unit="cell")
+    res["strdist_m_latlon"] = flw.stream_distance(unit="m")
+    res["strdist_m_proj"] = flw_proj.stream_distance(unit="m")
+    res["strdist_m_mask"] = flw.stream_distance(mask=GI.random_mask(d8.shape), unit="m")
 
     stats = dict(shape=[int(nrow), int(ncol)], n_valid=int(res["n_valid"]), n_pits=int(res["idxs_pit_int32"].size),
                  n_seq=int(res["idxs_seq_int32"].size), max_rank=int(res["rank"].max()),

@@ -183,6 +183,78 @@ def height_above_nearest_drain(idxs_ds, seq, drain, elevtn):
     return out
 
 
+def main_upstream(idxs_ds, uparea, upa_min=0.0):
+    """core.main_upstream (reference pyflwdir/core.py:191-219)."""
+    uparea = np.ascontiguousarray(uparea)
+    if np.dtype(uparea.dtype) not in _ACC:
+        uparea = uparea.astype(np.float64)
+    sfx, ct = _ACC[np.dtype(uparea.dtype)]
+    out = np.empty(idxs_ds.size, idxs_ds.dtype)
+    f = getattr(lib(), f"orc_main_upstream_{_sfx(idxs_ds)}_{sfx}")
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, ct, C.c_void_p]
+    # np.full(n, upa_min, dtype=uparea.dtype): the threshold is cast to the dtype of uparea
+    f(_p(idxs_ds), idxs_ds.size, _p(uparea), ct(uparea.dtype.type(upa_min).item()), _p(out))
+    return out
+
+
+def stream_order_classic(idxs_ds, seq, idxs_us_main, mask=None):
+    """streams.stream_order (reference pyflwdir/streams.py:191-225)."""
+    n = idxs_ds.size
+    out = np.empty(n, np.uint8)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    seq = np.ascontiguousarray(seq, dtype=idxs_ds.dtype)
+    main = np.ascontiguousarray(idxs_us_main, dtype=idxs_ds.dtype)
+    f = getattr(lib(), f"orc_stream_order_classic_{_sfx(idxs_ds)}")
+    f.restype = None
+    f(_p(idxs_ds), C.c_int64(n), _p(seq), C.c_int64(seq.size), _p(main), _p(m), _p(out))
+    return out
+
+
+def step_length_table(nrow, latlon, transform):
+    """float32 length of one D8 step, [2*nrow-1, 3]: row sum r0+r1 x {vertical, horizontal, diagonal}.
+    Restates gis_utils.distance (reference pyflwdir/gis_utils.py:452-486) with gis_utils.degree_metres_y/x
+    (:415-448), scalar by scalar like the reference evaluates it (incl. its projected-CRS quirk dy = xres,
+    dx = yres); the float32 rounding is the `float32 + python float` of the interpreted reference."""
+    import math
+
+    xres, yres, north = transform[0], transform[4], transform[5]
+    tab = np.zeros((max(1, 2 * nrow - 1), 3), np.float32)
+
+    def dmy(lat):
+        radlat = np.radians(lat)
+        return 111132.92 + (-559.82 * np.cos(2.0 * radlat)) + (1.175 * np.cos(4.0 * radlat)) + (-0.0023 * np.cos(6.0 * radlat))
+
+    def dmx(lat):
+        radlat = np.radians(lat)
+        return (111412.84 * np.cos(radlat)) + (-93.5 * np.cos(3.0 * radlat)) + (0.118 * np.cos(5.0 * radlat))
+
+    for s in range(2 * nrow - 1):
+        for kind, (dr, dc) in enumerate(((1, 0), (0, 1), (1, 1))):
+            if latlon:
+                lat = north + s / 2.0 * yres
+                dy = 0.0 if dr == 0 else dmy(lat) * yres
+                dx = 0.0 if dc == 0 else dmx(lat) * xres
+            else:
+                dy, dx = xres, yres
+            tab[s, kind] = np.float32(math.hypot(dy * dr, dx * dc))
+    return tab
+
+
+def stream_distance(idxs_ds, seq, ncol, mask=None, real_length=True, latlon=False, transform=(1, 0, 0, 0, 1, 0)):
+    """streams.stream_distance (reference pyflwdir/streams.py:272-315)."""
+    n = idxs_ds.size
+    out = np.empty(n, np.float32 if real_length else np.int32)
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    seq = np.ascontiguousarray(seq, dtype=idxs_ds.dtype)
+    tab = step_length_table(n // ncol, latlon, transform) if real_length else None
+    f = getattr(lib(), f"orc_stream_distance_{_sfx(idxs_ds)}")
+    f.restype = None
+    f(_p(idxs_ds), C.c_int64(n), _p(seq), C.c_int64(seq.size), C.c_int64(ncol), _p(m), C.c_int(int(real_length)),
+      _p(tab), _p(out))
+    return out
+
+
 def upstream_area_cell(d8, dtype=None):
     """Whole reference pipeline for ``upstream_area(unit="cell")``; returns
     (uparea int32 2-D, timings dict, stats dict)."""

@@ -35,7 +35,7 @@ SYMBOLS = [
     "pfd_comm_destroy", "pfd_upstream_area_cell_dist", "pfd_upstream_area_cell_begin", "pfd_upstream_area_cell_finish",
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
-    "pfd_basins", "pfd_hand", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
+    "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32",
 ]
 
@@ -87,6 +87,9 @@ def lib() -> C.CDLL:
         L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_main_upstream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int]
+        L.pfd_stream_order_classic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_stream_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int)]
@@ -292,6 +295,31 @@ class RasterHandle:
         if memspace == PFD_HOST:
             out = np.empty(self.n, np.float64)
         check(lib().pfd_hand(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(out), memspace))
+        return out
+
+    def main_upstream(self, uparea, dtype_code, idx_dtype, upa_min=0.0, out=None, memspace=PFD_HOST):
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, idx_dtype)
+        check(lib().pfd_main_upstream(self._h, dtype_code, ptr(uparea), float(upa_min), IDX_CODE[np.dtype(idx_dtype)],
+                                      ptr(out), memspace))
+        return out
+
+    def stream_order_classic(self, idxs_us_main, mask=None, out=None, memspace=PFD_HOST):
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, np.uint8)
+        check(lib().pfd_stream_order_classic(self._h, IDX_CODE[np.dtype(idxs_us_main.dtype)], ptr(idxs_us_main),
+                                             ptr(mask), ptr(out), memspace))
+        return out
+
+    def stream_distance(self, mask=None, step_lengths=None, out=None, memspace=PFD_HOST):
+        """``step_lengths`` None: int32 cell counts; else float32 with the host table [2*nrow-1, 3]."""
+        real = step_lengths is not None
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, np.float32 if real else np.int32)
+        if real:
+            step_lengths = np.ascontiguousarray(step_lengths, dtype=np.float32)
+            assert step_lengths.size == 3 * (2 * self.nrow - 1)
+        check(lib().pfd_stream_distance(self._h, ptr(mask), int(real), ptr(step_lengths), ptr(out), memspace))
         return out
 
 

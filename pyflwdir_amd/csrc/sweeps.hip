@@ -473,3 +473,219 @@ extern "C" int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, con
     PFDCHK(hand_t<double>(h, (const u8 *)dr.dev, el.dev, (double *)o.dev));
   return o.finish(h->stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// main upstream cell, classic stream order, stream distance
+//   core.main_upstream        pyflwdir/core.py:191-219      k_main_upstream (no ordering needed)
+//   streams.stream_order      pyflwdir/streams.py:191-225   k_trib_flag + Classic (down- to upstream)
+//   streams.stream_distance   pyflwdir/streams.py:272-315   Dist<T>            (down- to upstream)
+// ---------------------------------------------------------------------------------------------
+template <class I> struct IdxMv;
+template <> struct IdxMv<i32> { static __device__ __forceinline__ i32 mv() { return -1; } };
+template <> struct IdxMv<u32> { static __device__ __forceinline__ u32 mv() { return 0xFFFFFFFFu; } };
+template <> struct IdxMv<i64> { static __device__ __forceinline__ i64 mv() { return -1; } };
+
+// the reference scans the cells in ascending index and keeps a child only if its area is
+// strictly larger than the best so far (initially upa_min): first maximum in ascending order
+template <class T, class I>
+__global__ void __launch_bounds__(256) k_main_upstream(const u8 *__restrict__ ncode, Geo g, const T *__restrict__ uparea,
+                                                       T upa_min, I *__restrict__ out) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.n) return;
+  I best_i = IdxMv<I>::mv();
+  if (ncode[x] != D8_MV) {
+    const u32 r = geo_row(g, x), c = x - r * g.ncol;
+    T best = upa_min;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = PFD_SLOT_ASC[q];
+      u32 nb;
+      if (d8_child(ncode, g, x, r, c, k, &nb)) {
+        const T a = uparea[nb];
+        if (a > best) {
+          best = a;
+          best_i = (I)nb;
+        }
+      }
+    }
+  }
+  out[x] = best_i;
+}
+
+// flag[x] = 1 when x is a tributary at a confluence: its downstream cell has more than one
+// upstream cell inside the mask (core.upstream_count with mask, core.py:50-61) and x is not that
+// cell's main upstream cell
+template <class I>
+__global__ void __launch_bounds__(256) k_trib_flag(const u8 *__restrict__ ncode, Geo g, const I *__restrict__ main_us,
+                                                   const u8 *__restrict__ mask, u8 *__restrict__ flag) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.n) return;
+  u8 f = 0;
+  const u32 code = ncode[x];
+  if (d8_is_dir(code)) {
+    const u32 p = d8_down(g, x, code);
+    const u32 r = geo_row(g, p), c = p - r * g.ncol;
+    u32 nup = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      u32 nb;
+      if (d8_child(ncode, g, p, r, c, k, &nb) && (mask == nullptr || mask[nb])) ++nup;
+    }
+    f = (nup > 1 && main_us[p] != (I)x) ? 1 : 0;
+  }
+  flag[x] = f;
+}
+
+struct Classic {
+  const u8 *ncode;
+  Geo g;
+  const u8 *flag;
+  const u8 *mask;  // may be null
+  u8 *out;
+  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
+    if (mask != nullptr && !mask[x]) return;  // stays 0
+    const u32 p = d8_down(g, x, code);
+    out[x] = (p == x) ? (u8)1 : (u8)(out[p] + flag[x]);  // uint8 arithmetic like the reference
+  }
+};
+
+template <class T>
+struct Dist {
+  const u8 *ncode;
+  Geo g;
+  const u8 *mask;     // may be null
+  const float *dtab;  // T == float: [3 * (2*nrow-1)] step lengths by row sum and kind of step
+  T *out;
+  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
+    const u32 p = d8_down(g, x, code);
+    if (p == x || (mask != nullptr && mask[x])) {
+      out[x] = (T)0;
+      return;
+    }
+    if (sizeof(T) == 4 && dtab != nullptr) {
+      const int k = d8_slot(code);
+      const int dr = d8_dr(k), dc = d8_dc(k);
+      const u32 r0 = geo_row(g, x);
+      const u32 s = 2u * r0 + (u32)dr;  // r0 + r1
+      const int kind = (dr != 0 && dc != 0) ? 2 : (dr != 0 ? 0 : 1);
+      out[x] = (T)((float)out[p] + dtab[3u * s + (u32)kind]);
+    } else {
+      out[x] = (T)((u32)out[p] + 1u);
+    }
+  }
+};
+
+template <class T, class I>
+static void launch_main_upstream(pfd_raster *h, const void *upa, double upa_min, void *out) {
+  k_main_upstream<T, I><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo, (const T *)upa, (T)upa_min,
+                                                                        (I *)out);
+}
+template <class T>
+static int main_upstream_t(pfd_raster *h, const void *upa, double upa_min, int idx_dtype, void *out) {
+  if (idx_dtype == PFD_I32)
+    launch_main_upstream<T, i32>(h, upa, upa_min, out);
+  else if (idx_dtype == PFD_U32)
+    launch_main_upstream<T, u32>(h, upa, upa_min, out);
+  else
+    launch_main_upstream<T, i64>(h, upa, upa_min, out);
+  KCHK();
+  return PFD_OK;
+}
+static size_t idx_bytes(int idx_dtype) {
+  return idx_dtype == PFD_I32 || idx_dtype == PFD_U32 ? 4 : (idx_dtype == PFD_I64 ? 8 : 0);
+}
+static size_t payload_bytes(int dtype) {
+  return dtype == PFD_I32 || dtype == PFD_F32 ? 4 : (dtype == PFD_I64 || dtype == PFD_F64 ? 8 : 0);
+}
+
+extern "C" int pfd_main_upstream(pfd_raster *h, int dtype, const void *uparea, double upa_min, int idx_dtype,
+                                 void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_require_whole(h, "pfd_main_upstream"));
+  const size_t es = idx_bytes(idx_dtype), ps = payload_bytes(dtype);
+  if (!uparea || !out || !es || !ps) {
+    pfd_set_error("pfd_main_upstream: bad arguments (dtype %d, index dtype %d)", dtype, idx_dtype);
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  InArg a;
+  PFDCHK(a.bind(uparea, (size_t)h->n * ps, memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * es, memspace));
+  pfd_seg_begin(h, "main_upstream");
+  int rc;
+  switch (dtype) {
+    case PFD_I32: rc = main_upstream_t<i32>(h, a.dev, upa_min, idx_dtype, o.dev); break;
+    case PFD_I64: rc = main_upstream_t<i64>(h, a.dev, upa_min, idx_dtype, o.dev); break;
+    case PFD_F32: rc = main_upstream_t<float>(h, a.dev, upa_min, idx_dtype, o.dev); break;
+    default: rc = main_upstream_t<double>(h, a.dev, upa_min, idx_dtype, o.dev); break;
+  }
+  PFDCHK(rc);
+  pfd_seg_end(h, 1);
+  return o.finish(h->stream);
+}
+
+extern "C" int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void *idxs_us_main, const uint8_t *mask,
+                                        uint8_t *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  const size_t es = idx_bytes(idx_dtype);
+  if (!idxs_us_main || !out || !es) {
+    pfd_set_error("pfd_stream_order_classic: bad arguments (index dtype %d)", idx_dtype);
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  PFDCHK(pfd_order_cells_impl(h));
+  InArg mu, m;
+  PFDCHK(mu.bind(idxs_us_main, (size_t)h->n * es, memspace, h->stream));
+  PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n, memspace));
+  DevBuf flag;
+  PFDCHK(flag.alloc((size_t)h->n));
+  pfd_seg_begin(h, "init");
+  HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
+  const u32 grid = cdiv_u32((u64)h->n, 256);
+  if (idx_dtype == PFD_I32)
+    k_trib_flag<i32><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const i32 *)mu.dev, (const u8 *)m.dev, flag.as<u8>());
+  else if (idx_dtype == PFD_U32)
+    k_trib_flag<u32><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const u32 *)mu.dev, (const u8 *)m.dev, flag.as<u8>());
+  else
+    k_trib_flag<i64><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const i64 *)mu.dev, (const u8 *)m.dev, flag.as<u8>());
+  KCHK();
+  pfd_seg_end(h, 2);
+  Classic op{h->ncode, h->geo, flag.as<u8>(), (const u8 *)m.dev, (u8 *)o.dev};
+  PFDCHK(run_down(h, op, "sweep_classic_order", 0));
+  return o.finish(h->stream);  // (synchronises: `flag` may be released afterwards)
+}
+
+extern "C" int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_length, const float *step_lengths,
+                                   void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!out || (real_length && !step_lengths)) {
+    pfd_set_error("pfd_stream_distance: bad arguments");
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  PFDCHK(pfd_order_cells_impl(h));
+  InArg m, tab;
+  PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
+  if (real_length)  // the table always comes from the host
+    PFDCHK(tab.bind(step_lengths, 3 * (size_t)(2 * h->nrow - 1) * sizeof(float), PFD_HOST, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * 4, memspace));
+  pfd_seg_begin(h, "init");
+  if (real_length)
+    k_fill<float><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((float *)o.dev, h->geo.n, -9999.0f);
+  else
+    k_fill<i32><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((i32 *)o.dev, h->geo.n, -9999);
+  KCHK();
+  pfd_seg_end(h, 1);
+  if (real_length) {
+    Dist<float> op{h->ncode, h->geo, (const u8 *)m.dev, (const float *)tab.dev, (float *)o.dev};
+    PFDCHK(run_down(h, op, "sweep_stream_distance", 0));
+  } else {
+    Dist<i32> op{h->ncode, h->geo, (const u8 *)m.dev, nullptr, (i32 *)o.dev};
+    PFDCHK(run_down(h, op, "sweep_stream_distance", 0));
+  }
+  return o.finish(h->stream);  // (synchronises: the staged table may be released afterwards)
+}

@@ -65,6 +65,41 @@ def area_grid(transform, shape, latlon=False, unit="m2"):
     return np.full(shape, area0, dtype=np.float32)
 
 
+def degree_metres_y(lat):
+    """Vertical length of a degree [m] at a latitude; reference gis_utils.py:415-431."""
+    radlat = np.radians(lat)
+    return 111132.92 + (-559.82 * np.cos(2.0 * radlat)) + (1.175 * np.cos(4.0 * radlat)) + (-0.0023 * np.cos(6.0 * radlat))
+
+
+def degree_metres_x(lat):
+    """Horizontal length of a degree [m] at a latitude; reference gis_utils.py:434-448."""
+    radlat = np.radians(lat)
+    return (111412.84 * np.cos(radlat)) + (-93.5 * np.cos(3.0 * radlat)) + (0.118 * np.cos(5.0 * radlat))
+
+
+def step_length_table(nrow, latlon=False, transform=IDENTITY):
+    """float32 length of one D8 step as ``[2*nrow-1, 3]``: (row of the cell + row of its downstream
+    cell) x {vertical, horizontal, diagonal}.  ``gis_utils.distance(idx0, idx1, ncol, latlon,
+    transform)`` (reference gis_utils.py:452-486) depends on nothing else, so the host evaluates it
+    once per row pair — scalar by scalar, in the reference's own expression order (including its
+    projected-CRS assignment ``dy = xres; dx = yres``) — and the device only adds.  The float32
+    rounding is the reference's ``dist[idx_ds] + d`` (float32 scalar + Python float)."""
+    import math
+
+    xres, yres, north = transform[0], transform[4], transform[5]
+    tab = np.zeros((max(1, 2 * nrow - 1), 3), np.float32)
+    for s in range(2 * nrow - 1):
+        for kind, (dr, dc) in enumerate(((1, 0), (0, 1), (1, 1))):
+            if latlon:
+                lat = north + s / 2.0 * yres
+                dy = 0.0 if dr == 0 else degree_metres_y(lat) * yres
+                dx = 0.0 if dc == 0 else degree_metres_x(lat) * xres
+            else:
+                dy, dx = xres, yres
+            tab[s, kind] = np.float32(math.hypot(dy * dr, dx * dc))
+    return tab
+
+
 _OFFSETS = {"center": (0.5, 0.5), "ul": (0, 0), "ur": (1, 0), "ll": (0, 1), "lr": (1, 1)}
 
 

@@ -370,13 +370,45 @@ class FlwdirRaster(object):
                 strord = self._h.strahler(m)
                 if self.cache:
                     self._cached.update(strord=strord)
-        elif type.lower() == "classic":
-            raise NotImplementedError('stream_order(type="classic") is a "next" row of the scope table '
-                                      "(SURVEY.md §8f-1) and not on the GPU path yet")
+        elif type.lower() == "classic":  # reference pyflwdir/flwdir.py:540-543, streams.py:191-225
+            m = None if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
+            strord = self._h.stream_order_classic(np.ascontiguousarray(self.idxs_us_main), m)
         else:
             # the reference falls through to an UnboundLocalError here; be explicit instead
             raise ValueError(f'Unknown stream order type: {type}, select from ["strahler", "classic"].')
         return strord.reshape(self.shape)
+
+    def stream_distance(self, mask=None, unit="cell"):
+        """Distance to the outlet or to the next downstream True cell of ``mask``: int32 cell counts
+        (``unit="cell"``) or float32 metres (``unit="m"``); reference pyflwdir/pyflwdir.py:837-863."""
+        unit = str(unit).lower()
+        if unit not in ["m", "cell"]:
+            raise ValueError(f'Unknown unit: {unit}, select from "m", "cell"')
+        mask = self._check_data(mask, "mask", optional=True)
+        m = None if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
+        tab = None if unit == "cell" else gis.step_length_table(self.shape[0], self.latlon, self.transform)
+        return self._h.stream_distance(m, tab).reshape(self.shape)
+
+    def main_upstream(self, uparea=None):
+        """Linear index of the upstream cell with the largest ``uparea`` (default: the upstream cell
+        count), the index dtype's missing value at headwaters; reference pyflwdir/flwdir.py:252-258,
+        pyflwdir/core.py:191-219."""
+        uparea = self._check_data(uparea, "uparea")
+        if uparea.dtype not in _PAYLOAD:
+            if uparea.dtype.kind not in "iubf":
+                raise NotImplementedError(f"uparea dtype {uparea.dtype} is not supported on the HIP path")
+            uparea = uparea.astype(np.float64 if uparea.dtype.kind == "f" else np.int64)
+        idxs_us_main = self._h.main_upstream(np.ascontiguousarray(uparea), _PAYLOAD[uparea.dtype], self._idx_dtype)
+        if self.cache:
+            self._cached.update(idxs_us_main=idxs_us_main)
+        return idxs_us_main
+
+    @property
+    def idxs_us_main(self):
+        """Linear indices of the main upstream cell; reference pyflwdir/flwdir.py:153-161."""
+        if "idxs_us_main" in self._cached:
+            return self._cached["idxs_us_main"]
+        return self.main_upstream()
 
     def basins(self, idxs=None, xy=None, ids=None, **kwargs):
         """(Sub)basin map with a unique ID per (sub)basin; reference pyflwdir/pyflwdir.py:564-599."""

@@ -51,6 +51,18 @@ def test_vs_oracle(gpu_lib, oracle, shape, seed, kw):
     hand = flw.hand(drain, elev)
     assert np.array_equal(hand.ravel(), O.height_above_nearest_drain(idxs_ds, seq, drain.ravel(), elev.ravel()))
     assert np.array_equal(flw.rank.ravel(), O.rank(idxs_ds)[0])
+    # SURVEY 8(f)-1 functions
+    main = O.main_upstream(idxs_ds, upa_o.ravel())
+    assert np.array_equal(flw.idxs_us_main, main)
+    assert np.array_equal(flw.main_upstream(uparea=acc), O.main_upstream(idxs_ds, acc_o.ravel()))  # float32 areas
+    assert np.array_equal(flw.stream_order(type="classic").ravel(), O.stream_order_classic(idxs_ds, seq, main))
+    assert np.array_equal(flw.stream_order(type="classic", mask=drain).ravel(),
+                          O.stream_order_classic(idxs_ds, seq, main, drain.ravel()))
+    assert np.array_equal(flw.stream_distance(unit="cell").ravel(),
+                          O.stream_distance(idxs_ds, seq, shape[1], real_length=False))
+    assert np.array_equal(flw.stream_distance(mask=drain, unit="m").ravel(),
+                          O.stream_distance(idxs_ds, seq, shape[1], mask=drain.ravel(), latlon=False,
+                                            transform=tuple(flw.transform)[:6]))
 
 
 def test_add_pits(gpu_lib, oracle):

@@ -100,6 +100,36 @@ def test_strahler_basins_hand(case, flw):
     case.check("hand_f64", flw.hand(D["drain"], D["elevtn"].astype(np.float64) * 1.000001))
 
 
+def test_streams_next(case, flw):
+    """main upstream cell, classic stream order, stream distance (reference
+    tests/test_streams_basins.py:154-168, tests/test_pyflwdir.py:310-327)."""
+    upa = flw.upstream_area()
+    D = derived_inputs(case, upa, flw.idxs_pit)
+    case.check("idxs_us_main", flw.idxs_us_main)
+    case.check("idxs_us_main_km2", flw.main_upstream(uparea=flw.upstream_area("km2")))
+    sto = flw.stream_order(type="classic")
+    case.check("strord_classic", sto)
+    case.check("strord_classic_mask", flw.stream_order(type="classic", mask=D["mask_upa"]))
+    assert sto.dtype == np.uint8 and np.all(sto.flat[flw.idxs_pit] == 1)
+    dist = flw.stream_distance(unit="cell")
+    case.check("strdist_cell", dist)
+    assert dist.dtype == np.int32 and dist.max() == flw.rank.max()  # reference tests/test_pyflwdir.py:315-317
+    case.check("strdist_cell_mask", flw.stream_distance(mask=D["mask_upa"], unit="cell"))
+    case.check("strdist_m_latlon", flw.stream_distance(unit="m"))
+    case.check("strdist_m_mask", flw.stream_distance(mask=D["mask_rand"], unit="m"))
+    allmask = flw.stream_distance(mask=np.ones(case.shape, dtype=bool))
+    assert np.all(allmask[allmask != -9999] == 0)
+    with pytest.raises(ValueError, match="Unknown unit"):
+        flw.stream_distance(unit="km")
+    with pytest.raises(ValueError, match="size does not match"):
+        flw.stream_distance(mask=np.ones((2, 1)) if case.n != 2 else np.ones((3, 1)))
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd._affine import Affine
+
+    flw_proj = pyflwdir.from_array(case.d8, ftype="d8", transform=Affine(*GI.PROJ_TRANSFORM), latlon=False, cache=False)
+    case.check("strdist_m_proj", flw_proj.stream_distance(unit="m"))
+
+
 def test_constructor_from_idxs_ds(case, flw):
     """FlwdirRaster(idxs_ds, shape, "d8") like reference tests/conftest.py:49-54."""
     import pyflwdir_amd as pyflwdir
