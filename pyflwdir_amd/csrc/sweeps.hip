@@ -26,13 +26,18 @@
 // own normalised code (down-sweeps).  A level kernel is then two dependent global round trips
 // (seq + aux -> neighbour values) instead of three (seq -> 8 neighbour codes -> values), and needs
 // neither bounds checks nor the row/column of the cell.
-template <class Op>
-__global__ void __launch_bounds__(256) k_sweep(Op op, const u32 *__restrict__ seq, const u8 *__restrict__ aux,
-                                               u32 begin, u32 count) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < count) op(seq[begin + t], (u32)aux[begin + t]);
-}
-
+//
+// MULTI-HOP LAUNCHES.  On river-like rasters a level holds ~one raster row of cells and the sweep
+// is bound by launches x (kernel boundary + host launch cost, ~3.6 us), not by bandwidth.  The
+// value of a cell depends only on FINAL values a few hops away, so one launch can cover several
+// consecutive levels if a thread recomputes the not-yet-final values on its own dependency path:
+//   up-sweeps   2 (optionally 3) levels per launch: a cell of a lower level evaluates each of its upstream
+//               cells from THEIR upstream cells (recursively, down to final values), in the same
+//               order and with the same arithmetic as the thread that owns that cell —
+//               bit-identical, ~2x the work on a network with ~1 upstream cell per cell;
+//   down-sweeps up to 8 levels per launch: a cell climbs to the ancestor whose downstream cell is
+//               final and applies the per-cell update back down the chain (no fan-out at all).
+// Wide levels (rough rasters: few levels, bandwidth-bound) are launched one by one as before.
 __global__ void __launch_bounds__(256) k_seq_aux(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ seq,
                                                  u32 nseq, u8 *__restrict__ kids, u8 *__restrict__ own) {
   const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -48,18 +53,34 @@ __global__ void __launch_bounds__(256) k_seq_aux(const u8 *__restrict__ ncode, G
   kids[j] = (u8)m;
   own[j] = ncode[x];
 }
+// the same child mask per CELL (2-hop up-sweeps look up the children of a child)
+__global__ void __launch_bounds__(256) k_cell_kids(const u8 *__restrict__ ncode, Geo g, u8 *__restrict__ kids) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.n) return;
+  const u32 r = geo_row(g, x), c = x - r * g.ncol;
+  u32 m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    u32 nb;
+    if (d8_child(ncode, g, x, r, c, k, &nb)) m |= 1u << k;
+  }
+  kids[x] = (u8)m;
+}
 
 int pfd_ensure_seq_aux(pfd_raster *h) {
   if (h->aux_ready) return PFD_OK;
   if (h->seq_kids) pfd_dfree(h->seq_kids);
   h->seq_kids = nullptr;
-  PFDCHK(pfd_dmalloc((void **)&h->seq_kids, 2 * (size_t)std::max<i64>(h->n_seq, 1)));
+  PFDCHK(pfd_dmalloc((void **)&h->seq_kids, 2 * (size_t)std::max<i64>(h->n_seq, 1) + (size_t)h->n));
   h->seq_own = h->seq_kids + h->n_seq;
+  h->cell_kids = h->seq_own + h->n_seq;
   if (h->n_seq) {
     k_seq_aux<<<cdiv_u32((u64)h->n_seq, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, (u32)h->n_seq,
                                                                    h->seq_kids, h->seq_own);
     KCHK();
   }
+  k_cell_kids<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->cell_kids);
+  KCHK();
   h->aux_ready = true;
   return PFD_OK;
 }
@@ -69,33 +90,125 @@ __device__ __forceinline__ u32 nb_of(const Geo &g, u32 x, int k) {
   return (u32)((i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k));
 }
 
+// launches covering several levels are only used while they stay small (latency-bound regime)
+static const u32 MULTIHOP_MAX_CELLS = 1u << 18;
+
+// ---- up-sweeps --------------------------------------------------------------------------------
+// Op: V leaf(nb) = final value of an upstream cell; V combine(x, kids, child) = value of x given
+// child(nb) for its upstream cells (called in the order the op needs); store(x, v).
+// seq positions [begin, s1) = lowest level (3 hops), [s1, s2) = middle level (2 hops), [s2, end) =
+// upper level (children final); s1 = begin / s2 = s1 when fewer levels are taken.
+template <class Op>
+__global__ void __launch_bounds__(256) k_sweep_up(Op op, const u32 *__restrict__ seq, const u8 *__restrict__ kids_seq,
+                                                  const u8 *__restrict__ kids_cell, u32 begin, u32 s1, u32 s2,
+                                                  u32 end) {
+  const u32 pos = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= end) return;
+  const u32 x = seq[pos];
+  const u32 kids = kids_seq[pos];
+  auto leaf = [&](u32 nb) { return op.leaf(nb); };
+  auto hop2 = [&](u32 nb) { return op.combine(nb, (u32)kids_cell[nb], leaf); };
+  if (pos >= s2) {
+    op.store(x, op.combine(x, kids, leaf));
+  } else if (pos >= s1) {
+    op.store(x, op.combine(x, kids, hop2));
+  } else {
+    op.store(x, op.combine(x, kids, [&](u32 nb) { return op.combine(nb, (u32)kids_cell[nb], hop2); }));
+  }
+}
+
 // up- to downstream: deepest level first (children final before their parent's level runs)
 template <class Op>
 static int run_up(pfd_raster *h, const Op &op, const char *name) {
   PFDCHK(pfd_ensure_seq_aux(h));
   pfd_seg_begin(h, name);
   i64 launches = 0;
-  for (i64 l = h->n_levels - 1; l >= 0; --l) {
-    const u32 begin = (u32)h->lvl_off[l], cnt = (u32)(h->lvl_off[l + 1] - h->lvl_off[l]);
-    if (!cnt) continue;
-    k_sweep<Op><<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_kids, begin, cnt);
-    ++launches;
+  // (3 levels per launch are implemented but measured slower than 2: 35 vs 28 ms for 10003 levels —
+  //  the third hop squares the divergent fan-out)
+  int maxk = getenv("PFD_SINGLE_HOP") ? 1 : 2;
+  if (const char *e = getenv("PFD_UP_K")) maxk = std::max(1, std::min(3, atoi(e)));
+  for (i64 l = h->n_levels - 1; l >= 0;) {
+    const u32 end = (u32)h->lvl_off[l + 1];
+    int k = 1;  // levels l, l-1, .. l-k+1
+    while (k < maxk && l - k >= 0 && end - (u32)h->lvl_off[l - k] <= MULTIHOP_MAX_CELLS) ++k;
+    const u32 begin = (u32)h->lvl_off[l - k + 1];
+    const u32 s2 = (u32)h->lvl_off[l];                      // start of the upper level
+    const u32 s1 = k == 3 ? (u32)h->lvl_off[l - 1] : begin;  // start of the middle level
+    if (end > begin) {
+      k_sweep_up<Op><<<cdiv_u32(end - begin, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_kids, h->cell_kids, begin,
+                                                                        s1, k >= 2 ? s2 : begin, end);
+      ++launches;
+    }
+    l -= k;
   }
   KCHK();
   pfd_seg_end(h, launches);
   return PFD_OK;
 }
-// down- to upstream: level 1 first (level 0 = pits are seeded by the init step)
+
+// ---- down-sweeps ------------------------------------------------------------------------------
+// Op: V top(p) = final value of a cell below the launch's levels; V apply(x, code, root, pv) =
+// value of x from the value pv of its downstream cell (root: x is a pit, pv unused); store(x, v).
+// The launch covers seq positions [begin, end) = up to DOWN_K consecutive levels; off.o[i] = start of
+// the (i+1)-th of them (unused ones = end); `roots`: the first level is level 0 (the pits).
+enum { DOWN_K = 8 };
+struct DownOffsets {
+  u32 o[DOWN_K - 1];
+};
 template <class Op>
-static int run_down(pfd_raster *h, const Op &op, const char *name, i64 first_level) {
+__global__ void __launch_bounds__(256) k_sweep_down(Op op, const u32 *__restrict__ seq, const u8 *__restrict__ own_seq,
+                                                    const u8 *__restrict__ ncode, Geo g, u32 begin, DownOffsets off,
+                                                    u32 end, int roots) {
+  const u32 pos = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= end) return;
+  int hops = 0;  // ancestors inside the launch
+#pragma unroll
+  for (int i = 0; i < DOWN_K - 1; ++i) hops += (int)(pos >= off.o[i]);
+  u32 cx[DOWN_K], cc[DOWN_K];
+  cx[0] = seq[pos];
+  cc[0] = own_seq[pos];
+  u32 tx = cx[0], tc = cc[0];  // top of the chain
+#pragma unroll
+  for (int i = 1; i < DOWN_K; ++i) {
+    if (i <= hops) {
+      tx = d8_down(g, tx, tc);
+      tc = ncode[tx];
+      cx[i] = tx;
+      cc[i] = tc;
+    }
+  }
+  typename Op::V v;
+  if (roots)
+    v = op.apply(tx, tc, true, typename Op::V());
+  else
+    v = op.apply(tx, tc, false, op.top(d8_down(g, tx, tc)));
+#pragma unroll
+  for (int i = DOWN_K - 2; i >= 0; --i)
+    if (i < hops) v = op.apply(cx[i], cc[i], false, v);
+  op.store(cx[0], v);
+}
+
+// down- to upstream: level 0 (the pits) first
+template <class Op>
+static int run_down(pfd_raster *h, const Op &op, const char *name) {
   PFDCHK(pfd_ensure_seq_aux(h));
   pfd_seg_begin(h, name);
   i64 launches = 0;
-  for (i64 l = first_level; l < h->n_levels; ++l) {
-    const u32 begin = (u32)h->lvl_off[l], cnt = (u32)(h->lvl_off[l + 1] - h->lvl_off[l]);
-    if (!cnt) continue;
-    k_sweep<Op><<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_own, begin, cnt);
-    ++launches;
+  int maxk = getenv("PFD_SINGLE_HOP") ? 1 : DOWN_K;
+  if (const char *e = getenv("PFD_DOWN_K")) maxk = std::max(1, std::min((int)DOWN_K, atoi(e)));
+  for (i64 l = 0; l < h->n_levels;) {
+    const u32 begin = (u32)h->lvl_off[l];
+    int k = 1;
+    while (k < maxk && l + k < h->n_levels && (u32)h->lvl_off[l + k + 1] - begin <= MULTIHOP_MAX_CELLS) ++k;
+    const u32 end = (u32)h->lvl_off[l + k];
+    DownOffsets off;
+    for (int i = 0; i < DOWN_K - 1; ++i) off.o[i] = i + 1 < k ? (u32)h->lvl_off[l + i + 1] : end;
+    if (end > begin) {
+      k_sweep_down<Op><<<cdiv_u32(end - begin, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_own, h->ncode, h->geo,
+                                                                          begin, off, end, l == 0 ? 1 : 0);
+      ++launches;
+    }
+    l += k;
   }
   KCHK();
   pfd_seg_end(h, launches);
@@ -121,56 +234,64 @@ template <> struct Num<double> {
 
 template <class T>
 struct AccuUp {
+  typedef T V;
   const u8 *ncode;
   Geo g;
   const T *data;
   T *out;
   T nodata;
   int has_nodata;
-  __device__ __forceinline__ void operator()(u32 x, u32 kids) const {
+  __device__ __forceinline__ T leaf(u32 nb) const { return out[nb]; }
+  template <class F>
+  __device__ __forceinline__ T combine(u32 x, u32 kids, F child) const {
     T acc = data[x];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {  // children in descending linear index: the serial loop's order
       const int k = PFD_SLOT_DESC[q];
       if (kids & (1u << k)) {
-        const T a = out[nb_of(g, x, k)];
+        const T a = child(nb_of(g, x, k));
         if (!has_nodata || (acc != nodata && a != nodata)) acc = Num<T>::add(acc, a);
       }
     }
-    out[x] = acc;
+    return acc;
   }
+  __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
 };
 
 template <class T>
 struct AccuDown {
+  typedef T V;
   const u8 *ncode;
   Geo g;
   const T *data;
   T *out;
   T nodata;
   int has_nodata;
-  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
-    const u32 p = d8_down(g, x, code);
-    if (p == x) return;  // pit keeps its own value (copied by the init step)
-    T a = data[x];
-    const T b = out[p];
-    if (!has_nodata || (b != nodata && a != nodata)) a = Num<T>::add(a, b);
-    out[x] = a;
+  __device__ __forceinline__ T top(u32 p) const { return out[p]; }
+  __device__ __forceinline__ T apply(u32 x, u32, bool root, T pv) const {
+    T a = data[x];  // a pit keeps its own value
+    if (!root && (!has_nodata || (pv != nodata && a != nodata))) a = Num<T>::add(a, pv);
+    return a;
   }
+  __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
 };
 
 // FlwdirRaster.upstream_area(unit="cell"): unit weights, nothing read but the codes
 struct CountUp {
+  typedef u32 V;
   const u8 *ncode;
   Geo g;
   u32 *out;
-  __device__ __forceinline__ void operator()(u32 x, u32 kids) const {
+  __device__ __forceinline__ u32 leaf(u32 nb) const { return out[nb]; }
+  template <class F>
+  __device__ __forceinline__ u32 combine(u32 x, u32 kids, F child) const {
     u32 acc = 1;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (kids & (1u << k)) acc += out[nb_of(g, x, k)];
-    out[x] = acc;
+      if (kids & (1u << k)) acc += child(nb_of(g, x, k));
+    return acc;
   }
+  __device__ __forceinline__ void store(u32 x, u32 v) const { out[x] = v; }
 };
 
 // Strahler order, order-independent closed form of the reference's two-array update
@@ -178,17 +299,20 @@ struct CountUp {
 // the largest order; the cell gets m+1 if at least two of them have order m, else m; with no
 // such upstream cell it is a headwater: 1 if the cell itself is inside the mask, else 0.
 struct Strahler {
+  typedef u32 V;
   const u8 *ncode;
   Geo g;
   const u8 *mask;  // may be null
   u8 *out;
-  __device__ __forceinline__ void operator()(u32 x, u32 kids) const {
+  __device__ __forceinline__ u32 leaf(u32 nb) const { return out[nb]; }
+  template <class F>
+  __device__ __forceinline__ u32 combine(u32 x, u32 kids, F child) const {
     u32 m = 0, cnt = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const u32 nb = nb_of(g, x, k);
       if ((kids & (1u << k)) && (mask == nullptr || mask[nb])) {
-        const u32 v = out[nb];
+        const u32 v = child(nb) & 0xFFu;  // uint8 like the stored values
         if (v > m) {
           m = v;
           cnt = 1;
@@ -197,45 +321,47 @@ struct Strahler {
         }
       }
     }
-    u32 val;
-    if (cnt == 0)
-      val = (mask == nullptr || mask[x]) ? 1u : 0u;
-    else
-      val = cnt >= 2 ? m + 1 : m;
-    out[x] = (u8)val;
+    if (cnt == 0) return (mask == nullptr || mask[x]) ? 1u : 0u;
+    return cnt >= 2 ? m + 1 : m;
   }
+  __device__ __forceinline__ void store(u32 x, u32 v) const { out[x] = (u8)v; }
 };
 
 template <class L>
 struct Labels {
+  typedef L V;
   const u8 *ncode;
   Geo g;
   L *out;
-  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
-    if (out[x] != 0) return;  // seeded cells are never overwritten
-    const u32 p = d8_down(g, x, code);
-    const L v = out[p];
+  __device__ __forceinline__ L top(u32 p) const { return out[p]; }
+  // a seeded cell keeps its seed.  (A cell of this launch may be read here while its owner stores
+  // its final label: both values lead to the same result, the label is a pure function of the path.)
+  __device__ __forceinline__ L apply(u32 x, u32, bool root, L pv) const {
+    const L own = out[x];
+    if (own != 0) return own;
+    return root ? (L)0 : pv;
+  }
+  __device__ __forceinline__ void store(u32 x, L v) const {
     if (v != 0) out[x] = v;
   }
 };
 
 template <class E>
 struct Hand {
+  typedef double V;
   const u8 *ncode;
   Geo g;
   const u8 *drain;
   const E *elev;
   double *out;
-  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
-    if (drain[x] == 1) {
-      out[x] = 0.0;
-      return;
-    }
+  __device__ __forceinline__ double top(u32 p) const { return out[p]; }
+  __device__ __forceinline__ double apply(u32 x, u32 code, bool root, double pv) const {
+    if (drain[x] == 1) return 0.0;
     const u32 p = d8_down(g, x, code);
     const E dz = elev[x] - elev[p];  // difference in the elevation dtype (dem.py:328)
-    const double base = (p == x) ? 0.0 : out[p];
-    out[x] = base + (double)dz;
+    return (root ? 0.0 : pv) + (double)dz;
   }
+  __device__ __forceinline__ void store(u32 x, double v) const { out[x] = v; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -323,7 +449,7 @@ static int accuflux_t(pfd_raster *h, const void *data, T nodata, int has_nodata,
     PFDCHK(run_up(h, op, "sweep_accuflux_up"));
   } else {
     AccuDown<T> op{h->ncode, h->geo, (const T *)d.dev, (T *)o.dev, nodata, has_nodata};
-    PFDCHK(run_down(h, op, "sweep_accuflux_down", 1));
+    PFDCHK(run_down(h, op, "sweep_accuflux_down"));
   }
   if (mask_invalid) {
     k_mask_invalid<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, (T *)o.dev, nodata);
@@ -386,7 +512,7 @@ static int basins_t(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 
   }
   pfd_seg_end(h, 2);
   Labels<L> op{h->ncode, h->geo, (L *)out_dev};
-  return run_down(h, op, "sweep_labels", 0);
+  return run_down(h, op, "sweep_labels");
 }
 
 extern "C" int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k, int id_size,
@@ -450,7 +576,7 @@ static int hand_t(pfd_raster *h, const u8 *drain_dev, const void *elev_dev, doub
   KCHK();
   pfd_seg_end(h, 1);
   Hand<E> op{h->ncode, h->geo, drain_dev, (const E *)elev_dev, out_dev};
-  return run_down(h, op, "sweep_hand", 0);
+  return run_down(h, op, "sweep_hand");
 }
 
 extern "C" int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, double *out,
@@ -537,42 +663,41 @@ __global__ void __launch_bounds__(256) k_trib_flag(const u8 *__restrict__ ncode,
 }
 
 struct Classic {
+  typedef u32 V;
   const u8 *ncode;
   Geo g;
   const u8 *flag;
   const u8 *mask;  // may be null
   u8 *out;
-  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
-    if (mask != nullptr && !mask[x]) return;  // stays 0
-    const u32 p = d8_down(g, x, code);
-    out[x] = (p == x) ? (u8)1 : (u8)(out[p] + flag[x]);  // uint8 arithmetic like the reference
+  __device__ __forceinline__ u32 top(u32 p) const { return out[p]; }
+  __device__ __forceinline__ u32 apply(u32 x, u32, bool root, u32 pv) const {
+    if (mask != nullptr && !mask[x]) return 0;  // outside the mask: stays 0
+    return root ? 1u : ((pv + flag[x]) & 0xFFu);  // uint8 arithmetic like the reference
   }
+  __device__ __forceinline__ void store(u32 x, u32 v) const { out[x] = (u8)v; }
 };
 
 template <class T>
 struct Dist {
+  typedef T V;
   const u8 *ncode;
   Geo g;
   const u8 *mask;     // may be null
   const float *dtab;  // T == float: [3 * (2*nrow-1)] step lengths by row sum and kind of step
   T *out;
-  __device__ __forceinline__ void operator()(u32 x, u32 code) const {
-    const u32 p = d8_down(g, x, code);
-    if (p == x || (mask != nullptr && mask[x])) {
-      out[x] = (T)0;
-      return;
-    }
-    if (sizeof(T) == 4 && dtab != nullptr) {
+  __device__ __forceinline__ T top(u32 p) const { return out[p]; }
+  __device__ __forceinline__ T apply(u32 x, u32 code, bool root, T pv) const {
+    if (root || (mask != nullptr && mask[x])) return (T)0;
+    if (dtab != nullptr) {
       const int k = d8_slot(code);
       const int dr = d8_dr(k), dc = d8_dc(k);
-      const u32 r0 = geo_row(g, x);
-      const u32 s = 2u * r0 + (u32)dr;  // r0 + r1
+      const u32 s = 2u * geo_row(g, x) + (u32)dr;  // r0 + r1
       const int kind = (dr != 0 && dc != 0) ? 2 : (dr != 0 ? 0 : 1);
-      out[x] = (T)((float)out[p] + dtab[3u * s + (u32)kind]);
-    } else {
-      out[x] = (T)((u32)out[p] + 1u);
+      return (T)((float)pv + dtab[3u * s + (u32)kind]);
     }
+    return (T)((u32)pv + 1u);
   }
+  __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
 };
 
 template <class T, class I>
@@ -654,7 +779,7 @@ extern "C" int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void
   KCHK();
   pfd_seg_end(h, 2);
   Classic op{h->ncode, h->geo, flag.as<u8>(), (const u8 *)m.dev, (u8 *)o.dev};
-  PFDCHK(run_down(h, op, "sweep_classic_order", 0));
+  PFDCHK(run_down(h, op, "sweep_classic_order"));
   return o.finish(h->stream);  // (synchronises: `flag` may be released afterwards)
 }
 
@@ -682,10 +807,10 @@ extern "C" int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_
   pfd_seg_end(h, 1);
   if (real_length) {
     Dist<float> op{h->ncode, h->geo, (const u8 *)m.dev, (const float *)tab.dev, (float *)o.dev};
-    PFDCHK(run_down(h, op, "sweep_stream_distance", 0));
+    PFDCHK(run_down(h, op, "sweep_stream_distance"));
   } else {
     Dist<i32> op{h->ncode, h->geo, (const u8 *)m.dev, nullptr, (i32 *)o.dev};
-    PFDCHK(run_down(h, op, "sweep_stream_distance", 0));
+    PFDCHK(run_down(h, op, "sweep_stream_distance"));
   }
   return o.finish(h->stream);  // (synchronises: the staged table may be released afterwards)
 }
