@@ -232,7 +232,7 @@ static void free_handle(pfd_raster *h) {
   pfd_dfree(h->ncode);
   pfd_dfree(h->raw_owned);
   pfd_dfree(h->seq);
-  pfd_dfree(h->seq_kids);
+  pfd_dfree(h->seq_kids2);  // (seq_kids / seq_own / cell_kids live in the same allocation)
   pfd_dfree(h->pits);
   pfd_dfree(h->ctrl);
   if (h->stream) release_stream(h->device, h->stream);

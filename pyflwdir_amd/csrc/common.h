@@ -137,6 +137,7 @@ struct pfd_raster {
   u32 *seq = nullptr;   // device, capacity n_valid, allocated by the first ordering
   u8 *seq_kids = nullptr, *seq_own = nullptr;  // per ordered cell: mask of draining neighbours / own code
   u8 *cell_kids = nullptr;                     // per CELL: mask of draining neighbours (same allocation)
+  u64 *seq_kids2 = nullptr;                    // per ordered cell: the child masks of its upstream cells (owns the allocation)
   bool aux_ready = false;
   i64 n_seq = -1, n_levels = -1;
   std::vector<i64> lvl_off;  // host copy, n_levels+1 entries

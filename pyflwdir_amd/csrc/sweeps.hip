@@ -38,11 +38,7 @@
 //   down-sweeps up to 8 levels per launch: a cell climbs to the ancestor whose downstream cell is
 //               final and applies the per-cell update back down the chain (no fan-out at all).
 // Wide levels (rough rasters: few levels, bandwidth-bound) are launched one by one as before.
-__global__ void __launch_bounds__(256) k_seq_aux(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ seq,
-                                                 u32 nseq, u8 *__restrict__ kids, u8 *__restrict__ own) {
-  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nseq) return;
-  const u32 x = seq[j];
+__device__ __forceinline__ u32 kids_of(const u8 *__restrict__ ncode, const Geo &g, u32 x) {
   const u32 r = geo_row(g, x), c = x - r * g.ncol;
   u32 m = 0;
 #pragma unroll
@@ -50,33 +46,47 @@ __global__ void __launch_bounds__(256) k_seq_aux(const u8 *__restrict__ ncode, G
     u32 nb;
     if (d8_child(ncode, g, x, r, c, k, &nb)) m |= 1u << k;
   }
+  return m;
+}
+// kids2: byte k = child mask of the upstream cell in slot k (0 if none) — a 2-hop launch then needs
+// no lookup between the cell and its grandchildren
+__global__ void __launch_bounds__(256) k_seq_aux(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ seq,
+                                                 u32 nseq, u8 *__restrict__ kids, u8 *__restrict__ own,
+                                                 u64 *__restrict__ kids2) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nseq) return;
+  const u32 x = seq[j];
+  const u32 m = kids_of(ncode, g, x);
+  u64 m2 = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (m & (1u << k))
+      m2 |= (u64)kids_of(ncode, g, (u32)((i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k))) << (8 * k);
   kids[j] = (u8)m;
   own[j] = ncode[x];
+  kids2[j] = m2;
 }
 // the same child mask per CELL (2-hop up-sweeps look up the children of a child)
 __global__ void __launch_bounds__(256) k_cell_kids(const u8 *__restrict__ ncode, Geo g, u8 *__restrict__ kids) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= g.n) return;
-  const u32 r = geo_row(g, x), c = x - r * g.ncol;
-  u32 m = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    u32 nb;
-    if (d8_child(ncode, g, x, r, c, k, &nb)) m |= 1u << k;
-  }
-  kids[x] = (u8)m;
+  kids[x] = (u8)kids_of(ncode, g, x);
 }
 
 int pfd_ensure_seq_aux(pfd_raster *h) {
   if (h->aux_ready) return PFD_OK;
-  if (h->seq_kids) pfd_dfree(h->seq_kids);
+  if (h->seq_kids2) pfd_dfree(h->seq_kids2);
+  h->seq_kids2 = nullptr;
   h->seq_kids = nullptr;
-  PFDCHK(pfd_dmalloc((void **)&h->seq_kids, 2 * (size_t)std::max<i64>(h->n_seq, 1) + (size_t)h->n));
-  h->seq_own = h->seq_kids + h->n_seq;
-  h->cell_kids = h->seq_own + h->n_seq;
+  // layout: kids2 u64[n_seq] | kids u8[n_seq] | own u8[n_seq] | cell_kids u8[n]
+  const size_t ns = (size_t)std::max<i64>(h->n_seq, 1);
+  PFDCHK(pfd_dmalloc((void **)&h->seq_kids2, ns * 10 + (size_t)h->n));
+  h->seq_kids = (u8 *)(h->seq_kids2 + ns);
+  h->seq_own = h->seq_kids + ns;
+  h->cell_kids = h->seq_own + ns;
   if (h->n_seq) {
     k_seq_aux<<<cdiv_u32((u64)h->n_seq, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, (u32)h->n_seq,
-                                                                   h->seq_kids, h->seq_own);
+                                                                   h->seq_kids, h->seq_own, h->seq_kids2);
     KCHK();
   }
   k_cell_kids<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->cell_kids);
@@ -90,30 +100,67 @@ __device__ __forceinline__ u32 nb_of(const Geo &g, u32 x, int k) {
   return (u32)((i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k));
 }
 
+// 2-hop evaluation from REGISTERS.  A load inside a data-dependent branch is waited for on the spot, so
+// the nested "for each child / for each grandchild" loops serialise up to children x grandchildren
+// global round trips (~6 us per launch).  The grandchildren of x lie in the 5x5 window around it:
+// load the whole window unconditionally (clamped indices; unused values are never looked at), then
+// evaluate from registers.  With unrolled loops all window indices are compile-time constants.
+template <class A>
+__device__ __forceinline__ void load_window5(const A *__restrict__ arr, const Geo &g, u32 x, A (&w)[25]) {
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    const i64 j = (i64)x + (i64)(i / 5 - 2) * (i64)g.ncol + (i % 5 - 2);
+    w[i] = arr[j < 0 ? 0 : (j >= (i64)g.n ? (i64)g.n - 1 : j)];
+  }
+}
+__device__ __forceinline__ constexpr int slot_dr(int k) { return k == 1 || k == 2 || k == 3 ? 1 : (k == 5 || k == 6 || k == 7 ? -1 : 0); }
+__device__ __forceinline__ constexpr int slot_dc(int k) { return k == 0 || k == 1 || k == 7 ? 1 : (k == 3 || k == 4 || k == 5 ? -1 : 0); }
+// window index of the cell reached from x by slot k, then slot k2 (k2 < 0: the child itself)
+__device__ __forceinline__ constexpr int win_idx(int k, int k2) {
+  return (2 + slot_dr(k) + (k2 < 0 ? 0 : slot_dr(k2))) * 5 + 2 + slot_dc(k) + (k2 < 0 ? 0 : slot_dc(k2));
+}
+__device__ __forceinline__ constexpr int slot_desc(int q) {  // slots in descending linear index of the neighbour
+  return q == 0 ? 1 : q == 1 ? 2 : q == 2 ? 3 : q == 3 ? 0 : q == 4 ? 4 : q == 5 ? 7 : q == 6 ? 6 : 5;
+}
+
 // launches covering several levels are only used while they stay small (latency-bound regime)
-static const u32 MULTIHOP_MAX_CELLS = 1u << 18;
+static const u32 MULTIHOP_MAX_CELLS = 1u << 18;     // down-sweeps (a chain of single loads per thread)
+static const u32 MULTIHOP_MAX_CELLS_UP = 1u << 16;  // up-sweeps (the window form loads ~50 values per thread)
 
 // ---- up-sweeps --------------------------------------------------------------------------------
 // Op: V leaf(nb) = final value of an upstream cell; V combine(x, kids, child) = value of x given
 // child(nb) for its upstream cells (called in the order the op needs); store(x, v).
 // seq positions [begin, s1) = lowest level (3 hops), [s1, s2) = middle level (2 hops), [s2, end) =
 // upper level (children final); s1 = begin / s2 = s1 when fewer levels are taken.
+// one level per launch (wide levels: bandwidth-bound, kept lean — the multi-hop kernel's register
+// footprint would cost occupancy)
+template <class Op>
+__global__ void __launch_bounds__(256) k_sweep_up1(Op op, const u32 *__restrict__ seq, const u8 *__restrict__ kids_seq,
+                                                   u32 begin, u32 end) {
+  const u32 pos = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= end) return;
+  const u32 x = seq[pos];
+  op.store(x, op.combine(x, (u32)kids_seq[pos], [&](u32 nb, int) { return op.leaf(nb); }));
+}
 template <class Op>
 __global__ void __launch_bounds__(256) k_sweep_up(Op op, const u32 *__restrict__ seq, const u8 *__restrict__ kids_seq,
-                                                  const u8 *__restrict__ kids_cell, u32 begin, u32 s1, u32 s2,
-                                                  u32 end) {
+                                                  const u64 *__restrict__ kids2_seq, const u8 *__restrict__ kids_cell,
+                                                  u32 begin, u32 s1, u32 s2, u32 end) {
   const u32 pos = begin + blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= end) return;
   const u32 x = seq[pos];
   const u32 kids = kids_seq[pos];
-  auto leaf = [&](u32 nb) { return op.leaf(nb); };
-  auto hop2 = [&](u32 nb) { return op.combine(nb, (u32)kids_cell[nb], leaf); };
+  auto leaf = [&](u32 nb, int) { return op.leaf(nb); };
   if (pos >= s2) {
     op.store(x, op.combine(x, kids, leaf));
-  } else if (pos >= s1) {
-    op.store(x, op.combine(x, kids, hop2));
+    return;
+  }
+  const u64 kids2 = kids2_seq[pos];  // child masks of the children: no lookup on the way to the grandchildren
+  if (pos >= s1) {
+    op.store(x, op.eval2(x, kids, kids2));
   } else {
-    op.store(x, op.combine(x, kids, [&](u32 nb) { return op.combine(nb, (u32)kids_cell[nb], hop2); }));
+    auto hop2 = [&](u32 nb, int) { return op.combine(nb, (u32)kids_cell[nb], leaf); };
+    op.store(x, op.combine(x, kids, [&](u32 nb, int k) { return op.combine(nb, (u32)(kids2 >> (8 * k)) & 0xFFu, hop2); }));
   }
 }
 
@@ -130,13 +177,16 @@ static int run_up(pfd_raster *h, const Op &op, const char *name) {
   for (i64 l = h->n_levels - 1; l >= 0;) {
     const u32 end = (u32)h->lvl_off[l + 1];
     int k = 1;  // levels l, l-1, .. l-k+1
-    while (k < maxk && l - k >= 0 && end - (u32)h->lvl_off[l - k] <= MULTIHOP_MAX_CELLS) ++k;
+    while (k < maxk && l - k >= 0 && end - (u32)h->lvl_off[l - k] <= MULTIHOP_MAX_CELLS_UP) ++k;
     const u32 begin = (u32)h->lvl_off[l - k + 1];
     const u32 s2 = (u32)h->lvl_off[l];                      // start of the upper level
     const u32 s1 = k == 3 ? (u32)h->lvl_off[l - 1] : begin;  // start of the middle level
     if (end > begin) {
-      k_sweep_up<Op><<<cdiv_u32(end - begin, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_kids, h->cell_kids, begin,
-                                                                        s1, k >= 2 ? s2 : begin, end);
+      if (k == 1)
+        k_sweep_up1<Op><<<cdiv_u32(end - begin, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_kids, begin, end);
+      else
+        k_sweep_up<Op><<<cdiv_u32(end - begin, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_kids, h->seq_kids2,
+                                                                          h->cell_kids, begin, s1, s2, end);
       ++launches;
     }
     l -= k;
@@ -155,6 +205,18 @@ enum { DOWN_K = 8 };
 struct DownOffsets {
   u32 o[DOWN_K - 1];
 };
+// one level per launch (wide levels: bandwidth-bound, kept lean)
+template <class Op>
+__global__ void __launch_bounds__(256) k_sweep_down1(Op op, const u32 *__restrict__ seq, const u8 *__restrict__ own_seq,
+                                                     Geo g, u32 begin, u32 end, int roots) {
+  const u32 pos = begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= end) return;
+  const u32 x = seq[pos], code = own_seq[pos];
+  if (roots)
+    op.store(x, op.apply(x, code, true, typename Op::V()));
+  else
+    op.store(x, op.apply(x, code, false, op.top(d8_down(g, x, code))));
+}
 template <class Op>
 __global__ void __launch_bounds__(256) k_sweep_down(Op op, const u32 *__restrict__ seq, const u8 *__restrict__ own_seq,
                                                     const u8 *__restrict__ ncode, Geo g, u32 begin, DownOffsets off,
@@ -204,8 +266,12 @@ static int run_down(pfd_raster *h, const Op &op, const char *name) {
     DownOffsets off;
     for (int i = 0; i < DOWN_K - 1; ++i) off.o[i] = i + 1 < k ? (u32)h->lvl_off[l + i + 1] : end;
     if (end > begin) {
-      k_sweep_down<Op><<<cdiv_u32(end - begin, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_own, h->ncode, h->geo,
-                                                                          begin, off, end, l == 0 ? 1 : 0);
+      if (k == 1)
+        k_sweep_down1<Op><<<cdiv_u32(end - begin, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_own, h->geo, begin, end,
+                                                                             l == 0 ? 1 : 0);
+      else
+        k_sweep_down<Op><<<cdiv_u32(end - begin, 256), 256, 0, h->stream>>>(op, h->seq, h->seq_own, h->ncode, h->geo,
+                                                                            begin, off, end, l == 0 ? 1 : 0);
       ++launches;
     }
     l += k;
@@ -249,7 +315,32 @@ struct AccuUp {
     for (int q = 0; q < 8; ++q) {  // children in descending linear index: the serial loop's order
       const int k = PFD_SLOT_DESC[q];
       if (kids & (1u << k)) {
-        const T a = child(nb_of(g, x, k));
+        const T a = child(nb_of(g, x, k), k);
+        if (!has_nodata || (acc != nodata && a != nodata)) acc = Num<T>::add(acc, a);
+      }
+    }
+    return acc;
+  }
+  // value of x from its grandchildren's final values (window form, see load_window5)
+  __device__ __forceinline__ T eval2(u32 x, u32 kids, u64 kids2) const {
+    T W[25], D[25];
+    load_window5(out, g, x, W);
+    load_window5(data, g, x, D);
+    T acc = D[12];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = slot_desc(q);
+      if (kids & (1u << k)) {
+        const u32 kk = (u32)(kids2 >> (8 * k)) & 0xFFu;
+        T a = D[win_idx(k, -1)];
+#pragma unroll
+        for (int q2 = 0; q2 < 8; ++q2) {
+          const int k2 = slot_desc(q2);
+          if (kk & (1u << k2)) {
+            const T b = W[win_idx(k, k2)];
+            if (!has_nodata || (a != nodata && b != nodata)) a = Num<T>::add(a, b);
+          }
+        }
         if (!has_nodata || (acc != nodata && a != nodata)) acc = Num<T>::add(acc, a);
       }
     }
@@ -288,7 +379,24 @@ struct CountUp {
     u32 acc = 1;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (kids & (1u << k)) acc += child(nb_of(g, x, k));
+      if (kids & (1u << k)) acc += child(nb_of(g, x, k), k);
+    return acc;
+  }
+  __device__ __forceinline__ u32 eval2(u32 x, u32 kids, u64 kids2) const {
+    u32 W[25];
+    load_window5(out, g, x, W);
+    u32 acc = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (kids & (1u << k)) {
+        const u32 kk = (u32)(kids2 >> (8 * k)) & 0xFFu;
+        u32 a = 1;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2)
+          if (kk & (1u << k2)) a += W[win_idx(k, k2)];
+        acc += a;
+      }
+    }
     return acc;
   }
   __device__ __forceinline__ void store(u32 x, u32 v) const { out[x] = v; }
@@ -312,7 +420,7 @@ struct Strahler {
     for (int k = 0; k < 8; ++k) {
       const u32 nb = nb_of(g, x, k);
       if ((kids & (1u << k)) && (mask == nullptr || mask[nb])) {
-        const u32 v = child(nb) & 0xFFu;  // uint8 like the stored values
+        const u32 v = child(nb, k) & 0xFFu;  // uint8 like the stored values
         if (v > m) {
           m = v;
           cnt = 1;
@@ -322,6 +430,39 @@ struct Strahler {
       }
     }
     if (cnt == 0) return (mask == nullptr || mask[x]) ? 1u : 0u;
+    return cnt >= 2 ? m + 1 : m;
+  }
+  static __device__ __forceinline__ void join(u32 v, u32 &m, u32 &cnt) {
+    if (v > m) {
+      m = v;
+      cnt = 1;
+    } else if (v == m) {
+      ++cnt;
+    }
+  }
+  __device__ __forceinline__ u32 eval2(u32 x, u32 kids, u64 kids2) const {
+    u8 W[25], M[25];
+    load_window5(out, g, x, W);
+    if (mask != nullptr) {
+      load_window5(mask, g, x, M);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 25; ++i) M[i] = 1;
+    }
+    u32 m = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if ((kids & (1u << k)) && M[win_idx(k, -1)]) {
+        const u32 kk = (u32)(kids2 >> (8 * k)) & 0xFFu;
+        u32 m2 = 0, cnt2 = 0;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2)
+          if ((kk & (1u << k2)) && M[win_idx(k, k2)]) join(W[win_idx(k, k2)], m2, cnt2);
+        const u32 v = (cnt2 == 0 ? 1u : (cnt2 >= 2 ? m2 + 1 : m2)) & 0xFFu;  // the child is inside the mask
+        join(v, m, cnt);
+      }
+    }
+    if (cnt == 0) return M[12] ? 1u : 0u;
     return cnt >= 2 ? m + 1 : m;
   }
   __device__ __forceinline__ void store(u32 x, u32 v) const { out[x] = (u8)v; }
