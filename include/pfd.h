@@ -153,6 +153,12 @@ int pfd_upstream_area_cell_levels(pfd_raster *h, int32_t *out, int memspace);
  * (FlwdirRaster.upstream_area, pyflwdir.py:800). */
 int pfd_accuflux(pfd_raster *h, int dtype, const void *data, int64_t nodata_i, double nodata_f,
                  int has_nodata, int direction, int mask_invalid, void *out, int memspace);
+/* The same accumulation for a payload that is constant along raster rows: `row_values` is a HOST
+ * pointer to nrow values of `dtype` (cell areas of a regular grid depend on the row only —
+ * FlwdirRaster.upstream_area(unit != "cell"), reference pyflwdir/pyflwdir.py:770-801 with
+ * gis_utils.area_grid, gis_utils.py:388-402 — so no n-element input has to exist or travel). */
+int pfd_accuflux_rows(pfd_raster *h, int dtype, const void *row_values, int64_t nodata_i, double nodata_f,
+                      int has_nodata, int direction, int mask_invalid, void *out, int memspace);
 /* streams.strahler_order (reference pyflwdir/streams.py:228-269); mask uint8 or NULL. */
 int pfd_strahler(pfd_raster *h, const uint8_t *mask, uint8_t *out, int memspace);
 /* basins.basins + core.fillnodata_upstream (reference pyflwdir/basins.py:12-18,

@@ -35,7 +35,7 @@ SYMBOLS = [
     "pfd_comm_destroy", "pfd_upstream_area_cell_dist", "pfd_upstream_area_cell_begin", "pfd_upstream_area_cell_finish",
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
-    "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
+    "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32",
 ]
 
@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
         L.pfd_upstream_area_cell.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_upstream_area_cell_levels.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_accuflux.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_int]
+        L.pfd_accuflux_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p, C.c_int]
         L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
@@ -275,6 +277,17 @@ class RasterHandle:
             out = np.empty_like(data)
         check(lib().pfd_accuflux(self._h, dtype_code, ptr(data), int(nodata_i), float(nodata_f), int(has_nodata),
                                  direction, int(mask_invalid), ptr(out), memspace))
+        return out
+
+    def accuflux_rows(self, row_values, dtype_code, nodata_i=0, nodata_f=0.0, has_nodata=1, direction=PFD_UP,
+                      mask_invalid=0, out=None, memspace=PFD_HOST):
+        """accuflux of a payload that is constant along raster rows (``row_values``: nrow host values)."""
+        row_values = np.ascontiguousarray(row_values)
+        assert row_values.size == self.nrow
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, row_values.dtype)
+        check(lib().pfd_accuflux_rows(self._h, dtype_code, ptr(row_values), int(nodata_i), float(nodata_f),
+                                      int(has_nodata), direction, int(mask_invalid), ptr(out), memspace))
         return out
 
     def strahler(self, mask=None, out=None, memspace=PFD_HOST):

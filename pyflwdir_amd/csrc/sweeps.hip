@@ -298,19 +298,42 @@ template <> struct Num<double> {
   static __device__ __forceinline__ double add(double a, double b) { return a + b; }
 };
 
+// payload accessors: a full per-cell array, or one value per raster ROW (cell areas of a regular
+// grid depend on the row only — upstream_area(unit != "cell") then needs no n-element input at all)
 template <class T>
+struct CellData {
+  const T *p;
+  Geo g;
+  __device__ __forceinline__ T at(u32 x) const { return p[x]; }
+};
+template <class T>
+struct RowData {
+  const T *row;
+  Geo g;
+  __device__ __forceinline__ T at(u32 x) const { return row[geo_row(g, x)]; }
+};
+template <class D, class A>
+__device__ __forceinline__ void load_window5_of(const D &d, const Geo &g, u32 x, A (&w)[25]) {
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    const i64 j = (i64)x + (i64)(i / 5 - 2) * (i64)g.ncol + (i % 5 - 2);
+    w[i] = d.at((u32)(j < 0 ? 0 : (j >= (i64)g.n ? (i64)g.n - 1 : j)));
+  }
+}
+
+template <class T, class D = CellData<T>>
 struct AccuUp {
   typedef T V;
   const u8 *ncode;
   Geo g;
-  const T *data;
+  D data;
   T *out;
   T nodata;
   int has_nodata;
   __device__ __forceinline__ T leaf(u32 nb) const { return out[nb]; }
   template <class F>
   __device__ __forceinline__ T combine(u32 x, u32 kids, F child) const {
-    T acc = data[x];
+    T acc = data.at(x);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {  // children in descending linear index: the serial loop's order
       const int k = PFD_SLOT_DESC[q];
@@ -323,16 +346,16 @@ struct AccuUp {
   }
   // value of x from its grandchildren's final values (window form, see load_window5)
   __device__ __forceinline__ T eval2(u32 x, u32 kids, u64 kids2) const {
-    T W[25], D[25];
+    T W[25], Dw[25];
     load_window5(out, g, x, W);
-    load_window5(data, g, x, D);
-    T acc = D[12];
+    load_window5_of(data, g, x, Dw);
+    T acc = Dw[12];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = slot_desc(q);
       if (kids & (1u << k)) {
         const u32 kk = (u32)(kids2 >> (8 * k)) & 0xFFu;
-        T a = D[win_idx(k, -1)];
+        T a = Dw[win_idx(k, -1)];
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
           const int k2 = slot_desc(q2);
@@ -349,18 +372,18 @@ struct AccuUp {
   __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
 };
 
-template <class T>
+template <class T, class D = CellData<T>>
 struct AccuDown {
   typedef T V;
   const u8 *ncode;
   Geo g;
-  const T *data;
+  D data;
   T *out;
   T nodata;
   int has_nodata;
   __device__ __forceinline__ T top(u32 p) const { return out[p]; }
   __device__ __forceinline__ T apply(u32 x, u32, bool root, T pv) const {
-    T a = data[x];  // a pit keeps its own value
+    T a = data.at(x);  // a pit keeps its own value
     if (!root && (!has_nodata || (pv != nodata && a != nodata))) a = Num<T>::add(a, pv);
     return a;
   }
@@ -576,20 +599,40 @@ extern "C" int pfd_upstream_area_cell(pfd_raster *h, int32_t *out, int memspace)
 }
 
 template <class T>
-static int accuflux_t(pfd_raster *h, const void *data, T nodata, int has_nodata, int direction,
+__global__ void k_fill_rows(const T *__restrict__ row, Geo g, T *__restrict__ out) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < g.n) out[x] = row[geo_row(g, x)];
+}
+// by_row: `data` holds one value per raster row (always a HOST pointer: nrow elements)
+template <class T>
+static int accuflux_t(pfd_raster *h, const void *data, bool by_row, T nodata, int has_nodata, int direction,
                       int mask_invalid, void *out, int memspace) {
   InArg d;
-  PFDCHK(d.bind(data, (size_t)h->n * sizeof(T), memspace, h->stream));
+  if (by_row)
+    PFDCHK(d.bind(data, (size_t)h->nrow * sizeof(T), PFD_HOST, h->stream));
+  else
+    PFDCHK(d.bind(data, (size_t)h->n * sizeof(T), memspace, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(T), memspace));
   pfd_seg_begin(h, "init");
-  HIPCHK(hipMemcpyAsync(o.dev, d.dev, (size_t)h->n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
-  pfd_seg_end(h, 1);
-  if (direction == PFD_UP) {
-    AccuUp<T> op{h->ncode, h->geo, (const T *)d.dev, (T *)o.dev, nodata, has_nodata};
-    PFDCHK(run_up(h, op, "sweep_accuflux_up"));
+  if (by_row) {
+    k_fill_rows<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((const T *)d.dev, h->geo, (T *)o.dev);
+    KCHK();
   } else {
-    AccuDown<T> op{h->ncode, h->geo, (const T *)d.dev, (T *)o.dev, nodata, has_nodata};
+    HIPCHK(hipMemcpyAsync(o.dev, d.dev, (size_t)h->n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+  }
+  pfd_seg_end(h, 1);
+  if (direction == PFD_UP && by_row) {
+    AccuUp<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(run_up(h, op, "sweep_accuflux_up"));
+  } else if (direction == PFD_UP) {
+    AccuUp<T> op{h->ncode, h->geo, CellData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(run_up(h, op, "sweep_accuflux_up"));
+  } else if (by_row) {
+    AccuDown<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(run_down(h, op, "sweep_accuflux_down"));
+  } else {
+    AccuDown<T> op{h->ncode, h->geo, CellData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
     PFDCHK(run_down(h, op, "sweep_accuflux_down"));
   }
   if (mask_invalid) {
@@ -599,8 +642,8 @@ static int accuflux_t(pfd_raster *h, const void *data, T nodata, int has_nodata,
   return o.finish(h->stream);
 }
 
-extern "C" int pfd_accuflux(pfd_raster *h, int dtype, const void *data, int64_t nodata_i, double nodata_f,
-                            int has_nodata, int direction, int mask_invalid, void *out, int memspace) {
+static int accuflux_impl(pfd_raster *h, int dtype, const void *data, bool by_row, int64_t nodata_i, double nodata_f,
+                         int has_nodata, int direction, int mask_invalid, void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
   if (!data || !out || (direction != PFD_UP && direction != PFD_DOWN)) {
     pfd_set_error("pfd_accuflux: bad arguments");
@@ -610,17 +653,28 @@ extern "C" int pfd_accuflux(pfd_raster *h, int dtype, const void *data, int64_t 
   PFDCHK(pfd_order_cells_impl(h));
   switch (dtype) {
     case PFD_I32:
-      return accuflux_t<i32>(h, data, (i32)nodata_i, has_nodata, direction, mask_invalid, out, memspace);
+      return accuflux_t<i32>(h, data, by_row, (i32)nodata_i, has_nodata, direction, mask_invalid, out, memspace);
     case PFD_I64:
-      return accuflux_t<i64>(h, data, (i64)nodata_i, has_nodata, direction, mask_invalid, out, memspace);
+      return accuflux_t<i64>(h, data, by_row, (i64)nodata_i, has_nodata, direction, mask_invalid, out, memspace);
     case PFD_F32:
-      return accuflux_t<float>(h, data, (float)nodata_f, has_nodata, direction, mask_invalid, out, memspace);
+      return accuflux_t<float>(h, data, by_row, (float)nodata_f, has_nodata, direction, mask_invalid, out, memspace);
     case PFD_F64:
-      return accuflux_t<double>(h, data, nodata_f, has_nodata, direction, mask_invalid, out, memspace);
+      return accuflux_t<double>(h, data, by_row, nodata_f, has_nodata, direction, mask_invalid, out, memspace);
     default:
       pfd_set_error("pfd_accuflux: unsupported payload dtype code %d", dtype);
       return PFD_EUNSUPPORTED;
   }
+}
+
+extern "C" int pfd_accuflux(pfd_raster *h, int dtype, const void *data, int64_t nodata_i, double nodata_f,
+                            int has_nodata, int direction, int mask_invalid, void *out, int memspace) {
+  return accuflux_impl(h, dtype, data, false, nodata_i, nodata_f, has_nodata, direction, mask_invalid, out, memspace);
+}
+
+extern "C" int pfd_accuflux_rows(pfd_raster *h, int dtype, const void *row_values, int64_t nodata_i, double nodata_f,
+                                 int has_nodata, int direction, int mask_invalid, void *out, int memspace) {
+  return accuflux_impl(h, dtype, row_values, true, nodata_i, nodata_f, has_nodata, direction, mask_invalid, out,
+                       memspace);
 }
 
 extern "C" int pfd_strahler(pfd_raster *h, const uint8_t *mask, uint8_t *out, int memspace) {

@@ -65,6 +65,24 @@ def area_grid(transform, shape, latlon=False, unit="m2"):
     return np.full(shape, area0, dtype=np.float32)
 
 
+def area_rows(transform, shape, latlon=False, unit="m2"):
+    """Column 0 of ``area_grid`` without building the grid: the cell area of a regular grid depends on
+    the row only (same expressions, element for element, as ``area_grid`` / ``reggrid_area``)."""
+    unit = str(unit).lower()
+    if unit not in AREA_FACTORS:
+        fstr = '", "'.join(AREA_FACTORS.keys())
+        raise ValueError(f'Unknown unit: {unit}, select from "{fstr}".')
+    if unit == "cell":
+        return np.ones(shape[0], dtype=np.int32)
+    if latlon:
+        lon, lat = affine_to_coords(transform, shape)
+        xres = np.abs(np.mean(np.diff(lon)))
+        yres = np.abs(np.mean(np.diff(lat)))
+        return cellarea(lat, xres, yres) * np.ones(lat.size, dtype=np.float32) / AREA_FACTORS[unit]
+    area0 = abs(transform[0] * transform[4]) / AREA_FACTORS[unit]
+    return np.full(shape[0], area0, dtype=np.float32)
+
+
 def degree_metres_y(lat):
     """Vertical length of a degree [m] at a latitude; reference gis_utils.py:415-431."""
     radlat = np.radians(lat)

@@ -342,9 +342,12 @@ class FlwdirRaster(object):
             raise ValueError(f'Unknown unit: {unit}, select from "{fstr}".')
         if unit == "cell":
             return self._h.upstream_area_cell().reshape(self.shape)
-        area = np.ascontiguousarray(self.area.ravel() / gis.AREA_FACTORS[unit])
-        out = self._h.accuflux(area, _PAYLOAD[area.dtype], nodata_i=-9999, nodata_f=-9999.0, has_nodata=1,
-                               direction=_hip.PFD_UP, mask_invalid=1)
+        # the cell area of a regular grid depends on the row only: hand the device one value per row
+        # (element for element the reference's  area / AREA_FACTORS[unit]) instead of an n-element grid
+        rows = np.ascontiguousarray(gis.area_rows(self.transform, self.shape, self.latlon, unit="m2")
+                                    / gis.AREA_FACTORS[unit])
+        out = self._h.accuflux_rows(rows, _PAYLOAD[rows.dtype], nodata_i=-9999, nodata_f=-9999.0, has_nodata=1,
+                                    direction=_hip.PFD_UP, mask_invalid=1)
         return out.reshape(self.shape)
 
     def accuflux(self, data, nodata=-9999, direction="up"):

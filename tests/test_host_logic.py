@@ -113,3 +113,25 @@ def test_payload_args():
     assert (ndi, has) == (-1, 1)
     with pytest.raises(NotImplementedError):
         f(np.ones(3, np.int16), -9999)
+
+
+def test_area_rows_equal_area_grid_rows():
+    """upstream_area(unit != "cell") hands the device one area per row (pfd_accuflux_rows): the row
+    values must be, element for element, the reference's area grid (gis_utils.area_grid,
+    reference pyflwdir/gis_utils.py:388-402)."""
+    import numpy as np
+
+    from pyflwdir_amd import gis
+    from pyflwdir_amd._affine import Affine
+
+    cases = [((1 / 120.0, 0, 5.0, 0, -1 / 120.0, 50.0), True, (682, 997)),
+             ((30.0, 0, 1000.0, 0, -30.0, 5000.0), False, (20, 25)),
+             ((1 / 120.0, 0, 5.0, 0, -1 / 120.0, 50.0), True, (300, 1)),
+             ((0.1, 0, 0, 0, -0.1, 80.0), True, (1, 300))]
+    for tr, latlon, shape in cases:
+        for unit in ("m2", "km2", "ha"):
+            with np.errstate(all="ignore"):
+                grid = gis.area_grid(Affine(*tr), shape, latlon, unit)
+                rows = gis.area_rows(Affine(*tr), shape, latlon, unit)
+            assert grid.dtype == rows.dtype
+            assert np.array_equal(grid, np.broadcast_to(rows[:, None], shape), equal_nan=True)
