@@ -529,6 +529,262 @@ struct Hand {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Chain sweep — EXPERIMENTAL, off by default (env PFD_CHAIN_UP=1; layout: paths.hip, pfd_ensure_chains).
+// Status (r01): bit-exact on every golden / fuzz case, but 53 ms against 25 ms for the 2-hop level sweep on
+// the 10000 x 10000 river raster (14 vs 4.6 ms on the rough one): the critical path is gone, what is left is
+// the volume of scattered accesses (~800 cache-line transactions per 64-cell unit: neighbour positions,
+// payload, granules, results of cells that are contiguous in the chain layout but not in the raster).
+// Kept as the starting point for a locality-aware layout (what comes next).
+//
+// Work unit = 64 consecutive positions of the chain layout = one wave.  Waves claim units in layout
+// order from a counter; every value a cell needs sits at a smaller layout position, so the earliest
+// unfinished unit can always proceed: no deadlock, whatever the number of resident waves.
+//   * children in an EARLIER unit: wait for that unit's done mark (relaxed agent-scope polls, one
+//     acquire fence afterwards, then plain loads — MI355X_MICROARCH.md, inter-workgroup visibility);
+//   * children in the SAME unit (the heavy child is the previous lane; short tributary chains):
+//     resolved in rounds through LDS — a lane computes once all its in-unit children are resolved.
+// The arithmetic is the op's own `combine` (children in the reference's order): bit-identical.
+// A spin that exceeds its budget raises an error flag instead of hanging the GPU.
+// ---------------------------------------------------------------------------------------------
+enum { CH_NEXT = 48, CH_ERROR = 49 };  // ctrl slots (u64)
+#define CH_NONE 0xFFFFFFFFu
+// write-through ("sc1") stores and L1-bypassing loads: the only inter-workgroup traffic of the chain
+// sweep goes through them, so no release/acquire FENCE is needed (an agent-scope release fence writes
+// back the whole XCD L2 — measured: 0.6 us per unit, serialised — MI355X_MICROARCH.md, "valid forms")
+template <class V> struct Coh;
+template <> struct Coh<u32> {
+  static __device__ __forceinline__ void st(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  static __device__ __forceinline__ u32 ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+template <> struct Coh<u64> {
+  static __device__ __forceinline__ void st(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  static __device__ __forceinline__ u64 ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+template <class V, int N = sizeof(V)> struct Bits;
+template <class V> struct Bits<V, 4> {
+  typedef u32 U;
+};
+template <class V> struct Bits<V, 8> {
+  typedef u64 U;
+};
+template <class V>
+__device__ __forceinline__ void coh_store(V *p, V v) {
+  typedef typename Bits<V>::U U;
+  U b;
+  __builtin_memcpy(&b, &v, sizeof(V));
+  Coh<U>::st((U *)p, b);
+}
+template <class V>
+__device__ __forceinline__ V coh_load(const V *p) {
+  typedef typename Bits<V>::U U;
+  const U b = Coh<U>::ld((const U *)p);
+  V v;
+  __builtin_memcpy(&v, &b, sizeof(V));
+  return v;
+}
+
+// Exchange granule of one layout position: the value and a ready tag.  4-byte values travel with
+// their tag in ONE 8-byte write-through store (untorn: no ordering needed at all); 8-byte values are
+// stored first, drained (s_waitcnt vmcnt(0)), then tagged.
+template <class V, int N = sizeof(V)> struct Gran;
+template <class V> struct Gran<V, 4> {
+  typedef u64 Slot;
+  static __device__ __forceinline__ void put(Slot *p, V v) {
+    u32 b;
+    __builtin_memcpy(&b, &v, 4);
+    Coh<u64>::st(p, (u64)b | (1ull << 32));
+  }
+  static __device__ __forceinline__ bool get(const Slot *p, V *v) {
+    const u64 g = Coh<u64>::ld(p);
+    const u32 b = (u32)g;
+    __builtin_memcpy(v, &b, 4);
+    return (g >> 32) != 0;
+  }
+};
+template <class V> struct Gran<V, 8> {
+  struct Slot {
+    u64 val, tag;
+  };
+  static __device__ __forceinline__ void put(Slot *p, V v) {
+    u64 b;
+    __builtin_memcpy(&b, &v, 8);
+    Coh<u64>::st(&p->val, b);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Coh<u64>::st(&p->tag, 1ull);
+  }
+  static __device__ __forceinline__ bool get(const Slot *p, V *v) {
+    if (Coh<u64>::ld(&p->tag) == 0) return false;
+    const u64 b = Coh<u64>::ld(&p->val);
+    __builtin_memcpy(v, &b, 8);
+    return true;
+  }
+};
+
+// One wave per GROUP of CH_GROUP consecutive 64-cell units, processed in order.  A lane resolves as
+// soon as ITS inputs are there and publishes its granule at once, so a unit never holds back values
+// other units wait for.  Inputs: children in this unit -> LDS (s_val); children in the previous unit of
+// the same group (a chain that straddles the unit border — the common short-distance dependency) -> LDS
+// (s_prev); everything else -> the granule, polled only while no lane can make progress, and at most
+// two granules per lane and poll.
+enum { CH_GROUP = 1, CH_CHUNK = 16, CH_STRIDE = 512 };
+template <class Op>
+__global__ void __launch_bounds__(64) k_chain_up(Op op, const u32 *__restrict__ chain_seq,
+                                                 const u32 *__restrict__ chain_pos, const u8 *__restrict__ kids_cell,
+                                                 u32 total, typename Gran<typename Op::V>::Slot *stage, u64 *ctrl,
+                                                 int ablate) {
+  typedef typename Op::V V;
+  typedef Gran<V> G;
+  __shared__ V s_val[64], s_prev[64];
+  const u32 lane = threadIdx.x;
+  const u32 nunits = (total + 63u) >> 6;
+  const u32 ngroups = (nunits + CH_GROUP - 1) / CH_GROUP;
+  u32 ticket = 0, it = 0;
+  for (;;) {
+    // tickets: one atomic per CH_CHUNK units (same-address atomics cost ~12 ns each, serialised); ticket
+    // t owns units base + j * CH_STRIDE, j < CH_CHUNK, of its super-block, so that units are still
+    // started in (roughly) layout order by all waves together
+    u32 grp = 0;
+    if (it == 0) {
+      if (lane == 0) ticket = (u32)atomicAdd((unsigned long long *)&ctrl[CH_NEXT], 1ull);
+      ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
+    }
+    grp = (ticket / CH_STRIDE) * (CH_STRIDE * CH_CHUNK) + (ticket % CH_STRIDE) + it * CH_STRIDE;
+    it = (it + 1) % CH_CHUNK;
+    if (grp >= ngroups) {
+      if ((ticket / CH_STRIDE) * (CH_STRIDE * CH_CHUNK) >= ngroups) return;  // past the last super-block
+      continue;
+    }
+    for (u32 gi = 0; gi < CH_GROUP; ++gi) {
+      const u32 u = grp * CH_GROUP + gi;
+      if (u >= nunits) break;
+      const u32 i = (u << 6) + lane;
+      const bool active = i < total;
+      const u32 x = active ? chain_seq[i] : 0u;
+      const u32 kids = active ? (u32)kids_cell[x] : 0u;
+      // layout positions of the children (unconditional loads from clamped addresses)
+      u32 cpos[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const i64 j = (i64)x + (i64)d8_dr(k) * (i64)op.g.ncol + d8_dc(k);
+        const u32 pc = chain_pos[j < 0 ? 0 : (j >= (i64)op.g.n ? (i64)op.g.n - 1 : j)];
+        cpos[k] = (kids & (1u << k)) ? pc : CH_NONE;
+      }
+      u32 ext = 0, prevu = 0;  // children behind granules / in the previous unit of this group (LDS)
+      u64 need = 0;            // lanes of this unit the cell waits for
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (cpos[k] == CH_NONE) continue;
+        const u32 cu = cpos[k] >> 6;
+        if (cu == u)
+          need |= 1ull << (cpos[k] & 63u);
+        else if (gi > 0 && cu + 1 == u)
+          prevu |= 1u << k;
+        else
+          ext |= 1u << k;
+      }
+      V cv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cv[k] = (prevu & (1u << k)) ? s_prev[cpos[k] & 63u] : V();
+      u32 pending = (ablate & 2) ? 0u : ext;
+      bool resolved = !active;
+      V myval = V();
+      u32 spins = 0, backoff = 1;
+      bool progress = false;  // the first pass polls (the values have to be fetched anyway)
+      for (;;) {
+        const u64 R = __ballot((int)resolved);
+        if (R == ~0ull) break;
+        if (!progress && __any((int)(pending != 0))) {
+          // poll the first two pending granules of the lane, both loads in flight together
+          const u32 k0 = pending ? (u32)__builtin_ctz(pending) : 0u;
+          const u32 rest = pending & (pending - 1u);
+          const u32 k1 = rest ? (u32)__builtin_ctz(rest) : k0;
+          u32 p0 = i, p1 = i;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (pending && (u32)k == k0) p0 = cpos[k];
+            if (rest && (u32)k == k1) p1 = cpos[k];
+          }
+          V t0 = V(), t1 = V();
+          bool ok0 = false, ok1 = false;
+          if (pending) {  // only lanes that wait issue loads (both in flight together)
+            ok0 = G::get(&stage[p0], &t0);
+            ok1 = G::get(&stage[p1], &t1);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (pending && (u32)k == k0 && ok0) cv[k] = t0;
+            if (rest && (u32)k == k1 && ok1) cv[k] = t1;
+          }
+          if (pending && ok0) pending &= ~(1u << k0);
+          if (rest && ok1) pending &= ~(1u << k1);
+          ++spins;
+          if (!__any((int)(ok0 || ok1))) {  // nothing arrived: back off (64 cycles .. ~2 us)
+            backoff = backoff < 64u ? backoff * 2u : 64u;
+            for (u32 b = 0; b < backoff; ++b) __builtin_amdgcn_s_sleep(1);
+          } else {
+            backoff = 1;
+          }
+        }
+        const bool go = !resolved && pending == 0 && (need & ~R) == 0;
+        if (go) {
+          myval = op.combine(x, kids, [&](u32, int k) { return (need && !((ext | prevu) & (1u << k))) ? s_val[cpos[k] & 63u] : cv[k]; });
+          s_val[lane] = myval;
+          resolved = true;
+          op.store(x, myval);        // the result (plain store: nobody reads it inside this kernel)
+          G::put(&stage[i], myval);  // the granule other groups poll
+        }
+        progress = __any((int)go) != 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (spins > (1u << 22) || ((spins & 255u) == 255u && Coh<u64>::ld(&ctrl[CH_ERROR]))) {
+          if (lane == 0) Coh<u64>::st(&ctrl[CH_ERROR], (u64)1);
+          return;  // (the host reports the failure; nothing hangs)
+        }
+      }
+      s_prev[lane] = myval;  // the next unit of the group reads its straddling chain from here
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if ((ablate & 8) && lane == 0) atomicAdd((unsigned long long *)&ctrl[50], (unsigned long long)spins);
+    }
+  }
+}
+
+// returns *used = 1 if the sweep ran on the chain layout
+template <class Op>
+static int run_up_chains(pfd_raster *h, const Op &op, const char *name, int *used) {
+  *used = 0;
+  if (!getenv("PFD_CHAIN_UP")) return PFD_OK;
+  PFDCHK(pfd_ensure_chains(h));
+  if (h->chains_state != 1 || h->n_chain == 0) return PFD_OK;
+  typedef typename Gran<typename Op::V>::Slot Slot;
+  pfd_seg_begin(h, name);
+  HIPCHK(hipMemsetAsync(h->ctrl + CH_NEXT, 0, 8 * sizeof(u64), h->stream));
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const u32 nunits = (u32)((h->n_chain + 63) / 64);
+  const u32 grid = std::min<u32>((nunits + CH_GROUP - 1) / CH_GROUP, (u32)cus * 32u);
+  DevBuf stage;
+  PFDCHK(stage.alloc((size_t)nunits * 64 * sizeof(Slot)));
+  HIPCHK(hipMemsetAsync(stage.p, 0, (size_t)nunits * 64 * sizeof(Slot), h->stream));  // tags: not ready
+  const int ablate = getenv("PFD_CHAIN_ABLATE") ? atoi(getenv("PFD_CHAIN_ABLATE")) : 0;
+  k_chain_up<Op><<<grid, 64, 0, h->stream>>>(op, h->chain_seq, h->chain_pos, h->chain_kids, (u32)h->n_chain,
+                                             (Slot *)stage.p, h->ctrl, ablate);
+  KCHK();
+  u64 c[8];
+  HIPCHK(hipMemcpyAsync(c, h->ctrl + CH_NEXT, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  pfd_seg_end(h, 2);
+  if (ablate & 8) fprintf(stderr, "[chain] units %u, polls per unit %.1f\n", nunits, (double)c[2] / nunits);
+  if (c[1]) {
+    pfd_set_error("chain sweep: a unit waited for its inputs longer than the spin budget");
+    return PFD_EHIP;
+  }
+  *used = 1;
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // small streaming helpers
 // ---------------------------------------------------------------------------------------------
 template <class T>
@@ -624,10 +880,14 @@ static int accuflux_t(pfd_raster *h, const void *data, bool by_row, T nodata, in
   pfd_seg_end(h, 1);
   if (direction == PFD_UP && by_row) {
     AccuUp<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
-    PFDCHK(run_up(h, op, "sweep_accuflux_up"));
+    int used = 0;
+    PFDCHK(run_up_chains(h, op, "chain_accuflux_up", &used));
+    if (!used) PFDCHK(run_up(h, op, "sweep_accuflux_up"));
   } else if (direction == PFD_UP) {
     AccuUp<T> op{h->ncode, h->geo, CellData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
-    PFDCHK(run_up(h, op, "sweep_accuflux_up"));
+    int used = 0;
+    PFDCHK(run_up_chains(h, op, "chain_accuflux_up", &used));
+    if (!used) PFDCHK(run_up(h, op, "sweep_accuflux_up"));
   } else if (by_row) {
     AccuDown<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
     PFDCHK(run_down(h, op, "sweep_accuflux_down"));

@@ -1,0 +1,20 @@
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from pyflwdir_amd import _hip
+L = _hip.lib()
+nrow = int(sys.argv[1]); ncol = int(sys.argv[2]) if len(sys.argv) > 2 else nrow
+nd = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+tilt = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 26
+n = nrow * ncol
+d8 = _hip.synth_d8_device(nrow, ncol, seed=0, tilt=tilt, white=2, nodata_pct=nd)
+def sync(): _hip.check(L.pfd_device_synchronize(0))
+h = _hip.RasterHandle(d8, nrow, ncol, device=0, memspace=_hip.PFD_DEVICE)
+h.set_profiling(True)
+w = _hip.synth_weights_device(n, seed=1)
+out = _hip.DeviceBuffer(n * 4)
+for it in range(3):
+    sync(); t0 = time.perf_counter()
+    h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out, memspace=_hip.PFD_DEVICE)
+    sync(); t1 = time.perf_counter()
+    print(it, round(1e3 * (t1 - t0), 2), "ms", [(s['name'], round(s['ms'], 2)) for s in h.last_timing()], flush=True)
