@@ -128,6 +128,8 @@ def run_distributed(a, rank, world, local):
 
     from pyflwdir_amd import dist as pdist
 
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)  # (only missing for the single-process PFD_BENCH_FORCE_DIST run)
     dist.init_process_group(backend="gloo")  # rendezvous / barrier / max-reduce only (CPU, 128-byte id)
     device = local % max(1, _hip.device_count())  # (one rank per GPU; the modulo only matters on test boxes)
     ncol = a.size

@@ -320,23 +320,29 @@ extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_
     pfd_set_error("pfd_upstream_area_cell_dist: the block is too large for the tiled engine");
     return PFD_EUNSUPPORTED;
   }
-  PFDCHK(run.phase_a_checked());
+  // From here on every rank must reach both collectives whatever happens locally (a rank that
+  // returned early would leave the others waiting in RCCL forever): local failures are carried to
+  // the final agreement instead.
+  int rc = run.phase_a_checked();
   if (world > 1) {
     DevBuf rec, allrec;
     PFDCHK(rec.alloc(recw * sizeof(u32)));
     PFDCHK(allrec.alloc((size_t)world * recw * sizeof(u32)));
     pfd_seg_begin(h, "allgather");
-    k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(run.haloL, run.brow_sink, ncol, rec.as<u32>());
-    KCHK();
+    if (rc == PFD_OK) {
+      k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(run.haloL, run.brow_sink, ncol, rec.as<u32>());
+    } else {
+      (void)hipMemsetAsync(rec.p, 0, recw * sizeof(u32), h->stream);
+    }
     NCCLCHK(ncclAllGather(rec.p, allrec.p, recw, ncclUint32, comm->comm, h->stream));
     pfd_seg_end(h, 2);
-    PFDCHK(interface_solve(run, allrec.as<u32>(), (u32)world, (u32)rank));
+    if (rc == PFD_OK) rc = interface_solve(run, allrec.as<u32>(), (u32)world, (u32)rank);
   }
   int complete = 0;
-  PFDCHK(run.phase_b(&complete));
-  PFDCHK(o.finish(h->stream));
+  if (rc == PFD_OK) rc = run.phase_b(&complete);
+  if (rc == PFD_OK) rc = o.finish(h->stream);
   // every rank must agree on success: a cycle anywhere invalidates downstream blocks as well
-  int ok_local = complete ? 1 : 0, ok_all = ok_local;
+  int ok_local = (rc == PFD_OK && complete) ? 1 : 0, ok_all = ok_local;
   if (world > 1) {
     DevBuf flag;
     PFDCHK(flag.alloc(sizeof(int)));
@@ -345,9 +351,10 @@ extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_
     HIPCHK(hipMemcpyAsync(&ok_all, flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }
+  if (rc != PFD_OK) return rc;  // the local failure (its message is already set)
   if (!ok_all) {
-    pfd_set_error("the raster holds cells that never reach a pit (cycles); the multi-GPU path requires a "
-                  "valid flow direction raster (FlwdirRaster.isvalid)");
+    pfd_set_error("a row block failed or the raster holds cells that never reach a pit (cycles); the multi-GPU "
+                  "path requires a valid flow direction raster (FlwdirRaster.isvalid)");
     return PFD_EUNSUPPORTED;
   }
   return PFD_OK;

@@ -124,21 +124,35 @@ class DistributedRaster:
             import torch
             import torch.distributed as dist
 
-            res, rec = _hip.upstream_area_cell_begin(self.handle, out=out, memspace=memspace)
+            # every rank reaches both collectives whatever happens locally (a rank that raised early
+            # would leave the others waiting): a local failure travels with the final agreement
+            err, res, ok = None, out, False
+            rec = np.zeros(4 * self.handle.ncol, np.uint32)
+            try:
+                res, rec = _hip.upstream_area_cell_begin(self.handle, out=out, memspace=memspace)
+            except Exception as exc:  # noqa: BLE001
+                err = exc
             mine = torch.from_numpy(rec.view(np.int32).copy())
             parts = [torch.empty_like(mine) for _ in range(self.world)]
             if self.world > 1:
                 dist.all_gather(parts, mine, group=self.group)
             else:
                 parts = [mine]
-            allrec = np.stack([p.numpy().view(np.uint32) for p in parts])
-            ok = _hip.upstream_area_cell_finish(self.handle, allrec, self.world, self.rank)
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if err is None:
+                try:
+                    allrec = np.stack([p.numpy().view(np.uint32) for p in parts])
+                    ok = _hip.upstream_area_cell_finish(self.handle, allrec, self.world, self.rank)
+                except Exception as exc:  # noqa: BLE001
+                    err = exc
+            flag = torch.tensor([1 if (ok and err is None) else 0], dtype=torch.int32)
             if self.world > 1:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if err is not None:
+                raise err
             if int(flag[0]) == 0:
-                raise NotImplementedError("the raster holds cells that never reach a pit (cycles); the multi-GPU "
-                                          "path requires a valid flow direction raster (FlwdirRaster.isvalid)")
+                raise NotImplementedError("a row block failed or the raster holds cells that never reach a pit "
+                                          "(cycles); the multi-GPU path requires a valid flow direction raster "
+                                          "(FlwdirRaster.isvalid)")
         return res.reshape(self.handle.nrow, self.handle.ncol) if memspace == _hip.PFD_HOST else res
 
     def close(self):
