@@ -82,6 +82,8 @@ struct TileArgs {
   u8 *ncode_w;
   u64 *tcnt;       // [ntr*ntc] per tile: valid | pits << 16 | bad << 32 (raw pass only)
   u64 ntot;        // nrow * ncol
+  u32 *hcnt;       // [nht] super-exit counters of the hypertiles, cleared by the local pass
+  u32 nht;
   u32 nrow, ncol, ntr, ntc;
   u32 row_first, row_last;  // owned rows (inclusive) of the device raster; the rest are halo rows
   u32 nstc;        // supertiles per row; slot ids are supertile-major (sslot_base)
@@ -195,7 +197,7 @@ struct TiledRun {
   u32 *Tc = nullptr, *Tn = nullptr, *Jc = nullptr, *Jn = nullptr, *xin3 = nullptr, *R3 = nullptr, *hx_id = nullptr;
   size_t n3cap = 0, n4cap = 0;
   u32 *W2 = nullptr, *J4fin = nullptr;
-  int solve_exits(const u32 *start, i64 *launches);
+  int solve_exits(const u32 *start, i64 *launches, bool cleared = false);
   int level3_flat(i64 *launches);
   int level3_hyper(i64 *launches);
   TileArgs a{};
@@ -207,4 +209,4 @@ struct TiledRun {
 };
 
 int pfd_doubling_rounds(pfd_raster *h, u32 *T[3], u32 *J[2], u32 n, int first_batch, bool check, bool *done,
-                        int *rounds_issued, i64 *launches, const u64 *ncnt = nullptr);
+                        int *rounds_issued, i64 *launches, const u64 *ncnt = nullptr, bool prepared = false);

@@ -68,6 +68,8 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   const u32 tc = blockIdx.x, tr = blockIdx.y;
   const u32 sbase = sslot_base(tr, tc, a.nstc);  // first of this tile's 256 slot ids
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
+  if (!FINAL && tc == 0 && tr == 0)  // (the exit-graph solve starts after this kernel: no memset launch)
+    for (u32 q = tid; q < a.nht; q += 256u) a.hcnt[q] = 0;
 
   // ---- stage the tile's codes (+halo) as dwords: all loads in flight before the first store ----
   u32 cq[QPT];  // FINAL: the codes of the thread's quads
@@ -556,9 +558,11 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
 __device__ __forceinline__ bool sx_active(const SuperArgs &s, u32 k) {
   return !s.hmode || (k % HCAP) < s.hcnt[k / HCAP];
 }
-__global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__restrict__ J3) {
+__global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__restrict__ J3,
+                                               u32 *__restrict__ clear = nullptr) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nsuper) return;
+  if (clear) clear[k] = 0;  // (hyper mode: the level-3 inflow array, filled by k_push4 later on)
   if (s.hmode && s.ctrl[T_OVERFLOW]) return;  // ids are invalid: the host redoes the pass flat
   if (!sx_active(s, k)) {
     J3[k] = k | XDONE;
@@ -572,7 +576,6 @@ __global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__r
     if (id != NONE32) j = id;
   }
   J3[k] = j;
-  if (!(j & XDONE)) flag_active(s.ctrl);
 }
 // flow through a super-exit enters the next supertile at the exit its target entry leads to
 __global__ void __launch_bounds__(256) k_push3(SuperArgs s, u32 nsuper, const u32 *__restrict__ T3final) {
@@ -677,14 +680,14 @@ __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
   }
 }
 // level-4 links: hyper-exit -> next hyper-exit on its path (through the hypertile it enters)
-__global__ void __launch_bounds__(256) k_link4(HyperArgs s, u32 cap, u32 *__restrict__ J4) {
+__global__ void __launch_bounds__(256) k_link4(HyperArgs s, u32 cap, u32 *__restrict__ J4, u32 *__restrict__ Tnext) {
   const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= min(cap, (u32)s.ctrl[T_NHYPER]) || s.ctrl[T_OVERFLOW]) return;
+  Tnext[m] = 0;  // the first round accumulates into a cleared buffer (pfd_doubling_rounds, prepared)
   const u32 n1 = s.J3[s.hx_node[m]];  // first node inside the entered hypertile
   const u32 id = s.hx_id[s.R3[n1]];
   const u32 j = (id != NONE32) ? id : (m | XDONE);
   J4[m] = j;
-  if (!(j & XDONE)) flag_active(s.ctrl);
 }
 __global__ void __launch_bounds__(256) k_push4(HyperArgs s, u32 cap, const u32 *__restrict__ T4final, u32 *xin3) {
   const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -738,11 +741,13 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
 // first_batch rounds are issued and *done is left to the caller, who compares ctrl[T_XACTIVE]
 // with the returned round count at its next synchronisation.
 int pfd_doubling_rounds(pfd_raster *h, u32 *T[3], u32 *J[2], u32 n, int first_batch, bool check, bool *done,
-                        int *rounds_issued, i64 *launches, const u64 *ncnt) {
+                        int *rounds_issued, i64 *launches, const u64 *ncnt, bool prepared) {
   const u32 grid = cdiv_u32(n, 256);
   *done = false;
-  HIPCHK(hipMemsetAsync(T[1], 0, (size_t)n * sizeof(u32), h->stream));
-  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+  if (!prepared) {  // (prepared: the caller's kernels have cleared T[1] and the round mark already)
+    HIPCHK(hipMemsetAsync(T[1], 0, (size_t)n * sizeof(u32), h->stream));
+    HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+  }
   int batch = first_batch, rounds = 0;
   while (rounds < 48 && !*done) {
     for (int b = 0; b < batch; ++b) {
@@ -879,7 +884,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   haloL = b + 2 * nb;
   brow_sink = b + 3 * nb;
   brow_inflow = b + 4 * nb;
-  a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
+  a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, hcntbuf.as<u32>(), nht, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
@@ -918,8 +923,7 @@ int TiledRun::level3_hyper(i64 *launches) {
   u32 *y = l4.as<u32>();
   u32 *hx_node = y, *T4c = y + n4cap, *J4c = y + 3 * n4cap;
   u32 *T4[3] = {y + n4cap, y + 2 * n4cap, y + 5 * n4cap}, *J4[2] = {y + 3 * n4cap, y + 4 * n4cap};
-  HIPCHK(hipMemsetAsync(xin3, 0, (size_t)n3 * sizeof(u32), h->stream));
-  k_link3<<<g3, 256, 0, h->stream>>>(sa, n3, J3);
+  k_link3<<<g3, 256, 0, h->stream>>>(sa, n3, J3, xin3);
   HyperArgs ha{nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl};
   k_hyper<false><<<nht, 1024, 0, h->stream>>>(ha);
   KCHK();
@@ -927,7 +931,7 @@ int TiledRun::level3_hyper(i64 *launches) {
   {  // level 4: the number of hyper-exits stays on the device (grids are sized for the capacity)
     const u32 cap4 = (u32)std::min<size_t>(n4cap, 0x7FFFFFFF);
     const u32 g4 = cdiv_u32(cap4, 256);
-    k_link4<<<g4, 256, 0, h->stream>>>(ha, cap4, J4c);
+    k_link4<<<g4, 256, 0, h->stream>>>(ha, cap4, J4c, T4[1]);
     // No host round trip here: a fixed number of rounds is issued (rounds past saturation are
     // idempotent) and the "last round that moved a pointer" mark is compared with it at the pass's
     // final synchronisation; a miss redoes the pass with more rounds.
@@ -935,7 +939,7 @@ int TiledRun::level3_hyper(i64 *launches) {
     for (u32 span = 1; span < (ntr + ntc) / (SG * HG) + 2; span <<= 1) ++batch;  // ~log2 of a path in hypertiles
     if (const char *e = getenv("PFD_TEST_ROUNDS4")) batch = atoi(e) + extra_rounds;  // (tests: force a miss)
     bool done4 = false;
-    PFDCHK(pfd_doubling_rounds(h, T4, J4, cap4, batch, false, &done4, &rounds4, launches, h->ctrl + T_NHYPER));
+    PFDCHK(pfd_doubling_rounds(h, T4, J4, cap4, batch, false, &done4, &rounds4, launches, h->ctrl + T_NHYPER, true));
     J4fin = J4[0];
     k_push4<<<g4, 256, 0, h->stream>>>(ha, cap4, T4[0], xin3);
     *launches += 2;
@@ -949,9 +953,13 @@ int TiledRun::level3_hyper(i64 *launches) {
 
 // hierarchical solve of the exit graph for the start values `start` (one u32 per slot): totals of
 // all exits, delivered (added) to the tile entries they drain into
-int TiledRun::solve_exits(const u32 *start, i64 *launches) {
-  HIPCHK(hipMemsetAsync(hcntbuf.p, 0, (size_t)nht * sizeof(u32), h->stream));
-  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, 3 * sizeof(u64), h->stream));  // T_XACTIVE, T_NSUPER, T_NHYPER
+// (cleared: the hypertile counters and the ctrl words of the solve are zero already — first solve of a
+//  pass: the ctrl memset of phase_a and the local tile pass have done it)
+int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared) {
+  if (!cleared) {
+    HIPCHK(hipMemsetAsync(hcntbuf.p, 0, (size_t)nht * sizeof(u32), h->stream));
+    HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, 3 * sizeof(u64), h->stream));  // T_XACTIVE, T_NSUPER, T_NHYPER
+  }
   sa.xT = start;
   Tc = l3.as<u32>() + n3cap, Tn = Tc + n3cap, Jc = Tn + n3cap, Jn = Jc + n3cap;  // undo earlier ping-pong swaps
   sa.T3 = Tc;
@@ -990,7 +998,7 @@ int TiledRun::phase_a() {
     HIPCHK(hipMemsetAsync(haloA, 0, 2 * nb * sizeof(u32), h->stream));
     HIPCHK(hipMemsetAsync(brow_sink, 0xFF, nb * sizeof(u32), h->stream));
   }
-  HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));  // read by the final tile pass
+  if (is_block) HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));  // read by the final tile pass
   const dim3 grid(ntc, ntr);
   pfd_seg_begin(h, "tile_local");
   if (!h->normalised) {  // deferred handle: decode + validate + count inside the tile pass
@@ -1010,7 +1018,7 @@ int TiledRun::phase_a() {
 
   pfd_seg_begin(h, "exit_graph");
   i64 launches = 0;
-  PFDCHK(solve_exits(xT, &launches));
+  PFDCHK(solve_exits(xT, &launches, true));
   if (is_block) {  // what leaves through the halo rows, and where boundary-row inflow would leave
     HIPCHK(hipMemcpyAsync(haloL, haloA, nb * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
     const u32 ne = (ntr > 1 ? 2u : 1u) * ntc * PSL;
