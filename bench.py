@@ -44,8 +44,8 @@ KERNEL_OF = {"tile_local": "void k_tile<false, true>(TileArgs)", "tile_final": "
 # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3
 # --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of this same command, 10000 x 10000):
 # bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024, raw counter values (calibration in DESIGN.md)
-PMC_TRAFFIC = {("void k_tile<true, false>(TileArgs)", 10000): (147187.047 + 390625.000) * 1024,  # profiles/r01e_*
-               ("void k_tile<false, true>(TileArgs)", 10000): (176831.812 + 221867.781) * 1024}
+PMC_TRAFFIC = {("void k_tile<true, false>(TileArgs)", 10000): (147178.969 + 390625.000) * 1024,  # profiles/r01g_*
+               ("void k_tile<false, true>(TileArgs)", 10000): (176827.453 + 221867.906) * 1024}
 
 
 def roofline_of(segs, n, size, ms_per_step):

@@ -1,7 +1,7 @@
-# round-1 evidence run (profiles/r01e_*): kernel stats, PMC traffic, other sizes and operations
+# round-1 evidence run (profiles/r01g_*): kernel stats, PMC traffic, other sizes and operations
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01e
+O=$R/gpurun_out/r01g
 mkdir -p $O
 cd /tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
