@@ -35,7 +35,7 @@
 //               cells from THEIR upstream cells (recursively, down to final values), in the same
 //               order and with the same arithmetic as the thread that owns that cell —
 //               bit-identical, ~2x the work on a network with ~1 upstream cell per cell;
-//   down-sweeps up to 8 levels per launch: a cell climbs to the ancestor whose downstream cell is
+//   down-sweeps up to 16 levels per launch: a cell climbs to the ancestor whose downstream cell is
 //               final and applies the per-cell update back down the chain (no fan-out at all).
 // Wide levels (rough rasters: few levels, bandwidth-bound) are launched one by one as before.
 __device__ __forceinline__ u32 kids_of(const u8 *__restrict__ ncode, const Geo &g, u32 x) {
@@ -124,7 +124,7 @@ __device__ __forceinline__ constexpr int slot_desc(int q) {  // slots in descend
 }
 
 // launches covering several levels are only used while they stay small (latency-bound regime)
-static const u32 MULTIHOP_MAX_CELLS = 1u << 18;     // down-sweeps (a chain of single loads per thread)
+static const u32 MULTIHOP_MAX_CELLS = 1u << 20;     // down-sweeps (a chain of single loads per thread)
 static const u32 MULTIHOP_MAX_CELLS_UP = 1u << 16;  // up-sweeps (the window form loads ~50 values per thread)
 
 // ---- up-sweeps --------------------------------------------------------------------------------
@@ -201,7 +201,7 @@ static int run_up(pfd_raster *h, const Op &op, const char *name) {
 // value of x from the value pv of its downstream cell (root: x is a pit, pv unused); store(x, v).
 // The launch covers seq positions [begin, end) = up to DOWN_K consecutive levels; off.o[i] = start of
 // the (i+1)-th of them (unused ones = end); `roots`: the first level is level 0 (the pits).
-enum { DOWN_K = 8 };
+enum { DOWN_K = 16 };
 struct DownOffsets {
   u32 o[DOWN_K - 1];
 };
