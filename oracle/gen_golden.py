@@ -180,6 +180,21 @@ def run_case(name, case):
     res["strdist_m_latlon"] = flw.stream_distance(unit="m")
     res["strdist_m_proj"] = flw_proj.stream_distance(unit="m")
     res["strdist_m_mask"] = flw.stream_distance(mask=GI.random_mask(d8.shape), unit="m")
+    # ---- codecs — re-encoding to D8 / LDD and an LDD raster as input -----------------
+    res["to_array_d8"] = flw.to_array("d8")
+    ldd = flw.to_array("ldd")
+    res["to_array_ldd"] = ldd
+    try:
+        flw_ldd = pyflwdir.from_array(ldd, ftype="infer", transform=A, latlon=latlon, cache=False)
+        res["ldd_inferred_is_ldd"] = np.uint8(flw_ldd.ftype == "ldd")
+        res["ldd_idxs_ds"] = flw_ldd.idxs_ds
+        res["ldd_idxs_outlet"] = flw_ldd.idxs_outlet
+        res["ldd_uparea_cell"] = flw_ldd.upstream_area()
+    except OverflowError:
+        # interpreted (no JIT) under numpy >= 2 the reference's own core_ldd.from_array overflows its
+        # int8 column offset on rasters wider than 127 columns (core_ldd.py:55): LDD *input* is pinned
+        # on the narrow cases only; the LDD *output* (to_array) on all of them
+        pass
 
     stats = dict(shape=[int(nrow), int(ncol)], n_valid=int(res["n_valid"]), n_pits=int(res["idxs_pit_int32"].size),
                  n_seq=int(res["idxs_seq_int32"].size), max_rank=int(res["rank"].max()),

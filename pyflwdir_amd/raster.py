@@ -37,7 +37,18 @@ D8_DS = np.array([[32, 64, 128], [16, 0, 1], [8, 4, 2]], dtype=np.uint8)
 D8_MV = np.uint8(247)
 D8_PV = np.array([0, 255], dtype=np.uint8)
 D8_ALL = np.array([32, 64, 128, 16, 0, 1, 8, 4, 2, 247, 255], dtype=np.uint8)
-FTYPES = ("d8", "ldd", "nextxy")  # names known to the reference; only "d8" runs on the GPU
+FTYPES = ("d8", "ldd", "nextxy")  # names known to the reference; "d8" and "ldd" run on the GPU
+# LDD (PCRaster keypad codes, reference pyflwdir/core_ldd.py:11-17) is the same 8-neighbour scheme with
+# other labels: a 256-entry table turns it into D8 on the way in (7 8 9 / 4 5 6 / 1 2 3; 5 = pit,
+# 255 = nodata) and back on the way out; values outside the alphabet map to an invalid D8 code
+LDD_DS = np.array([[7, 8, 9], [4, 5, 6], [1, 2, 3]], dtype=np.uint8)
+LDD_MV = np.uint8(255)
+LDD_ALL = np.array([7, 8, 9, 4, 5, 6, 1, 2, 3, 255], dtype=np.uint8)
+_LDD_TO_D8 = np.full(256, 3, dtype=np.uint8)  # 3 is not a D8 code: rejected by the device like in the reference
+_LDD_TO_D8[LDD_DS.ravel()] = D8_DS.ravel()
+_LDD_TO_D8[LDD_MV] = D8_MV
+_D8_TO_LDD = np.full(256, LDD_MV, dtype=np.uint8)
+_D8_TO_LDD[D8_DS.ravel()] = LDD_DS.ravel()
 
 _PAYLOAD = {np.dtype(np.int32): _hip.PFD_I32, np.dtype(np.int64): _hip.PFD_I64,
             np.dtype(np.float32): _hip.PFD_F32, np.dtype(np.float64): _hip.PFD_F64}
@@ -62,10 +73,20 @@ def d8_isvalid(flwdir) -> bool:
     return not present.any()
 
 
+def ldd_isvalid(flwdir) -> bool:
+    """True if ``flwdir`` is a 2-D uint8 raster of LDD values; reference pyflwdir/core_ldd.py:100-102."""
+    if not (isinstance(flwdir, np.ndarray) and flwdir.dtype == np.uint8 and flwdir.ndim == 2):
+        return False
+    return bool(np.isin(flwdir, LDD_ALL).all())
+
+
 def _infer_ftype(flwdir):
-    """reference pyflwdir/pyflwdir.py:39-48 (only D8 can be inferred here)."""
+    """reference pyflwdir/pyflwdir.py:39-48: the first type whose alphabet holds every value, in
+    the reference's order (d8, ldd; nextxy rasters cannot be inferred here)."""
     if d8_isvalid(flwdir):
         return "d8"
+    if ldd_isvalid(flwdir):
+        return "ldd"
     raise ValueError("The flow direction type could not be inferred.")
 
 
@@ -89,25 +110,29 @@ def from_array(data, ftype="infer", check_ftype=True, mask=None, transform=gis.I
     """Flow direction raster parsed to an actionable (device-resident) format.
 
     Same signature and checks as the reference's ``from_array`` (pyflwdir/pyflwdir.py:130-205).
-    Only ``ftype="d8"`` (or ``"infer"`` on D8 data) is implemented on the GPU path."""
+    ``ftype="d8"`` and ``"ldd"`` (or ``"infer"`` on either) run on the GPU path."""
     if ftype == "infer":
         ftype = _infer_ftype(data)
         check_ftype = False
     if ftype not in FTYPES:
         raise ValueError(f'Unknown flow direction type: "{ftype}", select from {", ".join(FTYPES)}')
-    if ftype != "d8":
-        raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path; only "d8" is implemented')
+    if ftype == "nextxy":
+        raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path; "d8" and "ldd" are implemented')
     data = np.asarray(data)
     if data.ndim != 2:
         raise ValueError("The FlwdirRaster should be 2 dimensional")
-    if check_ftype and not d8_isvalid(data):
+    if check_ftype and not (d8_isvalid(data) if ftype == "d8" else ldd_isvalid(data)):
         raise ValueError(f'The flow direction data with type "{ftype}" is invalid.')
+    if ftype == "ldd":  # same graph, other labels (core_ldd.from_array, reference pyflwdir/core_ldd.py:41-66)
+        data = _LDD_TO_D8[np.ascontiguousarray(data, dtype=np.uint8)]
     if mask is not None:
         if mask.shape != data.shape:
             raise ValueError('"mask" shape does not match with data shape')
         data = np.where(mask != 0, data, D8_MV)
-    return FlwdirRaster._from_d8(np.ascontiguousarray(data, dtype=np.uint8), transform=transform, latlon=latlon,
-                                 **kwargs)
+    flw = FlwdirRaster._from_d8(np.ascontiguousarray(data, dtype=np.uint8), transform=transform, latlon=latlon,
+                                **kwargs)
+    flw.ftype = ftype
+    return flw
 
 
 class FlwdirRaster(object):
@@ -121,13 +146,14 @@ class FlwdirRaster(object):
             raise ValueError(f"Invalid FlwdirRaster: size {idxs_ds.size}")
         if ftype not in FTYPES:
             raise ValueError(f'Unknown flow direction type: "{ftype}", select from {", ".join(FTYPES)}')
-        if ftype != "d8":
-            raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path; only "d8" is implemented')
+        if ftype == "nextxy":
+            raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path; "d8" and "ldd" are implemented')
         if np.multiply(*np.array(shape, np.uint64)) != idxs_ds.size:
             raise ValueError(f"Invalid FlwdirRaster: shape {shape} does not match size {idxs_ds.size}")
         mv = self._mv_for(idxs_ds.dtype)
         d8 = _d8_from_idxs_ds(idxs_ds.ravel(), tuple(shape), mv)
         self._setup(d8, transform, latlon, cache, device)
+        self.ftype = ftype
         self._idxs_ds = idxs_ds.ravel()
         self._idx_dtype = idxs_ds.dtype
         self._mv = mv
@@ -311,18 +337,17 @@ class FlwdirRaster(object):
         self.idxs_outlet = pits[np.isin(self._d8.flat[pits], D8_PV)]
 
     def to_array(self, ftype=None):
-        """2-D flow direction raster (D8 only)."""
+        """2-D flow direction raster in D8 or LDD codes; reference pyflwdir/pyflwdir.py:341-359
+        (core_d8.to_array / core_ldd.to_array re-encode ``idxs_ds``: every pit is written as the pit code)."""
         if ftype is None:
             ftype = self.ftype
-        if ftype != "d8":
+        if ftype not in ("d8", "ldd"):
             if ftype in FTYPES:
                 raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path')
             raise ValueError(f'ftype "{ftype}" unknown')
-        # cells that decode to pits but carry a direction code keep the code of the input,
-        # like the reference which re-encodes idxs_ds: a pit is written as 0
         d8 = self._d8.copy()
         d8.flat[self.idxs_pit] = 0
-        return d8
+        return d8 if ftype == "d8" else _D8_TO_LDD[d8]
 
     # -- spatial ----------------------------------------------------------------------------
     def index(self, xs, ys, **kwargs):

@@ -130,6 +130,31 @@ def test_streams_next(case, flw):
     case.check("strdist_m_proj", flw_proj.stream_distance(unit="m"))
 
 
+def test_codecs(case, flw):
+    """re-encoding to D8 / LDD and LDD rasters as input (reference
+    tests/test_pyflwdir.py:19-34, tests/test_core_xx.py:12-62)."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd._affine import Affine
+
+    case.check("to_array_d8", flw.to_array("d8"))
+    ldd = flw.to_array("ldd")
+    case.check("to_array_ldd", ldd)
+    assert np.all(pyflwdir.from_array(flw.to_array()).idxs_ds == flw.idxs_ds)  # tests/test_pyflwdir.py:24
+    flw_ldd = pyflwdir.from_array(ldd, ftype="infer", transform=Affine(*case.transform), latlon=case.latlon, cache=False)
+    if "ldd_idxs_ds" in case.digests:  # (the interpreted reference parses LDD input on narrow rasters only)
+        if "ldd_inferred_is_ldd" in case.full:
+            assert (flw_ldd.ftype == "ldd") == bool(case.full["ldd_inferred_is_ldd"])
+        case.check("ldd_idxs_ds", flw_ldd.idxs_ds)
+        case.check("ldd_idxs_outlet", flw_ldd.idxs_outlet)
+        case.check("ldd_uparea_cell", flw_ldd.upstream_area())
+    # an LDD raster is the same graph as its D8 twin
+    assert np.array_equal(flw_ldd.idxs_ds, flw.idxs_ds) and np.array_equal(flw_ldd.upstream_area(), flw.upstream_area())
+    if flw_ldd.ftype == "ldd":
+        case.check("to_array_ldd", flw_ldd.to_array())  # default: the input's own type
+    with pytest.raises(ValueError, match="unknown"):
+        flw.to_array("unknown")  # tests/test_pyflwdir.py:32-33
+
+
 def test_constructor_from_idxs_ds(case, flw):
     """FlwdirRaster(idxs_ds, shape, "d8") like reference tests/conftest.py:49-54."""
     import pyflwdir_amd as pyflwdir
