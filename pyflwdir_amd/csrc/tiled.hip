@@ -3,7 +3,7 @@
 //
 // Integer accumulation is associative (int32 wrap-around included), so the serial ordering of
 // the reference is not needed.  The raster is cut into 64x64-cell tiles; one 256-thread
-// workgroup owns one tile and keeps its whole state in LDS (160 KB/CU on MI355X, 5 tiles
+// workgroup owns one tile and keeps its whole state in LDS (160 KB/CU on MI355X, 5-6 tiles
 // resident per CU).  Inside a tile — and again on the graph of tile exits — subtree sums are
 // computed by POINTER DOUBLING instead of a dependent walk:
 //
@@ -22,12 +22,17 @@
 //                            every cell that drains out of the tile ("exit") and the slot it
 //                            drains into; for every perimeter cell that receives flow from
 //                            outside ("entry") the exit its in-tile path ends at ("link").
-//   phase 2  k_super / k_*3  the exits form a forest ~50x smaller than the raster:
+//                            On a deferred handle (RAW) the pass also decodes / validates /
+//                            counts the raw codes and writes the normalised ones.
+//   phase 2  exit graph      the exits form a forest ~50x smaller than the raster:
 //                            exit e -> link(target(e)).  Solved hierarchically with the same
-//                            doubling: per 8x8-tile supertile in LDS (k_super), then globally
-//                            over the exits that leave their supertile (ping-pong buffers, one
-//                            launch per round), then per supertile again with the flow entering
-//                            it: TOTAL count at every exit, inflow at every tile entry.
+//                            doubling, bottom-up then top-down:
+//                              level 2  k_super   8x8-tile supertile in LDS (16384 slots)
+//                              level 3  k_hyper   4x4-supertile hypertile in LDS (dense ids of
+//                                                 the exits that leave their supertile)
+//                              level 4  k_coarse_round  global memory, one launch per round,
+//                                                 three rotating value buffers, fixed round budget
+//                            -> TOTAL count at every exit, inflow at every tile entry.
 //   phase 3  k_tile<true>    per tile: the doubling again with entries weighted 1 + inflow;
 //                            the finished tile is written to HBM once, coalesced.
 //
@@ -424,8 +429,8 @@ __global__ void __launch_bounds__(1024) k_tile_counts(const u64 *__restrict__ tc
 }
 
 // ---------------------------------------------------------------------------------------------
-// coarse graph: exit e -> exit reached from the cell it drains into.  Pointer doubling with
-// ping-pong buffers (a launch is the round barrier).
+// coarse graph: exit e -> exit reached from the cell it drains into.  Pointer doubling in global
+// memory (a launch is the round barrier; k_coarse_round further down).
 // ---------------------------------------------------------------------------------------------
 // raise the "a pointer is still unsaturated" flag: one store per wave at most, and none once
 // the flag is visible (millions of same-address stores would serialise in L2)
@@ -975,7 +980,7 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared) {
     HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, 3 * sizeof(u64), h->stream));  // T_XACTIVE, T_NSUPER, T_NHYPER
   }
   sa.xT = start;
-  Tc = l3.as<u32>() + n3cap, Tn = Tc + n3cap, Jc = Tn + n3cap, Jn = Jc + n3cap;  // undo earlier ping-pong swaps
+  Tc = l3.as<u32>() + n3cap, Tn = Tc + n3cap, Jc = Tn + n3cap, Jn = Jc + n3cap;  // undo earlier buffer rotations
   sa.T3 = Tc;
   // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
   sa.hmode = (nht > 1 && !force_flat && !getenv("PFD_FLAT_L3")) ? 1 : 0;
