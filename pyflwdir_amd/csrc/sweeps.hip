@@ -50,18 +50,22 @@ __device__ __forceinline__ u32 kids_of(const u8 *__restrict__ ncode, const Geo &
 }
 // kids2: byte k = child mask of the upstream cell in slot k (0 if none) — a 2-hop launch then needs
 // no lookup between the cell and its grandchildren
+// (the per-cell masks are built first — k_cell_kids — and only gathered here: 8 neighbour tests per
+//  cell instead of 72)
 __global__ void __launch_bounds__(256) k_seq_aux(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ seq,
-                                                 u32 nseq, u8 *__restrict__ kids, u8 *__restrict__ own,
-                                                 u64 *__restrict__ kids2) {
+                                                 u32 nseq, const u8 *__restrict__ cell_kids, u8 *__restrict__ kids,
+                                                 u8 *__restrict__ own, u64 *__restrict__ kids2) {
   const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nseq) return;
   const u32 x = seq[j];
-  const u32 m = kids_of(ncode, g, x);
+  const u32 m = cell_kids[x];
   u64 m2 = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (m & (1u << k))
-      m2 |= (u64)kids_of(ncode, g, (u32)((i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k))) << (8 * k);
+  for (int k = 0; k < 8; ++k) {  // unconditional loads from clamped addresses, masked afterwards
+    const i64 nb = (i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k);
+    const u64 c = cell_kids[nb < 0 ? 0 : (nb >= (i64)g.n ? (i64)g.n - 1 : nb)];
+    if (m & (1u << k)) m2 |= c << (8 * k);
+  }
   kids[j] = (u8)m;
   own[j] = ncode[x];
   kids2[j] = m2;
@@ -84,13 +88,13 @@ int pfd_ensure_seq_aux(pfd_raster *h) {
   h->seq_kids = (u8 *)(h->seq_kids2 + ns);
   h->seq_own = h->seq_kids + ns;
   h->cell_kids = h->seq_own + ns;
-  if (h->n_seq) {
-    k_seq_aux<<<cdiv_u32((u64)h->n_seq, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, (u32)h->n_seq,
-                                                                   h->seq_kids, h->seq_own, h->seq_kids2);
-    KCHK();
-  }
   k_cell_kids<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->cell_kids);
   KCHK();
+  if (h->n_seq) {
+    k_seq_aux<<<cdiv_u32((u64)h->n_seq, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, (u32)h->n_seq,
+                                                                   h->cell_kids, h->seq_kids, h->seq_own, h->seq_kids2);
+    KCHK();
+  }
   h->aux_ready = true;
   return PFD_OK;
 }
