@@ -247,6 +247,6 @@ int pfd_ensure_chains(pfd_raster *h);                           // paths.hip (h-
 void pfd_free_chains(pfd_raster *h);                            // paths.hip
 int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev,
                      int *ok);                                   // paths.hip
-int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete);  // tiled.hip
+int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete, const i32 *weights = nullptr);  // tiled.hip
 
 static inline u32 cdiv_u32(u64 a, u32 b) { return (u32)((a + b - 1) / b); }

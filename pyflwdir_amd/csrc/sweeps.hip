@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <unordered_set>
 
 #include "common.h"
@@ -863,6 +864,72 @@ __global__ void k_fill_rows(const T *__restrict__ row, Geo g, T *__restrict__ ou
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x < g.n) out[x] = row[geo_row(g, x)];
 }
+// ---- int32 accuflux on the tiled engine ----------------------------------------------------------
+// Integer accumulation is associative, so the LDS-tiled pointer-doubling engine (tiled.hip) gives the
+// reference's result whenever the nodata rule of streams.accuflux (streams.py:38-40) cannot interfere:
+// no valid cell holds the nodata value and no running sum can become it.  Checked in one pass: every
+// valid cell's value >= 0, nodata < 0 (or no nodata test at all), and the total < 2^31 (no wrap, so
+// every partial sum is >= 0).  Anything else goes through the level engine.
+__global__ void __launch_bounds__(256) k_payload_check(const u8 *__restrict__ ncode, const i32 *__restrict__ data, u32 n,
+                                                       i32 nodata, unsigned long long *__restrict__ res) {
+  // res[0] = sum of the valid cells' values, res[1] = number of valid cells that are negative or nodata
+  __shared__ unsigned long long s_sum;
+  __shared__ u32 s_bad;
+  if (threadIdx.x == 0) s_sum = 0, s_bad = 0;
+  __syncthreads();
+  unsigned long long sum = 0;
+  u32 bad = 0;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (ncode[i] == D8_MV) continue;
+    const i32 v = data[i];
+    if (v < 0 || v == nodata) ++bad; else sum += (unsigned long long)v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_down(sum, o);
+    bad += __shfl_down(bad, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (sum) atomicAdd(&s_sum, sum);
+    if (bad) atomicAdd(&s_bad, bad);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_sum) atomicAdd(&res[0], s_sum);
+    if (s_bad) atomicAdd(&res[1], (unsigned long long)s_bad);
+  }
+}
+__global__ void __launch_bounds__(256) k_restore_invalid(const u8 *__restrict__ ncode, const i32 *__restrict__ data, u32 n,
+                                                         i32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && ncode[i] == D8_MV) out[i] = data[i];  // (nodata cells of the raster keep their input value)
+}
+// *used = 1 if the tiled engine produced the result
+static int accuflux_i32_tiled(pfd_raster *h, const i32 *data_dev, i32 nodata, int has_nodata, i32 *out_dev,
+                              int *used) {
+  *used = 0;
+  if (getenv("PFD_ACCUFLUX_LEVELS") || h->halo_top || h->halo_bot) return PFD_OK;
+  if (has_nodata && nodata >= 0) return PFD_OK;
+  DevBuf res;
+  PFDCHK(res.alloc(2 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(res.p, 0, 2 * sizeof(unsigned long long), h->stream));
+  pfd_seg_begin(h, "payload_check");
+  k_payload_check<<<2048, 256, 0, h->stream>>>(h->ncode, data_dev, h->geo.n, has_nodata ? nodata : (i32)-1,
+                                               res.as<unsigned long long>());
+  KCHK();
+  unsigned long long r[2];
+  HIPCHK(hipMemcpyAsync(r, res.p, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  pfd_seg_end(h, 1);
+  if (r[1] != 0 || r[0] >= (1ull << 31)) return PFD_OK;
+  int complete = 0;
+  PFDCHK(pfd_upstream_area_cell_tiled(h, out_dev, &complete, data_dev));
+  if (!complete) return PFD_OK;  // cycles: the level engine keeps the reference's semantics for them
+  k_restore_invalid<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, data_dev, h->geo.n, out_dev);
+  KCHK();
+  *used = 1;
+  return PFD_OK;
+}
+
 // by_row: `data` holds one value per raster row (always a HOST pointer: nrow elements)
 template <class T>
 static int accuflux_t(pfd_raster *h, const void *data, bool by_row, T nodata, int has_nodata, int direction,
@@ -874,6 +941,18 @@ static int accuflux_t(pfd_raster *h, const void *data, bool by_row, T nodata, in
     PFDCHK(d.bind(data, (size_t)h->n * sizeof(T), memspace, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(T), memspace));
+  if (std::is_same<T, i32>::value && direction == PFD_UP && !by_row) {  // tiled engine where provably equivalent
+    int used = 0;
+    PFDCHK(accuflux_i32_tiled(h, (const i32 *)d.dev, (i32)nodata, has_nodata, (i32 *)o.dev, &used));
+    if (used) {
+      if (mask_invalid) {
+        k_mask_invalid<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, (T *)o.dev, nodata);
+        KCHK();
+      }
+      return o.finish(h->stream);
+    }
+  }
+  PFDCHK(pfd_order_cells_impl(h));
   pfd_seg_begin(h, "init");
   if (by_row) {
     k_fill_rows<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((const T *)d.dev, h->geo, (T *)o.dev);
@@ -914,7 +993,6 @@ static int accuflux_impl(pfd_raster *h, int dtype, const void *data, bool by_row
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  PFDCHK(pfd_order_cells_impl(h));
   switch (dtype) {
     case PFD_I32:
       return accuflux_t<i32>(h, data, by_row, (i32)nodata_i, has_nodata, direction, mask_invalid, out, memspace);

@@ -84,6 +84,7 @@ struct TileArgs {
   u64 ntot;        // nrow * ncol
   u32 *hcnt;       // [nht] super-exit counters of the hypertiles, cleared by the local pass
   u32 nht;
+  const i32 *weights;  // [n] integer payload to accumulate (accuflux), nullptr = unit weights
   u32 nrow, ncol, ntr, ntc;
   u32 row_first, row_last;  // owned rows (inclusive) of the device raster; the rest are halo rows
   u32 nstc;        // supertiles per row; slot ids are supertile-major (sslot_base)

@@ -148,6 +148,8 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       const int lr = l0 >> 6, lc0 = l0 & 63;
       const u32 c4 = FINAL ? cq[j] : *(const u32 *)&CODE(lr, lc0);
       u32 w4[4], p4[4];
+      // integer accuflux: the payload instead of unit weights (clamped address, masked by the code)
+      const i64 wrow = (i64)min((i64)(r0 + lr), (i64)a.nrow - 1) * (i64)a.ncol;
       u32 n4 = 0;  // RAW: the normalised codes of the quad
       const bool halorow = (i64)r0 + lr < (i64)a.row_first || (i64)r0 + lr > (i64)a.row_last;
 #pragma unroll
@@ -174,7 +176,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
         const bool go = isdir && (unsigned)nr < TS && (unsigned)nc < TS;
         // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
         p4[s] = go ? PHYS((u32)(nr * TS + nc)) : (l | PDONE);
-        w4[s] = (c != D8_MV && c != D8_HALO) ? 1u : 0u;
+        u32 wv = 1u;
+        if (a.weights != nullptr) wv = (u32)a.weights[wrow + min((i64)(c0 + lc0) + (i64)b, (i64)a.ncol - 1)];
+        w4[s] = (c != D8_MV && c != D8_HALO) ? wv : 0u;
       }
       *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
       *(uint2 *)&P[l0] = make_uint2(p4[0] | (p4[1] << 16), p4[2] | (p4[3] << 16));
@@ -903,7 +907,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   haloL = b + 2 * nb;
   brow_sink = b + 3 * nb;
   brow_inflow = b + 4 * nb;
-  a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, hcntbuf.as<u32>(), nht, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
+  a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, hcntbuf.as<u32>(), nht, nullptr, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
@@ -1120,11 +1124,14 @@ int TiledRun::phase_a_checked() {
 }
 
 // returns PFD_OK and *complete = 1 when every valid cell was finalised (no cycles)
-int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete) {
+// `weights` (optional): integer payload accumulated instead of unit weights (int32 wrap like the
+// reference's int32 accuflux; the caller guarantees that the nodata rule cannot interfere)
+int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete, const i32 *weights) {
   *complete = 0;
   TiledRun run;
   PFDCHK(run.init(h, out_dev));
   if (!run.supported) return PFD_OK;
+  run.a.weights = weights;
   PFDCHK(run.phase_a());
   PFDCHK(run.phase_b(complete));
   for (int tries = 0; tries < 3 && (run.overflowed || (run.short_of_rounds && tries < 2)); ++tries) {

@@ -60,6 +60,8 @@ def test_random_rasters(gpu_lib, oracle, seed):
     assert np.array_equal(flw.accuflux(w.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, w))
     assert np.array_equal(flw.accuflux(w.reshape(shape), direction="down").ravel(),
                           O.accuflux(idxs_ds, seq, w, direction="down"))
+    wi32 = rng.integers(0, 1000, n).astype(np.int32)  # tiled engine if the raster is acyclic
+    assert np.array_equal(flw.accuflux(wi32.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wi32))
     wi = rng.integers(-5, 1000, n).astype(np.int64)
     assert np.array_equal(flw.accuflux(wi.reshape(shape), nodata=-3).ravel(), O.accuflux(idxs_ds, seq, wi, nodata=-3))
     mask = rng.random(n) < 0.6

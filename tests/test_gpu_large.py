@@ -51,6 +51,22 @@ def test_vs_oracle(gpu_lib, oracle, shape, seed, kw):
     hand = flw.hand(drain, elev)
     assert np.array_equal(hand.ravel(), O.height_above_nearest_drain(idxs_ds, seq, drain.ravel(), elev.ravel()))
     assert np.array_equal(flw.rank.ravel(), O.rank(idxs_ds)[0])
+    # int32 payloads: the tiled engine where the nodata rule provably cannot interfere, else the level engine
+    flw._h.set_profiling(True)
+    wi = (w * 1000).astype(np.int32)
+    assert np.array_equal(flw.accuflux(wi.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wi))
+    assert any(s["name"] == "tile_local" for s in flw._h.last_timing())       # non-negative, no nodata hit: tiled
+    wneg = wi - 300
+    assert np.array_equal(flw.accuflux(wneg.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wneg))
+    assert not any(s["name"] == "tile_local" for s in flw._h.last_timing())   # negative values: level engine
+    wbig = np.full(d8.size, 2000, np.int32)                                   # total >= 2^31: int32 wrap, level engine
+    assert np.array_equal(flw.accuflux(wbig.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wbig))
+    wnd = wi.copy()
+    wnd[::13] = -9999                                                          # nodata inside the domain: level engine
+    assert np.array_equal(flw.accuflux(wnd.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wnd))
+    wu = wi.astype(np.uint32)                                                  # unsigned view, nodata can never match
+    assert np.array_equal(flw.accuflux(wu.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wu))
+    flw._h.set_profiling(False)
     # SURVEY 8(f)-1 functions
     main = O.main_upstream(idxs_ds, upa_o.ravel())
     assert np.array_equal(flw.idxs_us_main, main)

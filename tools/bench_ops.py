@@ -39,6 +39,11 @@ print(f"{'order_cells':22s} {1e3*(t1-t0):10.2f} ms  {n/(t1-t0)/1e6:10.1f} Mcells
 w = _hip.synth_weights_device(n, seed=1)
 timed("accuflux f32 (up)", lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out4, memspace=_hip.PFD_DEVICE))
 timed("accuflux f32 (down)", lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, direction=_hip.PFD_DOWN, out=out4, memspace=_hip.PFD_DEVICE))
+wi = _hip.DeviceBuffer(n * 4)
+wi.upload(np.random.default_rng(0).integers(0, 20, n, dtype=np.int32)) if n <= 200_000_000 else None
+if n <= 200_000_000:
+    timed("accuflux i32 (up, tiled)", lambda: h.accuflux(wi, _hip.PFD_I32, nodata_i=-9999, out=out4, memspace=_hip.PFD_DEVICE))
+del wi
 out1 = _hip.DeviceBuffer(n)
 timed("strahler", lambda: h.strahler(None, out=out1, memspace=_hip.PFD_DEVICE))
 # basins from 1000 outlets: the pits + evenly spread cells (ids 1..k)
