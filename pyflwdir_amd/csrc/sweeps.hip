@@ -175,8 +175,9 @@ static int run_up(pfd_raster *h, const Op &op, const char *name) {
   PFDCHK(pfd_ensure_seq_aux(h));
   pfd_seg_begin(h, name);
   i64 launches = 0;
-  // (3 levels per launch are implemented but measured slower than 2: 35 vs 28 ms for 10003 levels —
-  //  the third hop squares the divergent fan-out)
+  // (3 levels per launch are implemented but measured slower than 2: 35 vs 28 ms for 10003 levels with
+  //  nested lookups — the third hop squares the divergent fan-out — and 58 vs 25 ms with a 7x7 register
+  //  window, which spills: 100 loads per thread are too many registers)
   int maxk = getenv("PFD_SINGLE_HOP") ? 1 : 2;
   if (const char *e = getenv("PFD_UP_K")) maxk = std::max(1, std::min(3, atoi(e)));
   for (i64 l = h->n_levels - 1; l >= 0;) {
