@@ -384,8 +384,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     if (tr == 0) a.esink[(size_t)tc * PSL + tid] = esink;
     if (tr == a.ntr - 1 && a.ntr > 1) a.esink[((size_t)a.ntc + tc) * PSL + tid] = esink;
   }
-  // row-block bookkeeping: flow collected by the halo sinks, first hop of the boundary rows
-  if (a.row_first > 0 || a.row_last + 1 < a.nrow) {
+  // row-block bookkeeping: flow collected by the halo sinks, first hop of the boundary rows — only the
+  // tiles that hold a halo row or a boundary row of the block have any
+  if ((a.row_first > 0 && (u32)r0 <= a.row_first) || (a.row_last + 1 < a.nrow && (u32)r0 + TS > a.row_last)) {
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
       const u32 l = tid + 256u * j;
