@@ -36,6 +36,22 @@ def test_engines_agree_at_scale(gpu_lib, kw):
     assert np.all(rank[pits] == 0) and np.all(rank[~valid] == -9999)
     nonpit = valid & (idxs_ds != np.arange(n, dtype=np.int32))
     assert np.all(rank[nonpit] == rank[idxs_ds[nonpit]] + 1)
+    # deferred handle: decode / validation / counts fused into the first tile pass
+    hd = _hip.RasterHandle(d8, nrow, ncol, device=0, memspace=_hip.PFD_DEVICE, deferred=True)
+    assert np.array_equal(hd.upstream_area_cell(), tiled)
+    assert hd.info()["n_valid"] == info["n_valid"] and hd.info()["n_pits"] == info["n_pits"]
+    hd.close()
+    # int32 payload on the tiled engine == the level engine (PFD_ACCUFLUX_LEVELS forces the latter)
+    import os
+
+    w = ((np.arange(n, dtype=np.int64) * 2654435761) % 7).astype(np.int32)
+    acc_tiled = h.accuflux(w, _hip.PFD_I32, nodata_i=-9999)
+    os.environ["PFD_ACCUFLUX_LEVELS"] = "1"
+    try:
+        acc_levels = h.accuflux(w, _hip.PFD_I32, nodata_i=-9999)
+    finally:
+        del os.environ["PFD_ACCUFLUX_LEVELS"]
+    assert np.array_equal(acc_tiled, acc_levels)
     h.close()
     # row blocks (multi-GPU protocol, in-process): 3 blocks of the same raster
     from pyflwdir_amd import dist
