@@ -1,3 +1,7 @@
+"""Timing of float32 accuflux (up) on a synthetic raster, first call and warm calls, with the phase
+segments (set PFD_CHAIN_UP=1 for the experimental chain sweep).
+
+    python tools/accuflux_probe.py NROW [NCOL [nodata_pct [tilt]]]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
