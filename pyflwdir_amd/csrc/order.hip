@@ -43,8 +43,10 @@ __global__ void __launch_bounds__(256) k_normalise(const u8 *__restrict__ d8, Ge
   const u32 c0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
   const size_t n = (size_t)g.nrow * g.ncol;
   u32 valid = 0, pit = 0, bad = 0;
+  // (grid.y is capped at 65535: taller rasters loop over bands of 16 rows)
+  for (u32 band = blockIdx.y; band * 16u < g.nrow; band += gridDim.y)
   for (u32 pass = 0; pass < 4; ++pass) {
-    const u32 r = blockIdx.y * 16 + pass * 4 + (threadIdx.x >> 6);
+    const u32 r = band * 16 + pass * 4 + (threadIdx.x >> 6);
     if (r >= g.nrow || c0 >= g.ncol) continue;
     // windows: byte k of win[j] = column c0 - 1 + k of row r - 1 + j
     const u32 cstart = c0 ? c0 - 1 : 0;
@@ -227,12 +229,8 @@ static int alloc_pits(pfd_raster *h) {
 }
 
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
-  if (cdiv_u32((u64)h->nrow, 16) > 65535u) {
-    pfd_set_error("rasters with more than %d rows per handle are not supported", 65535 * 16);
-    return PFD_EUNSUPPORTED;
-  }
   HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
-  const u32 gy = cdiv_u32((u64)h->nrow, 16);
+  const u32 gy = std::min<u32>(cdiv_u32((u64)h->nrow, 16), 65535u);
   dim3 grid(cdiv_u32((u64)h->ncol, 256), gy);
   k_normalise<<<grid, 256, 0, h->stream>>>(d8_dev, h->geo, h->ncode, h->ctrl, (u32)h->halo_top,
                                            (u32)(h->halo_top + h->own_rows - 1));
