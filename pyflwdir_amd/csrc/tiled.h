@@ -57,6 +57,7 @@ struct SuperArgs {
   u32 *hcnt;        // [nht] super-exits per hypertile (hmode 1: ids = ht*HCAP + rank)
   int hmode;        // 1: per-hypertile ids (level 3 solved in LDS), 0: one flat id range
   int bonly;        // final pass over the flow entering from other row blocks only (xT ignored)
+  u32 edge_nstr;    // final pass: != 0 -> only the first and last of the edge_nstr supertile rows deliver
   u32 ntr, ntc;     // tiles per column / row (slots of tiles beyond them do not exist)
   u32 hcap;         // super-exits per hypertile that fit in LDS (HCAP; lowered by tests via PFD_TEST_HCAP)
 };
@@ -74,6 +75,7 @@ struct HyperArgs {
   u32 *hx_node;     // [nhyper] node of the hyper-exit
   u32 *T4;          // [nhyper] level-4 start value
   u64 *ctrl;
+  u32 edge_nstr, nhtc;  // final pass: != 0 -> only the hypertile rows that feed the edge supertile rows
 };
 
 struct TileArgs {
@@ -197,8 +199,9 @@ struct TiledRun {
   u32 *brow_first = nullptr, *haloA = nullptr, *haloL = nullptr, *brow_sink = nullptr, *brow_inflow = nullptr;
   u32 *Tc = nullptr, *Tn = nullptr, *Jc = nullptr, *Jn = nullptr, *xin3 = nullptr, *R3 = nullptr, *hx_id = nullptr;
   size_t n3cap = 0, n4cap = 0;
-  u32 *W2 = nullptr, *J4fin = nullptr;
-  int solve_exits(const u32 *start, i64 *launches, bool cleared = false);
+  u32 *J4fin = nullptr;
+  int solve_exits(const u32 *start, i64 *launches, bool cleared = false, bool edge_down = false);
+  bool edge_down_now = false;
   int level3_flat(i64 *launches);
   int level3_hyper(i64 *launches);
   TileArgs a{};

@@ -467,6 +467,12 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
   const u32 st = blockIdx.x;
   const u32 base = st << SSHIFT;
   constexpr int SPT = SSL / 1024;  // slots per thread
+  if (FINAL && s.edge_nstr) {
+    // row blocks, first solve: only the deliveries into the first and last TILE row are needed yet; they
+    // come from exits in tile rows 0..1 and ntr-2..ntr-1 -> supertile row 0 and the rows of those two
+    const u32 row = st / s.nstc;
+    if (row != 0 && row != (s.ntr - 1) / SG && row != (s.ntr >= 2 ? (s.ntr - 2) / SG : 0u)) return;
+  }
   if (tid == 0) s_cnt = 0;
   u32 tg[SPT];
   u32 y[SPT];
@@ -613,6 +619,11 @@ __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
   const u32 ht = blockIdx.x;
   const u32 base = ht * HCAP;
   if (s.ctrl[T_OVERFLOW]) return;  // (uniform) ids are invalid: the host redoes the pass flat
+  if (FINAL && s.edge_nstr) {
+    // hypertile rows holding the supertile rows that feed those edge rows: 0..1 and the last three
+    const u32 hr = ht / s.nhtc, n_ = s.edge_nstr;
+    if (hr != 0 && hr < (n_ >= 3 ? (n_ - 3) / HG : 0u)) return;
+  }
   const u32 n = s.hcnt[ht];
   constexpr int SPT = HCAP / 1024;
   if (tid == 0) s_cnt = 0;
@@ -887,7 +898,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   const size_t sxcap = (size_t)nst * 4 * SG * TS;  // super-exits sit on the supertile perimeter
   n3cap = std::max(sxcap, (size_t)nht * HCAP);
   n4cap = (size_t)nht * 4 * HG * SG * TS;           // hyper-exits sit on the hypertile perimeter
-  PFDCHK(slots.alloc(9 * nslots * sizeof(u32)));
+  PFDCHK(slots.alloc(8 * nslots * sizeof(u32)));
   PFDCHK(l3.alloc(8 * n3cap * sizeof(u32)));
   PFDCHK(l4.alloc(6 * n4cap * sizeof(u32)));
   PFDCHK(hcntbuf.alloc((size_t)nht * sizeof(u32)));
@@ -897,7 +908,6 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   xtgt = q, elink = q + nslots, sxid = q + 2 * nslots;              // 0xFF-initialised
   xT = q + 3 * nslots, inflow = q + 4 * nslots, xin = q + 5 * nslots;  // zero-initialised
   T2 = q + 6 * nslots, R2 = q + 7 * nslots;                          // written before read
-  W2 = q + 8 * nslots;                                                // start values of the second solve (row blocks)
   u32 *x = l3.as<u32>();
   sx_slot = x;
   Tc = x + n3cap, Tn = x + 2 * n3cap, Jc = x + 3 * n3cap, Jn = x + 4 * n3cap;
@@ -912,7 +922,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
-                 hcntbuf.as<u32>(), 0, 0, ntr, ntc, HCAP};
+                 hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP};
   if (const char *e = getenv("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
   is_block = h->halo_top || h->halo_bot;
@@ -948,7 +958,8 @@ int TiledRun::level3_hyper(i64 *launches) {
   u32 *hx_node = y, *T4c = y + n4cap, *J4c = y + 3 * n4cap;
   u32 *T4[3] = {y + n4cap, y + 2 * n4cap, y + 5 * n4cap}, *J4[2] = {y + 3 * n4cap, y + 4 * n4cap};
   k_link3<<<g3, 256, 0, h->stream>>>(sa, n3, J3, xin3);
-  HyperArgs ha{nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl};
+  HyperArgs ha{nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl,
+               edge_down_now ? cdiv_u32(ntr, SG) : 0u, nhtc};
   k_hyper<false><<<nht, 1024, 0, h->stream>>>(ha);
   KCHK();
   *launches += 2;
@@ -979,7 +990,11 @@ int TiledRun::level3_hyper(i64 *launches) {
 // all exits, delivered (added) to the tile entries they drain into
 // (cleared: the hypertile counters and the ctrl words of the solve are zero already — first solve of a
 //  pass: the ctrl memset of phase_a and the local tile pass have done it)
-int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared) {
+// (edge_down: row blocks, first solve — the deliveries of the down-pass are only needed in the first
+//  and last supertile row yet, where the halo sinks collect them; the second solve delivers everything)
+int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool edge_down) {
+  edge_down_now = edge_down;
+  sa.edge_nstr = edge_down ? cdiv_u32(ntr, SG) : 0u;
   if (!cleared) {
     HIPCHK(hipMemsetAsync(hcntbuf.p, 0, (size_t)nht * sizeof(u32), h->stream));
     HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, 3 * sizeof(u64), h->stream));  // T_XACTIVE, T_NSUPER, T_NHYPER
@@ -1042,7 +1057,7 @@ int TiledRun::phase_a() {
 
   pfd_seg_begin(h, "exit_graph");
   i64 launches = 0;
-  PFDCHK(solve_exits(xT, &launches, true));
+  PFDCHK(solve_exits(xT, &launches, true, is_block));
   if (is_block) {  // what leaves through the halo rows, and where boundary-row inflow would leave
     HIPCHK(hipMemcpyAsync(haloL, haloA, nb * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
     const u32 ne = (ntr > 1 ? 2u : 1u) * ntc * PSL;
@@ -1064,13 +1079,22 @@ int TiledRun::phase_b(int *complete) {
   const size_t nb = 2 * (size_t)h->ncol;
   if (is_block) {
     // The flow entering from the other row blocks is one more set of start values on the same exit
-    // graph: solve it once more (the solve is linear) — its totals are ADDED to the tile entries.
+    // graph (added to the local counts of the exits it reaches first): the graph is solved once more,
+    // now with the full down-pass.  The first solve delivered to the edge supertile rows only (that
+    // is all the halo sinks needed); those deliveries are cleared and made again.
     pfd_seg_begin(h, "block_inflow");
-    i64 launches = 2;
-    HIPCHK(hipMemsetAsync(W2, 0, nslots * sizeof(u32), h->stream));
-    k_brow_scatter<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, W2);
+    i64 launches = 3;
+    k_brow_scatter<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, xT);
     KCHK();
-    PFDCHK(solve_exits(W2, &launches));
+    const u32 nstr = cdiv_u32(ntr, SG);
+    const size_t rowslots = (size_t)nstc * SSL;
+    // (an exit of an edge row may drain into the neighbouring supertile row: rows 0-1 and n-2..n-1)
+    // (deliveries of the first solve: by supertile row 0 and the rows of the last two tile rows, each
+    //  into itself or a neighbouring row)
+    const u32 top = std::min<u32>(2u, nstr), bot = nstr > 2 ? std::min<u32>(3u, nstr - 2) : 0u;
+    HIPCHK(hipMemsetAsync(inflow, 0, (size_t)top * rowslots * sizeof(u32), h->stream));
+    if (bot) HIPCHK(hipMemsetAsync(inflow + (size_t)(nstr - bot) * rowslots, 0, (size_t)bot * rowslots * sizeof(u32), h->stream));
+    PFDCHK(solve_exits(xT, &launches));
     pfd_seg_end(h, launches);
   }
   const dim3 grid(ntc, ntr);

@@ -75,3 +75,18 @@ def test_split_phase_api(gpu_lib, oracle):
         assert _hip.upstream_area_cell_finish(h, allrec, nb, b)
     got = np.concatenate([o.reshape(-1, d8.shape[1]) for o in outs])
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("rows_per_block,nblocks", [(2100, 2), (1050, 4), (513, 3), (1024, 2), (577, 5), (4100, 2)])
+def test_blocks_supertile_edge_geometries(gpu_lib, oracle, rows_per_block, nblocks):
+    """The first exit-graph solve of a block delivers only where the halo sinks need it (supertile rows
+    of tile rows 0-1 and ntr-2..ntr-1).  Geometries where the last supertile row holds one or two tile
+    rows, where a block spans 2..9 supertile rows, and where flow weaves across the block border."""
+    from pyflwdir_amd import dist
+
+    nrow, ncol = rows_per_block * nblocks, 700
+    for kw in (dict(tilt=1 << 26, white=2, nodata_pct=0), dict(tilt=100000, white=2, nodata_pct=15)):
+        d8 = oracle.synth_d8(nrow, ncol, seed=21, **kw)
+        exp, _, _ = oracle.upstream_area_cell(d8)
+        assert np.array_equal(dist.upstream_area_blocks(d8, nblocks), exp)
+        assert np.array_equal(dist.upstream_area_blocks(d8, nblocks, deferred=True), exp)
