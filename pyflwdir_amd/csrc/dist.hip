@@ -131,7 +131,7 @@ static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u3
   pfd_raster *h = run.h;
   const u32 ncol = (u32)h->ncol;
   const u32 nn = nblocks * 2 * ncol;
-  DevBuf buf;
+  DevBuf &buf = run.iface_buf;  // (lives as long as the run: no synchronisation needed before returning)
   PFDCHK(buf.alloc(5 * (size_t)nn * sizeof(u32)));
   u32 *T[3] = {buf.as<u32>(), buf.as<u32>() + nn, buf.as<u32>() + 2 * (size_t)nn};
   u32 *J[2] = {buf.as<u32>() + 3 * (size_t)nn, buf.as<u32>() + 4 * (size_t)nn};
@@ -146,7 +146,6 @@ static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u3
   PFDCHK(pfd_doubling_rounds(h, T, J, nn, 4, true, &done, &rounds, &launches));
   k_iface_inflow<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(T[0], nblocks, ncol, blk, run.brow_inflow);
   KCHK();
-  HIPCHK(hipStreamSynchronize(h->stream));
   pfd_seg_end(h, launches + 1);
   if (!done) run.coarse_done = false;  // a cycle through several blocks
   return PFD_OK;

@@ -189,7 +189,7 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (8 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf, tcntbuf;
+  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;
