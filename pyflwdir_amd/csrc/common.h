@@ -139,6 +139,7 @@ struct pfd_raster {
   u8 *cell_kids = nullptr;                     // per CELL: mask of draining neighbours (same allocation)
   u64 *seq_kids2 = nullptr;                    // per ordered cell: the child masks of its upstream cells (owns the allocation)
   // heavy-chain layout for exact up-sweeps at chain speed (paths.hip: pfd_ensure_chains)
+  int acyclic = 0;               // 0 unknown, 1 every valid cell reaches a pit, -1 the raster holds cycles
   int chains_state = 0;          // 0 not built, 1 ready, -1 not available (cycles / raster too large)
   u32 *chain_seq = nullptr;      // [n_chain] cells, chain after chain (upstream end first), chains in dependency order
   u32 *chain_pos = nullptr;      // [n] position of a cell in chain_seq, 0xFFFFFFFF if it is in no chain

@@ -263,6 +263,7 @@ int pfd_adopt_counts(pfd_raster *h, const u64 *c) {
     return PFD_ENOPITS;
   }
   h->ordered = false;
+  h->acyclic = 0;
   pfd_free_chains(h);
   h->aux_ready = false;
   h->pits_ready = false;  // the ascending pit list is compacted on first use
@@ -344,6 +345,7 @@ extern "C" int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k) {
   HIPCHK(hipStreamSynchronize(h->stream));
   h->n_pits = (i64)c[C_NPITS];
   h->ordered = false;
+  h->acyclic = 0;
   pfd_free_chains(h);
   h->aux_ready = false;
   h->n_seq = h->n_levels = -1;

@@ -374,6 +374,7 @@ int pfd_order_cells_by_rank(pfd_raster *h, int *ok) {
   int complete = 0;
   u32 maxrank = 0;
   PFDCHK(run_paths<MODE_RANK>(h, nullptr, keys.as<u32>(), &complete, &maxrank));
+  h->acyclic = complete ? 1 : -1;  // (too large for the slot ids also lands here: the level engine serves it)
   if (!complete) return PFD_OK;  // cycles (or raster too large for the slot ids): breadth-first build instead
   PFDCHK(keys2.alloc((size_t)n * sizeof(u32)));
   PFDCHK(vals.alloc((size_t)n * sizeof(u32)));
@@ -437,6 +438,20 @@ int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32
   DevBuf seed, num;
   PFDCHK(seed.alloc((size_t)n * sizeof(u32) + 64));  // + slack: quads are loaded 16 bytes at a time
   PFDCHK(num.alloc((size_t)n * sizeof(u32)));
+  // The label query stops at the first outlet, so an outlet on (or downstream of) a cycle would hide the
+  // cycle and label cells that never reach a pit — cells the reference never visits (they are not in
+  // idxs_seq; found by the randomised stress test).  The tiled path is only taken on rasters known to
+  // be acyclic; the rank query answers that once per handle.
+  if (h->acyclic == 0) {
+    DevBuf rk;
+    PFDCHK(rk.alloc((size_t)n * sizeof(u32)));
+    int ok_rank = 0;
+    pfd_seg_begin(h, "tile_rank_check");
+    PFDCHK(run_paths<MODE_RANK>(h, nullptr, rk.as<u32>(), &ok_rank, nullptr));
+    pfd_seg_end(h, 2);
+    h->acyclic = ok_rank ? 1 : -1;
+  }
+  if (h->acyclic < 0) return PFD_OK;
   HIPCHK(hipMemsetAsync(seed.p, 0, (size_t)n * sizeof(u32), h->stream));
   if (k) {
     k_seed_numbers<<<cdiv_u32(k, 256), 256, 0, h->stream>>>(idx_dev, k, seed.as<u32>());

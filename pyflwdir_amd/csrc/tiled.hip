@@ -1170,5 +1170,6 @@ int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete, con
     PFDCHK(run.phase_a());
     PFDCHK(run.phase_b(complete));
   }
+  if (*complete && !run.is_block) h->acyclic = 1;  // every valid cell was finalised: no cycles
   return PFD_OK;
 }

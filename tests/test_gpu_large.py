@@ -161,3 +161,37 @@ def test_experimental_chain_sweep(gpu_lib, oracle, monkeypatch):
         wi = (w * 1000).astype(np.int32)
         assert np.array_equal(flw.accuflux(wi.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wi))
         assert np.array_equal(flw.upstream_area("km2"), flw.upstream_area("km2"))
+
+
+def test_basins_outlet_on_a_cycle(gpu_lib, oracle):
+    """An outlet seeded on (or downstream of) a cycle: the cells draining into it never reach a pit, the
+    reference never visits them (they are not in idxs_seq) and they keep label 0 — the tiled label query
+    alone would stop at the outlet and label them (found by tools/stress_fuzz.py)."""
+    import pyflwdir_amd as pyflwdir
+
+    d8 = np.array([[4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 8, 4],
+                   [4, 2, 1, 4, 4, 4, 1, 255, 4, 32, 4, 128],
+                   [4, 4, 1, 4, 4, 4, 4, 4, 4, 4, 64, 4],
+                   [4, 4, 1, 4, 4, 4, 4, 32, 4, 8, 4, 4],
+                   [2, 4, 4, 4, 4, 4, 4, 32, 4, 4, 4, 4]], np.uint8)
+    idxs_ds, idxs_pit, _ = oracle.from_array(d8)
+    seq = oracle.idxs_seq(idxs_ds, idxs_pit)
+    assert (oracle.rank(idxs_ds)[0] == -1).any()  # the raster holds a cycle (cells 22, 34)
+    oidx = np.array([5, 6, 7, 19, 20, 21, 32, 34, 35, 36, 37, 39, 40, 41, 50, 52, 54])
+    oids = (np.arange(oidx.size) + 5).astype(np.uint16)
+    exp = oracle.basins(idxs_ds, oidx.astype(idxs_ds.dtype), seq, oids)
+    for first in ("basins", "uparea"):  # with and without an earlier operation that already knows about the cycle
+        flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+        if first == "uparea":
+            flw.upstream_area()
+        assert np.array_equal(flw.basins(idxs=oidx, ids=oids).ravel(), exp)
+    # a larger raster: synthetic rivers with injected cycles and outlets on them
+    d8 = oracle.synth_d8(300, 400, seed=31, tilt=1 << 26, white=2, nodata_pct=5)
+    d8[100, 100], d8[100, 101] = 1, 16
+    d8[200, 50], d8[201, 51], d8[201, 50] = 2, 16, 64
+    idxs_ds, idxs_pit, _ = oracle.from_array(d8)
+    seq = oracle.idxs_seq(idxs_ds, idxs_pit)
+    oidx = np.array([100 * 400 + 101, 201 * 400 + 50, 50 * 400 + 7, 299 * 400 + 3])
+    oids = np.array([3, 4, 5, 6], np.uint32)
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    assert np.array_equal(flw.basins(idxs=oidx, ids=oids).ravel(), oracle.basins(idxs_ds, oidx.astype(idxs_ds.dtype), seq, oids))
