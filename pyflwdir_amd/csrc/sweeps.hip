@@ -130,7 +130,7 @@ __device__ __forceinline__ constexpr int slot_desc(int q) {  // slots in descend
 
 // launches covering several levels are only used while they stay small (latency-bound regime)
 static const u32 MULTIHOP_MAX_CELLS = 1u << 20;     // down-sweeps (a chain of single loads per thread)
-static const u32 MULTIHOP_MAX_CELLS_UP = 1u << 16;  // up-sweeps (the window form loads ~50 values per thread)
+static const u32 MULTIHOP_MAX_CELLS_UP = 1u << 18;  // up-sweeps (the window form loads ~50 values per thread)
 
 // ---- up-sweeps --------------------------------------------------------------------------------
 // Op: V leaf(nb) = final value of an upstream cell; V combine(x, kids, child) = value of x given
