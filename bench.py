@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark: Mcells/s of FlwdirRaster.upstream_area("cell") on a synthetic
-D8 raster (BASELINE.json configs[1]: 10000 x 10000, 1 MI355X), with the HBM-roofline fraction of
-the dominant kernel and the single-thread CPU baseline (the oracle restatement of the
-reference's serial algorithm) timed on the same host.
+"""bench.py — headline benchmark: Mcells/s of FlwdirRaster.upstream_area("cell") on the synthetic
+90000 x 90000 D8 raster of BASELINE.json configs[3] (8.1 Gcells; it fits one 288 GB MI355X), with the
+HBM-roofline fraction of the dominant kernel and of the whole pass, the graph statistics SURVEY.md §8d
+asks for, and the single-thread CPU baseline (the oracle restatement of the reference's serial
+algorithm) timed on the same host on a bounded sample of the same raster.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--regime river|rough|meander]
+                    [--no-cpu-baseline] [--no-secondary]
 
-A "step" is one complete pass of the hot path on one raster: device-resident uint8 D8 codes in
--> device-resident int32 upstream cell counts out, INCLUDING the decode/normalisation of the
-raster and the construction of whatever ordering structure the kernels need (a fresh raster
-handle is created every step; nothing is cached between steps).  Inputs are generated in HBM
-by the device twin of the oracle's synthetic generator and are resident before the timed
-region starts; the result stays in HBM.
+A "step" is one complete pass of the hot path over the raster: device-resident uint8 D8 codes in ->
+device-resident int32 upstream cell counts out, INCLUDING the decode / pit rule / validation of the
+raster and every structure the kernels need (a fresh raster handle per step; nothing is cached
+between steps).  Inputs are generated in HBM by the device twin of the oracle's synthetic generator
+before the timed region; the result stays in HBM.
 
 N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
-the raster is row-tiled over the N GPUs (weak scaling: every rank owns `size` rows); see
-DESIGN.md §Multi-GPU.  torch.distributed is used only for rendezvous/barrier/max-reduce.
+STRONG scaling — the same size x size raster is split into N row blocks (size/N rows each + one halo
+row per inner edge), one block per rank/GPU, one RCCL all-gather of the boundary records per pass
+(DESIGN.md §4.4).  torch.distributed (gloo) is only used for the barrier and the max-reduce of the
+wall time.
+
+With N = 1 the JSON line also carries `secondary`: the 10000 x 10000 pass (configs[1]) and the
+configs[2] operations (float32 accuflux + Strahler order at 30000 x 30000), each with its own
+roofline object.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,40 +41,49 @@ sys.path.insert(0, ROOT)
 from pyflwdir_amd import _hip  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# algorithmic bytes per cell of upstream_area("cell"): 29 B/cell in total,
-# split over the phases of the level engine as documented in DESIGN.md §Roofline
-B_ALG_TOTAL = 29.0
-B_ALG_PHASE = {"order_cells": 8.0, "init": 4.0, "sweep_count_up": 17.0,
-               "tile_local": 8.0, "exit_graph": 4.0, "tile_final": 17.0}
+# algorithmic bytes per cell; the split of the 29 B of upstream_area("cell") over the
+# phases that replace build / init / sweep is documented in DESIGN.md §5
+B_ALG = {"upstream_area_cell": 29.0, "accuflux_f32": 33.0, "strahler": 18.0, "basins_u32": 18.0, "hand_f32": 35.0}
+B_ALG_PHASE = {"tile_local": 8.0, "exit_graph": 4.0, "tile_final": 17.0}
 # segment -> the kernel it times (names as rocprofv3 prints them); single-launch segments only
-KERNEL_OF = {"tile_local": "void k_tile<false, true>(TileArgs)", "tile_final": "void k_tile<true, false>(TileArgs)",
-             "order_cells": "k_bfs_level(...)", "sweep_count_up": "void k_sweep<CountUp>(...)"}
-# HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3
-# --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of this same command, 10000 x 10000):
-# bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024, raw counter values (calibration in DESIGN.md)
-PMC_TRAFFIC = {("void k_tile<true, false>(TileArgs)", 10000): (147178.969 + 390625.000) * 1024,  # profiles/r01g_*
-               ("void k_tile<false, true>(TileArgs)", 10000): (176827.453 + 221867.906) * 1024}
+KERNEL_OF = {"tile_local": "void k_tile<false, true>(TileArgs)", "tile_final": "void k_tile<true, false>(TileArgs)"}
+# synthetic regimes (oracle/pfd_oracle.c orc_synth_d8 and its device twin): tilt >> noise gives long
+# parallel rivers (max rank ~ nrow), small tilt a rough surface with many pits and meandering paths
+REGIMES = {"river": dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0),
+           "rough": dict(seed=0, tilt=100000, white=2, nodata_pct=0),
+           "meander": dict(seed=0, tilt=3000, white=2, nodata_pct=0)}
 
 
-def roofline_of(segs, n, size, ms_per_step):
-    """Roofline object for the dominant KERNEL (the tile pass that takes longest; multi-launch
-    segments such as the exit graph are reported in phases_ms but are not one kernel)."""
+def measured_traffic(kernel, nrow, ncol):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this command at THIS raster size; tools/prof_pmc.sh
+    writes the table).  None when the size was not measured: never a number from another size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        return None
+    e = tab.get(f"{kernel}|{nrow}x{ncol}")
+    return None if e is None else float(e["bytes_per_launch"])
+
+
+def roofline_upa(segs, n, nrow, ncol, ms_per_step):
+    """Roofline object for the dominant KERNEL of the tiled pass (the tile pass that takes longest;
+    the exit graph is many small launches and is reported in phases_ms) + the whole pass."""
     cand = [s for s in segs if s["name"] in KERNEL_OF] or segs
     dom = max(cand, key=lambda s: s["ms"])
-    b_alg = B_ALG_PHASE.get(dom["name"], B_ALG_TOTAL)
+    b_alg = B_ALG_PHASE.get(dom["name"], B_ALG["upstream_area_cell"])
     launches = max(1, dom["launches"])
     avg_ms = dom["ms"] / launches
     achieved = (b_alg * n / launches) / (avg_ms * 1e-3) / 1e9
     kname = KERNEL_OF.get(dom["name"], dom["name"])
-    traffic = PMC_TRAFFIC.get((kname, size))
-    whole = B_ALG_TOTAL * n / (ms_per_step * 1e-3) / 1e9
+    whole = B_ALG["upstream_area_cell"] * n / (ms_per_step * 1e-3) / 1e9
     return dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                frac=round(achieved / PEAK_HBM_GBS, 5), traffic=traffic, kernel=kname, launches=dom["launches"],
-                avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
-                whole_pass=dict(alg_bytes_per_cell=B_ALG_TOTAL, achieved=round(whole, 2),
+                frac=round(achieved / PEAK_HBM_GBS, 5), traffic=measured_traffic(kname, nrow, ncol), kernel=kname,
+                launches=dom["launches"], avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
+                whole_pass=dict(alg_bytes_per_cell=B_ALG["upstream_area_cell"], achieved=round(whole, 2),
                                 frac=round(whole / PEAK_HBM_GBS, 5)),
                 phases_ms={s["name"]: round(s["ms"], 3) for s in segs})
-SYNTH = dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0)  # "river" regime: max_rank = nrow-1
 
 
 def parse():
@@ -74,8 +91,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=10000, help="raster is size x size per GPU")
+    ap.add_argument("--size", type=int, default=90000, help="the raster is size x size (split over the GPUs)")
+    ap.add_argument("--regime", default="river", choices=sorted(REGIMES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the raster given to the CPU baseline (0=auto)")
     return ap.parse_args()
 
@@ -83,8 +102,7 @@ def parse():
 def one_step(d8_buf, out_buf, nrow, ncol, device, profile=False):
     """One pass of the hot path.  With profile=True the library brackets every phase with HIP
     events on its own stream (6 events per pass) and the phase times are returned."""
-    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE,
-                          deferred=not os.environ.get("PFD_BENCH_EAGER"))  # (eager create: A/B knob)
+    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE, deferred=True)
     if profile:
         h.set_profiling(True)
     h.upstream_area_cell(out=out_buf, memspace=_hip.PFD_DEVICE)
@@ -103,10 +121,27 @@ def mean_segments(all_segs):
     return list(acc.values())
 
 
-def cpu_baseline(d8_host, rows):
+def timed_steps(step, steps, warmup, device):
+    """W untimed steps, then exactly K steps between two device synchronisations.  Every step ends
+    with the library's own stream synchronisation, so the per-step wall times are exact too."""
+    for _ in range(warmup):
+        step(False)
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    marks = [time.perf_counter()]
+    timed = []
+    for _ in range(steps):
+        timed.append(step(True))
+        marks.append(time.perf_counter())
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    total = time.perf_counter() - marks[0]
+    per = [(b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:])]
+    return total, per, timed
+
+
+def cpu_baseline(d8_host, rows, nrow):
     """Single-thread oracle (restatement of the reference's serial pipeline) on a bounded sample:
-    the first `rows` rows of the same raster (a self-contained raster: flow is southwards, the
-    cut edge simply becomes an outlet row)."""
+    the first `rows` rows of the same raster (a self-contained raster: the cut edge simply becomes an
+    outlet row)."""
     from oracle import oracle as O
 
     sample = np.ascontiguousarray(d8_host[:rows])
@@ -114,15 +149,157 @@ def cpu_baseline(d8_host, rows):
     upa, tim, st = O.upstream_area_cell(sample)
     dt = time.perf_counter() - t0
     return dict(value=round(sample.size / dt / 1e6, 3), unit="Mcells/s", cores=1, kind="port",
-                sample=f"first {rows} of {d8_host.shape[0]} rows x {d8_host.shape[1]} cols of the same raster "
+                sample=f"first {rows} of {nrow} rows x {d8_host.shape[1]} cols of the same raster "
                        f"({sample.size / 1e6:.0f} Mcells, {dt:.1f} s; decode {tim['decode_s']:.2f} s, idxs_seq "
                        f"{tim['idxs_seq_s']:.2f} s, accuflux {tim['accuflux_s']:.2f} s)",
                 host_cpus=os.cpu_count()), upa
 
 
+def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, checks=True):
+    """The upstream_area("cell") pass on one GPU: returns the JSON fields of one bench line."""
+    n = nrow * ncol
+    synth = REGIMES[regime]
+    d8_buf = _hip.synth_d8_device(nrow, ncol, device=device, **synth)
+    out_buf = _hip.DeviceBuffer(n * 4, device)
+    total, per, timed = timed_steps(lambda prof: one_step(d8_buf, out_buf, nrow, ncol, device, profile=prof), steps,
+                                    warmup, device)
+    ms_per_step = total / steps * 1e3
+    segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
+    out = dict(value=round(n * steps / total / 1e6, 2), ms_per_step=round(ms_per_step, 3),
+               ms_per_step_median=round(statistics.median(per), 3), ms_per_step_min=round(min(per), 3),
+               roofline=roofline_upa(segs, n, nrow, ncol, ms_per_step))
+    cfg = dict(workload=f"{nrow}x{ncol} synthetic D8 ({regime} regime, seed {synth['seed']}, tilt {synth['tilt']}), "
+                        "upstream_area(unit='cell') int32 on 1 GPU; a step = decode + pit rule + validation + tile "
+                        "pass + exit-graph solve + final tile pass on a fresh handle",
+               n_cells=n, n_valid=info["n_valid"], n_pits=info["n_pits"], parallelism="1 GPU")
+    if checks:
+        # graph statistics (outside the timed region): longest flow path and in-degree histogram
+        h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE, deferred=True)
+        st = h.graph_stats()
+        h.close()
+        cfg.update(max_rank=st["max_rank"], indegree_hist=st["indegree_hist"])
+        # size-independent invariants (reference tests/test_streams_basins.py:24-27): the upstream areas of the
+        # pits add up to the number of valid cells; nodata cells hold -9999; upa == 1 + sum over the upstream cells
+        out["invariants"] = invariants(d8_buf, out_buf, nrow, ncol, info, device)
+    if cpu:
+        rows = cpu_rows or min(nrow, max(1, int(1.2e8 // ncol)))
+        d8_host = d8_buf.download(np.uint8, (rows + 1 if rows < nrow else rows, ncol))
+        base, upa_cpu = cpu_baseline(d8_host, rows, nrow)
+        out["cpu_baseline"] = base
+        # parity of the benchmarked result with the oracle on the sample: flow never runs northwards in the
+        # synthetic regimes' first rows only if every upstream cell lies in the sample — compare the cells whose
+        # upstream area the oracle could see completely (all of them when no cell of the row below drains up)
+        got = out_buf.download(np.int32, (rows, ncol))
+        if rows < nrow:
+            below = d8_host[rows]
+            closed = not np.isin(below, (32, 64, 128)).any()  # no NW / N / NE pointer into the sample
+        else:
+            closed = True
+        out["parity_vs_oracle"] = bool(np.array_equal(got, upa_cpu)) if closed else None
+        out["parity_rows"] = rows
+    d8_buf.free()
+    out_buf.free()
+    _hip.check(_hip.lib().pfd_trim(device))
+    return out, cfg
+
+
+def invariants(d8_buf, out_buf, nrow, ncol, info, device, samples=1_000_000):
+    """Full-size checks that need no oracle (SURVEY.md §8d, C4 checks ii/iii):
+    * device: every cell's local equation upa == 1 + sum over the cells draining into it, -9999 exactly on
+      nodata, the pits' sum == n_valid (reference tests/test_streams_basins.py:24-27) — one streaming kernel
+      that shares nothing with the engines (pfd_verify_upstream_area_cell); on an acyclic raster the
+      equations have one solution, the reference's result;
+    * host (numpy, independent of the device decode): the same equation at ~`samples` random cells."""
+    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE, deferred=True)
+    v = h.verify_upstream_area_cell(out_buf, memspace=_hip.PFD_DEVICE)
+    h.close()
+    res = dict(all_cells_upa_equals_1_plus_children=bool(v["bad_cells"] == 0 and v["n_valid"] == info["n_valid"]),
+               nodata_is_minus_9999=bool(v["bad_nodata"] == 0),
+               pit_sum_equals_n_valid=bool(v["pit_sum"] == info["n_valid"] and v["n_pits"] == info["n_pits"]),
+               result_checksum=v["checksum"])
+    rng = np.random.default_rng(12345)
+    rows = np.unique(rng.integers(0, nrow, size=64))
+    per_row = max(1, samples // len(rows))
+    DR = {1: (0, 1), 2: (1, 1), 4: (1, 0), 8: (1, -1), 16: (0, -1), 32: (-1, -1), 64: (-1, 0), 128: (-1, 1)}
+    ok, checked = True, 0
+    for r in rows:
+        r = int(r)
+        r0, r1 = max(0, r - 1), min(nrow, r + 2)
+        d = d8_buf.download(np.uint8, (r1 - r0, ncol), offset_bytes=r0 * ncol)
+        u = out_buf.download(np.int32, (r1 - r0, ncol), offset_bytes=r0 * ncol * 4)
+        k = r - r0
+        cols = rng.integers(0, ncol, size=min(per_row, ncol))
+        exp = np.ones(cols.size, np.int64)
+        for code, (dr, dc) in DR.items():
+            rr, cc = k - dr, cols - dc  # the neighbour that drains into (k, cols) if it holds `code`
+            if rr < 0 or rr >= d.shape[0]:
+                continue
+            inside = (cc >= 0) & (cc < ncol)
+            ccc = np.clip(cc, 0, ncol - 1)
+            hit = inside & (d[rr, ccc] == code)
+            exp += np.where(hit, u[rr, ccc].astype(np.int64), 0)
+        valid = d[k, cols] != 247
+        ok &= bool(np.all((u[k, cols].astype(np.int64) == exp)[valid])) and bool(np.all(u[k, cols][~valid] == -9999))
+        checked += int(cols.size)
+    res["host_sample_upa_equals_1_plus_children"] = ok
+    res["host_sample_cells"] = checked
+    return res
+
+
+# ---- secondary lines: BASELINE.json configs[2] (float32 accuflux + Strahler at 30000 x 30000) ----------
+def c3_lines(size, regime, steps, device):
+    """Wall time of a complete warm call of the exact (bit-identical to the serial loop) float32
+    accuflux and of the Strahler order, everything device-resident; the one-off cell ordering of the
+    handle is reported separately (the reference orders once per object too, flwdir.py:231-250)."""
+    n = size * size
+    d8_buf = _hip.synth_d8_device(size, size, device=device, **REGIMES[regime])
+    h = _hip.RasterHandle(d8_buf, size, size, device=device, memspace=_hip.PFD_DEVICE)
+    w = _hip.synth_weights_device(n, seed=1, device=device)
+    out_f = _hip.DeviceBuffer(n * 4, device)
+    out_b = _hip.DeviceBuffer(n, device)
+    t0 = time.perf_counter()
+    h.order_cells()
+    t_order = (time.perf_counter() - t0) * 1e3
+    lines = []
+
+    def run(name, fn, b_alg, dtype):
+        fn()  # warm (allocations, lazily built per-handle structures)
+        per = []
+        segs = None
+        h.set_profiling(True)
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            fn()
+            per.append((time.perf_counter() - t1) * 1e3)
+            segs = h.last_timing()
+        h.set_profiling(False)
+        ms = statistics.median(per)
+        sweep = [s for s in segs if s["name"].startswith(("sweep", "chain", "exact"))]
+        achieved = b_alg * n / (ms * 1e-3) / 1e9
+        lines.append(dict(op=name, workload=f"{size}x{size} synthetic D8 ({regime} regime), {name}, handle ordered once",
+                          dtype=dtype, ms_per_call=round(ms, 3), ms_per_call_min=round(min(per), 3),
+                          value=round(n / ms / 1e3, 2), unit="Mcells/s", order_cells_ms=round(t_order, 2),
+                          n_levels=h.info()["n_levels"],
+                          roofline=dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                        frac=round(achieved / PEAK_HBM_GBS, 5), traffic=None, alg_bytes_per_cell=b_alg,
+                                        phases_ms={s["name"]: round(s["ms"], 3) for s in segs},
+                                        launches={s["name"]: s["launches"] for s in sweep})))
+
+    run("accuflux(float32, direction='up')",
+        lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, has_nodata=1, direction=_hip.PFD_UP, out=out_f,
+                           memspace=_hip.PFD_DEVICE), B_ALG["accuflux_f32"], "f32")
+    run("stream_order(type='strahler')", lambda: h.strahler(None, out=out_b, memspace=_hip.PFD_DEVICE),
+        B_ALG["strahler"], "u8")
+    h.close()
+    for b in (d8_buf, w, out_f, out_b):
+        b.free()
+    _hip.check(_hip.lib().pfd_trim(device))
+    return lines
+
+
 def run_distributed(a, rank, world, local):
-    """N > 1: one rank per GPU, weak scaling — every rank owns a size x size row block of the
-    (N*size) x size raster (+ one halo row per inner edge), generated directly in its HBM."""
+    """N > 1: one rank per GPU, STRONG scaling — the size x size raster is split into N row blocks;
+    every rank generates its own rows (+ one halo row per inner edge) directly in its HBM."""
     import torch
     import torch.distributed as dist
 
@@ -130,24 +307,25 @@ def run_distributed(a, rank, world, local):
 
     for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
         os.environ.setdefault(k, v)  # (only missing for the single-process PFD_BENCH_FORCE_DIST run)
-    dist.init_process_group(backend="gloo")  # rendezvous / barrier / max-reduce only (CPU, 128-byte id)
+    dist.init_process_group(backend="gloo")  # barrier / max-reduce only (CPU)
     device = local % max(1, _hip.device_count())  # (one rank per GPU; the modulo only matters on test boxes)
-    ncol = a.size
-    nrow_total = a.size * world
-    r0, r1 = rank * a.size, (rank + 1) * a.size
+    ncol = nrow_total = a.size
+    r0, r1 = pdist.block_rows(nrow_total, world)[rank]
+    own = r1 - r0
     top, bot = pdist.halo_of(rank, world)
-    d8_buf = _hip.synth_d8_device(nrow_total, ncol, row0=r0 - top, nrows=(r1 - r0) + top + bot, device=device, **SYNTH)
-    out_buf = _hip.DeviceBuffer(a.size * ncol * 4, device)
-    # RCCL communicator (all-gather over xGMI); if it cannot be brought up on every rank the same
-    # protocol runs with the records travelling through torch.distributed (transport named in the output)
-    probe = pdist.DistributedRaster(d8_buf, a.size, ncol, rank, world, device, memspace=_hip.PFD_DEVICE,
+    synth = REGIMES[a.regime]
+    d8_buf = _hip.synth_d8_device(nrow_total, ncol, row0=r0 - top, nrows=own + top + bot, device=device, **synth)
+    out_buf = _hip.DeviceBuffer(own * ncol * 4, device)
+    # RCCL communicator (all-gather over xGMI); if it cannot be brought up on every rank the same protocol
+    # runs with the records travelling through the host (transport named in the output)
+    probe = pdist.DistributedRaster(d8_buf, own, ncol, rank, world, device, memspace=_hip.PFD_DEVICE,
                                     transport=os.environ.get("PFD_DIST_TRANSPORT", "auto"))
     comm, transport = probe.comm, probe.transport
     probe.handle.close()
 
     def step(profile=False):
         # a fresh handle per step, like the single-GPU bench: decode + local solve + exchange + final pass
-        h = _hip.RasterHandle(d8_buf, a.size, ncol, device=device, memspace=_hip.PFD_DEVICE, halo=(top, bot),
+        h = _hip.RasterHandle(d8_buf, own, ncol, device=device, memspace=_hip.PFD_DEVICE, halo=(top, bot),
                               deferred=True)
         if profile:
             h.set_profiling(True)
@@ -173,21 +351,37 @@ def run_distributed(a, rank, world, local):
     dt = float(dt[0])
     segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
     # cross-rank invariant: the cells draining off the last row of the raster carry every cell
-    stats = torch.tensor([info["n_valid"]], dtype=torch.int64)
+    # (river regime: every pit sits on the last row); checksum of the whole result for the 1-vs-N comparison
+    res = out_buf.download(np.int32, (own, ncol))
+    csum = int(res.astype(np.int64).sum())  # (sum over ranks == the 1-GPU run's invariants.result_checksum)
+    stats = torch.tensor([info["n_valid"], info["n_pits"], csum], dtype=torch.int64)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    pit_sum = torch.zeros(1, dtype=torch.int64)
+    if rank == world - 1:
+        last_codes = d8_buf.download(np.uint8, (ncol,), offset_bytes=(top + own - 1) * ncol)
+        pit_sum[0] = int(res[-1][last_codes == 0].astype(np.int64).sum())
+    dist.all_reduce(pit_sum, op=dist.ReduceOp.SUM)
     if rank == 0:
         n = nrow_total * ncol
         ms_per_step = dt / a.steps * 1e3
-        roof = roofline_of(segs, n // world, a.size, ms_per_step)
+        roof = roofline_upa(segs, own * ncol, own, ncol, ms_per_step)
         roof["per_gpu"] = True
+        roof["whole_pass"] = dict(alg_bytes_per_cell=B_ALG["upstream_area_cell"],
+                                  achieved=round(B_ALG["upstream_area_cell"] * n / (ms_per_step * 1e-3) / 1e9 / world, 2),
+                                  frac=round(B_ALG["upstream_area_cell"] * n / (ms_per_step * 1e-3) / 1e9 / world / PEAK_HBM_GBS, 5),
+                                  note="per GPU")
         out = dict(metric="Mcells/s upstream_area on D8 raster", value=round(n * a.steps / dt / 1e6, 2), unit="Mcells/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
-                   config=dict(workload=f"{nrow_total}x{ncol} synthetic D8 (river regime, seed 0) row-tiled over {world} "
-                                        f"GPUs ({a.size} rows each + halo), upstream_area(unit='cell') int32, "
-                                        "decode+local solve+RCCL all-gather+final pass per step",
-                               n_valid=int(stats[0]), parallelism=f"{world} row blocks, 1 all-gather/pass", transport=transport),
-                   roofline=roof)
+                   higher_is_better=True, scaling="strong", vs_baseline=None, dtype="int32", data="synthetic",
+                   config=dict(workload=f"{nrow_total}x{ncol} synthetic D8 ({a.regime} regime, seed {synth['seed']}) split "
+                                        f"into {world} row blocks ({own} rows + halo on rank 0), one block per GPU, "
+                                        "upstream_area(unit='cell') int32; a step = decode + local solve + all-gather of "
+                                        "the boundary records + interface solve + final pass on fresh handles",
+                               n_cells=n, n_valid=int(stats[0]), n_pits=int(stats[1]),
+                               parallelism=f"{world} row blocks, 1 all-gather/pass", transport=transport),
+                   roofline=roof, result_checksum=int(stats[2]),
+                   invariants=dict(last_row_pit_sum_equals_n_valid=bool(int(pit_sum[0]) == int(stats[0]))
+                                   if a.regime == "river" else None))
         print(json.dumps(out))
     dist.barrier()
     if comm is not None:
@@ -207,53 +401,20 @@ def main():
     if world > 1 or os.environ.get("PFD_BENCH_FORCE_DIST"):  # the env knob runs the RCCL path with 1 rank
         return run_distributed(a, rank, world, local)
     device = local
-    nrow = ncol = a.size
-    n = nrow * ncol
-    d8_buf = _hip.synth_d8_device(nrow, ncol, device=device, **SYNTH)
-    out_buf = _hip.DeviceBuffer(n * 4, device)
-
-    for _ in range(a.warmup):
-        one_step(d8_buf, out_buf, nrow, ncol, device)
-    _hip.check(_hip.lib().pfd_device_synchronize(device))
-    t0 = time.perf_counter()
-    timed = [one_step(d8_buf, out_buf, nrow, ncol, device, profile=True) for _ in range(a.steps)]
-    _hip.check(_hip.lib().pfd_device_synchronize(device))
-    dt = time.perf_counter() - t0
-    ms_per_step = dt / a.steps * 1e3
-    value = n * a.steps / dt / 1e6
-    # kernel durations: HIP events recorded live, inside the timed region, on the library's stream
-    segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
-    roofline = roofline_of(segs, n, a.size, ms_per_step)
-
-    out = dict(metric="Mcells/s upstream_area on D8 raster", value=round(value, 2), unit="Mcells/s", n_gpus=1,
-               steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="int32", data="synthetic",
-               config=dict(workload=f"{nrow}x{ncol} synthetic D8 (river regime, seed 0), "
-                                    "upstream_area(unit='cell') int32, decode+order+sweep per step",
-                           n_valid=info["n_valid"], n_pits=info["n_pits"], n_levels=info["n_levels"],
-                           parallelism="1 GPU"),
-               roofline=roofline)
-
-    # size-independent invariant (reference tests/test_streams_basins.py:24-27): the upstream areas of
-    # the pits add up to the number of valid cells.  In the river regime every pit sits on the last row.
-    last_codes = d8_buf.download(np.uint8, (ncol,), offset_bytes=(nrow - 1) * ncol)
-    last_upa = out_buf.download(np.int32, (ncol,), offset_bytes=(nrow - 1) * ncol * 4)
-    pits = last_codes == 0
-    if int(pits.sum()) == info["n_pits"]:
-        out["invariant_pit_sum_equals_n_valid"] = bool(int(last_upa[pits].astype(np.int64).sum()) == info["n_valid"])
-
-    if not a.no_cpu_baseline:
-        d8_host = d8_buf.download(np.uint8, (nrow, ncol))
-        rows = a.cpu_rows or min(nrow, max(1, int(1.2e8 // ncol)))
-        cpu, upa_cpu = cpu_baseline(d8_host, rows)
-        out["cpu_baseline"] = cpu
-        # parity spot check of the benchmarked result against the oracle on the sample's interior:
-        # rows whose whole upstream area lies inside the sample are identical in both rasters
-        got = out_buf.download(np.int32, (rows, ncol))
-        if rows == nrow:
-            out["parity_vs_oracle"] = bool(np.array_equal(got, upa_cpu))
-        else:
-            out["parity_vs_oracle"] = bool(np.array_equal(got, upa_cpu))  # flow is southwards: upstream = rows above
+    line, cfg = upa_line(a.size, a.size, a.regime, a.steps, a.warmup, device, cpu=not a.no_cpu_baseline,
+                         cpu_rows=a.cpu_rows)
+    out = dict(metric="Mcells/s upstream_area on D8 raster", value=line.pop("value"), unit="Mcells/s", n_gpus=1,
+               steps=a.steps, warmup=a.warmup, ms_per_step=line.pop("ms_per_step"), higher_is_better=True,
+               scaling="strong", vs_baseline=None, dtype="int32", data="synthetic", config=cfg)
+    out.update(line)
+    if not a.no_secondary:
+        sec = []
+        l2, c2 = upa_line(10000, 10000, a.regime, 20, 5, device, cpu=False, checks=False)
+        sec.append(dict(op="upstream_area(unit='cell')", workload=c2["workload"], value=l2["value"], unit="Mcells/s",
+                        ms_per_step=l2["ms_per_step"], ms_per_step_median=l2["ms_per_step_median"], dtype="int32",
+                        n_valid=c2["n_valid"], n_pits=c2["n_pits"], roofline=l2["roofline"]))
+        sec += c3_lines(30000, a.regime, 3, device)
+        out["secondary"] = sec
     print(json.dumps(out))
 
 

@@ -223,6 +223,21 @@ int pfd_set_profiling(pfd_raster *h, int enable);
 int pfd_last_timing(pfd_raster *h, int max_seg, double *ms, int64_t *launches, char *names,
                     size_t names_len, int *nseg);
 
+/* Graph statistics a benchmark reports next to every number: stats[0] = n_valid,
+ * [1] = n_pits, [2] = max rank = longest flow path in cells (reference core.rank, pyflwdir/core.py:17-47;
+ * -1 if the raster holds cycles or is a row block), [3..11] = number of valid cells with 0..8
+ * upstream cells (reference core.upstream_count, pyflwdir/core.py:50-61).  Works on rasters beyond 2^32
+ * cells. */
+int pfd_graph_stats(pfd_raster *h, int64_t stats[16]);
+
+/* Verifies an upstream_area("cell") result of this raster by its local equations, at any size
+ * (whole rasters, incl. beyond 2^32 cells): res[0] = valid cells with upa != 1 + sum over the cells
+ * draining into them, [1] = nodata cells != -9999, [2] = sum of upa over the pits, [3] = pits,
+ * [4] = sum of all n values (two's complement), [5] = valid cells.  On a raster without cycles
+ * res[0] == res[1] == 0 holds for exactly one array: the reference's result (streams.accuflux over
+ * ones, pyflwdir/streams.py:15-41; invariant [2] == [5]: tests/test_streams_basins.py:24-27). */
+int pfd_verify_upstream_area_cell(pfd_raster *h, const int32_t *upa, int memspace, int64_t res[8]);
+
 /* ---- synthetic rasters (bench / tests; device twin of oracle/pfd_oracle.c orc_synth_*) ---- */
 /* writes rows [row0, row0+nrows) of the nrow x ncol synthetic raster to device memory */
 int pfd_synth_d8(int device, uint64_t seed, int64_t nrow, int64_t ncol, int64_t tilt, int64_t white,

@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell",
 ]
 
 _lib = None
@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
         L.pfd_main_upstream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int]
         L.pfd_stream_order_classic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_stream_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.pfd_verify_upstream_area_cell.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int)]
@@ -215,6 +217,19 @@ class RasterHandle:
         check(lib().pfd_raster_info(self._h, a))
         keys = ["nrow", "ncol", "n_valid", "n_pits", "n_seq", "n_levels", "device", "bytes_held"]
         return dict(zip(keys, [int(v) for v in a]))
+
+    def graph_stats(self) -> dict:
+        """n_valid, n_pits, max_rank (longest flow path, -1 with cycles) and the in-degree histogram."""
+        a = (C.c_int64 * 16)()
+        check(lib().pfd_graph_stats(self._h, a))
+        return dict(n_valid=int(a[0]), n_pits=int(a[1]), max_rank=int(a[2]), indegree_hist=[int(a[3 + k]) for k in range(9)])
+
+    def verify_upstream_area_cell(self, upa, memspace=PFD_HOST) -> dict:
+        """Local-equation check of an upstream_area("cell") result (see include/pfd.h)."""
+        a = (C.c_int64 * 8)()
+        check(lib().pfd_verify_upstream_area_cell(self._h, ptr(upa), memspace, a))
+        return dict(bad_cells=int(a[0]), bad_nodata=int(a[1]), pit_sum=int(a[2]), n_pits=int(a[3]), checksum=int(a[4]),
+                    n_valid=int(a[5]))
 
     def set_profiling(self, on: bool = True):
         check(lib().pfd_set_profiling(self._h, int(on)))

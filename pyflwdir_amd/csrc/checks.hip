@@ -1,0 +1,80 @@
+// checks.hip — full-size verification of an upstream_area("cell") result by its LOCAL equations.
+//
+// On a raster without cycles the system   upa(x) = 1 + sum of upa over the cells draining into x
+// (valid x),   upa(x) = -9999 (nodata x)   has exactly one solution — the result of the reference's
+// streams.accuflux over ones (pyflwdir/streams.py:15-41, pyflwdir/pyflwdir.py:770-801).  Checking
+// every cell's equation is one streaming pass that shares nothing with the engines that produced the
+// result (no tiles, no ordering), needs no oracle and works at any size: it is how bench.py and the
+// large-size tests certify the 8.1-Gcell result (SURVEY.md 8d, C4 checks ii/iii), together with the
+// reference's own invariant "the upstream areas of the pits add up to the number of valid cells"
+// (tests/test_streams_basins.py:24-27).
+#include "common.h"
+
+__global__ void __launch_bounds__(256) k_verify_upa(const u8 *__restrict__ ncode, const i32 *__restrict__ upa, u32 nrow,
+                                                    u32 ncol, unsigned long long *__restrict__ res) {
+  __shared__ unsigned long long s[6];
+  if (threadIdx.x < 6) s[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
+  unsigned long long bad = 0, badmv = 0, pitsum = 0, npit = 0, csum = 0, nvalid = 0;
+  for (u32 r = blockIdx.y * 4 + (threadIdx.x >> 6); r < nrow && c < ncol; r += gridDim.y * 4) {
+    const size_t i = (size_t)r * ncol + c;
+    const u32 code = ncode[i];
+    const i32 v = upa[i];
+    csum += (unsigned long long)(long long)v;
+    if (code == D8_MV) {
+      badmv += v != -9999;
+      continue;
+    }
+    ++nvalid;
+    u32 acc = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 rr = r + (u32)d8_dr(k), cc = c + (u32)d8_dc(k);
+      if (rr < nrow && cc < ncol) {
+        const size_t j = (size_t)rr * ncol + cc;
+        if (ncode[j] == (1u << ((k + 4) & 7))) acc += (u32)upa[j];
+      }
+    }
+    bad += acc != (u32)v;
+    if (code == 0) {
+      ++npit;
+      pitsum += (unsigned long long)(u32)v;
+    }
+  }
+  unsigned long long vals[6] = {bad, badmv, pitsum, npit, csum, nvalid};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    unsigned long long v = vals[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 6 && s[threadIdx.x]) atomicAdd(&res[threadIdx.x], s[threadIdx.x]);
+}
+
+extern "C" int pfd_verify_upstream_area_cell(pfd_raster *h, const int32_t *upa, int memspace, int64_t res[8]) {
+  PFDCHK(pfd_check_handle(h));
+  if (!upa || !res) {
+    pfd_set_error("pfd_verify_upstream_area_cell: bad arguments");
+    return PFD_EINVAL;
+  }
+  if (h->halo_top || h->halo_bot) {
+    pfd_set_error("pfd_verify_upstream_area_cell: whole rasters only");
+    return PFD_EUNSUPPORTED;
+  }
+  InArg in;
+  PFDCHK(in.bind(upa, (size_t)h->n * sizeof(i32), memspace, h->stream));
+  DevBuf acc;
+  PFDCHK(acc.alloc(8 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(acc.p, 0, 8 * sizeof(unsigned long long), h->stream));
+  const dim3 grid(cdiv_u32((u64)h->ncol, 64), std::min<u32>(cdiv_u32((u64)h->nrow, 4), 8192u));
+  k_verify_upa<<<grid, 256, 0, h->stream>>>(h->ncode, (const i32 *)in.dev, (u32)h->nrow, (u32)h->ncol,
+                                            acc.as<unsigned long long>());
+  KCHK();
+  unsigned long long r[8];
+  HIPCHK(hipMemcpyAsync(r, acc.p, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 8; ++k) res[k] = (int64_t)r[k];
+  return PFD_OK;
+}

@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
         }
         o4[b] = val;
       }
+      if (a.out == nullptr) continue;  // (statistics only: pfd_graph_stats)
       u32 *dst = a.out + (size_t)gr * a.ncol + (size_t)gc0;
       if (gc0 + 3 < (i64)a.ncol && (((size_t)dst) & 15) == 0) {
         *(uint4 *)dst = make_uint4(o4[0], o4[1], o4[2], o4[3]);
@@ -474,6 +475,70 @@ int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32
   return PFD_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// graph statistics a benchmark has to report next to every number: longest flow path
+// (max rank; the tiled rank query without its output array, so it also serves rasters beyond 2^32
+// cells) and the in-degree histogram of the valid cells (reference core.upstream_count, core.py:50-61).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_indeg_hist(const u8 *__restrict__ ncode, u32 nrow, u32 ncol, u32 row_first,
+                                                    u32 row_last, unsigned long long *__restrict__ hist) {
+  __shared__ u32 s[9];
+  if (threadIdx.x < 9) s[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
+  u32 cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (u32 r = row_first + blockIdx.y * 4 + (threadIdx.x >> 6); r <= row_last && c < ncol; r += gridDim.y * 4) {
+    const size_t i = (size_t)r * ncol + c;
+    if (ncode[i] == D8_MV) continue;
+    u32 d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 rr = r + (u32)d8_dr(k), cc = c + (u32)d8_dc(k);
+      if (rr < nrow && cc < ncol) d += ncode[(size_t)rr * ncol + cc] == (1u << ((k + 4) & 7)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cnt[k] += d == (u32)k ? 1u : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    u32 v = cnt[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 9 && s[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+
+extern "C" int pfd_graph_stats(pfd_raster *h, int64_t stats[16]) {
+  PFDCHK(pfd_check_handle(h));
+  if (!stats) {
+    pfd_set_error("pfd_graph_stats: NULL stats");
+    return PFD_EINVAL;
+  }
+  for (int k = 0; k < 16; ++k) stats[k] = 0;
+  DevBuf hist;
+  PFDCHK(hist.alloc(9 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(hist.p, 0, 9 * sizeof(unsigned long long), h->stream));
+  const dim3 grid(cdiv_u32((u64)h->ncol, 64), std::min<u32>(cdiv_u32((u64)h->own_rows, 4), 4096u));
+  k_indeg_hist<<<grid, 256, 0, h->stream>>>(h->ncode, (u32)h->nrow, (u32)h->ncol, (u32)h->halo_top,
+                                            (u32)(h->halo_top + h->own_rows - 1), hist.as<unsigned long long>());
+  KCHK();
+  unsigned long long hh[9];
+  HIPCHK(hipMemcpyAsync(hh, hist.p, sizeof(hh), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  stats[0] = h->n_valid;
+  stats[1] = h->n_pits;
+  stats[2] = -1;
+  for (int k = 0; k < 9; ++k) stats[3 + k] = (int64_t)hh[k];
+  if (!h->halo_top && !h->halo_bot) {  // longest flow path (cells): max rank over the raster
+    int complete = 0;
+    u32 maxrank = 0;
+    PFDCHK(run_paths<MODE_RANK>(h, nullptr, nullptr, &complete, &maxrank));
+    if (complete) stats[2] = (int64_t)maxrank;
+  }
+  return PFD_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Heavy-chain layout (for exact up-sweeps at chain speed, sweeps.hip: k_chain_up).
