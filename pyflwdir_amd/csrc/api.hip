@@ -233,7 +233,7 @@ static void free_handle(pfd_raster *h) {
   pfd_dfree(h->raw_owned);
   pfd_dfree(h->seq);
   pfd_dfree(h->seq_kids2);  // (seq_kids / seq_own / cell_kids live in the same allocation)
-  pfd_free_chains(h);
+  pfd_free_xplan(h);
   pfd_dfree(h->pits);
   pfd_dfree(h->ctrl);
   if (h->stream) release_stream(h->device, h->stream);

@@ -138,15 +138,10 @@ struct pfd_raster {
   u8 *seq_kids = nullptr, *seq_own = nullptr;  // per ordered cell: mask of draining neighbours / own code
   u8 *cell_kids = nullptr;                     // per CELL: mask of draining neighbours (same allocation)
   u64 *seq_kids2 = nullptr;                    // per ordered cell: the child masks of its upstream cells (owns the allocation)
-  // heavy-chain layout for exact up-sweeps at chain speed (paths.hip: pfd_ensure_chains)
   int acyclic = 0;               // 0 unknown, 1 every valid cell reaches a pit, -1 the raster holds cycles
-  int chains_state = 0;          // 0 not built, 1 ready, -1 not available (cycles / raster too large)
-  u32 *chain_seq = nullptr;      // [n_chain] cells, chain after chain (upstream end first), chains in dependency order
-  u32 *chain_pos = nullptr;      // [n] position of a cell in chain_seq, 0xFFFFFFFF if it is in no chain
-  u32 *chain_done = nullptr;     // [units] epoch of the last sweep that finished the 64-cell unit
-  u8 *chain_kids = nullptr;      // [n] mask of draining neighbours per cell
-  i64 n_chain = 0;
-  u32 chain_epoch = 0;
+  // plan of the exact-order engine (exact.h): 0 not built, 1 ready, -1 not available
+  void *xplan = nullptr;
+  int xplan_state = 0;
   bool aux_ready = false;
   i64 n_seq = -1, n_levels = -1;
   std::vector<i64> lvl_off;  // host copy, n_levels+1 entries
@@ -244,8 +239,7 @@ int pfd_ensure_pits(pfd_raster *h);                             // order.hip
 int pfd_require_whole(pfd_raster *h, const char *what);          // order.hip
 void pfd_free_pending(pfd_raster *h);                            // dist.hip
 int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
-int pfd_ensure_chains(pfd_raster *h);                           // paths.hip (h->chains_state says whether they exist)
-void pfd_free_chains(pfd_raster *h);                            // paths.hip
+void pfd_free_xplan(pfd_raster *h);                             // exact.hip
 int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev,
                      int *ok);                                   // paths.hip
 int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete, const i32 *weights = nullptr);  // tiled.hip

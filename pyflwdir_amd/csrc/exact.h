@@ -1,0 +1,53 @@
+// exact.h — the exact-order engine (exact.hip): plan of a raster + the sweep drivers sweeps.hip calls.
+//
+// Order-sensitive operations (float accuflux, HAND, ...) must combine values in the order of the
+// reference's serial loop, so their critical path is the longest flow path: one dependent update per
+// cell.  The level engine pays one kernel launch per 1-2 cells of that path.  This engine splits the
+// raster so that the dependent chain runs at register speed instead:
+//
+//   LEAVES  cells whose whole upstream subtree lies inside their 64 x 64 tile and is at most XCAP steps
+//           high: a tile kernel resolves them in LDS, step by step, in a precomputed per-tile order;
+//   TRUNK   every other cell.  The trunk is cut into heavy chains (heavy child = upstream TRUNK cell with
+//           the largest upstream area); chains are laid out contiguously, upstream end first, grouped by
+//           bucket = floor(log2(upstream area of the chain's last cell)) — a chain only depends on chains
+//           of lower buckets.  Per bucket: a parallel pre-pass gathers, per layout slot, everything that
+//           does not depend on the chain itself (own payload + light upstream cells, already final); one
+//           LANE per chain then folds the slots serially (running value in a register, loads software-
+//           pipelined); a parallel scatter writes the results back to the raster.
+//
+// An upstream cell that the serial loop adds AFTER the heavy one gets a slot of its own behind its
+// parent's ("post" slot), so that the fold stays a flat left-to-right scan with the reference's exact
+// operand order.
+#pragma once
+#include "common.h"
+
+#define XT 64            // tile edge
+#define XTC (XT * XT)    // 4096 cells
+#define XCAP 62          // highest leaf step; toff holds XCAP + 2 = 64 u16 per tile
+#define XOFF (XCAP + 2)
+#define XL_TRUNK 255u    // lh[] marks
+#define XL_NODATA 254u
+// sinfo (u16 per slot): bits 0-7 child mask, 8-11 slot of the heavy child (8 = none: chain head),
+// 12-14 number of post slots that follow, 15 = this is a post slot (scell = the upstream cell it carries)
+#define XS_POST 0x8000u
+
+struct ExactPlan {
+  u32 ntr = 0, ntc = 0;
+  u8 *lh = nullptr;       // [n] leaf step (0..XCAP), XL_TRUNK, XL_NODATA
+  u8 *kids = nullptr;     // [n] mask of the neighbour slots draining into the cell
+  uint16_t *tord = nullptr;  // [ntiles * 4096] leaf cells of the tile (local index), ordered by step
+  uint16_t *toff = nullptr;  // [ntiles * XOFF] start of step s in tord; entries past the last step = total
+  u32 *scell = nullptr;   // [nslot]
+  uint16_t *sinfo = nullptr;  // [nslot]
+  u32 *cstart = nullptr;  // [nchain] first slot of the chain
+  u32 *clen = nullptr;    // [nchain] slots in the chain
+  i64 nslot = 0, nchain = 0, ntrunk = 0;
+  i64 b_chain[33] = {0};  // chains of bucket b = [b_chain[b], b_chain[b+1])
+  i64 b_slot[33] = {0};   // slots  of bucket b = [b_slot[b],  b_slot[b+1])
+  size_t bytes = 0;
+};
+
+// builds the plan on first use; h->xplan_state: 0 not built, 1 ready, -1 not available (cycles, row
+// block, more than 2^32 - 2 cells)
+int pfd_ensure_xplan(pfd_raster *h);
+void pfd_free_xplan(pfd_raster *h);

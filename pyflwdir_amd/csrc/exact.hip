@@ -1,0 +1,471 @@
+// exact.hip — builds the plan of the exact-order engine (exact.h): leaf steps per tile, heavy chains
+// of the trunk, slot layout.  The sweeps themselves are templates over the operation (exact_sweep.h,
+// instantiated in sweeps.hip).
+//
+// Everything here is integer work that is exact in any execution order; the plan only decides WHERE
+// and WHEN a cell is computed, never in which order its operands are combined.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "exact.h"
+#include "tiled.h"
+
+int pfd_path_rank(pfd_raster *h, const u8 *codes, u32 *out_dev, int *complete);                         // paths.hip
+int pfd_path_labels(pfd_raster *h, const u8 *codes, const u32 *seed_dev, u32 *out_dev, int *complete);  // paths.hip
+
+// ---------------------------------------------------------------------------------------------
+// P2: leaf steps of one tile.  A cell is a leaf of step s if all its upstream cells lie in the tile and
+// are leaves of steps < s (s = 1 + max), s <= XCAP; headwaters are step 0.  Found by in-degree counting
+// in LDS: a finished cell decrements its downstream cell; a cell whose counter reaches zero joins the
+// next step.  A cell with an upstream cell outside the tile never starts counting down ("blocked").
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode, u32 nrow, u32 ncol, u32 ntc,
+                                                   u8 *__restrict__ lh, u8 *__restrict__ kids_out,
+                                                   uint16_t *__restrict__ tord, uint16_t *__restrict__ toff) {
+  __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
+  __shared__ u32 cnt[XTC];         // unresolved upstream cells | 0x100 blocked | 0x200 nodata
+  __shared__ uint16_t ord[XTC];
+  __shared__ u32 s_n;              // entries in ord
+  __shared__ uint16_t off[XOFF];
+  const u32 tid = threadIdx.x;
+  const u32 tc = blockIdx.x, tr = blockIdx.y;
+  const i64 r0 = (i64)tr * XT, c0 = (i64)tc * XT;
+  {
+    u32 v[5];
+    stage_load(ncode, nrow, ncol, r0, c0, tid, v);
+    stage_store(code, tid, v);
+  }
+  if (tid == 0) s_n = 0;
+  if (tid < XOFF) off[tid] = 0;
+  __syncthreads();
+  u32 mykids[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const u32 l = tid + 256u * j;
+    const int lr = l >> 6, lc = l & 63;
+    const u32 c = CODE(lr, lc);
+    u32 m = 0, blocked = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
+      if (CODE(nr, nc) == (1u << ((k + 4) & 7))) {
+        m |= 1u << k;
+        if ((unsigned)nr >= XT || (unsigned)nc >= XT) blocked = 0x100u;
+      }
+    }
+    if (c == D8_MV) {
+      m = 0;
+      blocked = 0x200u;
+    }
+    mykids[j] = m;
+    const u32 v = (u32)__popc(m) | blocked;
+    cnt[l] = v;
+    if (v == 0) ord[atomicAdd(&s_n, 1u)] = (uint16_t)l;  // headwater: step 0
+  }
+  __syncthreads();
+  u32 begin = 0, end = s_n;
+  int s = 0;
+  // (off[0] = 0 already)
+  while (end > begin && s < XCAP) {
+    if (tid == 0) off[s + 1] = (uint16_t)end;
+    for (u32 j = begin + tid; j < end; j += 256u) {
+      const u32 x = ord[j];
+      const int lr = x >> 6, lc = x & 63;
+      const u32 c = CODE(lr, lc);
+      if (d8_is_dir(c)) {
+        const int k = d8_slot(c);
+        const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
+        if ((unsigned)nr < XT && (unsigned)nc < XT) {
+          const u32 p = (u32)(nr * XT + nc);
+          if (atomicSub(&cnt[p], 1u) == 1u) ord[atomicAdd(&s_n, 1u)] = (uint16_t)p;  // last upstream cell done
+        }
+      }
+    }
+    __syncthreads();
+    begin = end;
+    end = s_n;
+    ++s;
+    __syncthreads();
+  }
+  // cells appended by the last executed step (step index s) stay leaves only if s <= XCAP: the loop
+  // stops at s == XCAP with [begin, end) = the cells of step XCAP, which are kept; their parents are not
+  // appended any more (the loop did not run for them) -> trunk.
+  const u32 total = end;
+  if (tid == 0) off[s + 1 <= XOFF - 1 ? s + 1 : XOFF - 1] = (uint16_t)total;
+  __syncthreads();
+  // steps of the leaves: position in ord -> step by the offsets
+  // lhl: reuse cnt[] as the per-cell step (0xFFFF.. = not a leaf)
+  const int nsteps = s + 1;  // steps 0 .. s hold cells ([off[t], off[t+1]) ), off[s+1] = total
+  if (tid >= (u32)nsteps + 1 && tid < XOFF) off[tid] = (uint16_t)total;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const u32 l = tid + 256u * j;
+    cnt[l] = (cnt[l] & 0x200u) ? XL_NODATA : XL_TRUNK;
+  }
+  __syncthreads();
+  for (u32 j = tid; j < total; j += 256u) {
+    // step of entry j: largest t with off[t] <= j
+    int t = 0;
+    for (int q = 1; q < nsteps; ++q) t += (j >= (u32)off[q]) ? 1 : 0;
+    cnt[ord[j]] = (u32)t;
+  }
+  __syncthreads();
+  const size_t tile = (size_t)tr * ntc + tc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const u32 l = tid + 256u * j;
+    const i64 gr = r0 + (l >> 6), gc = c0 + (l & 63);
+    if (gr < (i64)nrow && gc < (i64)ncol) {
+      const size_t g = (size_t)gr * ncol + (size_t)gc;
+      lh[g] = (u8)cnt[l];
+      kids_out[g] = (u8)mykids[j];
+    }
+    tord[tile * XTC + l] = l < total ? ord[l] : (uint16_t)0;
+  }
+  if (tid < XOFF) toff[tile * XOFF + tid] = off[tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// P3: heavy links of the trunk.  heavy child of x = its upstream TRUNK cell with the largest upstream
+// area (first maximum in ascending index).  hcode = the forest of heavy links only (light trunk cells
+// and pits become path ends, everything else nodata); seed marks the chain ends for the label query.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 heavy_slot(const u8 *__restrict__ lh, const u32 *__restrict__ upa, const Geo &g, u32 x,
+                                          u32 kids) {
+  u32 best = 0, arg = 8;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int k = PFD_SLOT_ASC[q];
+    // unconditional loads from clamped addresses, masked afterwards
+    const i64 j = (i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k);
+    const u32 jj = (u32)(j < 0 ? 0 : (j >= (i64)g.n ? (i64)g.n - 1 : j));
+    const u32 a = upa[jj];
+    const u32 t = lh[jj];
+    if ((kids & (1u << k)) && t == XL_TRUNK && a > best) {
+      best = a;
+      arg = (u32)k;
+    }
+  }
+  return arg;
+}
+
+__global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ lh,
+                                                    const u8 *__restrict__ kids, const u32 *__restrict__ upa,
+                                                    u8 *__restrict__ hcode, u32 *__restrict__ seed,
+                                                    uint16_t *__restrict__ hinfo) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.n) return;
+  u32 hc = D8_MV, sd = 0, info = 0;
+  if (lh[x] == XL_TRUNK) {
+    const u32 c = ncode[x];
+    const u32 m = kids[x];
+    const u32 hs = heavy_slot(lh, upa, g, x, m);
+    // post cells: upstream cells the serial loop adds after the heavy one = those of lower linear index
+    u32 npost = 0;
+    if (hs < 8) {
+      const i64 hoff = (i64)d8_dr((int)hs) * (i64)g.ncol + d8_dc((int)hs);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const i64 off = (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k);
+        if ((m & (1u << k)) && off < hoff) ++npost;
+      }
+    }
+    info = m | (hs << 8) | (npost << 12);
+    bool heavy = false;
+    if (d8_is_dir(c)) {
+      const u32 p = d8_down(g, x, c);
+      const u32 ps = heavy_slot(lh, upa, g, p, kids[p]);
+      heavy = ps < 8 && ((d8_slot(c) + 4) & 7) == (int)ps;  // the slot of p that holds x
+    }
+    hc = heavy ? c : 0u;
+    sd = heavy ? 0u : x + 1u;
+  }
+  hcode[x] = (u8)hc;
+  seed[x] = sd;
+  hinfo[x] = (uint16_t)info;
+}
+
+// the head of a chain (a trunk cell without heavy child) knows the length of its chain
+__global__ void __launch_bounds__(256) k_plan_len(const u8 *__restrict__ lh, const uint16_t *__restrict__ hinfo,
+                                                  const u32 *__restrict__ hops, const u32 *__restrict__ tailnum, u32 n,
+                                                  u32 *__restrict__ len_at) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n || lh[x] != XL_TRUNK || ((hinfo[x] >> 8) & 0xFu) != 8u) return;
+  const u32 tn = tailnum[x];
+  if (tn) len_at[tn - 1] = hops[x] + 1;
+}
+
+// pass 0: cells and chains per bucket; pass 1: base position / chain id of every chain
+template <int PASS>
+__global__ void __launch_bounds__(256) k_plan_place(const u32 *__restrict__ seed, const u32 *__restrict__ upa,
+                                                    const u32 *__restrict__ len_at, u32 n,
+                                                    unsigned long long *__restrict__ bucket,  // [64]: cells, chains
+                                                    u32 *__restrict__ base_at, u32 *__restrict__ cpos,
+                                                    u32 *__restrict__ clen) {
+  __shared__ u32 s_tot[32], s_cnt[32];
+  __shared__ unsigned long long s_base[32], s_cbase[32];
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (threadIdx.x < 32) s_tot[threadIdx.x] = s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const bool tail = t < n && seed[t] != 0;
+  u32 b = 0, len = 0, local = 0, clocal = 0;
+  if (tail) {
+    b = 31u - (u32)__builtin_clz(upa[t] | 1u);
+    len = len_at[t];
+    local = atomicAdd(&s_tot[b], len);
+    clocal = atomicAdd(&s_cnt[b], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 32 && s_cnt[threadIdx.x]) {
+    s_base[threadIdx.x] = atomicAdd(&bucket[threadIdx.x], (unsigned long long)s_tot[threadIdx.x]);
+    s_cbase[threadIdx.x] = atomicAdd(&bucket[32 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+  }
+  if (PASS == 1) {
+    __syncthreads();
+    if (tail) {
+      const u32 base = (u32)(s_base[b] + local);
+      const u32 cid = (u32)(s_cbase[b] + clocal);
+      base_at[t] = base;
+      cpos[cid] = base;
+      clen[cid] = len;
+    }
+  }
+}
+
+// position of every trunk cell: chain base + distance from the chain head; w = slots the cell needs
+__global__ void __launch_bounds__(256) k_plan_scatter(const u8 *__restrict__ lh, const uint16_t *__restrict__ hinfo,
+                                                      const u32 *__restrict__ hops, const u32 *__restrict__ tailnum,
+                                                      const u32 *__restrict__ len_at, const u32 *__restrict__ base_at,
+                                                      u32 n, u32 *__restrict__ ucell, u32 *__restrict__ w) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n || lh[x] != XL_TRUNK) return;
+  const u32 tn = tailnum[x];
+  if (!tn) return;
+  const u32 t = tn - 1;
+  const u32 p = base_at[t] + len_at[t] - 1 - hops[x];
+  ucell[p] = x;
+  w[p] = 1u + ((hinfo[x] >> 12) & 7u);
+}
+
+__global__ void __launch_bounds__(256) k_plan_expand(const u32 *__restrict__ ucell, const u32 *__restrict__ S,
+                                                     const uint16_t *__restrict__ hinfo, Geo g, u32 npos,
+                                                     u32 *__restrict__ scell, uint16_t *__restrict__ sinfo) {
+  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npos) return;
+  const u32 x = ucell[p];
+  const u32 info = hinfo[x];
+  u32 s = S[p];
+  scell[s] = x;
+  sinfo[s] = (uint16_t)info;
+  const u32 hs = (info >> 8) & 0xFu;
+  if (hs < 8 && (info >> 12)) {
+    const i64 hoff = (i64)d8_dr((int)hs) * (i64)g.ncol + d8_dc((int)hs);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // descending linear index = the serial loop's order
+      const int k = PFD_SLOT_DESC[q];
+      const i64 off = (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k);
+      if ((info & (1u << k)) && off < hoff) {
+        ++s;
+        scell[s] = (u32)((i64)x + off);
+        sinfo[s] = (uint16_t)XS_POST;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_plan_chains(const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos,
+                                                     const u32 *__restrict__ S, u32 nchain, u32 *__restrict__ cstart,
+                                                     u32 *__restrict__ clen) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchain) return;
+  const u32 p = cpos[c], l = clen_pos[c];
+  const u32 s0 = S[p];
+  cstart[c] = s0;
+  clen[c] = S[p + l] - s0;
+}
+__global__ void k_plan_pick(const u32 *__restrict__ S, const u32 *__restrict__ idx, u32 k, u32 *__restrict__ out) {
+  const u32 t = threadIdx.x;
+  if (t < k) out[t] = S[idx[t]];
+}
+
+void pfd_free_xplan(pfd_raster *h) {
+  ExactPlan *p = (ExactPlan *)h->xplan;
+  if (p) {
+    pfd_dfree(p->lh);
+    pfd_dfree(p->kids);
+    pfd_dfree(p->tord);
+    pfd_dfree(p->toff);
+    pfd_dfree(p->scell);
+    pfd_dfree(p->sinfo);
+    pfd_dfree(p->cstart);
+    pfd_dfree(p->clen);
+    h->bytes_held -= std::min(h->bytes_held, p->bytes);
+    delete p;
+  }
+  h->xplan = nullptr;
+  h->xplan_state = 0;
+}
+
+int pfd_ensure_xplan(pfd_raster *h) {
+  if (h->xplan_state != 0) return PFD_OK;
+  h->xplan_state = -1;
+  if (h->n > 4294967294ll || h->halo_top || h->halo_bot || getenv("PFD_EXACT_LEVELS")) return PFD_OK;
+  if (h->acyclic < 0) return PFD_OK;
+  const u32 n = h->geo.n;
+  const u32 ntr = cdiv_u32((u64)h->nrow, XT), ntc = cdiv_u32((u64)h->ncol, XT);
+  const size_t ntiles = (size_t)ntr * ntc;
+  if (ntr > 65535u) return PFD_OK;
+  pfd_seg_begin(h, "exact_plan");
+  DevBuf upa;
+  PFDCHK(upa.alloc((size_t)n * sizeof(u32)));
+  int complete = 0;
+  {
+    const bool prof = h->profiling;  // (the tiled pass records its own segments: keep ours intact)
+    h->profiling = false;
+    const int rc = pfd_upstream_area_cell_tiled(h, (i32 *)upa.p, &complete);
+    h->profiling = prof;
+    PFDCHK(rc);
+  }
+  if (!complete) {  // cycles: the level engine keeps the reference's semantics for them
+    h->acyclic = -1;
+    pfd_seg_end(h, 0);
+    return PFD_OK;
+  }
+  h->acyclic = 1;
+  ExactPlan *p = new ExactPlan();
+  h->xplan = p;  // (freed by pfd_free_xplan also when a later step fails)
+  p->ntr = ntr;
+  p->ntc = ntc;
+  int rc = PFD_OK;
+  auto fail = [&](int code) {
+    pfd_free_xplan(h);
+    h->xplan_state = -1;
+    return code;
+  };
+  if ((rc = pfd_dmalloc((void **)&p->lh, (size_t)n + 64)) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->kids, (size_t)n + 64)) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->tord, ntiles * XTC * sizeof(uint16_t))) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->toff, ntiles * XOFF * sizeof(uint16_t))) != PFD_OK) return fail(rc);
+  k_plan_tile<<<dim3(ntc, ntr), 256, 0, h->stream>>>(h->ncode, (u32)h->nrow, (u32)h->ncol, ntc, p->lh, p->kids, p->tord,
+                                                     p->toff);
+  if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
+  DevBuf hcode, seed, hinfo, hops, tailnum, len_at, base_at, buckets;
+  if ((rc = hcode.alloc((size_t)n + 64)) != PFD_OK) return fail(rc);
+  if ((rc = seed.alloc((size_t)n * sizeof(u32) + 64)) != PFD_OK) return fail(rc);
+  if ((rc = hinfo.alloc((size_t)n * sizeof(uint16_t))) != PFD_OK) return fail(rc);
+  const u32 grid = cdiv_u32(n, 256);
+  k_plan_heavy<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, p->lh, p->kids, upa.as<u32>(), hcode.as<u8>(),
+                                            seed.as<u32>(), hinfo.as<uint16_t>());
+  if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
+  if ((rc = hops.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = tailnum.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pfd_path_rank(h, hcode.as<u8>(), hops.as<u32>(), &complete)) != PFD_OK) return fail(rc);
+  if (!complete) return fail(PFD_OK);
+  if ((rc = pfd_path_labels(h, hcode.as<u8>(), seed.as<u32>(), tailnum.as<u32>(), &complete)) != PFD_OK) return fail(rc);
+  if (!complete) return fail(PFD_OK);
+  hcode.alloc(0);
+  if ((rc = len_at.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = base_at.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = buckets.alloc(64 * sizeof(unsigned long long))) != PFD_OK) return fail(rc);
+  k_plan_len<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), n,
+                                          len_at.as<u32>());
+  if (hipMemsetAsync(buckets.p, 0, 64 * sizeof(unsigned long long), h->stream) != hipSuccess) return fail(PFD_EHIP);
+  k_plan_place<0><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), upa.as<u32>(), len_at.as<u32>(), n,
+                                               buckets.as<unsigned long long>(), nullptr, nullptr, nullptr);
+  unsigned long long tot[64], cur[64];
+  if (hipMemcpyAsync(tot, buckets.p, sizeof(tot), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  unsigned long long npos = 0, nchain = 0;
+  i64 b_pos[33];
+  for (int b = 0; b < 32; ++b) {
+    cur[b] = npos;
+    cur[32 + b] = nchain;
+    b_pos[b] = (i64)npos;
+    p->b_chain[b] = (i64)nchain;
+    npos += tot[b];
+    nchain += tot[32 + b];
+  }
+  b_pos[32] = (i64)npos;
+  p->b_chain[32] = (i64)nchain;
+  p->ntrunk = (i64)npos;
+  p->nchain = (i64)nchain;
+  DevBuf ucell, w, cpos, clenp, tmp, pick;
+  if ((rc = ucell.alloc(std::max<size_t>(npos, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = w.alloc((npos + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = cpos.alloc(std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = clenp.alloc(std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if (hipMemcpyAsync(buckets.p, cur, sizeof(cur), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(PFD_EHIP);
+  k_plan_place<1><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), upa.as<u32>(), len_at.as<u32>(), n,
+                                               buckets.as<unsigned long long>(), base_at.as<u32>(), cpos.as<u32>(),
+                                               clenp.as<u32>());
+  if (hipMemsetAsync(w.p, 0, (npos + 1) * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
+  k_plan_scatter<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(),
+                                              len_at.as<u32>(), base_at.as<u32>(), n, ucell.as<u32>(), w.as<u32>());
+  if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
+  // slot of a position = exclusive scan of the slots the positions before it need (in place)
+  size_t tmp_bytes = 0;
+  if (rocprim::exclusive_scan(nullptr, tmp_bytes, w.as<u32>(), w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
+                              h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
+  if (rocprim::exclusive_scan(tmp.p, tmp_bytes, w.as<u32>(), w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
+                              h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  // slot offsets of the buckets
+  u32 pidx[33], pval[33];
+  for (int b = 0; b <= 32; ++b) pidx[b] = (u32)b_pos[b];
+  if ((rc = pick.alloc(2 * 33 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if (hipMemcpyAsync(pick.p, pidx, sizeof(pidx), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(PFD_EHIP);
+  k_plan_pick<<<1, 64, 0, h->stream>>>(w.as<u32>(), pick.as<u32>(), 33, pick.as<u32>() + 33);
+  if (hipMemcpyAsync(pval, pick.as<u32>() + 33, sizeof(pval), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  for (int b = 0; b <= 32; ++b) p->b_slot[b] = (i64)pval[b];
+  p->nslot = (i64)pval[32];
+  if ((rc = pfd_dmalloc((void **)&p->scell, std::max<size_t>((size_t)p->nslot, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->sinfo, std::max<size_t>((size_t)p->nslot, 1) * sizeof(uint16_t) + 16)) != PFD_OK)
+    return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->cstart, std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->clen, std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if (npos) {
+    k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<u32>(), w.as<u32>(), hinfo.as<uint16_t>(), h->geo,
+                                                              (u32)npos, p->scell, p->sinfo);
+    k_plan_chains<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(cpos.as<u32>(), clenp.as<u32>(), w.as<u32>(), (u32)nchain,
+                                                                p->cstart, p->clen);
+  }
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(PFD_EHIP);
+  p->bytes = 2 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)nchain * 8;
+  h->bytes_held += p->bytes;
+  h->xplan_state = 1;
+  pfd_seg_end(h, 14);
+  if (getenv("PFD_DEBUG"))
+    fprintf(stderr, "[xplan] %lld cells: %lld trunk (%.1f%%) in %lld chains, %lld slots\n", (long long)h->n_valid,
+            (long long)p->ntrunk, 100.0 * (double)p->ntrunk / (double)std::max<i64>(h->n_valid, 1), (long long)p->nchain,
+            (long long)p->nslot);
+  return PFD_OK;
+}
+
+// debug export (tests / tools): plan summary; not part of the C-ABI contract
+extern "C" int pfd_debug_xplan(pfd_raster *h, int64_t info[8], uint8_t *lh_host) {
+  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_ensure_xplan(h));
+  for (int k = 0; k < 8; ++k) info[k] = 0;
+  info[0] = h->xplan_state;
+  if (h->xplan_state != 1) return PFD_OK;
+  ExactPlan *p = (ExactPlan *)h->xplan;
+  info[1] = p->ntrunk;
+  info[2] = p->nchain;
+  info[3] = p->nslot;
+  int nb = 0;
+  i64 longest = 0;
+  for (int b = 0; b < 32; ++b) nb += p->b_chain[b + 1] > p->b_chain[b];
+  info[4] = nb;
+  (void)longest;
+  if (lh_host) HIPCHK(hipMemcpy(lh_host, p->lh, (size_t)h->n, hipMemcpyDeviceToHost));
+  return PFD_OK;
+}

@@ -264,7 +264,7 @@ int pfd_adopt_counts(pfd_raster *h, const u64 *c) {
   }
   h->ordered = false;
   h->acyclic = 0;
-  pfd_free_chains(h);
+  pfd_free_xplan(h);
   h->aux_ready = false;
   h->pits_ready = false;  // the ascending pit list is compacted on first use
   h->normalised = true;
@@ -346,7 +346,7 @@ extern "C" int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k) {
   h->n_pits = (i64)c[C_NPITS];
   h->ordered = false;
   h->acyclic = 0;
-  pfd_free_chains(h);
+  pfd_free_xplan(h);
   h->aux_ready = false;
   h->n_seq = h->n_levels = -1;
   h->lvl_off.clear();

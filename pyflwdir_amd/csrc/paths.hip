@@ -294,8 +294,10 @@ __global__ void __launch_bounds__(256) k_xround(const u32 *__restrict__ Wo, u32 
 
 // one complete path query; on return *complete = 0 means cycles were found (caller falls back)
 template <int MODE>
-static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *complete, u32 *maxrank) {
+static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *complete, u32 *maxrank,
+                     const u8 *codes = nullptr) {
   *complete = 0;
+  if (!codes) codes = h->ncode;  // (exact.hip queries a derived forest: heavy links only)
   const u32 ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
   const u32 nstc = cdiv_u32(ntc, SG);
   const size_t nslots = (size_t)cdiv_u32(ntr, SG) * nstc * SSL;
@@ -307,7 +309,7 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   u32 *Wc = b + 3 * nslots, *Wn = b + 4 * nslots, *Jc = b + 5 * nslots, *Jn = b + 6 * nslots;
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 8 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(xtgt, 0xFF, nslots * sizeof(u32), h->stream));  // slots of tiles that do not exist
-  PathArgs a{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, h->ctrl};
+  PathArgs a{codes, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, h->ctrl};
   const dim3 grid(ntc, ntr);
   i64 launches = 2;
   k_path<MODE, false><<<grid, 256, 0, h->stream>>>(a);
@@ -345,6 +347,14 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   if (maxrank) *maxrank = (u32)c[P_MAXRANK - 8];
   (void)launches;
   return PFD_OK;
+}
+
+// path queries over a derived code raster (same shape as the handle's), for exact.hip
+int pfd_path_rank(pfd_raster *h, const u8 *codes, u32 *out_dev, int *complete) {
+  return run_paths<MODE_RANK>(h, nullptr, out_dev, complete, nullptr, codes);
+}
+int pfd_path_labels(pfd_raster *h, const u8 *codes, const u32 *seed_dev, u32 *out_dev, int *complete) {
+  return run_paths<MODE_LABEL>(h, seed_dev, out_dev, complete, nullptr, codes);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,199 +547,5 @@ extern "C" int pfd_graph_stats(pfd_raster *h, int64_t stats[16]) {
     PFDCHK(run_paths<MODE_RANK>(h, nullptr, nullptr, &complete, &maxrank));
     if (complete) stats[2] = (int64_t)maxrank;
   }
-  return PFD_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Heavy-chain layout (for exact up-sweeps at chain speed, sweeps.hip: k_chain_up).
-//
-// The critical path of an up-sweep is the main stem: one dependent update per cell, 30005 of them
-// at 30000 x 30000.  Level by level that is 30005 launches; along a CHAIN the running value can stay
-// in registers.  Decomposition: the heavy child of a cell is its upstream cell with the largest
-// upstream cell count (core.main_upstream's rule); a chain follows heavy links from a source down to
-// its TAIL, the first cell that is not the heavy child of its downstream cell (or a pit).
-//   tail(x)  = first "light" cell on the downstream path of x, x included  -> the tiled label query
-//   pos(x)   = rank(x) - rank(tail(x))                                      -> the tiled rank query
-//   len(t)   = pos(source of the chain) + 1
-// Chains are laid out contiguously, upstream end first, in DEPENDENCY ORDER: a tributary chain L
-// joins chain C at a cell p with uparea(p) >= 2 uparea(tail L) + 1 (the heavy sibling is at least as
-// large), so key(chain) = floor(log2(uparea(tail))) is strictly smaller for every chain another
-// chain waits for — 32 buckets, no sort.  Every value a cell needs then sits at a smaller layout
-// position than the cell itself.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 chain_kids_of(const u8 *__restrict__ ncode, const Geo &g, u32 x) {
-  const u32 r = geo_row(g, x), c = x - r * g.ncol;
-  u32 m = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    u32 nb;
-    if (d8_child(ncode, g, x, r, c, k, &nb)) m |= 1u << k;
-  }
-  return m;
-}
-// seed[x] = x + 1 on tails (light cells and pits), 0 elsewhere; kids[x] = child mask
-__global__ void __launch_bounds__(256) k_chain_seed(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ uparea,
-                                                    u32 *__restrict__ seed, u8 *__restrict__ kids) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= g.n) return;
-  const u32 c = ncode[x];
-  u32 s = 0, m = 0;
-  if (c != D8_MV) {
-    m = chain_kids_of(ncode, g, x);
-    if (!d8_is_dir(c)) {
-      s = x + 1;  // pit
-    } else {
-      const u32 p = d8_down(g, x, c);
-      const u32 pr = geo_row(g, p), pc = p - pr * g.ncol;
-      u32 best = 0, arg = NONE32;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {  // first maximum in ascending index (core.main_upstream, core.py:191-219)
-        const int k = PFD_SLOT_ASC[q];
-        u32 nb;
-        if (d8_child(ncode, g, p, pr, pc, k, &nb)) {
-          const u32 a = uparea[nb];
-          if (a > best) {
-            best = a;
-            arg = nb;
-          }
-        }
-      }
-      s = (arg == x) ? 0u : x + 1;
-    }
-  }
-  seed[x] = s;
-  kids[x] = (u8)m;
-}
-// the source of a chain (a cell without upstream cells) knows the length of its chain
-__global__ void __launch_bounds__(256) k_chain_len(const u8 *__restrict__ kids, const u8 *__restrict__ ncode,
-                                                   const u32 *__restrict__ rank, const u32 *__restrict__ tailnum, u32 n,
-                                                   u32 *__restrict__ len_at) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n || ncode[x] == D8_MV || kids[x] != 0) return;
-  const u32 tn = tailnum[x];
-  if (tn == 0) return;
-  len_at[tn - 1] = rank[x] - rank[tn - 1] + 1;
-}
-// pass 0: cells per bucket; pass 1: base position of every chain (bucket cursor, one global atomic
-// per bucket and workgroup)
-template <int PASS>
-__global__ void __launch_bounds__(256) k_chain_place(const u32 *__restrict__ seed, const u32 *__restrict__ uparea,
-                                                     const u32 *__restrict__ len_at, u32 n,
-                                                     unsigned long long *__restrict__ bucket, u32 *__restrict__ base_at) {
-  __shared__ u32 s_tot[32];
-  __shared__ unsigned long long s_base[32];
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (threadIdx.x < 32) s_tot[threadIdx.x] = 0;
-  __syncthreads();
-  const bool tail = t < n && seed[t] != 0;
-  u32 b = 0, len = 0, local = 0;
-  if (tail) {
-    b = 31u - (u32)__builtin_clz(uparea[t] | 1u);
-    len = len_at[t];
-    local = atomicAdd(&s_tot[b], len);
-  }
-  __syncthreads();
-  if (threadIdx.x < 32 && s_tot[threadIdx.x])
-    s_base[threadIdx.x] = atomicAdd(&bucket[threadIdx.x], (unsigned long long)s_tot[threadIdx.x]);
-  if (PASS == 1) {
-    __syncthreads();
-    if (tail) base_at[t] = (u32)(s_base[b] + local);
-  }
-}
-__global__ void __launch_bounds__(256) k_chain_scatter(const u32 *__restrict__ rank, const u32 *__restrict__ tailnum,
-                                                       const u32 *__restrict__ len_at, const u32 *__restrict__ base_at,
-                                                       u32 n, u32 *__restrict__ chain_seq, u32 *__restrict__ chain_pos) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n) return;
-  const u32 tn = tailnum[x];
-  u32 p = NONE32;
-  if (tn != 0) {
-    const u32 t = tn - 1;
-    p = base_at[t] + len_at[t] - 1 - (rank[x] - rank[t]);
-    chain_seq[p] = x;
-  }
-  chain_pos[x] = p;
-}
-
-void pfd_free_chains(pfd_raster *h) {
-  pfd_dfree(h->chain_seq);
-  pfd_dfree(h->chain_pos);
-  pfd_dfree(h->chain_done);
-  pfd_dfree(h->chain_kids);
-  h->chain_seq = h->chain_pos = h->chain_done = nullptr;
-  h->chain_kids = nullptr;
-  h->chains_state = 0;
-  h->n_chain = 0;
-}
-
-int pfd_ensure_chains(pfd_raster *h) {
-  if (h->chains_state != 0) return PFD_OK;
-  h->chains_state = -1;
-  if (h->n > 4294967294ll || h->halo_top || h->halo_bot) return PFD_OK;
-  const u32 n = h->geo.n;
-  DevBuf upa, rank, seed, tailnum, len_at, base_at, buckets;
-  PFDCHK(upa.alloc((size_t)n * sizeof(u32)));
-  int complete = 0;
-  PFDCHK(pfd_upstream_area_cell_tiled(h, (i32 *)upa.p, &complete));
-  if (!complete) return PFD_OK;  // cycles: the level engine keeps the reference's semantics for them
-  PFDCHK(rank.alloc((size_t)n * sizeof(u32)));
-  PFDCHK(run_paths<MODE_RANK>(h, nullptr, rank.as<u32>(), &complete, nullptr));
-  if (!complete) return PFD_OK;
-  PFDCHK(seed.alloc((size_t)n * sizeof(u32) + 64));
-  PFDCHK(pfd_dmalloc((void **)&h->chain_kids, (size_t)n));
-  const u32 grid = cdiv_u32(n, 256);
-  k_chain_seed<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, upa.as<u32>(), seed.as<u32>(), h->chain_kids);
-  KCHK();
-  PFDCHK(tailnum.alloc((size_t)n * sizeof(u32)));
-  PFDCHK(run_paths<MODE_LABEL>(h, seed.as<u32>(), tailnum.as<u32>(), &complete, nullptr));
-  if (!complete) return PFD_OK;
-  PFDCHK(len_at.alloc((size_t)n * sizeof(u32)));
-  PFDCHK(base_at.alloc((size_t)n * sizeof(u32)));
-  PFDCHK(buckets.alloc(32 * sizeof(unsigned long long)));
-  k_chain_len<<<grid, 256, 0, h->stream>>>(h->chain_kids, h->ncode, rank.as<u32>(), tailnum.as<u32>(), n,
-                                           len_at.as<u32>());
-  HIPCHK(hipMemsetAsync(buckets.p, 0, 32 * sizeof(unsigned long long), h->stream));
-  k_chain_place<0><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), upa.as<u32>(), len_at.as<u32>(), n,
-                                                buckets.as<unsigned long long>(), nullptr);
-  KCHK();
-  unsigned long long tot[32], cur[32];
-  HIPCHK(hipMemcpyAsync(tot, buckets.p, sizeof(tot), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  unsigned long long total = 0;
-  for (int b = 0; b < 32; ++b) {
-    cur[b] = total;
-    total += tot[b];
-  }
-  if (total != (unsigned long long)h->n_valid) {  // (every valid cell of an acyclic raster is in exactly one chain)
-    if (getenv("PFD_DEBUG")) fprintf(stderr, "[chains] %llu cells placed, %lld valid: not used\n", total, (long long)h->n_valid);
-    return PFD_OK;
-  }
-  HIPCHK(hipMemcpyAsync(buckets.p, cur, sizeof(cur), hipMemcpyHostToDevice, h->stream));
-  k_chain_place<1><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), upa.as<u32>(), len_at.as<u32>(), n,
-                                                buckets.as<unsigned long long>(), base_at.as<u32>());
-  KCHK();
-  const size_t units = (size_t)((total + 63) / 64);
-  PFDCHK(pfd_dmalloc((void **)&h->chain_seq, (size_t)std::max<unsigned long long>(total, 1) * sizeof(u32)));
-  PFDCHK(pfd_dmalloc((void **)&h->chain_pos, (size_t)n * sizeof(u32)));
-  PFDCHK(pfd_dmalloc((void **)&h->chain_done, std::max<size_t>(units, 1) * sizeof(u32)));
-  HIPCHK(hipMemsetAsync(h->chain_done, 0, std::max<size_t>(units, 1) * sizeof(u32), h->stream));
-  k_chain_scatter<<<grid, 256, 0, h->stream>>>(rank.as<u32>(), tailnum.as<u32>(), len_at.as<u32>(), base_at.as<u32>(), n,
-                                               h->chain_seq, h->chain_pos);
-  KCHK();
-  HIPCHK(hipStreamSynchronize(h->stream));  // the temporaries are released on return
-  h->n_chain = (i64)total;
-  h->chain_epoch = 0;
-  h->chains_state = 1;
-  return PFD_OK;
-}
-
-// debug export of the chain layout (tools/chain_analyse.py); not part of the C-ABI contract
-extern "C" int pfd_debug_chain_layout(pfd_raster *h, uint32_t *pos_host, uint32_t *seq_host, int64_t *n_chain) {
-  PFDCHK(pfd_check_handle(h));
-  PFDCHK(pfd_ensure_chains(h));
-  *n_chain = h->chains_state == 1 ? h->n_chain : -1;
-  if (h->chains_state != 1) return PFD_OK;
-  HIPCHK(hipMemcpy(pos_host, h->chain_pos, (size_t)h->n * sizeof(u32), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(seq_host, h->chain_seq, (size_t)h->n_chain * sizeof(u32), hipMemcpyDeviceToHost));
   return PFD_OK;
 }

@@ -21,6 +21,7 @@
 #include <unordered_set>
 
 #include "common.h"
+#include "exact.h"
 
 // Every ordered cell carries one byte of pre-decoded graph next to its index (built once per
 // ordering by k_seq_aux): the mask of the neighbour slots that drain into it (up-sweeps) and its
@@ -376,6 +377,51 @@ struct AccuUp {
     return acc;
   }
   __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
+  // ---- exact-order engine (exact_sweep.h) ----
+  typedef T LV;
+  typedef T Elem;
+  __device__ __forceinline__ T join(T acc, T a) const {
+    if (!has_nodata || (acc != nodata && a != nodata)) acc = Num<T>::add(acc, a);
+    return acc;
+  }
+  __device__ __forceinline__ T tile_init(u32 x, bool) const { return data.at(x); }
+  __device__ __forceinline__ T tile_combine(u32 l, u32 kids, const T *val) const {
+    T acc = val[l];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = slot_desc(q);
+      if (kids & (1u << k)) acc = join(acc, val[(int)l + slot_dr(k) * XT + slot_dc(k)]);
+    }
+    return acc;
+  }
+  __device__ __forceinline__ void tile_store(u32 x, T v) const { out[x] = v; }
+  // own payload + the light upstream cells that precede the heavy one (slot hs) in the serial loop's order
+  __device__ __forceinline__ T pre_real(u32 x, u32 kids, u32 hs) const {
+    u32 m = 0;
+    bool before = true;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = slot_desc(q);
+      if ((u32)k == hs) before = false;
+      else if (before && (kids & (1u << k))) m |= 1u << k;
+    }
+    T v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // all needed loads in flight together
+      const int k = slot_desc(q);
+      v[q] = (m & (1u << k)) ? out[nb_of(g, x, k)] : T();
+    }
+    T acc = data.at(x);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (m & (1u << slot_desc(q))) acc = join(acc, v[q]);
+    return acc;
+  }
+  __device__ __forceinline__ T pre_post(u32 child) const { return out[child]; }
+  __device__ __forceinline__ T first(T e) const { return e; }
+  // real slot: accumulator = the cell's own part, operand = the heavy upstream cell's value (the running
+  // value); post slot: accumulator = the running value, operand = the light upstream cell
+  __device__ __forceinline__ T fold(T t, T e, bool post) const { return post ? join(t, e) : join(e, t); }
 };
 
 template <class T, class D = CellData<T>>
@@ -394,6 +440,14 @@ struct AccuDown {
     return a;
   }
   __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
+  // ---- exact-order engine ----
+  typedef T DElem;
+  __device__ __forceinline__ T dpre(u32 x, u32) const { return data.at(x); }
+  __device__ __forceinline__ T droot(T e) const { return e; }
+  __device__ __forceinline__ T dfold(T e, T pv) const {
+    if (!has_nodata || (pv != nodata && e != nodata)) e = Num<T>::add(e, pv);
+    return e;
+  }
 };
 
 // FlwdirRaster.upstream_area(unit="cell"): unit weights, nothing read but the codes
@@ -495,6 +549,56 @@ struct Strahler {
     return cnt >= 2 ? m + 1 : m;
   }
   __device__ __forceinline__ void store(u32 x, u32 v) const { out[x] = (u8)v; }
+  // ---- exact-order engine: the closed form is order-independent, so the light upstream cells of a
+  // trunk cell are folded into ONE element (max order, how many hold it) and post slots pass through.
+  // LDS image of a tile: bit 7 = the cell is inside the mask, bits 0-6 = its order (an order of 128 would
+  // need 2^127 cells)
+  typedef u8 LV;
+  typedef u32 Elem;
+  __device__ __forceinline__ u8 tile_init(u32 x, bool nodata_cell) const {
+    if (nodata_cell) return 0;
+    const u32 m = (mask == nullptr || mask[x]) ? 1u : 0u;
+    return (u8)((m << 7) | m);  // a headwater: 1 inside the mask, 0 outside
+  }
+  __device__ __forceinline__ u8 tile_combine(u32 l, u32 kids, const u8 *val) const {
+    const u32 own = val[l] >> 7;
+    u32 m = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (kids & (1u << k)) {
+        const u32 c = val[(int)l + slot_dr(k) * XT + slot_dc(k)];
+        if (c & 0x80u) join(c & 0x7Fu, m, cnt);
+      }
+    }
+    const u32 r = cnt == 0 ? own : (cnt >= 2 ? m + 1 : m);
+    return (u8)((own << 7) | (r & 0x7Fu));
+  }
+  __device__ __forceinline__ void tile_store(u32 x, u8 v) const { out[x] = v & 0x7Fu; }
+  // element: bits 0-7 max order of the light cells inside the mask, 8-9 min(their count of it, 3),
+  // 10 heavy cell inside the mask, 11 own cell inside the mask, 31 post slot (no-op)
+  __device__ __forceinline__ u32 pre_real(u32 x, u32 kids, u32 hs) const {
+    u32 m = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 nb = nb_of(g, x, k);
+      if ((kids & (1u << k)) && (u32)k != hs && (mask == nullptr || mask[nb])) join((u32)out[nb], m, cnt);
+    }
+    u32 hin = 0;
+    if (hs < 8) hin = (mask == nullptr || mask[nb_of(g, x, (int)hs)]) ? 1u : 0u;
+    const u32 own = (mask == nullptr || mask[x]) ? 1u : 0u;
+    return m | ((cnt > 3 ? 3u : cnt) << 8) | (hin << 10) | (own << 11);
+  }
+  __device__ __forceinline__ u32 pre_post(u32) const { return 0x80000000u; }
+  __device__ __forceinline__ u32 first(u32 e) const {
+    const u32 m = e & 0xFFu, cnt = (e >> 8) & 3u;
+    return cnt == 0 ? ((e >> 11) & 1u) : (cnt >= 2 ? m + 1 : m);
+  }
+  __device__ __forceinline__ u32 fold(u32 t, u32 e, bool post) const {
+    if (post) return t;
+    u32 m = e & 0xFFu, cnt = (e >> 8) & 3u;
+    if (e & (1u << 10)) join(t & 0xFFu, m, cnt);
+    return cnt == 0 ? ((e >> 11) & 1u) : (cnt >= 2 ? m + 1 : m);
+  }
 };
 
 template <class L>
@@ -532,262 +636,42 @@ struct Hand {
     return (root ? 0.0 : pv) + (double)dz;
   }
   __device__ __forceinline__ void store(u32 x, double v) const { out[x] = v; }
-};
-
-// ---------------------------------------------------------------------------------------------
-// Chain sweep — EXPERIMENTAL, off by default (env PFD_CHAIN_UP=1; layout: paths.hip, pfd_ensure_chains).
-// Status (r01): bit-exact on every golden / fuzz case, but 53 ms against 25 ms for the 2-hop level sweep on
-// the 10000 x 10000 river raster (14 vs 4.6 ms on the rough one): the critical path is gone, what is left is
-// the volume of scattered accesses (~800 cache-line transactions per 64-cell unit: neighbour positions,
-// payload, granules, results of cells that are contiguous in the chain layout but not in the raster).
-// Kept as the starting point for a locality-aware layout (what comes next).
-//
-// Work unit = 64 consecutive positions of the chain layout = one wave.  Waves claim units in layout
-// order from a counter; every value a cell needs sits at a smaller layout position, so the earliest
-// unfinished unit can always proceed: no deadlock, whatever the number of resident waves.
-//   * children in an EARLIER unit: wait for that unit's done mark (relaxed agent-scope polls, one
-//     acquire fence afterwards, then plain loads — MI355X_MICROARCH.md, inter-workgroup visibility);
-//   * children in the SAME unit (the heavy child is the previous lane; short tributary chains):
-//     resolved in rounds through LDS — a lane computes once all its in-unit children are resolved.
-// The arithmetic is the op's own `combine` (children in the reference's order): bit-identical.
-// A spin that exceeds its budget raises an error flag instead of hanging the GPU.
-// ---------------------------------------------------------------------------------------------
-enum { CH_NEXT = 48, CH_ERROR = 49 };  // ctrl slots (u64)
-#define CH_NONE 0xFFFFFFFFu
-// write-through ("sc1") stores and L1-bypassing loads: the only inter-workgroup traffic of the chain
-// sweep goes through them, so no release/acquire FENCE is needed (an agent-scope release fence writes
-// back the whole XCD L2 — measured: 0.6 us per unit, serialised — MI355X_MICROARCH.md, "valid forms")
-template <class V> struct Coh;
-template <> struct Coh<u32> {
-  static __device__ __forceinline__ void st(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  static __device__ __forceinline__ u32 ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-};
-template <> struct Coh<u64> {
-  static __device__ __forceinline__ void st(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  static __device__ __forceinline__ u64 ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-};
-template <class V, int N = sizeof(V)> struct Bits;
-template <class V> struct Bits<V, 4> {
-  typedef u32 U;
-};
-template <class V> struct Bits<V, 8> {
-  typedef u64 U;
-};
-template <class V>
-__device__ __forceinline__ void coh_store(V *p, V v) {
-  typedef typename Bits<V>::U U;
-  U b;
-  __builtin_memcpy(&b, &v, sizeof(V));
-  Coh<U>::st((U *)p, b);
-}
-template <class V>
-__device__ __forceinline__ V coh_load(const V *p) {
-  typedef typename Bits<V>::U U;
-  const U b = Coh<U>::ld((const U *)p);
-  V v;
-  __builtin_memcpy(&v, &b, sizeof(V));
-  return v;
-}
-
-// Exchange granule of one layout position: the value and a ready tag.  4-byte values travel with
-// their tag in ONE 8-byte write-through store (untorn: no ordering needed at all); 8-byte values are
-// stored first, drained (s_waitcnt vmcnt(0)), then tagged.
-template <class V, int N = sizeof(V)> struct Gran;
-template <class V> struct Gran<V, 4> {
-  typedef u64 Slot;
-  static __device__ __forceinline__ void put(Slot *p, V v) {
-    u32 b;
-    __builtin_memcpy(&b, &v, 4);
-    Coh<u64>::st(p, (u64)b | (1ull << 32));
-  }
-  static __device__ __forceinline__ bool get(const Slot *p, V *v) {
-    const u64 g = Coh<u64>::ld(p);
-    const u32 b = (u32)g;
-    __builtin_memcpy(v, &b, 4);
-    return (g >> 32) != 0;
-  }
-};
-template <class V> struct Gran<V, 8> {
-  struct Slot {
-    u64 val, tag;
+  // ---- exact-order engine ----
+  struct DElem {
+    double dz;
+    u32 is_drain, pad;
   };
-  static __device__ __forceinline__ void put(Slot *p, V v) {
-    u64 b;
-    __builtin_memcpy(&b, &v, 8);
-    Coh<u64>::st(&p->val, b);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    Coh<u64>::st(&p->tag, 1ull);
+  __device__ __forceinline__ DElem dpre(u32 x, u32 code) const {
+    DElem e;
+    e.is_drain = drain[x] == 1 ? 1u : 0u;
+    const E dz = elev[x] - elev[d8_down(g, x, code)];
+    e.dz = (double)dz;
+    e.pad = 0;
+    return e;
   }
-  static __device__ __forceinline__ bool get(const Slot *p, V *v) {
-    if (Coh<u64>::ld(&p->tag) == 0) return false;
-    const u64 b = Coh<u64>::ld(&p->val);
-    __builtin_memcpy(v, &b, 8);
-    return true;
-  }
+  __device__ __forceinline__ double droot(const DElem &e) const { return e.is_drain ? 0.0 : 0.0 + e.dz; }
+  __device__ __forceinline__ double dfold(const DElem &e, double pv) const { return e.is_drain ? 0.0 : pv + e.dz; }
 };
 
-// One wave per GROUP of CH_GROUP consecutive 64-cell units, processed in order.  A lane resolves as
-// soon as ITS inputs are there and publishes its granule at once, so a unit never holds back values
-// other units wait for.  Inputs: children in this unit -> LDS (s_val); children in the previous unit of
-// the same group (a chain that straddles the unit border — the common short-distance dependency) -> LDS
-// (s_prev); everything else -> the granule, polled only while no lane can make progress, and at most
-// two granules per lane and poll.
-enum { CH_GROUP = 1, CH_CHUNK = 16, CH_STRIDE = 512 };
-template <class Op>
-__global__ void __launch_bounds__(64) k_chain_up(Op op, const u32 *__restrict__ chain_seq,
-                                                 const u32 *__restrict__ chain_pos, const u8 *__restrict__ kids_cell,
-                                                 u32 total, typename Gran<typename Op::V>::Slot *stage, u64 *ctrl,
-                                                 int ablate) {
-  typedef typename Op::V V;
-  typedef Gran<V> G;
-  __shared__ V s_val[64], s_prev[64];
-  const u32 lane = threadIdx.x;
-  const u32 nunits = (total + 63u) >> 6;
-  const u32 ngroups = (nunits + CH_GROUP - 1) / CH_GROUP;
-  u32 ticket = 0, it = 0;
-  for (;;) {
-    // tickets: one atomic per CH_CHUNK units (same-address atomics cost ~12 ns each, serialised); ticket
-    // t owns units base + j * CH_STRIDE, j < CH_CHUNK, of its super-block, so that units are still
-    // started in (roughly) layout order by all waves together
-    u32 grp = 0;
-    if (it == 0) {
-      if (lane == 0) ticket = (u32)atomicAdd((unsigned long long *)&ctrl[CH_NEXT], 1ull);
-      ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
-    }
-    grp = (ticket / CH_STRIDE) * (CH_STRIDE * CH_CHUNK) + (ticket % CH_STRIDE) + it * CH_STRIDE;
-    it = (it + 1) % CH_CHUNK;
-    if (grp >= ngroups) {
-      if ((ticket / CH_STRIDE) * (CH_STRIDE * CH_CHUNK) >= ngroups) return;  // past the last super-block
-      continue;
-    }
-    for (u32 gi = 0; gi < CH_GROUP; ++gi) {
-      const u32 u = grp * CH_GROUP + gi;
-      if (u >= nunits) break;
-      const u32 i = (u << 6) + lane;
-      const bool active = i < total;
-      const u32 x = active ? chain_seq[i] : 0u;
-      const u32 kids = active ? (u32)kids_cell[x] : 0u;
-      // layout positions of the children (unconditional loads from clamped addresses)
-      u32 cpos[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const i64 j = (i64)x + (i64)d8_dr(k) * (i64)op.g.ncol + d8_dc(k);
-        const u32 pc = chain_pos[j < 0 ? 0 : (j >= (i64)op.g.n ? (i64)op.g.n - 1 : j)];
-        cpos[k] = (kids & (1u << k)) ? pc : CH_NONE;
-      }
-      u32 ext = 0, prevu = 0;  // children behind granules / in the previous unit of this group (LDS)
-      u64 need = 0;            // lanes of this unit the cell waits for
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (cpos[k] == CH_NONE) continue;
-        const u32 cu = cpos[k] >> 6;
-        if (cu == u)
-          need |= 1ull << (cpos[k] & 63u);
-        else if (gi > 0 && cu + 1 == u)
-          prevu |= 1u << k;
-        else
-          ext |= 1u << k;
-      }
-      V cv[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) cv[k] = (prevu & (1u << k)) ? s_prev[cpos[k] & 63u] : V();
-      u32 pending = (ablate & 2) ? 0u : ext;
-      bool resolved = !active;
-      V myval = V();
-      u32 spins = 0, backoff = 1;
-      bool progress = false;  // the first pass polls (the values have to be fetched anyway)
-      for (;;) {
-        const u64 R = __ballot((int)resolved);
-        if (R == ~0ull) break;
-        if (!progress && __any((int)(pending != 0))) {
-          // poll the first two pending granules of the lane, both loads in flight together
-          const u32 k0 = pending ? (u32)__builtin_ctz(pending) : 0u;
-          const u32 rest = pending & (pending - 1u);
-          const u32 k1 = rest ? (u32)__builtin_ctz(rest) : k0;
-          u32 p0 = i, p1 = i;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            if (pending && (u32)k == k0) p0 = cpos[k];
-            if (rest && (u32)k == k1) p1 = cpos[k];
-          }
-          V t0 = V(), t1 = V();
-          bool ok0 = false, ok1 = false;
-          if (pending) {  // only lanes that wait issue loads (both in flight together)
-            ok0 = G::get(&stage[p0], &t0);
-            ok1 = G::get(&stage[p1], &t1);
-          }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            if (pending && (u32)k == k0 && ok0) cv[k] = t0;
-            if (rest && (u32)k == k1 && ok1) cv[k] = t1;
-          }
-          if (pending && ok0) pending &= ~(1u << k0);
-          if (rest && ok1) pending &= ~(1u << k1);
-          ++spins;
-          if (!__any((int)(ok0 || ok1))) {  // nothing arrived: back off (64 cycles .. ~2 us)
-            backoff = backoff < 64u ? backoff * 2u : 64u;
-            for (u32 b = 0; b < backoff; ++b) __builtin_amdgcn_s_sleep(1);
-          } else {
-            backoff = 1;
-          }
-        }
-        const bool go = !resolved && pending == 0 && (need & ~R) == 0;
-        if (go) {
-          myval = op.combine(x, kids, [&](u32, int k) { return (need && !((ext | prevu) & (1u << k))) ? s_val[cpos[k] & 63u] : cv[k]; });
-          s_val[lane] = myval;
-          resolved = true;
-          op.store(x, myval);        // the result (plain store: nobody reads it inside this kernel)
-          G::put(&stage[i], myval);  // the granule other groups poll
-        }
-        progress = __any((int)go) != 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (spins > (1u << 22) || ((spins & 255u) == 255u && Coh<u64>::ld(&ctrl[CH_ERROR]))) {
-          if (lane == 0) Coh<u64>::st(&ctrl[CH_ERROR], (u64)1);
-          return;  // (the host reports the failure; nothing hangs)
-        }
-      }
-      s_prev[lane] = myval;  // the next unit of the group reads its straddling chain from here
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      if ((ablate & 8) && lane == 0) atomicAdd((unsigned long long *)&ctrl[50], (unsigned long long)spins);
-    }
-  }
-}
+#include "exact_sweep.h"
 
-// returns *used = 1 if the sweep ran on the chain layout
+// up-/down-sweep of an operation: the exact-order engine when the raster has a plan (no cycles, whole
+// raster), else the level engine
 template <class Op>
-static int run_up_chains(pfd_raster *h, const Op &op, const char *name, int *used) {
-  *used = 0;
-  if (!getenv("PFD_CHAIN_UP")) return PFD_OK;
-  PFDCHK(pfd_ensure_chains(h));
-  if (h->chains_state != 1 || h->n_chain == 0) return PFD_OK;
-  typedef typename Gran<typename Op::V>::Slot Slot;
-  pfd_seg_begin(h, name);
-  HIPCHK(hipMemsetAsync(h->ctrl + CH_NEXT, 0, 8 * sizeof(u64), h->stream));
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const u32 nunits = (u32)((h->n_chain + 63) / 64);
-  const u32 grid = std::min<u32>((nunits + CH_GROUP - 1) / CH_GROUP, (u32)cus * 32u);
-  DevBuf stage;
-  PFDCHK(stage.alloc((size_t)nunits * 64 * sizeof(Slot)));
-  HIPCHK(hipMemsetAsync(stage.p, 0, (size_t)nunits * 64 * sizeof(Slot), h->stream));  // tags: not ready
-  const int ablate = getenv("PFD_CHAIN_ABLATE") ? atoi(getenv("PFD_CHAIN_ABLATE")) : 0;
-  k_chain_up<Op><<<grid, 64, 0, h->stream>>>(op, h->chain_seq, h->chain_pos, h->chain_kids, (u32)h->n_chain,
-                                             (Slot *)stage.p, h->ctrl, ablate);
-  KCHK();
-  u64 c[8];
-  HIPCHK(hipMemcpyAsync(c, h->ctrl + CH_NEXT, sizeof(c), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  pfd_seg_end(h, 2);
-  if (ablate & 8) fprintf(stderr, "[chain] units %u, polls per unit %.1f\n", nunits, (double)c[2] / nunits);
-  if (c[1]) {
-    pfd_set_error("chain sweep: a unit waited for its inputs longer than the spin budget");
-    return PFD_EHIP;
-  }
-  *used = 1;
-  return PFD_OK;
+static int sweep_up(pfd_raster *h, const Op &op, const char *name, const char *xname) {
+  if (h->xplan_state == 1) return run_exact_up(h, op, xname);
+  return run_up(h, op, name);
+}
+template <class Op>
+static int sweep_down(pfd_raster *h, const Op &op, const char *name, const char *xname) {
+  if (h->xplan_state == 1) return run_exact_down(h, op, xname);
+  return run_down(h, op, name);
+}
+// the structure the sweeps of a handle run on: the exact plan, or the level structure
+static int ensure_sweep_structure(pfd_raster *h) {
+  PFDCHK(pfd_ensure_xplan(h));
+  if (h->xplan_state == 1) return PFD_OK;
+  return pfd_order_cells_impl(h);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -953,31 +837,30 @@ static int accuflux_t(pfd_raster *h, const void *data, bool by_row, T nodata, in
       return o.finish(h->stream);
     }
   }
-  PFDCHK(pfd_order_cells_impl(h));
-  pfd_seg_begin(h, "init");
-  if (by_row) {
-    k_fill_rows<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((const T *)d.dev, h->geo, (T *)o.dev);
-    KCHK();
-  } else {
-    HIPCHK(hipMemcpyAsync(o.dev, d.dev, (size_t)h->n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+  PFDCHK(ensure_sweep_structure(h));
+  // (the exact engine's tile pass writes every cell of an up-sweep from the payload: no initial copy)
+  if (!(h->xplan_state == 1 && direction == PFD_UP)) {
+    pfd_seg_begin(h, "init");
+    if (by_row) {
+      k_fill_rows<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((const T *)d.dev, h->geo, (T *)o.dev);
+      KCHK();
+    } else {
+      HIPCHK(hipMemcpyAsync(o.dev, d.dev, (size_t)h->n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    }
+    pfd_seg_end(h, 1);
   }
-  pfd_seg_end(h, 1);
   if (direction == PFD_UP && by_row) {
     AccuUp<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
-    int used = 0;
-    PFDCHK(run_up_chains(h, op, "chain_accuflux_up", &used));
-    if (!used) PFDCHK(run_up(h, op, "sweep_accuflux_up"));
+    PFDCHK(sweep_up(h, op, "sweep_accuflux_up", "exact_accuflux_up"));
   } else if (direction == PFD_UP) {
     AccuUp<T> op{h->ncode, h->geo, CellData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
-    int used = 0;
-    PFDCHK(run_up_chains(h, op, "chain_accuflux_up", &used));
-    if (!used) PFDCHK(run_up(h, op, "sweep_accuflux_up"));
+    PFDCHK(sweep_up(h, op, "sweep_accuflux_up", "exact_accuflux_up"));
   } else if (by_row) {
     AccuDown<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
-    PFDCHK(run_down(h, op, "sweep_accuflux_down"));
+    PFDCHK(sweep_down(h, op, "sweep_accuflux_down", "exact_accuflux_down"));
   } else {
     AccuDown<T> op{h->ncode, h->geo, CellData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
-    PFDCHK(run_down(h, op, "sweep_accuflux_down"));
+    PFDCHK(sweep_down(h, op, "sweep_accuflux_down", "exact_accuflux_down"));
   }
   if (mask_invalid) {
     k_mask_invalid<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, (T *)o.dev, nodata);
@@ -1027,16 +910,18 @@ extern "C" int pfd_strahler(pfd_raster *h, const uint8_t *mask, uint8_t *out, in
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  PFDCHK(pfd_order_cells_impl(h));
+  PFDCHK(ensure_sweep_structure(h));
   InArg m;
   PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n, memspace));
-  pfd_seg_begin(h, "init");
-  HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
-  pfd_seg_end(h, 1);
+  if (h->xplan_state != 1) {  // (the exact engine's tile pass writes every cell)
+    pfd_seg_begin(h, "init");
+    HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
+    pfd_seg_end(h, 1);
+  }
   Strahler op{h->ncode, h->geo, (const u8 *)m.dev, (u8 *)o.dev};
-  PFDCHK(run_up(h, op, "sweep_strahler"));
+  PFDCHK(sweep_up(h, op, "sweep_strahler", "exact_strahler"));
   return o.finish(h->stream);
 }
 
@@ -1114,7 +999,7 @@ static int hand_t(pfd_raster *h, const u8 *drain_dev, const void *elev_dev, doub
   KCHK();
   pfd_seg_end(h, 1);
   Hand<E> op{h->ncode, h->geo, drain_dev, (const E *)elev_dev, out_dev};
-  return run_down(h, op, "sweep_hand");
+  return sweep_down(h, op, "sweep_hand", "exact_hand");
 }
 
 extern "C" int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, double *out,
@@ -1125,7 +1010,7 @@ extern "C" int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, con
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  PFDCHK(pfd_order_cells_impl(h));
+  PFDCHK(ensure_sweep_structure(h));
   InArg dr, el;
   PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
   PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
@@ -1213,6 +1098,13 @@ struct Classic {
     return root ? 1u : ((pv + flag[x]) & 0xFFu);  // uint8 arithmetic like the reference
   }
   __device__ __forceinline__ void store(u32 x, u32 v) const { out[x] = (u8)v; }
+  // ---- exact-order engine: bit 0 = tributary flag, bit 1 = outside the mask ----
+  typedef u32 DElem;
+  __device__ __forceinline__ u32 dpre(u32 x, u32) const {
+    return (u32)flag[x] | ((mask != nullptr && !mask[x]) ? 2u : 0u);
+  }
+  __device__ __forceinline__ u32 droot(u32 e) const { return (e & 2u) ? 0u : 1u; }
+  __device__ __forceinline__ u32 dfold(u32 e, u32 pv) const { return (e & 2u) ? 0u : ((pv + (e & 1u)) & 0xFFu); }
 };
 
 template <class T>
@@ -1236,6 +1128,25 @@ struct Dist {
     return (T)((u32)pv + 1u);
   }
   __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
+  // ---- exact-order engine: the step length of the cell (1 in cell units), negative = the distance restarts ----
+  typedef T DElem;
+  __device__ __forceinline__ T dpre(u32 x, u32 code) const {
+    if (!d8_is_dir(code) || (mask != nullptr && mask[x])) return (T)-1;
+    if (dtab != nullptr) {
+      const int k = d8_slot(code);
+      const int dr = d8_dr(k), dc = d8_dc(k);
+      const u32 s = 2u * geo_row(g, x) + (u32)dr;
+      const int kind = (dr != 0 && dc != 0) ? 2 : (dr != 0 ? 0 : 1);
+      return (T)dtab[3u * s + (u32)kind];
+    }
+    return (T)1;
+  }
+  __device__ __forceinline__ T droot(T) const { return (T)0; }
+  __device__ __forceinline__ T dfold(T e, T pv) const {
+    if (e < (T)0) return (T)0;
+    if (dtab != nullptr) return (T)((float)pv + (float)e);
+    return (T)((u32)pv + 1u);
+  }
 };
 
 template <class T, class I>
@@ -1297,7 +1208,7 @@ extern "C" int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  PFDCHK(pfd_order_cells_impl(h));
+  PFDCHK(ensure_sweep_structure(h));
   InArg mu, m;
   PFDCHK(mu.bind(idxs_us_main, (size_t)h->n * es, memspace, h->stream));
   PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
@@ -1317,7 +1228,7 @@ extern "C" int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void
   KCHK();
   pfd_seg_end(h, 2);
   Classic op{h->ncode, h->geo, flag.as<u8>(), (const u8 *)m.dev, (u8 *)o.dev};
-  PFDCHK(run_down(h, op, "sweep_classic_order"));
+  PFDCHK(sweep_down(h, op, "sweep_classic_order", "exact_classic_order"));
   return o.finish(h->stream);  // (synchronises: `flag` may be released afterwards)
 }
 
@@ -1329,7 +1240,7 @@ extern "C" int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  PFDCHK(pfd_order_cells_impl(h));
+  PFDCHK(ensure_sweep_structure(h));
   InArg m, tab;
   PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
   if (real_length)  // the table always comes from the host
@@ -1345,10 +1256,10 @@ extern "C" int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_
   pfd_seg_end(h, 1);
   if (real_length) {
     Dist<float> op{h->ncode, h->geo, (const u8 *)m.dev, (const float *)tab.dev, (float *)o.dev};
-    PFDCHK(run_down(h, op, "sweep_stream_distance"));
+    PFDCHK(sweep_down(h, op, "sweep_stream_distance", "exact_stream_distance"));
   } else {
     Dist<i32> op{h->ncode, h->geo, (const u8 *)m.dev, nullptr, (i32 *)o.dev};
-    PFDCHK(run_down(h, op, "sweep_stream_distance"));
+    PFDCHK(sweep_down(h, op, "sweep_stream_distance", "exact_stream_distance"));
   }
   return o.finish(h->stream);  // (synchronises: the staged table may be released afterwards)
 }

@@ -138,15 +138,19 @@ def test_level4_round_budget_miss(gpu_lib, oracle, monkeypatch):
     assert np.array_equal(dist.upstream_area_blocks(d8, 2), exp)
 
 
-def test_experimental_chain_sweep(gpu_lib, oracle, monkeypatch):
-    """The opt-in chain sweep (PFD_CHAIN_UP=1: heavy-chain layout + dataflow kernel, sweeps.hip) must stay
-    bit-identical to the reference's accuflux for floats and ints, with and without in-domain nodata."""
+@pytest.mark.parametrize("engine", ["exact", "levels"])
+def test_exact_engine_accuflux(gpu_lib, oracle, monkeypatch, engine):
+    """float / int accuflux through the exact-order engine (tile leaves + heavy-chain trunk, exact.hip) and,
+    forced by PFD_EXACT_LEVELS=1, through the level engine: both bit-identical to the reference's serial
+    loop, with and without in-domain nodata, rasters spanning many tiles."""
     import pyflwdir_amd as pyflwdir
 
     O = oracle
-    monkeypatch.setenv("PFD_CHAIN_UP", "1")
+    if engine == "levels":
+        monkeypatch.setenv("PFD_EXACT_LEVELS", "1")
     for shape, seed, kw in [((1500, 2100), 3, dict(tilt=1 << 26, white=2, nodata_pct=0)),
-                            ((1024, 1024), 4, dict(tilt=100000, white=2, nodata_pct=30))]:
+                            ((1024, 1024), 4, dict(tilt=100000, white=2, nodata_pct=30)),
+                            ((700, 900), 5, dict(tilt=3000, white=2, nodata_pct=3))]:
         d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
         idxs_ds, idxs_pit, _ = O.from_array(d8)
         seq = O.idxs_seq(idxs_ds, idxs_pit)
@@ -154,13 +158,20 @@ def test_experimental_chain_sweep(gpu_lib, oracle, monkeypatch):
         flw._h.set_profiling(True)
         w = O.synth_weights_f32(d8.size, seed=1)
         assert np.array_equal(flw.accuflux(w.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, w))
-        assert any(s["name"] == "chain_accuflux_up" for s in flw._h.last_timing())  # the chain path did run
+        ran = [s["name"] for s in flw._h.last_timing()]
+        assert ("exact_accuflux_up" in ran) == (engine == "exact"), ran
         w64 = w.astype(np.float64) * 3.25
         w64[::17] = -9999.0
         assert np.array_equal(flw.accuflux(w64.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, w64))
+        assert np.array_equal(flw.accuflux(w64.reshape(shape), direction="down").ravel(),
+                              O.accuflux(idxs_ds, seq, w64, direction="down"))
         wi = (w * 1000).astype(np.int32)
+        wi[::13] = -7
         assert np.array_equal(flw.accuflux(wi.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wi))
-        assert np.array_equal(flw.upstream_area("km2"), flw.upstream_area("km2"))
+        wl = wi.astype(np.int64) * 100000
+        assert np.array_equal(flw.accuflux(wl.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wl))
+        assert np.array_equal(flw.accuflux(w.reshape(shape), direction="down").ravel(),
+                              O.accuflux(idxs_ds, seq, w, direction="down"))
 
 
 def test_basins_outlet_on_a_cycle(gpu_lib, oracle):

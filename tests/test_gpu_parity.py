@@ -23,12 +23,22 @@ def case(request, manifest):
     return Case(request.param, manifest)
 
 
-@pytest.fixture(scope="module")
-def flw(case, gpu_lib):
+@pytest.fixture(scope="module", params=["exact", "levels"])
+def flw(request, case, gpu_lib):
+    """Every golden case runs twice: order-sensitive sweeps through the exact-order engine (exact.hip; the
+    default on rasters without cycles) and, with PFD_EXACT_LEVELS=1, through the level engine."""
+    import os
+
     import pyflwdir_amd as pyflwdir
     from pyflwdir_amd._affine import Affine
 
-    return pyflwdir.from_array(case.d8, ftype="d8", transform=Affine(*case.transform), latlon=case.latlon, cache=False)
+    if request.param == "levels":
+        os.environ["PFD_EXACT_LEVELS"] = "1"
+    try:
+        yield pyflwdir.from_array(case.d8, ftype="d8", transform=Affine(*case.transform), latlon=case.latlon,
+                                  cache=False)
+    finally:
+        os.environ.pop("PFD_EXACT_LEVELS", None)
 
 
 def test_graph_exports(case, flw):
