@@ -9,9 +9,10 @@
 //           high: a tile kernel resolves them in LDS, step by step, in a precomputed per-tile order;
 //   TRUNK   every other cell.  The trunk is cut into heavy chains (heavy child = upstream TRUNK cell with
 //           the largest upstream area); chains are laid out contiguously, upstream end first, grouped by
-//           bucket = floor(log2(upstream area of the chain's last cell)) — a chain only depends on chains
-//           of lower buckets.  Per bucket: a parallel pre-pass gathers, per layout slot, everything that
-//           does not depend on the chain itself (own payload + light upstream cells, already final); one
+//           ROUND = 31 - (light cells between the chain's last cell and the pit; at most log2(n) of them) — a
+//           chain only depends on chains of earlier rounds, and all main stems share the last round.  Per
+//           round: a parallel pre-pass gathers, per layout slot, everything that does not depend on the
+//           chain itself (own payload + light upstream cells, already final); one
 //           LANE per chain then folds the slots serially (running value in a register, loads software-
 //           pipelined); a parallel scatter writes the results back to the raster.
 //
@@ -30,6 +31,7 @@
 // sinfo (u16 per slot): bits 0-7 child mask, 8-11 slot of the heavy child (8 = none: chain head),
 // 12-14 number of post slots that follow, 15 = this is a post slot (scell = the upstream cell it carries)
 #define XS_POST 0x8000u
+#define XC_LEN 0x1FFFFFFFu  // clen: length bits
 
 struct ExactPlan {
   u32 ntr = 0, ntc = 0;
@@ -39,11 +41,12 @@ struct ExactPlan {
   uint16_t *toff = nullptr;  // [ntiles * XOFF] start of step s in tord; entries past the last step = total
   u32 *scell = nullptr;   // [nslot]
   uint16_t *sinfo = nullptr;  // [nslot]
-  u32 *cstart = nullptr;  // [nchain] first slot of the chain
-  u32 *clen = nullptr;    // [nchain] slots in the chain
+  u32 *spost = nullptr;   // [nslot / 32 + 4] bit s = slot s is a post slot (what the serial fold needs of sinfo)
+  u32 *cstart = nullptr;  // [nchain] first slot of the chain (a multiple of 4: chains are padded)
+  u32 *clen = nullptr;    // [nchain] slots in the chain | post slots behind its last cell << 29
   i64 nslot = 0, nchain = 0, ntrunk = 0;
-  i64 b_chain[33] = {0};  // chains of bucket b = [b_chain[b], b_chain[b+1])
-  i64 b_slot[33] = {0};   // slots  of bucket b = [b_slot[b],  b_slot[b+1])
+  i64 b_chain[33] = {0};  // chains of round b = [b_chain[b], b_chain[b+1])
+  i64 b_slot[33] = {0};   // slots  of round b = [b_slot[b],  b_slot[b+1])
   size_t bytes = 0;
 };
 

@@ -199,13 +199,58 @@ __global__ void __launch_bounds__(256) k_plan_len(const u8 *__restrict__ lh, con
   if (tn) len_at[tn - 1] = hops[x] + 1;
 }
 
+// Round of a chain = 31 - (number of light cells between its last cell and the pit): the chain a
+// tributary joins runs one round later, and all the main stems (chains ending in a pit) share the LAST
+// round, so independent long chains never queue up behind one another.  With heavy = largest upstream
+// area a path crosses at most log2(n) <= 32 light cells.  The count is a pointer doubling over the chain
+// ends only (6 rounds cover 64 links): D(t) += D(P(t)), P(t) = P(P(t)), gather-only, double-buffered.
+__global__ void __launch_bounds__(256) k_plan_tails(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ seed,
+                                                    const u32 *__restrict__ tailnum, u32 *__restrict__ D,
+                                                    u32 *__restrict__ P, u32 *__restrict__ tails,
+                                                    unsigned long long *__restrict__ ntails) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool tail = x < g.n && seed[x] != 0;
+  u32 d = 0, p = NONE32;
+  if (tail) {
+    const u32 c = ncode[x];
+    if (d8_is_dir(c)) {
+      d = 1;
+      p = tailnum[d8_down(g, x, c)] - 1u;  // the end of the chain this one joins (a trunk cell: never 0)
+    }
+    D[x] = d;
+    P[x] = p;
+  }
+  const u64 m = __ballot((int)tail);
+  if (m) {
+    const u32 lane = threadIdx.x & 63;
+    u32 base = 0;
+    if (lane == (u32)__ffsll((long long)m) - 1u) base = (u32)atomicAdd(ntails, (unsigned long long)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (tail) tails[base + (u32)__popcll(m & ((1ull << lane) - 1ull))] = x;
+  }
+}
+__global__ void __launch_bounds__(256) k_plan_depth_round(const u32 *__restrict__ tails, u32 nt,
+                                                          const u32 *__restrict__ Di, const u32 *__restrict__ Pi,
+                                                          u32 *__restrict__ Do, u32 *__restrict__ Po) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nt) return;
+  const u32 t = tails[j];
+  u32 d = Di[t], p = Pi[t];
+  if (p != NONE32) {
+    d += Di[p];
+    p = Pi[p];
+  }
+  Do[t] = d;
+  Po[t] = p;
+}
+
 // pass 0: cells and chains per bucket; pass 1: base position / chain id of every chain
 template <int PASS>
-__global__ void __launch_bounds__(256) k_plan_place(const u32 *__restrict__ seed, const u32 *__restrict__ upa,
+__global__ void __launch_bounds__(256) k_plan_place(const u32 *__restrict__ seed, const u32 *__restrict__ depth,
                                                     const u32 *__restrict__ len_at, u32 n,
                                                     unsigned long long *__restrict__ bucket,  // [64]: cells, chains
                                                     u32 *__restrict__ base_at, u32 *__restrict__ cpos,
-                                                    u32 *__restrict__ clen) {
+                                                    u32 *__restrict__ clen, u32 *__restrict__ ctail) {
   __shared__ u32 s_tot[32], s_cnt[32];
   __shared__ unsigned long long s_base[32], s_cbase[32];
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,7 +259,7 @@ __global__ void __launch_bounds__(256) k_plan_place(const u32 *__restrict__ seed
   const bool tail = t < n && seed[t] != 0;
   u32 b = 0, len = 0, local = 0, clocal = 0;
   if (tail) {
-    b = 31u - (u32)__builtin_clz(upa[t] | 1u);
+    b = 31u - min(depth[t], 31u);
     len = len_at[t];
     local = atomicAdd(&s_tot[b], len);
     clocal = atomicAdd(&s_cnt[b], 1u);
@@ -232,6 +277,7 @@ __global__ void __launch_bounds__(256) k_plan_place(const u32 *__restrict__ seed
       base_at[t] = base;
       cpos[cid] = base;
       clen[cid] = len;
+      ctail[cid] = t;
     }
   }
 }
@@ -251,14 +297,46 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const u8 *__restrict__ lh,
   w[p] = 1u + ((hinfo[x] >> 12) & 7u);
 }
 
+// chain c occupies the unpadded slots [S[cpos], S[cpos + len)); every chain starts on a multiple of 4 slots
+// (the lane that folds it loads and stores 4 slots per instruction): cpad = its padded length
+__global__ void __launch_bounds__(256) k_plan_chain_len(const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos,
+                                                        const u32 *__restrict__ S, u32 nchain, u32 *__restrict__ cpad) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nchain) return;
+  u32 v = 0;
+  if (c < nchain) {
+    const u32 p = cpos[c];
+    v = (S[p + clen_pos[c]] - S[p] + 3u) & ~3u;
+  }
+  cpad[c] = v;
+}
+// cstart = padded start; clen = slots | trailing post slots of the last cell << 29; adj_at[tail] = what
+// turns an unpadded slot number of this chain into the padded one
+__global__ void __launch_bounds__(256) k_plan_chains(const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos,
+                                                     const u32 *__restrict__ ctail, const u32 *__restrict__ S,
+                                                     const u32 *__restrict__ cstart_pad,
+                                                     const uint16_t *__restrict__ hinfo, u32 nchain,
+                                                     u32 *__restrict__ cstart, u32 *__restrict__ clen,
+                                                     u32 *__restrict__ adj_at) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchain) return;
+  const u32 p = cpos[c], l = clen_pos[c];
+  const u32 u0 = S[p];
+  const u32 t = ctail[c];
+  cstart[c] = cstart_pad[c];
+  clen[c] = (S[p + l] - u0) | ((((u32)hinfo[t] >> 12) & 7u) << 29);
+  adj_at[t] = cstart_pad[c] - u0;
+}
 __global__ void __launch_bounds__(256) k_plan_expand(const u32 *__restrict__ ucell, const u32 *__restrict__ S,
-                                                     const uint16_t *__restrict__ hinfo, Geo g, u32 npos,
-                                                     u32 *__restrict__ scell, uint16_t *__restrict__ sinfo) {
+                                                     const uint16_t *__restrict__ hinfo,
+                                                     const u32 *__restrict__ tailnum, const u32 *__restrict__ adj_at,
+                                                     Geo g, u32 npos, u32 *__restrict__ scell,
+                                                     uint16_t *__restrict__ sinfo, u32 *__restrict__ spost) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npos) return;
   const u32 x = ucell[p];
   const u32 info = hinfo[x];
-  u32 s = S[p];
+  u32 s = S[p] + adj_at[tailnum[x] - 1u];
   scell[s] = x;
   sinfo[s] = (uint16_t)info;
   const u32 hs = (info >> 8) & 0xFu;
@@ -272,20 +350,10 @@ __global__ void __launch_bounds__(256) k_plan_expand(const u32 *__restrict__ uce
         ++s;
         scell[s] = (u32)((i64)x + off);
         sinfo[s] = (uint16_t)XS_POST;
+        atomicOr(&spost[s >> 5], 1u << (s & 31u));
       }
     }
   }
-}
-
-__global__ void __launch_bounds__(256) k_plan_chains(const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos,
-                                                     const u32 *__restrict__ S, u32 nchain, u32 *__restrict__ cstart,
-                                                     u32 *__restrict__ clen) {
-  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchain) return;
-  const u32 p = cpos[c], l = clen_pos[c];
-  const u32 s0 = S[p];
-  cstart[c] = s0;
-  clen[c] = S[p + l] - s0;
 }
 __global__ void k_plan_pick(const u32 *__restrict__ S, const u32 *__restrict__ idx, u32 k, u32 *__restrict__ out) {
   const u32 t = threadIdx.x;
@@ -301,6 +369,7 @@ void pfd_free_xplan(pfd_raster *h) {
     pfd_dfree(p->toff);
     pfd_dfree(p->scell);
     pfd_dfree(p->sinfo);
+    pfd_dfree(p->spost);
     pfd_dfree(p->cstart);
     pfd_dfree(p->clen);
     h->bytes_held -= std::min(h->bytes_held, p->bytes);
@@ -368,14 +437,36 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if ((rc = pfd_path_labels(h, hcode.as<u8>(), seed.as<u32>(), tailnum.as<u32>(), &complete)) != PFD_OK) return fail(rc);
   if (!complete) return fail(PFD_OK);
   hcode.alloc(0);
+  upa.alloc(0);
+  // rounds of the chains (see k_plan_tails)
+  DevBuf dA, dB, pA, pB, tails;
+  if ((rc = dA.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = dB.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pA.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pB.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = tails.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = buckets.alloc(64 * sizeof(unsigned long long))) != PFD_OK) return fail(rc);
+  if (hipMemsetAsync(buckets.p, 0, 64 * sizeof(unsigned long long), h->stream) != hipSuccess) return fail(PFD_EHIP);
+  k_plan_tails<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(h->ncode, h->geo, seed.as<u32>(), tailnum.as<u32>(), dA.as<u32>(),
+                                                        pA.as<u32>(), tails.as<u32>(), buckets.as<unsigned long long>());
+  unsigned long long ntails = 0;
+  if (hipMemcpyAsync(&ntails, buckets.p, sizeof(ntails), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  u32 *Dc = dA.as<u32>(), *Dn = dB.as<u32>(), *Pc = pA.as<u32>(), *Pn = pB.as<u32>();
+  for (int r = 0; r < 6 && ntails; ++r) {
+    k_plan_depth_round<<<cdiv_u32(ntails, 256), 256, 0, h->stream>>>(tails.as<u32>(), (u32)ntails, Dc, Pc, Dn, Pn);
+    std::swap(Dc, Dn);
+    std::swap(Pc, Pn);
+  }
+  const u32 *depth = Dc;
   if ((rc = len_at.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = base_at.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = buckets.alloc(64 * sizeof(unsigned long long))) != PFD_OK) return fail(rc);
   k_plan_len<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), n,
                                           len_at.as<u32>());
   if (hipMemsetAsync(buckets.p, 0, 64 * sizeof(unsigned long long), h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_place<0><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), upa.as<u32>(), len_at.as<u32>(), n,
-                                               buckets.as<unsigned long long>(), nullptr, nullptr, nullptr);
+  k_plan_place<0><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), depth, len_at.as<u32>(), n,
+                                               buckets.as<unsigned long long>(), nullptr, nullptr, nullptr, nullptr);
   unsigned long long tot[64], cur[64];
   if (hipMemcpyAsync(tot, buckets.p, sizeof(tot), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
@@ -394,15 +485,17 @@ int pfd_ensure_xplan(pfd_raster *h) {
   p->b_chain[32] = (i64)nchain;
   p->ntrunk = (i64)npos;
   p->nchain = (i64)nchain;
-  DevBuf ucell, w, cpos, clenp, tmp, pick;
+  DevBuf ucell, w, cpos, clenp, ctail, cpad, tmp, pick;
   if ((rc = ucell.alloc(std::max<size_t>(npos, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = w.alloc((npos + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = cpos.alloc(std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = clenp.alloc(std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = ctail.alloc(std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = cpad.alloc((nchain + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemcpyAsync(buckets.p, cur, sizeof(cur), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_place<1><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), upa.as<u32>(), len_at.as<u32>(), n,
+  k_plan_place<1><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), depth, len_at.as<u32>(), n,
                                                buckets.as<unsigned long long>(), base_at.as<u32>(), cpos.as<u32>(),
-                                               clenp.as<u32>());
+                                               clenp.as<u32>(), ctail.as<u32>());
   if (hipMemsetAsync(w.p, 0, (npos + 1) * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
   k_plan_scatter<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(),
                                               len_at.as<u32>(), base_at.as<u32>(), n, ucell.as<u32>(), w.as<u32>());
@@ -416,30 +509,49 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if (rocprim::exclusive_scan(tmp.p, tmp_bytes, w.as<u32>(), w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
                               h->stream) != hipSuccess)
     return fail(PFD_EHIP);
-  // slot offsets of the buckets
+  // padded chain starts: exclusive scan of the padded chain lengths; round offsets = starts of their first chains
+  k_plan_chain_len<<<cdiv_u32(nchain + 1, 256), 256, 0, h->stream>>>(cpos.as<u32>(), clenp.as<u32>(), w.as<u32>(),
+                                                                    (u32)nchain, cpad.as<u32>());
+  if (rocprim::exclusive_scan(nullptr, tmp_bytes, cpad.as<u32>(), cpad.as<u32>(), 0u, (size_t)nchain + 1,
+                              rocprim::plus<u32>(), h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
+  if (rocprim::exclusive_scan(tmp.p, tmp_bytes, cpad.as<u32>(), cpad.as<u32>(), 0u, (size_t)nchain + 1,
+                              rocprim::plus<u32>(), h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
   u32 pidx[33], pval[33];
-  for (int b = 0; b <= 32; ++b) pidx[b] = (u32)b_pos[b];
+  for (int b = 0; b <= 32; ++b) pidx[b] = (u32)p->b_chain[b];
   if ((rc = pick.alloc(2 * 33 * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemcpyAsync(pick.p, pidx, sizeof(pidx), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_pick<<<1, 64, 0, h->stream>>>(w.as<u32>(), pick.as<u32>(), 33, pick.as<u32>() + 33);
+  k_plan_pick<<<1, 64, 0, h->stream>>>(cpad.as<u32>(), pick.as<u32>(), 33, pick.as<u32>() + 33);
   if (hipMemcpyAsync(pval, pick.as<u32>() + 33, sizeof(pval), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
     return fail(PFD_EHIP);
   for (int b = 0; b <= 32; ++b) p->b_slot[b] = (i64)pval[b];
   p->nslot = (i64)pval[32];
-  if ((rc = pfd_dmalloc((void **)&p->scell, std::max<size_t>((size_t)p->nslot, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = pfd_dmalloc((void **)&p->sinfo, std::max<size_t>((size_t)p->nslot, 1) * sizeof(uint16_t) + 16)) != PFD_OK)
-    return fail(rc);
+  const size_t nsl = std::max<size_t>((size_t)p->nslot, 4);
+  const size_t nwords = nsl / 32 + 4;
+  if ((rc = pfd_dmalloc((void **)&p->scell, nsl * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->sinfo, nsl * sizeof(uint16_t) + 16)) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->spost, nwords * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->cstart, std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->clen, std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  // padding slots: post slots that carry cell 0 (never folded: they lie beyond their chain's length)
+  if (hipMemsetAsync(p->scell, 0, nsl * sizeof(u32), h->stream) != hipSuccess ||
+      hipMemsetAsync(p->sinfo, 0x80, nsl * sizeof(uint16_t), h->stream) != hipSuccess ||
+      hipMemsetAsync(p->spost, 0, nwords * sizeof(u32), h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
   if (npos) {
-    k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<u32>(), w.as<u32>(), hinfo.as<uint16_t>(), h->geo,
-                                                              (u32)npos, p->scell, p->sinfo);
-    k_plan_chains<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(cpos.as<u32>(), clenp.as<u32>(), w.as<u32>(), (u32)nchain,
-                                                                p->cstart, p->clen);
+    // (base_at is reused: from here on it holds the padding adjustment of the chain ending at that cell)
+    k_plan_chains<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(cpos.as<u32>(), clenp.as<u32>(), ctail.as<u32>(),
+                                                                w.as<u32>(), cpad.as<u32>(), hinfo.as<uint16_t>(),
+                                                                (u32)nchain, p->cstart, p->clen, base_at.as<u32>());
+    k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<u32>(), w.as<u32>(), hinfo.as<uint16_t>(),
+                                                              tailnum.as<u32>(), base_at.as<u32>(), h->geo, (u32)npos,
+                                                              p->scell, p->sinfo, p->spost);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(PFD_EHIP);
-  p->bytes = 2 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)nchain * 8;
+  p->bytes = 2 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)p->nslot / 8 + (size_t)nchain * 8;
   h->bytes_held += p->bytes;
   h->xplan_state = 1;
   pfd_seg_end(h, 14);

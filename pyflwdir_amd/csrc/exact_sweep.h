@@ -83,51 +83,72 @@ __global__ void __launch_bounds__(256) k_xtrunk_pre(Op op, const u32 *__restrict
   E[s] = (info & XS_POST) ? op.pre_post(x) : op.pre_real(x, info & 0xFFu, (info >> 8) & 0xFu);
 }
 
-// one LANE per chain: the running value never leaves its register; the slots of a chain are contiguous,
-// so the loads of the next XU slots are all in flight while the current ones are folded
-#define XU 16
+// ---- the serial fold: one LANE per chain ---------------------------------------------------------
+// The running value never leaves its register.  A chain's slots are contiguous and start on a multiple of
+// 4, so a lane moves 4 slots per load / store instruction; two register buffers of XB slots are used
+// alternately (no copies between them: a copy of a loaded value would wait for the whole prefetch), and the
+// post flags come from a bit array (2 loads per block).  In the last rounds only a few lanes of the chip
+// are busy and the time is the INSTRUCTION count per slot of one wave: the body is branch-free, slots past
+// the end of a chain are folded into a value nobody reads (the padding belongs to the chain).
+template <class T>
+struct alignas(16) XVec4 {
+  T v[4];
+};
+template <class E>
+struct XBlk {  // slots per register buffer: 16, or 8 for 16-byte elements
+  static constexpr int G = sizeof(E) <= 8 ? 4 : 2;  // groups of 4 slots
+};
+__device__ __forceinline__ u32 xpost_bits(const u32 *__restrict__ spost, u32 s) {  // flags of slots s .. s+31 (low bits first)
+  const u32 w0 = spost[s >> 5], w1 = spost[(s >> 5) + 1u];
+  return (u32)((((u64)w1 << 32) | (u64)w0) >> (s & 31u));
+}
+
 template <class Op>
 __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
-                                                    u32 c0, u32 c1, const uint16_t *__restrict__ sinfo,
+                                                    u32 c0, u32 c1, const u32 *__restrict__ spost,
                                                     const typename Op::Elem *__restrict__ E,
                                                     typename Op::V *__restrict__ R) {
   typedef typename Op::Elem Elem;
   typedef typename Op::V V;
+  constexpr int G = XBlk<Elem>::G, XB = 4 * G;
   const u32 c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = c < c1;
   const u32 s0 = active ? cstart[c] : 0u;
-  const u32 m = active ? clen[c] : 0u;
+  const u32 m = active ? (clen[c] & XC_LEN) : 0u;
+  const u32 ng = (m + 3u) >> 2;  // groups of the chain
+  const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
+  XVec4<V> *R4 = (XVec4<V> *)R + (s0 >> 2);
   V t = V();
-  Elem cur[XU], nxt[XU];
-  u32 curi[XU], nxti[XU];
+  XVec4<Elem> ea[G], eb[G];
+  u32 ba, bb;
+  auto load = [&](u32 g0, XVec4<Elem>(&e)[G], u32 &bits) {  // groups g0 .. g0+G-1 (clamped: always a group of the chain)
 #pragma unroll
-  for (int u = 0; u < XU; ++u) {
-    const u32 sl = s0 + ((u32)u < m ? (u32)u : 0u);
-    cur[u] = E[sl];
-    curi[u] = sinfo[sl];
-  }
-  for (u32 base = 0; __any((int)(base < m)); base += XU) {
-    const u32 nb = base + XU;
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {  // prefetch the next block (clamped address: always a valid slot of the chain)
-      const u32 i = nb + (u32)u;
-      const u32 sl = s0 + (i < m ? i : (m ? m - 1u : 0u));
-      nxt[u] = E[sl];
-      nxti[u] = sinfo[sl];
+    for (int g = 0; g < G; ++g) {
+      const u32 gi = g0 + (u32)g;
+      e[g] = E4[gi < ng ? gi : (ng ? ng - 1u : 0u)];
     }
+    bits = xpost_bits(spost, s0 + 4u * (g0 < ng ? g0 : 0u));
+  };
+  auto fold = [&](u32 g0, const XVec4<Elem>(&e)[G], u32 bits) {
 #pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const u32 i = base + (u32)u;
-      if (i < m) {
-        t = i == 0 ? op.first(cur[u]) : op.fold(t, cur[u], (curi[u] & XS_POST) != 0);
-        R[s0 + i] = t;
+    for (int g = 0; g < G; ++g) {
+      const u32 gi = g0 + (u32)g;
+      XVec4<V> r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const V f = op.fold(t, e[g].v[j], ((bits >> (4 * g + j)) & 1u) != 0);
+        t = (g == 0 && j == 0 && g0 == 0) ? op.first(e[g].v[j]) : f;
+        r.v[j] = t;
       }
+      if (gi < ng) R4[gi] = r;
     }
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      cur[u] = nxt[u];
-      curi[u] = nxti[u];
-    }
+  };
+  load(0, ea, ba);
+  for (u32 g0 = 0; __any((int)(g0 < ng)); g0 += 2 * G) {
+    load(g0 + G, eb, bb);
+    fold(g0, ea, ba);
+    load(g0 + 2 * G, ea, ba);
+    fold(g0 + G, eb, bb);
   }
 }
 
@@ -160,7 +181,7 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
     if (c1 == c0) continue;
     k_xtrunk_pre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, E.as<Elem>());
-    k_xtrunk_scan<Op><<<cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->sinfo, E.as<Elem>(),
+    k_xtrunk_scan<Op><<<cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->spost, E.as<Elem>(),
                                                                    R.as<V>());
     k_xtrunk_scatter<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, R.as<V>());
     launches += 3;
@@ -183,60 +204,70 @@ __global__ void __launch_bounds__(256) k_xtrunk_dpre(Op op, const u32 *__restric
   E[s] = op.dpre(x, (u32)ncode[x]);
 }
 
+// the chain is walked from its last cell (slot `tail`, possibly followed by its post slots) upstream;
+// post slots are skipped.  The value of the tail comes from its downstream cell, which belongs to a chain
+// of a later round (final), or the tail is a pit.
 template <class Op>
 __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
                                                      u32 c0, u32 c1, const u32 *__restrict__ scell,
-                                                     const uint16_t *__restrict__ sinfo, const u8 *__restrict__ ncode,
-                                                     Geo g, const typename Op::DElem *__restrict__ E,
+                                                     const u32 *__restrict__ spost, const u8 *__restrict__ ncode, Geo g,
+                                                     const typename Op::DElem *__restrict__ E,
                                                      typename Op::V *__restrict__ R) {
   typedef typename Op::DElem Elem;
   typedef typename Op::V V;
+  constexpr int G = XBlk<Elem>::G;
   const u32 c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = c < c1;
   const u32 s0 = active ? cstart[c] : 0u;
-  const u32 m = active ? clen[c] : 0u;
-  // the chain is walked from its last slot (the tail cell, possibly followed by its post slots) upstream;
-  // position i counts from the end: slot = s0 + m - 1 - i
+  const u32 cl = active ? clen[c] : 0u;
+  const u32 m = cl & XC_LEN;
+  const u32 tail = m ? m - 1u - (cl >> 29) : 0u;  // slot of the last cell
+  const u32 ng = m ? (tail >> 2) + 1u : 0u;        // groups 0 .. ng-1 hold the slots 0 .. tail
+  const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
+  XVec4<V> *R4 = (XVec4<V> *)R + (s0 >> 2);
   V t = V();
-  bool started = false;
-  Elem cur[XU], nxt[XU];
-  u32 curi[XU], nxti[XU];
-#pragma unroll
-  for (int u = 0; u < XU; ++u) {
-    const u32 sl = s0 + (m ? m - 1u - ((u32)u < m ? (u32)u : m - 1u) : 0u);
-    cur[u] = E[sl];
-    curi[u] = sinfo[sl];
+  if (active && m) {
+    const u32 x = scell[s0 + tail];
+    const u32 code = ncode[x];
+    const Elem e = E[s0 + tail];
+    t = d8_is_dir(code) ? op.dfold(e, op.top(d8_down(g, x, code))) : op.droot(e);
   }
-  for (u32 base = 0; __any((int)(base < m)); base += XU) {
-    const u32 nb = base + XU;
+  // blocks of G groups, counted from the top: block q holds the groups ng-1-q*G-(0..G-1)
+  XVec4<Elem> ea[G], eb[G];
+  u32 ba[G], bb[G];
+  auto load = [&](u32 q, XVec4<Elem>(&e)[G], u32(&bits)[G]) {
 #pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const u32 i = nb + (u32)u;
-      const u32 sl = s0 + (m ? m - 1u - (i < m ? i : m - 1u) : 0u);
-      nxt[u] = E[sl];
-      nxti[u] = sinfo[sl];
+    for (int k = 0; k < G; ++k) {
+      const u32 back = q * (u32)G + (u32)k;
+      const u32 gi = back < ng ? ng - 1u - back : 0u;
+      e[k] = E4[gi];
+      bits[k] = xpost_bits(spost, s0 + 4u * gi);
     }
+  };
+  auto fold = [&](u32 q, const XVec4<Elem>(&e)[G], const u32(&bits)[G]) {
 #pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const u32 i = base + (u32)u;
-      if (i < m && !(curi[u] & XS_POST)) {
-        const u32 sl = s0 + m - 1u - i;
-        if (!started) {  // the tail: its downstream cell belongs to a chain of a higher bucket (final), or it is a pit
-          started = true;
-          const u32 x = scell[sl];
-          const u32 code = ncode[x];
-          t = d8_is_dir(code) ? op.dfold(cur[u], op.top(d8_down(g, x, code))) : op.droot(cur[u]);
-        } else {
-          t = op.dfold(cur[u], t);
-        }
-        R[sl] = t;
+    for (int k = 0; k < G; ++k) {
+      const u32 back = q * (u32)G + (u32)k;
+      const u32 gi = ng - 1u - back;  // (only used when back < ng)
+      XVec4<V> r;
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {
+        const u32 i = 4u * gi + (u32)j;
+        const V f = op.dfold(e[k].v[j], t);
+        // slots behind the tail and post slots do not change the running value; the tail keeps its own
+        const bool skip = ((bits[k] >> j) & 1u) != 0 || i >= tail;
+        t = skip ? t : f;
+        r.v[j] = t;
       }
+      if (back < ng) R4[gi] = r;
     }
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      cur[u] = nxt[u];
-      curi[u] = nxti[u];
-    }
+  };
+  load(0, ea, ba);
+  for (u32 q = 0; __any((int)(q * (u32)G < ng)); q += 2) {
+    load(q + 1, eb, bb);
+    fold(q, ea, ba);
+    load(q + 2, ea, ba);
+    fold(q + 1, eb, bb);
   }
 }
 
@@ -323,7 +354,7 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
     if (c1 == c0) continue;
     k_xtrunk_dpre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, h->ncode, s0, s1,
                                                                      E.as<Elem>());
-    k_xtrunk_dscan<Op><<<cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, p->sinfo,
+    k_xtrunk_dscan<Op><<<cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, p->spost,
                                                                     h->ncode, h->geo, E.as<Elem>(), R.as<V>());
     k_xtrunk_dscatter<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, R.as<V>());
     launches += 3;

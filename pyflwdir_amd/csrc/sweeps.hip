@@ -380,9 +380,10 @@ struct AccuUp {
   // ---- exact-order engine (exact_sweep.h) ----
   typedef T LV;
   typedef T Elem;
-  __device__ __forceinline__ T join(T acc, T a) const {
-    if (!has_nodata || (acc != nodata && a != nodata)) acc = Num<T>::add(acc, a);
-    return acc;
+  __device__ __forceinline__ T join(T acc, T a) const {  // (branch-free: runs on the serial critical path)
+    const T sum = Num<T>::add(acc, a);
+    const bool ok = !has_nodata || (acc != nodata && a != nodata);
+    return ok ? sum : acc;
   }
   __device__ __forceinline__ T tile_init(u32 x, bool) const { return data.at(x); }
   __device__ __forceinline__ T tile_combine(u32 l, u32 kids, const T *val) const {
@@ -421,7 +422,7 @@ struct AccuUp {
   __device__ __forceinline__ T first(T e) const { return e; }
   // real slot: accumulator = the cell's own part, operand = the heavy upstream cell's value (the running
   // value); post slot: accumulator = the running value, operand = the light upstream cell
-  __device__ __forceinline__ T fold(T t, T e, bool post) const { return post ? join(t, e) : join(e, t); }
+  __device__ __forceinline__ T fold(T t, T e, bool post) const { return join(post ? t : e, post ? e : t); }
 };
 
 template <class T, class D = CellData<T>>
@@ -638,19 +639,17 @@ struct Hand {
   __device__ __forceinline__ void store(u32 x, double v) const { out[x] = v; }
   // ---- exact-order engine ----
   struct DElem {
-    double dz;
-    u32 is_drain, pad;
+    E dz;  // the difference in the elevation dtype (dem.py:328); widened when it is added
+    u32 is_drain;
   };
   __device__ __forceinline__ DElem dpre(u32 x, u32 code) const {
     DElem e;
     e.is_drain = drain[x] == 1 ? 1u : 0u;
-    const E dz = elev[x] - elev[d8_down(g, x, code)];
-    e.dz = (double)dz;
-    e.pad = 0;
+    e.dz = elev[x] - elev[d8_down(g, x, code)];
     return e;
   }
-  __device__ __forceinline__ double droot(const DElem &e) const { return e.is_drain ? 0.0 : 0.0 + e.dz; }
-  __device__ __forceinline__ double dfold(const DElem &e, double pv) const { return e.is_drain ? 0.0 : pv + e.dz; }
+  __device__ __forceinline__ double droot(const DElem &e) const { return e.is_drain ? 0.0 : 0.0 + (double)e.dz; }
+  __device__ __forceinline__ double dfold(const DElem &e, double pv) const { return e.is_drain ? 0.0 : pv + (double)e.dz; }
 };
 
 #include "exact_sweep.h"

@@ -5,7 +5,7 @@
 Prints one line per operation: wall time of a complete call (HIP work + host launch loop) and
 Mcells/s over all raster cells.  Used for the C3/C5-shaped measurements quoted in DESIGN.md."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyflwdir_amd import _hip
 L = _hip.lib()
@@ -37,6 +37,14 @@ info = h.info()
 print(f"{'order_cells':22s} {1e3*(t1-t0):10.2f} ms  {n/(t1-t0)/1e6:10.1f} Mcells/s  levels={info['n_levels']} n_seq={info['n_seq']} "
       f"n_pits={info['n_pits']} bytes_held={info['bytes_held']/1e9:.2f} GB", flush=True)
 w = _hip.synth_weights_device(n, seed=1)
+h.set_profiling(True)
+sync(); t0 = time.perf_counter()
+h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out4, memspace=_hip.PFD_DEVICE)
+sync(); t1 = time.perf_counter()
+print(f"{'first accuflux f32':22s} {1e3*(t1-t0):10.2f} ms  (builds the exact plan) segments", [(s['name'], round(s['ms'], 2), s['launches']) for s in h.last_timing()], flush=True)
+h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out4, memspace=_hip.PFD_DEVICE)
+print("   warm segments", [(s['name'], round(s['ms'], 2), s['launches']) for s in h.last_timing()], flush=True)
+h.set_profiling(False)
 timed("accuflux f32 (up)", lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out4, memspace=_hip.PFD_DEVICE))
 timed("accuflux f32 (down)", lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, direction=_hip.PFD_DOWN, out=out4, memspace=_hip.PFD_DEVICE))
 wi = _hip.DeviceBuffer(n * 4)
