@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
   const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
   XVec4<V> *R4 = (XVec4<V> *)R + (s0 >> 2);
   V t = V();
-  XVec4<Elem> ea[G], eb[G];
-  u32 ba, bb;
+  XVec4<Elem> ea[G], eb[G], ec[G], ed[G];
+  u32 ba, bb, bc, bd;
   auto load = [&](u32 g0, XVec4<Elem>(&e)[G], u32 &bits) {  // groups g0 .. g0+G-1 (clamped: always a group of the chain)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -130,6 +130,38 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
     bits = xpost_bits(spost, s0 + 4u * (g0 < ng ? g0 : 0u));
   };
   auto fold = [&](u32 g0, const XVec4<Elem>(&e)[G], u32 bits) {
+    if (Op::FAST) {
+      // speculative block: fold without the operation's special cases (accuflux: the nodata rule) and
+      // check afterwards that no operand of the block was special — one dependent instruction per slot
+      // instead of six.  A block with a special operand in ANY lane of the wave is redone exactly.
+      V tt = t;
+      bool bad = false;
+      XVec4<V> r[G];
+      const bool head = g0 == 0;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const Elem x = e[g].v[j];
+          if (g == 0 && j == 0) {
+            bad |= !head && op.special(tt, x);
+            const V f = op.fold_fast(tt, x);
+            tt = head ? op.first(x) : f;
+          } else {
+            bad |= op.special(tt, x);
+            tt = op.fold_fast(tt, x);
+          }
+          r[g].v[j] = tt;
+        }
+      }
+      if (!__any((int)bad)) {
+        t = tt;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (g0 + (u32)g < ng) R4[g0 + (u32)g] = r[g];
+        return;
+      }
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const u32 gi = g0 + (u32)g;
@@ -143,12 +175,19 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
       if (gi < ng) R4[gi] = r;
     }
   };
+  // four buffers in a ring: the loads run 3 blocks (48 slots) ahead of the fold — one HBM round trip
   load(0, ea, ba);
-  for (u32 g0 = 0; __any((int)(g0 < ng)); g0 += 2 * G) {
-    load(g0 + G, eb, bb);
+  load(G, eb, bb);
+  load(2 * G, ec, bc);
+  for (u32 g0 = 0; __any((int)(g0 < ng)); g0 += 4 * G) {
+    load(g0 + 3 * G, ed, bd);
     fold(g0, ea, ba);
-    load(g0 + 2 * G, ea, ba);
+    load(g0 + 4 * G, ea, ba);
     fold(g0 + G, eb, bb);
+    load(g0 + 5 * G, eb, bb);
+    fold(g0 + 2 * G, ec, bc);
+    load(g0 + 6 * G, ec, bc);
+    fold(g0 + 3 * G, ed, bd);
   }
 }
 
@@ -232,42 +271,83 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
     const Elem e = E[s0 + tail];
     t = d8_is_dir(code) ? op.dfold(e, op.top(d8_down(g, x, code))) : op.droot(e);
   }
-  // blocks of G groups, counted from the top: block q holds the groups ng-1-q*G-(0..G-1)
-  XVec4<Elem> ea[G], eb[G];
-  u32 ba[G], bb[G];
-  auto load = [&](u32 q, XVec4<Elem>(&e)[G], u32(&bits)[G]) {
+  // blocks of G groups, counted from the top: block q holds the groups [lo, lo + G), lo = ng - (q+1) G
+  // (groups below 0 do not exist: the top block of a chain may be partial)
+  XVec4<Elem> ea[G], eb[G], ec[G], ed[G];
+  u32 ba, bb, bc, bd;
+  auto load = [&](u32 q, XVec4<Elem>(&e)[G], u32 &bits) {
+    const i32 lo = (i32)ng - (i32)((q + 1u) * (u32)G);
 #pragma unroll
     for (int k = 0; k < G; ++k) {
-      const u32 back = q * (u32)G + (u32)k;
-      const u32 gi = back < ng ? ng - 1u - back : 0u;
-      e[k] = E4[gi];
-      bits[k] = xpost_bits(spost, s0 + 4u * gi);
+      const i32 gi = lo + k;
+      e[k] = E4[gi > 0 ? gi : 0];
     }
+    bits = xpost_bits(spost, s0 + 4u * (u32)(lo > 0 ? lo : 0));
   };
-  auto fold = [&](u32 q, const XVec4<Elem>(&e)[G], const u32(&bits)[G]) {
+  auto fold = [&](u32 q, const XVec4<Elem>(&e)[G], u32 bits) {
+    const i32 lo = (i32)ng - (i32)((q + 1u) * (u32)G);
+    // skip mask of the block's 4 G slots (bit 4 k + j = slot j of group lo + k): post slots, the slots
+    // from the tail on (the tail keeps the value computed above) and the slots of groups below 0 do not
+    // change the running value
+    u32 skip;
+    {
+      const i32 b0 = lo > 0 ? lo : 0;
+      const u32 sh = (u32)(b0 - lo) * 4u;                     // slots of missing groups
+      skip = (sh >= 32u ? 0xFFFFFFFFu : ((bits << sh) | ((1u << sh) - 1u)));
+      const i32 first_bad = (i32)tail - 4 * lo;               // block-relative slot of the tail
+      if (first_bad < 4 * G) skip |= first_bad <= 0 ? 0xFFFFFFFFu : ~((1u << first_bad) - 1u);
+    }
+    if (Op::FAST) {
+      V tt = t;
+      bool bad = false;
+      XVec4<V> r[G];
 #pragma unroll
-    for (int k = 0; k < G; ++k) {
-      const u32 back = q * (u32)G + (u32)k;
-      const u32 gi = ng - 1u - back;  // (only used when back < ng)
+      for (int k = G - 1; k >= 0; --k) {
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+          const Elem x = e[k].v[j];
+          const bool sk = ((skip >> (4 * k + j)) & 1u) != 0;
+          bad |= !sk && op.dspecial(x, tt);
+          const V f = op.dfold_fast(x, tt);
+          tt = sk ? tt : f;
+          r[k].v[j] = tt;
+        }
+      }
+      if (!__any((int)bad)) {
+        t = tt;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          const i32 gi = lo + k;
+          if (gi >= 0 && gi < (i32)ng) R4[gi] = r[k];
+        }
+        return;
+      }
+    }
+#pragma unroll
+    for (int k = G - 1; k >= 0; --k) {
+      const i32 gi = lo + k;
       XVec4<V> r;
 #pragma unroll
       for (int j = 3; j >= 0; --j) {
-        const u32 i = 4u * gi + (u32)j;
         const V f = op.dfold(e[k].v[j], t);
-        // slots behind the tail and post slots do not change the running value; the tail keeps its own
-        const bool skip = ((bits[k] >> j) & 1u) != 0 || i >= tail;
-        t = skip ? t : f;
+        t = ((skip >> (4 * k + j)) & 1u) ? t : f;
         r.v[j] = t;
       }
-      if (back < ng) R4[gi] = r;
+      if (gi >= 0 && gi < (i32)ng) R4[gi] = r;
     }
   };
   load(0, ea, ba);
-  for (u32 q = 0; __any((int)(q * (u32)G < ng)); q += 2) {
-    load(q + 1, eb, bb);
+  load(1, eb, bb);
+  load(2, ec, bc);
+  for (u32 q = 0; __any((int)(q * (u32)G < ng)); q += 4) {
+    load(q + 3, ed, bd);
     fold(q, ea, ba);
-    load(q + 2, ea, ba);
+    load(q + 4, ea, ba);
     fold(q + 1, eb, bb);
+    load(q + 5, eb, bb);
+    fold(q + 2, ec, bc);
+    load(q + 6, ec, bc);
+    fold(q + 3, ed, bd);
   }
 }
 

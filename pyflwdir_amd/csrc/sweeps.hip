@@ -423,6 +423,10 @@ struct AccuUp {
   // real slot: accumulator = the cell's own part, operand = the heavy upstream cell's value (the running
   // value); post slot: accumulator = the running value, operand = the light upstream cell
   __device__ __forceinline__ T fold(T t, T e, bool post) const { return join(post ? t : e, post ? e : t); }
+  // speculative form (exact_sweep.h): a plain add is the exact result whenever neither operand is the nodata value
+  static constexpr bool FAST = true;
+  __device__ __forceinline__ bool special(T t, T e) const { return has_nodata && ((t == nodata) | (e == nodata)); }
+  __device__ __forceinline__ T fold_fast(T t, T e) const { return Num<T>::add(e, t); }
 };
 
 template <class T, class D = CellData<T>>
@@ -449,6 +453,9 @@ struct AccuDown {
     if (!has_nodata || (pv != nodata && e != nodata)) e = Num<T>::add(e, pv);
     return e;
   }
+  static constexpr bool FAST = true;
+  __device__ __forceinline__ bool dspecial(T e, T pv) const { return has_nodata && ((pv == nodata) | (e == nodata)); }
+  __device__ __forceinline__ T dfold_fast(T e, T pv) const { return Num<T>::add(e, pv); }
 };
 
 // FlwdirRaster.upstream_area(unit="cell"): unit weights, nothing read but the codes
@@ -594,6 +601,9 @@ struct Strahler {
     const u32 m = e & 0xFFu, cnt = (e >> 8) & 3u;
     return cnt == 0 ? ((e >> 11) & 1u) : (cnt >= 2 ? m + 1 : m);
   }
+  static constexpr bool FAST = false;
+  __device__ __forceinline__ bool special(u32, u32) const { return false; }
+  __device__ __forceinline__ u32 fold_fast(u32 t, u32) const { return t; }
   __device__ __forceinline__ u32 fold(u32 t, u32 e, bool post) const {
     if (post) return t;
     u32 m = e & 0xFFu, cnt = (e >> 8) & 3u;
@@ -648,6 +658,9 @@ struct Hand {
     e.dz = elev[x] - elev[d8_down(g, x, code)];
     return e;
   }
+  static constexpr bool FAST = false;
+  __device__ __forceinline__ bool dspecial(const DElem &, double) const { return false; }
+  __device__ __forceinline__ double dfold_fast(const DElem &, double pv) const { return pv; }
   __device__ __forceinline__ double droot(const DElem &e) const { return e.is_drain ? 0.0 : 0.0 + (double)e.dz; }
   __device__ __forceinline__ double dfold(const DElem &e, double pv) const { return e.is_drain ? 0.0 : pv + (double)e.dz; }
 };
@@ -1102,6 +1115,9 @@ struct Classic {
   __device__ __forceinline__ u32 dpre(u32 x, u32) const {
     return (u32)flag[x] | ((mask != nullptr && !mask[x]) ? 2u : 0u);
   }
+  static constexpr bool FAST = false;
+  __device__ __forceinline__ bool dspecial(u32, u32) const { return false; }
+  __device__ __forceinline__ u32 dfold_fast(u32, u32 pv) const { return pv; }
   __device__ __forceinline__ u32 droot(u32 e) const { return (e & 2u) ? 0u : 1u; }
   __device__ __forceinline__ u32 dfold(u32 e, u32 pv) const { return (e & 2u) ? 0u : ((pv + (e & 1u)) & 0xFFu); }
 };
@@ -1140,6 +1156,9 @@ struct Dist {
     }
     return (T)1;
   }
+  static constexpr bool FAST = false;
+  __device__ __forceinline__ bool dspecial(T, T) const { return false; }
+  __device__ __forceinline__ T dfold_fast(T, T pv) const { return pv; }
   __device__ __forceinline__ T droot(T) const { return (T)0; }
   __device__ __forceinline__ T dfold(T e, T pv) const {
     if (e < (T)0) return (T)0;

@@ -3,7 +3,7 @@ segments (set PFD_CHAIN_UP=1 for the experimental chain sweep).
 
     python tools/accuflux_probe.py NROW [NCOL [nodata_pct [tilt]]]"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyflwdir_amd import _hip
 L = _hip.lib()
