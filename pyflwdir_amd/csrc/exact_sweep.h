@@ -13,8 +13,8 @@
 //   Elem pre_post(child)              a light upstream cell added AFTER the heavy one
 //   V first(Elem) / V fold(V, Elem, bool post)   the serial fold along a chain;  void store(x, V)
 // and for the down direction:
-//   DElem dpre(x, code)               everything apply() reads from memory, gathered per trunk slot
-//   V droot(DElem) / V dfold(DElem, V pv);  V top(p);  V apply(x, code, root, pv);  void store(x, V)
+//   DElem dpre(x, code)               everything apply() reads from memory, gathered per cell
+//   V droot(DElem) / V dfold(DElem, V pv);  V top(p);  void store(x, V);  V dnodata(x) value of a nodata cell
 #pragma once
 #include "exact.h"
 
@@ -25,12 +25,14 @@ struct XTileArgs {
 };
 
 // ---- leaves, up ---------------------------------------------------------------------------------
+// A thread owns 4 quads of 4 consecutive cells (one 16-byte global access per quad and array where the
+// quad lies inside the raster; cell by cell on the raster's last columns / rows).
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtile_up(Op op, XTileArgs a) {
   typedef typename Op::LV LV;
-  __shared__ LV val[XTC];
-  __shared__ u8 K[XTC];
-  __shared__ uint16_t ord[XTC];
+  __shared__ __attribute__((aligned(16))) LV val[XTC];
+  __shared__ __attribute__((aligned(16))) u8 K[XTC];
+  __shared__ __attribute__((aligned(16))) uint16_t ord[XTC];
   __shared__ uint16_t off[XOFF];
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
@@ -38,19 +40,38 @@ __global__ void __launch_bounds__(256) k_xtile_up(Op op, XTileArgs a) {
   const u32 r0 = tr * XT, c0 = tc * XT;
   if (tid < XOFF) off[tid] = a.toff[tile * XOFF + tid];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const u32 l = tid + 256u * j;
-    const u32 gr = r0 + (l >> 6), gc = c0 + (l & 63);
-    LV v = LV();
-    u32 k = 0;
-    if (gr < a.nrow && gc < a.ncol) {
-      const u32 g = gr * a.ncol + gc;
-      k = a.kids[g];
-      v = op.tile_init(g, a.lh[g] == XL_NODATA);
+  for (int j = 0; j < 4; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 gr = r0 + (l0 >> 6), gc = c0 + (l0 & 63);
+    LV v[4] = {LV(), LV(), LV(), LV()};
+    u32 k4 = 0;
+    if (gr < a.nrow && gc + 3 < a.ncol) {
+      const u32 g0 = gr * a.ncol + gc;
+      __builtin_memcpy(&k4, a.kids + g0, 4);
+      u32 nd = 0;
+      if (Op::NEEDS_NODATA) {
+        u32 l4;
+        __builtin_memcpy(&l4, a.lh + g0, 4);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) nd |= (((l4 >> (8 * b)) & 0xFFu) == XL_NODATA) ? 1u << b : 0u;
+      }
+      op.tile_init4(g0, nd, v);
+    } else if (gr < a.nrow) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (gc + b < a.ncol) {
+          const u32 g = gr * a.ncol + gc + b;
+          k4 |= (u32)a.kids[g] << (8 * b);
+          v[b] = op.tile_init(g, a.lh[g] == XL_NODATA);
+        }
+      }
     }
-    val[l] = v;
-    K[l] = (u8)k;
-    ord[l] = a.tord[tile * XTC + l];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) val[l0 + b] = v[b];
+    *(u32 *)&K[l0] = k4;
+    uint2 o4;
+    __builtin_memcpy(&o4, a.tord + tile * XTC + l0, 8);
+    *(uint2 *)&ord[l0] = o4;
   }
   __syncthreads();
   const u32 total = off[XOFF - 1];
@@ -64,10 +85,19 @@ __global__ void __launch_bounds__(256) k_xtile_up(Op op, XTileArgs a) {
     __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const u32 l = tid + 256u * j;
-    const u32 gr = r0 + (l >> 6), gc = c0 + (l & 63);
-    if (gr < a.nrow && gc < a.ncol) op.tile_store(gr * a.ncol + gc, val[l]);
+  for (int j = 0; j < 4; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 gr = r0 + (l0 >> 6), gc = c0 + (l0 & 63);
+    LV v[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) v[b] = val[l0 + b];
+    if (gr < a.nrow && gc + 3 < a.ncol) {
+      op.tile_store4(gr * a.ncol + gc, v);
+    } else if (gr < a.nrow) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (gc + b < a.ncol) op.tile_store(gr * a.ncol + gc + b, v[b]);
+    }
   }
 }
 
@@ -362,13 +392,19 @@ __global__ void __launch_bounds__(256) k_xtrunk_dscatter(Op op, const u32 *__res
 }
 
 // ---- leaves, down -------------------------------------------------------------------------------
+// LDS image: the values with a 1-cell ring (the downstream cell of a leaf may be a trunk cell next door:
+// trunk values are final when this kernel runs) and, per own cell, the element of the operation (what
+// apply() would read from memory: gathered up front, quad by quad).  Writes every own cell once.
+// (LDS per workgroup decides how many tiles a CU overlaps, and the step loop is latency: keep it small.)
 #define XHW (XT + 2)
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   typedef typename Op::V V;
-  __shared__ V val[XHW * XHW];  // with a 1-cell ring: the downstream cell of a leaf may be a trunk cell next door
-  __shared__ u8 C[XTC];
-  __shared__ uint16_t ord[XTC];
+  typedef typename Op::DElem Elem;
+  __shared__ __attribute__((aligned(16))) V val[XHW * XHW];
+  __shared__ __attribute__((aligned(16))) Elem De[XTC];
+  __shared__ __attribute__((aligned(16))) u8 C[XTC];
+  __shared__ __attribute__((aligned(16))) uint16_t ord[XTC];
   __shared__ uint16_t off[XOFF];
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
@@ -382,11 +418,29 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     val[i] = v;
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const u32 l = tid + 256u * j;
-    const i64 gr = r0 + (l >> 6), gc = c0 + (l & 63);
-    C[l] = (gr < (i64)a.nrow && gc < (i64)a.ncol) ? a.ncode[(size_t)gr * a.ncol + (size_t)gc] : (u8)D8_MV;
-    ord[l] = a.tord[tile * XTC + l];
+  for (int j = 0; j < 4; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const i64 gr = r0 + (l0 >> 6), gc = c0 + (l0 & 63);
+    u32 c4 = D8_MV * 0x01010101u;
+    if (gr < (i64)a.nrow && gc + 3 < (i64)a.ncol) {
+      __builtin_memcpy(&c4, a.ncode + (size_t)gr * a.ncol + (size_t)gc, 4);
+    } else if (gr < (i64)a.nrow) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (gc + b < (i64)a.ncol)
+          c4 = (c4 & ~(0xFFu << (8 * b))) | ((u32)a.ncode[(size_t)gr * a.ncol + (size_t)(gc + b)] << (8 * b));
+    }
+    *(u32 *)&C[l0] = c4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const u32 code = (c4 >> (8 * b)) & 0xFFu;
+      Elem e = Elem();
+      if (code != D8_MV) e = op.dpre((u32)(gr * (i64)a.ncol + gc + b), code);
+      De[l0 + b] = e;
+    }
+    uint2 o4;
+    __builtin_memcpy(&o4, a.tord + tile * XTC + l0, 8);
+    *(uint2 *)&ord[l0] = o4;
   }
   __syncthreads();
   const u32 total = off[XOFF - 1];
@@ -406,15 +460,31 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
         pc += d8_dc(k);
       }
       const V pv = val[(pr + 1) * XHW + pc + 1];
-      const u32 g = (u32)((r0 + lr) * (i64)a.ncol + c0 + lc);
-      val[(lr + 1) * XHW + lc + 1] = op.apply(g, code, root, pv);
+      const Elem el = De[x];
+      val[(lr + 1) * XHW + lc + 1] = root ? op.droot(el) : op.dfold(el, pv);
     }
     __syncthreads();
   }
-  for (u32 j = tid; j < total; j += 256u) {  // only the leaves changed
-    const u32 x = ord[j];
-    const int lr = x >> 6, lc = x & 63;
-    op.store((u32)((r0 + lr) * (i64)a.ncol + c0 + lc), val[(lr + 1) * XHW + lc + 1]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const int lr = l0 >> 6, lc = l0 & 63;
+    const i64 gr = r0 + lr, gc = c0 + lc;
+    if (gr >= (i64)a.nrow) continue;
+    const u32 c4 = *(const u32 *)&C[l0];
+    V v[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      v[b] = val[(lr + 1) * XHW + lc + b + 1];
+      if (((c4 >> (8 * b)) & 0xFFu) == D8_MV && gc + b < (i64)a.ncol) v[b] = op.dnodata((u32)(gr * (i64)a.ncol + gc + b));
+    }
+    if (gc + 3 < (i64)a.ncol) {
+      op.dstore4((u32)(gr * (i64)a.ncol + gc), v);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (gc + b < (i64)a.ncol) op.store((u32)(gr * (i64)a.ncol + gc + b), v[b]);
+    }
   }
 }
 

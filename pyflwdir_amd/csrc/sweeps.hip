@@ -312,12 +312,17 @@ struct CellData {
   const T *p;
   Geo g;
   __device__ __forceinline__ T at(u32 x) const { return p[x]; }
+  __device__ __forceinline__ void load4(u32 x0, T (&v)[4]) const { __builtin_memcpy(v, p + x0, 4 * sizeof(T)); }
 };
 template <class T>
 struct RowData {
   const T *row;
   Geo g;
   __device__ __forceinline__ T at(u32 x) const { return row[geo_row(g, x)]; }
+  __device__ __forceinline__ void load4(u32 x0, T (&v)[4]) const {  // (a quad never crosses a row)
+    const T r = row[geo_row(g, x0)];
+    v[0] = v[1] = v[2] = v[3] = r;
+  }
 };
 template <class D, class A>
 __device__ __forceinline__ void load_window5_of(const D &d, const Geo &g, u32 x, A (&w)[25]) {
@@ -396,6 +401,9 @@ struct AccuUp {
     return acc;
   }
   __device__ __forceinline__ void tile_store(u32 x, T v) const { out[x] = v; }
+  static constexpr bool NEEDS_NODATA = false;
+  __device__ __forceinline__ void tile_init4(u32 x0, u32, T (&v)[4]) const { data.load4(x0, v); }
+  __device__ __forceinline__ void tile_store4(u32 x0, const T (&v)[4]) const { __builtin_memcpy(out + x0, v, 4 * sizeof(T)); }
   // own payload + the light upstream cells that precede the heavy one (slot hs) in the serial loop's order
   __device__ __forceinline__ T pre_real(u32 x, u32 kids, u32 hs) const {
     u32 m = 0;
@@ -447,6 +455,8 @@ struct AccuDown {
   __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
   // ---- exact-order engine ----
   typedef T DElem;
+  __device__ __forceinline__ T dnodata(u32 x) const { return data.at(x); }  // nodata cells keep their input value
+  __device__ __forceinline__ void dstore4(u32 x0, const T (&v)[4]) const { __builtin_memcpy(out + x0, v, 4 * sizeof(T)); }
   __device__ __forceinline__ T dpre(u32 x, u32) const { return data.at(x); }
   __device__ __forceinline__ T droot(T e) const { return e; }
   __device__ __forceinline__ T dfold(T e, T pv) const {
@@ -582,6 +592,20 @@ struct Strahler {
     return (u8)((own << 7) | (r & 0x7Fu));
   }
   __device__ __forceinline__ void tile_store(u32 x, u8 v) const { out[x] = v & 0x7Fu; }
+  static constexpr bool NEEDS_NODATA = true;
+  __device__ __forceinline__ void tile_init4(u32 x0, u32 nd, u8 (&v)[4]) const {
+    u32 m4 = 0x01010101u;
+    if (mask != nullptr) __builtin_memcpy(&m4, mask + x0, 4);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const u32 m = ((m4 >> (8 * b)) & 0xFFu) ? 1u : 0u;
+      v[b] = (nd & (1u << b)) ? (u8)0 : (u8)((m << 7) | m);
+    }
+  }
+  __device__ __forceinline__ void tile_store4(u32 x0, const u8 (&v)[4]) const {
+    const u32 o = (u32)(v[0] & 0x7Fu) | ((u32)(v[1] & 0x7Fu) << 8) | ((u32)(v[2] & 0x7Fu) << 16) | ((u32)(v[3] & 0x7Fu) << 24);
+    __builtin_memcpy(out + x0, &o, 4);
+  }
   // element: bits 0-7 max order of the light cells inside the mask, 8-9 min(their count of it, 3),
   // 10 heavy cell inside the mask, 11 own cell inside the mask, 31 post slot (no-op)
   __device__ __forceinline__ u32 pre_real(u32 x, u32 kids, u32 hs) const {
@@ -652,6 +676,8 @@ struct Hand {
     E dz;  // the difference in the elevation dtype (dem.py:328); widened when it is added
     u32 is_drain;
   };
+  __device__ __forceinline__ double dnodata(u32) const { return -9999.0; }
+  __device__ __forceinline__ void dstore4(u32 x0, const double (&v)[4]) const { __builtin_memcpy(out + x0, v, 32); }
   __device__ __forceinline__ DElem dpre(u32 x, u32 code) const {
     DElem e;
     e.is_drain = drain[x] == 1 ? 1u : 0u;
@@ -850,8 +876,8 @@ static int accuflux_t(pfd_raster *h, const void *data, bool by_row, T nodata, in
     }
   }
   PFDCHK(ensure_sweep_structure(h));
-  // (the exact engine's tile pass writes every cell of an up-sweep from the payload: no initial copy)
-  if (!(h->xplan_state == 1 && direction == PFD_UP)) {
+  // (the exact engine's tile pass writes every cell, nodata cells from the payload: no initial copy)
+  if (h->xplan_state != 1) {
     pfd_seg_begin(h, "init");
     if (by_row) {
       k_fill_rows<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((const T *)d.dev, h->geo, (T *)o.dev);
@@ -1006,10 +1032,12 @@ extern "C" int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids
 
 template <class E>
 static int hand_t(pfd_raster *h, const u8 *drain_dev, const void *elev_dev, double *out_dev) {
-  pfd_seg_begin(h, "init");
-  k_fill<double><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(out_dev, h->geo.n, -9999.0);
-  KCHK();
-  pfd_seg_end(h, 1);
+  if (h->xplan_state != 1) {  // (the exact engine's tile pass writes every cell, -9999 on nodata)
+    pfd_seg_begin(h, "init");
+    k_fill<double><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(out_dev, h->geo.n, -9999.0);
+    KCHK();
+    pfd_seg_end(h, 1);
+  }
   Hand<E> op{h->ncode, h->geo, drain_dev, (const E *)elev_dev, out_dev};
   return sweep_down(h, op, "sweep_hand", "exact_hand");
 }
@@ -1112,6 +1140,11 @@ struct Classic {
   __device__ __forceinline__ void store(u32 x, u32 v) const { out[x] = (u8)v; }
   // ---- exact-order engine: bit 0 = tributary flag, bit 1 = outside the mask ----
   typedef u32 DElem;
+  __device__ __forceinline__ u32 dnodata(u32) const { return 0u; }
+  __device__ __forceinline__ void dstore4(u32 x0, const u32 (&v)[4]) const {
+    const u32 o = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | ((v[3] & 0xFFu) << 24);
+    __builtin_memcpy(out + x0, &o, 4);
+  }
   __device__ __forceinline__ u32 dpre(u32 x, u32) const {
     return (u32)flag[x] | ((mask != nullptr && !mask[x]) ? 2u : 0u);
   }
@@ -1145,6 +1178,8 @@ struct Dist {
   __device__ __forceinline__ void store(u32 x, T v) const { out[x] = v; }
   // ---- exact-order engine: the step length of the cell (1 in cell units), negative = the distance restarts ----
   typedef T DElem;
+  __device__ __forceinline__ T dnodata(u32) const { return (T)-9999; }
+  __device__ __forceinline__ void dstore4(u32 x0, const T (&v)[4]) const { __builtin_memcpy(out + x0, v, 4 * sizeof(T)); }
   __device__ __forceinline__ T dpre(u32 x, u32 code) const {
     if (!d8_is_dir(code) || (mask != nullptr && mask[x])) return (T)-1;
     if (dtab != nullptr) {
@@ -1235,7 +1270,7 @@ extern "C" int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void
   DevBuf flag;
   PFDCHK(flag.alloc((size_t)h->n));
   pfd_seg_begin(h, "init");
-  HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
+  if (h->xplan_state != 1) HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
   const u32 grid = cdiv_u32((u64)h->n, 256);
   if (idx_dtype == PFD_I32)
     k_trib_flag<i32><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const i32 *)mu.dev, (const u8 *)m.dev, flag.as<u8>());
@@ -1265,13 +1300,15 @@ extern "C" int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_
     PFDCHK(tab.bind(step_lengths, 3 * (size_t)(2 * h->nrow - 1) * sizeof(float), PFD_HOST, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * 4, memspace));
-  pfd_seg_begin(h, "init");
-  if (real_length)
-    k_fill<float><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((float *)o.dev, h->geo.n, -9999.0f);
-  else
-    k_fill<i32><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((i32 *)o.dev, h->geo.n, -9999);
-  KCHK();
-  pfd_seg_end(h, 1);
+  if (h->xplan_state != 1) {
+    pfd_seg_begin(h, "init");
+    if (real_length)
+      k_fill<float><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((float *)o.dev, h->geo.n, -9999.0f);
+    else
+      k_fill<i32><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((i32 *)o.dev, h->geo.n, -9999);
+    KCHK();
+    pfd_seg_end(h, 1);
+  }
   if (real_length) {
     Dist<float> op{h->ncode, h->geo, (const u8 *)m.dev, (const float *)tab.dev, (float *)o.dev};
     PFDCHK(sweep_down(h, op, "sweep_stream_distance", "exact_stream_distance"));
