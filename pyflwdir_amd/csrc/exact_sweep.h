@@ -400,58 +400,83 @@ __global__ void __launch_bounds__(256) k_xtrunk_dscatter(Op op, const u32 *__res
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   typedef typename Op::V V;
-  typedef typename Op::DElem Elem;
+  typedef typename Op::DTile Elem;
   __shared__ __attribute__((aligned(16))) V val[XHW * XHW];
   __shared__ __attribute__((aligned(16))) Elem De[XTC];
-  __shared__ __attribute__((aligned(16))) u8 C[XTC];
-  __shared__ __attribute__((aligned(16))) uint16_t ord[XTC];
+  // per leaf, in step order: own cell (12 bits) | ring index of its downstream cell << 12 (13 bits) | pit << 25
+  // (looked up once per leaf here instead of once per step through the cell's code)
+  __shared__ __attribute__((aligned(16))) u32 ord[XTC];
+  __shared__ u32 F[XTC / 32];  // one flag bit per cell, for operations whose element needs one (HAND: drain)
   __shared__ uint16_t off[XOFF];
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
   const size_t tile = (size_t)tr * a.ntc + tc;
   const i64 r0 = (i64)tr * XT, c0 = (i64)tc * XT;
   if (tid < XOFF) off[tid] = a.toff[tile * XOFF + tid];
-  for (u32 i = tid; i < XHW * XHW; i += 256u) {
-    const i64 gr = r0 + (i64)(i / XHW) - 1, gc = c0 + (i64)(i % XHW) - 1;
+  if (tid < XTC / 32) F[tid] = 0;
+  // the ring: 2 x 66 + 2 x 64 cells of the neighbouring tiles (trunk cells there are final)
+  for (u32 i = tid; i < 4u * XT + 4u; i += 256u) {
+    int rr, cc;
+    if (i < (u32)XHW) {
+      rr = -1, cc = (int)i - 1;
+    } else if (i < 2u * XHW) {
+      rr = XT, cc = (int)(i - XHW) - 1;
+    } else if (i < 2u * XHW + XT) {
+      rr = (int)(i - 2u * XHW), cc = -1;
+    } else {
+      rr = (int)(i - 2u * XHW - XT), cc = XT;
+    }
+    const i64 gr = r0 + rr, gc = c0 + cc;
     V v = V();
     if (gr >= 0 && gr < (i64)a.nrow && gc >= 0 && gc < (i64)a.ncol) v = op.top((u32)(gr * (i64)a.ncol + gc));
-    val[i] = v;
+    val[(rr + 1) * XHW + cc + 1] = v;
   }
+  __syncthreads();  // (F is cleared)
+  u32 mycodes[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const u32 l0 = 4u * tid + 1024u * j;
-    const i64 gr = r0 + (l0 >> 6), gc = c0 + (l0 & 63);
+    const int lr = l0 >> 6, lc = l0 & 63;
+    const i64 gr = r0 + lr, gc = c0 + lc;
     u32 c4 = D8_MV * 0x01010101u;
+    V v[4] = {V(), V(), V(), V()};
     if (gr < (i64)a.nrow && gc + 3 < (i64)a.ncol) {
-      __builtin_memcpy(&c4, a.ncode + (size_t)gr * a.ncol + (size_t)gc, 4);
+      const u32 g0 = (u32)(gr * (i64)a.ncol + gc);
+      __builtin_memcpy(&c4, a.ncode + g0, 4);
+      op.top4(g0, v);
     } else if (gr < (i64)a.nrow) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if (gc + b < (i64)a.ncol)
-          c4 = (c4 & ~(0xFFu << (8 * b))) | ((u32)a.ncode[(size_t)gr * a.ncol + (size_t)(gc + b)] << (8 * b));
+      for (int b = 0; b < 4; ++b) {
+        if (gc + b < (i64)a.ncol) {
+          const u32 g = (u32)(gr * (i64)a.ncol + gc + b);
+          c4 = (c4 & ~(0xFFu << (8 * b))) | ((u32)a.ncode[g] << (8 * b));
+          v[b] = op.top(g);
+        }
+      }
     }
-    *(u32 *)&C[l0] = c4;
+    mycodes[j] = c4;
+    u32 fl = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const u32 code = (c4 >> (8 * b)) & 0xFFu;
       Elem e = Elem();
-      if (code != D8_MV) e = op.dpre((u32)(gr * (i64)a.ncol + gc + b), code);
+      bool f = false;
+      if (code != D8_MV) e = op.dtile((u32)(gr * (i64)a.ncol + gc + b), code, f);
       De[l0 + b] = e;
+      fl |= f ? 1u << b : 0u;
+      val[(lr + 1) * XHW + lc + b + 1] = v[b];
     }
-    uint2 o4;
-    __builtin_memcpy(&o4, a.tord + tile * XTC + l0, 8);
-    *(uint2 *)&ord[l0] = o4;
+    if (Op::DTILE_FLAG && fl) atomicOr(&F[l0 >> 5], fl << (l0 & 31u));
   }
-  __syncthreads();
   const u32 total = off[XOFF - 1];
-  int last = 0;
-  for (int s = 1; s < XOFF - 1; ++s) last = off[s] < total ? s : last;
-  for (int s = last; s >= 0; --s) {
-    const u32 b = off[s], e = off[s + 1];
-    for (u32 j = b + tid; j < e; j += 256u) {
-      const u32 x = ord[j];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const u32 i = tid + 256u * j;
+    u32 w = 0;
+    if (i < total) {
+      const u32 x = a.tord[tile * XTC + i];
       const int lr = x >> 6, lc = x & 63;
-      const u32 code = C[x];
+      const u32 code = a.ncode[(size_t)(r0 + lr) * a.ncol + (size_t)(c0 + lc)];  // (a line this tile just read)
       const bool root = !d8_is_dir(code);
       int pr = lr, pc = lc;
       if (!root) {
@@ -459,9 +484,22 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
         pr += d8_dr(k);
         pc += d8_dc(k);
       }
-      const V pv = val[(pr + 1) * XHW + pc + 1];
+      w = x | ((u32)((pr + 1) * XHW + pc + 1) << 12) | (root ? 1u << 25 : 0u);
+    }
+    ord[i] = w;
+  }
+  __syncthreads();
+  int last = 0;
+  for (int s = 1; s < XOFF - 1; ++s) last = off[s] < total ? s : last;
+  for (int s = last; s >= 0; --s) {
+    const u32 b = off[s], e = off[s + 1];
+    for (u32 j = b + tid; j < e; j += 256u) {
+      const u32 w = ord[j];
+      const u32 x = w & 0xFFFu;
+      const V pv = val[(w >> 12) & 0x1FFFu];
       const Elem el = De[x];
-      val[(lr + 1) * XHW + lc + 1] = root ? op.droot(el) : op.dfold(el, pv);
+      const bool f = Op::DTILE_FLAG ? ((F[x >> 5] >> (x & 31u)) & 1u) != 0 : false;
+      val[((x >> 6) + 1) * XHW + (x & 63u) + 1] = (w >> 25) ? op.dtroot(el, f) : op.dtfold(el, f, pv);
     }
     __syncthreads();
   }
@@ -471,7 +509,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     const int lr = l0 >> 6, lc = l0 & 63;
     const i64 gr = r0 + lr, gc = c0 + lc;
     if (gr >= (i64)a.nrow) continue;
-    const u32 c4 = *(const u32 *)&C[l0];
+    const u32 c4 = mycodes[j];
     V v[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {

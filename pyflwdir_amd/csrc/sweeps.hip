@@ -463,6 +463,16 @@ struct AccuDown {
     if (!has_nodata || (pv != nodata && e != nodata)) e = Num<T>::add(e, pv);
     return e;
   }
+  // tile image of the element (exact_sweep.h, k_xtile_down): the element itself, no flag
+  typedef DElem DTile;
+  static constexpr bool DTILE_FLAG = false;
+  __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
+  __device__ __forceinline__ T dtroot(DElem e, bool) const { return droot(e); }
+  __device__ __forceinline__ T dtfold(DElem e, bool, T pv) const { return dfold(e, pv); }
+  __device__ __forceinline__ void top4(u32 x0, T (&v)[4]) const {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) v[b] = top(x0 + b);
+  }
   static constexpr bool FAST = true;
   __device__ __forceinline__ bool dspecial(T e, T pv) const { return has_nodata && ((pv == nodata) | (e == nodata)); }
   __device__ __forceinline__ T dfold_fast(T e, T pv) const { return Num<T>::add(e, pv); }
@@ -684,6 +694,16 @@ struct Hand {
     e.dz = elev[x] - elev[d8_down(g, x, code)];
     return e;
   }
+  // tile image (k_xtile_down): the difference alone, the drain flag goes to the tile's flag bitmap
+  typedef E DTile;
+  static constexpr bool DTILE_FLAG = true;
+  __device__ __forceinline__ E dtile(u32 x, u32 code, bool &is_drain) const {
+    is_drain = drain[x] == 1;
+    return elev[x] - elev[d8_down(g, x, code)];
+  }
+  __device__ __forceinline__ double dtroot(E dz, bool is_drain) const { return is_drain ? 0.0 : 0.0 + (double)dz; }
+  __device__ __forceinline__ double dtfold(E dz, bool is_drain, double pv) const { return is_drain ? 0.0 : pv + (double)dz; }
+  __device__ __forceinline__ void top4(u32 x0, double (&v)[4]) const { __builtin_memcpy(v, out + x0, 32); }
   static constexpr bool FAST = false;
   __device__ __forceinline__ bool dspecial(const DElem &, double) const { return false; }
   __device__ __forceinline__ double dfold_fast(const DElem &, double pv) const { return pv; }
@@ -1148,6 +1168,16 @@ struct Classic {
   __device__ __forceinline__ u32 dpre(u32 x, u32) const {
     return (u32)flag[x] | ((mask != nullptr && !mask[x]) ? 2u : 0u);
   }
+  // tile image of the element (exact_sweep.h, k_xtile_down): the element itself, no flag
+  typedef DElem DTile;
+  static constexpr bool DTILE_FLAG = false;
+  __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
+  __device__ __forceinline__ u32 dtroot(DElem e, bool) const { return droot(e); }
+  __device__ __forceinline__ u32 dtfold(DElem e, bool, u32 pv) const { return dfold(e, pv); }
+  __device__ __forceinline__ void top4(u32 x0, u32 (&v)[4]) const {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) v[b] = top(x0 + b);
+  }
   static constexpr bool FAST = false;
   __device__ __forceinline__ bool dspecial(u32, u32) const { return false; }
   __device__ __forceinline__ u32 dfold_fast(u32, u32 pv) const { return pv; }
@@ -1190,6 +1220,16 @@ struct Dist {
       return (T)dtab[3u * s + (u32)kind];
     }
     return (T)1;
+  }
+  // tile image of the element (exact_sweep.h, k_xtile_down): the element itself, no flag
+  typedef DElem DTile;
+  static constexpr bool DTILE_FLAG = false;
+  __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
+  __device__ __forceinline__ T dtroot(DElem e, bool) const { return droot(e); }
+  __device__ __forceinline__ T dtfold(DElem e, bool, T pv) const { return dfold(e, pv); }
+  __device__ __forceinline__ void top4(u32 x0, T (&v)[4]) const {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) v[b] = top(x0 + b);
   }
   static constexpr bool FAST = false;
   __device__ __forceinline__ bool dspecial(T, T) const { return false; }
