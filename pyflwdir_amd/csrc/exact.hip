@@ -8,7 +8,10 @@
 
 #include <algorithm>
 
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "exact.h"
 #include "tiled.h"
@@ -190,13 +193,19 @@ __global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode
 }
 
 // the head of a chain (a trunk cell without heavy child) knows the length of its chain
+// (per-chain arrays are indexed by the chain end's number j in the raster-ordered list `tails`;
+//  tidx_at[cell] = j for a chain end)
+__global__ void __launch_bounds__(256) k_plan_tidx(const u32 *__restrict__ tails, u32 nt, u32 *__restrict__ tidx_at) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nt) tidx_at[tails[j]] = j;
+}
 __global__ void __launch_bounds__(256) k_plan_len(const u8 *__restrict__ lh, const uint16_t *__restrict__ hinfo,
-                                                  const u32 *__restrict__ hops, const u32 *__restrict__ tailnum, u32 n,
-                                                  u32 *__restrict__ len_at) {
+                                                  const u32 *__restrict__ hops, const u32 *__restrict__ tailnum,
+                                                  const u32 *__restrict__ tidx_at, u32 n, u32 *__restrict__ len_of) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= n || lh[x] != XL_TRUNK || ((hinfo[x] >> 8) & 0xFu) != 8u) return;
   const u32 tn = tailnum[x];
-  if (tn) len_at[tn - 1] = hops[x] + 1;
+  if (tn) len_of[tidx_at[tn - 1]] = hops[x] + 1;
 }
 
 // Round of a chain = 31 - (number of light cells between its last cell and the pit): the chain a
@@ -204,95 +213,81 @@ __global__ void __launch_bounds__(256) k_plan_len(const u8 *__restrict__ lh, con
 // round, so independent long chains never queue up behind one another.  With heavy = largest upstream
 // area a path crosses at most log2(n) <= 32 light cells.  The count is a pointer doubling over the chain
 // ends only (6 rounds cover 64 links): D(t) += D(P(t)), P(t) = P(P(t)), gather-only, double-buffered.
-__global__ void __launch_bounds__(256) k_plan_tails(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ seed,
-                                                    const u32 *__restrict__ tailnum, u32 *__restrict__ D,
-                                                    u32 *__restrict__ P, u32 *__restrict__ tails,
-                                                    unsigned long long *__restrict__ ntails) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool tail = x < g.n && seed[x] != 0;
+__global__ void __launch_bounds__(256) k_plan_tails(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ tails,
+                                                    u32 nt, const u32 *__restrict__ tailnum,
+                                                    const u32 *__restrict__ tidx_at, u32 *__restrict__ D,
+                                                    u32 *__restrict__ P) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nt) return;
+  const u32 x = tails[j];
   u32 d = 0, p = NONE32;
-  if (tail) {
-    const u32 c = ncode[x];
-    if (d8_is_dir(c)) {
-      d = 1;
-      p = tailnum[d8_down(g, x, c)] - 1u;  // the end of the chain this one joins (a trunk cell: never 0)
-    }
-    D[x] = d;
-    P[x] = p;
+  const u32 c = ncode[x];
+  if (d8_is_dir(c)) {
+    d = 1;
+    p = tidx_at[tailnum[d8_down(g, x, c)] - 1u];  // the end of the chain this one joins (a trunk cell: never 0)
   }
-  const u64 m = __ballot((int)tail);
-  if (m) {
-    const u32 lane = threadIdx.x & 63;
-    u32 base = 0;
-    if (lane == (u32)__ffsll((long long)m) - 1u) base = (u32)atomicAdd(ntails, (unsigned long long)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (tail) tails[base + (u32)__popcll(m & ((1ull << lane) - 1ull))] = x;
-  }
+  D[j] = d;
+  P[j] = p;
 }
-__global__ void __launch_bounds__(256) k_plan_depth_round(const u32 *__restrict__ tails, u32 nt,
-                                                          const u32 *__restrict__ Di, const u32 *__restrict__ Pi,
+__global__ void __launch_bounds__(256) k_plan_depth_round(u32 nt, const u32 *__restrict__ Di, const u32 *__restrict__ Pi,
                                                           u32 *__restrict__ Do, u32 *__restrict__ Po) {
   const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nt) return;
-  const u32 t = tails[j];
-  u32 d = Di[t], p = Pi[t];
+  u32 d = Di[j], p = Pi[j];
   if (p != NONE32) {
     d += Di[p];
     p = Pi[p];
   }
-  Do[t] = d;
-  Po[t] = p;
+  Do[j] = d;
+  Po[j] = p;
 }
 
-// pass 0: cells and chains per bucket; pass 1: base position / chain id of every chain
-template <int PASS>
-__global__ void __launch_bounds__(256) k_plan_place(const u32 *__restrict__ seed, const u32 *__restrict__ depth,
-                                                    const u32 *__restrict__ len_at, u32 n,
-                                                    unsigned long long *__restrict__ bucket,  // [64]: cells, chains
-                                                    u32 *__restrict__ base_at, u32 *__restrict__ cpos,
-                                                    u32 *__restrict__ clen, u32 *__restrict__ ctail) {
-  __shared__ u32 s_tot[32], s_cnt[32];
-  __shared__ unsigned long long s_base[32], s_cbase[32];
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (threadIdx.x < 32) s_tot[threadIdx.x] = s_cnt[threadIdx.x] = 0;
+// chains in layout order = the chain ends sorted by round (stable: raster order inside a round);
+// the sort carries the list numbers j, rank_of[j] = chain id
+__global__ void __launch_bounds__(256) k_plan_keys(u32 nt, const u32 *__restrict__ depth, u32 *__restrict__ keys,
+                                                   u32 *__restrict__ iota, u32 *__restrict__ hist) {
+  __shared__ u32 s_h[32];
+  if (threadIdx.x < 32) s_h[threadIdx.x] = 0;
   __syncthreads();
-  const bool tail = t < n && seed[t] != 0;
-  u32 b = 0, len = 0, local = 0, clocal = 0;
-  if (tail) {
-    b = 31u - min(depth[t], 31u);
-    len = len_at[t];
-    local = atomicAdd(&s_tot[b], len);
-    clocal = atomicAdd(&s_cnt[b], 1u);
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nt) {
+    const u32 k = 31u - min(depth[j], 31u);
+    keys[j] = k;
+    iota[j] = j;
+    atomicAdd(&s_h[k], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < 32 && s_cnt[threadIdx.x]) {
-    s_base[threadIdx.x] = atomicAdd(&bucket[threadIdx.x], (unsigned long long)s_tot[threadIdx.x]);
-    s_cbase[threadIdx.x] = atomicAdd(&bucket[32 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+  if (threadIdx.x < 32 && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) k_plan_chain_lens(const u32 *__restrict__ cj, u32 nchain,
+                                                         const u32 *__restrict__ tails, const u32 *__restrict__ len_of,
+                                                         u32 *__restrict__ rank_of, u32 *__restrict__ ctail,
+                                                         u32 *__restrict__ clen_pos, u32 *__restrict__ cpos_in) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nchain) return;
+  u32 l = 0;
+  if (c < nchain) {
+    const u32 j = cj[c];
+    l = len_of[j];
+    rank_of[j] = c;
+    ctail[c] = tails[j];
+    clen_pos[c] = l;
   }
-  if (PASS == 1) {
-    __syncthreads();
-    if (tail) {
-      const u32 base = (u32)(s_base[b] + local);
-      const u32 cid = (u32)(s_cbase[b] + clocal);
-      base_at[t] = base;
-      cpos[cid] = base;
-      clen[cid] = len;
-      ctail[cid] = t;
-    }
-  }
+  cpos_in[c] = l;  // (exclusive scan in place -> first position of the chain)
 }
 
 // position of every trunk cell: chain base + distance from the chain head; w = slots the cell needs
 __global__ void __launch_bounds__(256) k_plan_scatter(const u8 *__restrict__ lh, const uint16_t *__restrict__ hinfo,
                                                       const u32 *__restrict__ hops, const u32 *__restrict__ tailnum,
-                                                      const u32 *__restrict__ len_at, const u32 *__restrict__ base_at,
+                                                      const u32 *__restrict__ tidx_at, const u32 *__restrict__ rank_of,
+                                                      const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos,
                                                       u32 n, u32 *__restrict__ ucell, u32 *__restrict__ w) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= n || lh[x] != XL_TRUNK) return;
   const u32 tn = tailnum[x];
   if (!tn) return;
-  const u32 t = tn - 1;
-  const u32 p = base_at[t] + len_at[t] - 1 - hops[x];
+  const u32 c = rank_of[tidx_at[tn - 1]];
+  const u32 p = cpos[c] + clen_pos[c] - 1 - hops[x];
   ucell[p] = x;
   w[p] = 1u + ((hinfo[x] >> 12) & 7u);
 }
@@ -317,7 +312,7 @@ __global__ void __launch_bounds__(256) k_plan_chains(const u32 *__restrict__ cpo
                                                      const u32 *__restrict__ cstart_pad,
                                                      const uint16_t *__restrict__ hinfo, u32 nchain,
                                                      u32 *__restrict__ cstart, u32 *__restrict__ clen,
-                                                     u32 *__restrict__ adj_at) {
+                                                     u32 *__restrict__ adj) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nchain) return;
   const u32 p = cpos[c], l = clen_pos[c];
@@ -325,18 +320,19 @@ __global__ void __launch_bounds__(256) k_plan_chains(const u32 *__restrict__ cpo
   const u32 t = ctail[c];
   cstart[c] = cstart_pad[c];
   clen[c] = (S[p + l] - u0) | ((((u32)hinfo[t] >> 12) & 7u) << 29);
-  adj_at[t] = cstart_pad[c] - u0;
+  adj[c] = cstart_pad[c] - u0;
 }
 __global__ void __launch_bounds__(256) k_plan_expand(const u32 *__restrict__ ucell, const u32 *__restrict__ S,
                                                      const uint16_t *__restrict__ hinfo,
-                                                     const u32 *__restrict__ tailnum, const u32 *__restrict__ adj_at,
+                                                     const u32 *__restrict__ tailnum, const u32 *__restrict__ tidx_at,
+                                                     const u32 *__restrict__ rank_of, const u32 *__restrict__ adj,
                                                      Geo g, u32 npos, u32 *__restrict__ scell,
                                                      uint16_t *__restrict__ sinfo, u32 *__restrict__ spost) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npos) return;
   const u32 x = ucell[p];
   const u32 info = hinfo[x];
-  u32 s = S[p] + adj_at[tailnum[x] - 1u];
+  u32 s = S[p] + adj[rank_of[tidx_at[tailnum[x] - 1u]]];
   scell[s] = x;
   sinfo[s] = (uint16_t)info;
   const u32 hs = (info >> 8) & 0xFu;
@@ -422,7 +418,7 @@ int pfd_ensure_xplan(pfd_raster *h) {
   k_plan_tile<<<dim3(ntc, ntr), 256, 0, h->stream>>>(h->ncode, (u32)h->nrow, (u32)h->ncol, ntc, p->lh, p->kids, p->tord,
                                                      p->toff);
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
-  DevBuf hcode, seed, hinfo, hops, tailnum, len_at, base_at, buckets;
+  DevBuf hcode, seed, hinfo, hops, tailnum;
   if ((rc = hcode.alloc((size_t)n + 64)) != PFD_OK) return fail(rc);
   if ((rc = seed.alloc((size_t)n * sizeof(u32) + 64)) != PFD_OK) return fail(rc);
   if ((rc = hinfo.alloc((size_t)n * sizeof(uint16_t))) != PFD_OK) return fail(rc);
@@ -437,71 +433,105 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if ((rc = pfd_path_labels(h, hcode.as<u8>(), seed.as<u32>(), tailnum.as<u32>(), &complete)) != PFD_OK) return fail(rc);
   if (!complete) return fail(PFD_OK);
   hcode.alloc(0);
-  upa.alloc(0);
-  // rounds of the chains (see k_plan_tails)
-  DevBuf dA, dB, pA, pB, tails;
-  if ((rc = dA.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = dB.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = pA.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = pB.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = tails.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = buckets.alloc(64 * sizeof(unsigned long long))) != PFD_OK) return fail(rc);
-  if (hipMemsetAsync(buckets.p, 0, 64 * sizeof(unsigned long long), h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_tails<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(h->ncode, h->geo, seed.as<u32>(), tailnum.as<u32>(), dA.as<u32>(),
-                                                        pA.as<u32>(), tails.as<u32>(), buckets.as<unsigned long long>());
-  unsigned long long ntails = 0;
-  if (hipMemcpyAsync(&ntails, buckets.p, sizeof(ntails), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+  // the chain ends, in raster order (selection by scan: no same-address atomics).  The list lives in the
+  // upstream-area buffer, which is no longer needed; tidx_at takes over the seed buffer afterwards.
+  DevBuf dA, dB, pA, pB, tmp, cnt, len_of, rank_of;
+  u32 *tails = upa.as<u32>();
+  if ((rc = cnt.alloc(64 * sizeof(u32))) != PFD_OK) return fail(rc);
+  size_t tmp_bytes = 0;
+  {
+    rocprim::counting_iterator<u32> cells(0u);
+    auto flags = rocprim::make_transform_iterator(seed.as<u32>(), [] __device__(u32 sd) { return sd != 0u; });
+    if (rocprim::select(nullptr, tmp_bytes, cells, flags, tails, cnt.as<u32>(), (size_t)n, h->stream) != hipSuccess)
+      return fail(PFD_EHIP);
+    if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
+    if (rocprim::select(tmp.p, tmp_bytes, cells, flags, tails, cnt.as<u32>(), (size_t)n, h->stream) != hipSuccess)
+      return fail(PFD_EHIP);
+  }
+  u32 nt32 = 0;
+  if (hipMemcpyAsync(&nt32, cnt.p, sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
     return fail(PFD_EHIP);
+  const unsigned long long nchain = nt32;
+  const size_t nc1 = std::max<size_t>(nchain, 1);
+  u32 *tidx_at = seed.as<u32>();
+  if (nchain) k_plan_tidx<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(tails, nt32, tidx_at);
+  // rounds of the chains (see k_plan_tails)
+  if ((rc = dA.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = dB.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pA.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pB.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
   u32 *Dc = dA.as<u32>(), *Dn = dB.as<u32>(), *Pc = pA.as<u32>(), *Pn = pB.as<u32>();
-  for (int r = 0; r < 6 && ntails; ++r) {
-    k_plan_depth_round<<<cdiv_u32(ntails, 256), 256, 0, h->stream>>>(tails.as<u32>(), (u32)ntails, Dc, Pc, Dn, Pn);
-    std::swap(Dc, Dn);
-    std::swap(Pc, Pn);
+  if (nchain) {
+    k_plan_tails<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(h->ncode, h->geo, tails, nt32, tailnum.as<u32>(), tidx_at, Dc, Pc);
+    for (int r = 0; r < 6; ++r) {
+      k_plan_depth_round<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(nt32, Dc, Pc, Dn, Pn);
+      std::swap(Dc, Dn);
+      std::swap(Pc, Pn);
+    }
   }
   const u32 *depth = Dc;
-  if ((rc = len_at.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = base_at.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  k_plan_len<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), n,
-                                          len_at.as<u32>());
-  if (hipMemsetAsync(buckets.p, 0, 64 * sizeof(unsigned long long), h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_place<0><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), depth, len_at.as<u32>(), n,
-                                               buckets.as<unsigned long long>(), nullptr, nullptr, nullptr, nullptr);
-  unsigned long long tot[64], cur[64];
-  if (hipMemcpyAsync(tot, buckets.p, sizeof(tot), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+  if ((rc = len_of.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = rank_of.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  k_plan_len<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at, n,
+                                          len_of.as<u32>());
+  // chains in layout order: stable sort of the chain ends by round; chain id = rank in that order
+  DevBuf ucell, w, cpos, clenp, ctail, cpad, pick, keys, keys2, iota, cj, adj;
+  if ((rc = keys.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = keys2.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = iota.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = cj.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = adj.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = ctail.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = cpos.alloc((nchain + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = clenp.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = cpad.alloc((nchain + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if (hipMemsetAsync(cnt.p, 0, 64 * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
+  if (nchain) {
+    k_plan_keys<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(nt32, depth, keys.as<u32>(), iota.as<u32>(), cnt.as<u32>());
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<u32>(), keys2.as<u32>(), iota.as<u32>(), cj.as<u32>(),
+                                  (size_t)nchain, 0u, 5u, h->stream) != hipSuccess)
+      return fail(PFD_EHIP);
+    if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
+    if (rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<u32>(), keys2.as<u32>(), iota.as<u32>(), cj.as<u32>(),
+                                  (size_t)nchain, 0u, 5u, h->stream) != hipSuccess)
+      return fail(PFD_EHIP);
+  }
+  k_plan_chain_lens<<<cdiv_u32(nchain + 1, 256), 256, 0, h->stream>>>(cj.as<u32>(), nt32, tails, len_of.as<u32>(),
+                                                                     rank_of.as<u32>(), ctail.as<u32>(), clenp.as<u32>(),
+                                                                     cpos.as<u32>());
+  if (rocprim::exclusive_scan(nullptr, tmp_bytes, cpos.as<u32>(), cpos.as<u32>(), 0u, (size_t)nchain + 1,
+                              rocprim::plus<u32>(), h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
+  if (rocprim::exclusive_scan(tmp.p, tmp_bytes, cpos.as<u32>(), cpos.as<u32>(), 0u, (size_t)nchain + 1,
+                              rocprim::plus<u32>(), h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  u32 hist[32], npos32 = 0;
+  if (hipMemcpyAsync(hist, cnt.p, sizeof(hist), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipMemcpyAsync(&npos32, cpos.as<u32>() + nchain, sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
     return fail(PFD_EHIP);
-  unsigned long long npos = 0, nchain = 0;
-  i64 b_pos[33];
-  for (int b = 0; b < 32; ++b) {
-    cur[b] = npos;
-    cur[32 + b] = nchain;
-    b_pos[b] = (i64)npos;
-    p->b_chain[b] = (i64)nchain;
-    npos += tot[b];
-    nchain += tot[32 + b];
+  const unsigned long long npos = npos32;
+  {
+    i64 c = 0;
+    for (int b = 0; b < 32; ++b) {
+      p->b_chain[b] = c;
+      c += hist[b];
+    }
+    p->b_chain[32] = c;
   }
-  b_pos[32] = (i64)npos;
-  p->b_chain[32] = (i64)nchain;
   p->ntrunk = (i64)npos;
   p->nchain = (i64)nchain;
-  DevBuf ucell, w, cpos, clenp, ctail, cpad, tmp, pick;
+  upa.alloc(0);  // (the list of chain ends is no longer needed: ctail holds them in layout order)
   if ((rc = ucell.alloc(std::max<size_t>(npos, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = w.alloc((npos + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = cpos.alloc(std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = clenp.alloc(std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = ctail.alloc(std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = cpad.alloc((nchain + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
-  if (hipMemcpyAsync(buckets.p, cur, sizeof(cur), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_place<1><<<grid, 256, 0, h->stream>>>(seed.as<u32>(), depth, len_at.as<u32>(), n,
-                                               buckets.as<unsigned long long>(), base_at.as<u32>(), cpos.as<u32>(),
-                                               clenp.as<u32>(), ctail.as<u32>());
   if (hipMemsetAsync(w.p, 0, (npos + 1) * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_scatter<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(),
-                                              len_at.as<u32>(), base_at.as<u32>(), n, ucell.as<u32>(), w.as<u32>());
+  k_plan_scatter<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at,
+                                              rank_of.as<u32>(), cpos.as<u32>(), clenp.as<u32>(), n, ucell.as<u32>(),
+                                              w.as<u32>());
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   // slot of a position = exclusive scan of the slots the positions before it need (in place)
-  size_t tmp_bytes = 0;
   if (rocprim::exclusive_scan(nullptr, tmp_bytes, w.as<u32>(), w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
                               h->stream) != hipSuccess)
     return fail(PFD_EHIP);
@@ -542,12 +572,12 @@ int pfd_ensure_xplan(pfd_raster *h) {
       hipMemsetAsync(p->spost, 0, nwords * sizeof(u32), h->stream) != hipSuccess)
     return fail(PFD_EHIP);
   if (npos) {
-    // (base_at is reused: from here on it holds the padding adjustment of the chain ending at that cell)
     k_plan_chains<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(cpos.as<u32>(), clenp.as<u32>(), ctail.as<u32>(),
                                                                 w.as<u32>(), cpad.as<u32>(), hinfo.as<uint16_t>(),
-                                                                (u32)nchain, p->cstart, p->clen, base_at.as<u32>());
+                                                                (u32)nchain, p->cstart, p->clen, adj.as<u32>());
     k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<u32>(), w.as<u32>(), hinfo.as<uint16_t>(),
-                                                              tailnum.as<u32>(), base_at.as<u32>(), h->geo, (u32)npos,
+                                                              tailnum.as<u32>(), tidx_at, rank_of.as<u32>(), adj.as<u32>(), h->geo,
+                                                              (u32)npos,
                                                               p->scell, p->sinfo, p->spost);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(PFD_EHIP);
