@@ -301,14 +301,21 @@ def c3_lines(size, regime, steps, device):
 def run_distributed(a, rank, world, local):
     """N > 1: one rank per GPU, STRONG scaling — the size x size raster is split into N row blocks;
     every rank generates its own rows (+ one halo row per inner edge) directly in its HBM."""
-    import torch
-    import torch.distributed as dist
-
     from pyflwdir_amd import dist as pdist
+    from pyflwdir_amd import hostgroup
 
     for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
         os.environ.setdefault(k, v)  # (only missing for the single-process PFD_BENCH_FORCE_DIST run)
-    dist.init_process_group(backend="gloo")  # barrier / max-reduce only (CPU)
+    # host-side group for barrier / max-reduce / unique-id rendezvous.  Launched by torch.distributed.run the
+    # rendezvous store of torch is already there (gloo, CPU); PFD_BENCH_GROUP=tcp uses the library's own
+    # torch-free TCP group instead
+    if os.environ.get("PFD_BENCH_GROUP", "torch") == "tcp":
+        grp = hostgroup.HostGroup(rank, world)
+    else:
+        import torch.distributed as tdist
+
+        tdist.init_process_group(backend="gloo")
+        grp = hostgroup.TorchGroup()
     device = local % max(1, _hip.device_count())  # (one rank per GPU; the modulo only matters on test boxes)
     ncol = nrow_total = a.size
     r0, r1 = pdist.block_rows(nrow_total, world)[rank]
@@ -318,9 +325,9 @@ def run_distributed(a, rank, world, local):
     d8_buf = _hip.synth_d8_device(nrow_total, ncol, row0=r0 - top, nrows=own + top + bot, device=device, **synth)
     out_buf = _hip.DeviceBuffer(own * ncol * 4, device)
     # RCCL communicator (all-gather over xGMI); if it cannot be brought up on every rank the same protocol
-    # runs with the records travelling through the host (transport named in the output)
-    probe = pdist.DistributedRaster(d8_buf, own, ncol, rank, world, device, memspace=_hip.PFD_DEVICE,
-                                    transport=os.environ.get("PFD_DIST_TRANSPORT", "auto"))
+    # runs with the records travelling through the host group (transport named in the output)
+    probe = pdist.DistributedRaster(d8_buf, own, ncol, rank, world, device, memspace=_hip.PFD_DEVICE, group=grp,
+                                    transport=os.environ.get("PFD_DIST_TRANSPORT", "auto"), deferred=True)
     comm, transport = probe.comm, probe.transport
     probe.handle.close()
 
@@ -342,35 +349,34 @@ def run_distributed(a, rank, world, local):
     for _ in range(a.warmup):
         step()
     _hip.check(_hip.lib().pfd_device_synchronize(device))
-    dist.barrier()
+    grp.barrier()
     t0 = time.perf_counter()
     timed = [step(profile=True) for _ in range(a.steps)]
     _hip.check(_hip.lib().pfd_device_synchronize(device))
-    dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt[0])
+    grp.barrier()
+    dt = grp.allreduce(time.perf_counter() - t0, "max")
     segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
-    # cross-rank invariant: the cells draining off the last row of the raster carry every cell
-    # (river regime: every pit sits on the last row); checksum of the whole result for the 1-vs-N comparison
-    res = out_buf.download(np.int32, (own, ncol))
-    csum = int(res.astype(np.int64).sum())  # (sum over ranks == the 1-GPU run's invariants.result_checksum)
-    stats = torch.tensor([info["n_valid"], info["n_pits"], csum], dtype=torch.int64)
-    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    pit_sum = torch.zeros(1, dtype=torch.int64)
+    # checksum of the whole result (the sum over the ranks must equal the 1-GPU run's
+    # invariants.result_checksum: SURVEY §8d C4 check iii) and the pit-sum invariant (river regime: every
+    # pit sits on the last row of the raster)
+    csum = _hip.checksum_i32(out_buf, own * ncol, device)
+    n_valid = grp.allreduce(int(info["n_valid"]), "sum")
+    n_pits = grp.allreduce(int(info["n_pits"]), "sum")
+    csum = grp.allreduce(int(csum), "sum")
+    pit_sum = 0
     if rank == world - 1:
         last_codes = d8_buf.download(np.uint8, (ncol,), offset_bytes=(top + own - 1) * ncol)
-        pit_sum[0] = int(res[-1][last_codes == 0].astype(np.int64).sum())
-    dist.all_reduce(pit_sum, op=dist.ReduceOp.SUM)
+        last_upa = out_buf.download(np.int32, (ncol,), offset_bytes=(own - 1) * ncol * 4)
+        pit_sum = int(last_upa[last_codes == 0].astype(np.int64).sum())
+    pit_sum = grp.allreduce(pit_sum, "sum")
     if rank == 0:
         n = nrow_total * ncol
         ms_per_step = dt / a.steps * 1e3
         roof = roofline_upa(segs, own * ncol, own, ncol, ms_per_step)
         roof["per_gpu"] = True
-        roof["whole_pass"] = dict(alg_bytes_per_cell=B_ALG["upstream_area_cell"],
-                                  achieved=round(B_ALG["upstream_area_cell"] * n / (ms_per_step * 1e-3) / 1e9 / world, 2),
-                                  frac=round(B_ALG["upstream_area_cell"] * n / (ms_per_step * 1e-3) / 1e9 / world / PEAK_HBM_GBS, 5),
-                                  note="per GPU")
+        per_gpu = B_ALG["upstream_area_cell"] * n / (ms_per_step * 1e-3) / 1e9 / world
+        roof["whole_pass"] = dict(alg_bytes_per_cell=B_ALG["upstream_area_cell"], achieved=round(per_gpu, 2),
+                                  frac=round(per_gpu / PEAK_HBM_GBS, 5), note="per GPU")
         out = dict(metric="Mcells/s upstream_area on D8 raster", value=round(n * a.steps / dt / 1e6, 2), unit="Mcells/s",
                    n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3),
                    higher_is_better=True, scaling="strong", vs_baseline=None, dtype="int32", data="synthetic",
@@ -378,16 +384,17 @@ def run_distributed(a, rank, world, local):
                                         f"into {world} row blocks ({own} rows + halo on rank 0), one block per GPU, "
                                         "upstream_area(unit='cell') int32; a step = decode + local solve + all-gather of "
                                         "the boundary records + interface solve + final pass on fresh handles",
-                               n_cells=n, n_valid=int(stats[0]), n_pits=int(stats[1]),
-                               parallelism=f"{world} row blocks, 1 all-gather/pass", transport=transport),
-                   roofline=roof, result_checksum=int(stats[2]),
-                   invariants=dict(last_row_pit_sum_equals_n_valid=bool(int(pit_sum[0]) == int(stats[0]))
-                                   if a.regime == "river" else None))
+                               n_cells=n, n_valid=n_valid, n_pits=n_pits,
+                               parallelism=f"{world} row blocks, 1 all-gather/pass", transport=transport,
+                               host_group=type(grp).__name__),
+                   roofline=roof,
+                   invariants=dict(result_checksum=csum,
+                                   last_row_pit_sum_equals_n_valid=bool(pit_sum == n_valid) if a.regime == "river" else None))
         print(json.dumps(out))
-    dist.barrier()
+    grp.barrier()
     if comm is not None:
         comm.close()
-    dist.destroy_process_group()
+    grp.close()
 
 
 def main():

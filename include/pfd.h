@@ -238,6 +238,10 @@ int pfd_graph_stats(pfd_raster *h, int64_t stats[16]);
  * ones, pyflwdir/streams.py:15-41; invariant [2] == [5]: tests/test_streams_basins.py:24-27). */
 int pfd_verify_upstream_area_cell(pfd_raster *h, const int32_t *upa, int memspace, int64_t res[8]);
 
+/* sum of n int32 values in HBM (two's complement, 64 bit): the checksum multi-block runs compare with a
+ * single-GPU run of the same raster */
+int pfd_checksum_i32(int device, const int32_t *dev_ptr, int64_t n, int64_t *sum);
+
 /* ---- synthetic rasters (bench / tests; device twin of oracle/pfd_oracle.c orc_synth_*) ---- */
 /* writes rows [row0, row0+nrows) of the nrow x ncol synthetic raster to device memory */
 int pfd_synth_d8(int device, uint64_t seed, int64_t nrow, int64_t ncol, int64_t tilt, int64_t white,

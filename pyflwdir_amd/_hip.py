@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32",
 ]
 
 _lib = None
@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
         L.pfd_stream_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.pfd_verify_upstream_area_cell.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        L.pfd_checksum_i32.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int)]
@@ -407,6 +408,13 @@ class Communicator:
         if self._c:
             lib().pfd_comm_destroy(self._c)
             self._c = C.c_void_p()
+
+
+def checksum_i32(buf, n: int, device: int = 0) -> int:
+    """Sum (64-bit two's complement) of n int32 values in a device buffer."""
+    out = C.c_int64(0)
+    check(lib().pfd_checksum_i32(device, ptr(buf), int(n), C.byref(out)))
+    return int(out.value)
 
 
 # -- synthetic rasters generated in HBM ---------------------------------------------------------

@@ -78,3 +78,30 @@ extern "C" int pfd_verify_upstream_area_cell(pfd_raster *h, const int32_t *upa, 
   for (int k = 0; k < 8; ++k) res[k] = (int64_t)r[k];
   return PFD_OK;
 }
+
+// sum of n int32 values (two's complement, 64 bit): the checksum the N-block runs compare with the 1-GPU run
+__global__ void __launch_bounds__(256) k_checksum_i32(const i32 *__restrict__ v, u64 n, unsigned long long *__restrict__ res) {
+  unsigned long long s = 0;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) s += (unsigned long long)(long long)v[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  __shared__ unsigned long long sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(res, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+extern "C" int pfd_checksum_i32(int device, const int32_t *dev_ptr, int64_t n, int64_t *sum) {
+  if (!dev_ptr || n < 0 || !sum) {
+    pfd_set_error("pfd_checksum_i32: bad arguments");
+    return PFD_EINVAL;
+  }
+  HIPCHK(hipSetDevice(device));
+  unsigned long long *acc = nullptr, host = 0;
+  HIPCHK(hipMalloc((void **)&acc, 8));
+  HIPCHK(hipMemset(acc, 0, 8));
+  if (n) k_checksum_i32<<<4096, 256>>>(dev_ptr, (u64)n, acc);
+  hipError_t e = hipMemcpy(&host, acc, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(acc);
+  HIPCHK(e);
+  *sum = (int64_t)host;
+  return PFD_OK;
+}

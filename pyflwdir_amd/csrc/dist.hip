@@ -31,6 +31,7 @@
 struct pfd_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
+  int *flag_dev = nullptr;  // two agreement words, allocated with the communicator (no allocation on the collective path)
 };
 
 #define NCCLCHK(expr)                                                                       \
@@ -71,6 +72,12 @@ extern "C" int pfd_comm_create(const void *id, size_t len, int rank, int world, 
     delete c;
     return PFD_ECOMM;
   }
+  if (hipMalloc((void **)&c->flag_dev, 64) != hipSuccess) {
+    pfd_set_error("pfd_comm_create: device allocation failed");
+    (void)ncclCommDestroy(c->comm);
+    delete c;
+    return PFD_ENOMEM;
+  }
   *out = c;
   return PFD_OK;
 }
@@ -78,6 +85,7 @@ extern "C" int pfd_comm_create(const void *id, size_t len, int rank, int world, 
 extern "C" int pfd_comm_destroy(pfd_comm *c) {
   if (c) {
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->flag_dev) (void)hipFree(c->flag_dev);
     delete c;
   }
   return PFD_OK;
@@ -172,7 +180,9 @@ extern "C" int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32
   std::vector<OutArg> o(nblocks);
   const size_t recw = 4 * (size_t)ncol;
   std::vector<u32> allrec_host((size_t)nblocks * recw);
-  for (int b = 0; b < nblocks; ++b) {  // phase A on every block
+  // phase A of every block is issued before the first synchronisation: blocks on different GPUs (and, as
+  // far as the hardware allows, on different streams of one GPU) run concurrently
+  for (int b = 0; b < nblocks; ++b) {
     pfd_raster *h = hs[b];
     PFDCHK(pfd_check_handle_lazy(h));
     pfd_seg_clear(h);
@@ -182,15 +192,23 @@ extern "C" int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32
       pfd_set_error("pfd_upstream_area_cell_blocks: block %d is too large for the tiled engine", b);
       return PFD_EUNSUPPORTED;
     }
-    PFDCHK(runs[b].phase_a_checked());
-    DevBuf rec;
-    PFDCHK(rec.alloc(recw * sizeof(u32)));
+    PFDCHK(runs[b].phase_a());
+  }
+  std::vector<DevBuf> recs(nblocks);
+  for (int b = 0; b < nblocks; ++b) {
+    pfd_raster *h = hs[b];
+    PFDCHK(pfd_check_handle_lazy(h));
+    PFDCHK(runs[b].phase_a_check());
+    PFDCHK(recs[b].alloc(recw * sizeof(u32)));
     k_pack_record<<<cdiv_u32(2 * (u32)ncol, 256), 256, 0, h->stream>>>(runs[b].haloL, runs[b].brow_sink, (u32)ncol,
-                                                                     rec.as<u32>());
+                                                                     recs[b].as<u32>());
     KCHK();
-    HIPCHK(hipMemcpyAsync(allrec_host.data() + (size_t)b * recw, rec.p, recw * sizeof(u32), hipMemcpyDeviceToHost,
+    HIPCHK(hipMemcpyAsync(allrec_host.data() + (size_t)b * recw, recs[b].p, recw * sizeof(u32), hipMemcpyDeviceToHost,
                           h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  for (int b = 0; b < nblocks; ++b) {
+    PFDCHK(pfd_check_handle_lazy(hs[b]));
+    HIPCHK(hipStreamSynchronize(hs[b]->stream));
   }
   int all_complete = 1;
   for (int b = 0; b < nblocks; ++b) {  // "all-gather" = every block gets all records; then phase B
@@ -311,30 +329,54 @@ extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_
   const u32 ncol = (u32)h->ncol;
   const size_t recw = 4 * (size_t)ncol;
   pfd_seg_clear(h);
+  // Every rank reaches every collective whatever happens locally (a rank that returned early would leave the
+  // others waiting in RCCL forever).  Local set-up (all allocations) comes first and is followed by an
+  // agreement: if it failed anywhere, all ranks return before any data collective starts.  After that, local
+  // failures - also of the collectives themselves - are carried to the final agreement.
   OutArg o;
-  PFDCHK(o.bind(out, (size_t)h->own_rows * ncol * sizeof(i32), memspace));
   TiledRun run;
-  PFDCHK(run.init(h, (i32 *)o.dev));
-  if (!run.supported) {
+  DevBuf rec, allrec;
+  int rc = o.bind(out, (size_t)h->own_rows * ncol * sizeof(i32), memspace);
+  if (rc == PFD_OK) rc = run.init(h, (i32 *)o.dev);
+  if (rc == PFD_OK && !run.supported) {
     pfd_set_error("pfd_upstream_area_cell_dist: the block is too large for the tiled engine");
-    return PFD_EUNSUPPORTED;
+    rc = PFD_EUNSUPPORTED;
   }
-  // From here on every rank must reach both collectives whatever happens locally (a rank that
-  // returned early would leave the others waiting in RCCL forever): local failures are carried to
-  // the final agreement instead.
-  int rc = run.phase_a_checked();
+  int *flag = comm->flag_dev;
   if (world > 1) {
-    DevBuf rec, allrec;
-    PFDCHK(rec.alloc(recw * sizeof(u32)));
-    PFDCHK(allrec.alloc((size_t)world * recw * sizeof(u32)));
+    if (rc == PFD_OK) rc = rec.alloc(recw * sizeof(u32));
+    if (rc == PFD_OK) rc = allrec.alloc((size_t)world * recw * sizeof(u32));
+    int ready = rc == PFD_OK ? 1 : 0, ready_all = 0;
+    bool comm_ok = hipMemcpyAsync(flag, &ready, sizeof(int), hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    comm_ok = ncclAllReduce(flag, flag + 8, 1, ncclInt32, ncclMin, comm->comm, h->stream) == ncclSuccess && comm_ok;
+    comm_ok = hipMemcpyAsync(&ready_all, flag + 8, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess && comm_ok;
+    comm_ok = hipStreamSynchronize(h->stream) == hipSuccess && comm_ok;
+    if (rc != PFD_OK) return rc;  // (every rank leaves here: ready_all is 0 everywhere)
+    if (!comm_ok) {
+      pfd_set_error("pfd_upstream_area_cell_dist: the set-up agreement (ncclAllReduce) failed");
+      return PFD_ECOMM;
+    }
+    if (!ready_all) {
+      pfd_set_error("pfd_upstream_area_cell_dist: another rank could not set up its block (out of memory or unsupported size)");
+      return PFD_EUNSUPPORTED;
+    }
+  } else if (rc != PFD_OK) {
+    return rc;
+  }
+  rc = run.phase_a_checked();
+  if (world > 1) {
     pfd_seg_begin(h, "allgather");
     if (rc == PFD_OK) {
       k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(run.haloL, run.brow_sink, ncol, rec.as<u32>());
     } else {
       (void)hipMemsetAsync(rec.p, 0, recw * sizeof(u32), h->stream);
     }
-    NCCLCHK(ncclAllGather(rec.p, allrec.p, recw, ncclUint32, comm->comm, h->stream));
+    const ncclResult_t r1 = ncclAllGather(rec.p, allrec.p, recw, ncclUint32, comm->comm, h->stream);
     pfd_seg_end(h, 2);
+    if (r1 != ncclSuccess && rc == PFD_OK) {
+      pfd_set_error("ncclAllGather failed: %s", ncclGetErrorString(r1));
+      rc = PFD_ECOMM;
+    }
     if (rc == PFD_OK) rc = interface_solve(run, allrec.as<u32>(), (u32)world, (u32)rank);
   }
   int complete = 0;
@@ -343,12 +385,17 @@ extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_
   // every rank must agree on success: a cycle anywhere invalidates downstream blocks as well
   int ok_local = (rc == PFD_OK && complete) ? 1 : 0, ok_all = ok_local;
   if (world > 1) {
-    DevBuf flag;
-    PFDCHK(flag.alloc(sizeof(int)));
-    HIPCHK(hipMemcpyAsync(flag.p, &ok_local, sizeof(int), hipMemcpyHostToDevice, h->stream));
-    NCCLCHK(ncclAllReduce(flag.p, flag.p, 1, ncclInt32, ncclMin, comm->comm, h->stream));
-    HIPCHK(hipMemcpyAsync(&ok_all, flag.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    const char *what = nullptr;
+    if (hipMemcpyAsync(flag, &ok_local, sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) what = "upload of the agreement flag";
+    const ncclResult_t r2 = ncclAllReduce(flag, flag + 8, 1, ncclInt32, ncclMin, comm->comm, h->stream);
+    if (r2 != ncclSuccess) what = "ncclAllReduce";
+    if (hipMemcpyAsync(&ok_all, flag + 8, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+      what = "download of the agreement flag";
+    if (what && rc == PFD_OK) {
+      pfd_set_error("pfd_upstream_area_cell_dist: %s failed", what);
+      rc = PFD_ECOMM;
+    }
   }
   if (rc != PFD_OK) return rc;  // the local failure (its message is already set)
   if (!ok_all) {

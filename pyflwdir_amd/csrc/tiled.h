@@ -209,6 +209,7 @@ struct TiledRun {
   bool overflowed = false;
   int phase_a();
   int phase_a_checked();
+  int phase_a_check();
   int phase_b(int *complete);
 };
 

@@ -1132,6 +1132,10 @@ int TiledRun::phase_b(int *complete) {
 // the per-hypertile id range has to be known (and repaired by a flat re-run) before that
 int TiledRun::phase_a_checked() {
   PFDCHK(phase_a());
+  return phase_a_check();
+}
+// the check alone: callers that run phase A of several blocks concurrently issue all of them first
+int TiledRun::phase_a_check() {
   for (int tries = 0; sa.hmode && tries < 3; ++tries) {
     u64 c[8];
     HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));

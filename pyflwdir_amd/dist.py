@@ -3,8 +3,7 @@ per GPU, one small RCCL all-gather per pass (kernels and protocol: csrc/dist.hip
 
 The reference has no distributed code at all; this module only adds what a
 driver script needs: the row partition, halo handling, and the rendezvous of the RCCL unique id
-through an existing ``torch.distributed`` process group (any backend — ``gloo`` on CPU works,
-nothing but 128 bytes travels through it).
+through a host-side process group — by default ``hostgroup.HostGroup``: plain TCP, no PyTorch.
 """
 from __future__ import annotations
 
@@ -56,74 +55,101 @@ def upstream_area_blocks(d8: np.ndarray, nblocks: int, devices=None, deferred: b
 
 
 def exchange_unique_id(rank: int, world: int, group=None) -> bytes:
-    """Rank 0 creates the RCCL unique id, everybody receives it through torch.distributed."""
-    import torch
-    import torch.distributed as dist
+    """Rank 0 creates the RCCL unique id, everybody receives it through the host group."""
+    group = group or _default_group(rank, world)
+    uid = _hip.Communicator.unique_id() if rank == 0 else b""
+    return group.bcast(uid, 0)
 
-    t = torch.zeros(_hip.Communicator.UID_BYTES, dtype=torch.uint8)
-    if rank == 0:
-        t = torch.frombuffer(bytearray(_hip.Communicator.unique_id()), dtype=torch.uint8).clone()
-    if world > 1:
-        dist.broadcast(t, src=0, group=group)
-    return bytes(t.numpy().tobytes())
+
+_GROUP = None
+
+
+def _default_group(rank, world):
+    """The process-wide HostGroup (plain TCP rendezvous, MASTER_ADDR / MASTER_PORT + 23): created on first use."""
+    global _GROUP
+    if _GROUP is None or _GROUP.world != world:
+        from .hostgroup import HostGroup
+
+        _GROUP = HostGroup(rank, world)
+    return _GROUP
 
 
 def _try_rccl(uid, rank, world, device, timeout):
     """Create the RCCL communicator in a watchdog thread: a bootstrap that cannot reach its peers
-    blocks forever instead of failing."""
+    blocks forever instead of failing.  A creation that finishes after the watchdog gave up destroys its
+    communicator again."""
     import threading
 
-    box = {}
+    box, lock = {}, threading.Lock()
 
     def work():
         try:
-            box["comm"] = _hip.Communicator(uid, rank, world, device)
+            comm = _hip.Communicator(uid, rank, world, device)
         except Exception as exc:  # noqa: BLE001 - any failure means "use the host transport"
-            box["err"] = exc
+            comm, box["err"] = None, exc
+        with lock:
+            if box.get("abandoned") and comm is not None:
+                comm.close()
+            else:
+                box["comm"] = comm
 
     t = threading.Thread(target=work, daemon=True)
     t.start()
     t.join(timeout)
-    return box.get("comm")
+    with lock:
+        if "comm" not in box:
+            box["abandoned"] = True
+        return box.get("comm")
 
 
 class DistributedRaster:
     """The row block of this rank; ``upstream_area()`` is collective over the process group.
 
+    ``group``: anything with ``bcast(bytes, src) / allgather(bytes) -> [bytes] / allreduce(x, op)`` —
+    by default a :class:`pyflwdir_amd.hostgroup.HostGroup` (plain TCP, no PyTorch, no MPI).
+
     transport="rccl": one ``ncclAllGather`` of the 4*ncol-word boundary record over xGMI (default).
-    transport="host": the same record travels through ``torch.distributed.all_gather`` (any backend);
-    identical kernels on either side of the exchange (split-phase C-ABI).  With transport="auto" RCCL
-    is tried first and every rank falls back to "host" if any rank could not create its communicator.
+    transport="host": the same record travels through ``group.allgather``; identical kernels on either
+    side of the exchange (split-phase C-ABI).  With transport="auto" RCCL is tried first and every rank
+    falls back to "host" if any rank could not create its communicator.
     """
 
     def __init__(self, d8_block, own_rows: int, ncol: int, rank: int, world: int, device: int,
-                 memspace=_hip.PFD_HOST, transport="auto", group=None, rccl_timeout=120.0):
-        import torch
-        import torch.distributed as dist
-
-        self.rank, self.world, self.device, self.group = rank, world, device, group
-        self.handle = _hip.RasterHandle(d8_block, own_rows, ncol, device=device, memspace=memspace,
-                                        halo=halo_of(rank, world))
+                 memspace=_hip.PFD_HOST, transport="auto", group=None, rccl_timeout=120.0, deferred=False):
+        self.rank, self.world, self.device = rank, world, device
+        self.group = group or _default_group(rank, world)
+        # a rank whose block cannot be created (bad code, out of memory) still takes part in the
+        # collectives below and raises afterwards: nobody is left waiting
+        err = None
+        self.handle = None
+        try:
+            self.handle = _hip.RasterHandle(d8_block, own_rows, ncol, device=device, memspace=memspace,
+                                            halo=halo_of(rank, world), deferred=deferred)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
         self.comm = None
-        if transport in ("auto", "rccl") and world >= 1:
-            uid = exchange_unique_id(rank, world, group)
-            self.comm = _try_rccl(uid, rank, world, device, rccl_timeout)
-            ok = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int32)
-            if world > 1:
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-            if int(ok[0]) == 0:
-                if transport == "rccl":
-                    raise RuntimeError("RCCL communicator could not be created on every rank")
-                self.comm = None  # a created communicator is simply not used
+        if transport in ("auto", "rccl"):
+            uid = exchange_unique_id(rank, world, self.group)
+            if err is None:
+                self.comm = _try_rccl(uid, rank, world, device, rccl_timeout)
+            ok = self.group.allreduce(1 if self.comm is not None else 0, "min")
+            if ok == 0:
+                if self.comm is not None:
+                    self.comm.close()  # created here, unusable elsewhere
+                    self.comm = None
+                if transport == "rccl" and err is None:
+                    err = RuntimeError("RCCL communicator could not be created on every rank")
+        all_ok = self.group.allreduce(0 if err is not None else 1, "min")
+        if err is not None:
+            raise err
+        if all_ok == 0:
+            raise RuntimeError("another rank could not create its row block")
         self.transport = "rccl" if self.comm is not None else "host"
 
     def upstream_area(self, out=None, memspace=_hip.PFD_HOST):
         if self.comm is not None:
             res = self.comm.upstream_area_cell(self.handle, out=out, memspace=memspace)
         else:
-            import torch
-            import torch.distributed as dist
-
             # every rank reaches both collectives whatever happens locally (a rank that raised early
             # would leave the others waiting): a local failure travels with the final agreement
             err, res, ok = None, out, False
@@ -132,30 +158,24 @@ class DistributedRaster:
                 res, rec = _hip.upstream_area_cell_begin(self.handle, out=out, memspace=memspace)
             except Exception as exc:  # noqa: BLE001
                 err = exc
-            mine = torch.from_numpy(rec.view(np.int32).copy())
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            if self.world > 1:
-                dist.all_gather(parts, mine, group=self.group)
-            else:
-                parts = [mine]
+            parts = self.group.allgather(rec.tobytes())
             if err is None:
                 try:
-                    allrec = np.stack([p.numpy().view(np.uint32) for p in parts])
+                    allrec = np.stack([np.frombuffer(p, np.uint32) for p in parts])
                     ok = _hip.upstream_area_cell_finish(self.handle, allrec, self.world, self.rank)
                 except Exception as exc:  # noqa: BLE001
                     err = exc
-            flag = torch.tensor([1 if (ok and err is None) else 0], dtype=torch.int32)
-            if self.world > 1:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            flag = self.group.allreduce(1 if (ok and err is None) else 0, "min")
             if err is not None:
                 raise err
-            if int(flag[0]) == 0:
+            if flag == 0:
                 raise NotImplementedError("a row block failed or the raster holds cells that never reach a pit "
                                           "(cycles); the multi-GPU path requires a valid flow direction raster "
                                           "(FlwdirRaster.isvalid)")
         return res.reshape(self.handle.nrow, self.handle.ncol) if memspace == _hip.PFD_HOST else res
 
     def close(self):
-        self.handle.close()
+        if self.handle is not None:
+            self.handle.close()
         if self.comm is not None:
             self.comm.close()

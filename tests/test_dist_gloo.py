@@ -2,7 +2,8 @@
 
 What can run without a GPU is the host side of the multi-GPU path and the PROTOCOL itself:
  * row partition / halo bookkeeping (pyflwdir_amd.dist),
- * the rendezvous of the 128-byte RCCL unique id through torch.distributed,
+ * the rendezvous of the 128-byte RCCL unique id through the host group interface (here the
+   torch.distributed adapter; the torch-free TCP group is tested in tests/test_hostgroup.py),
  * the block protocol of csrc/dist.hip restated in numpy — local solve with the halo rows as
    weightless sinks, all-gather of the boundary records {L_top, L_bottom, sink_first, sink_last},
    redundant interface-forest solve, final local solve with the boundary inflow — with the
@@ -47,8 +48,12 @@ def _worker(rank, world, port, tmpdir):
     try:
         # 1) unique-id rendezvous (the id itself comes from RCCL on a GPU box; here a stand-in)
         _hip.Communicator.unique_id = staticmethod(lambda: bytes(range(128)))
-        uid = pdist.exchange_unique_id(rank, world)
+        from pyflwdir_amd.hostgroup import TorchGroup
+
+        grp = TorchGroup()
+        uid = pdist.exchange_unique_id(rank, world, grp)
         assert uid == bytes(range(128))
+        assert grp.allreduce(rank + 1, "min") == 1 and grp.allreduce(float(rank), "max") == world - 1
 
         # 2) the block protocol, numpy + oracle + gloo all_gather
         for shape, seed, kw in [((97, 120), 21, dict(tilt=1 << 26, white=2, nodata_pct=0)),

@@ -1,0 +1,65 @@
+"""The one-process-per-GPU entry points on the single GPU of the test box:
+ * pfd_comm_create + pfd_upstream_area_cell_dist with world = 1 (RCCL communicator of one rank);
+ * bench.py launched as 2 ranks by torch.distributed.run and by plain processes over the torch-free TCP
+   group, both ranks on the one GPU: RCCL refuses two ranks on one device, so the records travel through
+   the host group — everything else (row blocks with halos, deferred handles, split-phase C-ABI, interface
+   solve, final pass, agreement) is the N > 1 path.  The result checksum must equal the single-GPU run's."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_comm_world_1(gpu_lib, oracle):
+    from pyflwdir_amd import _hip
+
+    d8 = oracle.synth_d8(700, 900, seed=11, tilt=1 << 26, white=2, nodata_pct=5)
+    exp = oracle.upstream_area_cell(d8)[0]
+    comm = _hip.Communicator(_hip.Communicator.unique_id(), 0, 1, 0)
+    for deferred in (False, True):
+        h = _hip.RasterHandle(d8, 700, 900, deferred=deferred)
+        got = comm.upstream_area_cell(h)
+        assert np.array_equal(got.reshape(700, 900), exp)
+        h.close()
+    comm.close()
+
+
+def _bench(args, env_extra, launcher):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29651",
+                 PFD_BENCH_GROUP="tcp")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    return json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "tcp"])
+def test_two_ranks_on_one_gpu(gpu_lib, launcher):
+    args = ["--size", "6000", "--steps", "2", "--warmup", "1"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary"] + args,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    two = _bench(args, dict(PFD_DIST_TRANSPORT="host"), launcher)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["transport"] == "host"
+    assert two["config"]["n_valid"] == ref["config"]["n_valid"] == 36_000_000
+    assert two["config"]["n_pits"] == ref["config"]["n_pits"]
+    assert two["invariants"]["last_row_pit_sum_equals_n_valid"] is True
+    assert two["invariants"]["result_checksum"] == ref["invariants"]["result_checksum"]
+    assert ref["invariants"]["all_cells_upa_equals_1_plus_children"] and ref["invariants"]["pit_sum_equals_n_valid"]
