@@ -1,0 +1,145 @@
+"""Parity at BASELINE.json's full sizes: what the oracle can still check in a minute or two
+is compared cell by cell; beyond that the size-independent properties of the domain take over.
+
+ * C3  30000 x 30000: float32 accuflux and Strahler order against the oracle (bit-exact), every cell.
+ * C4  90000 x 90000 (8.1 Gcells, beyond 2^32 tile addressing): every cell's local equation
+       upa == 1 + sum over the cells draining into it, -9999 on nodata, pit sum == n_valid (the reference's
+       own invariant, tests/test_streams_basins.py:24-27) — on an acyclic raster these equations have one
+       solution; the first rows against the oracle; and the 8-row-block run (the multi-GPU protocol, blocks
+       held by this process) must produce the same checksum and pass the same checks block by block.
+ * the uint32 rung of the index ladder (2^31 .. 2^32 cells, reference pyflwdir.py:105-127): idxs_ds /
+   idxs_pit exports against the oracle on sampled row bands.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RIVER = dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0)
+
+
+def test_c3_30000_accuflux_strahler_vs_oracle(gpu_lib, oracle):
+    from pyflwdir_amd import _hip
+
+    O = oracle
+    size = 30000
+    n = size * size
+    d8_buf = _hip.synth_d8_device(size, size, **RIVER)
+    d8 = d8_buf.download(np.uint8, (size, size))
+    assert np.array_equal(d8[:50], O.synth_d8(size, size, nrows=50, **RIVER))  # device generator == host generator
+    h = _hip.RasterHandle(d8_buf, size, size, memspace=_hip.PFD_DEVICE)
+    w_buf = _hip.synth_weights_device(n, seed=1)
+    out = _hip.DeviceBuffer(n * 4)
+    h.accuflux(w_buf, _hip.PFD_F32, nodata_f=-9999.0, has_nodata=1, out=out, memspace=_hip.PFD_DEVICE)
+    acc = out.download(np.float32, (n,))
+    sto = _hip.DeviceBuffer(n)
+    h.strahler(None, out=sto, memspace=_hip.PFD_DEVICE)
+    strord = sto.download(np.uint8, (n,))
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    assert seq.size == n
+    w = O.synth_weights_f32(n, seed=1)
+    assert np.array_equal(acc, O.accuflux(idxs_ds, seq, w))
+    assert np.array_equal(strord, O.strahler_order(idxs_ds, seq))
+    h.close()
+
+
+def test_c4_90000_properties_and_blocks(gpu_lib, oracle):
+    from pyflwdir_amd import _hip
+    from pyflwdir_amd import dist as pdist
+
+    size = 90000
+    d8_buf = _hip.synth_d8_device(size, size, **RIVER)
+    out = _hip.DeviceBuffer(size * size * 4)
+    h = _hip.RasterHandle(d8_buf, size, size, memspace=_hip.PFD_DEVICE, deferred=True)
+    h.upstream_area_cell(out=out, memspace=_hip.PFD_DEVICE)
+    info = h.info()
+    v = h.verify_upstream_area_cell(out, memspace=_hip.PFD_DEVICE)
+    assert v["bad_cells"] == 0 and v["bad_nodata"] == 0
+    assert v["n_valid"] == info["n_valid"] == size * size and v["n_pits"] == info["n_pits"]
+    assert v["pit_sum"] == info["n_valid"]
+    st = h.graph_stats()
+    assert st["max_rank"] >= size - 1 and sum(st["indegree_hist"]) == info["n_valid"]
+    h.close()
+    # the first rows against the oracle (no cell below them drains upwards: their upstream area is complete)
+    rows = 1200
+    d8_top = d8_buf.download(np.uint8, (rows + 1, size))
+    assert not np.isin(d8_top[rows], (32, 64, 128)).any()
+    exp = oracle.upstream_area_cell(d8_top[:rows])[0]
+    assert np.array_equal(out.download(np.int32, (rows, size)), exp)
+    whole_sum = v["checksum"]
+    out.free()
+    # 8 row blocks (the C4 split: 11250 rows each), all held by this process on the one GPU
+    nblocks = 8
+    handles, outs, bufs = [], [], []
+    for b, (r0, r1) in enumerate(pdist.block_rows(size, nblocks)):
+        top, bot = pdist.halo_of(b, nblocks)
+        blk = _hip.synth_d8_device(size, size, row0=r0 - top, nrows=(r1 - r0) + top + bot, **RIVER)
+        bufs.append(blk)
+        handles.append(_hip.RasterHandle(blk, r1 - r0, size, memspace=_hip.PFD_DEVICE, halo=(top, bot), deferred=True))
+        outs.append(_hip.DeviceBuffer((r1 - r0) * size * 4))
+    d8_buf.free()
+    _hip.upstream_area_cell_blocks(handles, outs, memspace=_hip.PFD_DEVICE)
+    total = 0
+    for b, (r0, r1) in enumerate(pdist.block_rows(size, nblocks)):
+        total += _hip.checksum_i32(outs[b], (r1 - r0) * size)
+    assert total == whole_sum
+    # spot check: the first rows of block 3 against the local equation with the row above (last row of block 2)
+    r0 = pdist.block_rows(size, nblocks)[3][0]
+    up3 = outs[3].download(np.int32, (2, size))
+    up2 = outs[2].download(np.int32, (1, size), offset_bytes=(pdist.block_rows(size, nblocks)[2][1] - pdist.block_rows(size, nblocks)[2][0] - 1) * size * 4)
+    codes = bufs[3].download(np.uint8, (3, size))  # halo row (= last row of block 2), first two own rows
+    exp = np.ones(size, np.int64)
+    for code, dc in ((2, 1), (4, 0), (8, -1)):  # cells of the row above that drain SE / S / SW into row r0
+        src = np.arange(size) - dc
+        ok = (src >= 0) & (src < size)
+        hit = ok & (codes[0, np.clip(src, 0, size - 1)] == code)
+        exp += np.where(hit, up2[0, np.clip(src, 0, size - 1)].astype(np.int64), 0)
+    for code, dc in ((1, 1), (16, -1)):  # E / W neighbours in the same row
+        src = np.arange(size) - dc
+        ok = (src >= 0) & (src < size)
+        hit = ok & (codes[1, np.clip(src, 0, size - 1)] == code)
+        exp += np.where(hit, up3[0, np.clip(src, 0, size - 1)].astype(np.int64), 0)
+    for code, dc in ((128, 1), (64, 0), (32, -1)):  # cells of the row below that drain NE / N / NW upwards
+        src = np.arange(size) - dc
+        ok = (src >= 0) & (src < size)
+        hit = ok & (codes[2, np.clip(src, 0, size - 1)] == code)
+        exp += np.where(hit, up3[1, np.clip(src, 0, size - 1)].astype(np.int64), 0)
+    assert np.array_equal(up3[0].astype(np.int64), exp)
+    for hh in handles:
+        hh.close()
+
+
+def test_uint32_index_rung(gpu_lib, oracle):
+    """50000 x 50000 = 2.5e9 cells: idxs_ds / idxs_pit in uint32 (mv = 4294967295), checked on row bands."""
+    from pyflwdir_amd import _hip
+
+    size = 50000
+    n = size * size
+    assert 2**31 - 1 <= n < 2**32 - 2
+    kw = dict(seed=3, tilt=100000, white=2, nodata_pct=20)
+    d8_buf = _hip.synth_d8_device(size, size, **kw)
+    h = _hip.RasterHandle(d8_buf, size, size, memspace=_hip.PFD_DEVICE)
+    ds = _hip.DeviceBuffer(n * 4)
+    _hip.check(_hip.lib().pfd_idxs_ds(h._h, _hip.PFD_U32, C.c_void_p(ds.addr), _hip.PFD_DEVICE))
+    npits = h.info()["n_pits"]
+    pits = np.empty(npits, np.uint32)
+    _hip.check(_hip.lib().pfd_idxs_pit(h._h, _hip.PFD_U32, _hip.ptr(pits), _hip.PFD_HOST))
+    assert np.all(np.diff(pits.astype(np.int64)) > 0)
+    for r0 in (0, 21474, 42949, size - 40):  # incl. the band where the linear index crosses 2^31
+        rows = min(40, size - r0)
+        a0, a1 = max(0, r0 - 1), min(size, r0 + rows + 1)
+        band = d8_buf.download(np.uint8, (a1 - a0, size), offset_bytes=a0 * size)
+        loc_ds, loc_pit, _ = oracle.from_array(band, dtype=np.int64)
+        loc = loc_ds.reshape(a1 - a0, size)[r0 - a0:r0 - a0 + rows]
+        exp = np.where(loc < 0, np.int64(0xFFFFFFFF), loc + a0 * size)
+        got = ds.download(np.uint32, (rows, size), offset_bytes=r0 * size * 4).astype(np.int64)
+        # (the band carries one context row on every inner side, so the compared rows see the same
+        #  neighbours as in the whole raster)
+        assert np.array_equal(got, exp)
+        in_band = pits[(pits >= r0 * size) & (pits < (r0 + rows) * size)].astype(np.int64)
+        exp_p = loc_pit[(loc_pit // size >= r0 - a0) & (loc_pit // size < r0 - a0 + rows)] + a0 * size
+        assert np.array_equal(in_band, exp_p)
+    h.close()
