@@ -214,6 +214,17 @@ int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int memspace, uint
 int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_records_host, int nblocks, int block,
                                   int *complete);
 
+/* basins (reference pyflwdir/basins.py:12-18, core.py:120-146) on a raster row-tiled over several GPUs /
+ * processes, split-phase like pfd_upstream_area_cell_begin/_finish (Multi-GPU): `outlets` are k
+ * linear indices INTO THE BLOCK'S OWN ROWS (r * ncol + c, r counted from the block's first own row), `ids`
+ * their labels (id_size bytes each, no zeros).  begin() runs the local label query and returns the block's
+ * boundary record (6 * ncol uint32, host); finish() takes the records of all blocks in block order
+ * (nblocks * 6 * ncol uint32, host), resolves the paths that leave the block and writes the own_rows * ncol
+ * labels to the `out` given to begin().  *complete = 0 reports a cycle through several blocks. */
+int pfd_basins_begin(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k, int id_size, void *out,
+                     int memspace, uint32_t *record_host);
+int pfd_basins_finish(pfd_raster *h, const uint32_t *all_records_host, int nblocks, int block, int *complete);
+
 /* ---- instrumentation ---------------------------------------------------------------------
  * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST
  * sweep/ordering call on the handle.  Enable with pfd_set_profiling(h, 1).  Up to max_seg

@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish",
 ]
 
 _lib = None
@@ -95,6 +95,8 @@ def lib() -> C.CDLL:
         L.pfd_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.pfd_verify_upstream_area_cell.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.pfd_checksum_i32.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.pfd_basins_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.pfd_basins_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int)]
@@ -378,6 +380,28 @@ def upstream_area_cell_finish(handle, all_records: np.ndarray, nblocks: int, blo
     assert all_records.size == nblocks * 4 * handle.ncol
     ok = C.c_int(0)
     check(lib().pfd_upstream_area_cell_finish(handle._h, ptr(all_records), nblocks, block, C.byref(ok)))
+    return bool(ok.value)
+
+
+def basins_begin(handle, outlets, ids, out=None, memspace=PFD_HOST):
+    """Local phase of a multi-block basins query; ``outlets`` index the block's own rows.  Returns
+    (out, record) with record = 6*ncol uint32."""
+    outlets = np.ascontiguousarray(outlets, dtype=np.int64).ravel()
+    ids = np.ascontiguousarray(ids).ravel()
+    if memspace == PFD_HOST:
+        out = np.empty(handle.n, ids.dtype)
+    rec = np.empty(6 * handle.ncol, np.uint32)
+    check(lib().pfd_basins_begin(handle._h, ptr(outlets), ptr(ids), outlets.size, ids.dtype.itemsize, ptr(out), memspace,
+                                 ptr(rec)))
+    handle._basins_out = out  # (the library writes it in finish: keep it alive)
+    return out, rec
+
+
+def basins_finish(handle, all_records: np.ndarray, nblocks: int, block: int) -> bool:
+    all_records = np.ascontiguousarray(all_records, dtype=np.uint32)
+    assert all_records.size == nblocks * 6 * handle.ncol
+    ok = C.c_int(0)
+    check(lib().pfd_basins_finish(handle._h, ptr(all_records), nblocks, block, C.byref(ok)))
     return bool(ok.value)
 
 

@@ -149,6 +149,7 @@ struct pfd_raster {
   u64 *ctrl = nullptr;
   size_t bytes_held = 0;
   void *pending = nullptr;  // split-phase multi-block pass in flight (dist.hip)
+  void *pending_basins = nullptr;  // split-phase multi-block basins query in flight (paths.hip)
   // profiling
   bool profiling = false;
   std::vector<PfdSegment> segs;
@@ -238,6 +239,7 @@ int pfd_order_cells_impl(pfd_raster *h);                        // order.hip
 int pfd_ensure_pits(pfd_raster *h);                             // order.hip
 int pfd_require_whole(pfd_raster *h, const char *what);          // order.hip
 void pfd_free_pending(pfd_raster *h);                            // dist.hip
+void pfd_free_pending_basins(pfd_raster *h);                     // paths.hip
 int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
 void pfd_free_xplan(pfd_raster *h);                             // exact.hip
 int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev,

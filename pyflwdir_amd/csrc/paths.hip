@@ -20,6 +20,8 @@
 #include <string.h>
 
 #include <cstring>
+#include <unordered_set>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -347,6 +349,266 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   if (maxrank) *maxrank = (u32)c[P_MAXRANK - 8];
   (void)launches;
   return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// basins on a raster row-tiled over several GPUs (BASELINE config 5): the mirror image of the
+// accumulation protocol of dist.hip.  A label is a property of the downstream path, so per block:
+//   begin   local label query with the halo cells as extra path ends carrying a TAG (side, column).  Every
+//           cell of the block then holds the number of a local outlet, 0 (its path ends at a pit of the
+//           block), or the tag of the halo cell through which its path leaves the block.  The record that
+//           leaves the GPU holds, per cell of the own first / last row: the final label, or that tag.
+//   exchange  all-gather of the records (6 * ncol words per block; any transport)
+//   finish  the halo cell (b, side, c) IS a boundary-row cell of block b -/+ 1: following the tags through
+//           the gathered records (host, O(interface cells), path compression) gives every halo cell of this
+//           block its final label; one streaming pass writes the block's labels.
+// Reference: basins.basins + core.fillnodata_upstream (pyflwdir/basins.py:12-18, core.py:120-146).
+// ---------------------------------------------------------------------------------------------
+#define BTAG 0x80000000u
+struct BasinsPending {
+  DevBuf num, ids;
+  OutArg out;
+  u32 k = 0;
+  int id_size = 0;
+};
+void pfd_free_pending_basins(pfd_raster *h) {
+  delete (BasinsPending *)h->pending_basins;
+  h->pending_basins = nullptr;
+}
+__global__ void k_seed_block(const i64 *__restrict__ idx, u32 k, u32 row_off, u32 ncol, u32 *__restrict__ seed) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < k) seed[(size_t)idx[t] + (size_t)row_off * ncol] = t + 1;
+}
+__global__ void k_seed_halo(const u8 *__restrict__ ncode, u32 ncol, u32 halo_top, u32 halo_bot, u32 nrow,
+                            u32 *__restrict__ seed) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncol) return;
+  const u32 side = t / ncol, col = t % ncol;
+  if ((side == 0 && !halo_top) || (side == 1 && !halo_bot)) return;
+  const size_t cell = (size_t)(side ? nrow - 1 : 0) * ncol + col;
+  if (ncode[cell] == D8_HALO) seed[cell] = BTAG | (side << 30) | col;
+}
+template <class L>
+__device__ __forceinline__ u64 label_bits(const L *ids, u32 num) { return num ? (u64)ids[num - 1] : 0ull; }
+template <class L>
+__global__ void k_basin_record(const u8 *__restrict__ ncode, const u32 *__restrict__ num, const L *__restrict__ ids,
+                               u32 ncol, u32 halo_top, u32 own_rows, u32 *__restrict__ rec) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncol) return;
+  const u32 side = t / ncol, col = t % ncol;
+  const size_t cell = (size_t)(halo_top + (side ? own_rows - 1 : 0)) * ncol + col;
+  u32 kind = 0;
+  u64 val = 0;
+  if (ncode[cell] != D8_MV) {
+    const u32 v = num[cell];
+    if (v & BTAG) {
+      kind = 1;
+      val = v & ~BTAG;
+    } else {
+      val = label_bits(ids, v);
+    }
+  }
+  rec[t] = kind;
+  rec[2 * ncol + t] = (u32)val;
+  rec[4 * ncol + t] = (u32)(val >> 32);
+}
+template <class L>
+__global__ void k_labels_out_block(const u32 *__restrict__ num, const L *__restrict__ ids,
+                                   const u64 *__restrict__ halo_label, u32 ncol, u32 n_own, L *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_own) return;
+  const u32 v = num[i];
+  L r = 0;
+  if (v & BTAG)
+    r = (L)halo_label[((v >> 30) & 1u) * ncol + (v & 0x3FFFFFFFu)];
+  else if (v)
+    r = ids[v - 1];
+  out[i] = r;
+}
+
+extern "C" int pfd_basins_begin(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k, int id_size,
+                                void *out, int memspace, uint32_t *record_host) {
+  PFDCHK(pfd_check_handle(h));
+  if (!out || !record_host || k < 0 || (k > 0 && (!outlets || !ids)) ||
+      (id_size != 1 && id_size != 2 && id_size != 4 && id_size != 8) || k >= 0x7FFFFFFFll) {
+    pfd_set_error("pfd_basins_begin: bad arguments (k=%lld, id_size=%d)", (long long)k, id_size);
+    return PFD_EINVAL;
+  }
+  if ((unsigned __int128)h->nrow * (unsigned __int128)h->ncol > 4294967294ull || (u64)h->ncol >= 0x40000000ull) {
+    pfd_set_error("pfd_basins_begin: the block is too large (32-bit cell indices)");
+    return PFD_EUNSUPPORTED;
+  }
+  pfd_free_pending_basins(h);
+  pfd_seg_clear(h);
+  const u32 ncol = (u32)h->ncol, n = h->geo.n;
+  const i64 n_own = h->own_rows * h->ncol;
+  // numpy's `basins[idxs] = ids` keeps the LAST id of a repeated index
+  std::vector<i64> uidx;
+  std::vector<unsigned char> uids;
+  {
+    std::unordered_set<i64> seen;
+    for (i64 j = k - 1; j >= 0; --j) {
+      const i64 i = outlets[j];
+      if (i < 0 || i >= n_own) {
+        pfd_set_error("pfd_basins_begin: outlet index %lld outside the block's own rows", (long long)i);
+        return PFD_EINVAL;
+      }
+      if (!seen.insert(i).second) continue;
+      uidx.push_back(i);
+      const unsigned char *src = (const unsigned char *)ids + (size_t)j * id_size;
+      uids.insert(uids.end(), src, src + id_size);
+    }
+  }
+  const u32 ku = (u32)uidx.size();
+  BasinsPending *p = new BasinsPending();
+  h->pending_basins = p;
+  p->k = ku;
+  p->id_size = id_size;
+  InArg di;
+  DevBuf seed;
+  int rc = di.bind(ku ? uidx.data() : nullptr, (size_t)ku * sizeof(i64), PFD_HOST, h->stream);
+  if (rc == PFD_OK) rc = p->ids.alloc(std::max<size_t>((size_t)ku * id_size, 8));
+  if (rc == PFD_OK && ku &&
+      hipMemcpyAsync(p->ids.p, uids.data(), (size_t)ku * id_size, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+    rc = PFD_EHIP;
+  if (rc == PFD_OK) rc = p->out.bind(out, (size_t)n_own * id_size, memspace);
+  if (rc == PFD_OK) rc = seed.alloc((size_t)n * sizeof(u32) + 64);
+  if (rc == PFD_OK) rc = p->num.alloc((size_t)n * sizeof(u32));
+  if (rc != PFD_OK) {
+    pfd_free_pending_basins(h);
+    return rc;
+  }
+  auto fail = [&](int code) {
+    (void)hipStreamSynchronize(h->stream);
+    pfd_free_pending_basins(h);
+    return code;
+  };
+  if (h->acyclic == 0) {  // (see pfd_basins_tiled: the label query must not hide a cycle)
+    int ok_rank = 0;
+    if ((rc = run_paths<MODE_RANK>(h, nullptr, p->num.as<u32>(), &ok_rank, nullptr)) != PFD_OK) return fail(rc);
+    h->acyclic = ok_rank ? 1 : -1;
+  }
+  if (h->acyclic < 0) {
+    pfd_set_error("the block holds cells that never reach a pit (cycles); the multi-block basins path requires a "
+                  "valid flow direction raster (FlwdirRaster.isvalid)");
+    return fail(PFD_EUNSUPPORTED);
+  }
+  if (hipMemsetAsync(seed.p, 0, (size_t)n * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
+  if (ku) k_seed_block<<<cdiv_u32(ku, 256), 256, 0, h->stream>>>((const i64 *)di.dev, ku, (u32)h->halo_top, ncol, seed.as<u32>());
+  k_seed_halo<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(h->ncode, ncol, (u32)h->halo_top, (u32)h->halo_bot,
+                                                              (u32)h->nrow, seed.as<u32>());
+  int complete = 0;
+  pfd_seg_begin(h, "tile_labels");
+  if ((rc = run_paths<MODE_LABEL>(h, seed.as<u32>(), p->num.as<u32>(), &complete, nullptr)) != PFD_OK) return fail(rc);
+  pfd_seg_end(h, 2);
+  if (!complete) {
+    pfd_set_error("pfd_basins_begin: the label query did not converge (cycles)");
+    return fail(PFD_EUNSUPPORTED);
+  }
+  DevBuf rec;
+  if ((rc = rec.alloc(6 * (size_t)ncol * sizeof(u32))) != PFD_OK) return fail(rc);
+  const u32 g = cdiv_u32(2 * ncol, 256);
+  switch (id_size) {
+    case 1: k_basin_record<u8><<<g, 256, 0, h->stream>>>(h->ncode, p->num.as<u32>(), p->ids.as<u8>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
+    case 2: k_basin_record<uint16_t><<<g, 256, 0, h->stream>>>(h->ncode, p->num.as<u32>(), p->ids.as<uint16_t>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
+    case 4: k_basin_record<u32><<<g, 256, 0, h->stream>>>(h->ncode, p->num.as<u32>(), p->ids.as<u32>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
+    default: k_basin_record<u64><<<g, 256, 0, h->stream>>>(h->ncode, p->num.as<u32>(), p->ids.as<u64>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
+  }
+  if (hipMemcpyAsync(record_host, rec.p, 6 * (size_t)ncol * sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  return PFD_OK;
+}
+
+extern "C" int pfd_basins_finish(pfd_raster *h, const uint32_t *all_records_host, int nblocks, int block, int *complete) {
+  PFDCHK(pfd_check_handle_lazy(h));
+  BasinsPending *p = (BasinsPending *)h->pending_basins;
+  if (!p || !all_records_host || nblocks < 1 || block < 0 || block >= nblocks || !complete) {
+    pfd_set_error("pfd_basins_finish: no query in flight on this handle, or bad arguments");
+    return PFD_EINVAL;
+  }
+  *complete = 1;
+  const u32 ncol = (u32)h->ncol;
+  const size_t recw = 6 * (size_t)ncol, nn = (size_t)nblocks * 2 * ncol;
+  // interface nodes: (blk, side, col) = the cell `col` of the first (side 0) / last (side 1) own row of blk
+  auto kind = [&](size_t nd) { return all_records_host[(nd / (2 * (size_t)ncol)) * recw + nd % (2 * (size_t)ncol)]; };
+  auto value = [&](size_t nd) {
+    const size_t b = nd / (2 * (size_t)ncol), t = nd % (2 * (size_t)ncol);
+    return (u64)all_records_host[b * recw + 2 * ncol + t] | ((u64)all_records_host[b * recw + 4 * ncol + t] << 32);
+  };
+  auto next = [&](size_t nd) -> i64 {  // the cell the path continues in: the halo cell named by the tag
+    const i64 b = (i64)(nd / (2 * (size_t)ncol));
+    const u64 v = value(nd);
+    const u32 hs = (u32)(v >> 30) & 1u, hc = (u32)v & 0x3FFFFFFFu;
+    const i64 nb = b + (hs ? 1 : -1);
+    if (nb < 0 || nb >= nblocks) return -1;
+    return (nb * 2 + (1 - (i64)hs)) * (i64)ncol + hc;
+  };
+  std::vector<u64> lab(nn, 0);
+  std::vector<unsigned char> state(nn, 0);  // 0 unknown, 1 on the current walk, 2 final
+  std::vector<size_t> walk;
+  for (size_t s0 = 0; s0 < nn; ++s0) {
+    if (state[s0] == 2) continue;
+    walk.clear();
+    size_t cur = s0;
+    u64 res = 0;
+    for (;;) {
+      if (state[cur] == 2) {
+        res = lab[cur];
+        break;
+      }
+      if (state[cur] == 1) {  // a cycle through several blocks
+        *complete = 0;
+        res = 0;
+        break;
+      }
+      if (kind(cur) == 0) {
+        res = value(cur);
+        state[cur] = 2;
+        lab[cur] = res;
+        break;
+      }
+      state[cur] = 1;
+      walk.push_back(cur);
+      const i64 nx = next(cur);
+      if (nx < 0) {  // (cannot happen: a halo row only exists towards an existing neighbour)
+        res = 0;
+        break;
+      }
+      cur = (size_t)nx;
+    }
+    for (size_t w : walk) {
+      lab[w] = res;
+      state[w] = 2;
+    }
+  }
+  // labels of this block's halo cells: halo (side, c) = boundary cell (block -/+ 1, other side, c)
+  std::vector<u64> halo((size_t)2 * ncol, 0);
+  for (u32 side = 0; side < 2; ++side) {
+    const i64 nb = (i64)block + (side ? 1 : -1);
+    if (nb < 0 || nb >= nblocks) continue;
+    for (u32 c = 0; c < ncol; ++c) halo[(size_t)side * ncol + c] = lab[(size_t)(nb * 2 + (1 - (i64)side)) * ncol + c];
+  }
+  InArg hl;
+  int rc = hl.bind(halo.data(), halo.size() * sizeof(u64), PFD_HOST, h->stream);
+  if (rc == PFD_OK) {
+    const u32 n_own = (u32)(h->own_rows * h->ncol);
+    const u32 *num = p->num.as<u32>() + (size_t)h->halo_top * ncol;
+    const u32 g = cdiv_u32(n_own, 256);
+    pfd_seg_begin(h, "labels_out");
+    switch (p->id_size) {
+      case 1: k_labels_out_block<u8><<<g, 256, 0, h->stream>>>(num, p->ids.as<u8>(), (const u64 *)hl.dev, ncol, n_own, (u8 *)p->out.dev); break;
+      case 2: k_labels_out_block<uint16_t><<<g, 256, 0, h->stream>>>(num, p->ids.as<uint16_t>(), (const u64 *)hl.dev, ncol, n_own, (uint16_t *)p->out.dev); break;
+      case 4: k_labels_out_block<u32><<<g, 256, 0, h->stream>>>(num, p->ids.as<u32>(), (const u64 *)hl.dev, ncol, n_own, (u32 *)p->out.dev); break;
+      default: k_labels_out_block<u64><<<g, 256, 0, h->stream>>>(num, p->ids.as<u64>(), (const u64 *)hl.dev, ncol, n_own, (u64 *)p->out.dev); break;
+    }
+    pfd_seg_end(h, 1);
+    if (hipGetLastError() != hipSuccess) rc = PFD_EHIP;
+  }
+  if (rc == PFD_OK) rc = p->out.finish(h->stream);
+  else (void)hipStreamSynchronize(h->stream);
+  pfd_free_pending_basins(h);
+  return rc;
 }
 
 // path queries over a derived code raster (same shape as the handle's), for exact.hip

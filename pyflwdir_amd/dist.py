@@ -54,6 +54,43 @@ def upstream_area_blocks(d8: np.ndarray, nblocks: int, devices=None, deferred: b
     return np.concatenate([o.reshape(-1, ncol) for o in outs], axis=0)
 
 
+def _split_outlets(idxs, ids, nrow, ncol, nblocks):
+    """Outlets (global linear indices) per row block, as indices into the block's own rows, in input order."""
+    idxs = np.asarray(idxs, dtype=np.int64).ravel()
+    ids = np.asarray(ids).ravel()
+    rows = idxs // ncol
+    out = []
+    for r0, r1 in block_rows(nrow, nblocks):
+        sel = (rows >= r0) & (rows < r1)
+        out.append((idxs[sel] - r0 * ncol, ids[sel]))
+    return out
+
+
+def basins_blocks(d8: np.ndarray, nblocks: int, idxs, ids=None, devices=None) -> np.ndarray:
+    """``basins(idxs, ids)`` of a host raster computed as ``nblocks`` row blocks held by this one process
+    (same kernels and protocol as the one-process-per-GPU path; the records are moved by numpy)."""
+    d8 = np.ascontiguousarray(d8, dtype=np.uint8)
+    nrow, ncol = d8.shape
+    idxs = np.asarray(idxs, dtype=np.int64).ravel()
+    ids = np.arange(1, idxs.size + 1, dtype=np.uint32) if ids is None else np.asarray(ids).ravel()
+    devices = devices or [0] * nblocks
+    parts = _split_outlets(idxs, ids, nrow, ncol, nblocks)
+    handles, outs, recs = [], [], []
+    for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
+        a, e = block_slice(nrow, nblocks, b)
+        h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
+        o, rec = _hip.basins_begin(h, parts[b][0], parts[b][1].astype(ids.dtype))
+        handles.append(h), outs.append(o), recs.append(rec)
+    allrec = np.stack(recs)
+    ok = True
+    for b, h in enumerate(handles):
+        ok &= _hip.basins_finish(h, allrec, nblocks, b)
+        h.close()
+    if not ok:
+        raise NotImplementedError("the raster holds a cycle through several row blocks")
+    return np.concatenate([o.reshape(-1, ncol) for o in outs], axis=0)
+
+
 def exchange_unique_id(rank: int, world: int, group=None) -> bytes:
     """Rank 0 creates the RCCL unique id, everybody receives it through the host group."""
     group = group or _default_group(rank, world)
@@ -173,6 +210,31 @@ class DistributedRaster:
                                           "(cycles); the multi-GPU path requires a valid flow direction raster "
                                           "(FlwdirRaster.isvalid)")
         return res.reshape(self.handle.nrow, self.handle.ncol) if memspace == _hip.PFD_HOST else res
+
+    def basins(self, idxs_global, ids, nrow_total: int, out=None, memspace=_hip.PFD_HOST):
+        """Collective ``basins``: every rank passes the same outlets (global linear indices) and ids; returns
+        the labels of this rank's rows.  The 6*ncol-word boundary records travel through the host group."""
+        ncol = self.handle.ncol
+        mine = _split_outlets(idxs_global, ids, nrow_total, ncol, self.world)[self.rank]
+        err, res, ok = None, out, False
+        rec = np.zeros(6 * ncol, np.uint32)
+        try:
+            res, rec = _hip.basins_begin(self.handle, mine[0], mine[1], out=out, memspace=memspace)
+        except Exception as exc:  # noqa: BLE001 - the failure travels with the final agreement
+            err = exc
+        parts = self.group.allgather(rec.tobytes())
+        if err is None:
+            try:
+                ok = _hip.basins_finish(self.handle, np.stack([np.frombuffer(p, np.uint32) for p in parts]), self.world,
+                                        self.rank)
+            except Exception as exc:  # noqa: BLE001
+                err = exc
+        flag = self.group.allreduce(1 if (ok and err is None) else 0, "min")
+        if err is not None:
+            raise err
+        if flag == 0:
+            raise NotImplementedError("a row block failed or the raster holds a cycle through several row blocks")
+        return res.reshape(self.handle.nrow, ncol) if memspace == _hip.PFD_HOST else res
 
     def close(self):
         if self.handle is not None:

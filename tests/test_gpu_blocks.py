@@ -90,3 +90,36 @@ def test_blocks_supertile_edge_geometries(gpu_lib, oracle, rows_per_block, nbloc
         exp, _, _ = oracle.upstream_area_cell(d8)
         assert np.array_equal(dist.upstream_area_blocks(d8, nblocks), exp)
         assert np.array_equal(dist.upstream_area_blocks(d8, nblocks, deferred=True), exp)
+
+
+@pytest.mark.parametrize("shape,seed,kw,nblocks", [
+    ((900, 700), 41, dict(tilt=1 << 26, white=2, nodata_pct=0), 2),
+    ((1300, 1100), 42, dict(tilt=100000, white=2, nodata_pct=25), 3),
+    ((2100, 1500), 43, dict(tilt=3000, white=2, nodata_pct=5), 5),
+    ((1600, 900), 44, dict(tilt=1 << 26, white=2, nodata_pct=10), 8),
+    ((64, 300), 45, dict(tilt=100000, white=2, nodata_pct=0), 8),   # 8 rows per block
+])
+def test_basins_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblocks):
+    """BASELINE config 5 shape of work: basins from 1000 outlets (largest upstream areas, so many of them are
+    nested in one another's basins) on a raster split into row blocks == the oracle on the whole raster."""
+    from pyflwdir_amd import dist
+
+    O = oracle
+    d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    upa = O.upstream_area_cell(d8)[0].ravel()
+    rng = np.random.default_rng(seed)
+    k = min(1000, int((upa > 0).sum()) // 4)
+    big = np.argsort(upa)[-k // 2:]                                  # nested along the main stems
+    rnd = rng.choice(np.flatnonzero(upa > 0), size=k - big.size, replace=False)
+    outl = np.unique(np.concatenate([big, rnd]))
+    rng.shuffle(outl)
+    for ids in (np.arange(1, outl.size + 1, dtype=np.uint32), (rng.permutation(outl.size) + 7).astype(np.int16),
+                (rng.integers(1, 2**62, outl.size)).astype(np.int64)):
+        exp = O.basins(idxs_ds, outl.astype(idxs_ds.dtype), seq, ids)
+        got = dist.basins_blocks(d8, nblocks, outl, ids)
+        assert got.dtype == ids.dtype
+        assert np.array_equal(got.ravel(), exp)
+    # default: one basin per pit
+    assert np.array_equal(dist.basins_blocks(d8, nblocks, idxs_pit).ravel(), O.basins(idxs_ds, idxs_pit, seq))

@@ -63,3 +63,18 @@ def test_two_ranks_on_one_gpu(gpu_lib, launcher):
     assert two["invariants"]["last_row_pit_sum_equals_n_valid"] is True
     assert two["invariants"]["result_checksum"] == ref["invariants"]["result_checksum"]
     assert ref["invariants"]["all_cells_upa_equals_1_plus_children"] and ref["invariants"]["pit_sum_equals_n_valid"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_collective_upstream_area_and_basins_over_tcp(gpu_lib, world):
+    """DistributedRaster.upstream_area / .basins of every rank's row block against the oracle on the whole raster;
+    plain processes + the torch-free TCP group (tools/dist_check.py)."""
+    procs = []
+    for r in range(world):
+        e = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + world),
+                 HSA_ENABLE_IPC_MODE_LEGACY="0", PFD_DIST_TRANSPORT="host")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dist_check.py")], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert all("ok (host)" in o[0] for o in outs)

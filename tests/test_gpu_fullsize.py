@@ -143,3 +143,85 @@ def test_uint32_index_rung(gpu_lib, oracle):
         exp_p = loc_pit[(loc_pit // size >= r0 - a0) & (loc_pit // size < r0 - a0 + rows)] + a0 * size
         assert np.array_equal(in_band, exp_p)
     h.close()
+
+
+def test_c5_basins_hand_at_size(gpu_lib, oracle):
+    """BASELINE config 5 at full size (36000 x 72000 = 2.592e9 cells, 30 % nodata, rough regime): basins from
+    1000 outlets and HAND on ONE GPU (HAND is replicas-only: it fits — 2.6 GB codes + 10.4 GB elevation + 2.6 GB
+    drain + 20.7 GB float64 result + the sweep plan), checked by their local equations on sampled row bands
+    (label(x) == id(x) at an outlet, else label(downstream cell), 0 at pits; hand(x) == 0 on drains, else
+    hand(downstream) + (double)(float32)(elev(x) - elev(downstream))) — on an acyclic raster the equations have
+    one solution.  Basins sharded over 4 row blocks (the multi-GPU protocol, blocks held by this process) must
+    give the identical labels."""
+    from pyflwdir_amd import _hip
+    from pyflwdir_amd import dist as pdist
+
+    nrow, ncol = 36000, 72000
+    n = nrow * ncol
+    kw = dict(seed=2, tilt=100000, white=2, nodata_pct=30)
+    d8_buf = _hip.synth_d8_device(nrow, ncol, **kw)
+    h = _hip.RasterHandle(d8_buf, nrow, ncol, memspace=_hip.PFD_DEVICE)
+    upa = _hip.DeviceBuffer(n * 4)
+    h.upstream_area_cell(out=upa, memspace=_hip.PFD_DEVICE)
+    # outlets: the largest upstream areas of 1000 sampled rows (distinct cells, many of them nested)
+    rng = np.random.default_rng(5)
+    outl = []
+    for r in np.unique(rng.integers(0, nrow, 1000)):
+        row = upa.download(np.int32, (ncol,), offset_bytes=int(r) * ncol * 4)
+        outl.append(int(r) * ncol + int(np.argmax(row)))
+    outl = np.array(outl[:1000], np.int64)
+    ids = np.arange(1, outl.size + 1, dtype=np.uint32)
+    lab = _hip.DeviceBuffer(n * 4)
+    h.basins(outl, ids, out=lab, memspace=_hip.PFD_DEVICE)
+    elev = _hip.synth_elev_device(nrow, ncol, **kw)
+    # drain = cells with more than 100 upstream cells; built band by band on the host (uint8, 2.6 GB on the device)
+    drain = _hip.DeviceBuffer(n)
+    band = 2000
+    for r0 in range(0, nrow, band):
+        u = upa.download(np.int32, (band, ncol), offset_bytes=r0 * ncol * 4)
+        _hip.check(_hip.lib().pfd_memcpy_h2d(0, C.c_void_p(drain.addr + r0 * ncol), _hip.ptr(np.ascontiguousarray(u > 100).view(np.uint8)),
+                                             C.c_size_t(band * ncol)))
+    upa.free()
+    hand = _hip.DeviceBuffer(n * 8)
+    h.hand(drain, elev, _hip.PFD_F32, out=hand, memspace=_hip.PFD_DEVICE)
+    DR = {1: (0, 1), 2: (1, 1), 4: (1, 0), 8: (1, -1), 16: (0, -1), 32: (-1, -1), 64: (-1, 0), 128: (-1, 1)}
+    is_outlet = np.zeros(0)
+    for r in (1, 7777, 18000, 25113, nrow - 2):
+        d = d8_buf.download(np.uint8, (3, ncol), offset_bytes=(r - 1) * ncol)
+        L = lab.download(np.uint32, (3, ncol), offset_bytes=(r - 1) * ncol * 4)
+        H = hand.download(np.float64, (3, ncol), offset_bytes=(r - 1) * ncol * 8)
+        E = elev.download(np.float32, (3, ncol), offset_bytes=(r - 1) * ncol * 4)
+        D = drain.download(np.uint8, (ncol,), offset_bytes=r * ncol)
+        cols = np.arange(ncol)
+        code = d[1]
+        valid = code != 247
+        # downstream cell of every cell of row r (pit rule: target outside the raster or nodata -> pit)
+        tr = np.ones(ncol, np.int64)
+        tc = cols.copy()
+        pit = ~np.isin(code, list(DR))
+        for cde, (dr, dc) in DR.items():
+            m = code == cde
+            tr[m] = 1 + dr
+            tc[m] = cols[m] + dc
+        off = (tc < 0) | (tc >= ncol)
+        tcc = np.clip(tc, 0, ncol - 1)
+        pit |= off | (d[tr, tcc] == 247)
+        # labels
+        out_id = np.zeros(ncol, np.uint32)
+        sel = (outl // ncol) == r
+        out_id[outl[sel] % ncol] = ids[sel]
+        expL = np.where(out_id != 0, out_id, np.where(pit, 0, L[tr, tcc]))
+        assert np.array_equal(L[1][valid], expL[valid]) and np.all(L[1][~valid] == 0)
+        # HAND
+        dz = (E[1] - np.where(pit, E[1], E[tr, tcc])).astype(np.float32)
+        expH = np.where(D == 1, 0.0, np.where(pit, 0.0, H[tr, tcc]) + dz.astype(np.float64))
+        assert np.array_equal(H[1][valid], expH[valid]) and np.all(H[1][~valid] == -9999.0)
+    h.close()
+    for b in (hand, elev, drain):
+        b.free()
+    # sharded over 4 row blocks == the single-GPU labels (compared through checksums of the uint32 labels)
+    d8 = d8_buf.download(np.uint8, (nrow, ncol))
+    d8_buf.free()
+    got = pdist.basins_blocks(d8, 4, outl, ids)
+    whole = lab.download(np.uint32, (nrow, ncol))
+    assert np.array_equal(got, whole)

@@ -1,0 +1,38 @@
+"""One rank of a 2+-process check of the collective entry points over the torch-free TCP group:
+DistributedRaster.upstream_area and .basins of a row block against the oracle on the whole raster.
+Launched by tests/test_gpu_dist.py (all ranks on the one GPU of the test box, records through the host).
+
+    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tools/dist_check.py"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O  # noqa: E402  (checker only)
+from pyflwdir_amd import _hip  # noqa: E402
+from pyflwdir_amd import dist as pdist  # noqa: E402
+from pyflwdir_amd.hostgroup import HostGroup  # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+grp = HostGroup(rank, world)
+shape = (1700, 1300)
+d8 = O.synth_d8(shape[0], shape[1], seed=77, tilt=100000, white=2, nodata_pct=20)
+idxs_ds, idxs_pit, _ = O.from_array(d8)
+seq = O.idxs_seq(idxs_ds, idxs_pit)
+upa = O.upstream_area_cell(d8)[0]
+r0, r1 = pdist.block_rows(shape[0], world)[rank]
+a, e = pdist.block_slice(shape[0], world, rank)
+dr = pdist.DistributedRaster(d8[a:e], r1 - r0, shape[1], rank, world, 0, transport=os.environ.get("PFD_DIST_TRANSPORT", "host"),
+                             group=grp)
+got = dr.upstream_area()
+assert np.array_equal(got, upa[r0:r1]), f"rank {rank}: upstream_area differs"
+outl = np.argsort(upa.ravel())[-400:]
+ids = (np.arange(outl.size) + 3).astype(np.uint32)
+lab = dr.basins(outl, ids, shape[0])
+exp = O.basins(idxs_ds, outl.astype(idxs_ds.dtype), seq, ids).reshape(shape)
+assert np.array_equal(lab, exp[r0:r1]), f"rank {rank}: basins differ"
+dr.close()
+grp.barrier()
+grp.close()
+print(f"rank {rank} of {world}: ok ({dr.transport})")
