@@ -225,6 +225,17 @@ int pfd_basins_begin(pfd_raster *h, const int64_t *outlets, const void *ids, int
                      int memspace, uint32_t *record_host);
 int pfd_basins_finish(pfd_raster *h, const uint32_t *all_records_host, int nblocks, int block, int *complete);
 
+/* ---- the step before the path (DEM -> D8) -------------------------------------------------
+ * dem.fill_depressions (reference pyflwdir/dem.py:17-143; from_dem pyflwdir/pyflwdir.py:51-102): priority flood
+ * (Wang & Liu 2006) with the reference's heap order (float32 elevation, boundary flag, row, column).  HOST
+ * function (inherently sequential), all pointers are host pointers.  dtype PFD_F32 / PFD_F64 / PFD_I32;
+ * nodata NaN selects isnan(); max_depth < 0: fill everything; outlets_min != 0: one outlet at the lowest edge
+ * cell; has_elv_max: edge outlets only up to elv_max; idxs_pit (nullable): user outlets instead of the edge;
+ * connectivity 4 or 8.  elev_out: filled elevation (dtype of the input), d8_out: uint8 D8 codes (247 nodata). */
+int pfd_fill_depressions(int dtype, const void *elevtn, int64_t nrow, int64_t ncol, double nodata, double max_depth,
+                         int outlets_min, int has_elv_max, double elv_max, const int64_t *idxs_pit, int64_t npit,
+                         int connectivity, void *elev_out, uint8_t *d8_out);
+
 /* ---- instrumentation ---------------------------------------------------------------------
  * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST
  * sweep/ordering call on the handle.  Enable with pfd_set_profiling(h, 1).  Up to max_seg

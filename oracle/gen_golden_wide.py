@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — golden vectors of the rows SURVEY.md 8(f) marks "next" (the callers and data formats
+either side of the hot path), recorded from the imported reference exactly like oracle/gen_golden.py does for
+the path itself (interpreted through the identity-njit shim; runs only where /root/reference exists).
+
+    tests/golden/wide_dem.npz      dem.fill_depressions / from_dem            (reference pyflwdir/dem.py:17-143)
+
+Fixtures are data only (inputs + the reference's outputs).   Usage: python oracle/gen_golden_wide.py [dem ...]
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path[:] = [q for q in sys.path if os.path.abspath(q or ".") != HERE]
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+os.environ["NUMBA_DISABLE_JIT"] = "1"
+
+import pyflwdir  # noqa: E402  (the reference)
+from pyflwdir import dem as rdem  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402  (synthetic inputs only)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+WANG_LIU = [[15, 15, 14, 15, 12, 6, 12], [14, 13, 10, 12, 15, 17, 15], [15, 15, 9, 11, 8, 15, 15],
+            [16, 17, 8, 16, 15, 7, 5], [19, 18, 19, 18, 17, 15, 14]]  # reference tests/test_dem.py:13-21
+
+
+def gen_dem():
+    store = {}
+    calls = []  # (key, input key, kwargs)
+
+    def run(key, inp_key, **kw):
+        a = store["in_" + inp_key]
+        try:
+            filled, d8 = rdem.fill_depressions(a.copy(), **kw)
+            store[f"out_{key}_elev"] = filled
+            store[f"out_{key}_d8"] = d8
+            calls.append((key, inp_key, kw, "ok"))
+        except (IndexError, ValueError) as exc:
+            calls.append((key, inp_key, kw, type(exc).__name__))
+
+    for dt in (np.float32, np.int32, np.float64):
+        nm = "wl_" + np.dtype(dt).name
+        store["in_" + nm] = np.array(WANG_LIU, dtype=dt)
+        run(nm + "_default", nm)
+        run(nm + "_min", nm, outlets="min")
+        run(nm + "_maxdepth2", nm, max_depth=2)
+        run(nm + "_conn4", nm, connectivity=4)
+        run(nm + "_pits", nm, idxs_pit=np.array([5, 27]))
+        run(nm + "_elvmax", nm, elv_max=13)
+    a = np.array(WANG_LIU, dtype=np.float32)
+    a[3, 5:] = -9999
+    store["in_wl_nodata"] = a
+    run("wl_nodata", "wl_nodata")
+    a = np.array(WANG_LIU, dtype=np.float32)
+    a[0, 0] = np.nan
+    a[2, 3] = np.nan
+    store["in_wl_nan"] = a
+    run("wl_nan", "wl_nan", nodata=np.nan)
+    np.random.seed(2345)
+    store["in_rand_15x10"] = np.random.rand(15, 10)  # float64: reference tests/conftest.py:57-60
+    run("rand_15x10", "rand_15x10")
+    run("rand_15x10_min", "rand_15x10", outlets="min")
+    rng = np.random.default_rng(7)
+    store["in_rand_40x50_f32"] = (rng.random((40, 50)) * 100).astype(np.float32)
+    run("rand_40x50", "rand_40x50_f32")
+    run("rand_40x50_md5", "rand_40x50_f32", max_depth=5.0)
+    run("rand_40x50_md20", "rand_40x50_f32", max_depth=20.0)
+    run("rand_40x50_conn4", "rand_40x50_f32", connectivity=4)
+    flat = np.round(rng.random((30, 36)) * 4).astype(np.float32)  # many ties: the heap's tie-breaking decides the D8
+    store["in_flat_30x36"] = flat
+    run("flat_30x36", "flat_30x36")
+    e = O.synth_elev_f32(120, 160, seed=3, tilt=100000, white=2, nodata_pct=20)
+    d8s = O.synth_d8(120, 160, seed=3, tilt=100000, white=2, nodata_pct=20)
+    e = np.where(d8s == 247, np.float32(-9999), e).astype(np.float32)
+    store["in_synth_120x160"] = e
+    run("synth_120x160", "synth_120x160")
+    store["calls"] = np.array(repr(calls))
+    np.savez_compressed(os.path.join(GOLD, "wide_dem.npz"), **store)
+    print(f"[wide] dem: {len(calls)} calls:", [(c[0], c[3]) for c in calls if c[3] != 'ok'] or "all ok")
+
+
+GENS = {"dem": gen_dem}
+
+if __name__ == "__main__":
+    for name in (sys.argv[1:] or GENS):
+        GENS[name]()

@@ -30,7 +30,7 @@ from ._affine import get_affine
 
 Affine = get_affine()
 
-__all__ = ["FlwdirRaster", "from_array", "FTYPES"]
+__all__ = ["FlwdirRaster", "from_array", "from_dem", "FTYPES"]
 
 # D8 alphabet, reference pyflwdir/core_d8.py:14-19
 D8_DS = np.array([[32, 64, 128], [16, 0, 1], [8, 4, 2]], dtype=np.uint8)
@@ -133,6 +133,15 @@ def from_array(data, ftype="infer", check_ftype=True, mask=None, transform=gis.I
                                 **kwargs)
     flw.ftype = ftype
     return flw
+
+
+def from_dem(data, nodata=-9999.0, max_depth=-1.0, transform=gis.IDENTITY, latlon=False, outlets="edge"):
+    """Flow direction raster derived from elevation data by depression filling + steepest local descent
+    (priority flood, Wang & Liu 2006); reference pyflwdir/pyflwdir.py:51-102."""
+    from .dem import fill_depressions
+
+    d8 = fill_depressions(data, nodata=nodata, max_depth=max_depth, outlets=outlets)[1]
+    return from_array(d8, ftype="d8", check_ftype=False, transform=transform, latlon=latlon)
 
 
 class FlwdirRaster(object):
