@@ -236,6 +236,20 @@ int pfd_fill_depressions(int dtype, const void *elevtn, int64_t nrow, int64_t nc
                          int outlets_min, int has_elv_max, double elv_max, const int64_t *idxs_pit, int64_t npit,
                          int connectivity, void *elev_out, uint8_t *d8_out);
 
+/* ---- SURVEY 8(f)-4 --------------------------------------------------------------------------------
+ * subgrid.ucat_area (reference pyflwdir/subgrid.py:51-93; FlwdirRaster.ucat_area pyflwdir.py:1159-1191): unit
+ * catchment map and area.  `idxs_out`: k outlet cells (HOST; < 0 = missing).  map_out: n labels of map_dtype
+ * (PFD_I32/U32/I64; label i+1 for outlet i, 0 elsewhere).  area_dtype PFD_I32: cell counts (area_rows NULL);
+ * PFD_F32/PFD_F64: `area_rows` = nrow HOST values, the area of a cell of that row; area_out: k HOST values of
+ * area_dtype (-9999 for missing outlets), float sums accumulated in the reference's (idxs_seq) order. */
+int pfd_ucat_area(pfd_raster *h, const int64_t *idxs_out, int64_t k, int map_dtype, void *map_out, int memspace,
+                  int area_dtype, const void *area_rows, void *area_out);
+/* dem.floodplains (reference pyflwdir/dem.py:333-379; FlwdirRaster.floodplains pyflwdir.py:1513-1545):
+ * `is_stream` uint8 (1 where uparea >= upa_min), `stream_h` float32 (uparea ** b on those cells — evaluated by
+ * the caller in the reference's dtype), elevtn PFD_F32 / PFD_F64; out int8: 1 floodplain, 0 not, -1 off the sequence. */
+int pfd_floodplains(pfd_raster *h, int elev_dtype, const void *elevtn, const uint8_t *is_stream, const float *stream_h,
+                    int8_t *out, int memspace);
+
 /* ---- instrumentation ---------------------------------------------------------------------
  * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST
  * sweep/ordering call on the handle.  Enable with pfd_set_profiling(h, 1).  Up to max_seg

@@ -4,6 +4,7 @@ either side of the hot path), recorded from the imported reference exactly like 
 the path itself (interpreted through the identity-njit shim; runs only where /root/reference exists).
 
     tests/golden/wide_dem.npz      dem.fill_depressions / from_dem            (reference pyflwdir/dem.py:17-143)
+    tests/golden/wide_subgrid.npz  FlwdirRaster.ucat_area / .floodplains      (subgrid.py:51-93, dem.py:333-379)
 
 Fixtures are data only (inputs + the reference's outputs).   Usage: python oracle/gen_golden_wide.py [dem ...]
 """
@@ -89,7 +90,60 @@ def gen_dem():
     print(f"[wide] dem: {len(calls)} calls:", [(c[0], c[3]) for c in calls if c[3] != 'ok'] or "all ok")
 
 
-GENS = {"dem": gen_dem}
+def gen_subgrid():
+    """FlwdirRaster.ucat_area (pyflwdir.py:1159-1191, subgrid.py:51-93) and .floodplains (pyflwdir.py:1513-1545,
+    dem.py:333-379) on the golden rasters of gen_golden.py (their D8 / elevation inputs are read back from
+    tests/golden/<case>.npz)."""
+    from pyflwdir_amd._affine import Affine
+    from oracle import golden_inputs as GI
+    import json
+
+    manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+    store = {}
+    for name, cellsize in [("flwdir0", 5), ("flwdir_large", 10), ("flwdir1", 3), ("synth_loops_96x80", 8), ("rhine", 20),
+                           ("synth_rough_nodata_384x512", 16)]:
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        d8 = z["d8"]
+        ent = manifest[name]
+        for tag, tr, latlon in (("ll", ent["transform"], ent["latlon"]), ("pr", GI.PROJ_TRANSFORM, False)):
+            flw = pyflwdir.from_array(d8, ftype="d8", check_ftype=False, transform=Affine(*tr), latlon=latlon, cache=False)
+            upa = flw.upstream_area()
+            if tag == "ll":
+                idxs_out = flw.ucat_outlets(cellsize, uparea=upa)[0]
+                # + a repeated outlet and a missing one: the reference's loop semantics for both
+                io = idxs_out.copy()
+                flat = io.ravel()
+                valid = np.flatnonzero(flat != flw._mv)
+                if valid.size > 3:
+                    flat[valid[1]] = flat[valid[0]]
+                store[f"in_{name}_idxs_out"] = io
+                store[f"in_{name}_idxs_out_dup"] = flat.reshape(io.shape)
+            for key_io in ("idxs_out", "idxs_out_dup"):
+                io = store[f"in_{name}_{key_io}"]
+                for unit in ("cell", "km2", "ha"):
+                    m, a = flw.ucat_area(io, unit=unit)
+                    store[f"out_{name}_{tag}_{key_io}_{unit}_map"] = m
+                    store[f"out_{name}_{tag}_{key_io}_{unit}_are"] = a
+            if "elevtn" in z.files:
+                elv = z["elevtn"].astype(np.float32)
+            elif ent.get("synth"):
+                sy = ent["synth"]
+                elv = O.synth_elev_f32(sy["nrow"], sy["ncol"], seed=sy["seed"], tilt=sy["tilt"], white=sy["white"],
+                                       nodata_pct=sy["nodata_pct"])
+            else:
+                elv = GI.elevation(None, upa)
+            store[f"in_{name}_elevtn"] = elv
+            upa_km2 = flw.upstream_area("km2")
+            thr = float(np.percentile(upa_km2[upa_km2 > 0], 90)) if (upa_km2 > 0).any() else 1.0
+            store[f"in_{name}_{tag}_upa_min"] = np.float64(thr)
+            store[f"out_{name}_{tag}_fld"] = flw.floodplains(elv, upa_min=thr, b=0.3)
+            store[f"out_{name}_{tag}_fld_b05_f64"] = flw.floodplains(elv.astype(np.float64) * 1.000001, uparea=upa_km2,
+                                                                      upa_min=thr * 0.5, b=0.5)
+    np.savez_compressed(os.path.join(GOLD, "wide_subgrid.npz"), **store)
+    print(f"[wide] subgrid: {len(store)} arrays")
+
+
+GENS = {"dem": gen_dem, "subgrid": gen_subgrid}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or GENS):

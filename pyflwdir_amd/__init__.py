@@ -9,7 +9,8 @@ Python host code -> ctypes -> C-ABI (include/pfd.h) -> hand-written HIP kernels 
 """
 from . import gis as gis_utils  # reference name of the module
 from . import gis
-from .raster import FTYPES, FlwdirRaster, from_array
+from . import dem
+from .raster import FTYPES, FlwdirRaster, from_array, from_dem
 
 __version__ = "0.1.0"
-__all__ = ["FlwdirRaster", "from_array", "gis_utils", "gis", "FTYPES"]
+__all__ = ["FlwdirRaster", "from_array", "from_dem", "dem", "gis_utils", "gis", "FTYPES"]

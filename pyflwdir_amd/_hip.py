@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains",
 ]
 
 _lib = None
@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
         L.pfd_basins_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.pfd_fill_depressions.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int,
                                            C.c_double, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.pfd_ucat_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.pfd_floodplains.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int)]
@@ -328,6 +330,25 @@ class RasterHandle:
         if memspace == PFD_HOST:
             out = np.empty(self.n, np.float64)
         check(lib().pfd_hand(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(out), memspace))
+        return out
+
+    def ucat_area(self, idxs_out, map_dtype, area_rows=None):
+        """(map[n] of map_dtype, area[k]); area_rows None: int32 cell counts, else nrow float32/float64 row areas."""
+        idxs_out = np.ascontiguousarray(idxs_out, dtype=np.int64).ravel()
+        ucmap = np.empty(self.n, map_dtype)
+        if area_rows is None:
+            code, are = PFD_I32, np.empty(idxs_out.size, np.int32)
+        else:
+            area_rows = np.ascontiguousarray(area_rows)
+            assert area_rows.size == self.nrow and area_rows.dtype in (np.float32, np.float64)
+            code, are = (PFD_F32 if area_rows.dtype == np.float32 else PFD_F64), np.empty(idxs_out.size, area_rows.dtype)
+        check(lib().pfd_ucat_area(self._h, ptr(idxs_out), idxs_out.size, IDX_CODE[np.dtype(map_dtype)], ptr(ucmap), PFD_HOST,
+                                  code, ptr(area_rows), ptr(are)))
+        return ucmap, are
+
+    def floodplains(self, elevtn, elev_code, is_stream, stream_h):
+        out = np.empty(self.n, np.int8)
+        check(lib().pfd_floodplains(self._h, elev_code, ptr(elevtn), ptr(is_stream), ptr(stream_h), ptr(out), PFD_HOST))
         return out
 
     def main_upstream(self, uparea, dtype_code, idx_dtype, upa_min=0.0, out=None, memspace=PFD_HOST):

@@ -685,18 +685,17 @@ __global__ void __launch_bounds__(1024) k_oseq_small(const u8 *__restrict__ ncod
   }
 }
 
-extern "C" int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace) {
-  PFDCHK(pfd_check_handle(h));
+// the exact core.idxs_seq order in device memory (oseq: n_seq entries)
+int pfd_exact_seq_dev(pfd_raster *h, DevBuf &oseq) {
   PFDCHK(pfd_order_cells_impl(h));
   pfd_seg_begin(h, "idxs_seq_exact_order");
-  DevBuf oseq;
-  PFDCHK(oseq.alloc((size_t)h->n_seq * sizeof(u32)));
+  PFDCHK(oseq.alloc((size_t)std::max<i64>(h->n_seq, 1) * sizeof(u32)));
   HIPCHK(hipMemcpyAsync(oseq.p, h->seq, (size_t)h->n_pits * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
   i64 maxlev = 0;
   for (i64 l = 0; l < h->n_levels; ++l) maxlev = std::max(maxlev, h->lvl_off[l + 1] - h->lvl_off[l]);
   const u32 maxchunks = cdiv_u32((u64)maxlev, OSEQ_CHUNK);
   DevBuf sums;
-  PFDCHK(sums.alloc((size_t)maxchunks * sizeof(u32)));
+  PFDCHK(sums.alloc((size_t)std::max<u32>(maxchunks, 1) * sizeof(u32)));
   i64 launches = 0;
   for (i64 l = 0; l + 1 < h->n_levels; ++l) {
     const u32 begin = (u32)h->lvl_off[l], end = (u32)h->lvl_off[l + 1];
@@ -714,5 +713,13 @@ extern "C" int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspac
   }
   KCHK();
   pfd_seg_end(h, launches);
+  HIPCHK(hipStreamSynchronize(h->stream));  // (`sums` is released on return)
+  return PFD_OK;
+}
+
+extern "C" int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  DevBuf oseq;
+  PFDCHK(pfd_exact_seq_dev(h, oseq));
   return pfd_export_u32(h, oseq.as<u32>(), h->n_seq, idx_dtype, out, memspace);
 }

@@ -711,6 +711,67 @@ struct Hand {
   __device__ __forceinline__ double dfold(const DElem &e, double pv) const { return e.is_drain ? 0.0 : pv + (double)e.dz; }
 };
 
+// dem.floodplains (reference pyflwdir/dem.py:333-379): down- to upstream.  A stream cell (upstream area >=
+// upa_min) starts a floodplain with its own elevation z and height threshold h = uparea ** b (evaluated by the
+// host in the reference's dtype: a pow() is not bit-reproducible across math libraries); any other cell joins
+// the floodplain of its downstream cell if that cell is in one and elev - z <= h, and inherits (z, h).
+struct FloodV {
+  float z, h;
+  i32 flag;  // 1 floodplain, 0 not (value of the result raster)
+  i32 pad;
+};
+template <class E>
+struct Flood {
+  typedef FloodV V;
+  const u8 *ncode;
+  Geo g;
+  const u8 *stream;  // 1 where uparea >= upa_min
+  const float *h_in; // uparea ** b as float32 (meaningful on stream cells)
+  const E *elev;
+  FloodV *state;     // [n] running state (z, h, flag)
+  struct DElem {
+    E elev;
+    float h;
+    u32 is_stream;
+  };
+  typedef DElem DTile;
+  static constexpr bool DTILE_FLAG = false;
+  static constexpr bool FAST = false;
+  __device__ __forceinline__ FloodV top(u32 p) const { return state[p]; }
+  __device__ __forceinline__ void top4(u32 x0, FloodV (&v)[4]) const {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) v[b] = state[x0 + b];
+  }
+  __device__ __forceinline__ DElem dpre(u32 x, u32) const { return DElem{elev[x], h_in[x], (u32)(stream[x] == 1)}; }
+  __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
+  __device__ __forceinline__ FloodV droot(const DElem &e) const {
+    // (a pit that is no stream cell looks at itself: its own flag is still 0)
+    return e.is_stream ? FloodV{(float)e.elev, e.h, 1, 0} : FloodV{-9999.f, -9999.f, 0, 0};
+  }
+  __device__ __forceinline__ FloodV dfold(const DElem &e, const FloodV &pv) const {
+    if (e.is_stream) return FloodV{(float)e.elev, e.h, 1, 0};
+    if (pv.flag == 1) {
+      const E dh = e.elev - (E)pv.z;  // float32 elevation: float32 arithmetic; float64: float64
+      if (dh <= (E)pv.h) return FloodV{pv.z, pv.h, 1, 0};
+    }
+    return FloodV{-9999.f, -9999.f, 0, 0};
+  }
+  __device__ __forceinline__ FloodV dtroot(const DElem &e, bool) const { return droot(e); }
+  __device__ __forceinline__ FloodV dtfold(const DElem &e, bool, const FloodV &pv) const { return dfold(e, pv); }
+  __device__ __forceinline__ bool dspecial(const DElem &, const FloodV &) const { return false; }
+  __device__ __forceinline__ FloodV dfold_fast(const DElem &, const FloodV &pv) const { return pv; }
+  __device__ __forceinline__ FloodV apply(u32 x, u32 code, bool root, const FloodV &pv) const {
+    const DElem e = dpre(x, code);
+    return root ? droot(e) : dfold(e, pv);
+  }
+  __device__ __forceinline__ FloodV dnodata(u32) const { return FloodV{-9999.f, -9999.f, -1, 0}; }
+  __device__ __forceinline__ void store(u32 x, const FloodV &v) const { state[x] = v; }
+  __device__ __forceinline__ void dstore4(u32 x0, const FloodV (&v)[4]) const {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) state[x0 + b] = v[b];
+  }
+};
+
 #include "exact_sweep.h"
 
 // up-/down-sweep of an operation: the exact-order engine when the raster has a plan (no cycles, whole
@@ -996,6 +1057,25 @@ static int basins_t(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 
   return run_down(h, op, "sweep_labels");
 }
 
+// labels from k distinct outlets (device arrays); fast path: LDS-tiled "first outlet downstream" query
+// (paths.hip; needs no cell ordering).  Rasters with cycles (and PFD_BASINS_LEVELS=1) go through the level engine.
+int pfd_basins_dev(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 ku, int id_size, void *out_dev) {
+  int tiled_ok = 0;
+  if (!getenv("PFD_BASINS_LEVELS")) PFDCHK(pfd_basins_tiled(h, idx_dev, ids_dev, ku, id_size, out_dev, &tiled_ok));
+  if (!tiled_ok) {
+    PFDCHK(pfd_order_cells_impl(h));
+    int rc;
+    switch (id_size) {
+      case 1: rc = basins_t<u8>(h, idx_dev, ids_dev, ku, out_dev); break;
+      case 2: rc = basins_t<uint16_t>(h, idx_dev, ids_dev, ku, out_dev); break;
+      case 4: rc = basins_t<u32>(h, idx_dev, ids_dev, ku, out_dev); break;
+      default: rc = basins_t<u64>(h, idx_dev, ids_dev, ku, out_dev); break;
+    }
+    PFDCHK(rc);
+  }
+  return PFD_OK;
+}
+
 extern "C" int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k, int id_size,
                           void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
@@ -1031,22 +1111,7 @@ extern "C" int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids
   PFDCHK(dl.bind(ku ? uids.data() : nullptr, (size_t)ku * id_size, PFD_HOST, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * id_size, memspace));
-  // fast path: LDS-tiled "first outlet downstream" query (paths.hip); needs no cell ordering.
-  // Rasters with cycles (and PFD_BASINS_LEVELS=1) go through the level engine.
-  int tiled_ok = 0;
-  if (!getenv("PFD_BASINS_LEVELS"))
-    PFDCHK(pfd_basins_tiled(h, (const i64 *)di.dev, dl.dev, ku, id_size, o.dev, &tiled_ok));
-  if (!tiled_ok) {
-    PFDCHK(pfd_order_cells_impl(h));
-    int rc;
-    switch (id_size) {
-      case 1: rc = basins_t<u8>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
-      case 2: rc = basins_t<uint16_t>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
-      case 4: rc = basins_t<u32>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
-      default: rc = basins_t<u64>(h, (const i64 *)di.dev, dl.dev, ku, o.dev); break;
-    }
-    PFDCHK(rc);
-  }
+  PFDCHK(pfd_basins_dev(h, (const i64 *)di.dev, dl.dev, ku, id_size, o.dev));
   return o.finish(h->stream);
 }
 
@@ -1357,4 +1422,49 @@ extern "C" int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_
     PFDCHK(sweep_down(h, op, "sweep_stream_distance", "exact_stream_distance"));
   }
   return o.finish(h->stream);  // (synchronises: the staged table may be released afterwards)
+}
+
+// ---------------------------------------------------------------------------------------------
+// dem.floodplains (reference pyflwdir/dem.py:333-379; FlwdirRaster.floodplains pyflwdir.py:1513-1545)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_flood_init(const u8 *__restrict__ ncode, u32 n, FloodV *__restrict__ st) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) st[i] = FloodV{-9999.f, -9999.f, -1, 0};  // cells off the sequence keep -1
+}
+__global__ void k_flood_out(const FloodV *__restrict__ st, u32 n, int8_t *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int8_t)st[i].flag;
+}
+template <class E>
+static int floodplains_t(pfd_raster *h, const u8 *stream, const float *hin, const void *elev, FloodV *st) {
+  Flood<E> op{h->ncode, h->geo, stream, hin, (const E *)elev, st};
+  return sweep_down(h, op, "sweep_floodplains", "exact_floodplains");
+}
+extern "C" int pfd_floodplains(pfd_raster *h, int elev_dtype, const void *elevtn, const uint8_t *is_stream,
+                               const float *stream_h, int8_t *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!elevtn || !is_stream || !stream_h || !out || (elev_dtype != PFD_F32 && elev_dtype != PFD_F64)) {
+    pfd_set_error("pfd_floodplains: bad arguments (elevation dtype code %d)", elev_dtype);
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  PFDCHK(ensure_sweep_structure(h));
+  InArg el, sm, hh;
+  PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
+  PFDCHK(sm.bind(is_stream, (size_t)h->n, memspace, h->stream));
+  PFDCHK(hh.bind(stream_h, (size_t)h->n * sizeof(float), memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n, memspace));
+  DevBuf st;
+  PFDCHK(st.alloc((size_t)h->n * sizeof(FloodV) + 64));
+  const u32 grid = cdiv_u32((u64)h->n, 256);
+  k_flood_init<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo.n, st.as<FloodV>());
+  KCHK();
+  if (elev_dtype == PFD_F32)
+    PFDCHK(floodplains_t<float>(h, (const u8 *)sm.dev, (const float *)hh.dev, el.dev, st.as<FloodV>()));
+  else
+    PFDCHK(floodplains_t<double>(h, (const u8 *)sm.dev, (const float *)hh.dev, el.dev, st.as<FloodV>()));
+  k_flood_out<<<grid, 256, 0, h->stream>>>(st.as<FloodV>(), h->geo.n, (int8_t *)o.dev);
+  KCHK();
+  return o.finish(h->stream);  // (synchronises: `st` may be released afterwards)
 }

@@ -482,6 +482,44 @@ class FlwdirRaster(object):
             raise NotImplementedError(f"elevation dtype {elevtn.dtype} is not supported on the HIP path")
         return self._h.hand(drain_u8, np.ascontiguousarray(elevtn), code).reshape(self.shape)
 
+    def ucat_area(self, idxs_out, unit="cell"):
+        """Unit catchment map (high resolution) and area (low resolution); reference
+        pyflwdir/pyflwdir.py:1159-1191 + pyflwdir/subgrid.py:51-93."""
+        unit = str(unit).lower()
+        if unit not in gis.AREA_FACTORS:
+            fstr = '", "'.join(gis.AREA_FACTORS.keys())
+            raise ValueError(f'Unknown unit: {unit}, select from "{fstr}".')
+        idxs_out = np.asarray(idxs_out)
+        flat = idxs_out.ravel()
+        idx64 = np.where(flat == self._mv, -1, flat.astype(np.int64)) if flat.size else flat.astype(np.int64)
+        rows = None
+        if unit != "cell":
+            rows = np.ascontiguousarray(gis.area_rows(self.transform, self.shape, self.latlon, unit="m2")
+                                        / gis.AREA_FACTORS[unit])
+        ucat_map, ucat_are = self._h.ucat_area(idx64, self._idx_dtype, rows)
+        return ucat_map.reshape(self.shape), ucat_are.reshape(idxs_out.shape)
+
+    def floodplains(self, elevtn, uparea=None, upa_min=1000, b=0.3):
+        """Floodplain boundaries from a HAND threshold that scales with upstream area, h ~ A**b (Nardi et al
+        2019); reference pyflwdir/pyflwdir.py:1513-1545 + pyflwdir/dem.py:333-379.  int8: 1 floodplain, 0 not,
+        -1 off the sequence."""
+        elevtn = self._check_data(elevtn, "elevtn")
+        uparea = self._check_data(uparea, "uparea", unit="km2")
+        is_stream = np.ascontiguousarray(uparea >= upa_min).view(np.uint8)
+        with np.errstate(invalid="ignore"):
+            # drainh[idx0] = uparea[idx0] ** b, stored as float32: evaluated here, element by element as the
+            # reference does (numpy scalar ** python float), only where it is used
+            hs = np.zeros(self.size, np.float32)
+            sel = np.flatnonzero(is_stream)
+            hs[sel] = (uparea[sel] ** b).astype(np.float32)
+        if elevtn.dtype == np.float32:
+            code = _hip.PFD_F32
+        elif elevtn.dtype == np.float64 or elevtn.dtype.kind in "iub":
+            code, elevtn = _hip.PFD_F64, elevtn.astype(np.float64, copy=False)
+        else:
+            raise NotImplementedError(f"elevation dtype {elevtn.dtype} is not supported on the HIP path")
+        return self._h.floodplains(np.ascontiguousarray(elevtn), code, is_stream, hs).reshape(self.shape)
+
     # -- shortcuts ------------------------------------------------------------------------------
     def _check_data(self, data, name, optional=False, flatten=True, **kwargs):
         """Check data shape and size, return the flattened array; reference
