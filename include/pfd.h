@@ -250,6 +250,13 @@ int pfd_ucat_area(pfd_raster *h, const int64_t *idxs_out, int64_t k, int map_dty
 int pfd_floodplains(pfd_raster *h, int elev_dtype, const void *elevtn, const uint8_t *is_stream, const float *stream_h,
                     int8_t *out, int memspace);
 
+/* core.snap in downstream direction, cell units (reference pyflwdir/core.py:440-480, Flwdir.snap
+ * flwdir.py:404-463; used by basins(streams=...) / add_pits(streams=...), flwdir.py:805-811): per start cell
+ * (k HOST indices) the first cell downstream, itself included, where mask != 0, or the pit its path ends in;
+ * dist_out = cells walked (float32 like the reference); max_hops < 0: unlimited. */
+int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k, const uint8_t *mask, int memspace,
+                        int64_t max_hops, int64_t *idxs_out, float *dist_out);
+
 /* ---- instrumentation ---------------------------------------------------------------------
  * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST
  * sweep/ordering call on the handle.  Enable with pfd_set_profiling(h, 1).  Up to max_seg

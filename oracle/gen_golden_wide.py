@@ -143,7 +143,45 @@ def gen_subgrid():
     print(f"[wide] subgrid: {len(store)} arrays")
 
 
-GENS = {"dem": gen_dem, "subgrid": gen_subgrid}
+def gen_snap():
+    """Flwdir.snap (downstream, cell units) and basins(xy/idxs, streams=...) / add_pits(streams=...):
+    reference pyflwdir/flwdir.py:404-463,805-811, core.py:440-480."""
+    from pyflwdir_amd._affine import Affine
+    import json
+
+    manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+    store = {}
+    # (rasters without cycles only: the reference's trace never returns from a cycle)
+    for name in ("flwdir0", "flwdir_large", "synth_rough_nodata_384x512", "rhine"):
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        d8 = z["d8"]
+        ent = manifest[name]
+        flw = pyflwdir.from_array(d8, ftype="d8", check_ftype=False, transform=Affine(*ent["transform"]),
+                                  latlon=ent["latlon"], cache=False)
+        upa = flw.upstream_area()
+        strord = flw.stream_order()
+        streams = strord >= max(2, int(strord.max()) - 2)
+        rng = np.random.default_rng(11)
+        valid = np.flatnonzero(flw.mask)
+        idxs = rng.choice(valid, size=min(200, valid.size), replace=False).astype(np.int64)
+        store[f"in_{name}_idxs"] = idxs
+        store[f"in_{name}_streams"] = streams
+        i1, d1 = flw.snap(idxs=idxs, mask=streams)
+        store[f"out_{name}_snap_idxs"], store[f"out_{name}_snap_dist"] = i1, d1
+        i2, d2 = flw.snap(idxs=idxs, mask=streams, max_length=5)
+        store[f"out_{name}_snap5_idxs"], store[f"out_{name}_snap5_dist"] = i2, d2
+        i3, d3 = flw.snap(idxs=idxs)
+        store[f"out_{name}_snap_nomask_idxs"], store[f"out_{name}_snap_nomask_dist"] = i3, d3
+        store[f"out_{name}_basins_streams"] = flw.basins(idxs=idxs[:40], streams=streams)
+        flw2 = pyflwdir.from_array(d8, ftype="d8", check_ftype=False, cache=False)
+        flw2.add_pits(idxs=idxs[:10], streams=streams)
+        store[f"out_{name}_addpits_streams_idxs_pit"] = flw2.idxs_pit
+        store[f"out_{name}_addpits_streams_upa"] = flw2.upstream_area()
+    np.savez_compressed(os.path.join(GOLD, "wide_snap.npz"), **store)
+    print(f"[wide] snap: {len(store)} arrays")
+
+
+GENS = {"dem": gen_dem, "subgrid": gen_subgrid, "snap": gen_snap}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or GENS):

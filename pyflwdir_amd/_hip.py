@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream",
 ]
 
 _lib = None
@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
                                            C.c_double, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
         L.pfd_ucat_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.pfd_floodplains.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_snap_downstream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int)]
@@ -350,6 +351,12 @@ class RasterHandle:
         out = np.empty(self.n, np.int8)
         check(lib().pfd_floodplains(self._h, elev_code, ptr(elevtn), ptr(is_stream), ptr(stream_h), ptr(out), PFD_HOST))
         return out
+
+    def snap_downstream(self, idxs, mask, max_hops=-1):
+        idxs = np.ascontiguousarray(idxs, dtype=np.int64).ravel()
+        out, dist = np.empty(idxs.size, np.int64), np.empty(idxs.size, np.float32)
+        check(lib().pfd_snap_downstream(self._h, ptr(idxs), idxs.size, ptr(mask), PFD_HOST, int(max_hops), ptr(out), ptr(dist)))
+        return out, dist
 
     def main_upstream(self, uparea, dtype_code, idx_dtype, upa_min=0.0, out=None, memspace=PFD_HOST):
         if memspace == PFD_HOST:

@@ -105,3 +105,55 @@ extern "C" int pfd_checksum_i32(int device, const int32_t *dev_ptr, int64_t n, i
   *sum = (int64_t)host;
   return PFD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// core.snap, downstream direction, cell units (reference pyflwdir/core.py:440-480 with core._trace
+// :316-366; Flwdir.snap flwdir.py:404-463): per start cell the first cell on its downstream path (the start
+// itself included) where `mask` is set, or the pit the path ends in; dist = hops walked.  One thread per start
+// cell; this is a bounded walk over k cells (k = number of outlets a user passes), not a raster sweep.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_snap_down(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ mask,
+                                                  const i64 *__restrict__ idx0, u32 k, i64 max_hops,
+                                                  i64 *__restrict__ out, float *__restrict__ dist) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k) return;
+  u32 x = (u32)idx0[t];
+  i64 d = 0;
+  while (!mask[x]) {
+    const u32 c = ncode[x];
+    if (!d8_is_dir(c)) break;  // pit (or nodata: `idx1 == mv`)
+    if (max_hops >= 0 && d + 1 > max_hops) break;
+    x = d8_down(g, x, c);
+    ++d;
+  }
+  out[t] = (i64)x;
+  dist[t] = (float)d;
+}
+extern "C" int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k, const uint8_t *mask, int memspace,
+                                   int64_t max_hops, int64_t *idxs_out, float *dist_out) {
+  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_require_whole(h, "snap"));
+  if (k < 0 || (k > 0 && (!idxs || !idxs_out || !dist_out)) || !mask) {
+    pfd_set_error("pfd_snap_downstream: bad arguments");
+    return PFD_EINVAL;
+  }
+  if (k == 0) return PFD_OK;
+  for (i64 i = 0; i < k; ++i)
+    if (idxs[i] < 0 || idxs[i] >= h->n) {
+      pfd_set_error("pfd_snap_downstream: index %lld outside the raster", (long long)idxs[i]);
+      return PFD_EINVAL;
+    }
+  InArg di, dm;
+  PFDCHK(di.bind(idxs, (size_t)k * sizeof(i64), PFD_HOST, h->stream));
+  PFDCHK(dm.bind(mask, (size_t)h->n, memspace, h->stream));
+  DevBuf o, d;
+  PFDCHK(o.alloc((size_t)k * sizeof(i64)));
+  PFDCHK(d.alloc((size_t)k * sizeof(float)));
+  k_snap_down<<<cdiv_u32((u64)k, 64), 64, 0, h->stream>>>(h->ncode, h->geo, (const u8 *)dm.dev, (const i64 *)di.dev, (u32)k,
+                                                         max_hops, o.as<i64>(), d.as<float>());
+  KCHK();
+  HIPCHK(hipMemcpyAsync(idxs_out, o.p, (size_t)k * sizeof(i64), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(dist_out, d.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}

@@ -334,6 +334,12 @@ class FlwdirRaster(object):
         """Add pits to the flow direction raster; reference pyflwdir/pyflwdir.py:299-315,
         pyflwdir/flwdir.py:261-279."""
         idxs1 = self._check_idxs_xy(idxs, xy, streams)
+        # validated on the host BEFORE anything is modified, so that host and device state cannot diverge
+        i64 = np.asarray(idxs1, dtype=np.int64)
+        if np.any(i64 < 0) or np.any(i64 >= self.size):
+            raise IndexError("idxs outside domain")
+        if np.any(self._d8.flat[i64] == D8_MV):
+            raise ValueError("add_pits: indices must address valid (non-nodata) cells")
         self._h.add_pits(idxs1)
         self._d8 = self._d8.copy()
         self._d8.flat[idxs1] = 0
@@ -553,9 +559,29 @@ class FlwdirRaster(object):
         elif xy is not None:
             idxs = self.index(*xy)
         idxs = np.atleast_1d(idxs).ravel()
-        if streams is not None:
-            raise NotImplementedError("snapping outlets to a stream mask (core.snap) is outside the GPU hot path")
+        streams = self._check_data(streams, "streams", optional=True)
+        if streams is not None:  # snap to the first downstream True cell (reference flwdir.py:805-811)
+            idxs = self.snap(idxs=idxs, mask=streams)[0]
         return idxs
+
+    def snap(self, idxs=None, xy=None, mask=None, max_length=None, unit="cell", direction="down"):
+        """Snap points to the first downstream cell where ``mask`` is True (or the pit of their path);
+        reference pyflwdir/pyflwdir.py:500-562, pyflwdir/flwdir.py:404-463, core.snap core.py:440-480.
+        The device path serves direction="down" with unit="cell" (what ``basins(streams=...)`` and
+        ``add_pits(streams=...)`` use); returns (idxs, dists)."""
+        if direction != "down" or str(unit).lower() != "cell":
+            raise NotImplementedError("snap: the HIP path implements direction='down', unit='cell'")
+        if (xy is not None and idxs is not None) or (xy is None and idxs is None):
+            raise ValueError("Either idxs or xy should be provided.")
+        if xy is not None:
+            idxs = self.index(*xy)
+        idxs = np.atleast_1d(idxs).ravel()
+        mask = self._check_data(mask, "mask", optional=True)
+        m = np.zeros(self.size, np.uint8) if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
+        if np.any(idxs < 0) or np.any(idxs >= self.size):
+            raise IndexError("idxs outside domain")
+        out, dist = self._h.snap_downstream(idxs, m, -1 if max_length is None else int(max_length))
+        return out.astype(idxs.dtype if idxs.dtype.kind in "iu" else np.int64), dist  # (core.snap: dtype of idxs0)
 
 
 def _payload_args(flat, nodata):
