@@ -88,6 +88,15 @@ int pfd_trim(int device);
 int pfd_raster_create(const uint8_t *d8, int64_t nrow, int64_t ncol, int memspace, int device,
                       pfd_raster **out);
 int pfd_raster_destroy(pfd_raster *h);
+/* A flow graph given by its downstream indices (idx_dtype PFD_I32 / PFD_U32 / PFD_I64; -1 cast = nodata,
+ * own index = pit) whose links are NOT restricted to the 8 neighbours: NEXTXY rasters (reference
+ * pyflwdir/core_nextxy.py:41-68) and upscaled networks (FlwdirRaster(idxs_ds=...), pyflwdir.py:1079-1085).
+ * Served by the general level engine (upstream CSR + one launch per level): ordering / idxs_seq / rank /
+ * upstream_count / upstream_area / accuflux / Strahler and classic order / basins / HAND / main_upstream /
+ * stream_distance (real_length: `step_lengths` = n HOST float32, one per cell); the tile engines, the
+ * multi-GPU entry points, ucat_area, floodplains and snap return PFD_EUNSUPPORTED on such a handle. */
+int pfd_raster_create_general(const void *idxs_ds, int idx_dtype, int64_t nrow, int64_t ncol, int memspace, int device,
+                              pfd_raster **out);
 /* One row block of a raster that is tiled over several GPUs (Multi-GPU): `d8` holds
  * halo_top + own_rows + halo_bot rows; the halo rows (0 or 1 each) are copies of the adjacent
  * rows of the neighbouring blocks and are only used to decide where flow leaves the block.
@@ -133,6 +142,11 @@ int pfd_order_cells(pfd_raster *h);
  * reference (pits ascending, then each dequeued cell's upstream cells ascending); out has
  * n_seq entries. */
 int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace);
+/* General idxs_ds graphs only: install the cell sequence the sweeps follow.  Flwdir.order_cells("sort")
+ * (reference pyflwdir/flwdir.py:231-245; the only ordering of NEXTXY rasters, pyflwdir.py:292-297) sorts the
+ * cells by rank with numpy's argsort, and the serial loops add upstream cells in the reverse order of that
+ * sequence — a float accumulation depends on it.  `seq`: HOST array of n_seq indices, ordered by rank. */
+int pfd_set_idxs_seq(pfd_raster *h, int idx_dtype, const void *seq, int64_t n_seq);
 /* core.rank (reference pyflwdir/core.py:17-47): int32 distance to the pit, -1 for cells that
  * do not drain to a pit, -9999 on nodata. */
 int pfd_rank(pfd_raster *h, int32_t *out, int memspace);

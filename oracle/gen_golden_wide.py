@@ -4,6 +4,8 @@ either side of the hot path), recorded from the imported reference exactly like 
 the path itself (interpreted through the identity-njit shim; runs only where /root/reference exists).
 
     tests/golden/wide_dem.npz      dem.fill_depressions / from_dem            (reference pyflwdir/dem.py:17-143)
+    tests/golden/wide_general.npz  NEXTXY rasters and FlwdirRaster(idxs_ds=...) with arbitrary links, all operations
+    tests/golden/wide_snap.npz     Flwdir.snap, basins / add_pits with streams=
     tests/golden/wide_subgrid.npz  FlwdirRaster.ucat_area / .floodplains      (subgrid.py:51-93, dem.py:333-379)
 
 Fixtures are data only (inputs + the reference's outputs).   Usage: python oracle/gen_golden_wide.py [dem ...]
@@ -181,7 +183,79 @@ def gen_snap():
     print(f"[wide] snap: {len(store)} arrays")
 
 
-GENS = {"dem": gen_dem, "subgrid": gen_subgrid, "snap": gen_snap}
+def gen_general():
+    """Graphs with links outside the 8 neighbours: NEXTXY rasters (core_nextxy.py:24-86, from_array / to_array;
+    pyflwdir.py:170-205) and FlwdirRaster(idxs_ds=...) with arbitrary links (pyflwdir.py:211-273, as upscale
+    builds them, :1079-1085) — every operation of the path on both; plus the keys of the dump/load dictionary
+    (pyflwdir.py:275-286)."""
+    from pyflwdir_amd._affine import Affine
+    from oracle import golden_inputs as GI
+    import json
+
+    manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+    store = {}
+
+    def ops(tag, flw, elv):
+        upa = flw.upstream_area()
+        store[f"out_{tag}_idxs_ds"] = flw.idxs_ds
+        store[f"out_{tag}_idxs_pit"] = flw.idxs_pit
+        if flw.idxs_outlet is not None:  # (None for FlwdirRaster(idxs_ds=...) built without outlets)
+            store[f"out_{tag}_idxs_outlet"] = flw.idxs_outlet
+        store[f"out_{tag}_idxs_seq"] = flw.idxs_seq
+        store[f"out_{tag}_rank"] = flw.rank
+        store[f"out_{tag}_n_upstream"] = flw.n_upstream
+        store[f"out_{tag}_upa"] = upa
+        store[f"out_{tag}_upa_km2"] = flw.upstream_area("km2")
+        P = GI.payloads(flw.shape)
+        store[f"out_{tag}_accu_f32"] = flw.accuflux(P["w32"])
+        store[f"out_{tag}_accu_ds_f64"] = flw.accuflux(P["w64"], direction="down")
+        store[f"out_{tag}_accu_i32_nd"] = flw.accuflux(P["wi32_nodata"], nodata=-9999)
+        store[f"out_{tag}_strahler"] = flw.stream_order()
+        store[f"out_{tag}_strahler_mask"] = flw.stream_order(mask=GI.random_mask(flw.shape))
+        store[f"out_{tag}_classic"] = flw.stream_order(type="classic")
+        store[f"out_{tag}_idxs_us_main"] = flw.idxs_us_main
+        store[f"out_{tag}_basins"] = flw.basins()
+        idxs, ids = GI.basin_outlets(upa, flw.idxs_pit)
+        store[f"in_{tag}_basins_idxs"], store[f"in_{tag}_basins_ids"] = idxs, ids
+        store[f"out_{tag}_basins_sub"] = flw.basins(idxs=idxs, ids=ids)
+        thr = GI.threshold(upa)
+        store[f"out_{tag}_hand"] = flw.hand(upa > thr, elv)
+        store[f"out_{tag}_dist_cell"] = flw.stream_distance(unit="cell")
+        store[f"out_{tag}_dist_m"] = flw.stream_distance(unit="m")
+        store[f"out_{tag}_dist_m_mask"] = flw.stream_distance(mask=upa > thr, unit="m")
+        flw.order_cells(method="sort")
+        store[f"out_{tag}_idxs_seq_sort"] = flw.idxs_seq
+
+    for name in ("flwdir0", "flwdir_large", "synth_loops_96x80"):
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        ent = manifest[name]
+        A = Affine(*ent["transform"])
+        flw8 = pyflwdir.from_array(z["d8"], ftype="d8", check_ftype=False, transform=A, latlon=ent["latlon"], cache=False)
+        upa8 = flw8.upstream_area()
+        elv = GI.elevation(None, upa8)
+        store[f"in_{name}_elevtn"] = elv
+        # NEXTXY: the same graph written as a NEXTXY raster and parsed back
+        nxy = flw8.to_array("nextxy")
+        store[f"in_{name}_nextxy"] = nxy
+        flwn = pyflwdir.from_array(nxy, ftype="nextxy", transform=A, latlon=ent["latlon"], cache=False)
+        store[f"out_{name}_nextxy_isvalid"] = np.uint8(pyflwdir.core_nextxy.isvalid(nxy))
+        ops(name + "_nextxy", flwn, elv)
+        store[f"out_{name}_nextxy_to_array"] = flwn.to_array()
+        store[f"out_{name}_nextxy_to_d8"] = flwn.to_array("d8")
+        # arbitrary links: every cell skips its downstream cell (the forest of 2-step links)
+        ds = flw8.idxs_ds
+        mv = flw8._mv
+        ds2 = np.where(ds == mv, mv, ds[np.where(ds == mv, 0, ds)]).astype(ds.dtype)
+        store[f"in_{name}_ds2"] = ds2
+        flw2 = pyflwdir.FlwdirRaster(idxs_ds=ds2, shape=flw8.shape, ftype="d8", transform=A, latlon=ent["latlon"], cache=False)
+        ops(name + "_ds2", flw2, elv)
+        store[f"out_{name}_ds2_to_nextxy"] = flw2.to_array("nextxy")
+    store["dump_keys"] = np.array(",".join(sorted(str(k) for k in flw2._dict.keys())))
+    np.savez_compressed(os.path.join(GOLD, "wide_general.npz"), **store)
+    print(f"[wide] general: {len(store)} arrays")
+
+
+GENS = {"dem": gen_dem, "subgrid": gen_subgrid, "snap": gen_snap, "general": gen_general}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or GENS):

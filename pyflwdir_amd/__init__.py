@@ -10,7 +10,9 @@ Python host code -> ctypes -> C-ABI (include/pfd.h) -> hand-written HIP kernels 
 from . import gis as gis_utils  # reference name of the module
 from . import gis
 from . import dem
+from . import regions
+from .nextxy import read_nextxy
 from .raster import FTYPES, FlwdirRaster, from_array, from_dem
 
 __version__ = "0.1.0"
-__all__ = ["FlwdirRaster", "from_array", "from_dem", "dem", "gis_utils", "gis", "FTYPES"]
+__all__ = ["FlwdirRaster", "from_array", "from_dem", "dem", "regions", "read_nextxy", "gis_utils", "gis", "FTYPES"]

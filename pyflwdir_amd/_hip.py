@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_raster_create_general", "pfd_set_idxs_seq",
 ]
 
 _lib = None
@@ -102,6 +102,8 @@ def lib() -> C.CDLL:
         L.pfd_ucat_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.pfd_floodplains.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_snap_downstream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        L.pfd_raster_create_general.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pfd_set_idxs_seq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int)]
@@ -202,6 +204,19 @@ class RasterHandle:
             check(lib().pfd_raster_create_block(ptr(d8), self.nrow, self.ncol, self.halo[0], self.halo[1], memspace,
                                                 device, C.byref(self._h)))
 
+    @classmethod
+    def general(cls, idxs_ds: np.ndarray, nrow: int, ncol: int, device: int = 0):
+        """Handle of a general ``idxs_ds`` graph (links outside the 8 neighbours; pfd_raster_create_general)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.nrow, self.ncol, self.n = int(nrow), int(ncol), int(nrow) * int(ncol)
+        self.device, self.halo, self._d8_ref = device, (0, 0), None
+        idxs_ds = np.ascontiguousarray(idxs_ds).ravel()
+        assert idxs_ds.size == self.n
+        check(lib().pfd_raster_create_general(ptr(idxs_ds), IDX_CODE[idxs_ds.dtype], self.nrow, self.ncol, PFD_HOST, device,
+                                              C.byref(self._h)))
+        return self
+
     def close(self):
         if self._h:
             lib().pfd_raster_destroy(self._h)
@@ -270,6 +285,11 @@ class RasterHandle:
         out = np.empty(self.info()["n_seq"], dtype)
         check(lib().pfd_idxs_seq(self._h, IDX_CODE[np.dtype(dtype)], ptr(out), PFD_HOST))
         return out
+
+    def set_idxs_seq(self, seq: np.ndarray):
+        """General graphs: install the host's cell sequence (order_cells("sort")) as the order of the sweeps."""
+        seq = np.ascontiguousarray(seq)
+        check(lib().pfd_set_idxs_seq(self._h, IDX_CODE[seq.dtype], ptr(seq), seq.size))
 
     def rank(self) -> np.ndarray:
         out = np.empty(self.n, np.int32)
@@ -372,14 +392,15 @@ class RasterHandle:
                                              ptr(mask), ptr(out), memspace))
         return out
 
-    def stream_distance(self, mask=None, step_lengths=None, out=None, memspace=PFD_HOST):
-        """``step_lengths`` None: int32 cell counts; else float32 with the host table [2*nrow-1, 3]."""
+    def stream_distance(self, mask=None, step_lengths=None, out=None, memspace=PFD_HOST, per_cell=False):
+        """``step_lengths`` None: int32 cell counts; else float32 with the host table [2*nrow-1, 3] (D8 rasters)
+        or one value per cell (``per_cell``: general idxs_ds graphs)."""
         real = step_lengths is not None
         if memspace == PFD_HOST:
             out = np.empty(self.n, np.float32 if real else np.int32)
         if real:
             step_lengths = np.ascontiguousarray(step_lengths, dtype=np.float32)
-            assert step_lengths.size == 3 * (2 * self.nrow - 1)
+            assert step_lengths.size == (self.n if per_cell else 3 * (2 * self.nrow - 1))
         check(lib().pfd_stream_distance(self._h, ptr(mask), int(real), ptr(step_lengths), ptr(out), memspace))
         return out
 

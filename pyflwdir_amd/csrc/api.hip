@@ -235,10 +235,37 @@ static void free_handle(pfd_raster *h) {
   pfd_dfree(h->seq);
   pfd_dfree(h->seq_kids2);  // (seq_kids / seq_own / cell_kids live in the same allocation)
   pfd_free_xplan(h);
+  pfd_free_general(h);
   pfd_dfree(h->pits);
   pfd_dfree(h->ctrl);
   if (h->stream) release_stream(h->device, h->stream);
   delete h;
+}
+
+int pfd_handle_alloc(i64 nrow, i64 ncol, int device, pfd_raster **out) {
+  PFDCHK(select_device(device));
+  pfd_raster *h = new pfd_raster();
+  h->device = device;
+  h->nrow = nrow;
+  h->ncol = ncol;
+  h->n = nrow * ncol;
+  h->own_rows = nrow;
+  h->geo = make_geo(nrow, ncol);
+  int rc = acquire_stream(device, &h->stream);
+  if (rc == PFD_OK) rc = pfd_dmalloc((void **)&h->ncode, (size_t)h->n + 64);
+  if (rc == PFD_OK) rc = pfd_dmalloc((void **)&h->ctrl, 64 * sizeof(u64));
+  if (rc != PFD_OK) {
+    free_handle(h);
+    return rc;
+  }
+  h->bytes_held = (size_t)h->n + 64 * sizeof(u64);
+  *out = h;
+  return PFD_OK;
+}
+int pfd_reject_general(pfd_raster *h, const char *what) {
+  if (!h->gen) return PFD_OK;
+  pfd_set_error("%s is not available on a general idxs_ds graph (links outside the 8 neighbours)", what);
+  return PFD_EUNSUPPORTED;
 }
 
 static int raster_create_impl(const uint8_t *d8, int64_t own_rows, int64_t ncol, int halo_top, int halo_bot,
@@ -453,6 +480,7 @@ static size_t idx_size(int idx_dtype) {
 
 extern "C" int pfd_idxs_ds(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
+  if (h->gen) return pfd_gen_idxs_ds(h, idx_dtype, out, memspace);
   PFDCHK(pfd_require_whole(h, "idxs_ds"));
   const size_t es = idx_size(idx_dtype);
   if (!es || !out) {

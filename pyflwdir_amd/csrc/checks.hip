@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256) k_verify_upa(const u8 *__restrict__ ncode
 
 extern "C" int pfd_verify_upstream_area_cell(pfd_raster *h, const int32_t *upa, int memspace, int64_t res[8]) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, "verify_upstream_area_cell"));
   if (!upa || !res) {
     pfd_set_error("pfd_verify_upstream_area_cell: bad arguments");
     return PFD_EINVAL;
@@ -132,6 +133,7 @@ __global__ void __launch_bounds__(64) k_snap_down(const u8 *__restrict__ ncode, 
 extern "C" int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k, const uint8_t *mask, int memspace,
                                    int64_t max_hops, int64_t *idxs_out, float *dist_out) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, "snap"));
   PFDCHK(pfd_require_whole(h, "snap"));
   if (k < 0 || (k > 0 && (!idxs || !idxs_out || !dist_out)) || !mask) {
     pfd_set_error("pfd_snap_downstream: bad arguments");

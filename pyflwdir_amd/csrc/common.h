@@ -140,6 +140,7 @@ struct pfd_raster {
   u64 *seq_kids2 = nullptr;                    // per ordered cell: the child masks of its upstream cells (owns the allocation)
   int acyclic = 0;               // 0 unknown, 1 every valid cell reaches a pit, -1 the raster holds cycles
   // plan of the exact-order engine (exact.h): 0 not built, 1 ready, -1 not available
+  void *gen = nullptr;    // general idxs_ds graph (general.hip): links outside the 8 neighbours; the D8 kernels stand down
   void *xplan = nullptr;
   int xplan_state = 0;
   bool aux_ready = false;
@@ -244,6 +245,25 @@ void pfd_free_pending(pfd_raster *h);                            // dist.hip
 void pfd_free_pending_basins(pfd_raster *h);                     // paths.hip
 int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
 void pfd_free_xplan(pfd_raster *h);                             // exact.hip
+void pfd_free_general(pfd_raster *h);                           // general.hip
+int pfd_handle_alloc(i64 nrow, i64 ncol, int device, pfd_raster **out);  // api.hip: empty handle (stream, code raster, ctrl)
+// general.hip: the entry points of a general idxs_ds graph (h->gen != nullptr)
+int pfd_gen_idxs_ds(pfd_raster *h, int idx_dtype, void *out, int memspace);
+int pfd_gen_order(pfd_raster *h);
+int pfd_gen_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace);
+int pfd_gen_rank(pfd_raster *h, i32 *out, int memspace);
+int pfd_gen_upstream_count(pfd_raster *h, const u8 *mask, int8_t *out, int memspace);
+int pfd_gen_accuflux(pfd_raster *h, int dtype, const void *data, bool by_row, int64_t nodata_i, double nodata_f,
+                     int has_nodata, int direction, int mask_invalid, void *out, int memspace);
+int pfd_gen_upstream_area_cell(pfd_raster *h, i32 *out, int memspace);
+int pfd_gen_strahler(pfd_raster *h, const u8 *mask, u8 *out, int memspace);
+int pfd_gen_basins(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev);
+int pfd_gen_hand(pfd_raster *h, const u8 *drain, int elev_dtype, const void *elevtn, double *out, int memspace);
+int pfd_gen_stream_distance(pfd_raster *h, const u8 *mask, int real_length, const float *step_lengths, void *out, int memspace);
+int pfd_gen_main_upstream(pfd_raster *h, int dtype, const void *uparea, double upa_min, int idx_dtype, void *out, int memspace);
+int pfd_gen_classic(pfd_raster *h, int idx_dtype, const void *idxs_us_main, const u8 *mask, u8 *out, int memspace);
+int pfd_gen_add_pits(pfd_raster *h, const i64 *idxs, i64 k);
+int pfd_reject_general(pfd_raster *h, const char *what);        // api.hip: PFD_EUNSUPPORTED on a general graph
 int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev,
                      int *ok);                                   // paths.hip
 int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete, const i32 *weights = nullptr);  // tiled.hip

@@ -378,6 +378,7 @@ void pfd_free_xplan(pfd_raster *h) {
 int pfd_ensure_xplan(pfd_raster *h) {
   if (h->xplan_state != 0) return PFD_OK;
   h->xplan_state = -1;
+  if (h->gen) return PFD_OK;
   if (h->n > 4294967294ll || h->halo_top || h->halo_bot || getenv("PFD_EXACT_LEVELS")) return PFD_OK;
   if (h->acyclic < 0) return PFD_OK;
   const u32 n = h->geo.n;

@@ -333,11 +333,16 @@ extern "C" int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k) {
     return PFD_EINVAL;
   }
   if (k == 0) return PFD_OK;
+  PFDCHK(pfd_require_whole(h, "add_pits"));
   InArg in;
-  PFDCHK(in.bind(idxs, (size_t)k * sizeof(i64), PFD_HOST, h->stream));
   HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
-  k_add_pits<<<cdiv_u32((u64)k, 256), 256, 0, h->stream>>>(h->ncode, (const i64 *)in.dev, (u32)k, h->geo.n, h->ctrl);
-  KCHK();
+  if (h->gen) {
+    PFDCHK(pfd_gen_add_pits(h, idxs, k));
+  } else {
+    PFDCHK(in.bind(idxs, (size_t)k * sizeof(i64), PFD_HOST, h->stream));
+    k_add_pits<<<cdiv_u32((u64)k, 256), 256, 0, h->stream>>>(h->ncode, (const i64 *)in.dev, (u32)k, h->geo.n, h->ctrl);
+    KCHK();
+  }
   k_count_pits<<<1024, 256, 0, h->stream>>>(h->ncode, h->geo.n, h->ctrl);
   KCHK();
   u64 c[3];
@@ -383,6 +388,7 @@ __global__ void __launch_bounds__(256) k_upstream_count(const u8 *__restrict__ n
 
 extern "C" int pfd_upstream_count(pfd_raster *h, const uint8_t *mask, int8_t *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
+  if (h->gen) return pfd_gen_upstream_count(h, mask, out, memspace);
   PFDCHK(pfd_require_whole(h, "upstream_count"));
   if (!out) {
     pfd_set_error("pfd_upstream_count: NULL out");
@@ -455,6 +461,7 @@ __global__ void __launch_bounds__(256) k_bfs_level(const u8 *__restrict__ ncode,
 }
 
 int pfd_order_cells_impl(pfd_raster *h) {
+  if (h->gen) return pfd_gen_order(h);
   if (h->ordered) return PFD_OK;
   PFDCHK(pfd_require_whole(h, "the cell ordering"));
   if (!getenv("PFD_ORDER_BFS")) {
@@ -568,6 +575,7 @@ extern "C" int pfd_rank(pfd_raster *h, int32_t *out, int memspace) {
     pfd_set_error("pfd_rank: NULL out");
     return PFD_EINVAL;
   }
+  if (h->gen) return pfd_gen_rank(h, out, memspace);
   PFDCHK(pfd_order_cells_impl(h));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
@@ -719,6 +727,7 @@ int pfd_exact_seq_dev(pfd_raster *h, DevBuf &oseq) {
 
 extern "C" int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
+  if (h->gen) return pfd_gen_idxs_seq(h, idx_dtype, out, memspace);
   DevBuf oseq;
   PFDCHK(pfd_exact_seq_dev(h, oseq));
   return pfd_export_u32(h, oseq.as<u32>(), h->n_seq, idx_dtype, out, memspace);

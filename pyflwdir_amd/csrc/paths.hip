@@ -429,6 +429,7 @@ __global__ void k_labels_out_block(const u32 *__restrict__ num, const L *__restr
 extern "C" int pfd_basins_begin(pfd_raster *h, const int64_t *outlets, const void *ids, int64_t k, int id_size,
                                 void *out, int memspace, uint32_t *record_host) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, "the multi-block basins query"));
   if (!out || !record_host || k < 0 || (k > 0 && (!outlets || !ids)) ||
       (id_size != 1 && id_size != 2 && id_size != 4 && id_size != 8) || k >= 0x7FFFFFFFll) {
     pfd_set_error("pfd_basins_begin: bad arguments (k=%lld, id_size=%d)", (long long)k, id_size);
@@ -784,6 +785,7 @@ __global__ void __launch_bounds__(256) k_indeg_hist(const u8 *__restrict__ ncode
 
 extern "C" int pfd_graph_stats(pfd_raster *h, int64_t stats[16]) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, "graph_stats"));
   if (!stats) {
     pfd_set_error("pfd_graph_stats: NULL stats");
     return PFD_EINVAL;

@@ -87,6 +87,7 @@ static int ucat_float(pfd_raster *h, const u32 *lab, const u8 *is_out, u32 k, co
 extern "C" int pfd_ucat_area(pfd_raster *h, const int64_t *idxs_out, int64_t k, int map_dtype, void *map_out, int memspace,
                              int area_dtype, const void *area_rows, void *area_out) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, "ucat_area"));
   PFDCHK(pfd_require_whole(h, "ucat_area"));
   if (!idxs_out || k < 0 || k >= 0xFFFFFFFFll || !map_out || !area_out ||
       (area_dtype != PFD_I32 && area_dtype != PFD_F32 && area_dtype != PFD_F64) || (area_dtype != PFD_I32 && !area_rows)) {

@@ -835,6 +835,7 @@ extern "C" int pfd_upstream_area_cell_levels(pfd_raster *h, int32_t *out, int me
     pfd_set_error("pfd_upstream_area_cell: NULL out");
     return PFD_EINVAL;
   }
+  if (h->gen) return pfd_gen_upstream_area_cell(h, out, memspace);
   pfd_seg_clear(h);
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
@@ -851,6 +852,7 @@ extern "C" int pfd_upstream_area_cell(pfd_raster *h, int32_t *out, int memspace)
     pfd_set_error("pfd_upstream_area_cell: NULL out");
     return PFD_EINVAL;
   }
+  if (h->gen) return pfd_gen_upstream_area_cell(h, out, memspace);
   pfd_seg_clear(h);
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
@@ -996,6 +998,7 @@ static int accuflux_impl(pfd_raster *h, int dtype, const void *data, bool by_row
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
+  if (h->gen) return pfd_gen_accuflux(h, dtype, data, by_row, nodata_i, nodata_f, has_nodata, direction, mask_invalid, out, memspace);
   switch (dtype) {
     case PFD_I32:
       return accuflux_t<i32>(h, data, by_row, (i32)nodata_i, has_nodata, direction, mask_invalid, out, memspace);
@@ -1029,6 +1032,7 @@ extern "C" int pfd_strahler(pfd_raster *h, const uint8_t *mask, uint8_t *out, in
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
+  if (h->gen) return pfd_gen_strahler(h, mask, out, memspace);
   PFDCHK(ensure_sweep_structure(h));
   InArg m;
   PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
@@ -1060,6 +1064,7 @@ static int basins_t(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 
 // labels from k distinct outlets (device arrays); fast path: LDS-tiled "first outlet downstream" query
 // (paths.hip; needs no cell ordering).  Rasters with cycles (and PFD_BASINS_LEVELS=1) go through the level engine.
 int pfd_basins_dev(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 ku, int id_size, void *out_dev) {
+  if (h->gen) return pfd_gen_basins(h, idx_dev, ids_dev, ku, id_size, out_dev);
   int tiled_ok = 0;
   if (!getenv("PFD_BASINS_LEVELS")) PFDCHK(pfd_basins_tiled(h, idx_dev, ids_dev, ku, id_size, out_dev, &tiled_ok));
   if (!tiled_ok) {
@@ -1135,6 +1140,7 @@ extern "C" int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, con
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
+  if (h->gen) return pfd_gen_hand(h, drain, elev_dtype, elevtn, out, memspace);
   PFDCHK(ensure_sweep_structure(h));
   InArg dr, el;
   PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
@@ -1333,6 +1339,7 @@ static size_t payload_bytes(int dtype) {
 extern "C" int pfd_main_upstream(pfd_raster *h, int dtype, const void *uparea, double upa_min, int idx_dtype,
                                  void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
+  if (h->gen) return pfd_gen_main_upstream(h, dtype, uparea, upa_min, idx_dtype, out, memspace);
   PFDCHK(pfd_require_whole(h, "pfd_main_upstream"));
   const size_t es = idx_bytes(idx_dtype), ps = payload_bytes(dtype);
   if (!uparea || !out || !es || !ps) {
@@ -1366,6 +1373,7 @@ extern "C" int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
+  if (h->gen) return pfd_gen_classic(h, idx_dtype, idxs_us_main, mask, out, memspace);
   PFDCHK(ensure_sweep_structure(h));
   InArg mu, m;
   PFDCHK(mu.bind(idxs_us_main, (size_t)h->n * es, memspace, h->stream));
@@ -1398,6 +1406,7 @@ extern "C" int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
+  if (h->gen) return pfd_gen_stream_distance(h, mask, real_length, step_lengths, out, memspace);
   PFDCHK(ensure_sweep_structure(h));
   InArg m, tab;
   PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
@@ -1443,6 +1452,7 @@ static int floodplains_t(pfd_raster *h, const u8 *stream, const float *hin, cons
 extern "C" int pfd_floodplains(pfd_raster *h, int elev_dtype, const void *elevtn, const uint8_t *is_stream,
                                const float *stream_h, int8_t *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, "floodplains"));
   if (!elevtn || !is_stream || !stream_h || !out || (elev_dtype != PFD_F32 && elev_dtype != PFD_F64)) {
     pfd_set_error("pfd_floodplains: bad arguments (elevation dtype code %d)", elev_dtype);
     return PFD_EINVAL;

@@ -118,6 +118,43 @@ def step_length_table(nrow, latlon=False, transform=IDENTITY):
     return tab
 
 
+def cell_step_lengths(idxs_ds, mv, ncol, latlon=False, transform=IDENTITY):
+    """float32 length of the step from every cell to its downstream cell for ARBITRARY links (general idxs_ds
+    graphs): ``gis_utils.distance`` (reference gis_utils.py:452-486) depends on (r0 + r1, |dr|, |dc|) only, so
+    it is evaluated once per distinct triple — scalar by scalar, in the reference's expression order — and
+    looked up per cell.  0 for pits / nodata (never read)."""
+    import math
+
+    ds = np.asarray(idxs_ds)
+    n = ds.size
+    idx0 = np.arange(n, dtype=np.int64)
+    d64 = np.where(ds == mv, idx0, ds.astype(np.int64))
+    r0, r1 = idx0 // ncol, d64 // ncol
+    dr, dc = np.abs(r1 - r0), np.abs(d64 % ncol - idx0 % ncol)
+    key = ((r0 + r1) << 42) | (dr << 21) | dc
+    uk, inv = np.unique(key, return_inverse=True)
+    xres, yres, north = transform[0], transform[4], transform[5]
+    vals = np.zeros(uk.size, np.float32)
+    for i, k in enumerate(uk.tolist()):
+        s, kdr, kdc = k >> 42, (k >> 21) & 0x1FFFFF, k & 0x1FFFFF
+        if latlon:
+            lat = north + s / 2.0 * yres
+            dy = 0.0 if kdr == 0 else degree_metres_y(lat) * yres
+            dx = 0.0 if kdc == 0 else degree_metres_x(lat) * xres
+        else:
+            dy, dx = xres, yres
+        vals[i] = np.float32(math.hypot(dy * kdr, dx * kdc))
+    return vals[inv]
+
+
+def transform_from_bounds(west, south, east, north, width, height):
+    """Affine transform of a raster given its bounds and size; reference gis_utils.py:162-170."""
+    from ._affine import get_affine
+
+    A = get_affine()
+    return A.translation(west, north) * A.scale((east - west) / width, (south - north) / height)
+
+
 _OFFSETS = {"center": (0.5, 0.5), "ul": (0, 0), "ur": (1, 0), "ll": (0, 1), "lr": (1, 1)}
 
 

@@ -26,6 +26,7 @@ import numpy as np
 
 from . import _hip
 from . import gis
+from . import nextxy as core_nextxy
 from ._affine import get_affine
 
 Affine = get_affine()
@@ -37,7 +38,7 @@ D8_DS = np.array([[32, 64, 128], [16, 0, 1], [8, 4, 2]], dtype=np.uint8)
 D8_MV = np.uint8(247)
 D8_PV = np.array([0, 255], dtype=np.uint8)
 D8_ALL = np.array([32, 64, 128, 16, 0, 1, 8, 4, 2, 247, 255], dtype=np.uint8)
-FTYPES = ("d8", "ldd", "nextxy")  # names known to the reference; "d8" and "ldd" run on the GPU
+FTYPES = ("d8", "ldd", "nextxy")  # "d8" / "ldd": the D8 engines; "nextxy" and non-neighbour idxs_ds: the general engine
 # LDD (PCRaster keypad codes, reference pyflwdir/core_ldd.py:11-17) is the same 8-neighbour scheme with
 # other labels: a 256-entry table turns it into D8 on the way in (7 8 9 / 4 5 6 / 1 2 3; 5 = pit,
 # 255 = nodata) and back on the way out; values outside the alphabet map to an invalid D8 code
@@ -82,11 +83,13 @@ def ldd_isvalid(flwdir) -> bool:
 
 def _infer_ftype(flwdir):
     """reference pyflwdir/pyflwdir.py:39-48: the first type whose alphabet holds every value, in
-    the reference's order (d8, ldd; nextxy rasters cannot be inferred here)."""
+    the reference's order (d8, ldd, nextxy)."""
     if d8_isvalid(flwdir):
         return "d8"
     if ldd_isvalid(flwdir):
         return "ldd"
+    if core_nextxy.isvalid(flwdir):
+        return "nextxy"
     raise ValueError("The flow direction type could not be inferred.")
 
 
@@ -116,8 +119,22 @@ def from_array(data, ftype="infer", check_ftype=True, mask=None, transform=gis.I
         check_ftype = False
     if ftype not in FTYPES:
         raise ValueError(f'Unknown flow direction type: "{ftype}", select from {", ".join(FTYPES)}')
-    if ftype == "nextxy":
-        raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path; "d8" and "ldd" are implemented')
+    if ftype == "nextxy":  # arbitrary links: the general idxs_ds engine (reference pyflwdir/pyflwdir.py:170-205)
+        if check_ftype and not core_nextxy.isvalid(data):
+            raise ValueError(f'The flow direction data with type "{ftype}" is invalid.')
+        nextx, nexty = core_nextxy._split(data)
+        if nextx.ndim != 2:
+            raise ValueError("The FlwdirRaster should be 2 dimensional")
+        if mask is not None:
+            if mask.shape != np.asarray(data).shape:
+                raise ValueError('"mask" shape does not match with data shape')
+            data = np.where(mask != 0, data, core_nextxy.MV)
+            nextx, nexty = core_nextxy._split(data)
+        shape = nextx.shape
+        idxs_ds, idxs_pit, _ = core_nextxy.from_array((nextx, nexty), dtype=_get_idxs_dtype(shape[0] * shape[1]))
+        idxs_outlet = idxs_pit[np.isin(nextx.flat[idxs_pit], core_nextxy.PV)]
+        return FlwdirRaster(idxs_ds=idxs_ds, idxs_pit=idxs_pit, idxs_outlet=idxs_outlet, shape=shape, ftype=ftype,
+                            transform=transform, latlon=latlon, **kwargs)
     data = np.asarray(data)
     if data.ndim != 2:
         raise ValueError("The FlwdirRaster should be 2 dimensional")
@@ -155,21 +172,29 @@ class FlwdirRaster(object):
             raise ValueError(f"Invalid FlwdirRaster: size {idxs_ds.size}")
         if ftype not in FTYPES:
             raise ValueError(f'Unknown flow direction type: "{ftype}", select from {", ".join(FTYPES)}')
-        if ftype == "nextxy":
-            raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path; "d8" and "ldd" are implemented')
         if np.multiply(*np.array(shape, np.uint64)) != idxs_ds.size:
             raise ValueError(f"Invalid FlwdirRaster: shape {shape} does not match size {idxs_ds.size}")
         mv = self._mv_for(idxs_ds.dtype)
-        d8 = _d8_from_idxs_ds(idxs_ds.ravel(), tuple(shape), mv)
-        self._setup(d8, transform, latlon, cache, device)
+        d8 = None
+        if ftype != "nextxy":
+            try:
+                d8 = _d8_from_idxs_ds(idxs_ds.ravel(), tuple(shape), mv)
+            except ValueError:  # links outside the 8 neighbours (e.g. an upscaled network): general engine
+                d8 = None
+        if d8 is not None:
+            self._setup(d8, transform, latlon, cache, device)
+        else:
+            self._setup_general(idxs_ds.ravel(), tuple(shape), transform, latlon, cache, device)
         self.ftype = ftype
+        if self._d8 is None and ftype == "nextxy":
+            self.order_cells(method="sort")  # the reference's only ordering of NEXTXY rasters (pyflwdir.py:292-297)
         self._idxs_ds = idxs_ds.ravel()
         self._idx_dtype = idxs_ds.dtype
         self._mv = mv
         if idxs_pit is not None:
             self._pit = np.asarray(idxs_pit)
-        if idxs_outlet is not None:
-            self.idxs_outlet = np.asarray(idxs_outlet)
+        # (the reference stores what it is given: None when the object is built without outlets, pyflwdir.py:211-273)
+        self.idxs_outlet = None if idxs_outlet is None else np.asarray(idxs_outlet)
 
     @classmethod
     def _from_d8(cls, d8, transform=gis.IDENTITY, latlon=False, cache=True, device=0, **kwargs):
@@ -188,6 +213,25 @@ class FlwdirRaster(object):
         if dtype.kind == "u":
             return dtype.type(np.iinfo(dtype).max)
         return np.intp(-1)
+
+    def _setup_general(self, idxs_ds, shape, transform, latlon, cache, device):
+        """A graph with arbitrary links: the general idxs_ds engine of the library (csrc/general.hip)."""
+        self._d8 = None
+        self.shape = tuple(int(s) for s in shape)
+        self.size = int(idxs_ds.size)
+        self.device = device
+        self._idx_dtype = np.dtype(idxs_ds.dtype)
+        self._mv = self._mv_for(self._idx_dtype)
+        self.cache = cache
+        self._cached = dict()
+        self._idxs_ds = idxs_ds
+        self._pit = None
+        self._seq = None
+        self._nnodes = None
+        self._h = _hip.RasterHandle.general(idxs_ds, self.shape[0], self.shape[1], device=device)
+        self.idxs_outlet = self.idxs_pit
+        self.set_transform(transform, latlon)
+        self._order_nextxy = True  # (see __init__: NEXTXY rasters are ordered by rank before the first sweep)
 
     def _setup(self, d8, transform, latlon, cache, device):
         self._d8 = d8
@@ -249,9 +293,10 @@ class FlwdirRaster(object):
     @property
     def idxs_seq(self):
         """Linear indices of valid cells ordered from down- to upstream, in the exact order of
-        the reference's ``core.idxs_seq`` (pyflwdir/core.py:87-117)."""
+        the reference's ``core.idxs_seq`` (pyflwdir/core.py:87-117); NEXTXY rasters are ordered by rank like
+        in the reference (pyflwdir/pyflwdir.py:292-297)."""
         if self._seq is None:
-            self.order_cells(method="walk")
+            self.order_cells(method="walk" if self.ftype != "nextxy" else "sort")
         return self._seq
 
     @property
@@ -268,6 +313,8 @@ class FlwdirRaster(object):
     @property
     def mask(self):
         """Boolean array of valid cells (flattened like the reference, pyflwdir/flwdir.py:201-204)."""
+        if self._d8 is None:
+            return self.idxs_ds != self._mv
         return self._d8.ravel() != D8_MV
 
     @property
@@ -317,15 +364,18 @@ class FlwdirRaster(object):
         self.transform = transform
         self.latlon = latlon
 
-    def order_cells(self, method="walk"):
-        """Order cells from down- to upstream; reference pyflwdir/flwdir.py:231-250.  "walk"
-        reproduces the reference's breadth-first order exactly; "sort" orders by rank."""
+    def order_cells(self, method="sort"):
+        """Order cells from down- to upstream; reference pyflwdir/flwdir.py:231-250 (default "sort" like the
+        reference).  "walk" reproduces the reference's breadth-first order exactly on the GPU; "sort" is the
+        reference's own numpy expression over the GPU-computed ranks."""
         if method == "walk":
             self._seq = self._h.idxs_seq(self._idx_dtype)
         elif method == "sort":
             rnk = self._h.rank()
             n = int(np.sum(rnk >= 0))
             self._seq = np.argsort(rnk)[-n:].astype(self._idx_dtype)
+            if self._d8 is None:  # general graph: the sweeps follow this sequence (float sums depend on it)
+                self._h.set_idxs_seq(self._seq)
         else:
             raise ValueError(f'Invalid method {method}, select from ["walk", "sort"]')
         self._nnodes = self._seq.size
@@ -338,9 +388,18 @@ class FlwdirRaster(object):
         i64 = np.asarray(idxs1, dtype=np.int64)
         if np.any(i64 < 0) or np.any(i64 >= self.size):
             raise IndexError("idxs outside domain")
-        if np.any(self._d8.flat[i64] == D8_MV):
+        if np.any(~self.mask[i64]):
             raise ValueError("add_pits: indices must address valid (non-nodata) cells")
         self._h.add_pits(idxs1)
+        if self._d8 is None:  # general graph: the host mirror is idxs_ds itself
+            self._idxs_ds = self._idxs_ds.copy()
+            self._idxs_ds[i64] = i64.astype(self._idx_dtype)
+            self._pit = None
+            self._seq = None
+            self._nnodes = None
+            self._cached.clear()
+            self.idxs_outlet = self.idxs_pit
+            return
         self._d8 = self._d8.copy()
         self._d8.flat[idxs1] = 0
         self._idxs_ds = None
@@ -356,10 +415,13 @@ class FlwdirRaster(object):
         (core_d8.to_array / core_ldd.to_array re-encode ``idxs_ds``: every pit is written as the pit code)."""
         if ftype is None:
             ftype = self.ftype
-        if ftype not in ("d8", "ldd"):
-            if ftype in FTYPES:
-                raise NotImplementedError(f'ftype "{ftype}" is outside the MI355X hot path')
+        if ftype not in FTYPES:
             raise ValueError(f'ftype "{ftype}" unknown')
+        if ftype == "nextxy":  # core_nextxy.to_array, reference pyflwdir/core_nextxy.py:36-86
+            return core_nextxy.to_array(self.idxs_ds, self.shape, mv=self._mv)
+        if self._d8 is None:  # raises for links outside the 8 neighbours, like core_d8.to_array (core_d8.py:86-102)
+            d8 = _d8_from_idxs_ds(self.idxs_ds, self.shape, self._mv)
+            return d8 if ftype == "d8" else _D8_TO_LDD[d8]
         d8 = self._d8.copy()
         d8.flat[self.idxs_pit] = 0
         return d8 if ftype == "d8" else _D8_TO_LDD[d8]
@@ -429,7 +491,13 @@ class FlwdirRaster(object):
             raise ValueError(f'Unknown unit: {unit}, select from "m", "cell"')
         mask = self._check_data(mask, "mask", optional=True)
         m = None if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
-        tab = None if unit == "cell" else gis.step_length_table(self.shape[0], self.latlon, self.transform)
+        if unit == "cell":
+            tab = None
+        elif self._d8 is None:  # general graph: one step length per cell
+            tab = gis.cell_step_lengths(self.idxs_ds, self._mv, self.shape[1], self.latlon, self.transform)
+            return self._h.stream_distance(m, tab, per_cell=True).reshape(self.shape)
+        else:
+            tab = gis.step_length_table(self.shape[0], self.latlon, self.transform)
         return self._h.stream_distance(m, tab).reshape(self.shape)
 
     def main_upstream(self, uparea=None):
@@ -569,6 +637,8 @@ class FlwdirRaster(object):
         reference pyflwdir/pyflwdir.py:500-562, pyflwdir/flwdir.py:404-463, core.snap core.py:440-480.
         The device path serves direction="down" with unit="cell" (what ``basins(streams=...)`` and
         ``add_pits(streams=...)`` use); returns (idxs, dists)."""
+        if self._d8 is None:
+            raise NotImplementedError("snap is not available on a general idxs_ds graph on the HIP path")
         if direction != "down" or str(unit).lower() != "cell":
             raise NotImplementedError("snap: the HIP path implements direction='down', unit='cell'")
         if (xy is not None and idxs is not None) or (xy is None and idxs is None):
