@@ -250,6 +250,18 @@ def gen_general():
         flw2 = pyflwdir.FlwdirRaster(idxs_ds=ds2, shape=flw8.shape, ftype="d8", transform=A, latlon=ent["latlon"], cache=False)
         ops(name + "_ds2", flw2, elv)
         store[f"out_{name}_ds2_to_nextxy"] = flw2.to_array("nextxy")
+    # from_array(check_ftype=False) on values outside the D8 alphabet (decoded by core_d8.drdc, core_d8.py:20-37)
+    rng = np.random.default_rng(3)
+    for nm, vals in (("odd_nbr", [3, 5, 6, 7, 17, 33, 65, 127, 129, 200, 4, 4, 4, 2, 8, 1, 16, 64, 247, 0]),
+                     ("odd_far", [9, 12, 15, 4, 4, 2, 8, 1, 16, 64, 32, 128, 247, 0, 255])):
+        d = rng.choice(np.array(vals, np.uint8), size=(40, 50))
+        d[-1, :] = 0
+        store[f"in_{nm}"] = d
+        f = pyflwdir.from_array(d, ftype="d8", check_ftype=False, cache=False)
+        store[f"out_{nm}_idxs_ds"] = f.idxs_ds
+        store[f"out_{nm}_idxs_pit"] = f.idxs_pit
+        store[f"out_{nm}_idxs_outlet"] = f.idxs_outlet
+        store[f"out_{nm}_rank"] = f.rank
     store["dump_keys"] = np.array(",".join(sorted(str(k) for k in flw2._dict.keys())))
     np.savez_compressed(os.path.join(GOLD, "wide_general.npz"), **store)
     print(f"[wide] general: {len(store)} arrays")

@@ -109,6 +109,56 @@ def _d8_from_idxs_ds(idxs_ds, shape, mv):
     return d8.reshape(shape)
 
 
+def _drdc_table():
+    """(dr, dc) of every uint8 value exactly as core_d8.drdc computes them (reference pyflwdir/core_d8.py:20-37,
+    including the values outside the D8 alphabet that ``check_ftype=False`` lets through: log2 arithmetic
+    truncated to int8, everything above 128 a pit)."""
+    dr = np.zeros(256, np.int64)
+    dc = np.zeros(256, np.int64)
+    for dd in range(256):
+        if dd <= 8:
+            if dd >= 2:
+                dr[dd], dc[dd] = 1, int(np.int8(2 - np.log2(dd)))
+            else:
+                dr[dd], dc[dd] = 0, dd
+        elif dd <= 128:
+            if dd == 16:
+                dr[dd], dc[dd] = 0, -1
+            else:
+                dr[dd], dc[dd] = -1, int(np.int8(np.log2(dd) - 6))
+    return dr, dc
+
+
+def _from_unchecked_d8(data, **kwargs):
+    """``from_array(ftype="d8", check_ftype=False)`` on a raster holding values outside the D8 alphabet: the
+    reference decodes them with core_d8.drdc; values that decode to a neighbour are rewritten to that
+    neighbour's code (D8 engines), a raster with the -2 column offsets of the values 9..15 becomes a general
+    idxs_ds graph."""
+    dr, dc = _drdc_table()
+    flat = data.ravel()
+    present = np.unique(flat[flat != D8_MV])
+    if np.all(np.abs(dc[present]) <= 1):
+        lut = D8_DS[np.clip(dr + 1, 0, 2), np.clip(dc + 1, 0, 2)].astype(np.uint8)
+        lut[D8_MV] = D8_MV
+        lut[255] = 255
+        flw = FlwdirRaster._from_d8(np.ascontiguousarray(lut[data]), **kwargs)
+        pits = flw.idxs_pit  # outlets = pits whose ORIGINAL value is a pit code (pyflwdir.py:193)
+        flw.idxs_outlet = pits[np.isin(flat[pits], D8_PV)]
+        return flw
+    nrow, ncol = data.shape
+    n = flat.size
+    idx0 = np.arange(n, dtype=np.int64)
+    r_ds, c_ds = idx0 // ncol + dr[flat], idx0 % ncol + dc[flat]
+    outside = (r_ds >= nrow) | (c_ds >= ncol) | (r_ds < 0) | (c_ds < 0)
+    idx_ds = c_ds + r_ds * ncol
+    pit = ((dr[flat] == 0) & (dc[flat] == 0)) | outside | (flat[np.where(outside, 0, idx_ds)] == D8_MV)
+    dtype = _get_idxs_dtype(n)
+    ds = np.where(flat == D8_MV, -1, np.where(pit, idx0, idx_ds)).astype(dtype)
+    pits = idx0[(flat != D8_MV) & pit].astype(dtype)
+    outl = pits[np.isin(flat[pits], D8_PV)]
+    return FlwdirRaster(idxs_ds=ds, shape=data.shape, ftype="d8", idxs_pit=pits, idxs_outlet=outl, **kwargs)
+
+
 def from_array(data, ftype="infer", check_ftype=True, mask=None, transform=gis.IDENTITY, latlon=False, **kwargs):
     """Flow direction raster parsed to an actionable (device-resident) format.
 
@@ -146,8 +196,11 @@ def from_array(data, ftype="infer", check_ftype=True, mask=None, transform=gis.I
         if mask.shape != data.shape:
             raise ValueError('"mask" shape does not match with data shape')
         data = np.where(mask != 0, data, D8_MV)
-    flw = FlwdirRaster._from_d8(np.ascontiguousarray(data, dtype=np.uint8), transform=transform, latlon=latlon,
-                                **kwargs)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    if ftype == "d8" and not check_ftype and not d8_isvalid(data):
+        flw = _from_unchecked_d8(data, transform=transform, latlon=latlon, **kwargs)
+    else:
+        flw = FlwdirRaster._from_d8(data, transform=transform, latlon=latlon, **kwargs)
     flw.ftype = ftype
     return flw
 

@@ -109,3 +109,21 @@ def test_dump_load_d8(gpu_lib, tmp_path):
     assert back.ftype == "d8" and back.shape == flw.shape
     assert np.array_equal(back.idxs_ds, flw.idxs_ds) and np.array_equal(back.to_array(), flw.to_array())
     assert np.array_equal(back.upstream_area(), flw.upstream_area()) and back.nnodes == flw.nnodes
+
+
+@pytest.mark.parametrize("nm", ["odd_nbr", "odd_far"])
+def test_unchecked_d8_values(gpu_lib, nm):
+    """from_array(ftype="d8", check_ftype=False) decodes values outside the alphabet like core_d8.drdc
+    (reference pyflwdir/core_d8.py:20-37): neighbour offsets on the D8 engines, the -2 column offsets of the
+    values 9..15 as a general graph."""
+    import pyflwdir_amd as pyflwdir
+
+    W = np.load(os.path.join(GOLD, "wide_general.npz"))
+    d = W[f"in_{nm}"]
+    with pytest.raises(ValueError, match="is invalid"):
+        pyflwdir.from_array(d, ftype="d8")
+    f = pyflwdir.from_array(d, ftype="d8", check_ftype=False, cache=False)
+    for key in ("idxs_ds", "idxs_pit", "idxs_outlet", "rank"):
+        exp = W[f"out_{nm}_{key}"]
+        got = getattr(f, key)
+        assert got.dtype == exp.dtype and np.array_equal(got, exp), (nm, key)
