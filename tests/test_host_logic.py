@@ -44,8 +44,10 @@ def test_from_array_argument_errors():
         raster.from_array(good, ftype="xyz")
     with pytest.raises(ValueError, match='type "ldd" is invalid'):
         raster.from_array(good, ftype="ldd")  # D8 values are not LDD values
-    with pytest.raises(NotImplementedError):
-        raster.from_array(np.zeros((2, 2, 2), np.int32), ftype="nextxy")
+    with pytest.raises(ValueError, match='type "nextxy" is invalid'):  # (negative values that are no pit / nodata code)
+        raster.from_array(np.full((2, 2, 2), -3, np.int32), ftype="nextxy")
+    with pytest.raises(TypeError, match="NEXTXY flwdir data not understood"):
+        raster.from_array(np.zeros((2, 2), np.int32), ftype="nextxy", check_ftype=False)
 
 
 def test_d8_from_idxs_ds_roundtrip(oracle):
@@ -157,3 +159,25 @@ def test_ldd_codec_tables():
     assert R._infer_ftype(d8) == "d8"  # D8 first, like the reference's FTYPES order
     with pytest.raises(ValueError, match="could not be inferred"):
         R._infer_ftype(np.array([[11, 12]], np.uint8))
+
+
+def test_nextxy_codec_host():
+    """core_nextxy from_array / to_array / isvalid restated in numpy (pyflwdir_amd/nextxy.py) on a hand-made
+    raster: 1-based (x, y) targets, -9 river mouth, -10 inland pit, -9999 nodata, a target off the raster and a
+    target on a nodata cell both become pits (reference pyflwdir/core_nextxy.py:41-68)."""
+    from pyflwdir_amd import nextxy
+
+    mv = -9999
+    nextx = np.array([[2, 3, -9], [1, mv, 3], [9, 2, -10]], np.int32)
+    nexty = np.array([[1, 1, -9], [1, mv, 1], [9, 2, -10]], np.int32)
+    assert nextxy.isvalid((nextx, nexty)) and nextxy.isvalid(np.stack([nextx, nexty]))
+    ds, pits, n = nextxy.from_array((nextx, nexty), dtype=np.int32)
+    # cell 6 points at (9, 9): outside -> pit; cell 7 points at (2, 2) = cell 4 = nodata -> pit
+    assert ds.tolist() == [1, 2, 2, 0, -1, 2, 6, 7, 8] and pits.tolist() == [2, 6, 7, 8] and n == 8
+    back = nextxy.to_array(ds, (3, 3), mv=-1)
+    assert back.shape == (2, 3, 3) and back.dtype == np.int32
+    assert back[0].ravel().tolist() == [2, 3, -9, 1, mv, 3, -9, -9, -9]
+    assert back[1].ravel().tolist() == [1, 1, -9, 1, mv, 1, -9, -9, -9]
+    dsu = nextxy.from_array((nextx, nexty), dtype=np.uint32)[0]
+    assert dsu[4] == np.uint32(4294967295)
+    assert not nextxy.isvalid(np.zeros((3, 3), np.int32))
