@@ -62,7 +62,26 @@ size_t size_class(size_t bytes) {
 const size_t IDLE_CAP = (size_t)96 << 30;  // keep at most 96 GiB of idle blocks per process
 }  // namespace
 
+// debugging aid: PFD_POISON=<byte> fills every block handed out with that byte (synchronously), which turns a
+// read of memory the caller never wrote into a reproducible failure instead of a sporadic one
+static int poison_byte() {
+  static const int v = [] {
+    const char *e = getenv("PFD_POISON");
+    return e ? (int)strtol(e, nullptr, 0) & 0xff : -1;
+  }();
+  return v;
+}
+static int pfd_dmalloc_raw(void **p, size_t bytes);
 int pfd_dmalloc(void **p, size_t bytes) {
+  const int rc = pfd_dmalloc_raw(p, bytes);
+  if (rc == PFD_OK && poison_byte() >= 0) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(*p, poison_byte(), size_class(bytes));
+    (void)hipDeviceSynchronize();
+  }
+  return rc;
+}
+static int pfd_dmalloc_raw(void **p, size_t bytes) {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   const size_t cls = size_class(bytes);
@@ -94,8 +113,18 @@ int pfd_dmalloc(void **p, size_t bytes) {
   return PFD_OK;
 }
 
+// The stream of the API call in progress on this thread (set by pfd_check_handle_lazy).  A block is only
+// recycled (or returned to the driver) once that stream is idle: work that still reads or writes it may be in
+// flight when a temporary is released in the middle of an asynchronous sequence (a re-used rocprim scratch
+// buffer, a DevBuf re-allocated for the next step), and the next owner may be another handle's stream, which is
+// not ordered behind this one.  The wait costs a few microseconds on an idle stream.
+static thread_local hipStream_t g_cur_stream = nullptr;
+static thread_local bool g_have_stream = false;
+
 void pfd_dfree(void *p) {
   if (!p) return;
+  if (g_have_stream) (void)hipStreamSynchronize(g_cur_stream);
+  else (void)hipDeviceSynchronize();
   DevCache &c = cache();
   std::lock_guard<std::mutex> g(c.mu);
   auto it = c.live.find(p);
@@ -213,6 +242,8 @@ int pfd_check_handle_lazy(pfd_raster *h) {
     return PFD_EINVAL;
   }
   HIPCHK(hipSetDevice(h->device));
+  g_cur_stream = h->stream;
+  g_have_stream = true;
   return PFD_OK;
 }
 int pfd_check_handle(pfd_raster *h) {
@@ -238,7 +269,10 @@ static void free_handle(pfd_raster *h) {
   pfd_free_general(h);
   pfd_dfree(h->pits);
   pfd_dfree(h->ctrl);
-  if (h->stream) release_stream(h->device, h->stream);
+  if (h->stream) {
+    if (g_have_stream && g_cur_stream == h->stream) g_have_stream = false;
+    release_stream(h->device, h->stream);
+  }
   delete h;
 }
 
@@ -252,6 +286,7 @@ int pfd_handle_alloc(i64 nrow, i64 ncol, int device, pfd_raster **out) {
   h->own_rows = nrow;
   h->geo = make_geo(nrow, ncol);
   int rc = acquire_stream(device, &h->stream);
+  if (rc == PFD_OK) g_cur_stream = h->stream, g_have_stream = true;
   if (rc == PFD_OK) rc = pfd_dmalloc((void **)&h->ncode, (size_t)h->n + 64);
   if (rc == PFD_OK) rc = pfd_dmalloc((void **)&h->ctrl, 64 * sizeof(u64));
   if (rc != PFD_OK) {
@@ -309,6 +344,7 @@ static int raster_create_impl(const uint8_t *d8, int64_t own_rows, int64_t ncol,
   int rc = PFD_OK;
   do {
     if ((rc = acquire_stream(device, &h->stream)) != PFD_OK) break;
+    g_cur_stream = h->stream, g_have_stream = true;
     if ((rc = pfd_dmalloc((void **)&h->ncode, (size_t)h->n + 64)) != PFD_OK) break;  // +slack: dword halo loads
     if ((rc = pfd_dmalloc((void **)&h->ctrl, 64 * sizeof(u64))) != PFD_OK) break;
     h->bytes_held = (size_t)h->n + 64 * sizeof(u64);

@@ -20,6 +20,9 @@
 // parent's ("post" slot), so that the fold stays a flat left-to-right scan with the reference's exact
 // operand order.
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 #define XT 64            // tile edge
@@ -54,3 +57,14 @@ struct ExactPlan {
 // block, more than 2^32 - 2 cells)
 int pfd_ensure_xplan(pfd_raster *h);
 void pfd_free_xplan(pfd_raster *h);
+
+// debugging aid (env PFD_XDEBUG): synchronise after a step and name it, so that a GPU memory fault points at its kernel
+#define XDBG(h, what)                                                          \
+  do {                                                                         \
+    const char *xd_ = getenv("PFD_XDEBUG");                                    \
+    if (xd_ && (xd_[0] == '1' || (xd_[0] == 'p') == (what[0] == 'k'))) {       \
+      const hipError_t e_ = hipStreamSynchronize((h)->stream);                 \
+      fprintf(stderr, "[xdbg] %s: %s\n", what, hipGetErrorString(e_));          \
+      fflush(stderr);                                                          \
+    }                                                                          \
+  } while (0)

@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
   __syncthreads();
   u32 begin = 0, end = s_n;
   int s = 0;
+  __syncthreads();  // every thread has read s_n before the first step appends to the list
   // (off[0] = 0 already)
   while (end > begin && s < XCAP) {
     if (tid == 0) off[s + 1] = (uint16_t)end;
@@ -356,6 +357,26 @@ __global__ void k_plan_pick(const u32 *__restrict__ S, const u32 *__restrict__ i
   if (t < k) out[t] = S[idx[t]];
 }
 
+// debugging aid (env PFD_XPLAN_DIGEST): 64-bit sum of a device array after a build step, printed to stderr —
+// two builds of the same raster must print identical lines (tools/plan_determinism.py)
+__global__ void __launch_bounds__(256) k_digest(const u32 *__restrict__ v, u64 nwords, unsigned long long *__restrict__ res) {
+  unsigned long long s = 0;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (u64)gridDim.x * 256) s += (unsigned long long)v[i] * (i % 1000003ull + 1ull);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(res, s);
+}
+static void xdigest(pfd_raster *h, const char *name, const void *p, size_t bytes) {
+  if (!getenv("PFD_XPLAN_DIGEST") || !p) return;
+  unsigned long long *acc = nullptr, host = 0;
+  (void)hipStreamSynchronize(h->stream);
+  if (hipMalloc((void **)&acc, 8) != hipSuccess) return;
+  (void)hipMemset(acc, 0, 8);
+  k_digest<<<2048, 256>>>((const u32 *)p, (u64)(bytes / 4), acc);
+  (void)hipMemcpy(&host, acc, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(acc);
+  fprintf(stderr, "[xdigest] %-10s %016llx\n", name, host);
+}
+
 void pfd_free_xplan(pfd_raster *h) {
   ExactPlan *p = (ExactPlan *)h->xplan;
   if (p) {
@@ -418,6 +439,12 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if ((rc = pfd_dmalloc((void **)&p->toff, ntiles * XOFF * sizeof(uint16_t))) != PFD_OK) return fail(rc);
   k_plan_tile<<<dim3(ntc, ntr), 256, 0, h->stream>>>(h->ncode, (u32)h->nrow, (u32)h->ncol, ntc, p->lh, p->kids, p->tord,
                                                      p->toff);
+  XDBG(h, "k_plan_tile");
+  xdigest(h, "upa", upa.p, (size_t)n * 4);
+  xdigest(h, "ncode", h->ncode, (size_t)n);
+  xdigest(h, "lh", p->lh, (size_t)n);
+  xdigest(h, "kids", p->kids, (size_t)n);
+  xdigest(h, "toff", p->toff, ntiles * XOFF * 2);
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   DevBuf hcode, seed, hinfo, hops, tailnum;
   if ((rc = hcode.alloc((size_t)n + 64)) != PFD_OK) return fail(rc);
@@ -426,6 +453,10 @@ int pfd_ensure_xplan(pfd_raster *h) {
   const u32 grid = cdiv_u32(n, 256);
   k_plan_heavy<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, p->lh, p->kids, upa.as<u32>(), hcode.as<u8>(),
                                             seed.as<u32>(), hinfo.as<uint16_t>());
+  XDBG(h, "k_plan_heavy");
+  xdigest(h, "hcode", hcode.p, (size_t)n);
+  xdigest(h, "seed", seed.p, (size_t)n * 4);
+  xdigest(h, "hinfo", hinfo.p, (size_t)n * 2);
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   if ((rc = hops.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = tailnum.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
@@ -433,6 +464,8 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if (!complete) return fail(PFD_OK);
   if ((rc = pfd_path_labels(h, hcode.as<u8>(), seed.as<u32>(), tailnum.as<u32>(), &complete)) != PFD_OK) return fail(rc);
   if (!complete) return fail(PFD_OK);
+  xdigest(h, "hops", hops.p, (size_t)n * 4);
+  xdigest(h, "tailnum", tailnum.p, (size_t)n * 4);
   hcode.alloc(0);
   // the chain ends, in raster order (selection by scan: no same-address atomics).  The list lives in the
   // upstream-area buffer, which is no longer needed; tidx_at takes over the seed buffer afterwards.
@@ -457,6 +490,7 @@ int pfd_ensure_xplan(pfd_raster *h) {
   const size_t nc1 = std::max<size_t>(nchain, 1);
   u32 *tidx_at = seed.as<u32>();
   if (nchain) k_plan_tidx<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(tails, nt32, tidx_at);
+  XDBG(h, "k_plan_tidx");
   // rounds of the chains (see k_plan_tails)
   if ((rc = dA.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = dB.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
@@ -465,8 +499,10 @@ int pfd_ensure_xplan(pfd_raster *h) {
   u32 *Dc = dA.as<u32>(), *Dn = dB.as<u32>(), *Pc = pA.as<u32>(), *Pn = pB.as<u32>();
   if (nchain) {
     k_plan_tails<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(h->ncode, h->geo, tails, nt32, tailnum.as<u32>(), tidx_at, Dc, Pc);
+  XDBG(h, "k_plan_tails");
     for (int r = 0; r < 6; ++r) {
       k_plan_depth_round<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(nt32, Dc, Pc, Dn, Pn);
+  XDBG(h, "k_plan_depth_round");
       std::swap(Dc, Dn);
       std::swap(Pc, Pn);
     }
@@ -476,6 +512,10 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if ((rc = rank_of.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
   k_plan_len<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at, n,
                                           len_of.as<u32>());
+  XDBG(h, "k_plan_len");
+  xdigest(h, "tails", tails, (size_t)nchain * 4);
+  xdigest(h, "depth", depth, (size_t)nchain * 4);
+  xdigest(h, "len_of", len_of.p, (size_t)nchain * 4);
   // chains in layout order: stable sort of the chain ends by round; chain id = rank in that order
   DevBuf ucell, w, cpos, clenp, ctail, cpad, pick, keys, keys2, iota, cj, adj;
   if ((rc = keys.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
@@ -490,6 +530,7 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if (hipMemsetAsync(cnt.p, 0, 64 * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
   if (nchain) {
     k_plan_keys<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(nt32, depth, keys.as<u32>(), iota.as<u32>(), cnt.as<u32>());
+  XDBG(h, "k_plan_keys");
     if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<u32>(), keys2.as<u32>(), iota.as<u32>(), cj.as<u32>(),
                                   (size_t)nchain, 0u, 5u, h->stream) != hipSuccess)
       return fail(PFD_EHIP);
@@ -501,6 +542,9 @@ int pfd_ensure_xplan(pfd_raster *h) {
   k_plan_chain_lens<<<cdiv_u32(nchain + 1, 256), 256, 0, h->stream>>>(cj.as<u32>(), nt32, tails, len_of.as<u32>(),
                                                                      rank_of.as<u32>(), ctail.as<u32>(), clenp.as<u32>(),
                                                                      cpos.as<u32>());
+  XDBG(h, "k_plan_chain_lens");
+  xdigest(h, "cj", cj.p, (size_t)nchain * 4);
+  xdigest(h, "ctail", ctail.p, (size_t)nchain * 4);
   if (rocprim::exclusive_scan(nullptr, tmp_bytes, cpos.as<u32>(), cpos.as<u32>(), 0u, (size_t)nchain + 1,
                               rocprim::plus<u32>(), h->stream) != hipSuccess)
     return fail(PFD_EHIP);
@@ -531,6 +575,7 @@ int pfd_ensure_xplan(pfd_raster *h) {
   k_plan_scatter<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at,
                                               rank_of.as<u32>(), cpos.as<u32>(), clenp.as<u32>(), n, ucell.as<u32>(),
                                               w.as<u32>());
+  XDBG(h, "k_plan_scatter");
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   // slot of a position = exclusive scan of the slots the positions before it need (in place)
   if (rocprim::exclusive_scan(nullptr, tmp_bytes, w.as<u32>(), w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
@@ -543,6 +588,7 @@ int pfd_ensure_xplan(pfd_raster *h) {
   // padded chain starts: exclusive scan of the padded chain lengths; round offsets = starts of their first chains
   k_plan_chain_len<<<cdiv_u32(nchain + 1, 256), 256, 0, h->stream>>>(cpos.as<u32>(), clenp.as<u32>(), w.as<u32>(),
                                                                     (u32)nchain, cpad.as<u32>());
+  XDBG(h, "k_plan_chain_len");
   if (rocprim::exclusive_scan(nullptr, tmp_bytes, cpad.as<u32>(), cpad.as<u32>(), 0u, (size_t)nchain + 1,
                               rocprim::plus<u32>(), h->stream) != hipSuccess)
     return fail(PFD_EHIP);
@@ -555,6 +601,7 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if ((rc = pick.alloc(2 * 33 * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemcpyAsync(pick.p, pidx, sizeof(pidx), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(PFD_EHIP);
   k_plan_pick<<<1, 64, 0, h->stream>>>(cpad.as<u32>(), pick.as<u32>(), 33, pick.as<u32>() + 33);
+  XDBG(h, "k_plan_pick");
   if (hipMemcpyAsync(pval, pick.as<u32>() + 33, sizeof(pval), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
     return fail(PFD_EHIP);
@@ -576,10 +623,18 @@ int pfd_ensure_xplan(pfd_raster *h) {
     k_plan_chains<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(cpos.as<u32>(), clenp.as<u32>(), ctail.as<u32>(),
                                                                 w.as<u32>(), cpad.as<u32>(), hinfo.as<uint16_t>(),
                                                                 (u32)nchain, p->cstart, p->clen, adj.as<u32>());
+  XDBG(h, "k_plan_chains");
     k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<u32>(), w.as<u32>(), hinfo.as<uint16_t>(),
                                                               tailnum.as<u32>(), tidx_at, rank_of.as<u32>(), adj.as<u32>(), h->geo,
                                                               (u32)npos,
                                                               p->scell, p->sinfo, p->spost);
+  XDBG(h, "k_plan_expand");
+  xdigest(h, "ucell", ucell.p, (size_t)npos * 4);
+  xdigest(h, "scell", p->scell, (size_t)p->nslot * 4);
+  xdigest(h, "sinfo", p->sinfo, (size_t)p->nslot * 2);
+  xdigest(h, "spost", p->spost, (size_t)(p->nslot / 32) * 4);
+  xdigest(h, "cstart", p->cstart, (size_t)nchain * 4);
+  xdigest(h, "clen", p->clen, (size_t)nchain * 4);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(PFD_EHIP);
   p->bytes = 2 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)p->nslot / 8 + (size_t)nchain * 8;

@@ -242,6 +242,7 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
   XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff};
   k_xtile_up<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a);
   KCHK();
+  XDBG(h, "tile_up");
   DevBuf E, R;
   PFDCHK(E.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(Elem) + 64));
   PFDCHK(R.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(V) + 64));
@@ -250,9 +251,12 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
     if (c1 == c0) continue;
     k_xtrunk_pre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, E.as<Elem>());
+    XDBG(h, "pre");
     k_xtrunk_scan<Op><<<cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->spost, E.as<Elem>(),
                                                                    R.as<V>());
+    XDBG(h, "scan");
     k_xtrunk_scatter<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, R.as<V>());
+    XDBG(h, "scatter");
     launches += 3;
   }
   KCHK();
