@@ -14,7 +14,9 @@
 //           round: a parallel pre-pass gathers, per layout slot, everything that does not depend on the
 //           chain itself (own payload + light upstream cells, already final); one
 //           LANE per chain then folds the slots serially (running value in a register, loads software-
-//           pipelined); a parallel scatter writes the results back to the raster.
+//           pipelined) — except for the few chains of XLONG slots or more (main stems), which get a WAVE
+//           each: 64 lanes stream the slots through LDS, one lane folds them from there, so that the
+//           fold runs at LDS instead of HBM latency; a parallel scatter writes the results back.
 //
 // An upstream cell that the serial loop adds AFTER the heavy one gets a slot of its own behind its
 // parent's ("post" slot), so that the fold stays a flat left-to-right scan with the reference's exact
@@ -35,6 +37,7 @@
 // 12-14 number of post slots that follow, 15 = this is a post slot (scell = the upstream cell it carries)
 #define XS_POST 0x8000u
 #define XC_LEN 0x1FFFFFFFu  // clen: length bits
+#define XLONG 512u          // a chain of at least this many slots is folded by a whole wave (see k_xtrunk_scan)
 
 struct ExactPlan {
   u32 ntr = 0, ntc = 0;
@@ -47,6 +50,9 @@ struct ExactPlan {
   u32 *spost = nullptr;   // [nslot / 32 + 4] bit s = slot s is a post slot (what the serial fold needs of sinfo)
   u32 *cstart = nullptr;  // [nchain] first slot of the chain (a multiple of 4: chains are padded)
   u32 *clen = nullptr;    // [nchain] slots in the chain | post slots behind its last cell << 29
+  u32 *longc = nullptr;   // [nlong] ids of the chains of >= XLONG slots, ascending (= by round)
+  i64 nlong = 0;
+  i64 b_long[33] = {0};   // long chains of round b = longc[b_long[b] .. b_long[b+1])
   i64 nslot = 0, nchain = 0, ntrunk = 0;
   i64 b_chain[33] = {0};  // chains of round b = [b_chain[b], b_chain[b+1])
   i64 b_slot[33] = {0};   // slots  of round b = [b_slot[b],  b_slot[b+1])

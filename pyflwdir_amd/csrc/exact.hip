@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -389,6 +390,7 @@ void pfd_free_xplan(pfd_raster *h) {
     pfd_dfree(p->spost);
     pfd_dfree(p->cstart);
     pfd_dfree(p->clen);
+    pfd_dfree(p->longc);
     h->bytes_held -= std::min(h->bytes_held, p->bytes);
     delete p;
   }
@@ -635,6 +637,27 @@ int pfd_ensure_xplan(pfd_raster *h) {
   xdigest(h, "spost", p->spost, (size_t)(p->nslot / 32) * 4);
   xdigest(h, "cstart", p->cstart, (size_t)nchain * 4);
   xdigest(h, "clen", p->clen, (size_t)nchain * 4);
+  }
+  // the long chains (one wave each in the sweeps): their ids in layout order, offsets per round
+  if (nchain) {
+    const size_t cap = (size_t)p->nslot / XLONG + 1;
+    if ((rc = pfd_dmalloc((void **)&p->longc, cap * sizeof(u32))) != PFD_OK) return fail(rc);
+    rocprim::counting_iterator<u32> ids(0u);
+    auto flags = rocprim::make_transform_iterator(p->clen, [] __device__(u32 cl) { return (cl & XC_LEN) >= XLONG; });
+    if (rocprim::select(nullptr, tmp_bytes, ids, flags, p->longc, cnt.as<u32>(), (size_t)nchain, h->stream) != hipSuccess)
+      return fail(PFD_EHIP);
+    if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
+    if (rocprim::select(tmp.p, tmp_bytes, ids, flags, p->longc, cnt.as<u32>(), (size_t)nchain, h->stream) != hipSuccess)
+      return fail(PFD_EHIP);
+    u32 nl = 0;
+    if (hipMemcpyAsync(&nl, cnt.p, sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+      return fail(PFD_EHIP);
+    p->nlong = nl;
+    std::vector<u32> lc(nl);
+    if (nl && hipMemcpy(lc.data(), p->longc, (size_t)nl * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return fail(PFD_EHIP);
+    for (int b = 0; b <= 32; ++b)
+      p->b_long[b] = (i64)(std::lower_bound(lc.begin(), lc.end(), (u32)std::min<i64>(p->b_chain[b], 0xFFFFFFFFll)) - lc.begin());
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(PFD_EHIP);
   p->bytes = 2 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)p->nslot / 8 + (size_t)nchain * 8;

@@ -16,6 +16,8 @@
 //   DElem dpre(x, code)               everything apply() reads from memory, gathered per cell
 //   V droot(DElem) / V dfold(DElem, V pv);  V top(p);  void store(x, V);  V dnodata(x) value of a nodata cell
 #pragma once
+#include <type_traits>
+
 #include "exact.h"
 
 struct XTileArgs {
@@ -133,18 +135,117 @@ __device__ __forceinline__ u32 xpost_bits(const u32 *__restrict__ spost, u32 s) 
   return (u32)((((u64)w1 << 32) | (u64)w0) >> (s & 31u));
 }
 
+// The first `nlong` workgroups take one LONG chain each (ids in longc): the wave streams the chain through LDS,
+// 64 groups of 4 slots per block (the next block's loads are in flight during the fold), lane 0 folds the block
+// from LDS and the wave stores the results.  A lane of its own would run at one HBM round trip per 48 slots.
 template <class Op>
 __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
-                                                    u32 c0, u32 c1, const u32 *__restrict__ spost,
+                                                    u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
+                                                    const u32 *__restrict__ spost,
                                                     const typename Op::Elem *__restrict__ E,
                                                     typename Op::V *__restrict__ R) {
   typedef typename Op::Elem Elem;
   typedef typename Op::V V;
   constexpr int G = XBlk<Elem>::G, XB = 4 * G;
-  const u32 c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x < nlong) {
+    __shared__ XVec4<Elem> sE[64];
+    __shared__ XVec4<V> sR[64];
+    __shared__ u32 sB[64];
+    const u32 lane = threadIdx.x;
+    const u32 cc = longc[blockIdx.x];
+    const u32 s0 = cstart[cc];
+    const u32 ng = ((clen[cc] & XC_LEN) + 3u) >> 2;
+    const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
+    XVec4<V> *R4 = (XVec4<V> *)R + (s0 >> 2);
+    auto gload = [&](u32 gi, XVec4<Elem> &e, u32 &bits) {
+      const u32 gg = gi < ng ? gi : ng - 1u;
+      e = E4[gg];
+      bits = xpost_bits(spost, s0 + 4u * gg) & 0xFu;
+    };
+    XVec4<Elem> cur;
+    u32 cb;
+    gload(lane, cur, cb);
+    V t = V();
+    for (u32 g0 = 0; g0 < ng; g0 += 64u) {
+      sE[lane] = cur;
+      sB[lane] = cb;
+      gload(g0 + 64u + lane, cur, cb);
+      __syncthreads();
+      const u32 cnt = ng - g0 < 64u ? ng - g0 : 64u;
+      // exact fold of the groups [q0, cnt) of the block by lane 0, from the running value tt
+      auto exact = [&](u32 q0, V tt) {
+        for (u32 gq = q0; gq < cnt; ++gq) {
+          const XVec4<Elem> e = sE[gq];
+          const u32 bits = sB[gq];
+          XVec4<V> r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const V f = op.fold(tt, e.v[j], ((bits >> j) & 1u) != 0);
+            tt = (j == 0 && g0 + gq == 0) ? op.first(e.v[j]) : f;
+            r.v[j] = tt;
+          }
+          sR[gq] = r;
+        }
+        return tt;
+      };
+      if (!Op::FAST) {
+        if (lane == 0) t = exact(0, t);
+      } else {
+        // speculative: lane 0 folds without the operation's special cases (one dependent instruction per slot),
+        // then every lane checks its own group; a block with a special operand is redone exactly
+        V tt = t;
+        const u32 q0 = g0 == 0 ? 1u : 0u;  // (the chain's first group holds the head: always exact)
+        if (lane == 0) {
+          if (q0) {
+            const XVec4<Elem> e = sE[0];
+            const u32 bits = sB[0];
+            XVec4<V> r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const V f = op.fold(tt, e.v[j], ((bits >> j) & 1u) != 0);
+              tt = j == 0 ? op.first(e.v[j]) : f;
+              r.v[j] = tt;
+            }
+            sR[0] = r;
+          }
+#pragma unroll 4
+          for (u32 gq = q0; gq < cnt; ++gq) {
+            const XVec4<Elem> e = sE[gq];
+            XVec4<V> r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              tt = op.fold_fast(tt, e.v[j]);
+              r.v[j] = tt;
+            }
+            sR[gq] = r;
+          }
+        }
+        __syncthreads();
+        bool bad = false;
+        if (lane >= q0 && lane < cnt) {
+          const XVec4<Elem> e = sE[lane];
+          const XVec4<V> r = sR[lane];
+          V prev = t;  // (lane 0: the value that entered the block)
+          if (lane) prev = sR[lane - 1u].v[3];
+          bad = op.special(prev, e.v[0]) | op.special(r.v[0], e.v[1]) | op.special(r.v[1], e.v[2]) |
+                op.special(r.v[2], e.v[3]);
+        }
+        if (__any((int)bad)) {
+          __syncthreads();
+          if (lane == 0) tt = exact(0, t);
+        }
+        t = tt;
+      }
+      __syncthreads();
+      if (g0 + lane < ng) R4[g0 + lane] = sR[lane];
+    }
+    return;
+  }
+  const u32 c = c0 + (blockIdx.x - nlong) * blockDim.x + threadIdx.x;
   const bool active = c < c1;
   const u32 s0 = active ? cstart[c] : 0u;
-  const u32 m = active ? (clen[c] & XC_LEN) : 0u;
+  u32 m = active ? (clen[c] & XC_LEN) : 0u;
+  if (m >= XLONG) m = 0;  // folded by a wave of its own (above)
   const u32 ng = (m + 3u) >> 2;  // groups of the chain
   const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
   XVec4<V> *R4 = (XVec4<V> *)R + (s0 >> 2);
@@ -252,8 +353,10 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
     if (c1 == c0) continue;
     k_xtrunk_pre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, E.as<Elem>());
     XDBG(h, "pre");
-    k_xtrunk_scan<Op><<<cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->spost, E.as<Elem>(),
-                                                                   R.as<V>());
+    const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
+    k_xtrunk_scan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
+                                                                        p->longc + p->b_long[b], nl, p->spost,
+                                                                        E.as<Elem>(), R.as<V>());
     XDBG(h, "scan");
     k_xtrunk_scatter<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, R.as<V>());
     XDBG(h, "scatter");
@@ -282,18 +385,115 @@ __global__ void __launch_bounds__(256) k_xtrunk_dpre(Op op, const u32 *__restric
 // of a later round (final), or the tail is a pit.
 template <class Op>
 __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
-                                                     u32 c0, u32 c1, const u32 *__restrict__ scell,
+                                                     u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
+                                                     const u32 *__restrict__ scell,
                                                      const u32 *__restrict__ spost, const u8 *__restrict__ ncode, Geo g,
                                                      const typename Op::DElem *__restrict__ E,
                                                      typename Op::V *__restrict__ R) {
   typedef typename Op::DElem Elem;
   typedef typename Op::V V;
   constexpr int G = XBlk<Elem>::G;
-  const u32 c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x < nlong) {  // a long chain: the whole wave (see k_xtrunk_scan), blocks of 64 groups from the top
+    __shared__ XVec4<Elem> sE[64];
+    __shared__ XVec4<V> sR[64];
+    __shared__ u32 sB[64];
+    __shared__ V sT;  // the running value that enters the block (lane 0 holds it)
+    const u32 lane = threadIdx.x;
+    const u32 cc = longc[blockIdx.x];
+    const u32 s0 = cstart[cc], cl = clen[cc];
+    const u32 m = cl & XC_LEN;
+    const u32 tail = m - 1u - (cl >> 29);
+    const u32 ng = (tail >> 2) + 1u;
+    const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
+    XVec4<V> *R4 = (XVec4<V> *)R + (s0 >> 2);
+    V t = V();
+    if (lane == 0) {
+      const u32 x = scell[s0 + tail];
+      const u32 code = ncode[x];
+      const Elem e = E[s0 + tail];
+      t = d8_is_dir(code) ? op.dfold(e, op.top(d8_down(g, x, code))) : op.droot(e);
+    }
+    auto gload = [&](i32 gi, XVec4<Elem> &e, u32 &bits) {
+      const u32 gg = gi > 0 ? (u32)gi : 0u;
+      e = E4[gg];
+      bits = xpost_bits(spost, s0 + 4u * gg) & 0xFu;
+    };
+    XVec4<Elem> cur;
+    u32 cb;
+    i32 lo = (i32)ng - 64;
+    gload(lo + (i32)lane, cur, cb);
+    for (; lo > -64; lo -= 64) {
+      sE[lane] = cur;
+      {
+        // post slots and the slots from the tail on do not change the running value
+        const i32 fb = (i32)tail - 4 * (lo + (i32)lane);  // group-relative slot of the tail
+        sB[lane] = fb < 4 ? (cb | (fb <= 0 ? 0xFu : (~((1u << fb) - 1u) & 0xFu))) : cb;
+      }
+      gload(lo - 64 + (i32)lane, cur, cb);
+      if (lane == 0) sT = t;
+      __syncthreads();
+      const int lmin = lo < 0 ? -lo : 0;
+      auto exact = [&](V tt) {
+        for (int l = 63; l >= lmin; --l) {
+          const XVec4<Elem> e = sE[l];
+          const u32 skip = sB[l];
+          XVec4<V> r;
+#pragma unroll
+          for (int j = 3; j >= 0; --j) {
+            const V f = op.dfold(e.v[j], tt);
+            tt = ((skip >> j) & 1u) ? tt : f;
+            r.v[j] = tt;
+          }
+          sR[l] = r;
+        }
+        return tt;
+      };
+      if (!Op::FAST) {
+        if (lane == 0) t = exact(t);
+      } else {
+        V tt = t;
+        if (lane == 0) {
+#pragma unroll 4
+          for (int l = 63; l >= lmin; --l) {
+            const XVec4<Elem> e = sE[l];
+            const u32 skip = sB[l];
+            XVec4<V> r;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+              const V f = op.dfold_fast(e.v[j], tt);
+              tt = ((skip >> j) & 1u) ? tt : f;
+              r.v[j] = tt;
+            }
+            sR[l] = r;
+          }
+        }
+        __syncthreads();
+        bool bad = false;
+        if ((int)lane >= lmin) {
+          const XVec4<Elem> e = sE[lane];
+          const XVec4<V> r = sR[lane];
+          const u32 skip = sB[lane];
+          const V prev = lane < 63u ? sR[lane + 1u].v[0] : sT;
+          bad = (!(skip & 8u) && op.dspecial(e.v[3], prev)) | (!(skip & 4u) && op.dspecial(e.v[2], r.v[3])) |
+                (!(skip & 2u) && op.dspecial(e.v[1], r.v[2])) | (!(skip & 1u) && op.dspecial(e.v[0], r.v[1]));
+        }
+        if (__any((int)bad)) {
+          __syncthreads();
+          if (lane == 0) tt = exact(t);
+        }
+        t = tt;
+      }
+      __syncthreads();
+      const i32 gi = lo + (i32)lane;
+      if (gi >= 0) R4[gi] = sR[lane];
+    }
+    return;
+  }
+  const u32 c = c0 + (blockIdx.x - nlong) * blockDim.x + threadIdx.x;
   const bool active = c < c1;
   const u32 s0 = active ? cstart[c] : 0u;
   const u32 cl = active ? clen[c] : 0u;
-  const u32 m = cl & XC_LEN;
+  const u32 m = (cl & XC_LEN) >= XLONG ? 0u : (cl & XC_LEN);
   const u32 tail = m ? m - 1u - (cl >> 29) : 0u;  // slot of the last cell
   const u32 ng = m ? (tail >> 2) + 1u : 0u;        // groups 0 .. ng-1 hold the slots 0 .. tail
   const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
@@ -405,8 +605,12 @@ template <class Op>
 __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   typedef typename Op::V V;
   typedef typename Op::DTile Elem;
+  // INPL: the tile image of a leaf has the type of the result and waits in the leaf's own word of val until the
+  // leaf is computed (trunk cells and the ring hold final values from the start) — no second array, one more
+  // workgroup per CU
+  constexpr bool INPL = std::is_same<Elem, V>::value;
   __shared__ __attribute__((aligned(16))) V val[XHW * XHW];
-  __shared__ __attribute__((aligned(16))) Elem De[XTC];
+  __shared__ __attribute__((aligned(16))) Elem De[INPL ? 4 : XTC];
   // per leaf, in step order: own cell (12 bits) | ring index of its downstream cell << 12 (13 bits) | pit << 25
   // (looked up once per leaf here instead of once per step through the cell's code)
   __shared__ __attribute__((aligned(16))) u32 ord[XTC];
@@ -443,17 +647,23 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     const int lr = l0 >> 6, lc = l0 & 63;
     const i64 gr = r0 + lr, gc = c0 + lc;
     u32 c4 = D8_MV * 0x01010101u;
+    u32 l4 = XL_TRUNK * 0x01010101u;  // INPL: the leaf steps of the quad (a leaf needs no final value, a trunk cell no image)
     V v[4] = {V(), V(), V(), V()};
     if (gr < (i64)a.nrow && gc + 3 < (i64)a.ncol) {
       const u32 g0 = (u32)(gr * (i64)a.ncol + gc);
       __builtin_memcpy(&c4, a.ncode + g0, 4);
-      op.top4(g0, v);
+      if (INPL) __builtin_memcpy(&l4, a.lh + g0, 4);
+      bool trunk = !INPL;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) trunk |= ((l4 >> (8 * b)) & 0xFFu) == XL_TRUNK;
+      if (trunk) op.top4(g0, v);
     } else if (gr < (i64)a.nrow) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         if (gc + b < (i64)a.ncol) {
           const u32 g = (u32)(gr * (i64)a.ncol + gc + b);
           c4 = (c4 & ~(0xFFu << (8 * b))) | ((u32)a.ncode[g] << (8 * b));
+          if (INPL) l4 = (l4 & ~(0xFFu << (8 * b))) | ((u32)a.lh[g] << (8 * b));
           v[b] = op.top(g);
         }
       }
@@ -463,11 +673,16 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const u32 code = (c4 >> (8 * b)) & 0xFFu;
+      const bool leaf = ((l4 >> (8 * b)) & 0xFFu) <= (u32)XCAP;
       Elem e = Elem();
       bool f = false;
-      if (code != D8_MV) e = op.dtile((u32)(gr * (i64)a.ncol + gc + b), code, f);
-      De[l0 + b] = e;
+      if (code != D8_MV && (!INPL || leaf)) e = op.dtile((u32)(gr * (i64)a.ncol + gc + b), code, f);
       fl |= f ? 1u << b : 0u;
+      if (INPL) {
+        if (leaf) __builtin_memcpy(&v[b], &e, sizeof(V));  // (Elem is V)
+      } else {
+        De[l0 + b] = e;
+      }
       val[(lr + 1) * XHW + lc + b + 1] = v[b];
     }
     if (Op::DTILE_FLAG && fl) atomicOr(&F[l0 >> 5], fl << (l0 & 31u));
@@ -501,9 +716,14 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
       const u32 w = ord[j];
       const u32 x = w & 0xFFFu;
       const V pv = val[(w >> 12) & 0x1FFFu];
-      const Elem el = De[x];
+      const u32 own = ((x >> 6) + 1) * XHW + (x & 63u) + 1;
+      Elem el;
+      if (INPL)
+        __builtin_memcpy(&el, &val[own], sizeof(Elem));
+      else
+        el = De[x];
       const bool f = Op::DTILE_FLAG ? ((F[x >> 5] >> (x & 31u)) & 1u) != 0 : false;
-      val[((x >> 6) + 1) * XHW + (x & 63u) + 1] = (w >> 25) ? op.dtroot(el, f) : op.dtfold(el, f, pv);
+      val[own] = (w >> 25) ? op.dtroot(el, f) : op.dtfold(el, f, pv);
     }
     __syncthreads();
   }
@@ -546,8 +766,10 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
     if (c1 == c0) continue;
     k_xtrunk_dpre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, h->ncode, s0, s1,
                                                                      E.as<Elem>());
-    k_xtrunk_dscan<Op><<<cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, p->spost,
-                                                                    h->ncode, h->geo, E.as<Elem>(), R.as<V>());
+    const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
+    k_xtrunk_dscan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
+                                                                         p->longc + p->b_long[b], nl, p->scell, p->spost,
+                                                                         h->ncode, h->geo, E.as<Elem>(), R.as<V>());
     k_xtrunk_dscatter<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, R.as<V>());
     launches += 3;
   }

@@ -635,8 +635,12 @@ struct Strahler {
     const u32 m = e & 0xFFu, cnt = (e >> 8) & 3u;
     return cnt == 0 ? ((e >> 11) & 1u) : (cnt >= 2 ? m + 1 : m);
   }
-  static constexpr bool FAST = false;
-  __device__ __forceinline__ bool special(u32, u32) const { return false; }
+  // speculative block fold: along a main stem nearly every slot leaves the order unchanged (the heavy cell is
+  // inside the mask and its order exceeds that of the light cells); anything else redoes the block exactly
+  static constexpr bool FAST = true;
+  __device__ __forceinline__ bool special(u32 t, u32 e) const {
+    return !(e & 0x80000000u) && !((e & (1u << 10)) && t > (e & 0xFFu));
+  }
   __device__ __forceinline__ u32 fold_fast(u32 t, u32) const { return t; }
   __device__ __forceinline__ u32 fold(u32 t, u32 e, bool post) const {
     if (post) return t;
@@ -695,18 +699,20 @@ struct Hand {
     return e;
   }
   // tile image (k_xtile_down): the difference alone, the drain flag goes to the tile's flag bitmap
-  typedef E DTile;
+  // (already widened: the tile image of a leaf then has the type of the result and lives in the result's LDS word)
+  typedef double DTile;
   static constexpr bool DTILE_FLAG = true;
-  __device__ __forceinline__ E dtile(u32 x, u32 code, bool &is_drain) const {
+  __device__ __forceinline__ double dtile(u32 x, u32 code, bool &is_drain) const {
     is_drain = drain[x] == 1;
-    return elev[x] - elev[d8_down(g, x, code)];
+    return (double)(E)(elev[x] - elev[d8_down(g, x, code)]);
   }
-  __device__ __forceinline__ double dtroot(E dz, bool is_drain) const { return is_drain ? 0.0 : 0.0 + (double)dz; }
-  __device__ __forceinline__ double dtfold(E dz, bool is_drain, double pv) const { return is_drain ? 0.0 : pv + (double)dz; }
+  __device__ __forceinline__ double dtroot(double dz, bool is_drain) const { return is_drain ? 0.0 : 0.0 + dz; }
+  __device__ __forceinline__ double dtfold(double dz, bool is_drain, double pv) const { return is_drain ? 0.0 : pv + dz; }
   __device__ __forceinline__ void top4(u32 x0, double (&v)[4]) const { __builtin_memcpy(v, out + x0, 32); }
-  static constexpr bool FAST = false;
-  __device__ __forceinline__ bool dspecial(const DElem &, double) const { return false; }
-  __device__ __forceinline__ double dfold_fast(const DElem &, double pv) const { return pv; }
+  // speculative block fold (exact_sweep.h): a drain cell on a chain is rare; everything else is one add
+  static constexpr bool FAST = true;
+  __device__ __forceinline__ bool dspecial(const DElem &e, double) const { return e.is_drain != 0u; }
+  __device__ __forceinline__ double dfold_fast(const DElem &e, double pv) const { return pv + (double)e.dz; }
   __device__ __forceinline__ double droot(const DElem &e) const { return e.is_drain ? 0.0 : 0.0 + (double)e.dz; }
   __device__ __forceinline__ double dfold(const DElem &e, double pv) const { return e.is_drain ? 0.0 : pv + (double)e.dz; }
 };

@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
 __global__ void __launch_bounds__(1024) k_tile_counts(const u64 *__restrict__ tcnt, u32 ntiles, u64 *ctrl) {
   __shared__ u64 s[3][16];
   u64 v = 0, p = 0, b = 0;
-  for (u32 i = threadIdx.x; i < ntiles; i += 1024u) {
+  for (u32 i = blockIdx.x * 1024u + threadIdx.x; i < ntiles; i += gridDim.x * 1024u) {
     const u64 x = tcnt[i];
     v += x & 0xFFFFu;
     p += (x >> 16) & 0xFFFFu;
@@ -427,9 +427,11 @@ __global__ void __launch_bounds__(1024) k_tile_counts(const u64 *__restrict__ tc
   if (threadIdx.x == 0) {
     v = p = b = 0;
     for (int k = 0; k < 16; ++k) v += s[0][k], p += s[1][k], b += s[2][k];
-    ctrl[16] = v;  // (copies 17..31 / 33..47 were cleared with the rest of ctrl)
-    ctrl[32] = p;
-    ctrl[2] = b;   // C_BAD
+    // (ctrl was cleared when the handle was set up; the host sums the 16 copies of each counter)
+    const u32 copy = blockIdx.x & 15u;
+    if (v) atomicAdd((unsigned long long *)&ctrl[16 + copy], (unsigned long long)v);
+    if (p) atomicAdd((unsigned long long *)&ctrl[32 + copy], (unsigned long long)p);
+    if (b) atomicAdd((unsigned long long *)&ctrl[2], (unsigned long long)b);  // C_BAD
   }
 }
 
@@ -1029,6 +1031,8 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
 int TiledRun::phase_a() {
   coarse_done = true;
   const size_t nb = 2 * (size_t)h->ncol;
+  // (a deferred handle has never run a kernel: its counters, C_BAD among them, still hold whatever the block held)
+  if (!h->normalised) HIPCHK(hipMemsetAsync(h->ctrl, 0, 8 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 56 * sizeof(u64), h->stream));
   // (no slot array needs clearing: every tile writes its 256 slots, slots of tiles beyond the
   //  raster edge are never read)
@@ -1048,7 +1052,7 @@ int TiledRun::phase_a() {
     fused_norm = true;
     KCHK();
     pfd_seg_end(h, 1);
-    k_tile_counts<<<1, 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);  // (10 us, outside the segments)
+    k_tile_counts<<<std::min<u32>(cdiv_u32((u64)ntr * ntc, 4096), 256u), 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);
   } else {
     k_tile<false><<<grid, 256, 0, h->stream>>>(a);
     KCHK();

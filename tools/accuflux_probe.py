@@ -1,5 +1,5 @@
 """Timing of float32 accuflux (up) on a synthetic raster, first call and warm calls, with the phase
-segments (set PFD_CHAIN_UP=1 for the experimental chain sweep).
+segments; PROBE_OP=up|down|strahler|hand picks the operation.
 
     python tools/accuflux_probe.py NROW [NCOL [nodata_pct [tilt]]]"""
 import sys, time
@@ -16,9 +16,21 @@ def sync(): _hip.check(L.pfd_device_synchronize(0))
 h = _hip.RasterHandle(d8, nrow, ncol, device=0, memspace=_hip.PFD_DEVICE)
 h.set_profiling(True)
 w = _hip.synth_weights_device(n, seed=1)
-out = _hip.DeviceBuffer(n * 4)
+out = _hip.DeviceBuffer(n * 8)
+op = os.environ.get("PROBE_OP", "up")
+if op == "hand":
+    so = _hip.DeviceBuffer(n)
+    h.strahler(None, out=so, memspace=_hip.PFD_DEVICE)
+    elev = _hip.synth_elev_device(nrow, ncol, seed=0, tilt=tilt, white=2, nodata_pct=nd)
 for it in range(3):
     sync(); t0 = time.perf_counter()
-    h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out, memspace=_hip.PFD_DEVICE)
+    if op == "up":
+        h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out, memspace=_hip.PFD_DEVICE)
+    elif op == "down":
+        h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, direction=_hip.PFD_DOWN, out=out, memspace=_hip.PFD_DEVICE)
+    elif op == "strahler":
+        h.strahler(None, out=out, memspace=_hip.PFD_DEVICE)
+    elif op == "hand":
+        h.hand(so, elev, _hip.PFD_F32, out=out, memspace=_hip.PFD_DEVICE)
     sync(); t1 = time.perf_counter()
     print(it, round(1e3 * (t1 - t0), 2), "ms", [(s['name'], round(s['ms'], 2)) for s in h.last_timing()], flush=True)
