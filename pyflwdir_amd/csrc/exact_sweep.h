@@ -423,12 +423,18 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
     i32 lo = (i32)ng - 64;
     gload(lo + (i32)lane, cur, cb);
     for (; lo > -64; lo -= 64) {
-      sE[lane] = cur;
       {
         // post slots and the slots from the tail on do not change the running value
         const i32 fb = (i32)tail - 4 * (lo + (i32)lane);  // group-relative slot of the tail
-        sB[lane] = fb < 4 ? (cb | (fb <= 0 ? 0xFu : (~((1u << fb) - 1u) & 0xFu))) : cb;
+        const u32 skip = fb < 4 ? (cb | (fb <= 0 ? 0xFu : (~((1u << fb) - 1u) & 0xFu))) : cb;
+        sB[lane] = skip;
+        if constexpr (Op::FAST) {  // the speculative fold runs over every slot: skipped ones hold the neutral element
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((skip >> j) & 1u) cur.v[j] = op.dneutral();
+        }
       }
+      sE[lane] = cur;
       gload(lo - 64 + (i32)lane, cur, cb);
       if (lane == 0) sT = t;
       __syncthreads();
@@ -448,7 +454,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
         }
         return tt;
       };
-      if (!Op::FAST) {
+      if constexpr (!Op::FAST) {
         if (lane == 0) t = exact(t);
       } else {
         V tt = t;
@@ -456,12 +462,10 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
 #pragma unroll 4
           for (int l = 63; l >= lmin; --l) {
             const XVec4<Elem> e = sE[l];
-            const u32 skip = sB[l];
             XVec4<V> r;
 #pragma unroll
             for (int j = 3; j >= 0; --j) {
-              const V f = op.dfold_fast(e.v[j], tt);
-              tt = ((skip >> j) & 1u) ? tt : f;
+              tt = op.dfold_fast(e.v[j], tt);
               r.v[j] = tt;
             }
             sR[l] = r;

@@ -292,16 +292,21 @@ static int run_down(pfd_raster *h, const Op &op, const char *name) {
 // payload arithmetic: integers wrap like numba's fixed-width ints, floats are plain IEEE adds
 // ---------------------------------------------------------------------------------------------
 template <class T> struct Num;
+// neutral(): x with add(x, y) == y bit for bit, for every y (-0.0 for floats: +0.0 would turn a -0.0 into +0.0)
 template <> struct Num<i32> {
+  static __device__ __forceinline__ i32 neutral() { return 0; }
   static __device__ __forceinline__ i32 add(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 };
 template <> struct Num<i64> {
+  static __device__ __forceinline__ i64 neutral() { return 0; }
   static __device__ __forceinline__ i64 add(i64 a, i64 b) { return (i64)((u64)a + (u64)b); }
 };
 template <> struct Num<float> {
+  static __device__ __forceinline__ float neutral() { return -0.0f; }
   static __device__ __forceinline__ float add(float a, float b) { return a + b; }
 };
 template <> struct Num<double> {
+  static __device__ __forceinline__ double neutral() { return -0.0; }
   static __device__ __forceinline__ double add(double a, double b) { return a + b; }
 };
 
@@ -476,6 +481,7 @@ struct AccuDown {
   static constexpr bool FAST = true;
   __device__ __forceinline__ bool dspecial(T e, T pv) const { return has_nodata && ((pv == nodata) | (e == nodata)); }
   __device__ __forceinline__ T dfold_fast(T e, T pv) const { return Num<T>::add(e, pv); }
+  __device__ __forceinline__ T dneutral() const { return Num<T>::neutral(); }  // dfold_fast(dneutral(), pv) == pv
 };
 
 // FlwdirRaster.upstream_area(unit="cell"): unit weights, nothing read but the codes
@@ -713,6 +719,7 @@ struct Hand {
   static constexpr bool FAST = true;
   __device__ __forceinline__ bool dspecial(const DElem &e, double) const { return e.is_drain != 0u; }
   __device__ __forceinline__ double dfold_fast(const DElem &e, double pv) const { return pv + (double)e.dz; }
+  __device__ __forceinline__ DElem dneutral() const { return DElem{(E)-0.0, 0u}; }  // pv + (-0.0) == pv for every pv
   __device__ __forceinline__ double droot(const DElem &e) const { return e.is_drain ? 0.0 : 0.0 + (double)e.dz; }
   __device__ __forceinline__ double dfold(const DElem &e, double pv) const { return e.is_drain ? 0.0 : pv + (double)e.dz; }
 };
