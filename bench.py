@@ -155,11 +155,47 @@ def cpu_baseline(d8_host, rows, nrow):
                 host_cpus=os.cpu_count()), upa
 
 
-def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, checks=True):
+def rhine_mosaic(min_edge=10000):
+    """The reference's 682 x 997 Rhine sub-basin (tests/golden/rhine.npz, from /root/reference/tests/data) tiled
+    to at least min_edge x min_edge cells.  Every copy gets a one-cell nodata frame: flow that left the fixture
+    stays an outlet (the pit rule) instead of entering the neighbouring copy, so the mosaic is acyclic and keeps
+    the real raster's path statistics."""
+    d8 = np.load(os.path.join(ROOT, "tests", "golden", "rhine.npz"))["d8"]
+    framed = np.full((d8.shape[0] + 2, d8.shape[1] + 2), 247, np.uint8)
+    framed[1:-1, 1:-1] = d8
+    reps = (-(-min_edge // framed.shape[0]), -(-min_edge // framed.shape[1]))
+    return np.ascontiguousarray(np.tile(framed, reps))
+
+
+def serpentine(nrow, ncol):
+    """Worst case of the tile pass: every 64 x 64 tile is ONE boustrophedon path of 4096 cells ending in a pit
+    (even rows flow east, odd rows west, the row ends flow south) — the longest in-tile path there is, so the
+    pointer doubling needs all its 12-13 rounds in every tile."""
+    t = np.empty((64, 64), np.uint8)
+    t[0::2, :] = 1
+    t[1::2, :] = 16
+    t[0::2, 63] = 4
+    t[1::2, 0] = 4
+    t[63, 0] = 0
+    return np.ascontiguousarray(np.tile(t, (-(-nrow // 64), -(-ncol // 64)))[:nrow, :ncol])
+
+
+def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, checks=True, invariant_checks=None):
     """The upstream_area("cell") pass on one GPU: returns the JSON fields of one bench line."""
+    if regime in ("rhine_mosaic", "serpentine"):
+        host = rhine_mosaic(min(nrow, ncol)) if regime == "rhine_mosaic" else serpentine(nrow, ncol)
+        nrow, ncol = host.shape
+        synth = dict(seed=None, tilt=None)
+        d8_buf = _hip.DeviceBuffer(host.size, device)
+        d8_buf.upload(host)
+        label = (f"{nrow}x{ncol} mosaic of the reference's Rhine sub-basin (682x997 cells, nodata frame per copy)"
+                 if regime == "rhine_mosaic" else
+                 f"{nrow}x{ncol} serpentine tiles (every 64x64 tile one 4096-cell path: worst case of the tile pass)")
+    else:
+        synth = REGIMES[regime]
+        d8_buf = _hip.synth_d8_device(nrow, ncol, device=device, **synth)
+        label = f"{nrow}x{ncol} synthetic D8 ({regime} regime, seed {synth['seed']}, tilt {synth['tilt']})"
     n = nrow * ncol
-    synth = REGIMES[regime]
-    d8_buf = _hip.synth_d8_device(nrow, ncol, device=device, **synth)
     out_buf = _hip.DeviceBuffer(n * 4, device)
     total, per, timed = timed_steps(lambda prof: one_step(d8_buf, out_buf, nrow, ncol, device, profile=prof), steps,
                                     warmup, device)
@@ -168,16 +204,19 @@ def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, ch
     out = dict(value=round(n * steps / total / 1e6, 2), ms_per_step=round(ms_per_step, 3),
                ms_per_step_median=round(statistics.median(per), 3), ms_per_step_min=round(min(per), 3),
                roofline=roofline_upa(segs, n, nrow, ncol, ms_per_step))
-    cfg = dict(workload=f"{nrow}x{ncol} synthetic D8 ({regime} regime, seed {synth['seed']}, tilt {synth['tilt']}), "
-                        "upstream_area(unit='cell') int32 on 1 GPU; a step = decode + pit rule + validation + tile "
-                        "pass + exit-graph solve + final tile pass on a fresh handle",
+    cfg = dict(workload=label + ", upstream_area(unit='cell') int32 on 1 GPU; a step = decode + pit rule + validation "
+                                "+ tile pass + exit-graph solve + final tile pass on a fresh handle",
                n_cells=n, n_valid=info["n_valid"], n_pits=info["n_pits"], parallelism="1 GPU")
     if checks:
-        # graph statistics (outside the timed region): longest flow path and in-degree histogram
+        # graph statistics (outside the timed region): longest flow path, in-degree histogram, and the pointer-
+        # doubling rounds the tile passes needed (counted by one extra profiled pass)
         h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE, deferred=True)
+        h.set_profiling(2)
+        h.upstream_area_cell(out=out_buf, memspace=_hip.PFD_DEVICE)
         st = h.graph_stats()
         h.close()
-        cfg.update(max_rank=st["max_rank"], indegree_hist=st["indegree_hist"])
+        cfg.update(max_rank=st["max_rank"], indegree_hist=st["indegree_hist"], tile_doubling_rounds=st["tile_rounds"])
+    if checks if invariant_checks is None else invariant_checks:
         # size-independent invariants (reference tests/test_streams_basins.py:24-27): the upstream areas of the
         # pits add up to the number of valid cells; nodata cells hold -9999; upa == 1 + sum over the upstream cells
         out["invariants"] = invariants(d8_buf, out_buf, nrow, ncol, info, device)
@@ -246,7 +285,7 @@ def invariants(d8_buf, out_buf, nrow, ncol, info, device, samples=1_000_000):
     return res
 
 
-# ---- secondary lines: BASELINE.json configs[2] (float32 accuflux + Strahler at 30000 x 30000) ----------
+# ---- secondary lines: BASELINE.json configs[2] (float32 accuflux + Strahler at 30000 x 30000) + HAND ----
 def c3_lines(size, regime, steps, device):
     """Wall time of a complete warm call of the exact (bit-identical to the serial loop) float32
     accuflux and of the Strahler order, everything device-resident; the first call on the handle, which
@@ -291,8 +330,14 @@ def c3_lines(size, regime, steps, device):
                            memspace=_hip.PFD_DEVICE), B_ALG["accuflux_f32"], "f32")
     run("stream_order(type='strahler')", lambda: h.strahler(None, out=out_b, memspace=_hip.PFD_DEVICE),
         B_ALG["strahler"], "u8")
+    # configs[4]'s second operation: height above the nearest drain, float32 elevation -> float64 (reference
+    # dem.height_above_nearest_drain, pyflwdir/dem.py:299-330); drain = the cells of Strahler order 1
+    elev = _hip.synth_elev_device(size, size, device=device, **REGIMES[regime])
+    out_d = _hip.DeviceBuffer(n * 8, device)
+    run("hand(drain, elevtn float32) -> float64", lambda: h.hand(out_b, elev, _hip.PFD_F32, out=out_d, memspace=_hip.PFD_DEVICE),
+        B_ALG["hand_f32"], "f64")
     h.close()
-    for b in (d8_buf, w, out_f, out_b):
+    for b in (d8_buf, w, out_f, out_b, elev, out_d):
         b.free()
     _hip.check(_hip.lib().pfd_trim(device))
     return lines
@@ -422,6 +467,13 @@ def main():
                         ms_per_step=l2["ms_per_step"], ms_per_step_median=l2["ms_per_step_median"], dtype="int32",
                         n_valid=c2["n_valid"], n_pits=c2["n_pits"], roofline=l2["roofline"]))
         sec += c3_lines(30000, a.regime, 3, device)
+        # workload spread: the same pass on a rough surface, on a pit-riddled one, on a mosaic of the reference's real
+        # Rhine raster and on the tile pass's worst case, with the graph statistics that explain the differences
+        for reg in ("rough", "meander", "rhine_mosaic", "serpentine"):
+            if reg == a.regime:
+                continue
+            l3, c3 = upa_line(10000, 10000, reg, 10, 2, device, cpu=False, checks=True)
+            sec.append(dict(op="upstream_area(unit='cell')", **c3, **l3, unit="Mcells/s", dtype="int32"))
         out["secondary"] = sec
     print(json.dumps(out))
 

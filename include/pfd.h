@@ -275,7 +275,9 @@ int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k, const uin
  * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST
  * sweep/ordering call on the handle.  Enable with pfd_set_profiling(h, 1).  Up to max_seg
  * segments are returned: ms[i] GPU milliseconds, launches[i] kernel launches in the segment,
- * names = segment names joined by ';' (e.g. "order_cells;init;sweep_count_up"). */
+ * names = segment names joined by ';' (e.g. "order_cells;init;sweep_count_up").  enable = 2 additionally makes
+ * the tile passes of upstream_area("cell") count their pointer-doubling rounds (pfd_graph_stats; costs two
+ * atomics per tile, so not for timed runs). */
 int pfd_set_profiling(pfd_raster *h, int enable);
 int pfd_last_timing(pfd_raster *h, int max_seg, double *ms, int64_t *launches, char *names,
                     size_t names_len, int *nseg);
@@ -283,8 +285,9 @@ int pfd_last_timing(pfd_raster *h, int max_seg, double *ms, int64_t *launches, c
 /* Graph statistics a benchmark reports next to every number: stats[0] = n_valid,
  * [1] = n_pits, [2] = max rank = longest flow path in cells (reference core.rank, pyflwdir/core.py:17-47;
  * -1 if the raster holds cycles or is a row block), [3..11] = number of valid cells with 0..8
- * upstream cells (reference core.upstream_count, pyflwdir/core.py:50-61).  Works on rasters beyond 2^32
- * cells. */
+ * upstream cells (reference core.upstream_count, pyflwdir/core.py:50-61); [12..15] = pointer-doubling rounds
+ * of the last upstream_area("cell") pass this handle ran under pfd_set_profiling(h, 2): max and sum over the tiles of the
+ * local pass, max and sum of the final pass (0 if there was none).  Works on rasters beyond 2^32 cells. */
 int pfd_graph_stats(pfd_raster *h, int64_t stats[16]);
 
 /* Verifies an upstream_area("cell") result of this raster by its local equations, at any size

@@ -245,7 +245,10 @@ class RasterHandle:
         """n_valid, n_pits, max_rank (longest flow path, -1 with cycles) and the in-degree histogram."""
         a = (C.c_int64 * 16)()
         check(lib().pfd_graph_stats(self._h, a))
-        return dict(n_valid=int(a[0]), n_pits=int(a[1]), max_rank=int(a[2]), indegree_hist=[int(a[3 + k]) for k in range(9)])
+        ntiles = max(1, -(-self.nrow // 64) * -(-self.ncol // 64))
+        return dict(n_valid=int(a[0]), n_pits=int(a[1]), max_rank=int(a[2]), indegree_hist=[int(a[3 + k]) for k in range(9)],
+                    tile_rounds=dict(local_max=int(a[12]), local_mean=round(int(a[13]) / ntiles, 2), final_max=int(a[14]),
+                                     final_mean=round(int(a[15]) / ntiles, 2)))
 
     def verify_upstream_area_cell(self, upa, memspace=PFD_HOST) -> dict:
         """Local-equation check of an upstream_area("cell") result (see include/pfd.h)."""
@@ -254,7 +257,7 @@ class RasterHandle:
         return dict(bad_cells=int(a[0]), bad_nodata=int(a[1]), pit_sum=int(a[2]), n_pits=int(a[3]), checksum=int(a[4]),
                     n_valid=int(a[5]))
 
-    def set_profiling(self, on: bool = True):
+    def set_profiling(self, on=True):  # (2: also count the doubling rounds of the tile passes, see graph_stats)
         check(lib().pfd_set_profiling(self._h, int(on)))
 
     def last_timing(self):

@@ -448,6 +448,7 @@ void pfd_seg_end(pfd_raster *h, i64 launches) {
 extern "C" int pfd_set_profiling(pfd_raster *h, int enable) {
   PFDCHK(pfd_check_handle_lazy(h));
   h->profiling = enable != 0;
+  h->count_rounds = enable >= 2;
   if (!enable) pfd_seg_clear(h);
   return PFD_OK;
 }

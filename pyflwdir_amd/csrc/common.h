@@ -153,6 +153,8 @@ struct pfd_raster {
   void *pending_basins = nullptr;  // split-phase multi-block basins query in flight (paths.hip)
   // profiling
   bool profiling = false;
+  bool count_rounds = false;  // pfd_set_profiling(h, 2): the tile passes also count their doubling rounds (two atomics per tile)
+  i64 tile_rounds[4] = {0, 0, 0, 0};  // last tiled pass with count_rounds on: doubling rounds max / sum over tiles, local and final pass
   std::vector<PfdSegment> segs;
 };
 

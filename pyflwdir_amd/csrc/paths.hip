@@ -805,6 +805,7 @@ extern "C" int pfd_graph_stats(pfd_raster *h, int64_t stats[16]) {
   stats[1] = h->n_pits;
   stats[2] = -1;
   for (int k = 0; k < 9; ++k) stats[3 + k] = (int64_t)hh[k];
+  for (int k = 0; k < 4; ++k) stats[12 + k] = h->tile_rounds[k];
   if (!h->halo_top && !h->halo_bot) {  // longest flow path (cells): max rank over the raster
     int complete = 0;
     u32 maxrank = 0;

@@ -100,7 +100,8 @@ struct TileArgs {
   u32 *brow_inflow;// [2*ncol] flow entering the boundary rows from the neighbouring row blocks
   u64 *ctrl;
   i32 *out;
-  int ablate;      // profiling knob (env PFD_TILE_ABLATE): bit0 skip doubling, bit4 cycle stamps
+  int ablate;      // profiling knob (env PFD_TILE_ABLATE): bit0 skip doubling, bit4 cycle stamps; bit5 (set by
+                   // pfd_set_profiling(h, 2)) counts the doubling rounds per tile into ctrl[48..51]
 };
 
 // ---- device helpers shared by the tile kernels (tiled.hip, paths.hip) ---------------------------

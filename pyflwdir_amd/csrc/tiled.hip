@@ -252,7 +252,8 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     // Branches are per QUAD only: inside a live quad all four cells run the same instruction
     // stream; a saturated cell re-reads its root's pointer and adds 0 to it (harmless), which is
     // cheaper than four exec-mask regions per quad and round.
-    for (int round = 0; round < MAXROUNDS_TILE; ++round) {
+    int round = 0;
+    for (; round < MAXROUNDS_TILE; ++round) {
       u32 av[QPT * 4], q[QPT * 4];
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
@@ -287,6 +288,11 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
         }
       }
       if (!__syncthreads_or((int)live)) break;
+    }
+    if ((a.ablate & 32) && tid == 0) {  // profiling only: rounds this tile needed (max and sum over the tiles)
+      const unsigned long long r = (unsigned long long)min(round + 1, MAXROUNDS_TILE);
+      atomicMax((unsigned long long *)&a.ctrl[FINAL ? 50 : 48], r);
+      atomicAdd((unsigned long long *)&a.ctrl[FINAL ? 51 : 49], r);
     }
   }
   TSTAMP(2)
@@ -927,6 +933,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
                  hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP};
   if (const char *e = getenv("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
+  if (h->count_rounds) a.ablate |= 32;
   is_block = h->halo_top || h->halo_bot;
   return PFD_OK;
 }
@@ -1110,6 +1117,7 @@ int TiledRun::phase_b(int *complete) {
   HIPCHK(hipMemcpyAsync(c0, h->ctrl, sizeof(c0), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   const u64 *c = c0 + 8;
+  if (a.ablate & 32) HIPCHK(hipMemcpy(h->tile_rounds, h->ctrl + 48, 4 * sizeof(u64), hipMemcpyDeviceToHost));
   if (fused_norm && !h->normalised) PFDCHK(pfd_adopt_counts(h, c0));  // bad codes / no pits surface here
   if (a.ablate & 16) {
     u64 t[32];
