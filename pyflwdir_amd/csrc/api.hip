@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -59,11 +60,31 @@ size_t size_class(size_t bytes) {
   while (c < bytes) c <<= 1;
   return c;
 }
-const size_t IDLE_CAP = (size_t)96 << 30;  // keep at most 96 GiB of idle blocks per process
+// idle blocks kept per process: 96 GiB unless PFD_IDLE_CAP_GB says otherwise (0 = return every block at once)
+size_t idle_cap() {
+  static const size_t v = [] {
+    const char *e = getenv("PFD_IDLE_CAP_GB");
+    return (size_t)(e ? std::max(0L, strtol(e, nullptr, 10)) : 96L) << 30;
+  }();
+  return v;
+}
 }  // namespace
 
-// debugging aid: PFD_POISON=<byte> fills every block handed out with that byte (synchronously), which turns a
-// read of memory the caller never wrote into a reproducible failure instead of a sporadic one
+// Test-only switches (forcing a fallback engine, shrinking a capacity): inert unless PFD_ENABLE_KNOBS=1 is in the
+// environment when the library is first used (tests/conftest.py sets it), so that a stray variable cannot change
+// what a production process runs.
+const char *pfd_knob(const char *name) {
+  static const bool on = [] {
+    const char *e = getenv("PFD_ENABLE_KNOBS");
+    return e && e[0] == '1';
+  }();
+  return on ? getenv(name) : nullptr;
+}
+
+static int pfd_dmalloc_raw(void **p, size_t bytes);
+#ifdef PFD_DEVTOOLS
+// debugging aid (builds with DEVTOOLS=1 only): PFD_POISON=<byte> fills every block handed out with that byte
+// (synchronously), which turns a read of memory the caller never wrote into a reproducible failure
 static int poison_byte() {
   static const int v = [] {
     const char *e = getenv("PFD_POISON");
@@ -71,7 +92,6 @@ static int poison_byte() {
   }();
   return v;
 }
-static int pfd_dmalloc_raw(void **p, size_t bytes);
 int pfd_dmalloc(void **p, size_t bytes) {
   const int rc = pfd_dmalloc_raw(p, bytes);
   if (rc == PFD_OK && poison_byte() >= 0) {
@@ -81,6 +101,9 @@ int pfd_dmalloc(void **p, size_t bytes) {
   }
   return rc;
 }
+#else
+int pfd_dmalloc(void **p, size_t bytes) { return pfd_dmalloc_raw(p, bytes); }
+#endif
 static int pfd_dmalloc_raw(void **p, size_t bytes) {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
@@ -134,7 +157,7 @@ void pfd_dfree(void *p) {
   }
   const auto key = it->second;
   c.live.erase(it);
-  if (c.idle_bytes + key.second > IDLE_CAP) {
+  if (c.idle_bytes + key.second > idle_cap()) {
     (void)hipFree(p);
     return;
   }

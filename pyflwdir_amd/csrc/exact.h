@@ -64,7 +64,9 @@ struct ExactPlan {
 int pfd_ensure_xplan(pfd_raster *h);
 void pfd_free_xplan(pfd_raster *h);
 
-// debugging aid (env PFD_XDEBUG): synchronise after a step and name it, so that a GPU memory fault points at its kernel
+// debugging aid (builds with DEVTOOLS=1 only, env PFD_XDEBUG): synchronise after a step and name it, so that a GPU
+// memory fault points at its kernel
+#ifdef PFD_DEVTOOLS
 #define XDBG(h, what)                                                          \
   do {                                                                         \
     const char *xd_ = getenv("PFD_XDEBUG");                                    \
@@ -74,3 +76,6 @@ void pfd_free_xplan(pfd_raster *h);
       fflush(stderr);                                                          \
     }                                                                          \
   } while (0)
+#else
+#define XDBG(h, what) ((void)0)
+#endif

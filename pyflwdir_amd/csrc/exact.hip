@@ -358,7 +358,7 @@ __global__ void k_plan_pick(const u32 *__restrict__ S, const u32 *__restrict__ i
   if (t < k) out[t] = S[idx[t]];
 }
 
-// debugging aid (env PFD_XPLAN_DIGEST): 64-bit sum of a device array after a build step, printed to stderr —
+// debugging aid (builds with DEVTOOLS=1 only, env PFD_XPLAN_DIGEST): 64-bit sum of a device array after a build step, printed to stderr —
 // two builds of the same raster must print identical lines (tools/plan_determinism.py)
 __global__ void __launch_bounds__(256) k_digest(const u32 *__restrict__ v, u64 nwords, unsigned long long *__restrict__ res) {
   unsigned long long s = 0;
@@ -367,6 +367,10 @@ __global__ void __launch_bounds__(256) k_digest(const u32 *__restrict__ v, u64 n
   if ((threadIdx.x & 63) == 0) atomicAdd(res, s);
 }
 static void xdigest(pfd_raster *h, const char *name, const void *p, size_t bytes) {
+#ifndef PFD_DEVTOOLS
+  (void)h, (void)name, (void)p, (void)bytes;
+  return;
+#else
   if (!getenv("PFD_XPLAN_DIGEST") || !p) return;
   unsigned long long *acc = nullptr, host = 0;
   (void)hipStreamSynchronize(h->stream);
@@ -376,6 +380,7 @@ static void xdigest(pfd_raster *h, const char *name, const void *p, size_t bytes
   (void)hipMemcpy(&host, acc, 8, hipMemcpyDeviceToHost);
   (void)hipFree(acc);
   fprintf(stderr, "[xdigest] %-10s %016llx\n", name, host);
+#endif
 }
 
 void pfd_free_xplan(pfd_raster *h) {
@@ -402,7 +407,7 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if (h->xplan_state != 0) return PFD_OK;
   h->xplan_state = -1;
   if (h->gen) return PFD_OK;
-  if (h->n > 4294967294ll || h->halo_top || h->halo_bot || getenv("PFD_EXACT_LEVELS")) return PFD_OK;
+  if (h->n > 4294967294ll || h->halo_top || h->halo_bot || pfd_knob("PFD_EXACT_LEVELS")) return PFD_OK;
   if (h->acyclic < 0) return PFD_OK;
   const u32 n = h->geo.n;
   const u32 ntr = cdiv_u32((u64)h->nrow, XT), ntc = cdiv_u32((u64)h->ncol, XT);
@@ -664,10 +669,12 @@ int pfd_ensure_xplan(pfd_raster *h) {
   h->bytes_held += p->bytes;
   h->xplan_state = 1;
   pfd_seg_end(h, 14);
+#ifdef PFD_DEVTOOLS
   if (getenv("PFD_DEBUG"))
     fprintf(stderr, "[xplan] %lld cells: %lld trunk (%.1f%%) in %lld chains, %lld slots\n", (long long)h->n_valid,
             (long long)p->ntrunk, 100.0 * (double)p->ntrunk / (double)std::max<i64>(h->n_valid, 1), (long long)p->nchain,
             (long long)p->nslot);
+#endif
   return PFD_OK;
 }
 

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
                                                     typename Op::V *__restrict__ R) {
   typedef typename Op::Elem Elem;
   typedef typename Op::V V;
-  constexpr int G = XBlk<Elem>::G, XB = 4 * G;
+  constexpr int G = XBlk<Elem>::G;
   if (blockIdx.x < nlong) {
     __shared__ XVec4<Elem> sE[64];
     __shared__ XVec4<V> sR[64];
@@ -227,8 +227,8 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
           const XVec4<V> r = sR[lane];
           V prev = t;  // (lane 0: the value that entered the block)
           if (lane) prev = sR[lane - 1u].v[3];
-          bad = op.special(prev, e.v[0]) | op.special(r.v[0], e.v[1]) | op.special(r.v[1], e.v[2]) |
-                op.special(r.v[2], e.v[3]);
+          bad = (int)op.special(prev, e.v[0]) | (int)op.special(r.v[0], e.v[1]) | (int)op.special(r.v[1], e.v[2]) |
+                (int)op.special(r.v[2], e.v[3]);
         }
         if (__any((int)bad)) {
           __syncthreads();
@@ -478,8 +478,8 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
           const XVec4<V> r = sR[lane];
           const u32 skip = sB[lane];
           const V prev = lane < 63u ? sR[lane + 1u].v[0] : sT;
-          bad = (!(skip & 8u) && op.dspecial(e.v[3], prev)) | (!(skip & 4u) && op.dspecial(e.v[2], r.v[3])) |
-                (!(skip & 2u) && op.dspecial(e.v[1], r.v[2])) | (!(skip & 1u) && op.dspecial(e.v[0], r.v[1]));
+          bad = (int)(!(skip & 8u) && op.dspecial(e.v[3], prev)) | (int)(!(skip & 4u) && op.dspecial(e.v[2], r.v[3])) |
+                (int)(!(skip & 2u) && op.dspecial(e.v[1], r.v[2])) | (int)(!(skip & 1u) && op.dspecial(e.v[0], r.v[1]));
         }
         if (__any((int)bad)) {
           __syncthreads();

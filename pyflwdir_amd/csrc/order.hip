@@ -464,7 +464,7 @@ int pfd_order_cells_impl(pfd_raster *h) {
   if (h->gen) return pfd_gen_order(h);
   if (h->ordered) return PFD_OK;
   PFDCHK(pfd_require_whole(h, "the cell ordering"));
-  if (!getenv("PFD_ORDER_BFS")) {
+  if (!pfd_knob("PFD_ORDER_BFS")) {
     // fast path: ranks by LDS-tiled pointer doubling + one radix sort of the cells by rank
     // (paths.hip); rasters with cycles fall through to the breadth-first build below
     int ok = 0;

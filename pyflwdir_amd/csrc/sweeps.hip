@@ -179,8 +179,8 @@ static int run_up(pfd_raster *h, const Op &op, const char *name) {
   // (3 levels per launch are implemented but measured slower than 2: 35 vs 28 ms for 10003 levels with
   //  nested lookups — the third hop squares the divergent fan-out — and 58 vs 25 ms with a 7x7 register
   //  window, which spills: 100 loads per thread are too many registers)
-  int maxk = getenv("PFD_SINGLE_HOP") ? 1 : 2;
-  if (const char *e = getenv("PFD_UP_K")) maxk = std::max(1, std::min(3, atoi(e)));
+  int maxk = pfd_knob("PFD_SINGLE_HOP") ? 1 : 2;
+  if (const char *e = pfd_knob("PFD_UP_K")) maxk = std::max(1, std::min(3, atoi(e)));
   for (i64 l = h->n_levels - 1; l >= 0;) {
     const u32 end = (u32)h->lvl_off[l + 1];
     int k = 1;  // levels l, l-1, .. l-k+1
@@ -263,8 +263,8 @@ static int run_down(pfd_raster *h, const Op &op, const char *name) {
   PFDCHK(pfd_ensure_seq_aux(h));
   pfd_seg_begin(h, name);
   i64 launches = 0;
-  int maxk = getenv("PFD_SINGLE_HOP") ? 1 : DOWN_K;
-  if (const char *e = getenv("PFD_DOWN_K")) maxk = std::max(1, std::min((int)DOWN_K, atoi(e)));
+  int maxk = pfd_knob("PFD_SINGLE_HOP") ? 1 : DOWN_K;
+  if (const char *e = pfd_knob("PFD_DOWN_K")) maxk = std::max(1, std::min((int)DOWN_K, atoi(e)));
   for (i64 l = 0; l < h->n_levels;) {
     const u32 begin = (u32)h->lvl_off[l];
     int k = 1;
@@ -926,7 +926,7 @@ __global__ void __launch_bounds__(256) k_restore_invalid(const u8 *__restrict__ 
 static int accuflux_i32_tiled(pfd_raster *h, const i32 *data_dev, i32 nodata, int has_nodata, i32 *out_dev,
                               int *used) {
   *used = 0;
-  if (getenv("PFD_ACCUFLUX_LEVELS") || h->halo_top || h->halo_bot) return PFD_OK;
+  if (pfd_knob("PFD_ACCUFLUX_LEVELS") || h->halo_top || h->halo_bot) return PFD_OK;
   if (has_nodata && nodata >= 0) return PFD_OK;
   DevBuf res;
   PFDCHK(res.alloc(2 * sizeof(unsigned long long)));
@@ -1079,7 +1079,7 @@ static int basins_t(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 
 int pfd_basins_dev(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 ku, int id_size, void *out_dev) {
   if (h->gen) return pfd_gen_basins(h, idx_dev, ids_dev, ku, id_size, out_dev);
   int tiled_ok = 0;
-  if (!getenv("PFD_BASINS_LEVELS")) PFDCHK(pfd_basins_tiled(h, idx_dev, ids_dev, ku, id_size, out_dev, &tiled_ok));
+  if (!pfd_knob("PFD_BASINS_LEVELS")) PFDCHK(pfd_basins_tiled(h, idx_dev, ids_dev, ku, id_size, out_dev, &tiled_ok));
   if (!tiled_ok) {
     PFDCHK(pfd_order_cells_impl(h));
     int rc;

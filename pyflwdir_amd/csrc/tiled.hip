@@ -931,8 +931,10 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
                  hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP};
-  if (const char *e = getenv("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
+  if (const char *e = pfd_knob("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
+#ifdef PFD_DEVTOOLS
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
+#endif
   if (h->count_rounds) a.ablate |= 32;
   is_block = h->halo_top || h->halo_bot;
   return PFD_OK;
@@ -1012,7 +1014,7 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   Tc = l3.as<u32>() + n3cap, Tn = Tc + n3cap, Jc = Tn + n3cap, Jn = Jc + n3cap;  // undo earlier buffer rotations
   sa.T3 = Tc;
   // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
-  sa.hmode = (nht > 1 && !force_flat && !getenv("PFD_FLAT_L3")) ? 1 : 0;
+  sa.hmode = (nht > 1 && !force_flat && !pfd_knob("PFD_FLAT_L3")) ? 1 : 0;
   k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
   KCHK();
   ++*launches;
@@ -1135,7 +1137,9 @@ int TiledRun::phase_b(int *complete) {
   overflowed = c[T_OVERFLOW - 8] != 0;
   // level 4 ran a fixed number of rounds: saturated iff the last one moved no pointer
   short_of_rounds = sa.hmode && rounds4 > 0 && c[T_XACTIVE - 8] >= (u64)rounds4;
+#ifdef PFD_DEVTOOLS
   if (getenv("PFD_DEBUG_ROUNDS")) fprintf(stderr, "[level4] rounds issued %d, last active %llu\n", rounds4, (unsigned long long)c[T_XACTIVE - 8]);
+#endif
   if (overflowed || short_of_rounds) *complete = 0;
   return PFD_OK;
 }

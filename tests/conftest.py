@@ -10,6 +10,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+# the library's test-only switches (PFD_EXACT_LEVELS, PFD_TEST_HCAP, ... forcing a fallback engine or shrinking a
+# capacity) are inert unless this is set before the library is first used
+os.environ.setdefault("PFD_ENABLE_KNOBS", "1")
 
 
 def pytest_configure(config):

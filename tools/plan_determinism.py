@@ -1,6 +1,7 @@
 """Builds the exact-engine plan of the same raster repeatedly and compares the per-step digests
-(PFD_XPLAN_DIGEST=1): any difference between two builds names the first non-deterministic step."""
+(PFD_XPLAN_DIGEST=1, library built with `make DEVTOOLS=1`): any difference between two builds names the first non-deterministic step."""
 import os, sys, subprocess
+os.environ.setdefault("PFD_ENABLE_KNOBS", "1")  # PFD_EXACT_LEVELS below is a test-only switch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import ctypes as C

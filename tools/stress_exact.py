@@ -1,6 +1,7 @@
 """Stress of the exact-order engine against the level engine on random larger rasters (device generator),
 all sweep operations; prints one line per raster.   python tools/stress_exact.py [seconds] [seed]"""
 import os, sys, time
+os.environ.setdefault("PFD_ENABLE_KNOBS", "1")  # PFD_EXACT_LEVELS below is a test-only switch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyflwdir_amd import _hip
