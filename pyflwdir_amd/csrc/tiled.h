@@ -100,6 +100,7 @@ struct TileArgs {
   u32 *brow_inflow;// [2*ncol] flow entering the boundary rows from the neighbouring row blocks
   u64 *ctrl;
   i32 *out;
+  u64 *stamps;     // DEVTOOLS: [1024][8] cycle stamps, spread over 1024 rows against same-address atomics
   int ablate;      // profiling knob (env PFD_TILE_ABLATE): bit0 skip doubling, bit4 cycle stamps; bit5 (set by
                    // pfd_set_profiling(h, 2)) counts the doubling rounds per tile into ctrl[48..51]
 };
@@ -190,7 +191,7 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (8 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf;
+  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;

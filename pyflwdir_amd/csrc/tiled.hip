@@ -42,6 +42,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 #include "tiled.h"
 
@@ -50,7 +52,8 @@
     __syncthreads();                                                                                        \
     if (tid == 0) {                                                                                         \
       const u64 t_ = __builtin_readcyclecounter();                                                          \
-      atomicAdd((unsigned long long *)&a.ctrl[(FINAL ? 40 : 24) + slot], (unsigned long long)(t_ - tprev)); \
+      atomicAdd((unsigned long long *)&a.stamps[(((blockIdx.y * gridDim.x + blockIdx.x) & 1023u) << 3) + (FINAL ? 4 : 0) + slot], \
+                (unsigned long long)(t_ - tprev));                                                        \
       tprev = t_;                                                                                           \
     }                                                                                                       \
   }
@@ -932,8 +935,14 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
                  hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP};
   if (const char *e = pfd_knob("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
+  a.stamps = nullptr;
 #ifdef PFD_DEVTOOLS
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
+  if (a.ablate & 16) {
+    PFDCHK(stampbuf.alloc(8192 * sizeof(u64)));
+    a.stamps = stampbuf.as<u64>();
+    HIPCHK(hipMemsetAsync(a.stamps, 0, 8192 * sizeof(u64), h->stream));
+  }
 #endif
   if (h->count_rounds) a.ablate |= 32;
   is_block = h->halo_top || h->halo_bot;
@@ -1122,11 +1131,14 @@ int TiledRun::phase_b(int *complete) {
   if (a.ablate & 32) HIPCHK(hipMemcpy(h->tile_rounds, h->ctrl + 48, 4 * sizeof(u64), hipMemcpyDeviceToHost));
   if (fused_norm && !h->normalised) PFDCHK(pfd_adopt_counts(h, c0));  // bad codes / no pits surface here
   if (a.ablate & 16) {
-    u64 t[32];
-    HIPCHK(hipMemcpy(t, h->ctrl + 24, sizeof(t), hipMemcpyDeviceToHost));
+    std::vector<u64> st(8192);
+    HIPCHK(hipMemcpy(st.data(), a.stamps, 8192 * sizeof(u64), hipMemcpyDeviceToHost));
+    u64 t[8] = {0};
+    for (int r = 0; r < 1024; ++r)
+      for (int k = 0; k < 8; ++k) t[k] += st[8 * r + k];
     const double nt = (double)ntr * ntc;
     for (int ph = 0; ph < 2; ++ph) {
-      const u64 *q = t + 16 * ph;
+      const u64 *q = t + 4 * ph;
       fprintf(stderr, "[k_tile<%d>] cycles/tile: load %.0f init %.0f doubling %.0f out %.0f\n", ph, q[0] / nt,
               q[1] / nt, q[2] / nt, q[3] / nt);
     }
