@@ -175,6 +175,21 @@ __device__ __forceinline__ void stage_load(const u8 *__restrict__ ncode, u32 nro
     v[k] = w;
   }
 }
+// the same for an INTERIOR tile (the tile and its halo ring lie inside the raster, at least 4 columns from its
+// left and right edges): no clamping, no masking — a fifth of the VALU work of the general form, and the tile
+// kernels are VALU-bound
+__device__ __forceinline__ void stage_load_interior(const u8 *__restrict__ ncode, u32 ncol, i64 r0, i64 c0, u32 tid,
+                                                    u32 (&v)[5]) {
+  const u8 *base = ncode + (size_t)(r0 - 1) * ncol + (size_t)(c0 - 4);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const u32 idx = tid + 256u * k;
+    u32 hr = idx / 18u;
+    const u32 d = idx - hr * 18u;
+    hr = hr < HW - 1u ? hr : HW - 1u;  // (dwords past the staging area re-read its last row and are dropped)
+    __builtin_memcpy(&v[k], base + (size_t)hr * ncol + 4u * d, 4);
+  }
+}
 __device__ __forceinline__ void stage_store(u8 *code, u32 tid, const u32 (&v)[5]) {
 #pragma unroll
   for (int k = 0; k < 5; ++k) {

@@ -64,13 +64,10 @@
 // A neighbour's raw byte serves wherever a normalised one would: normalisation only ever turns a
 // cell into a pit (0) when its TARGET is nodata, and the halo ring is only asked "are you nodata"
 // and "do you point at this valid cell".
-template <bool FINAL, bool RAW = false>
-__global__ void __launch_bounds__(256) k_tile(TileArgs a) {
-  __shared__ __attribute__((aligned(16))) u32 A[TCELLS + 64];  // running subtree count of the cell (+64 sink words)
-  __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2^k-th ancestor | PDONE once saturated
-  // codes with a 1-cell halo.  The final pass needs neither the halo ring nor lookups of other
-  // cells' codes: it keeps its own quads' codes in registers (cq) and stages nothing.
-  __shared__ __attribute__((aligned(16))) u8 code[FINAL ? 16 : HW * CP];
+// INT: the tile is an interior one — it lies, halo ring and the 4 staging columns either side included, inside
+// the raster, and the raster is no row block.  All bounds handling compiles away; the branch is per workgroup.
+template <bool FINAL, bool RAW, bool INT>
+__device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P, u8 *code, u64 *s_cnt) {
   u64 tprev = __builtin_readcyclecounter();
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
@@ -88,22 +85,28 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       for (int j = 0; j < QPT; ++j) {  // own quads straight from HBM (clamped address, masked afterwards)
         const u32 l0 = 4u * tid + 1024u * j;
         const i64 gr = r0 + (l0 >> 6), gc0 = c0 + (l0 & 63);
-        const i64 crr = gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr;
-        const i64 ccs = gc0 >= (i64)a.ncol ? (i64)a.ncol - 1 : gc0;
         u32 w;
-        __builtin_memcpy(&w, a.ncode + (size_t)crr * a.ncol + (size_t)ccs, 4);  // (ncode carries slack)
+        if (INT) {
+          __builtin_memcpy(&w, a.ncode + (size_t)gr * a.ncol + (size_t)gc0, 4);
+        } else {
+          const i64 crr = gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr;
+          const i64 ccs = gc0 >= (i64)a.ncol ? (i64)a.ncol - 1 : gc0;
+          __builtin_memcpy(&w, a.ncode + (size_t)crr * a.ncol + (size_t)ccs, 4);  // (ncode carries slack)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (gr >= (i64)a.nrow || gc0 + b >= (i64)a.ncol) w = (w & ~(0xFFu << (8 * b))) | (D8_MV << (8 * b));
+          for (int b = 0; b < 4; ++b)
+            if (gr >= (i64)a.nrow || gc0 + b >= (i64)a.ncol) w = (w & ~(0xFFu << (8 * b))) | (D8_MV << (8 * b));
+        }
         cq[j] = w;
       }
+    } else if (INT) {
+      stage_load_interior(RAW ? a.raw : a.ncode, a.ncol, r0, c0, tid, v);
     } else if (RAW) {
       stage_load<true>(a.raw, a.nrow, a.ncol, r0, c0, tid, v, a.ntot);
     } else {
       stage_load(a.ncode, a.nrow, a.ncol, r0, c0, tid, v);
     }
     u32 nbad = 0, cnt = 0;  // RAW: cnt = valid | pits << 10 | bad << 20 of this thread's 16 cells
-    if (RAW && (a.row_first > 0 || a.row_last + 1 < a.nrow)) {
+    if (RAW && !INT && (a.row_first > 0 || a.row_last + 1 < a.nrow)) {
       // halo rows of a row block: weightless sinks (D8_HALO) wherever they are seen, ring included
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
@@ -152,9 +155,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       const u32 c4 = FINAL ? cq[j] : *(const u32 *)&CODE(lr, lc0);
       u32 w4[4], p4[4];
       // integer accuflux: the payload instead of unit weights (clamped address, masked by the code)
-      const i64 wrow = (i64)min((i64)(r0 + lr), (i64)a.nrow - 1) * (i64)a.ncol;
+      const i64 wrow = (INT ? (i64)(r0 + lr) : (i64)min((i64)(r0 + lr), (i64)a.nrow - 1)) * (i64)a.ncol;
       u32 n4 = 0;  // RAW: the normalised codes of the quad
-      const bool halorow = (i64)r0 + lr < (i64)a.row_first || (i64)r0 + lr > (i64)a.row_last;
+      const bool halorow = !INT && ((i64)r0 + lr < (i64)a.row_first || (i64)r0 + lr > (i64)a.row_last);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {  // branch-free: (dr, dc) from two packed 2-bit tables
         const u32 b = (u32)s ^ qs;   // logical position in the quad of register slot s
@@ -178,9 +181,12 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
         }
         const bool go = isdir && (unsigned)nr < TS && (unsigned)nc < TS;
         // nodata, pit, halo sink, or flow leaves the tile: the cell is its own root
-        p4[s] = go ? PHYS((u32)(nr * TS + nc)) : (l | PDONE);
+        // pointers are kept as BYTE offsets into P (2 x the physical index): the gather needs one AND, the
+        // atomic's address one shift more — the tile kernels are VALU-bound
+        p4[s] = go ? PHYS((u32)(nr * TS + nc)) << 1 : ((l << 1) | PDONE);
         u32 wv = 1u;
-        if (a.weights != nullptr) wv = (u32)a.weights[wrow + min((i64)(c0 + lc0) + (i64)b, (i64)a.ncol - 1)];
+        if (a.weights != nullptr)
+          wv = (u32)a.weights[wrow + (INT ? (i64)(c0 + lc0) + (i64)b : min((i64)(c0 + lc0) + (i64)b, (i64)a.ncol - 1))];
         w4[s] = (c != D8_MV && c != D8_HALO) ? wv : 0u;
       }
       *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
@@ -188,9 +194,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       if (RAW) {
         *(u32 *)&CODE(lr, lc0) = n4;  // (readers of the raw byte only ask "== nodata": unchanged)
         const i64 gr = r0 + lr, gc0 = c0 + lc0;
-        if (gr < (i64)a.nrow && gc0 < (i64)a.ncol) {
+        if (INT || (gr < (i64)a.nrow && gc0 < (i64)a.ncol)) {
           u8 *dst = a.ncode_w + (size_t)gr * a.ncol + (size_t)gc0;
-          if (gc0 + 3 < (i64)a.ncol) {
+          if (INT || gc0 + 3 < (i64)a.ncol) {
             __builtin_memcpy(dst, &n4, 4);  // (possibly unaligned) dword store
           } else {
             for (int k = 0; k < 4 && gc0 + k < (i64)a.ncol; ++k) dst[k] = (u8)(n4 >> (8 * k));
@@ -199,14 +205,13 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       }
     }
     if (RAW) {  // counts of the tile -> tcnt (summed by k_tile_counts: no same-address atomics)
-      __shared__ u64 s_cnt[4];
       u64 pk = (u64)(cnt & 1023u) | ((u64)((cnt >> 10) & 1023u) << 16) | ((u64)((cnt >> 20) + nbad) << 32);
       for (int o = 32; o > 0; o >>= 1) pk += __shfl_down(pk, o);
       if ((tid & 63u) == 0) s_cnt[tid >> 6] = pk;
       __syncthreads();
       if (tid == 0) a.tcnt[(size_t)tr * a.ntc + tc] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     }
-    if (FINAL && (a.row_first > 0 || a.row_last + 1 < a.nrow)) {
+    if (FINAL && !INT && (a.row_first > 0 || a.row_last + 1 < a.nrow)) {
       // row blocks: flow entering the owned boundary rows from the neighbouring GPUs
       __syncthreads();
       if (tid < 2 * TS) {
@@ -236,8 +241,8 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   TSTAMP(1)
 
   // ---- pointer doubling ------------------------------------------------------------------------
-  u32 pc[QPT * 4];   // current pointer word (ancestor | PDONE) of own cell 4*j+b
-  u32 live = 0;      // bit 4*j+b: own cell still has an unsaturated pointer
+  u32 pc[QPT * 4];   // current pointer word (2 x ancestor | PDONE) of own cell 4*j+b
+  u32 live = 0;      // bit j: own quad j still has an unsaturated pointer
 #pragma unroll
   for (int j = 0; j < QPT; ++j) {
     const u32 l0 = 4u * tid + 1024u * j;
@@ -246,60 +251,56 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     pc[4 * j + 1] = pp.x >> 16;
     pc[4 * j + 2] = pp.y & 0xFFFFu;
     pc[4 * j + 3] = pp.y >> 16;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (!(pc[4 * j + b] & PDONE)) live |= 1u << (4 * j + b);
-    }
+    if (!(pp.x & pp.y & (pp.x >> 16) & (pp.y >> 16) & PDONE)) live |= 1u << j;
   }
+  int round = 0;
   if (!(a.ablate & 1)) {
     // Branches are per QUAD only: inside a live quad all four cells run the same instruction
-    // stream; a saturated cell re-reads its root's pointer and adds 0 to it (harmless), which is
-    // cheaper than four exec-mask regions per quad and round.
-    int round = 0;
+    // stream; a saturated cell re-reads its root's pointer (its own value) and adds to a sink word,
+    // which is cheaper than four exec-mask regions per quad and round.
+    const u32 sink = (TCELLS + (tid & 63u)) * 4u;  // byte offset of this lane's sink word of A
     for (; round < MAXROUNDS_TILE; ++round) {
       u32 av[QPT * 4], q[QPT * 4];
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
-        if (live & (0xFu << (4 * j))) {
+        if (live & (1u << j)) {
           const uint4 a4 = *(const uint4 *)&A[4u * tid + 1024u * j];
           av[4 * j + 0] = a4.x;
           av[4 * j + 1] = a4.y;
           av[4 * j + 2] = a4.z;
           av[4 * j + 3] = a4.w;
 #pragma unroll
-          for (int b = 0; b < 4; ++b) q[4 * j + b] = P[pc[4 * j + b] & 0xFFFu];
+          for (int b = 0; b < 4; ++b) q[4 * j + b] = *(const uint16_t *)((const u8 *)P + (pc[4 * j + b] & 0x1FFEu));
         }
       }
       __syncthreads();  // every read of this round precedes every write of this round
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
-        if (live & (0xFu << (4 * j))) {
+        if (live & (1u << j)) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             const u32 p = pc[4 * j + b];
-            const bool done = p & PDONE;
-            // a saturated cell adds 0 to a per-lane sink word: adding it to its root would pile
-            // same-address LDS atomics onto the few roots of the tile (n-way bank conflicts)
-            atomicAdd(&A[done ? TCELLS + (tid & 63u) : (p & 0xFFFu)], done ? 0u : av[4 * j + b]);
-            pc[4 * j + b] = done ? p : q[4 * j + b];
+            // a saturated cell adds to a per-lane sink word nobody reads: adding to its root would pile
+            // same-address LDS atomics onto the few roots of the tile (n-way bank conflicts).  Its pointer
+            // needs no select: a root points at itself, so a saturated pointer re-reads its own value.
+            atomicAdd((u32 *)((u8 *)A + (p >= PDONE ? sink : (p & 0x1FFEu) << 1)), av[4 * j + b]);
+            pc[4 * j + b] = q[4 * j + b];
           }
-          const u32 d4 = ((pc[4 * j + 0] >> 15) & 1u) | ((pc[4 * j + 1] >> 14) & 2u) | ((pc[4 * j + 2] >> 13) & 4u) |
-                         ((pc[4 * j + 3] >> 12) & 8u);
-          live = (live & ~(0xFu << (4 * j))) | ((~d4 & 0xFu) << (4 * j));
+          if (pc[4 * j + 0] & pc[4 * j + 1] & pc[4 * j + 2] & pc[4 * j + 3] & PDONE) live &= ~(1u << j);
           *(uint2 *)&P[4u * tid + 1024u * j] =
               make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
         }
       }
       if (!__syncthreads_or((int)live)) break;
     }
-    if ((a.ablate & 32) && tid == 0) {  // profiling only: rounds this tile needed (max and sum over the tiles)
+    if ((a.ablate & 32) && tid == 0) {  // pfd_set_profiling(h, 2): rounds this tile needed (max and sum over the tiles)
       const unsigned long long r = (unsigned long long)min(round + 1, MAXROUNDS_TILE);
       atomicMax((unsigned long long *)&a.ctrl[FINAL ? 50 : 48], r);
       atomicAdd((unsigned long long *)&a.ctrl[FINAL ? 51 : 49], r);
     }
   }
   TSTAMP(2)
-  // a cell on or upstream of a cycle never saturates: count them (normally zero, so that no
+  // a cell on or upstream of a cycle never saturates: count their quads (normally zero, so that no
   // same-address global atomic is issued at all — 25k of them would cost ~0.3 ms)
   if (live) atomicAdd((unsigned long long *)&a.ctrl[T_UNSAT], (unsigned long long)__popc(live));
   __syncthreads();
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       const u32 l0 = 4u * tid + 1024u * j;
       const int lr = l0 >> 6, lc0 = l0 & 63;
       const i64 gr = r0 + lr, gc0 = c0 + lc0;
-      if (gr < (i64)a.row_first || gr > (i64)a.row_last || gc0 >= (i64)a.ncol) continue;
+      if (!INT && (gr < (i64)a.row_first || gr > (i64)a.row_last || gc0 >= (i64)a.ncol)) continue;
       const u32 c4 = cq[j];
       const uint4 a4 = *(const uint4 *)&A[l0];
       const u32 qs = (tid >> 3) & 3u;  // undo the swizzle: logical cell k sits in slot k ^ qs
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
       for (int b = 0; b < 4; ++b)
         if (((c4 >> (8 * b)) & 0xFFu) == D8_MV) o4[b] = -9999;
       i32 *dst = a.out + (size_t)(gr - a.row_first) * a.ncol + (size_t)gc0;
-      if (gc0 + 3 < (i64)a.ncol && (((size_t)dst) & 15) == 0) {
+      if ((INT || gc0 + 3 < (i64)a.ncol) && (((size_t)dst) & 15) == 0) {
         *(int4 *)dst = make_int4(o4[0], o4[1], o4[2], o4[3]);
       } else {
 #pragma unroll
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   __syncthreads();
   // where does the in-tile path of a cell end?  -> exit slot, halo sink (row block), or nothing
   auto path_end = [&](u32 l) -> u32 {
-    const u32 root = PHYS(P[PHYS(l)] & 0xFFFu);
+    const u32 root = PHYS((P[PHYS(l)] & 0x1FFEu) >> 1);
     const int rr = root >> 6, rc = root & 63;
     const u32 cr = CODE(rr, rc);
     if (cr == D8_HALO) return ENC_SINK | (((u32)r0 + (u32)rr > a.row_last) ? ENC_SIDE1 : 0u) | ((u32)c0 + (u32)rc);
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   }
   // row-block bookkeeping: flow collected by the halo sinks, first hop of the boundary rows — only the
   // tiles that hold a halo row or a boundary row of the block have any
-  if ((a.row_first > 0 && (u32)r0 <= a.row_first) || (a.row_last + 1 < a.nrow && (u32)r0 + TS > a.row_last)) {
+  if (!INT && ((a.row_first > 0 && (u32)r0 <= a.row_first) || (a.row_last + 1 < a.nrow && (u32)r0 + TS > a.row_last))) {
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
       const u32 l = tid + 256u * j;
@@ -410,6 +411,23 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
     }
   }
   TSTAMP(3)
+}
+
+template <bool FINAL, bool RAW = false>
+__global__ void __launch_bounds__(256) k_tile(TileArgs a) {
+  __shared__ __attribute__((aligned(16))) u32 A[TCELLS + 64];       // running subtree count of the cell (+64 sink words)
+  __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2 x (2^k-th ancestor) | PDONE once saturated
+  // codes with a 1-cell halo.  The final pass needs neither the halo ring nor lookups of other
+  // cells' codes: it keeps its own quads' codes in registers (cq) and stages nothing.
+  __shared__ __attribute__((aligned(16))) u8 code[FINAL ? 16 : HW * CP];
+  __shared__ u64 s_cnt[4];
+  const i64 r0 = (i64)blockIdx.y * TS, c0 = (i64)blockIdx.x * TS;
+  const bool interior = r0 >= 1 && c0 >= 4 && r0 + TS + 1 <= (i64)a.nrow && c0 + TS + 4 <= (i64)a.ncol &&
+                        a.row_first == 0 && a.row_last + 1 == a.nrow;
+  if (interior)
+    tile_body<FINAL, RAW, true>(a, A, P, code, s_cnt);
+  else
+    tile_body<FINAL, RAW, false>(a, A, P, code, s_cnt);
 }
 
 // per-tile counts of a raw pass -> the counters k_normalise would have left in ctrl
