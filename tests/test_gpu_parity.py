@@ -106,6 +106,9 @@ def test_strahler_basins_hand(case, flw):
     case.check("basins", bas)
     assert bas.dtype == np.uint32 and bas.max() <= flw.idxs_pit.size
     case.check("basins_sub_i16", flw.basins(idxs=D["basins_idxs"], ids=D["basins_ids"]))
+    # the same outlets given as coordinates (reference pyflwdir.py:564-599: idxs = self.index(*xy))
+    xs, ys = flw.xy(D["basins_idxs"])
+    case.check("basins_sub_i16", flw.basins(xy=(xs, ys), ids=D["basins_ids"]))
     case.check("hand_f32", flw.hand(D["drain"], D["elevtn"]))
     case.check("hand_f64", flw.hand(D["drain"], D["elevtn"].astype(np.float64) * 1.000001))
 
