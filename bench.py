@@ -67,7 +67,7 @@ def measured_traffic(kernel, nrow, ncol):
     return None if e is None else float(e["bytes_per_launch"])
 
 
-def roofline_upa(segs, n, nrow, ncol, ms_per_step):
+def roofline_upa(segs, n, nrow, ncol, ms_per_step, regime="river"):
     """Roofline object for the dominant KERNEL of the tiled pass (the tile pass that takes longest;
     the exit graph is many small launches and is reported in phases_ms) + the whole pass."""
     cand = [s for s in segs if s["name"] in KERNEL_OF] or segs
@@ -79,7 +79,9 @@ def roofline_upa(segs, n, nrow, ncol, ms_per_step):
     kname = KERNEL_OF.get(dom["name"], dom["name"])
     whole = B_ALG["upstream_area_cell"] * n / (ms_per_step * 1e-3) / 1e9
     return dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                frac=round(achieved / PEAK_HBM_GBS, 5), traffic=measured_traffic(kname, nrow, ncol), kernel=kname,
+                frac=round(achieved / PEAK_HBM_GBS, 5),
+                traffic=measured_traffic(kname, nrow, ncol) if regime == "river" else None,  # (PMC passes: river raster)
+                kernel=kname,
                 launches=dom["launches"], avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
                 whole_pass=dict(alg_bytes_per_cell=B_ALG["upstream_area_cell"], achieved=round(whole, 2),
                                 frac=round(whole / PEAK_HBM_GBS, 5)),
@@ -203,7 +205,7 @@ def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, ch
     segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
     out = dict(value=round(n * steps / total / 1e6, 2), ms_per_step=round(ms_per_step, 3),
                ms_per_step_median=round(statistics.median(per), 3), ms_per_step_min=round(min(per), 3),
-               roofline=roofline_upa(segs, n, nrow, ncol, ms_per_step))
+               roofline=roofline_upa(segs, n, nrow, ncol, ms_per_step, regime))
     cfg = dict(workload=label + ", upstream_area(unit='cell') int32 on 1 GPU; a step = decode + pit rule + validation "
                                 "+ tile pass + exit-graph solve + final tile pass on a fresh handle",
                n_cells=n, n_valid=info["n_valid"], n_pits=info["n_pits"], parallelism="1 GPU")
