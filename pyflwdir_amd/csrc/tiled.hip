@@ -77,7 +77,8 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
     for (u32 q = tid; q < a.nht; q += 256u) a.hcnt[q] = 0;
 
   // ---- stage the tile's codes (+halo) as dwords: all loads in flight before the first store ----
-  u32 cq[QPT];  // FINAL: the codes of the thread's quads
+  u32 cq[QPT];      // FINAL: the codes of the thread's quads
+  u32 wk[QPT * 4];  // local pass: the weights of the own cells (added to their roots after the pointer jumping)
   {
     u32 v[5];
     if (FINAL) {
@@ -189,7 +190,13 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
           wv = (u32)a.weights[wrow + (INT ? (i64)(c0 + lc0) + (i64)b : min((i64)(c0 + lc0) + (i64)b, (i64)a.ncol - 1))];
         w4[s] = (c != D8_MV && c != D8_HALO) ? wv : 0u;
       }
-      *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+      if (FINAL) {
+        *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+      } else {
+        *(uint4 *)&A[l0] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wk[4 * j + s] = w4[s];
+      }
       *(uint2 *)&P[l0] = make_uint2(p4[0] | (p4[1] << 16), p4[2] | (p4[3] << 16));
       if (RAW) {
         *(u32 *)&CODE(lr, lc0) = n4;  // (readers of the raw byte only ask "== nodata": unchanged)
@@ -259,6 +266,55 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
     // stream; a saturated cell re-reads its root's pointer (its own value) and adds to a sink word,
     // which is cheaper than four exec-mask regions per quad and round.
     const u32 sink = (TCELLS + (tid & 63u)) * 4u;  // byte offset of this lane's sink word of A
+    if (!FINAL) {
+      // The local pass only needs ROOTS (where does an entry's path end, which exit does a cell drain to) and
+      // the count per root (the local count of an exit) — not the count of every cell.  So it jumps pointers
+      // without carrying values, J_{k+1}(z) = J_k(J_k(z)): gather-only, half the LDS work of the value-carrying
+      // doubling, and a read that sees a pointer already advanced by its owner just jumps further (every value
+      // a pointer ever holds is an ancestor), so one barrier per round is enough.  Afterwards every cell adds
+      // its weight to its root.
+      for (; round < MAXROUNDS_TILE; ++round) {
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+          if (live & (1u << j)) {
+            u32 q[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) q[b] = *(const uint16_t *)((const u8 *)P + (pc[4 * j + b] & 0x1FFEu));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) pc[4 * j + b] = q[b];
+            if (q[0] & q[1] & q[2] & q[3] & PDONE) live &= ~(1u << j);
+            *(uint2 *)&P[4u * tid + 1024u * j] = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
+          }
+        }
+        if (!__syncthreads_or((int)live)) break;
+      }
+      // The four cells of a quad are neighbours in a row and mostly share their root: combine them in registers
+      // first (same-address LDS atomics are served one lane per cycle).
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        u32 r0 = pc[4 * j + 0], r1 = pc[4 * j + 1], r2 = pc[4 * j + 2], r3 = pc[4 * j + 3];
+        u32 w0 = wk[4 * j + 0], w1 = wk[4 * j + 1], w2 = wk[4 * j + 2], w3 = wk[4 * j + 3];
+        {
+          const bool e10 = r1 == r0;
+          w0 += e10 ? w1 : 0u;
+          w1 = e10 ? 0u : w1;
+          const bool e20 = r2 == r0, e21 = r2 == r1;
+          w0 += e20 ? w2 : 0u;
+          w1 += (!e20 && e21) ? w2 : 0u;
+          w2 = (e20 || e21) ? 0u : w2;
+          const bool e30 = r3 == r0, e31 = r3 == r1, e32 = r3 == r2;
+          w0 += e30 ? w3 : 0u;
+          w1 += (!e30 && e31) ? w3 : 0u;
+          w2 += (!e30 && !e31 && e32) ? w3 : 0u;
+          w3 = (e30 || e31 || e32) ? 0u : w3;
+        }
+        // (a cell that never saturated sits on or upstream of a cycle: the pass is redone by the level engine)
+        if (w0 && r0 >= PDONE) atomicAdd((u32 *)((u8 *)A + ((r0 & 0x1FFEu) << 1)), w0);
+        if (w1 && r1 >= PDONE) atomicAdd((u32 *)((u8 *)A + ((r1 & 0x1FFEu) << 1)), w1);
+        if (w2 && r2 >= PDONE) atomicAdd((u32 *)((u8 *)A + ((r2 & 0x1FFEu) << 1)), w2);
+        if (w3 && r3 >= PDONE) atomicAdd((u32 *)((u8 *)A + ((r3 & 0x1FFEu) << 1)), w3);
+      }
+    } else
     for (; round < MAXROUNDS_TILE; ++round) {
       u32 av[QPT * 4], q[QPT * 4];
 #pragma unroll
