@@ -78,7 +78,6 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
 
   // ---- stage the tile's codes (+halo) as dwords: all loads in flight before the first store ----
   u32 cq[QPT];      // FINAL: the codes of the thread's quads
-  u32 wk[QPT * 4];  // local pass: the weights of the own cells (added to their roots after the pointer jumping)
   {
     u32 v[5];
     if (FINAL) {
@@ -193,9 +192,7 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
       if (FINAL) {
         *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
       } else {
-        *(uint4 *)&A[l0] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) wk[4 * j + s] = w4[s];
+        *(uint4 *)&A[l0] = make_uint4(0u, 0u, 0u, 0u);  // (the weights are added to the roots after the pointer jumping)
       }
       *(uint2 *)&P[l0] = make_uint2(p4[0] | (p4[1] << 16), p4[2] | (p4[3] << 16));
       if (RAW) {
@@ -266,6 +263,7 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
     // stream; a saturated cell re-reads its root's pointer (its own value) and adds to a sink word,
     // which is cheaper than four exec-mask regions per quad and round.
     const u32 sink = (TCELLS + (tid & 63u)) * 4u;  // byte offset of this lane's sink word of A
+    const i64 r0_ = r0;                            // (the tile's first row; r0..r3 below are roots)
     if (!FINAL) {
       // The local pass only needs ROOTS (where does an entry's path end, which exit does a cell drain to) and
       // the count per root (the local count of an exit) — not the count of every cell.  So it jumps pointers
@@ -293,7 +291,26 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         u32 r0 = pc[4 * j + 0], r1 = pc[4 * j + 1], r2 = pc[4 * j + 2], r3 = pc[4 * j + 3];
-        u32 w0 = wk[4 * j + 0], w1 = wk[4 * j + 1], w2 = wk[4 * j + 2], w3 = wk[4 * j + 3];
+        // the weights again (from the staged codes; keeping 16 of them in registers through the rounds costs a
+        // wave of occupancy): register slot s holds logical cell s ^ qs of the quad
+        u32 wq[4];
+        {
+          const u32 l0 = 4u * tid + 1024u * j;
+          const int lr = l0 >> 6, lc0 = l0 & 63;
+          const u32 qs = (tid >> 3) & 3u;
+          const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+          const i64 wrow = (INT ? (i64)(r0_ + lr) : (i64)min((i64)(r0_ + lr), (i64)a.nrow - 1)) * (i64)a.ncol;
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) {
+            const u32 b = (u32)sl ^ qs;
+            const u32 c = (c4 >> (8 * b)) & 0xFFu;
+            u32 wv = 1u;
+            if (a.weights != nullptr)
+              wv = (u32)a.weights[wrow + (INT ? (i64)(c0 + lc0) + (i64)b : min((i64)(c0 + lc0) + (i64)b, (i64)a.ncol - 1))];
+            wq[sl] = (c != D8_MV && c != D8_HALO) ? wv : 0u;
+          }
+        }
+        u32 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
         {
           const bool e10 = r1 == r0;
           w0 += e10 ? w1 : 0u;
