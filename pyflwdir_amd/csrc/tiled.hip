@@ -830,25 +830,53 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
                                                       u32 *__restrict__ Tzero, const u32 *__restrict__ Jold,
                                                       u32 *__restrict__ Jnew, u32 nexits, u64 *ctrl,
                                                       const u64 *__restrict__ ncnt, u32 round) {
-  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  // As the pointers converge, thousands of nodes of a large basin push to the same few ancestors in one round, and
+  // same-address global atomics are served one after the other in L2 (~12 ns each: 0.4 ms per round at 90000^2).
+  // The workgroup therefore combines its pushes per target in a small LDS hash table first (integer adds: any
+  // order) and issues one global atomic per distinct target.
+  __shared__ u32 hk[512], hv[512];
+  const u32 tid = threadIdx.x;
+  hk[tid] = NONE32, hk[tid + 256u] = NONE32;
+  hv[tid] = 0, hv[tid + 256u] = 0;
+  const u32 e = blockIdx.x * blockDim.x + tid;
   if (ncnt) {
     // device-side node count (level 4).  After a hypertile overflow the level-4 graph is only
     // partly built (the pass is about to be redone flat): touch nothing.
     nexits = ctrl[T_OVERFLOW] ? 0u : min(nexits, (u32)*ncnt);
   }
-  if (e >= nexits) return;
-  const u32 j = Jold[e];
-  const u32 t = Told[e];
-  Tzero[e] = 0;
-  if (t) atomicAdd(&Tnew[e], t);
-  if (j & XDONE) {
-    Jnew[e] = j;
-    return;
+  __syncthreads();
+  bool moving = false;
+  if (e < nexits) {
+    const u32 j = Jold[e];
+    const u32 t = Told[e];
+    Tzero[e] = 0;
+    if (t) atomicAdd(&Tnew[e], t);  // (its own word: no contention)
+    if (j & XDONE) {
+      Jnew[e] = j;
+    } else {
+      const u32 q = Jold[j];
+      Jnew[e] = q;
+      moving = !(q & XDONE);
+      if (t) {
+        u32 slot = (j * 2654435761u) >> 23;  // 9 bits
+        for (;;) {
+          const u32 prev = atomicCAS(&hk[slot], NONE32, j);
+          if (prev == NONE32 || prev == j) {
+            atomicAdd(&hv[slot], t);
+            break;
+          }
+          slot = (slot + 1u) & 511u;
+        }
+      }
+    }
   }
-  const u32 q = Jold[j];
-  if (t) atomicAdd(&Tnew[j], t);
-  Jnew[e] = q;
-  if (round && !(q & XDONE)) {  // at most one store per wave, none once this round's mark is visible
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const u32 key = hk[tid + 256u * k], val = hv[tid + 256u * k];
+    if (key != NONE32 && val) atomicAdd(&Tnew[key], val);
+  }
+  if (round && moving) {  // at most one store per wave, none once this round's mark is visible
     const u64 m = __ballot(1);
     if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
       if (__hip_atomic_load(&ctrl[T_XACTIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (u64)round)
