@@ -232,7 +232,17 @@ extern "C" int pfd_malloc(int device, size_t bytes, void **ptr) {
     return PFD_EINVAL;
   }
   PFDCHK(select_device(device));
-  HIPCHK(hipMalloc(ptr, bytes ? bytes : 16));
+  hipError_t e = hipMalloc(ptr, bytes ? bytes : 16);
+  if (e != hipSuccess) {  // the library's own idle blocks may be what is in the way: give them back, retry once
+    (void)hipGetLastError();
+    pfd_trim(device);
+    e = hipMalloc(ptr, bytes ? bytes : 16);
+  }
+  if (e != hipSuccess) {
+    *ptr = nullptr;
+    pfd_set_error("pfd_malloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return PFD_ENOMEM;
+  }
   return PFD_OK;
 }
 extern "C" int pfd_free(int device, void *ptr) {

@@ -13,15 +13,18 @@
 //     => A_k(y) = sum of w over the upstream cells of y closer than 2^k   (exact, any order)
 //
 // log2(longest in-tile path) rounds, every lane busy, no dependent chains: the work per round
-// is a handful of LDS reads, one non-returning ds_add_u32 and one ds_write_b16 per cell.
+// is a handful of LDS reads, one non-returning ds_add_u32 and one ds_write_b16 per cell (final
+// pass; the local pass needs no values, see phase 1).
 // A pointer that runs off the end of its path saturates at the path's last cell ("root": the
 // cell where the flow leaves the tile, or a pit) and is flagged done; the roots of the
 // perimeter cells are exactly the links the coarse graph needs.
 //
-//   phase 1  k_tile<false>   per tile: local counts -> per perimeter slot: the local count of
-//                            every cell that drains out of the tile ("exit") and the slot it
-//                            drains into; for every perimeter cell that receives flow from
-//                            outside ("entry") the exit its in-tile path ends at ("link").
+//   phase 1  k_tile<false>   per tile: per perimeter slot the local count of every cell that
+//                            drains out of the tile ("exit") and the slot it drains into; for
+//                            every perimeter cell that receives flow from outside ("entry") the
+//                            exit its in-tile path ends at ("link").  Only roots and counts per
+//                            root are needed here, so this pass jumps pointers WITHOUT values
+//                            (gather-only) and adds every cell's weight to its root afterwards.
 //                            On a deferred handle (RAW) the pass also decodes / validates /
 //                            counts the raw codes and writes the normalised ones.
 //   phase 2  exit graph      the exits form a forest ~50x smaller than the raster:
