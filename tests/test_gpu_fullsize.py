@@ -43,6 +43,17 @@ def test_c3_30000_accuflux_strahler_vs_oracle(gpu_lib, oracle):
     w = O.synth_weights_f32(n, seed=1)
     assert np.array_equal(acc, O.accuflux(idxs_ds, seq, w))
     assert np.array_equal(strord, O.strahler_order(idxs_ds, seq))
+    # int32 accuflux of small non-negative weights rides the tiled engine (weights instead of ones in both tile
+    # passes): on the eager handle and on a deferred one, whose first tile pass also decodes the raster
+    wi = (np.arange(n, dtype=np.int64) * 2654435761 >> 7 & 3).astype(np.int32)
+    exp = O.accuflux(idxs_ds, seq, wi)
+    h.set_profiling(True)
+    got = h.accuflux(wi, _hip.PFD_I32, nodata_i=-9999, has_nodata=1)
+    assert "tile_local" in [s_["name"] for s_ in h.last_timing()]
+    assert np.array_equal(got, exp)
+    h.close()
+    h = _hip.RasterHandle(d8_buf, size, size, memspace=_hip.PFD_DEVICE, deferred=True)
+    assert np.array_equal(h.accuflux(wi, _hip.PFD_I32, nodata_i=-9999, has_nodata=1), exp)
     h.close()
 
 
