@@ -46,11 +46,10 @@ struct SuperArgs {
   u32 nst;          // number of supertiles
   const u32 *xT, *xtgt, *elink;  // xT = start values of the solve
   u32 *xin;         // [nslots] flow entering the supertile at this exit (from other supertiles)
-  u32 *T2;          // [nslots] supertile-local total of the exit
   u32 *R2;          // [nslots] last exit (slot) of the exit's path inside its supertile
   u32 *sxid;        // [nslots] dense id of a super-exit (drains into another supertile), else NONE32
   u32 *sx_slot;     // [nsuper] slot of the super-exit
-  u32 *T3;          // [nsuper] level-3 start value (= T2 of the super-exit)
+  u32 *T3;          // [nsuper] level-3 start value (= supertile-local total of the super-exit)
   u32 *inflow;      // [nslots] (final pass) flow delivered to the tile entries
   u64 *ctrl;
   u32 nstc, nhtc;   // supertiles / hypertiles per row
@@ -204,13 +203,13 @@ struct TiledRun {
   u32 ntr = 0, ntc = 0, nexits = 0;
   size_t nslots = 0;
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
-  DevBuf slots, sx, esink, bnd;  // per-slot arrays (8 x nslots), per-super-exit arrays (5 x cap)
+  DevBuf slots, sx, esink, bnd;  // per-slot arrays (7 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
   DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;
-  u32 *xT = nullptr, *xtgt = nullptr, *elink = nullptr, *inflow = nullptr, *xin = nullptr, *T2 = nullptr,
+  u32 *xT = nullptr, *xtgt = nullptr, *elink = nullptr, *inflow = nullptr, *xin = nullptr,
       *R2 = nullptr, *sxid = nullptr, *sx_slot = nullptr;
   SuperArgs sa{};
   u32 *brow_first = nullptr, *haloA = nullptr, *haloL = nullptr, *brow_sink = nullptr, *brow_inflow = nullptr;

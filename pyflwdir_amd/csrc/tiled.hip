@@ -558,7 +558,7 @@ __device__ __forceinline__ void flag_active(u64 *ctrl) {
 // stay inside the supertile.  Exits that drain into another supertile ("super-exits") are the
 // only nodes left for the global (level-3) solve: ~8x fewer nodes, ~8x shorter paths, and the
 // global atomics of the previous single-level solve become LDS atomics.
-//   FINAL == false: T2 = supertile-local total, R2 = last exit of the path inside the supertile,
+//   FINAL == false: R2 = last exit of the path inside the supertile,
 //                   dense ids + start values for the super-exits
 //   FINAL == true : exits start with their tile-local count + the flow entering the supertile
 //                   at them (xin, from level 3); every exit delivers its total to its tile entry
@@ -663,7 +663,6 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
     const u32 g = base + i;
     u32 id = NONE32;
     if (tg[j] != NONE32) {
-      s.T2[g] = T[i];
       s.R2[g] = base + (P[i] & (SSL - 1));
       if (rank[j] != NONE32) {
         id = s_base + rank[j];
@@ -1031,7 +1030,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   const size_t sxcap = (size_t)nst * 4 * SG * TS;  // super-exits sit on the supertile perimeter
   n3cap = std::max(sxcap, (size_t)nht * HCAP);
   n4cap = (size_t)nht * 4 * HG * SG * TS;           // hyper-exits sit on the hypertile perimeter
-  PFDCHK(slots.alloc(8 * nslots * sizeof(u32)));
+  PFDCHK(slots.alloc(7 * nslots * sizeof(u32)));
   PFDCHK(l3.alloc(8 * n3cap * sizeof(u32)));
   PFDCHK(l4.alloc(6 * n4cap * sizeof(u32)));
   PFDCHK(hcntbuf.alloc((size_t)nht * sizeof(u32)));
@@ -1040,7 +1039,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   u32 *q = slots.as<u32>();
   xtgt = q, elink = q + nslots, sxid = q + 2 * nslots;              // 0xFF-initialised
   xT = q + 3 * nslots, inflow = q + 4 * nslots, xin = q + 5 * nslots;  // zero-initialised
-  T2 = q + 6 * nslots, R2 = q + 7 * nslots;                          // written before read
+  R2 = q + 6 * nslots;                                                // written before read
   u32 *x = l3.as<u32>();
   sx_slot = x;
   Tc = x + n3cap, Tn = x + 2 * n3cap, Jc = x + 3 * n3cap, Jn = x + 4 * n3cap;
@@ -1054,7 +1053,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, hcntbuf.as<u32>(), nht, nullptr, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
-  sa = SuperArgs{nst, xT, xtgt, elink, xin, T2, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
+  sa = SuperArgs{nst, xT, xtgt, elink, xin, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
                  hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP};
   if (const char *e = pfd_knob("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
   a.stamps = nullptr;
