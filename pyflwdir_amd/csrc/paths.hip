@@ -149,6 +149,16 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
   };
 
   if (FINAL) {
+    // The result of an exit (hops from there to the pit / outlet met further down) goes into the exit cell's own
+    // word of V — a root, whose word holds 0 so far — by the <= 252 perimeter threads; every cell then reads its
+    // root's word from LDS instead of decoding the root and gathering from global memory itself.
+    if (tid < NPERIM) {
+      int plr, plc;
+      pslot_inv((int)tid, &plr, &plc);
+      const u32 l = (u32)(plr * TS + plc);
+      if (exit_slot_of(l) != NONE32) V[l] = a.xres[sbase + tid];
+    }
+    __syncthreads();
     u32 mx = 0;
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
@@ -167,17 +177,11 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
         if (MODE == MODE_RANK) {
           val = KEY_INVALID;
           if (c != D8_MV) {
-            val = V[l];
-            const u32 xs = exit_slot_of(root);
-            if (xs != NONE32) val += a.xres[xs];
+            val = V[l] + (root != l ? V[root] : 0u);  // hops to the root + the root's hops from there on
             mx = max(mx, val);
           }
         } else {
-          val = V[root];  // outlet at the end of the in-tile path (also: the cell's own seed)
-          if (!val && c != D8_MV) {
-            const u32 xs = exit_slot_of(root);
-            if (xs != NONE32) val = a.xres[xs];
-          }
+          val = V[root];  // outlet at the end of the in-tile path (the cell's own seed, or what the exit reaches)
         }
         o4[b] = val;
       }
@@ -192,8 +196,17 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
       }
     }
     if (MODE == MODE_RANK) {
+      // the longest path: one candidate per tile, and the atomic only if it can still raise the maximum (same-address
+      // global atomics are served one after the other: four per tile cost 10 ms at 30000^2)
+      __shared__ u32 s_mx[4];
       for (int o = 32; o > 0; o >>= 1) mx = max(mx, (u32)__shfl_down(mx, o));
-      if ((tid & 63) == 0 && mx) atomicMax((unsigned long long *)&a.ctrl[P_MAXRANK], (unsigned long long)mx);
+      if ((tid & 63) == 0) s_mx[tid >> 6] = mx;
+      __syncthreads();
+      if (tid == 0) {
+        const u32 m = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+        if ((u64)m > __hip_atomic_load(&a.ctrl[P_MAXRANK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicMax((unsigned long long *)&a.ctrl[P_MAXRANK], (unsigned long long)m);
+      }
     }
     return;
   }
