@@ -193,6 +193,13 @@ int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *el
  * for headwaters and nodata cells.  out: n indices of idx_dtype. */
 int pfd_main_upstream(pfd_raster *h, int dtype, const void *uparea, double upa_min, int idx_dtype, void *out,
                       int memspace);
+/* arithmetics.upstream_sum (reference pyflwdir/arithmetics.py:147-169; Flwdir.upstream_sum flwdir.py:412-433):
+ * per cell the sum of `data` over the cells directly upstream, in the payload dtype (int wrap-around, float
+ * addition in ascending cell index like the reference's loop); cells whose own or downstream value is `nodata`
+ * get nodata in the place the serial loop would write it; 0 elsewhere (headwaters, nodata cells).  has_nodata = 0:
+ * no value compares equal to the missing value (NaN, or not representable in the payload dtype). */
+int pfd_upstream_sum(pfd_raster *h, int dtype, const void *data, int64_t nodata_i, double nodata_f, int has_nodata,
+                     void *out, int memspace);
 /* streams.stream_order, the classic "bottom up" order (reference pyflwdir/streams.py:191-225;
  * Flwdir.stream_order(type="classic") flwdir.py:540-543): uint8; pits 1, tributaries (cells that
  * are not the main upstream cell of a downstream cell with more than one upstream cell inside

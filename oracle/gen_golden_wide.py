@@ -3,6 +3,7 @@
 either side of the hot path), recorded from the imported reference exactly like oracle/gen_golden.py does for
 the path itself (interpreted through the identity-njit shim; runs only where /root/reference exists).
 
+    tests/golden/wide_arith.npz    Flwdir.upstream_sum                        (reference pyflwdir/arithmetics.py:147-169)
     tests/golden/wide_dem.npz      dem.fill_depressions / from_dem            (reference pyflwdir/dem.py:17-143)
     tests/golden/wide_general.npz  NEXTXY rasters and FlwdirRaster(idxs_ds=...) with arbitrary links, all operations
     tests/golden/wide_snap.npz     Flwdir.snap, basins / add_pits with streams=
@@ -268,6 +269,36 @@ def gen_general():
 
 
 GENS = {"dem": gen_dem, "subgrid": gen_subgrid, "snap": gen_snap, "general": gen_general}
+
+def gen_arith():
+    """Flwdir.upstream_sum (reference pyflwdir/flwdir.py:412-433, arithmetics.py:147-169) for int32 / int64 /
+    float32 / float64 data with missing values in it, on the golden rasters."""
+    from pyflwdir_amd._affine import Affine  # noqa: F401
+    store = {}
+    rng = np.random.default_rng(11)
+    for name in ("flwdir0", "flwdir1", "synth_loops_96x80", "synth_tiny_5x7", "synth_onerow_1x300"):
+        fn = os.path.join(GOLD, name + ".npz")
+        if not os.path.exists(fn):
+            continue
+        d8 = np.load(fn)["d8"]
+        flw = pyflwdir.from_array(d8, ftype="d8", check_ftype=False)
+        for dt in ((np.int32, np.float32) if name == "flwdir1" else (np.int32, np.int64, np.float32, np.float64)):
+            if np.dtype(dt).kind == "i":
+                data = rng.integers(-50, 1000, size=d8.shape).astype(dt)
+            else:
+                data = (rng.random(d8.shape) * 100).astype(dt)
+            data[rng.random(d8.shape) < 0.05] = -9999  # missing values inside the domain
+            key = f"{name}_{np.dtype(dt).name}"
+            store["in_" + key] = data
+            store["out_" + key] = flw.upstream_sum(data, mv=-9999)
+        data = np.ones(d8.shape, np.float64)
+        store[f"out_{name}_ones_nan"] = flw.upstream_sum(data, mv=np.nan)  # a missing value that never compares equal
+    store["cases"] = np.array(repr(sorted(k[3:] for k in store if k.startswith("in_"))))
+    np.savez_compressed(os.path.join(GOLD, "wide_arith.npz"), **store)
+    print(f"[wide] arith: {len(store)} arrays")
+
+
+GENS["arith"] = gen_arith
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or GENS):

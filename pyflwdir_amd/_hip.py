@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_raster_create_general", "pfd_set_idxs_seq",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
 ]
 
 _lib = None
@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_main_upstream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int]
+        L.pfd_upstream_sum.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_int]
         L.pfd_stream_order_classic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_stream_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_graph_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -386,6 +387,13 @@ class RasterHandle:
             out = np.empty(self.n, idx_dtype)
         check(lib().pfd_main_upstream(self._h, dtype_code, ptr(uparea), float(upa_min), IDX_CODE[np.dtype(idx_dtype)],
                                       ptr(out), memspace))
+        return out
+
+    def upstream_sum(self, data, dtype_code, nodata_i=0, nodata_f=0.0, has_nodata=1, out=None, memspace=PFD_HOST):
+        if memspace == PFD_HOST:
+            out = np.empty_like(data)
+        check(lib().pfd_upstream_sum(self._h, dtype_code, ptr(data), int(nodata_i), float(nodata_f), int(has_nodata),
+                                     ptr(out), memspace))
         return out
 
     def stream_order_classic(self, idxs_us_main, mask=None, out=None, memspace=PFD_HOST):

@@ -1377,6 +1377,71 @@ extern "C" int pfd_main_upstream(pfd_raster *h, int dtype, const void *uparea, d
   return o.finish(h->stream);
 }
 
+// arithmetics.upstream_sum (reference pyflwdir/arithmetics.py:147-169; Flwdir.upstream_sum flwdir.py:412-433): the sum of
+// the values of the cells directly upstream.  The reference is a serial loop over ascending index
+//     if ds != mv and ds != i:  if data[i] == nodata or data[ds] == nodata: out[i] = nodata  else: out[ds] += data[i]
+// so what a cell x ends up with is decided by the events that touch out[x] in ascending index order: every upstream
+// cell c adds data[c] (unless data[c] or data[x] is nodata), and x itself, in its place among them, OVERWRITES out[x]
+// with nodata if data[x] or the value of its downstream cell is nodata.  Pull form: one thread per cell, neighbours
+// in ascending index with the cell itself between its W and E neighbour — the operand order of the serial loop.
+template <class T>
+__global__ void __launch_bounds__(256) k_upstream_sum(const u8 *__restrict__ ncode, Geo g, const T *__restrict__ data,
+                                                      T nodata, int has_nodata, T *__restrict__ out) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.n) return;
+  const u32 cx = ncode[x];
+  const T dx = data[x];
+  T acc = T(0);
+  const u32 row = geo_row(g, x), col = x - row * g.ncol;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {  // (-1,-1) (-1,0) (-1,1) (0,-1) SELF (0,1) (1,-1) (1,0) (1,1)
+    if (q == 4) {
+      if (d8_is_dir(cx)) {  // a pit points at itself, a nodata cell at nothing: no event
+        const T dd = data[d8_down(g, x, cx)];
+        if (has_nodata && (dx == nodata || dd == nodata)) acc = nodata;
+      }
+      continue;
+    }
+    const int dr = q / 3 - 1, dc = q % 3 - 1;
+    const i64 r = (i64)row + dr, c = (i64)col + dc;
+    if (r < 0 || r >= (i64)g.nrow || c < 0 || c >= (i64)g.ncol) continue;
+    const u32 nb = (u32)(r * (i64)g.ncol + c);
+    const u32 cn = ncode[nb];
+    if (!d8_is_dir(cn) || d8_down(g, nb, cn) != x) continue;
+    const T dn = data[nb];
+    if (!has_nodata || (dn != nodata && dx != nodata)) acc = Num<T>::add(acc, dn);
+  }
+  out[x] = acc;
+}
+
+extern "C" int pfd_upstream_sum(pfd_raster *h, int dtype, const void *data, int64_t nodata_i, double nodata_f,
+                                int has_nodata, void *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, "pfd_upstream_sum"));
+  PFDCHK(pfd_require_whole(h, "pfd_upstream_sum"));
+  const size_t ps = payload_bytes(dtype);
+  if (!data || !out || !ps) {
+    pfd_set_error("pfd_upstream_sum: bad arguments (dtype %d)", dtype);
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  InArg a;
+  PFDCHK(a.bind(data, (size_t)h->n * ps, memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * ps, memspace));
+  pfd_seg_begin(h, "upstream_sum");
+  const u32 grid = cdiv_u32(h->geo.n, 256);
+  switch (dtype) {
+    case PFD_I32: k_upstream_sum<i32><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const i32 *)a.dev, (i32)nodata_i, has_nodata, (i32 *)o.dev); break;
+    case PFD_I64: k_upstream_sum<i64><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const i64 *)a.dev, (i64)nodata_i, has_nodata, (i64 *)o.dev); break;
+    case PFD_F32: k_upstream_sum<float><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const float *)a.dev, (float)nodata_f, has_nodata, (float *)o.dev); break;
+    default: k_upstream_sum<double><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, (const double *)a.dev, nodata_f, has_nodata, (double *)o.dev); break;
+  }
+  KCHK();
+  pfd_seg_end(h, 1);
+  return o.finish(h->stream);
+}
+
 extern "C" int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void *idxs_us_main, const uint8_t *mask,
                                         uint8_t *out, int memspace) {
   PFDCHK(pfd_check_handle(h));

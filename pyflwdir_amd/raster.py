@@ -516,6 +516,17 @@ class FlwdirRaster(object):
                                direction=_hip.PFD_UP if direction == "up" else _hip.PFD_DOWN)
         return out.view(flat.dtype).reshape(data.shape)
 
+    def upstream_sum(self, data, mv=-9999):
+        """Sum of the values of the cells directly upstream; reference pyflwdir/flwdir.py:412-433,
+        pyflwdir/arithmetics.py:147-169 (incl. where its serial loop writes the missing value)."""
+        if self._d8 is None:  # (general graphs: the C layer would refuse as well)
+            raise NotImplementedError("upstream_sum is not available for flow directions with non-neighbour links")
+        data = np.asarray(data)
+        flat = self._check_data(data, "data")
+        view, code, nd_i, nd_f, has_nd = _payload_args(flat, mv)
+        out = self._h.upstream_sum(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd)
+        return out.view(flat.dtype).reshape(data.shape)
+
     def stream_order(self, type="strahler", mask=None):
         """Strahler stream order map (uint8); reference pyflwdir/flwdir.py:508-547.  Like the
         reference, the result is cached under "strord" when ``cache=True`` regardless of mask."""
