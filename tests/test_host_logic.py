@@ -181,3 +181,25 @@ def test_nextxy_codec_host():
     dsu = nextxy.from_array((nextx, nexty), dtype=np.uint32)[0]
     assert dsu[4] == np.uint32(4294967295)
     assert not nextxy.isvalid(np.zeros((3, 3), np.int32))
+
+
+def test_bench_spread_rasters_are_valid_and_acyclic(oracle):
+    """The host-built rasters of bench.py's workload-spread lines (Rhine mosaic, serpentine tiles) hold only D8
+    codes and no cycle: every valid cell is ordered by the oracle's idxs_seq, so the timed pass never leaves the
+    tiled engine for them."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for d8 in (bench.rhine_mosaic(1500), bench.serpentine(200, 330)):
+        assert d8.dtype == np.uint8 and d8.flags["C_CONTIGUOUS"]
+        assert np.isin(d8, (0, 1, 2, 4, 8, 16, 32, 64, 128, 247, 255)).all()
+        idxs_ds, idxs_pit, n_valid = oracle.from_array(d8)
+        seq = oracle.idxs_seq(idxs_ds, idxs_pit)
+        assert seq.size == n_valid == int((d8 != 247).sum())
+    s = bench.serpentine(64, 64)
+    idxs_ds, idxs_pit, _ = oracle.from_array(s)
+    assert idxs_pit.size == 1 and oracle.rank(idxs_ds)[0].max() == 4095  # one 4096-cell path per tile
