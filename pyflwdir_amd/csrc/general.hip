@@ -51,22 +51,31 @@ template <class I>
 __global__ void __launch_bounds__(256) k_gen_import(const I *__restrict__ src, u32 n, u32 *__restrict__ ds,
                                                     u8 *__restrict__ ncode, unsigned long long *__restrict__ cnt) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n) return;
-  const I v = src[x];
-  u32 d = GNONE, code = D8_MV;
-  if (v != (I)-1) {  // (-1 cast to the index dtype = the reference's missing value)
-    const unsigned long long t = (unsigned long long)v;
-    if (t >= (unsigned long long)n) {
-      atomicAdd(&cnt[2], 1ull);
-    } else {
-      d = (u32)t;
-      code = d == x ? 0u : 1u;  // the byte raster only tells nodata / pit / other apart on this engine
-      atomicAdd(&cnt[0], 1ull);
-      if (d == x) atomicAdd(&cnt[1], 1ull);
+  bool valid = false, pit = false, bad = false;
+  if (x < n) {
+    const I v = src[x];
+    u32 d = GNONE, code = D8_MV;
+    if (v != (I)-1) {  // (-1 cast to the index dtype = the reference's missing value)
+      const unsigned long long t = (unsigned long long)v;
+      if (t >= (unsigned long long)n) {
+        bad = true;
+      } else {
+        d = (u32)t;
+        code = d == x ? 0u : 1u;  // the byte raster only tells nodata / pit / other apart on this engine
+        valid = true;
+        pit = d == x;
+      }
     }
+    ds[x] = d;
+    ncode[x] = (u8)code;
   }
-  ds[x] = d;
-  ncode[x] = (u8)code;
+  // one atomic per wave and counter (one per cell would queue up n same-address atomics in L2)
+  const u32 nv = (u32)__popcll(__ballot(valid)), np = (u32)__popcll(__ballot(pit)), nb = (u32)__popcll(__ballot(bad));
+  if ((threadIdx.x & 63u) == 0) {
+    if (nv) atomicAdd(&cnt[0], (unsigned long long)nv);
+    if (np) atomicAdd(&cnt[1], (unsigned long long)np);
+    if (nb) atomicAdd(&cnt[2], (unsigned long long)nb);
+  }
 }
 __global__ void __launch_bounds__(256) k_gen_check_targets(const u32 *__restrict__ ds, u32 n, unsigned long long *__restrict__ cnt) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
