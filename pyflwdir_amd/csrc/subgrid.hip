@@ -23,9 +23,22 @@ __global__ void k_mark_cells(const i64 *__restrict__ idx, u32 k, u8 *__restrict_
 __global__ void __launch_bounds__(256) k_ucat_count(const u32 *__restrict__ lab, const u8 *__restrict__ is_out, u32 n,
                                                     u32 *__restrict__ cnt) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n) return;
-  const u32 u = lab[x];
-  if (u && !is_out[x]) atomicAdd(&cnt[u - 1], 1u);
+  u32 u = 0;
+  if (x < n) {
+    u = lab[x];
+    if (is_out[x]) u = 0;
+  }
+  // neighbouring cells mostly carry the same label: the first lane of a run of equal labels adds the run's
+  // length (a large catchment would otherwise queue up one same-address atomic per cell in L2)
+  const u32 lane = threadIdx.x & 63u;
+  const u32 prev = (u32)__shfl_up((int)u, 1);
+  const bool head = lane == 0 || prev != u;
+  const u64 heads = __ballot(head);
+  if (head && u) {
+    const u64 later = lane == 63u ? 0ull : (heads >> (lane + 1u));
+    const u32 len = later ? (u32)__ffsll((long long)later) : 64u - lane;
+    atomicAdd(&cnt[u - 1], len);
+  }
 }
 __global__ void __launch_bounds__(256) k_ucat_keys(const u32 *__restrict__ oseq, u32 nseq, const u32 *__restrict__ lab,
                                                    const u8 *__restrict__ is_out, u32 *__restrict__ keys) {
