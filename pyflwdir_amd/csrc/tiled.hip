@@ -69,7 +69,11 @@
 // and "do you point at this valid cell".
 // INT: the tile is an interior one — it lies, halo ring and the 4 staging columns either side included, inside
 // the raster, and the raster is no row block.  All bounds handling compiles away; the branch is per workgroup.
-template <bool FINAL, bool RAW, bool INT>
+// PERIM (local pass of a WHOLE raster): only the exits of the tile need a count, so A holds PREP words per perimeter
+// slot instead of one per cell (8 KB instead of 16.6 KB of LDS: a sixth workgroup per CU) — cells whose root is a pit
+// issue no atomic at all, and the PREP replicas of a slot (picked by lane) spread the same-address ones.
+#define PREP 8
+template <bool FINAL, bool RAW, bool INT, bool PERIM>
 __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P, u8 *code, u64 *s_cnt) {
   u64 tprev = __builtin_readcyclecounter();
   const u32 tid = threadIdx.x;
@@ -194,8 +198,10 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
       }
       if (FINAL) {
         *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-      } else {
+      } else if (!PERIM) {
         *(uint4 *)&A[l0] = make_uint4(0u, 0u, 0u, 0u);  // (the weights are added to the roots after the pointer jumping)
+      } else if (j < 2) {
+        *(uint4 *)&A[4u * tid + 1024u * j] = make_uint4(0u, 0u, 0u, 0u);  // 256 x PREP words
       }
       *(uint2 *)&P[l0] = make_uint2(p4[0] | (p4[1] << 16), p4[2] | (p4[3] << 16));
       if (RAW) {
@@ -329,10 +335,20 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
           w3 = (e30 || e31 || e32) ? 0u : w3;
         }
         // (a cell that never saturated sits on or upstream of a cycle: the pass is redone by the level engine)
-        if (w0 && r0 >= PDONE) atomicAdd((u32 *)((u8 *)A + ((r0 & 0x1FFEu) << 1)), w0);
-        if (w1 && r1 >= PDONE) atomicAdd((u32 *)((u8 *)A + ((r1 & 0x1FFEu) << 1)), w1);
-        if (w2 && r2 >= PDONE) atomicAdd((u32 *)((u8 *)A + ((r2 & 0x1FFEu) << 1)), w2);
-        if (w3 && r3 >= PDONE) atomicAdd((u32 *)((u8 *)A + ((r3 & 0x1FFEu) << 1)), w3);
+        auto push = [&](u32 r, u32 w) {
+          if (!w || r < PDONE) return;
+          if (!PERIM) {
+            atomicAdd((u32 *)((u8 *)A + ((r & 0x1FFEu) << 1)), w);
+          } else {
+            const u32 L = PHYS((r & 0x1FFEu) >> 1);  // logical index of the root
+            const int ps = pslot((int)(L >> 6), (int)(L & 63u));
+            if (ps >= 0) atomicAdd(&A[(u32)ps * PREP + (tid & (PREP - 1u))], w);  // (a pit inside the tile: nobody asks)
+          }
+        };
+        push(r0, w0);
+        push(r1, w1);
+        push(r2, w2);
+        push(r3, w3);
       }
     } else
     for (; round < MAXROUNDS_TILE; ++round) {
@@ -427,7 +443,12 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
         if ((unsigned)nr >= TS || (unsigned)nc >= TS) {
           const i64 gr = r0 + nr, gc = c0 + nc;  // inside the raster and valid (normalised codes)
           tgt = sslot_base((u32)(gr >> 6), (u32)(gc >> 6), a.nstc) + (u32)pslot((int)(gr & 63), (int)(gc & 63));
-          xt = A[PHYS((u32)(plr * TS + plc))];
+          if (!PERIM) {
+            xt = A[PHYS((u32)(plr * TS + plc))];
+          } else {
+            const uint4 lo = *(const uint4 *)&A[tid * PREP], hi = *(const uint4 *)&A[tid * PREP + 4];
+            xt = lo.x + lo.y + lo.z + lo.w + hi.x + hi.y + hi.z + hi.w;
+          }
         }
       }
     }
@@ -472,7 +493,7 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
   }
   // row-block bookkeeping: flow collected by the halo sinks, first hop of the boundary rows — only the
   // tiles that hold a halo row or a boundary row of the block have any
-  if (!INT && ((a.row_first > 0 && (u32)r0 <= a.row_first) || (a.row_last + 1 < a.nrow && (u32)r0 + TS > a.row_last))) {
+  if (!INT && !PERIM && ((a.row_first > 0 && (u32)r0 <= a.row_first) || (a.row_last + 1 < a.nrow && (u32)r0 + TS > a.row_last))) {
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
       const u32 l = tid + 256u * j;
@@ -489,9 +510,10 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
   TSTAMP(3)
 }
 
-template <bool FINAL, bool RAW = false>
+template <bool FINAL, bool RAW = false, bool PERIM = false>
 __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
-  __shared__ __attribute__((aligned(16))) u32 A[TCELLS + 64];       // running subtree count of the cell (+64 sink words)
+  // running subtree count of the cell (+64 sink words) — or, PERIM, PREP count words per perimeter slot
+  __shared__ __attribute__((aligned(16))) u32 A[PERIM ? 256 * PREP : TCELLS + 64];
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2 x (2^k-th ancestor) | PDONE once saturated
   // codes with a 1-cell halo.  The final pass needs neither the halo ring nor lookups of other
   // cells' codes: it keeps its own quads' codes in registers (cq) and stages nothing.
@@ -501,9 +523,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   const bool interior = r0 >= 1 && c0 >= 4 && r0 + TS + 1 <= (i64)a.nrow && c0 + TS + 4 <= (i64)a.ncol &&
                         a.row_first == 0 && a.row_last + 1 == a.nrow;
   if (interior)
-    tile_body<FINAL, RAW, true>(a, A, P, code, s_cnt);
+    tile_body<FINAL, RAW, true, PERIM>(a, A, P, code, s_cnt);
   else
-    tile_body<FINAL, RAW, false>(a, A, P, code, s_cnt);
+    tile_body<FINAL, RAW, false, PERIM>(a, A, P, code, s_cnt);
 }
 
 // per-tile counts of a raw pass -> the counters k_normalise would have left in ctrl
@@ -1187,13 +1209,19 @@ int TiledRun::phase_a() {
     if (!tcntbuf.p) PFDCHK(tcntbuf.alloc((size_t)ntr * ntc * sizeof(u64)));
     a.raw = h->raw;
     a.tcnt = tcntbuf.as<u64>();
-    k_tile<false, true><<<grid, 256, 0, h->stream>>>(a);
+    if (is_block)
+      k_tile<false, true><<<grid, 256, 0, h->stream>>>(a);
+    else
+      k_tile<false, true, true><<<grid, 256, 0, h->stream>>>(a);
     fused_norm = true;
     KCHK();
     pfd_seg_end(h, 1);
     k_tile_counts<<<std::min<u32>(cdiv_u32((u64)ntr * ntc, 4096), 256u), 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);
   } else {
-    k_tile<false><<<grid, 256, 0, h->stream>>>(a);
+    if (is_block)
+      k_tile<false><<<grid, 256, 0, h->stream>>>(a);
+    else
+      k_tile<false, false, true><<<grid, 256, 0, h->stream>>>(a);
     KCHK();
     pfd_seg_end(h, 1);
   }
