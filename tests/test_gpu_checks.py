@@ -40,3 +40,32 @@ def test_stats_and_verifier(gpu_lib, oracle, shape, kw):
         bad[np.flatnonzero(d8.ravel() == 247)[0]] = 0
         assert h.verify_upstream_area_cell(bad)["bad_nodata"] == 1
     h.close()
+
+
+def test_tile_round_statistics(gpu_lib):
+    """pfd_set_profiling(h, 2) counts the pointer-doubling rounds of the tile passes (pfd_graph_stats[12..15]): a
+    raster whose every 64 x 64 tile is one 4096-cell path needs log2(4096) = 12 rounds in every tile, a raster of
+    isolated pits none beyond the first."""
+    from pyflwdir_amd import _hip
+
+    t = np.empty((64, 64), np.uint8)
+    t[0::2, :] = 1
+    t[1::2, :] = 16
+    t[0::2, 63] = 4
+    t[1::2, 0] = 4
+    t[63, 0] = 0
+    d8 = np.ascontiguousarray(np.tile(t, (5, 7)))
+    h = _hip.RasterHandle(d8, d8.shape[0], d8.shape[1], deferred=True)
+    h.set_profiling(2)
+    upa = h.upstream_area_cell().reshape(d8.shape)
+    st = h.graph_stats()["tile_rounds"]
+    h.close()
+    assert upa.max() == 4096 and st["local_max"] == st["final_max"] == 12
+    assert st["local_mean"] == st["final_mean"] == 12.0 and h is not None
+    pits = np.zeros((130, 70), np.uint8)
+    h = _hip.RasterHandle(pits, 130, 70, deferred=True)
+    h.set_profiling(2)
+    assert (h.upstream_area_cell() == 1).all()
+    st = h.graph_stats()["tile_rounds"]
+    h.close()
+    assert st["local_max"] == st["final_max"] == 1
