@@ -340,9 +340,15 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
           if (!PERIM) {
             atomicAdd((u32 *)((u8 *)A + ((r & 0x1FFEu) << 1)), w);
           } else {
+            // perimeter slot of the root, branch-free (pslot(), tiled.h): row 0 -> lc, row 63 -> 64 + lc,
+            // column 0 -> 127 + lr, column 63 -> 189 + lr; (x + 1) & 62 == 0 exactly for x in {0, 63}
             const u32 L = PHYS((r & 0x1FFEu) >> 1);  // logical index of the root
-            const int ps = pslot((int)(L >> 6), (int)(L & 63u));
-            if (ps >= 0) atomicAdd(&A[(u32)ps * PREP + (tid & (PREP - 1u))], w);  // (a pit inside the tile: nobody asks)
+            const u32 lr = L >> 6, lc = L & 63u;
+            const bool tb = ((lr + 1u) & 62u) == 0u, lrc = ((lc + 1u) & 62u) == 0u;
+            const u32 s_tb = lc + ((lr + 1u) & 64u);
+            const u32 s_lr = 127u + lr + (((lc + 1u) & 64u) - (((lc + 1u) >> 5) & 2u));
+            const u32 ps = tb ? s_tb : s_lr;
+            if (tb || lrc) atomicAdd(&A[ps * PREP + (tid & (PREP - 1u))], w);  // (a pit inside the tile: nobody asks)
           }
         };
         push(r0, w0);
