@@ -182,16 +182,35 @@ def serpentine(nrow, ncol):
     return np.ascontiguousarray(np.tile(t, (-(-nrow // 64), -(-ncol // 64)))[:nrow, :ncol])
 
 
+def filled_mosaic(min_edge=10000, base=2048, device=0):
+    """The realistic variant SURVEY 8d asks for: the synthetic elevation (rough regime) of a base x base raster,
+    depression-filled by the library's priority flood (fill_depressions, reference pyflwdir/dem.py:17-143) so that
+    rivers run through the former pits to the raster edge, tiled like the Rhine mosaic (nodata frame per copy)."""
+    from pyflwdir_amd import dem
+
+    elev = _hip.synth_elev_device(base, base, device=device, **REGIMES["rough"])
+    z = elev.download(np.float32, (base, base))
+    elev.free()
+    _, d8 = dem.fill_depressions(z)
+    framed = np.full((base + 2, base + 2), 247, np.uint8)
+    framed[1:-1, 1:-1] = d8
+    reps = (-(-min_edge // framed.shape[0]), -(-min_edge // framed.shape[1]))
+    return np.ascontiguousarray(np.tile(framed, reps))
+
+
 def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, checks=True, invariant_checks=None):
     """The upstream_area("cell") pass on one GPU: returns the JSON fields of one bench line."""
-    if regime in ("rhine_mosaic", "serpentine"):
-        host = rhine_mosaic(min(nrow, ncol)) if regime == "rhine_mosaic" else serpentine(nrow, ncol)
+    if regime in ("rhine_mosaic", "serpentine", "filled_mosaic"):
+        host = (rhine_mosaic(min(nrow, ncol)) if regime == "rhine_mosaic" else
+                filled_mosaic(min(nrow, ncol), device=device) if regime == "filled_mosaic" else serpentine(nrow, ncol))
         nrow, ncol = host.shape
         synth = dict(seed=None, tilt=None)
         d8_buf = _hip.DeviceBuffer(host.size, device)
         d8_buf.upload(host)
         label = (f"{nrow}x{ncol} mosaic of the reference's Rhine sub-basin (682x997 cells, nodata frame per copy)"
                  if regime == "rhine_mosaic" else
+                 f"{nrow}x{ncol} mosaic of a depression-filled synthetic DEM (2048x2048, fill_depressions, nodata frame per copy)"
+                 if regime == "filled_mosaic" else
                  f"{nrow}x{ncol} serpentine tiles (every 64x64 tile one 4096-cell path: worst case of the tile pass)")
     else:
         synth = REGIMES[regime]
@@ -471,7 +490,7 @@ def main():
         sec += c3_lines(30000, a.regime, 3, device)
         # workload spread: the same pass on a rough surface, on a pit-riddled one, on a mosaic of the reference's real
         # Rhine raster and on the tile pass's worst case, with the graph statistics that explain the differences
-        for reg in ("rough", "meander", "rhine_mosaic", "serpentine"):
+        for reg in ("rough", "meander", "rhine_mosaic", "filled_mosaic", "serpentine"):
             if reg == a.regime:
                 continue
             l3, c3 = upa_line(10000, 10000, reg, 10, 2, device, cpu=False, checks=True)
