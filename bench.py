@@ -14,11 +14,12 @@ raster and every structure the kernels need (a fresh raster handle per step; not
 between steps).  Inputs are generated in HBM by the device twin of the oracle's synthetic generator
 before the timed region; the result stays in HBM.
 
-N > 1 (launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`):
-STRONG scaling — the same size x size raster is split into N row blocks (size/N rows each + one halo
-row per inner edge), one block per rank/GPU, one RCCL all-gather of the boundary records per pass
-(DESIGN.md §4.4).  torch.distributed (gloo) is only used for the barrier and the max-reduce of the
-wall time.
+N > 1: STRONG scaling — the same size x size raster is split into N row blocks (size/N rows each + one
+halo row per inner edge), one block per rank/GPU, one RCCL all-gather of the boundary records per pass
+(DESIGN.md §4.4).  `python bench.py --gpus N` starts its N ranks itself (plain processes, LOCAL_RANK = GPU
+index); under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) the
+launcher's RANK / WORLD_SIZE / MASTER_* are used.  Either way the host side (barrier, max-reduce of the wall
+time, rendezvous of the RCCL unique id) is the library's torch-free TCP group; no PyTorch is imported.
 
 With N = 1 the JSON line also carries `secondary`: the 10000 x 10000 pass (configs[1]) and the
 configs[2] operations (float32 accuflux + Strahler order at 30000 x 30000), each with its own
@@ -364,6 +365,27 @@ def c3_lines(size, regime, steps, device):
     return lines
 
 
+N1_RECORD = os.path.join(ROOT, ".bench_n1.json")  # (git-ignored scratch: lets the N > 1 lines quote their speed-up)
+
+
+def save_n1_record(a, out):
+    try:
+        with open(N1_RECORD, "w") as f:
+            json.dump(dict(size=a.size, regime=a.regime, ms_per_step=out["ms_per_step"],
+                           result_checksum=out.get("invariants", {}).get("result_checksum")), f)
+    except OSError:
+        pass
+
+
+def load_n1_record(a):
+    try:
+        with open(N1_RECORD) as f:
+            r = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return r if r.get("size") == a.size and r.get("regime") == a.regime else None
+
+
 def run_distributed(a, rank, world, local):
     """N > 1: one rank per GPU, STRONG scaling — the size x size raster is split into N row blocks;
     every rank generates its own rows (+ one halo row per inner edge) directly in its HBM."""
@@ -372,10 +394,10 @@ def run_distributed(a, rank, world, local):
 
     for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
         os.environ.setdefault(k, v)  # (only missing for the single-process PFD_BENCH_FORCE_DIST run)
-    # host-side group for barrier / max-reduce / unique-id rendezvous.  Launched by torch.distributed.run the
-    # rendezvous store of torch is already there (gloo, CPU); PFD_BENCH_GROUP=tcp uses the library's own
-    # torch-free TCP group instead
-    if os.environ.get("PFD_BENCH_GROUP", "torch") == "tcp":
+    # host-side group for barrier / max-reduce / unique-id rendezvous: the library's own torch-free TCP group
+    # (MASTER_ADDR / MASTER_PORT + 23: next to, not on, the port of a launcher's store).  PFD_BENCH_GROUP=torch
+    # uses the gloo group of torch.distributed instead (only meaningful under torch.distributed.run)
+    if os.environ.get("PFD_BENCH_GROUP", "tcp") == "tcp":
         grp = hostgroup.HostGroup(rank, world)
     else:
         import torch.distributed as tdist
@@ -395,6 +417,7 @@ def run_distributed(a, rank, world, local):
     probe = pdist.DistributedRaster(d8_buf, own, ncol, rank, world, device, memspace=_hip.PFD_DEVICE, group=grp,
                                     transport=os.environ.get("PFD_DIST_TRANSPORT", "auto"), deferred=True)
     comm, transport = probe.comm, probe.transport
+    rccl_world = comm.info()["nranks"] if comm is not None else None  # (what RCCL itself reports)
     probe.handle.close()
 
     def step(profile=False):
@@ -452,15 +475,103 @@ def run_distributed(a, rank, world, local):
                                         "the boundary records + interface solve + final pass on fresh handles",
                                n_cells=n, n_valid=n_valid, n_pits=n_pits,
                                parallelism=f"{world} row blocks, 1 all-gather/pass", transport=transport,
-                               host_group=type(grp).__name__),
+                               rccl_world_size=rccl_world, host_group=type(grp).__name__,
+                               launcher="self-spawned" if os.environ.get("PFD_BENCH_SPAWNED") else "external",
+                               devices_visible=_hip.device_count()),
                    roofline=roof,
                    invariants=dict(result_checksum=csum,
                                    last_row_pit_sum_equals_n_valid=bool(pit_sum == n_valid) if a.regime == "river" else None))
+        n1 = load_n1_record(a)
+        if n1 is not None:  # the N = 1 run of the same raster on this box (bench.py writes it at N = 1)
+            out["speedup_vs_n1"] = round(n1["ms_per_step"] / ms_per_step, 3)
+            out["n1_ms_per_step"] = n1["ms_per_step"]
+            if n1.get("result_checksum") is not None:
+                out["invariants"]["result_checksum_equals_n1"] = bool(n1["result_checksum"] == csum)
         print(json.dumps(out))
     grp.barrier()
     if comm is not None:
         comm.close()
     grp.close()
+
+
+def free_port():
+    """A TCP port on 127.0.0.1 with 64 free ports above it (MASTER_PORT; the host group listens on MASTER_PORT + 23)."""
+    import socket
+
+    for _ in range(64):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        if port + 64 >= 65535:
+            continue
+        try:
+            t = socket.socket()
+            t.bind(("127.0.0.1", port + 23))
+            t.close()
+            return port
+        except OSError:
+            continue
+    raise RuntimeError("no free TCP port pair on 127.0.0.1")
+
+
+def rank_environments(n, n_devices, port, base_env=None):
+    """Environment of each of the n ranks `bench.py --gpus n` starts itself: the variables a launcher would set
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), the torch-free TCP host group, dmabuf IPC for RCCL.
+    LOCAL_RANK is the GPU index; with fewer GPUs than ranks (test boxes) the ranks share GPUs and the boundary
+    records travel through the host group, because RCCL refuses two ranks on one device."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base_env is None else base_env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 PFD_BENCH_SPAWNED="1")
+        e.setdefault("PFD_BENCH_GROUP", "tcp")
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if n_devices < n:
+            e.setdefault("PFD_DIST_TRANSPORT", "host")
+        envs.append(e)
+    return envs
+
+
+def spawn_ranks(a, argv=None, n_devices=None, timeout=3000.0, script=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as plain processes (one per GPU), pass rank
+    0's JSON line through on stdout, return the first non-zero exit code.  A rank that dies takes the others down
+    (each child is killed by its own PID) instead of leaving them waiting in a collective."""
+    import subprocess
+
+    n_devices = _hip.device_count() if n_devices is None else n_devices
+    if n_devices < 1:
+        raise SystemExit("bench.py: no HIP device visible")
+    argv = sys.argv[1:] if argv is None else argv
+    envs = rank_environments(a.gpus, n_devices, free_port())
+    procs = []
+    for r, e in enumerate(envs):
+        # rank 0 owns stdout (the one JSON line); whatever another rank prints goes to stderr
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.time() + timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if live and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 124
+            time.sleep(2.0 if rc != 124 else 0.0)  # (a failing rank's message travels with the agreement first)
+            for p in live:
+                if p.poll() is None:
+                    p.kill()
+            for p in live:
+                p.wait()
+            break
+        time.sleep(0.02)
+    return rc
 
 
 def main():
@@ -471,7 +582,8 @@ def main():
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        # no launcher (this is how the driver calls it): bench.py starts its own ranks
+        raise SystemExit(spawn_ranks(a))
     if world > 1 or os.environ.get("PFD_BENCH_FORCE_DIST"):  # the env knob runs the RCCL path with 1 rank
         return run_distributed(a, rank, world, local)
     device = local
@@ -481,6 +593,7 @@ def main():
                steps=a.steps, warmup=a.warmup, ms_per_step=line.pop("ms_per_step"), higher_is_better=True,
                scaling="strong", vs_baseline=None, dtype="int32", data="synthetic", config=cfg)
     out.update(line)
+    save_n1_record(a, out)
     if not a.no_secondary:
         sec = []
         l2, c2 = upa_line(10000, 10000, a.regime, 20, 5, device, cpu=False, checks=False)

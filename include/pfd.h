@@ -145,7 +145,10 @@ int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace);
 /* General idxs_ds graphs only: install the cell sequence the sweeps follow.  Flwdir.order_cells("sort")
  * (reference pyflwdir/flwdir.py:231-245; the only ordering of NEXTXY rasters, pyflwdir.py:292-297) sorts the
  * cells by rank with numpy's argsort, and the serial loops add upstream cells in the reverse order of that
- * sequence — a float accumulation depends on it.  `seq`: HOST array of n_seq indices, ordered by rank. */
+ * sequence — a float accumulation depends on it.  `seq`: HOST array of n_seq indices, ordered by rank, every
+ * cell that drains to a pit exactly once (anything else: PFD_EINVAL).  seq == NULL with n_seq == 0 forgets an
+ * installed sequence: the sweeps (and pfd_idxs_seq) are back on the breadth-first order of core.idxs_seq.
+ * pfd_add_pits forgets it as well (it describes the graph before the edit). */
 int pfd_set_idxs_seq(pfd_raster *h, int idx_dtype, const void *seq, int64_t n_seq);
 /* core.rank (reference pyflwdir/core.py:17-47): int32 distance to the pit, -1 for cells that
  * do not drain to a pit, -9999 on nodata. */
@@ -226,6 +229,8 @@ typedef struct pfd_comm pfd_comm;
 int pfd_comm_unique_id(void *id_out, size_t len);
 int pfd_comm_create(const void *id, size_t len, int rank, int world, int device, pfd_comm **out);
 int pfd_comm_destroy(pfd_comm *c);
+/* what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) */
+int pfd_comm_info(pfd_comm *c, int *nranks, int *rank, int *device);
 int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int memspace);
 /* Split-phase form for callers that move the boundary records themselves (MPI, gloo, shared memory ...):
  * begin() runs the local phase and returns this block's record (4*ncol uint32, host memory); finish()

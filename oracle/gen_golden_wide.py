@@ -13,6 +13,7 @@ Fixtures are data only (inputs + the reference's outputs).   Usage: python oracl
 """
 from __future__ import annotations
 
+import json
 import os
 import sys
 
@@ -88,7 +89,14 @@ def gen_dem():
     e = np.where(d8s == 247, np.float32(-9999), e).astype(np.float32)
     store["in_synth_120x160"] = e
     run("synth_120x160", "synth_120x160")
-    store["calls"] = np.array(repr(calls))
+    def enc(v):  # JSON, so that the test never has to eval() anything
+        if isinstance(v, np.ndarray):
+            return {"__array__": v.tolist()}
+        if isinstance(v, float) and np.isnan(v):
+            return {"__nan__": True}
+        return v
+
+    store["calls"] = np.array(json.dumps([[k, i, {a: enc(b) for a, b in kw.items()}, st] for k, i, kw, st in calls]))
     np.savez_compressed(os.path.join(GOLD, "wide_dem.npz"), **store)
     print(f"[wide] dem: {len(calls)} calls:", [(c[0], c[3]) for c in calls if c[3] != 'ok'] or "all ok")
 
@@ -268,7 +276,54 @@ def gen_general():
     print(f"[wide] general: {len(store)} arrays")
 
 
-GENS = {"dem": gen_dem, "subgrid": gen_subgrid, "snap": gen_snap, "general": gen_general}
+def gen_general_pits():
+    """add_pits on general graphs (reference pyflwdir/flwdir.py:261-279 resets the cell order; the next sweep
+    re-orders — NEXTXY rasters by rank, pyflwdir.py:292-297): a NEXTXY raster and a raster of non-neighbour links,
+    three interior cells turned into pits, then the order and the order-sensitive sweeps."""
+    from pyflwdir_amd._affine import Affine
+    from oracle import golden_inputs as GI
+    import json
+
+    manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+    W = np.load(os.path.join(GOLD, "wide_general.npz"))
+    store = {}
+    for name in ("flwdir0", "flwdir_large", "synth_loops_96x80"):
+        ent = manifest[name]
+        A = Affine(*ent["transform"])
+        elv = W[f"in_{name}_elevtn"]
+        nxy = W[f"in_{name}_nextxy"]
+        ds2 = W[f"in_{name}_ds2"]
+        for kind in ("nextxy", "ds2"):
+            if kind == "nextxy":
+                flw = pyflwdir.from_array(nxy, ftype="nextxy", transform=A, latlon=ent["latlon"], cache=False)
+            else:
+                flw = pyflwdir.FlwdirRaster(idxs_ds=ds2, shape=nxy.shape[1:], ftype="d8", transform=A, latlon=ent["latlon"], cache=False)
+            tag = f"{name}_{kind}"
+            upa0 = flw.upstream_area()
+            flw.order_cells(method="sort")  # (an installed order exists when the pits arrive)
+            cand = W[f"in_{tag}_basins_idxs"]  # a few pits + high-accumulation interior cells
+            idxs = cand[~np.isin(cand, flw.idxs_pit)][:3]  # three interior cells with a large upstream area
+            assert idxs.size == 3
+            store[f"in_{tag}_pits"] = idxs
+            flw.add_pits(idxs=idxs)
+            store[f"out_{tag}_idxs_pit"] = flw.idxs_pit
+            store[f"out_{tag}_idxs_ds"] = flw.idxs_ds
+            store[f"out_{tag}_idxs_seq"] = flw.idxs_seq
+            store[f"out_{tag}_rank"] = flw.rank
+            upa = flw.upstream_area()
+            assert not np.array_equal(upa, upa0)
+            store[f"out_{tag}_upa"] = upa
+            P = GI.payloads(flw.shape)
+            store[f"out_{tag}_accu_f32"] = flw.accuflux(P["w32"])
+            store[f"out_{tag}_accu_ds_f64"] = flw.accuflux(P["w64"], direction="down")
+            store[f"out_{tag}_strahler"] = flw.stream_order()
+            store[f"out_{tag}_basins"] = flw.basins()
+            store[f"out_{tag}_hand"] = flw.hand(upa > GI.threshold(upa), elv)
+    np.savez_compressed(os.path.join(GOLD, "wide_general_pits.npz"), **store)
+    print(f"[wide] general_pits: {len(store)} arrays")
+
+
+GENS = {"dem": gen_dem, "subgrid": gen_subgrid, "snap": gen_snap, "general": gen_general, "general_pits": gen_general_pits}
 
 def gen_arith():
     """Flwdir.upstream_sum (reference pyflwdir/flwdir.py:412-433, arithmetics.py:147-169) for int32 / int64 /

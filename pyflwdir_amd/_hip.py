@@ -32,7 +32,7 @@ SYMBOLS = [
     "pfd_memcpy_d2h", "pfd_device_synchronize", "pfd_trim", "pfd_raster_create", "pfd_raster_create_block",
     "pfd_raster_create_deferred", "pfd_raster_validate",
     "pfd_raster_destroy", "pfd_raster_info", "pfd_upstream_area_cell_blocks", "pfd_comm_unique_id", "pfd_comm_create",
-    "pfd_comm_destroy", "pfd_upstream_area_cell_dist", "pfd_upstream_area_cell_begin", "pfd_upstream_area_cell_finish",
+    "pfd_comm_destroy", "pfd_comm_info", "pfd_upstream_area_cell_dist", "pfd_upstream_area_cell_begin", "pfd_upstream_area_cell_finish",
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
         L.pfd_comm_unique_id.argtypes = [C.c_void_p, C.c_size_t]
         L.pfd_comm_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.pfd_comm_destroy.argtypes = [C.c_void_p]
+        L.pfd_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.pfd_upstream_area_cell_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_upstream_area_cell_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.pfd_upstream_area_cell_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
@@ -295,6 +296,10 @@ class RasterHandle:
         seq = np.ascontiguousarray(seq)
         check(lib().pfd_set_idxs_seq(self._h, IDX_CODE[seq.dtype], ptr(seq), seq.size))
 
+    def clear_idxs_seq(self):
+        """General graphs: forget an installed sequence (back to the breadth-first order of core.idxs_seq)."""
+        check(lib().pfd_set_idxs_seq(self._h, PFD_I32, None, 0))
+
     def rank(self) -> np.ndarray:
         out = np.empty(self.n, np.int32)
         check(lib().pfd_rank(self._h, ptr(out), PFD_HOST))
@@ -483,6 +488,12 @@ class Communicator:
         buf = C.create_string_buffer(Communicator.UID_BYTES)
         check(lib().pfd_comm_unique_id(buf, Communicator.UID_BYTES))
         return buf.raw
+
+    def info(self) -> dict:
+        """World size / rank / device as RCCL reports them for this communicator."""
+        n, r, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().pfd_comm_info(self._c, C.byref(n), C.byref(r), C.byref(d)))
+        return dict(nranks=n.value, rank=r.value, device=d.value)
 
     def upstream_area_cell(self, handle, out=None, memspace=PFD_HOST):
         if memspace == PFD_HOST:

@@ -91,6 +91,21 @@ extern "C" int pfd_comm_destroy(pfd_comm *c) {
   return PFD_OK;
 }
 
+extern "C" int pfd_comm_info(pfd_comm *c, int *nranks, int *rank, int *device) {
+  if (!c || !c->comm) {
+    pfd_set_error("pfd_comm_info: no communicator");
+    return PFD_EINVAL;
+  }
+  int n = 0, r = 0, d = 0;
+  NCCLCHK(ncclCommCount(c->comm, &n));
+  NCCLCHK(ncclCommUserRank(c->comm, &r));
+  NCCLCHK(ncclCommCuDevice(c->comm, &d));
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (device) *device = d;
+  return PFD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // interface graph.  Node id = (block*2 + side)*ncol + col stands for the halo cell `col` on
 // `side` (0 top, 1 bottom) of `block`; rec = the gathered records, 4*ncol words per block.

@@ -113,12 +113,14 @@ __global__ void __launch_bounds__(256) k_gen_notin(const u32 *__restrict__ pos, 
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x <= n) flag[x] = (x < n && pos[x] == GNONE) ? 1u : 0u;
 }
+// the sequence must be rank-ordered AND hold every cell once (pos[seq[j]] == j fails for a repeated cell; m = the
+// number of cells that reach a pit, so "no repeats" + "every entry has a rank" = a permutation of those cells)
 __global__ void __launch_bounds__(256) k_gen_check_seq(const u32 *__restrict__ useq, u32 m, const i32 *__restrict__ rank,
-                                                       unsigned long long *__restrict__ bad) {
+                                                       const u32 *__restrict__ pos, unsigned long long *__restrict__ bad) {
   const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   const i32 r = rank[useq[j]];
-  if (r < 0 || (j > 0 && rank[useq[j - 1]] > r)) atomicAdd(bad, 1ull);
+  if (r < 0 || (j > 0 && rank[useq[j - 1]] > r) || pos[useq[j]] != j) atomicAdd(bad, 1ull);
 }
 
 static int gen_build_csr(pfd_raster *h) {
@@ -136,6 +138,10 @@ static int gen_build_csr(pfd_raster *h) {
   PFDCHK(vals.alloc((size_t)n * sizeof(u32)));
   HIPCHK(hipMemsetAsync(g->coff, 0, ((size_t)n + 1) * sizeof(u32), h->stream));
   DevBuf order, flag, tmp0;
+  if (g->pos && (h->n_seq < 0 || h->n_seq > (i64)n)) {  // (cannot happen: every path that invalidates n_seq frees pos)
+    pfd_set_error("internal: an installed cell order without its length");
+    return PFD_EINVAL;
+  }
   if (g->pos) {  // an installed sequence decides the order of the upstream cells
     PFDCHK(order.alloc((size_t)n * sizeof(u32)));
     PFDCHK(flag.alloc(((size_t)n + 1) * sizeof(u32)));
@@ -732,6 +738,10 @@ int pfd_gen_add_pits(pfd_raster *h, const i64 *idxs, i64 k) {
   k_gen_add_pits<<<cdiv_u32((u64)k, 256), 256, 0, h->stream>>>(g->ds, h->ncode, (const i64 *)in.dev, (u32)k);
   KCHK();
   HIPCHK(hipStreamSynchronize(h->stream));
+  // an installed sequence (pfd_set_idxs_seq) describes the graph before the edit: drop it with everything derived
+  // from it; the caller re-installs its order (FlwdirRaster.add_pits re-runs order_cells("sort") on NEXTXY rasters)
+  pfd_dfree(g->pos);
+  g->pos = nullptr;
   g->csr_ready = false;
   g->ordered = false;
   h->ordered = false;
@@ -751,10 +761,13 @@ extern "C" int pfd_set_idxs_seq(pfd_raster *h, int idx_dtype, const void *seq, i
     return PFD_EUNSUPPORTED;
   }
   GenGraph *g = G(h);
-  pfd_dfree(g->pos);
-  g->pos = nullptr;
-  g->csr_ready = false;
-  g->ordered = false;
+  if (g->pos || !g->ordered) {  // (back to the own breadth-first order first)
+    pfd_dfree(g->pos);
+    g->pos = nullptr;
+    g->csr_ready = false;
+    g->ordered = false;
+  }
+  if (!seq && n_seq == 0) return PFD_OK;  // "forget the installed order": the next operation orders breadth-first
   PFDCHK(gen_order(h));  // own breadth-first order: levels + the number of cells in the sequence
   const size_t es = idx_dtype == PFD_I64 ? 8 : 4;
   if (!seq || (idx_dtype != PFD_I32 && idx_dtype != PFD_U32 && idx_dtype != PFD_I64) || n_seq != h->n_seq) {
@@ -785,7 +798,7 @@ extern "C" int pfd_set_idxs_seq(pfd_raster *h, int idx_dtype, const void *seq, i
   HIPCHK(hipMemsetAsync(g->pos, 0xFF, (size_t)n * sizeof(u32), h->stream));
   if (m) {
     k_gen_pos<<<cdiv_u32(m, 256), 256, 0, h->stream>>>(g->seq, m, g->pos);
-    k_gen_check_seq<<<cdiv_u32(m, 256), 256, 0, h->stream>>>(g->seq, m, rank.as<i32>(), bad.as<unsigned long long>());
+    k_gen_check_seq<<<cdiv_u32(m, 256), 256, 0, h->stream>>>(g->seq, m, rank.as<i32>(), g->pos, bad.as<unsigned long long>());
   }
   unsigned long long nbad = 0;
   HIPCHK(hipMemcpyAsync(&nbad, bad.p, sizeof(nbad), hipMemcpyDeviceToHost, h->stream));
@@ -795,7 +808,7 @@ extern "C" int pfd_set_idxs_seq(pfd_raster *h, int idx_dtype, const void *seq, i
     g->pos = nullptr;
     g->csr_ready = g->ordered = false;
     h->ordered = false;
-    pfd_set_error("pfd_set_idxs_seq: the sequence is not ordered from down- to upstream (by rank)");
+    pfd_set_error("pfd_set_idxs_seq: the sequence is not ordered from down- to upstream (by rank) or repeats a cell");
     return PFD_EINVAL;
   }
   g->csr_ready = false;  // upstream cells by ascending position from now on

@@ -555,7 +555,7 @@ extern "C" int pfd_basins_finish(pfd_raster *h, const uint32_t *all_records_host
     const u64 v = value(nd);
     const u32 hs = (u32)(v >> 30) & 1u, hc = (u32)v & 0x3FFFFFFFu;
     const i64 nb = b + (hs ? 1 : -1);
-    if (nb < 0 || nb >= nblocks) return -1;
+    if (nb < 0 || nb >= nblocks || hc >= ncol) return -1;  // (hc comes from a peer's record: never index with it unchecked)
     return (nb * 2 + (1 - (i64)hs)) * (i64)ncol + hc;
   };
   std::vector<u64> lab(nn, 0);

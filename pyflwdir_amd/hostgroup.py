@@ -28,8 +28,14 @@ def _send_msg(sock, payload: bytes):
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
 
+MAX_MESSAGE = 1 << 30  # the largest payload is an all-gather of boundary records (a few MB): anything beyond 1 GiB is
+                        # a corrupt or hostile length word, not a message
+
+
 def _recv_msg(sock) -> bytes:
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > MAX_MESSAGE:
+        raise ConnectionError(f"peer announced a {n}-byte message (limit {MAX_MESSAGE})")
     return _recv_exact(sock, n)
 
 
@@ -42,8 +48,15 @@ class HostGroup:
             port = int(os.environ.get("PFD_HOSTGROUP_PORT", "0")) or int(os.environ.get("MASTER_PORT", "29500")) + 23
         self._peers = {}
         self._sock = None
+        if not 0 <= self.rank < self.world:
+            raise ValueError(f"rank {self.rank} outside a world of {self.world}")
         if self.world == 1:
             return
+        # 16-byte job token (optional shared secret PFD_HOSTGROUP_TOKEN): a connection that does not present it is
+        # dropped at accept time instead of becoming a rank
+        import hashlib
+
+        token = hashlib.sha256(("pfd-hostgroup:" + os.environ.get("PFD_HOSTGROUP_TOKEN", "")).encode()).digest()[:16]
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -55,7 +68,15 @@ class HostGroup:
                     conn, _ = srv.accept()
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     conn.settimeout(timeout)
-                    (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                    try:
+                        (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                        tok = _recv_exact(conn, len(token))
+                    except (OSError, ConnectionError):  # not one of ours (port scan, wrong protocol)
+                        conn.close()
+                        continue
+                    if not (1 <= r < self.world) or r in self._peers or tok != token:
+                        conn.close()  # out of range / duplicate rank / wrong job: never part of the group
+                        continue
                     self._peers[r] = conn
             finally:
                 srv.close()
@@ -71,7 +92,7 @@ class HostGroup:
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
-            s.sendall(struct.pack("<I", self.rank))
+            s.sendall(struct.pack("<I", self.rank) + token)
             self._sock = s
 
     # -- collectives (every rank calls them in the same order) ---------------------------------

@@ -422,6 +422,8 @@ class FlwdirRaster(object):
         reference).  "walk" reproduces the reference's breadth-first order exactly on the GPU; "sort" is the
         reference's own numpy expression over the GPU-computed ranks."""
         if method == "walk":
+            if self._d8 is None:  # general graph: an installed "sort" order must not pose as the breadth-first one
+                self._h.clear_idxs_seq()
             self._seq = self._h.idxs_seq(self._idx_dtype)
         elif method == "sort":
             rnk = self._h.rank()
@@ -452,6 +454,8 @@ class FlwdirRaster(object):
             self._nnodes = None
             self._cached.clear()
             self.idxs_outlet = self.idxs_pit
+            if self.ftype == "nextxy":  # the device forgot the installed order with the edit: the reference re-orders
+                self.order_cells(method="sort")  # NEXTXY rasters by rank before the next sweep (pyflwdir.py:292-297)
             return
         self._d8 = self._d8.copy()
         self._d8.flat[idxs1] = 0

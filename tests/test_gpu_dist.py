@@ -49,6 +49,35 @@ def _bench(args, env_extra, launcher):
     return json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
 
 
+def test_bench_spawns_its_own_ranks(gpu_lib):
+    """`python bench.py --gpus 2` with NO launcher — the way the driver calls it: bench.py starts its two ranks itself
+    (here both on the one GPU, so the records travel through the host group), prints one JSON line, exits 0."""
+    args = ["--size", "6000", "--steps", "2", "--warmup", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary"] + args,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["steps"] == 2 and two["warmup"] == 1
+    cfg = two["config"]
+    assert cfg["launcher"] == "self-spawned" and cfg["host_group"] == "HostGroup"
+    from pyflwdir_amd import _hip
+
+    if _hip.device_count() >= 2:
+        assert cfg["transport"] == "rccl" and cfg["rccl_world_size"] == 2
+    else:
+        assert cfg["transport"] == "host" and cfg["rccl_world_size"] is None
+    assert two["invariants"]["result_checksum"] == ref["invariants"]["result_checksum"]
+    assert two["invariants"]["result_checksum_equals_n1"] is True and two["speedup_vs_n1"] > 0
+    assert two["invariants"]["last_row_pit_sum_equals_n_valid"] is True
+
+
 @pytest.mark.parametrize("launcher", ["torchrun", "tcp"])
 def test_two_ranks_on_one_gpu(gpu_lib, launcher):
     args = ["--size", "6000", "--steps", "2", "--warmup", "1"]
@@ -56,7 +85,8 @@ def test_two_ranks_on_one_gpu(gpu_lib, launcher):
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
-    two = _bench(args, dict(PFD_DIST_TRANSPORT="host"), launcher)
+    two = _bench(args, dict(PFD_DIST_TRANSPORT="host", **({"PFD_BENCH_GROUP": "torch"} if launcher == "torchrun" else {})),
+                 launcher)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["transport"] == "host"
     assert two["config"]["n_valid"] == ref["config"]["n_valid"] == 36_000_000
     assert two["config"]["n_pits"] == ref["config"]["n_pits"]

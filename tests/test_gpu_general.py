@@ -127,3 +127,70 @@ def test_unchecked_d8_values(gpu_lib, nm):
         exp = W[f"out_{nm}_{key}"]
         got = getattr(f, key)
         assert got.dtype == exp.dtype and np.array_equal(got, exp), (nm, key)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("kind", ["nextxy", "ds2"])
+def test_add_pits_on_general_graphs(gpu_lib, name, kind):
+    """add_pits on a NEXTXY raster / a raster of non-neighbour links while a sorted cell order is installed (reference
+    pyflwdir/flwdir.py:261-279 resets the order; tests/golden/wide_general_pits.npz, oracle/gen_golden_wide.py): the
+    device must forget the installed order with the edit (it kept it and indexed with a stale length)."""
+    import pyflwdir_amd as pyflwdir
+    from oracle import golden_inputs as GI
+    from pyflwdir_amd._affine import Affine
+
+    W = np.load(os.path.join(GOLD, "wide_general.npz"))
+    Pz = np.load(os.path.join(GOLD, "wide_general_pits.npz"))
+    ent = json.load(open(os.path.join(GOLD, "manifest.json")))[name]
+    A = Affine(*ent["transform"])
+    nxy = W[f"in_{name}_nextxy"]
+    if kind == "nextxy":
+        flw = pyflwdir.from_array(nxy, ftype="nextxy", transform=A, latlon=ent["latlon"], cache=False)
+    else:
+        flw = pyflwdir.FlwdirRaster(idxs_ds=W[f"in_{name}_ds2"], shape=nxy.shape[1:], ftype="d8", transform=A,
+                                    latlon=ent["latlon"], cache=False)
+    tag = f"{name}_{kind}"
+    flw.upstream_area()
+    flw.order_cells(method="sort")
+    flw.add_pits(idxs=Pz[f"in_{tag}_pits"])
+
+    def eq(key, got):
+        exp = Pz[f"out_{tag}_{key}"]
+        got = np.asarray(got)
+        assert got.dtype == exp.dtype and got.shape == exp.shape, (tag, key, got.dtype, exp.dtype)
+        assert np.array_equal(got, exp, equal_nan=True), (tag, key, np.flatnonzero(got.ravel() != exp.ravel())[:5])
+
+    eq("idxs_pit", flw.idxs_pit)
+    eq("idxs_ds", flw.idxs_ds)
+    eq("idxs_seq", flw.idxs_seq)
+    eq("rank", flw.rank)
+    upa = flw.upstream_area()
+    eq("upa", upa)
+    P = GI.payloads(flw.shape)
+    eq("accu_f32", flw.accuflux(P["w32"]))
+    eq("accu_ds_f64", flw.accuflux(P["w64"], direction="down"))
+    eq("strahler", flw.stream_order())
+    eq("basins", flw.basins())
+    eq("hand", flw.hand(upa > GI.threshold(upa), W[f"in_{name}_elevtn"]))
+
+
+def test_walk_after_sort_is_breadth_first(gpu_lib):
+    """order_cells("walk") after order_cells("sort") on a general graph returns the reference's breadth-first
+    core.idxs_seq order, not the installed argsort order; a sequence that repeats a cell is refused."""
+    import pyflwdir_amd as pyflwdir
+
+    W = np.load(os.path.join(GOLD, "wide_general.npz"))
+    name = "flwdir_large"
+    flw = pyflwdir.FlwdirRaster(idxs_ds=W[f"in_{name}_ds2"], shape=W[f"in_{name}_nextxy"].shape[1:], ftype="d8", cache=False)
+    flw.order_cells(method="sort")
+    assert np.array_equal(flw.idxs_seq, W[f"out_{name}_ds2_idxs_seq_sort"])
+    flw.order_cells(method="walk")
+    assert np.array_equal(flw.idxs_seq, W[f"out_{name}_ds2_idxs_seq"])
+    assert np.array_equal(flw.upstream_area(), W[f"out_{name}_ds2_upa"])
+    seq = W[f"out_{name}_ds2_idxs_seq_sort"].copy()
+    rnk = flw.rank.ravel()
+    same = np.flatnonzero(rnk[seq[1:]] == rnk[seq[:-1]])
+    seq[same[0] + 1] = seq[same[0]]  # still rank-ordered, but one cell twice and one missing
+    with pytest.raises(ValueError, match="repeats a cell"):
+        flw._h.set_idxs_seq(seq)
+    assert np.array_equal(flw.upstream_area(), W[f"out_{name}_ds2_upa"])  # the handle is still usable
