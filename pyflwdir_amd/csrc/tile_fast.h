@@ -1,0 +1,379 @@
+// tile_fast.h — the tile passes for INTERIOR tiles (included by tiled.hip).
+//
+// A tile is interior when it, its halo ring and the 4 staging columns either side lie inside the device raster and
+// none of those rows is a halo row or a boundary row of a row block: no bounds handling, no halo sinks, no
+// boundary-row bookkeeping.  That is all but a one-tile frame of a raster (99.7 % of the tiles at 90000 x 90000),
+// so these kernels ARE the tile passes; k_tile (tiled.hip) keeps the general form for the frame.
+//
+// Both passes sit on the VALU (SQ counters, profiles/r02y_sq_counters_tile.csv: 123 and 89 VALU instructions per
+// cell in round 2, LDS and HBM far from their limits), so everything here is about instructions per cell:
+//  * decode by byte permute: the step of a direction code c = 1 << k inside the tile (dr * 64 + dc) and inside the
+//    staged codes (dr * 72 + dc) are 8-entry byte tables looked up with v_perm_b32 (selector k); "the step stays in
+//    the tile" is one AND with a per-cell constant mask of the directions that leave it; the raw pass classifies a
+//    byte by its population count (0 / 8: pit, 1: direction, else nodata or a bad code), again through a byte table;
+//  * pointers are LDS byte offsets, so that a gather needs no address arithmetic at all (local pass) or one shift
+//    (final pass), and "saturated" is a range test on the pointer itself instead of a flag bit that every use has to
+//    mask away;
+//  * local pass: a root is not "the cell where the path ends" but the perimeter SLOT of that cell — the 256 slots
+//    (+ one "nobody asks": pits, nodata) have pointer words of their own behind the 4096 cells, written by one
+//    thread per slot — so that after the pointer jumping a cell holds the address of its exit's counter and the
+//    count per exit costs three instructions per cell instead of a slot computation per cell;
+//  * final pass: a saturated cell points at a per-lane sink word behind the tile's counts, with a pointer word behind
+//    the tile's pointers that points at itself: no compare / select per cell and round;
+//  * one (local) / two (final) barriers per round: the "is any pointer still moving" vote goes through two
+//    alternating LDS flag rows written by the wave leaders instead of three barriers of __syncthreads_or.
+#pragma once
+
+#define FX_SLOT0 (2u * TCELLS)              // local pass: P byte offset of the pointer word of perimeter slot 0
+#define FX_NOBODY (FX_SLOT0 + 2u * PSL)     // ... of the root nobody asks about (pit, nodata, cell of a cycle)
+#define FX_PN (TCELLS + PSL + 8)            // P entries of the local pass
+#define FY_SINK0 (4u * TCELLS)              // final pass: A byte offset of sink word 0 (64 of them, one per lane)
+
+// step tables (selector k = position of the code's bit): E, SE, S, SW | W, NW, N, NE
+#define FX_TP_LO 0x3F404101u  // tile index steps  +1 +65 +64 +63
+#define FX_TP_HI 0xC1C0BFFFu  //                   -1 -65 -64 -63
+#define FX_TC_LO 0x47484901u  // staged-code steps +1 +73 +72 +71   (row pitch CP = 72)
+#define FX_TC_HI 0xB9B8B7FFu  //                   -1 -73 -72 -71
+// normalised code of a cell that is no direction, by population count of its raw byte: 0 (code 0) and 8 (code 255:
+// selector 8 replicates the sign bit of table byte 1 = 0) are pits -> 0; 1 is a direction (-> 0 when its target is
+// nodata); everything else is nodata (247 itself, 7 bits) or a bad code -> 247
+#define FX_T0_LO 0xF7F70000u
+#define FX_T0_HI 0xF7F7F7F7u
+
+__device__ __forceinline__ u32 fx_ffbl(u32 x) {  // position of the lowest set bit, 0xFFFFFFFF for 0 (v_ffbl_b32)
+  u32 r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ int fx_sext8(u32 x) { return (int)(int8_t)(x & 0xFFu); }
+
+// directions that leave the tile from a cell in row lr / column lc (only perimeter cells have any)
+__device__ __forceinline__ u32 fx_rowmask(u32 lr) { return (lr == 0u ? 0xE0u : 0u) | (lr == TS - 1u ? 0x0Eu : 0u); }
+__device__ __forceinline__ u32 fx_colmask(u32 lc) { return (lc == 0u ? 0x38u : 0u) | (lc == TS - 1u ? 0x83u : 0u); }
+
+// wave leaders publish "one of my lanes still moves a pointer"; everybody reads the four flags after the barrier.
+// Two alternating rows: a wave can only reach the write of round r + 2 after every wave has read round r's row.
+__device__ __forceinline__ bool fx_vote(u32 (*s_flag)[4], int round, u32 tid, bool live) {
+  const bool any = __ballot(live) != 0ull;
+  if ((tid & 63u) == 0u) s_flag[round & 1][tid >> 6] = any ? 1u : 0u;
+  __syncthreads();
+  const uint4 f = *(const uint4 *)s_flag[round & 1];
+  return (f.x | f.y | f.z | f.w) != 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// local pass of an interior tile
+// ---------------------------------------------------------------------------------------------------------------
+template <bool RAW, bool WEIGHTS>
+__global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
+  __shared__ __attribute__((aligned(16))) u32 A[PSL * PREP];     // PREP count words per perimeter slot
+  __shared__ __attribute__((aligned(16))) uint16_t P[FX_PN];     // byte offset into P of an ancestor / of a root word
+  __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
+  __shared__ u64 s_cnt[4];
+  const u32 tid = threadIdx.x;
+  const u32 tc = blockIdx.x + a.tc_lo, tr = blockIdx.y + a.tr_lo;
+  const u32 sbase = sslot_base(tr, tc, a.nstc);
+  const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
+  {
+    u32 v[5];
+    stage_load_interior(RAW ? a.raw : a.ncode, a.ncol, r0, c0, tid, v);
+    stage_store(code, tid, v);
+  }
+  *(uint4 *)&A[PREP * tid] = make_uint4(0u, 0u, 0u, 0u);
+  *(uint4 *)&A[PREP * tid + 4] = make_uint4(0u, 0u, 0u, 0u);
+  P[TCELLS + tid] = (uint16_t)(FX_SLOT0 + 2u * tid);  // a root word points at itself
+  if (tid == 0) P[TCELLS + PSL] = (uint16_t)FX_NOBODY;
+  __syncthreads();
+
+  // ---- decode (+ normalise) the thread's 4 quads, initial pointers ------------------------------------------
+  const u32 qs = (tid >> 3) & 3u;      // register slot s of a quad holds logical cell s ^ qs (swizzle, see k_tile)
+  const u32 lcq = 4u * (tid & 15u);    // first column of the thread's quads
+  u32 sh[4], cm[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const u32 b = (u32)s ^ qs;
+    sh[s] = 8u * b;
+    cm[s] = fx_colmask(lcq + b);
+  }
+  u32 ndir = 0, npit = 0, nbad = 0;
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    const u32 lr = (tid >> 4) + 16u * j;
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 ca0 = (lr + 1u) * CP + lcq + 4u;  // byte offset of CODE(lr, lcq)
+    const u32 c4 = *(const u32 *)&code[ca0];
+    const u32 rm = (j == 0 || j == QPT - 1) ? fx_rowmask(lr) : 0u;
+    u32 p[4], n4 = 0, badq = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32 c = (c4 >> sh[s]) & 0xFFu;
+      const u32 k = fx_ffbl(c);
+      const u32 pcnt = __popc(c);
+      bool isdir = pcnt == 1u;
+      if (RAW) {
+        const u32 t = code[(u32)((int)(ca0 + (sh[s] >> 3)) + fx_sext8(__builtin_amdgcn_perm(FX_TC_HI, FX_TC_LO, k)))];
+        isdir = isdir && t != D8_MV;  // flow into nodata ends here (interior tile: never off the raster)
+        const u32 t0 = __builtin_amdgcn_perm(FX_T0_HI, FX_T0_LO, pcnt);
+        const u32 n = isdir ? c : t0;
+        badq |= t0 & ~c;  // != 0 exactly for a byte that is neither a code nor 247 (247 & ~c == 0 <=> c in {247, 255})
+        n4 |= n << sh[s];
+        ndir += isdir ? 1u : 0u;
+        npit += n == 0u ? 1u : 0u;
+      }
+      const bool go = isdir && (c & (rm | cm[s])) == 0u;
+      const u32 lt = (u32)((int)(l0 + (sh[s] >> 3)) + fx_sext8(__builtin_amdgcn_perm(FX_TP_HI, FX_TP_LO, k)));
+      p[s] = go ? (PHYS(lt) << 1) : FX_NOBODY;  // (an exit's own word is set by its slot's thread below)
+    }
+    *(uint2 *)&P[l0] = make_uint2(p[0] | (p[1] << 16), p[2] | (p[3] << 16));
+    if (RAW) {
+      if (badq) {  // rare: count the bad bytes of the quad exactly (the error message quotes the number)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const u32 c = (c4 >> sh[s]) & 0xFFu;
+          nbad += (__builtin_amdgcn_perm(FX_T0_HI, FX_T0_LO, __popc(c)) & ~c) ? 1u : 0u;
+        }
+      }
+      *(u32 *)&code[ca0] = n4;  // (readers of a raw byte only ask "== nodata": unchanged unless the raster is rejected)
+      __builtin_memcpy(a.ncode_w + (size_t)(r0 + lr) * a.ncol + (size_t)(c0 + lcq), &n4, 4);  // possibly unaligned dword
+    }
+  }
+  if (RAW) {  // counts of the tile -> tcnt (summed by k_tile_counts: no same-address atomics)
+    u64 pk = (u64)(ndir + npit) | ((u64)npit << 16) | ((u64)nbad << 32);
+    for (int o = 32; o > 0; o >>= 1) pk += __shfl_down(pk, o);
+    if ((tid & 63u) == 0) s_cnt[tid >> 6] = pk;
+  }
+  __syncthreads();
+  if (RAW && tid == 0) a.tcnt[(size_t)tr * a.ntc + tc] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+
+  // ---- one thread per perimeter slot: an exit's pointer word names its slot -----------------------------------
+  u32 tgt = NONE32;
+  int plr = 0, plc = 0;
+  if (tid < NPERIM) {
+    pslot_inv((int)tid, &plr, &plc);
+    const u32 c = CODE(plr, plc);
+    if (d8_is_dir(c)) {
+      const int k = d8_slot(c);
+      const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
+      if ((unsigned)nr >= TS || (unsigned)nc >= TS) {  // inside the raster and valid (normalised codes)
+        const i64 gr = r0 + nr, gc = c0 + nc;
+        tgt = sslot_base((u32)(gr >> 6), (u32)(gc >> 6), a.nstc) + (u32)pslot((int)(gr & 63), (int)(gc & 63));
+        P[PHYS((u32)(plr * TS + plc))] = (uint16_t)(FX_SLOT0 + 2u * tid);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- pointer jumping, gather-only: J <- J o J until every pointer sits on a root word ------------------------
+  // (the "quad j still moves" flags are separate bools on purpose: the compiler keeps them as lane masks in
+  //  scalar registers, so that testing and clearing them costs no VALU instruction)
+  u32 pc[QPT * 4];
+  bool lv[QPT];
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    const uint2 pp = *(const uint2 *)&P[4u * tid + 1024u * j];
+    pc[4 * j + 0] = pp.x & 0xFFFFu;
+    pc[4 * j + 1] = pp.x >> 16;
+    pc[4 * j + 2] = pp.y & 0xFFFFu;
+    pc[4 * j + 3] = pp.y >> 16;
+    lv[j] = !(pp.x & pp.y & (pp.x >> 16) & (pp.y >> 16) & FX_SLOT0);  // (offsets < 0x4000: bit 13 <=> root word)
+  }
+  int round = 0;
+#pragma nounroll
+  for (; round < MAXROUNDS_TILE; ++round) {
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+      if (lv[j]) {
+        u32 q[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[b] = *(const uint16_t *)((const u8 *)P + pc[4 * j + b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pc[4 * j + b] = q[b];
+        lv[j] = !(q[0] & q[1] & q[2] & q[3] & FX_SLOT0);
+        *(uint2 *)&P[4u * tid + 1024u * j] = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
+      }
+    }
+    if (!fx_vote(s_flag, round, tid, lv[0] | lv[1] | lv[2] | lv[3])) break;
+  }
+  const u32 live = (lv[0] ? 1u : 0u) + (lv[1] ? 1u : 0u) + (lv[2] ? 1u : 0u) + (lv[3] ? 1u : 0u);
+  if ((a.ablate & 32) && tid == 0) {  // pfd_set_profiling(h, 2): rounds this tile needed (max and sum over the tiles)
+    const unsigned long long r = (unsigned long long)min(round + 1, MAXROUNDS_TILE);
+    atomicMax((unsigned long long *)&a.ctrl[48], r);
+    atomicAdd((unsigned long long *)&a.ctrl[49], r);
+  }
+  // a cell on or upstream of a cycle never reaches a root word: count their quads (normally zero)
+  if (live) atomicAdd((unsigned long long *)&a.ctrl[T_UNSAT], (unsigned long long)live);
+
+  // ---- every cell adds its weight to the counter of its exit (PREP replicas per slot, picked by lane) ---------
+  const u32 rep = 4u * (tid & (PREP - 1u));
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32 x = pc[4 * j + s] - FX_SLOT0;  // 2 x slot; >= 2 * PSL: nobody asks (a nodata cell is its own root)
+      if (x < 2u * PSL) {
+        u32 w = 1u;
+        if (WEIGHTS) {
+          const u32 lr = (tid >> 4) + 16u * j;
+          w = (u32)a.weights[(size_t)(r0 + lr) * a.ncol + (size_t)(c0 + lcq + (sh[s] >> 3))];
+        }
+        atomicAdd((u32 *)((u8 *)A + (x << 4) + rep), w);  // word slot * PREP + replica
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- perimeter records for the exit graph -------------------------------------------------------------------
+  u32 xt = 0, link = NONE32;
+  if (tid < NPERIM) {
+    if (tgt != NONE32) {
+      const uint4 lo = *(const uint4 *)&A[tid * PREP], hi = *(const uint4 *)&A[tid * PREP + 4];
+      xt = lo.x + lo.y + lo.z + lo.w + hi.x + hi.y + hi.z + hi.w;
+    }
+    const u32 c = CODE(plr, plc);
+    bool entry = false;
+    if (c != D8_MV) {  // entry?  (a neighbour outside the tile drains into this cell)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
+        if (((unsigned)nr >= TS || (unsigned)nc >= TS) && CODE(nr, nc) == (1u << ((k + 4) & 7))) entry = true;
+      }
+    }
+    if (entry) {  // the exit its in-tile path reaches
+      const u32 x = (u32)P[PHYS((u32)(plr * TS + plc))] - FX_SLOT0;
+      if (x < 2u * PSL) link = sbase + (x >> 1);
+    }
+  }
+  a.xT[sbase + tid] = xt;
+  a.xtgt[sbase + tid] = tgt;
+  a.elink[sbase + tid] = link;
+  a.inflow[sbase + tid] = 0;  // accumulated by the exit-graph solve
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// final pass of an interior tile: the doubling with values; entries start with 1 + inflow
+// ---------------------------------------------------------------------------------------------------------------
+template <bool WEIGHTS>
+__global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
+  __shared__ __attribute__((aligned(16))) u32 A[TCELLS + 64];        // running count of the cell; 64 sink words
+  __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS + 64];   // A byte offset of an ancestor / of a sink word
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
+  const u32 tid = threadIdx.x;
+  const u32 tc = blockIdx.x + a.tc_lo, tr = blockIdx.y + a.tr_lo;
+  const u32 sbase = sslot_base(tr, tc, a.nstc);
+  const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
+  const u32 lcq = 4u * (tid & 15u);
+  u32 cq[QPT];
+#pragma unroll
+  for (int j = 0; j < QPT; ++j)
+    __builtin_memcpy(&cq[j], a.ncode + (size_t)(r0 + (tid >> 4) + 16u * j) * a.ncol + (size_t)(c0 + lcq), 4);
+  const u32 inf = a.inflow[sbase + tid];
+  const u32 sink = FY_SINK0 + 4u * (tid & 63u);
+  if (tid < 64u) P[TCELLS + tid] = (uint16_t)sink;  // a sink's pointer word points at the sink
+
+  const u32 qs = (tid >> 3) & 3u;
+  u32 sh[4], cm[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const u32 b = (u32)s ^ qs;
+    sh[s] = 8u * b;
+    cm[s] = fx_colmask(lcq + b);
+  }
+  u32 pc[QPT * 4], qn[QPT * 4];
+  bool lv[QPT];
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    const u32 lr = (tid >> 4) + 16u * j;
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 c4 = cq[j];
+    const u32 rm = (j == 0 || j == QPT - 1) ? fx_rowmask(lr) : 0u;
+    u32 w4[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const u32 c = (c4 >> sh[s]) & 0xFFu;
+      // a direction (one bit) whose step stays in the tile; 247 / 254 keep >= 4 bits whatever the mask removes
+      const bool go = __popc(c & ~(rm | cm[s])) == 1u;
+      const u32 lt = (u32)((int)(l0 + (sh[s] >> 3)) + fx_sext8(__builtin_amdgcn_perm(FX_TP_HI, FX_TP_LO, fx_ffbl(c))));
+      pc[4 * j + s] = go ? (PHYS(lt) << 2) : sink;
+      u32 wv = 1u;
+      if (WEIGHTS) wv = (u32)a.weights[(size_t)(r0 + lr) * a.ncol + (size_t)(c0 + lcq + (sh[s] >> 3))];
+      w4[s] = c != D8_MV ? wv : 0u;
+    }
+    *(uint4 *)&A[l0] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    *(uint2 *)&P[l0] = make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
+    lv[j] = !(pc[4 * j + 0] & pc[4 * j + 1] & pc[4 * j + 2] & pc[4 * j + 3] & FY_SINK0);
+  }
+  __syncthreads();
+  if (tid < NPERIM && inf) {  // flow entering the tile from its neighbours
+    int lr, lc;
+    pslot_inv((int)tid, &lr, &lc);
+    A[PHYS((u32)(lr * TS + lc))] += inf;
+  }
+  __syncthreads();
+
+  // ---- doubling: A[J(z)] += A(z); J(z) <- J(J(z)).  A saturated cell adds to its lane's sink word --------------
+  // One round reads (own counts, the pointers of the ancestors), waits for everybody's reads, then writes.  Two
+  // rounds per trip with the pointer registers swapping roles, so that no register copies are needed.
+#define FY_ROUND(PC, QN)                                                                                          \
+  {                                                                                                               \
+    u32 av[QPT * 4];                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < QPT; ++j) {                                                             \
+      if (lv[j]) {                                                                                                \
+        const uint4 a4 = *(const uint4 *)&A[4u * tid + 1024u * j];                                                \
+        av[4 * j + 0] = a4.x, av[4 * j + 1] = a4.y, av[4 * j + 2] = a4.z, av[4 * j + 3] = a4.w;                   \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                             \
+            QN[4 * j + b] = *(const uint16_t *)((const u8 *)P + (PC[4 * j + b] >> 1));                           \
+      }                                                                                                           \
+    }                                                                                                             \
+    __syncthreads(); /* every read of this round precedes every write of this round */                           \
+    _Pragma("unroll") for (int j = 0; j < QPT; ++j) {                                                             \
+      if (lv[j]) {                                                                                                \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b) atomicAdd((u32 *)((u8 *)A + PC[4 * j + b]), av[4 * j + b]); \
+        lv[j] = !(QN[4 * j + 0] & QN[4 * j + 1] & QN[4 * j + 2] & QN[4 * j + 3] & FY_SINK0);                      \
+        *(uint2 *)&P[4u * tid + 1024u * j] =                                                                      \
+            make_uint2(QN[4 * j + 0] | (QN[4 * j + 1] << 16), QN[4 * j + 2] | (QN[4 * j + 3] << 16));             \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+  int round = 0;
+#pragma nounroll
+  for (; round < MAXROUNDS_TILE; round += 2) {
+    FY_ROUND(pc, qn)
+    if (!fx_vote(s_flag, 0, tid, lv[0] | lv[1] | lv[2] | lv[3])) break;
+    FY_ROUND(qn, pc)
+    if (!fx_vote(s_flag, 1, tid, lv[0] | lv[1] | lv[2] | lv[3])) {
+      ++round;
+      break;
+    }
+  }
+#undef FY_ROUND
+  const u32 live = (lv[0] ? 1u : 0u) + (lv[1] ? 1u : 0u) + (lv[2] ? 1u : 0u) + (lv[3] ? 1u : 0u);
+  if ((a.ablate & 32) && tid == 0) {
+    const unsigned long long r = (unsigned long long)min(round + 1, MAXROUNDS_TILE);
+    atomicMax((unsigned long long *)&a.ctrl[50], r);
+    atomicAdd((unsigned long long *)&a.ctrl[51], r);
+  }
+  if (live) atomicAdd((unsigned long long *)&a.ctrl[T_UNSAT], (unsigned long long)live);
+
+  // ---- write the finished tile (16 B per lane) -----------------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 c4 = cq[j];
+    const uint4 a4 = *(const uint4 *)&A[l0];
+    const u32 x0 = (qs & 1u) ? a4.y : a4.x, x1 = (qs & 1u) ? a4.x : a4.y;  // undo the swizzle: logical cell k sits in slot k ^ qs
+    const u32 x2 = (qs & 1u) ? a4.w : a4.z, x3 = (qs & 1u) ? a4.z : a4.w;
+    i32 o4[4] = {(i32)((qs & 2u) ? x2 : x0), (i32)((qs & 2u) ? x3 : x1), (i32)((qs & 2u) ? x0 : x2),
+                 (i32)((qs & 2u) ? x1 : x3)};
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (((c4 >> (8 * b)) & 0xFFu) == D8_MV) o4[b] = -9999;
+    i32 *dst = a.out + (size_t)(r0 + (tid >> 4) + 16u * j - a.row_first) * a.ncol + (size_t)(c0 + lcq);
+    if ((((size_t)dst) & 15) == 0) {
+      *(int4 *)dst = make_int4(o4[0], o4[1], o4[2], o4[3]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) dst[b] = o4[b];
+    }
+  }
+}

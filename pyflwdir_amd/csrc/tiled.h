@@ -99,12 +99,36 @@ struct TileArgs {
   u32 *brow_inflow;// [2*ncol] flow entering the boundary rows from the neighbouring row blocks
   u64 *ctrl;
   i32 *out;
+  u32 tr_lo, tr_hi, tc_lo, tc_hi;  // the rectangle of INTERIOR tiles [tr_lo, tr_hi) x [tc_lo, tc_hi) (k_tile_*_fast,
+                   // tile_fast.h); k_tile runs on the frame around it (1-D grid, frame_tile())
   u64 *stamps;     // DEVTOOLS: [1024][8] cycle stamps, spread over 1024 rows against same-address atomics
   int ablate;      // profiling knob (env PFD_TILE_ABLATE): bit0 skip doubling, bit4 cycle stamps; bit5 (set by
                    // pfd_set_profiling(h, 2)) counts the doubling rounds per tile into ctrl[48..51]
 };
 
 // ---- device helpers shared by the tile kernels (tiled.hip, paths.hip) ---------------------------
+// the id-th tile of the frame around the interior rectangle: top strip, bottom strip, then the left and right
+// pieces of the rows in between
+__host__ __device__ inline u32 frame_tiles(u32 ntr, u32 ntc, u32 tr_lo, u32 tr_hi, u32 tc_lo, u32 tc_hi) {
+  return ntr * ntc - (tr_hi - tr_lo) * (tc_hi - tc_lo);
+}
+__host__ __device__ inline void frame_tile(u32 id, u32 ntr, u32 ntc, u32 tr_lo, u32 tr_hi, u32 tc_lo, u32 tc_hi, u32 *tr,
+                                           u32 *tc) {
+  const u32 top = tr_lo * ntc, bot = (ntr - tr_hi) * ntc;
+  if (id < top) {
+    *tr = id / ntc, *tc = id % ntc;
+  } else if (id < top + bot) {
+    id -= top;
+    *tr = tr_hi + id / ntc, *tc = id % ntc;
+  } else {
+    id -= top + bot;
+    const u32 side = tc_lo + (ntc - tc_hi);
+    const u32 x = id % side;
+    *tr = tr_lo + id / side;
+    *tc = x < tc_lo ? x : tc_hi + (x - tc_lo);
+  }
+}
+
 #ifdef __HIPCC__
 __device__ __forceinline__ int pslot(int lr, int lc) {
   if (lr == 0) return lc;

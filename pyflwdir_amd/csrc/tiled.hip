@@ -55,7 +55,7 @@
     __syncthreads();                                                                                        \
     if (tid == 0) {                                                                                         \
       const u64 t_ = __builtin_readcyclecounter();                                                          \
-      atomicAdd((unsigned long long *)&a.stamps[(((blockIdx.y * gridDim.x + blockIdx.x) & 1023u) << 3) + (FINAL ? 4 : 0) + slot], \
+      atomicAdd((unsigned long long *)&a.stamps[(((tr * a.ntc + tc) & 1023u) << 3) + (FINAL ? 4 : 0) + slot], \
                 (unsigned long long)(t_ - tprev));                                                        \
       tprev = t_;                                                                                           \
     }                                                                                                       \
@@ -74,10 +74,10 @@
 // issue no atomic at all, and the PREP replicas of a slot (picked by lane) spread the same-address ones.
 #define PREP 8
 template <bool FINAL, bool RAW, bool INT, bool PERIM>
-__device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P, u8 *code, u64 *s_cnt) {
+__device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P, u8 *code, u64 *s_cnt, const u32 tr,
+                                          const u32 tc) {
   u64 tprev = __builtin_readcyclecounter();
   const u32 tid = threadIdx.x;
-  const u32 tc = blockIdx.x, tr = blockIdx.y;
   const u32 sbase = sslot_base(tr, tc, a.nstc);  // first of this tile's 256 slot ids
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   if (!FINAL && tc == 0 && tr == 0)  // (the exit-graph solve starts after this kernel: no memset launch)
@@ -516,6 +516,8 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
   TSTAMP(3)
 }
 
+// the general form runs on the FRAME of tiles around the interior rectangle (1-D grid, frame_tile()): tiles that touch
+// the raster edge, a halo row or a boundary row of a row block.  Interior tiles: tile_fast.h.
 template <bool FINAL, bool RAW = false, bool PERIM = false>
 __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   // running subtree count of the cell (+64 sink words) — or, PERIM, PREP count words per perimeter slot
@@ -525,14 +527,12 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   // cells' codes: it keeps its own quads' codes in registers (cq) and stages nothing.
   __shared__ __attribute__((aligned(16))) u8 code[FINAL ? 16 : HW * CP];
   __shared__ u64 s_cnt[4];
-  const i64 r0 = (i64)blockIdx.y * TS, c0 = (i64)blockIdx.x * TS;
-  const bool interior = r0 >= 1 && c0 >= 4 && r0 + TS + 1 <= (i64)a.nrow && c0 + TS + 4 <= (i64)a.ncol &&
-                        a.row_first == 0 && a.row_last + 1 == a.nrow;
-  if (interior)
-    tile_body<FINAL, RAW, true, PERIM>(a, A, P, code, s_cnt);
-  else
-    tile_body<FINAL, RAW, false, PERIM>(a, A, P, code, s_cnt);
+  u32 tr, tc;
+  frame_tile(blockIdx.x, a.ntr, a.ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi, &tr, &tc);
+  tile_body<FINAL, RAW, false, PERIM>(a, A, P, code, s_cnt, tr, tc);
 }
+
+#include "tile_fast.h"
 
 // per-tile counts of a raw pass -> the counters k_normalise would have left in ctrl
 __global__ void __launch_bounds__(1024) k_tile_counts(const u64 *__restrict__ tcnt, u32 ntiles, u64 *ctrl) {
@@ -1095,6 +1095,14 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
 #endif
   if (h->count_rounds) a.ablate |= 32;
   is_block = h->halo_top || h->halo_bot;
+  // interior tiles (tile_fast.h): the tile, its ring and 4 staging columns either side inside the device raster, and
+  // none of those rows a halo row or a boundary row of a row block:  r0 >= row_first + 1,  r0 + TS <= row_last,
+  // c0 >= 4,  c0 + TS + 4 <= ncol
+  a.tr_lo = (a.row_first + 1u + TS - 1u) / TS;
+  a.tr_hi = a.row_last >= TS ? a.row_last / TS : 0u;
+  a.tc_lo = 1u;
+  a.tc_hi = a.ncol >= TS + 4u ? (a.ncol - 4u) / TS : 0u;
+  if (a.tr_hi <= a.tr_lo || a.tc_hi <= a.tc_lo || pfd_knob("PFD_TILE_GENERAL")) a.tr_lo = a.tr_hi = a.tc_lo = a.tc_hi = 0u;
   return PFD_OK;
 }
 
@@ -1209,27 +1217,38 @@ int TiledRun::phase_a() {
     HIPCHK(hipMemsetAsync(brow_sink, 0xFF, nb * sizeof(u32), h->stream));
   }
   if (is_block) HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));  // read by the final tile pass
-  const dim3 grid(ntc, ntr);
+  // interior tiles: k_tile_local_fast; the frame around them (raster edge, halo and boundary rows): k_tile
+  const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
+  const bool have_i = gridi.x && gridi.y;
+  const u32 gridf = frame_tiles(ntr, ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi);
   pfd_seg_begin(h, "tile_local");
   if (!h->normalised) {  // deferred handle: decode + validate + count inside the tile pass
     if (!tcntbuf.p) PFDCHK(tcntbuf.alloc((size_t)ntr * ntc * sizeof(u64)));
     a.raw = h->raw;
     a.tcnt = tcntbuf.as<u64>();
+    if (have_i) {
+      if (a.weights) k_tile_local_fast<true, true><<<gridi, 256, 0, h->stream>>>(a);
+      else k_tile_local_fast<true, false><<<gridi, 256, 0, h->stream>>>(a);
+    }
     if (is_block)
-      k_tile<false, true><<<grid, 256, 0, h->stream>>>(a);
+      k_tile<false, true><<<gridf, 256, 0, h->stream>>>(a);
     else
-      k_tile<false, true, true><<<grid, 256, 0, h->stream>>>(a);
+      k_tile<false, true, true><<<gridf, 256, 0, h->stream>>>(a);
     fused_norm = true;
     KCHK();
-    pfd_seg_end(h, 1);
+    pfd_seg_end(h, have_i ? 2 : 1);
     k_tile_counts<<<std::min<u32>(cdiv_u32((u64)ntr * ntc, 4096), 256u), 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);
   } else {
+    if (have_i) {
+      if (a.weights) k_tile_local_fast<false, true><<<gridi, 256, 0, h->stream>>>(a);
+      else k_tile_local_fast<false, false><<<gridi, 256, 0, h->stream>>>(a);
+    }
     if (is_block)
-      k_tile<false><<<grid, 256, 0, h->stream>>>(a);
+      k_tile<false><<<gridf, 256, 0, h->stream>>>(a);
     else
-      k_tile<false, false, true><<<grid, 256, 0, h->stream>>>(a);
+      k_tile<false, false, true><<<gridf, 256, 0, h->stream>>>(a);
     KCHK();
-    pfd_seg_end(h, 1);
+    pfd_seg_end(h, have_i ? 2 : 1);
   }
 
   pfd_seg_begin(h, "exit_graph");
@@ -1274,11 +1293,16 @@ int TiledRun::phase_b(int *complete) {
     PFDCHK(solve_exits(xT, &launches));
     pfd_seg_end(h, launches);
   }
-  const dim3 grid(ntc, ntr);
+  const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
+  const bool have_i = gridi.x && gridi.y;
   pfd_seg_begin(h, "tile_final");
-  k_tile<true><<<grid, 256, 0, h->stream>>>(a);
+  if (have_i) {
+    if (a.weights) k_tile_final_fast<true><<<gridi, 256, 0, h->stream>>>(a);
+    else k_tile_final_fast<false><<<gridi, 256, 0, h->stream>>>(a);
+  }
+  k_tile<true><<<frame_tiles(ntr, ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi), 256, 0, h->stream>>>(a);
   KCHK();
-  pfd_seg_end(h, 1);
+  pfd_seg_end(h, have_i ? 2 : 1);
   u64 c0[48];
   HIPCHK(hipMemcpyAsync(c0, h->ctrl, sizeof(c0), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

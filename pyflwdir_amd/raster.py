@@ -445,11 +445,14 @@ class FlwdirRaster(object):
             raise IndexError("idxs outside domain")
         if np.any(~self.mask[i64]):
             raise ValueError("add_pits: indices must address valid (non-nodata) cells")
+        # the reference keeps its pit list as np.unique(concatenate([idxs_pit, idxs1])) (flwdir.py:276): same set as
+        # the device's, in the promoted dtype of the two
+        pit_after = np.unique(np.concatenate([self.idxs_pit, idxs1]))
         self._h.add_pits(idxs1)
         if self._d8 is None:  # general graph: the host mirror is idxs_ds itself
             self._idxs_ds = self._idxs_ds.copy()
             self._idxs_ds[i64] = i64.astype(self._idx_dtype)
-            self._pit = None
+            self._pit = pit_after
             self._seq = None
             self._nnodes = None
             self._cached.clear()
@@ -460,7 +463,7 @@ class FlwdirRaster(object):
         self._d8 = self._d8.copy()
         self._d8.flat[idxs1] = 0
         self._idxs_ds = None
-        self._pit = None
+        self._pit = pit_after
         self._seq = None
         self._nnodes = None
         self._cached.clear()
