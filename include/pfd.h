@@ -240,6 +240,16 @@ int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int memspace, uint
 int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_records_host, int nblocks, int block,
                                   int *complete);
 
+/* HAND (reference pyflwdir/dem.py:299-330) of a ROW BLOCK: like pfd_hand on the block's device raster (own rows +
+ * halo rows; drain / elevtn / out cover all of them), except that a valid halo cell — the neighbouring block's
+ * boundary cell — takes its height from `halo_seed_host` (HOST, 2 * ncol doubles: top halo row, bottom halo row)
+ * instead of being computed.  A path that leaves the block therefore continues the neighbour's sum with the same
+ * operands in the same order: bit-identical to the whole raster once the seeds are the neighbour's final values.
+ * The caller iterates (pyflwdir_amd/dist.py DistributedRaster.hand): seeds start as -inf ("not known yet", which
+ * every sum that depends on it inherits), the blocks exchange their boundary rows, until no owned cell is -inf. */
+int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn,
+                   const double *halo_seed_host, double *out, int memspace);
+
 /* basins (reference pyflwdir/basins.py:12-18, core.py:120-146) on a raster row-tiled over several GPUs /
  * processes, split-phase like pfd_upstream_area_cell_begin/_finish (Multi-GPU): `outlets` are k
  * linear indices INTO THE BLOCK'S OWN ROWS (r * ncol + c, r counted from the block's first own row), `ids`
@@ -309,6 +319,17 @@ int pfd_graph_stats(pfd_raster *h, int64_t stats[16]);
  * res[0] == res[1] == 0 holds for exactly one array: the reference's result (streams.accuflux over
  * ones, pyflwdir/streams.py:15-41; invariant [2] == [5]: tests/test_streams_basins.py:24-27). */
 int pfd_verify_upstream_area_cell(pfd_raster *h, const int32_t *upa, int memspace, int64_t res[8]);
+
+/* The same for a basins() result with uint32 ids (reference pyflwdir/basins.py:12-18, core.py:120-146) and for a HAND
+ * result (dem.py:299-330), each cell against its downstream cell only: res[0] = valid cells violating their equation
+ * (labels: seeded cell == its id, other cells == the label of their downstream cell, 0 for a pit; HAND: 0 on drain
+ * cells, else hand[ds] + (double)(elevtn[x] - elevtn[ds]) with the difference in the elevation dtype, bit for bit),
+ * res[1] = nodata cells != 0 / != -9999, res[2] = sum of all values (HAND: of their bit patterns), res[3] = labelled
+ * cells / drain cells.  `outlets` (k distinct linear indices, HOST) and `ids` (HOST) are the seeds of the labels. */
+int pfd_verify_basins(pfd_raster *h, const int64_t *outlets, const uint32_t *ids, int64_t k, const uint32_t *labels,
+                      int memspace, int64_t res[4]);
+int pfd_verify_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, const double *hand,
+                    int memspace, int64_t res[4]);
 
 /* sum of n int32 values in HBM (two's complement, 64 bit): the checksum multi-block runs compare with a
  * single-GPU run of the same raster */

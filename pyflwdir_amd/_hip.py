@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
 ]
 
 _lib = None
@@ -90,6 +90,9 @@ def lib() -> C.CDLL:
         L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_hand_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_verify_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        L.pfd_verify_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.pfd_main_upstream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int]
         L.pfd_upstream_sum.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_int]
         L.pfd_stream_order_classic.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -361,6 +364,30 @@ class RasterHandle:
             out = np.empty(self.n, np.float64)
         check(lib().pfd_hand(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(out), memspace))
         return out
+
+    def hand_block(self, drain, elevtn, elev_code, halo_seed, out=None, memspace=PFD_HOST):
+        """HAND of a row block whose halo cells take their height from ``halo_seed`` (2 * ncol float64, host); drain,
+        elevtn and the result cover the block's device raster (own + halo rows)."""
+        halo_seed = np.ascontiguousarray(halo_seed, dtype=np.float64)
+        assert halo_seed.size == 2 * self.ncol
+        if memspace == PFD_HOST:
+            out = np.empty((self.nrow + sum(self.halo)) * self.ncol, np.float64)
+        check(lib().pfd_hand_block(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(halo_seed), ptr(out), memspace))
+        return out
+
+    def verify_basins(self, outlets, ids, labels, memspace=PFD_HOST) -> dict:
+        """Local-equation check of a basins() result with uint32 ids (see include/pfd.h)."""
+        outlets = np.ascontiguousarray(outlets, dtype=np.int64).ravel()
+        ids = np.ascontiguousarray(ids, dtype=np.uint32).ravel()
+        a = (C.c_int64 * 4)()
+        check(lib().pfd_verify_basins(self._h, ptr(outlets), ptr(ids), outlets.size, ptr(labels), memspace, a))
+        return dict(bad_cells=int(a[0]), bad_nodata=int(a[1]), checksum=int(a[2]), n_labelled=int(a[3]))
+
+    def verify_hand(self, drain, elevtn, elev_code, hand, memspace=PFD_HOST) -> dict:
+        """Local-equation check of a HAND result, bit for bit (see include/pfd.h)."""
+        a = (C.c_int64 * 4)()
+        check(lib().pfd_verify_hand(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(hand), memspace, a))
+        return dict(bad_cells=int(a[0]), bad_nodata=int(a[1]), checksum=int(a[2]), n_drain=int(a[3]))
 
     def ucat_area(self, idxs_out, map_dtype, area_rows=None):
         """(map[n] of map_dtype, area[k]); area_rows None: int32 cell counts, else nrow float32/float64 row areas."""

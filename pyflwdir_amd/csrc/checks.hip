@@ -8,6 +8,8 @@
 // large-size tests certify the 8.1-Gcell result (SURVEY.md 8d, C4 checks ii/iii), together with the
 // reference's own invariant "the upstream areas of the pits add up to the number of valid cells"
 // (tests/test_streams_basins.py:24-27).
+#include <algorithm>
+
 #include "common.h"
 
 __global__ void __launch_bounds__(256) k_verify_upa(const u8 *__restrict__ ncode, const i32 *__restrict__ upa, u32 nrow,
@@ -78,6 +80,171 @@ extern "C" int pfd_verify_upstream_area_cell(pfd_raster *h, const int32_t *upa, 
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int k = 0; k < 8; ++k) res[k] = (int64_t)r[k];
   return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// basins labels and HAND by their local equations (twins of k_verify_upa): every cell is checked against its
+// downstream cell only, so the kernels share nothing with the engines (no tiles, no ordering, no path queries).
+// On a raster without cycles each system has exactly one solution, the reference's result:
+//   labels (basins.basins + core.fillnodata_upstream, pyflwdir/basins.py:12-18, core.py:120-146):
+//       seeded cell -> its seed;  other valid cell -> the label of its downstream cell, 0 for a pit;  nodata -> 0
+//   HAND (dem.height_above_nearest_drain, pyflwdir/dem.py:299-330):
+//       nodata -> -9999;  drain cell -> 0;  other cell -> hand[ds] + (double)(elevtn[x] - elevtn[ds]), the
+//       difference in the elevation dtype (a pit is its own downstream cell: 0 + 0), compared bit for bit
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t chk_down(size_t i, u32 ncol, u32 code) {
+  if (!d8_is_dir(code)) return i;
+  const int k = d8_slot(code);
+  return (size_t)((long long)i + (long long)d8_dr(k) * (long long)ncol + d8_dc(k));
+}
+__device__ __forceinline__ void chk_reduce(const unsigned long long (&vals)[4], unsigned long long *s,
+                                           unsigned long long *__restrict__ res) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned long long v = vals[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && s[threadIdx.x]) atomicAdd(&res[threadIdx.x], s[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) k_scatter_seed(const i64 *__restrict__ idx, const u32 *__restrict__ ids, u32 k,
+                                                      u32 *__restrict__ seed) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < k) seed[idx[t]] = ids[t];
+}
+__global__ void __launch_bounds__(256) k_verify_labels(const u8 *__restrict__ ncode, const u32 *__restrict__ seed,
+                                                       const u32 *__restrict__ lab, u32 nrow, u32 ncol,
+                                                       unsigned long long *__restrict__ res) {
+  __shared__ unsigned long long s[4];
+  if (threadIdx.x < 4) s[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
+  unsigned long long bad = 0, badmv = 0, csum = 0, nlab = 0;
+  for (u32 r = blockIdx.y * 4 + (threadIdx.x >> 6); r < nrow && c < ncol; r += gridDim.y * 4) {
+    const size_t i = (size_t)r * ncol + c;
+    const u32 code = ncode[i], v = lab[i];
+    csum += v;
+    if (code == D8_MV) {
+      badmv += v != 0u;
+      continue;
+    }
+    nlab += v != 0u;
+    const u32 sd = seed[i];
+    u32 exp = sd;
+    if (!sd) exp = d8_is_dir(code) ? lab[chk_down(i, ncol, code)] : 0u;
+    bad += exp != v;
+  }
+  const unsigned long long vals[4] = {bad, badmv, csum, nlab};
+  chk_reduce(vals, s, res);
+}
+template <class E>
+__global__ void __launch_bounds__(256) k_verify_hand(const u8 *__restrict__ ncode, const u8 *__restrict__ drain,
+                                                     const E *__restrict__ elev, const double *__restrict__ hand,
+                                                     u32 nrow, u32 ncol, unsigned long long *__restrict__ res) {
+  __shared__ unsigned long long s[4];
+  if (threadIdx.x < 4) s[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 c = blockIdx.x * 64 + (threadIdx.x & 63);
+  unsigned long long bad = 0, badmv = 0, csum = 0, ndrain = 0;
+  for (u32 r = blockIdx.y * 4 + (threadIdx.x >> 6); r < nrow && c < ncol; r += gridDim.y * 4) {
+    const size_t i = (size_t)r * ncol + c;
+    const u32 code = ncode[i];
+    const double v = hand[i];
+    csum += (unsigned long long)__double_as_longlong(v);
+    if (code == D8_MV) {
+      badmv += v != -9999.0;
+      continue;
+    }
+    double exp = 0.0;
+    if (drain[i] == 1) {
+      ++ndrain;
+    } else {
+      const size_t p = chk_down(i, ncol, code);
+      const E dz = elev[i] - elev[p];
+      exp = (p == i ? 0.0 : hand[p]) + (double)dz;
+    }
+    bad += !(__double_as_longlong(exp) == __double_as_longlong(v) || (exp != exp && v != v));
+  }
+  const unsigned long long vals[4] = {bad, badmv, csum, ndrain};
+  chk_reduce(vals, s, res);
+}
+
+static int chk_common(pfd_raster *h, const char *what, const void *a, const void *b) {
+  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, what));
+  if (!a || !b) {
+    pfd_set_error("%s: bad arguments", what);
+    return PFD_EINVAL;
+  }
+  if (h->halo_top || h->halo_bot) {
+    pfd_set_error("%s: whole rasters only", what);
+    return PFD_EUNSUPPORTED;
+  }
+  return PFD_OK;
+}
+static int chk_finish(pfd_raster *h, DevBuf &acc, int64_t res[4]) {
+  KCHK();
+  unsigned long long r[4];
+  HIPCHK(hipMemcpyAsync(r, acc.p, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 4; ++k) res[k] = (int64_t)r[k];
+  return PFD_OK;
+}
+
+extern "C" int pfd_verify_basins(pfd_raster *h, const int64_t *outlets, const uint32_t *ids, int64_t k,
+                                 const uint32_t *labels, int memspace, int64_t res[4]) {
+  PFDCHK(chk_common(h, "pfd_verify_basins", labels, res));
+  if (k < 0 || (k > 0 && (!outlets || !ids))) {
+    pfd_set_error("pfd_verify_basins: bad arguments");
+    return PFD_EINVAL;
+  }
+  for (i64 j = 0; j < k; ++j)
+    if (outlets[j] < 0 || outlets[j] >= h->n || ids[j] == 0) {
+      pfd_set_error("pfd_verify_basins: outlet %lld outside the raster or id 0", (long long)j);
+      return PFD_EINVAL;
+    }
+  InArg in, di, dl;
+  PFDCHK(in.bind(labels, (size_t)h->n * sizeof(u32), memspace, h->stream));
+  PFDCHK(di.bind(k ? outlets : nullptr, (size_t)k * sizeof(i64), PFD_HOST, h->stream));
+  PFDCHK(dl.bind(k ? ids : nullptr, (size_t)k * sizeof(u32), PFD_HOST, h->stream));
+  DevBuf seed, acc;
+  PFDCHK(seed.alloc((size_t)h->n * sizeof(u32)));
+  PFDCHK(acc.alloc(4 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(seed.p, 0, (size_t)h->n * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(acc.p, 0, 4 * sizeof(unsigned long long), h->stream));
+  // (the outlets must be distinct: a repeated index would make the scatter's winner arbitrary)
+  if (k) k_scatter_seed<<<cdiv_u32((u64)k, 256), 256, 0, h->stream>>>((const i64 *)di.dev, (const u32 *)dl.dev, (u32)k, seed.as<u32>());
+  const dim3 grid(cdiv_u32((u64)h->ncol, 64), std::min<u32>(cdiv_u32((u64)h->nrow, 4), 8192u));
+  k_verify_labels<<<grid, 256, 0, h->stream>>>(h->ncode, seed.as<u32>(), (const u32 *)in.dev, (u32)h->nrow, (u32)h->ncol,
+                                              acc.as<unsigned long long>());
+  return chk_finish(h, acc, res);
+}
+
+extern "C" int pfd_verify_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn,
+                               const double *hand, int memspace, int64_t res[4]) {
+  PFDCHK(chk_common(h, "pfd_verify_hand", hand, res));
+  if (!drain || !elevtn || (elev_dtype != PFD_F32 && elev_dtype != PFD_F64)) {
+    pfd_set_error("pfd_verify_hand: bad arguments (elevation dtype code %d)", elev_dtype);
+    return PFD_EINVAL;
+  }
+  InArg dr, el, ha;
+  PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
+  PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
+  PFDCHK(ha.bind(hand, (size_t)h->n * sizeof(double), memspace, h->stream));
+  DevBuf acc;
+  PFDCHK(acc.alloc(4 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(acc.p, 0, 4 * sizeof(unsigned long long), h->stream));
+  const dim3 grid(cdiv_u32((u64)h->ncol, 64), std::min<u32>(cdiv_u32((u64)h->nrow, 4), 8192u));
+  if (elev_dtype == PFD_F32)
+    k_verify_hand<float><<<grid, 256, 0, h->stream>>>(h->ncode, (const u8 *)dr.dev, (const float *)el.dev,
+                                                     (const double *)ha.dev, (u32)h->nrow, (u32)h->ncol,
+                                                     acc.as<unsigned long long>());
+  else
+    k_verify_hand<double><<<grid, 256, 0, h->stream>>>(h->ncode, (const u8 *)dr.dev, (const double *)el.dev,
+                                                      (const double *)ha.dev, (u32)h->nrow, (u32)h->ncol,
+                                                      acc.as<unsigned long long>());
+  return chk_finish(h, acc, res);
 }
 
 // sum of n int32 values (two's complement, 64 bit): the checksum the N-block runs compare with the 1-GPU run

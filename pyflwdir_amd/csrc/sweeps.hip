@@ -1145,6 +1145,54 @@ static int hand_t(pfd_raster *h, const u8 *drain_dev, const void *elev_dev, doub
   return sweep_down(h, op, "sweep_hand", "exact_hand");
 }
 
+// HAND of a row block (multi-GPU, DESIGN.md: sharded HAND): the halo cells stand for the neighbouring block's
+// boundary cells and carry THEIR height (`seed`, 2 * ncol doubles on the device: top halo row, bottom halo row);
+// every other cell is computed from its downstream cell exactly as on a whole raster, so a path that leaves the
+// block continues the neighbour's sum with the same operands in the same order.
+template <class E>
+struct HandSeeded : Hand<E> {
+  const double *seed;
+  u32 row_first, row_last;  // owned rows of the device raster
+  __device__ __forceinline__ double apply(u32 x, u32 code, bool root, double pv) const {
+    if (code == D8_HALO) {
+      const u32 r = geo_row(this->g, x);
+      return seed[(r > row_last ? this->g.ncol : 0u) + (x - r * this->g.ncol)];
+    }
+    return Hand<E>::apply(x, code, root, pv);
+  }
+};
+
+extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn,
+                              const double *halo_seed_host, double *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!drain || !elevtn || !out || !halo_seed_host || (elev_dtype != PFD_F32 && elev_dtype != PFD_F64)) {
+    pfd_set_error("pfd_hand_block: bad arguments (elevation dtype code %d)", elev_dtype);
+    return PFD_EINVAL;
+  }
+  PFDCHK(pfd_reject_general(h, "hand_block"));
+  pfd_seg_clear(h);
+  PFDCHK(pfd_order_cells_impl(h));  // (the level structure of the block: its halo cells are roots like its pits)
+  InArg dr, el, sd;
+  PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
+  PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
+  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol * sizeof(double), PFD_HOST, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * sizeof(double), memspace));
+  pfd_seg_begin(h, "init");
+  k_fill<double><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((double *)o.dev, h->geo.n, -9999.0);
+  KCHK();
+  pfd_seg_end(h, 1);
+  const u32 rf = (u32)h->halo_top, rl = (u32)(h->halo_top + h->own_rows - 1);
+  if (elev_dtype == PFD_F32) {
+    HandSeeded<float> op{{h->ncode, h->geo, (const u8 *)dr.dev, (const float *)el.dev, (double *)o.dev}, (const double *)sd.dev, rf, rl};
+    PFDCHK(run_down(h, op, "sweep_hand_block"));
+  } else {
+    HandSeeded<double> op{{h->ncode, h->geo, (const u8 *)dr.dev, (const double *)el.dev, (double *)o.dev}, (const double *)sd.dev, rf, rl};
+    PFDCHK(run_down(h, op, "sweep_hand_block"));
+  }
+  return o.finish(h->stream);
+}
+
 extern "C" int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, double *out,
                         int memspace) {
   PFDCHK(pfd_check_handle(h));

@@ -91,6 +91,67 @@ def basins_blocks(d8: np.ndarray, nblocks: int, idxs, ids=None, devices=None) ->
     return np.concatenate([o.reshape(-1, ncol) for o in outs], axis=0)
 
 
+_ELEV_CODE = {np.dtype(np.float32): _hip.PFD_F32, np.dtype(np.float64): _hip.PFD_F64}
+
+
+def _hand_inputs(drain, elevtn):
+    drain = np.ascontiguousarray(drain).astype(np.uint8, copy=False)
+    elevtn = np.ascontiguousarray(elevtn)
+    if elevtn.dtype not in _ELEV_CODE:
+        raise NotImplementedError(f"elevation dtype {elevtn.dtype} is not supported on the HIP path")
+    return drain, elevtn, _ELEV_CODE[elevtn.dtype]
+
+
+def hand_blocks(d8: np.ndarray, nblocks: int, drain, elevtn, devices=None, max_iter=None):
+    """``hand(drain, elevtn)`` (reference pyflwdir/dem.py:299-330) of a host raster computed as ``nblocks`` row blocks
+    held by this one process; same kernels and protocol as ``DistributedRaster.hand``, the boundary rows are moved
+    by numpy.  Returns (hand, iterations).
+
+    HAND is a sum along the path to the nearest drain cell, float64, one addition per step — not associative, so a
+    path that crosses a block edge must CONTINUE the neighbour's sum.  Every block sweeps down- to upstream with its
+    halo cells (the neighbour's boundary cells) holding the neighbour's height; a height that is not known yet is
+    -inf, which every sum depending on it inherits.  The blocks exchange their boundary rows and sweep again until
+    no owned cell is -inf: once per block edge a path crosses before it meets a drain cell (rivers are drain cells
+    themselves, so two sweeps are the rule)."""
+    d8 = np.ascontiguousarray(d8, dtype=np.uint8)
+    nrow, ncol = d8.shape
+    drain, elevtn, code = _hand_inputs(drain, elevtn)
+    drain, elevtn = drain.reshape(nrow, ncol), elevtn.reshape(nrow, ncol)
+    devices = devices or [0] * nblocks
+    rows = block_rows(nrow, nblocks)
+    handles, parts = [], []
+    for b, (r0, r1) in enumerate(rows):
+        a, e = block_slice(nrow, nblocks, b)
+        handles.append(_hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks)))
+        parts.append((np.ascontiguousarray(drain[a:e]), np.ascontiguousarray(elevtn[a:e])))
+    seeds = [np.full(2 * ncol, -np.inf) for _ in range(nblocks)]
+    own = [None] * nblocks
+    unknown_before, it = None, 0
+    try:
+        while True:
+            it += 1
+            for b, h in enumerate(handles):
+                top, _ = halo_of(b, nblocks)
+                out = h.hand_block(parts[b][0], parts[b][1], code, seeds[b]).reshape(-1, ncol)
+                own[b] = out[top:top + (rows[b][1] - rows[b][0])]
+            unknown = sum(int(np.isneginf(o).sum()) for o in own)
+            if unknown == 0:
+                break
+            if unknown == unknown_before or (max_iter is not None and it >= max_iter):
+                raise NotImplementedError("hand: heights that depend on each other through several row blocks "
+                                          "(a cycle through the block edges)")
+            unknown_before = unknown
+            for b in range(nblocks):  # halo rows = the neighbours' boundary rows
+                if b > 0:
+                    seeds[b][:ncol] = own[b - 1][-1]
+                if b + 1 < nblocks:
+                    seeds[b][ncol:] = own[b + 1][0]
+    finally:
+        for h in handles:
+            h.close()
+    return np.concatenate(own, axis=0), it
+
+
 def exchange_unique_id(rank: int, world: int, group=None) -> bytes:
     """Rank 0 creates the RCCL unique id, everybody receives it through the host group."""
     group = group or _default_group(rank, world)
@@ -235,6 +296,44 @@ class DistributedRaster:
         if flag == 0:
             raise NotImplementedError("a row block failed or the raster holds a cycle through several row blocks")
         return res.reshape(self.handle.nrow, ncol) if memspace == _hip.PFD_HOST else res
+
+    def hand(self, drain_block, elevtn_block, max_iter=None):
+        """Collective ``hand(drain, elevtn)`` (reference pyflwdir/dem.py:299-330): every rank passes the rows of its
+        block INCLUDING its halo rows (like the D8 codes); returns (float64 heights of the rank's own rows,
+        iterations).  Bit-identical to the whole raster: see :func:`hand_blocks`.  Per iteration one all-gather of
+        the two boundary rows (2 * ncol doubles per rank) and one agreement on the number of unknown cells."""
+        h = self.handle
+        ncol, top = h.ncol, halo_of(self.rank, self.world)[0]
+        drain, elevtn, code = _hand_inputs(drain_block, elevtn_block)
+        seed = np.full(2 * ncol, -np.inf)
+        unknown_before, it, own = None, 0, None
+        while True:
+            it += 1
+            err = None
+            try:
+                out = h.hand_block(drain, elevtn, code, seed).reshape(-1, ncol)
+                own = out[top:top + h.nrow]
+                rec = np.concatenate([own[0], own[-1]])
+                mine = int(np.isneginf(own).sum())
+            except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
+                err, rec, mine = exc, np.zeros(2 * ncol), -1
+            parts = self.group.allgather(rec.tobytes())
+            counts = [int(x) for x in np.frombuffer(b"".join(self.group.allgather(np.int64(mine).tobytes())), np.int64)]
+            if err is not None:
+                raise err
+            if min(counts) < 0:
+                raise RuntimeError("another rank failed in hand()")
+            unknown = sum(counts)
+            if unknown == 0:
+                return own, it
+            if unknown == unknown_before or (max_iter is not None and it >= max_iter):
+                raise NotImplementedError("hand: heights that depend on each other through several row blocks "
+                                          "(a cycle through the block edges)")
+            unknown_before = unknown
+            if self.rank > 0:
+                seed[:ncol] = np.frombuffer(parts[self.rank - 1], np.float64)[ncol:]
+            if self.rank + 1 < self.world:
+                seed[ncol:] = np.frombuffer(parts[self.rank + 1], np.float64)[:ncol]
 
     def close(self):
         if self.handle is not None:

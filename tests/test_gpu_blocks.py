@@ -123,3 +123,35 @@ def test_basins_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblocks):
         assert np.array_equal(got.ravel(), exp)
     # default: one basin per pit
     assert np.array_equal(dist.basins_blocks(d8, nblocks, idxs_pit).ravel(), O.basins(idxs_ds, idxs_pit, seq))
+
+
+@pytest.mark.parametrize("shape,seed,kw,nblocks,edtype", [
+    ((900, 700), 51, dict(tilt=1 << 26, white=2, nodata_pct=0), 2, np.float32),
+    ((1300, 1100), 52, dict(tilt=100000, white=2, nodata_pct=25), 3, np.float32),
+    ((2100, 1500), 53, dict(tilt=3000, white=2, nodata_pct=5), 5, np.float64),
+    ((1600, 900), 54, dict(tilt=1 << 26, white=2, nodata_pct=10), 8, np.float32),
+    ((64, 300), 55, dict(tilt=100000, white=2, nodata_pct=0), 8, np.float64),   # 8 rows per block
+])
+def test_hand_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblocks, edtype):
+    """BASELINE config 5's second operation over row blocks: HAND (reference pyflwdir/dem.py:299-330) of a raster
+    split into 2-8 row blocks == the oracle on the whole raster, BIT FOR BIT — a path that crosses a block edge
+    continues the neighbour's float64 sum (sharded HAND).  Sparse drains make paths cross several edges."""
+    from pyflwdir_amd import dist
+
+    O = oracle
+    d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    upa = O.upstream_area_cell(d8)[0].ravel()
+    elev = O.synth_elev_f32(shape[0], shape[1], seed=seed, **kw).astype(edtype).ravel()
+    for thr in (np.percentile(upa[upa > 0], 80), np.percentile(upa[upa > 0], 99.7), upa.max() + 1):
+        drain = upa > thr  # the last one: no drain cell at all, every path runs to its pit
+        exp = O.height_above_nearest_drain(idxs_ds, seq, drain, elev)
+        got, iters = dist.hand_blocks(d8, nblocks, drain, elev)
+        assert got.dtype == np.float64 and iters >= 1
+        assert np.array_equal(got.ravel().view(np.uint64), exp.view(np.uint64)), (thr, iters)
+    # all blocks at once == the whole-raster engines
+    import pyflwdir_amd as pyflwdir
+
+    flw = pyflwdir.from_array(d8, ftype="d8")
+    assert np.array_equal(flw.hand(drain.reshape(shape), elev.reshape(shape)).ravel().view(np.uint64), got.ravel().view(np.uint64))

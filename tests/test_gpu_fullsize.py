@@ -20,6 +20,27 @@ pytestmark = pytest.mark.gpu
 RIVER = dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0)
 
 
+def test_c2_10000_upstream_area_vs_oracle(gpu_lib, oracle):
+    """BASELINE configs[1] exactly as stated: 10000 x 10000 synthetic D8 (the bench's river raster), upstream cell
+    counts on one GPU, bit-exact against the oracle's serial pipeline — through the FlwdirRaster surface and through
+    the deferred handle bench.py times."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd import _hip
+
+    n = 10000
+    buf = _hip.synth_d8_device(n, n, seed=0, tilt=1 << 26, white=2, nodata_pct=0)
+    d8 = buf.download(np.uint8, (n, n))
+    exp, _, st = oracle.upstream_area_cell(d8)
+    flw = pyflwdir.from_array(d8, ftype="d8")
+    got = flw.upstream_area()
+    assert got.dtype == np.int32 and np.array_equal(got, exp)
+    h = _hip.RasterHandle(buf, n, n, memspace=_hip.PFD_DEVICE, deferred=True)
+    assert np.array_equal(h.upstream_area_cell().reshape(n, n), exp)
+    assert h.info()["n_valid"] == n * n == int(exp[d8 == 0].astype(np.int64).sum())  # pit sums == valid cells
+    h.close()
+    buf.free()
+
+
 def test_c3_30000_accuflux_strahler_vs_oracle(gpu_lib, oracle):
     from pyflwdir_amd import _hip
 
@@ -195,8 +216,20 @@ def test_c5_basins_hand_at_size(gpu_lib, oracle):
     upa.free()
     hand = _hip.DeviceBuffer(n * 8)
     h.hand(drain, elev, _hip.PFD_F32, out=hand, memspace=_hip.PFD_DEVICE)
+    # every cell's local equation on the device (streaming kernels that share nothing with the engines; on an
+    # acyclic raster each system has one solution, the reference's): labels and HAND at all 2.59 Gcells
+    vb = h.verify_basins(outl, ids, lab, memspace=_hip.PFD_DEVICE)
+    assert vb["bad_cells"] == 0 and vb["bad_nodata"] == 0 and vb["n_labelled"] > 1000, vb
+    vh = h.verify_hand(drain, elev, _hip.PFD_F32, hand, memspace=_hip.PFD_DEVICE)
+    assert vh["bad_cells"] == 0 and vh["bad_nodata"] == 0 and vh["n_drain"] > 0, vh
+    # ... and the checkers themselves notice a single wrong cell
+    probe = int(outl[0]) + 1
+    keep = lab.download(np.uint32, (1,), offset_bytes=probe * 4)
+    _hip.check(_hip.lib().pfd_memcpy_h2d(0, C.c_void_p(lab.addr + probe * 4), _hip.ptr(keep + np.uint32(1)), C.c_size_t(4)))
+    assert h.verify_basins(outl, ids, lab, memspace=_hip.PFD_DEVICE)["bad_cells"] >= 1
+    _hip.check(_hip.lib().pfd_memcpy_h2d(0, C.c_void_p(lab.addr + probe * 4), _hip.ptr(keep), C.c_size_t(4)))
+    # the same equations recomputed by numpy (independent of the device decode) on sampled rows
     DR = {1: (0, 1), 2: (1, 1), 4: (1, 0), 8: (1, -1), 16: (0, -1), 32: (-1, -1), 64: (-1, 0), 128: (-1, 1)}
-    is_outlet = np.zeros(0)
     for r in (1, 7777, 18000, 25113, nrow - 2):
         d = d8_buf.download(np.uint8, (3, ncol), offset_bytes=(r - 1) * ncol)
         L = lab.download(np.uint32, (3, ncol), offset_bytes=(r - 1) * ncol * 4)
@@ -228,7 +261,41 @@ def test_c5_basins_hand_at_size(gpu_lib, oracle):
         expH = np.where(D == 1, 0.0, np.where(pit, 0.0, H[tr, tcc]) + dz.astype(np.float64))
         assert np.array_equal(H[1][valid], expH[valid]) and np.all(H[1][~valid] == -9999.0)
     h.close()
-    for b in (hand, elev, drain):
+    # HAND sharded over 4 row blocks (config 5 names 4 GPUs) == the single-GPU result, bit for bit: the blocks'
+    # inputs are slices of the device-resident rasters, the boundary rows travel through the host
+    nb = 4
+    rows = pdist.block_rows(nrow, nb)
+    seeds = [np.full(2 * ncol, -np.inf) for _ in range(nb)]
+    bout = _hip.DeviceBuffer((rows[0][1] - rows[0][0] + 2) * ncol * 8)
+    unknown_before = None
+    for it in range(1, 8):
+        first, last, unknown = [], [], 0
+        for b, (r0, r1) in enumerate(rows):
+            a, e = pdist.block_slice(nrow, nb, b)
+            top = r0 - a
+            hb = _hip.RasterHandle(d8_buf.addr + a * ncol, r1 - r0, ncol, memspace=_hip.PFD_DEVICE, halo=pdist.halo_of(b, nb))
+            hb.hand_block(drain.addr + a * ncol, elev.addr + a * ncol * 4, _hip.PFD_F32, seeds[b], out=bout, memspace=_hip.PFD_DEVICE)
+            hb.close()
+            own = bout.download(np.float64, (r1 - r0, ncol), offset_bytes=top * ncol * 8)
+            first.append(own[0].copy()), last.append(own[-1].copy())
+            n_unknown = int(np.isneginf(own).sum())
+            unknown += n_unknown
+            if n_unknown == 0:  # final: the block's rows must equal the whole raster's
+                whole = hand.download(np.float64, (r1 - r0, ncol), offset_bytes=r0 * ncol * 8)
+                assert np.array_equal(own.view(np.uint64), whole.view(np.uint64)), (it, b)
+                del whole
+            del own
+        if unknown == 0:
+            break
+        assert unknown != unknown_before
+        unknown_before = unknown
+        for b in range(nb):
+            if b > 0:
+                seeds[b][:ncol] = last[b - 1]
+            if b + 1 < nb:
+                seeds[b][ncol:] = first[b + 1]
+    assert unknown == 0 and it <= 4, (unknown, it)
+    for b in (hand, elev, drain, bout):
         b.free()
     # sharded over 4 row blocks == the single-GPU labels (compared through checksums of the uint32 labels)
     d8 = d8_buf.download(np.uint8, (nrow, ncol))
