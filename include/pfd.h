@@ -246,9 +246,14 @@ int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_records_hos
  * instead of being computed.  A path that leaves the block therefore continues the neighbour's sum with the same
  * operands in the same order: bit-identical to the whole raster once the seeds are the neighbour's final values.
  * The caller iterates (pyflwdir_amd/dist.py DistributedRaster.hand): seeds start as -inf ("not known yet", which
- * every sum that depends on it inherits), the blocks exchange their boundary rows, until no owned cell is -inf. */
+ * every sum that depends on it inherits), the blocks exchange their boundary rows, until no owned cell is -inf.
+ * update != 0: `out` holds the result of an earlier call (other seeds); only its -inf cells are recomputed (collected
+ * and relaxed to a fixpoint; a full sweep again when they are more than 1/16 of the block).
+ * boundary_rows_host (nullable): receives the first and the last OWN row (2 * ncol doubles); n_unknown (nullable):
+ * the number of own cells that are still -inf. */
 int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn,
-                   const double *halo_seed_host, double *out, int memspace);
+                   const double *halo_seed_host, int update, double *out, int memspace, double *boundary_rows_host,
+                   int64_t *n_unknown);
 
 /* basins (reference pyflwdir/basins.py:12-18, core.py:120-146) on a raster row-tiled over several GPUs /
  * processes, split-phase like pfd_upstream_area_cell_begin/_finish (Multi-GPU): `outlets` are k

@@ -90,7 +90,8 @@ def lib() -> C.CDLL:
         L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
-        L.pfd_hand_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_hand_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.POINTER(C.c_int64)]
         L.pfd_verify_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.pfd_verify_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
         L.pfd_main_upstream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int]
@@ -365,15 +366,20 @@ class RasterHandle:
         check(lib().pfd_hand(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(out), memspace))
         return out
 
-    def hand_block(self, drain, elevtn, elev_code, halo_seed, out=None, memspace=PFD_HOST):
+    def hand_block(self, drain, elevtn, elev_code, halo_seed, out=None, memspace=PFD_HOST, update=False):
         """HAND of a row block whose halo cells take their height from ``halo_seed`` (2 * ncol float64, host); drain,
-        elevtn and the result cover the block's device raster (own + halo rows)."""
+        elevtn and the result cover the block's device raster (own + halo rows).  ``update``: ``out`` holds an earlier
+        result, only its unknown (-inf) cells are recomputed.  Returns (out, boundary rows [2, ncol], unknown own cells)."""
         halo_seed = np.ascontiguousarray(halo_seed, dtype=np.float64)
         assert halo_seed.size == 2 * self.ncol
-        if memspace == PFD_HOST:
+        if memspace == PFD_HOST and out is None:
+            assert not update
             out = np.empty((self.nrow + sum(self.halo)) * self.ncol, np.float64)
-        check(lib().pfd_hand_block(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(halo_seed), ptr(out), memspace))
-        return out
+        brows = np.empty((2, self.ncol), np.float64)
+        unk = C.c_int64(0)
+        check(lib().pfd_hand_block(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(halo_seed), 1 if update else 0, ptr(out),
+                                   memspace, ptr(brows), C.byref(unk)))
+        return out, brows, int(unk.value)
 
     def verify_basins(self, outlets, ids, labels, memspace=PFD_HOST) -> dict:
         """Local-equation check of a basins() result with uint32 ids (see include/pfd.h)."""

@@ -130,12 +130,14 @@ __global__ void __launch_bounds__(256) k_normalise(const u8 *__restrict__ d8, Ge
 // ---------------------------------------------------------------------------------------------
 #define PIT_CHUNK 4096u  // cells per block (256 threads x 16)
 
-__global__ void __launch_bounds__(256) k_pit_count(const u8 *__restrict__ ncode, u32 n, u32 *__restrict__ counts) {
+// (halo != 0: row blocks — the halo sinks are roots of the block's level structure like its pits)
+__global__ void __launch_bounds__(256) k_pit_count(const u8 *__restrict__ ncode, u32 n, u32 *__restrict__ counts,
+                                                   int halo = 0) {
   const u32 base = blockIdx.x * PIT_CHUNK;
   u32 cnt = 0;
   for (u32 t = threadIdx.x; t < PIT_CHUNK; t += 256) {
     const u32 i = base + t;
-    if (i < n && ncode[i] == 0) ++cnt;
+    if (i < n && (ncode[i] == 0 || (halo && ncode[i] == D8_HALO))) ++cnt;
   }
   __shared__ u32 s;
   if (threadIdx.x == 0) s = 0;
@@ -176,13 +178,13 @@ __global__ void __launch_bounds__(1024) k_scan_u32_1block(u32 *__restrict__ v, u
 }
 
 __global__ void __launch_bounds__(256) k_pit_scatter(const u8 *__restrict__ ncode, u32 n,
-                                                     const u32 *__restrict__ offs, u32 *__restrict__ seq) {
+                                                     const u32 *__restrict__ offs, u32 *__restrict__ seq, int halo = 0) {
   // each thread owns 16 CONSECUTIVE cells so that the in-block order is the linear order
   const u32 base = blockIdx.x * PIT_CHUNK + threadIdx.x * 16;
   u32 mask = 0;
   for (u32 t = 0; t < 16; ++t) {
     const u32 i = base + t;
-    if (i < n && ncode[i] == 0) mask |= 1u << t;
+    if (i < n && (ncode[i] == 0 || (halo && ncode[i] == D8_HALO))) mask |= 1u << t;
   }
   const u32 cnt = __popc(mask);
   // block exclusive scan over the 256 thread counts
@@ -217,6 +219,31 @@ static int compact_pits(pfd_raster *h) {
   k_pit_scatter<<<nchunk, 256, 0, h->stream>>>(h->ncode, n, counts.as<u32>(), h->pits);
   KCHK();
   HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}
+
+// row blocks: the roots of the block's level structure = its pits + its halo sinks, ascending (kept in h->pits;
+// the public pit list stays refused on block handles)
+static int block_roots(pfd_raster *h, i64 *nroots) {
+  const u32 n = h->geo.n;
+  const u32 nchunk = cdiv_u32((u64)n, PIT_CHUNK);
+  DevBuf counts;
+  PFDCHK(counts.alloc(((size_t)nchunk + 1) * sizeof(u32)));
+  HIPCHK(hipMemsetAsync(counts.p, 0, ((size_t)nchunk + 1) * sizeof(u32), h->stream));
+  k_pit_count<<<nchunk, 256, 0, h->stream>>>(h->ncode, n, counts.as<u32>(), 1);
+  KCHK();
+  k_scan_u32_1block<<<1, 1024, 0, h->stream>>>(counts.as<u32>(), nchunk + 1);  // (last entry = the total)
+  KCHK();
+  u32 total = 0;
+  HIPCHK(hipMemcpyAsync(&total, counts.as<u32>() + nchunk, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->pits) pfd_dfree(h->pits);
+  h->pits = nullptr;
+  PFDCHK(pfd_dmalloc((void **)&h->pits, (size_t)std::max<u32>(total, 1u) * sizeof(u32)));
+  k_pit_scatter<<<nchunk, 256, 0, h->stream>>>(h->ncode, n, counts.as<u32>(), h->pits, 1);
+  KCHK();
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *nroots = (i64)total;
   return PFD_OK;
 }
 
@@ -463,8 +490,15 @@ __global__ void __launch_bounds__(256) k_bfs_level(const u8 *__restrict__ ncode,
 int pfd_order_cells_impl(pfd_raster *h) {
   if (h->gen) return pfd_gen_order(h);
   if (h->ordered) return PFD_OK;
-  PFDCHK(pfd_require_whole(h, "the cell ordering"));
-  if (!pfd_knob("PFD_ORDER_BFS")) {
+  const bool block = h->halo_top || h->halo_bot;  // row block: breadth-first from its pits and halo sinks
+  if (!block) PFDCHK(pfd_require_whole(h, "the cell ordering"));
+  if (block && h->n > 4294967294ll) {
+    pfd_set_error("the cell ordering needs 32-bit cell indices: a row block of %lld cells is too large", (long long)h->n);
+    return PFD_EUNSUPPORTED;
+  }
+  if (block) PFDCHK(pfd_ensure_normalised(h));
+  i64 nroot = h->n_pits;
+  if (!block && !pfd_knob("PFD_ORDER_BFS")) {
     // fast path: ranks by LDS-tiled pointer doubling + one radix sort of the cells by rank
     // (paths.hip); rasters with cycles fall through to the breadth-first build below
     int ok = 0;
@@ -473,30 +507,35 @@ int pfd_order_cells_impl(pfd_raster *h) {
     pfd_seg_end(h, 4);
     if (ok) return PFD_OK;
   }
-  PFDCHK(pfd_ensure_pits(h));
+  if (block) {
+    PFDCHK(block_roots(h, &nroot));
+  } else {
+    PFDCHK(pfd_ensure_pits(h));
+  }
   if (!h->seq) {  // (a buffer left by an abandoned rank-sort attempt holds n >= n_valid entries)
-    PFDCHK(pfd_dmalloc((void **)&h->seq, (size_t)h->n_valid * sizeof(u32)));
-    h->bytes_held += (size_t)h->n_valid * sizeof(u32);
+    const size_t cap_seq = block ? (size_t)h->n : (size_t)h->n_valid;  // (block: own cells + halo sinks)
+    PFDCHK(pfd_dmalloc((void **)&h->seq, std::max<size_t>(cap_seq, 1) * sizeof(u32)));
+    h->bytes_held += cap_seq * sizeof(u32);
   }
   pfd_seg_begin(h, "order_cells");
-  HIPCHK(hipMemcpyAsync(h->seq, h->pits, (size_t)h->n_pits * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->seq, h->pits, (size_t)nroot * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
   const int BATCH = 128;
   size_t cap = (size_t)(2 * (h->nrow + h->ncol) + 4 * BATCH + 64);
   DevBuf lvl;
   PFDCHK(lvl.alloc(cap * sizeof(i64)));
   HIPCHK(hipMemsetAsync(lvl.p, 0, cap * sizeof(i64), h->stream));
-  const i64 first[2] = {0, h->n_pits};
+  const i64 first[2] = {0, nroot};
   HIPCHK(hipMemcpyAsync(lvl.p, first, sizeof(first), hipMemcpyHostToDevice, h->stream));
   u64 ctrl0[8] = {0};
-  ctrl0[C_TAIL] = (u64)h->n_pits;
+  ctrl0[C_TAIL] = (u64)nroot;
   HIPCHK(hipMemcpyAsync(h->ctrl, ctrl0, sizeof(ctrl0), hipMemcpyHostToDevice, h->stream));
   std::vector<i64> off;
   off.push_back(0);
-  off.push_back(h->n_pits);
+  off.push_back(nroot);
   int lvl_next = 0;  // next level to expand
   i64 launches = 0;
   bool done = false;
-  i64 recent_max = h->n_pits;
+  i64 recent_max = nroot;
   std::vector<i64> tmp(BATCH);
   while (!done) {
     if ((size_t)(lvl_next + BATCH + 2) > cap) {  // grow the device offsets array

@@ -119,22 +119,19 @@ def hand_blocks(d8: np.ndarray, nblocks: int, drain, elevtn, devices=None, max_i
     drain, elevtn = drain.reshape(nrow, ncol), elevtn.reshape(nrow, ncol)
     devices = devices or [0] * nblocks
     rows = block_rows(nrow, nblocks)
-    handles, parts = [], []
-    for b, (r0, r1) in enumerate(rows):
-        a, e = block_slice(nrow, nblocks, b)
-        handles.append(_hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks)))
-        parts.append((np.ascontiguousarray(drain[a:e]), np.ascontiguousarray(elevtn[a:e])))
-    seeds = [np.full(2 * ncol, -np.inf) for _ in range(nblocks)]
-    own = [None] * nblocks
-    unknown_before, it = None, 0
+    blocks = []
     try:
+        for b, (r0, r1) in enumerate(rows):
+            a, e = block_slice(nrow, nblocks, b)
+            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
+            blocks.append(_HandBlock(h, drain[a:e], elevtn[a:e], code))
+        seeds = [np.full(2 * ncol, -np.inf) for _ in range(nblocks)]
+        unknown_before, it = None, 0
         while True:
             it += 1
-            for b, h in enumerate(handles):
-                top, _ = halo_of(b, nblocks)
-                out = h.hand_block(parts[b][0], parts[b][1], code, seeds[b]).reshape(-1, ncol)
-                own[b] = out[top:top + (rows[b][1] - rows[b][0])]
-            unknown = sum(int(np.isneginf(o).sum()) for o in own)
+            for b, blk in enumerate(blocks):
+                blk.sweep(seeds[b])
+            unknown = sum(blk.unknown for blk in blocks)
             if unknown == 0:
                 break
             if unknown == unknown_before or (max_iter is not None and it >= max_iter):
@@ -143,13 +140,49 @@ def hand_blocks(d8: np.ndarray, nblocks: int, drain, elevtn, devices=None, max_i
             unknown_before = unknown
             for b in range(nblocks):  # halo rows = the neighbours' boundary rows
                 if b > 0:
-                    seeds[b][:ncol] = own[b - 1][-1]
+                    seeds[b][:ncol] = blocks[b - 1].brows[1]
                 if b + 1 < nblocks:
-                    seeds[b][ncol:] = own[b + 1][0]
+                    seeds[b][ncol:] = blocks[b + 1].brows[0]
+        return np.concatenate([blk.result() for blk in blocks], axis=0), it
     finally:
-        for h in handles:
-            h.close()
-    return np.concatenate(own, axis=0), it
+        for blk in blocks:
+            blk.close()
+
+
+class _HandBlock:
+    """Device-resident state of one row block's HAND between the exchanges: drain, elevation and the heights stay in
+    HBM; only the two boundary rows and the number of unknown cells travel."""
+
+    def __init__(self, handle, drain_rows, elevtn_rows, code):
+        self.h, self.code = handle, code
+        ncol = handle.ncol
+        self.nrows_dev = handle.nrow + sum(handle.halo)
+        dev = handle.device
+        drain_rows = np.ascontiguousarray(drain_rows)
+        elevtn_rows = np.ascontiguousarray(elevtn_rows)
+        assert drain_rows.size == elevtn_rows.size == self.nrows_dev * ncol
+        self.drain = _hip.DeviceBuffer(drain_rows.nbytes, dev).upload(drain_rows)
+        self.elev = _hip.DeviceBuffer(elevtn_rows.nbytes, dev).upload(elevtn_rows)
+        self.out = _hip.DeviceBuffer(self.nrows_dev * ncol * 8, dev)
+        self.swept_with, self.brows, self.unknown = None, None, None
+
+    def sweep(self, seed):
+        if self.swept_with is not None and np.array_equal(self.swept_with.view(np.uint64), seed.view(np.uint64)):
+            return  # the heights of the halo cells did not change: neither did the block
+        update = self.swept_with is not None
+        self.swept_with = seed.copy()
+        _, self.brows, self.unknown = self.h.hand_block(self.drain, self.elev, self.code, seed, out=self.out,
+                                                        memspace=_hip.PFD_DEVICE, update=update)
+
+    def result(self):
+        ncol = self.h.ncol
+        return self.out.download(np.float64, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol * 8)
+
+    def close(self, close_handle=True):
+        for b in (self.drain, self.elev, self.out):
+            b.free()
+        if close_handle:
+            self.h.close()
 
 
 def exchange_unique_id(rank: int, world: int, group=None) -> bytes:
@@ -303,37 +336,45 @@ class DistributedRaster:
         iterations).  Bit-identical to the whole raster: see :func:`hand_blocks`.  Per iteration one all-gather of
         the two boundary rows (2 * ncol doubles per rank) and one agreement on the number of unknown cells."""
         h = self.handle
-        ncol, top = h.ncol, halo_of(self.rank, self.world)[0]
+        ncol = h.ncol
         drain, elevtn, code = _hand_inputs(drain_block, elevtn_block)
         seed = np.full(2 * ncol, -np.inf)
-        unknown_before, it, own = None, 0, None
-        while True:
-            it += 1
-            err = None
-            try:
-                out = h.hand_block(drain, elevtn, code, seed).reshape(-1, ncol)
-                own = out[top:top + h.nrow]
-                rec = np.concatenate([own[0], own[-1]])
-                mine = int(np.isneginf(own).sum())
-            except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
-                err, rec, mine = exc, np.zeros(2 * ncol), -1
-            parts = self.group.allgather(rec.tobytes())
-            counts = [int(x) for x in np.frombuffer(b"".join(self.group.allgather(np.int64(mine).tobytes())), np.int64)]
-            if err is not None:
-                raise err
-            if min(counts) < 0:
-                raise RuntimeError("another rank failed in hand()")
-            unknown = sum(counts)
-            if unknown == 0:
-                return own, it
-            if unknown == unknown_before or (max_iter is not None and it >= max_iter):
-                raise NotImplementedError("hand: heights that depend on each other through several row blocks "
-                                          "(a cycle through the block edges)")
-            unknown_before = unknown
-            if self.rank > 0:
-                seed[:ncol] = np.frombuffer(parts[self.rank - 1], np.float64)[ncol:]
-            if self.rank + 1 < self.world:
-                seed[ncol:] = np.frombuffer(parts[self.rank + 1], np.float64)[:ncol]
+        unknown_before, it = None, 0
+        blk, err = None, None
+        try:
+            blk = _HandBlock(h, drain, elevtn, code)
+        except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
+            err = exc
+        try:
+            while True:
+                it += 1
+                rec, mine = np.zeros(2 * ncol), -1
+                if err is None:
+                    try:
+                        blk.sweep(seed)
+                        rec, mine = blk.brows.ravel(), blk.unknown
+                    except Exception as exc:  # noqa: BLE001
+                        err = exc
+                parts = self.group.allgather(rec.tobytes())
+                counts = [int(x) for x in np.frombuffer(b"".join(self.group.allgather(np.int64(mine).tobytes())), np.int64)]
+                if err is not None:
+                    raise err
+                if min(counts) < 0:
+                    raise RuntimeError("another rank failed in hand()")
+                unknown = sum(counts)
+                if unknown == 0:
+                    return blk.result(), it
+                if unknown == unknown_before or (max_iter is not None and it >= max_iter):
+                    raise NotImplementedError("hand: heights that depend on each other through several row blocks "
+                                              "(a cycle through the block edges)")
+                unknown_before = unknown
+                if self.rank > 0:
+                    seed[:ncol] = np.frombuffer(parts[self.rank - 1], np.float64)[ncol:]
+                if self.rank + 1 < self.world:
+                    seed[ncol:] = np.frombuffer(parts[self.rank + 1], np.float64)[:ncol]
+        finally:
+            if blk is not None:
+                blk.close(close_handle=False)
 
     def close(self):
         if self.handle is not None:

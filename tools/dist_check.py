@@ -1,5 +1,5 @@
 """One rank of a 2+-process check of the collective entry points over the torch-free TCP group:
-DistributedRaster.upstream_area and .basins of a row block against the oracle on the whole raster.
+DistributedRaster.upstream_area, .basins and .hand of a row block against the oracle on the whole raster.
 Launched by tests/test_gpu_dist.py (all ranks on the one GPU of the test box, records through the host).
 
     RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tools/dist_check.py"""
@@ -32,6 +32,12 @@ ids = (np.arange(outl.size) + 3).astype(np.uint32)
 lab = dr.basins(outl, ids, shape[0])
 exp = O.basins(idxs_ds, outl.astype(idxs_ds.dtype), seq, ids).reshape(shape)
 assert np.array_equal(lab, exp[r0:r1]), f"rank {rank}: basins differ"
+# collective HAND: bit-identical to the oracle on the whole raster (the block passes its rows incl. halo rows)
+elev = O.synth_elev_f32(shape[0], shape[1], seed=77, tilt=100000, white=2, nodata_pct=20)
+drain = upa > np.percentile(upa[upa > 0], 97)
+exp_h = O.height_above_nearest_drain(idxs_ds, seq, drain.ravel(), elev.ravel()).reshape(shape)
+got_h, iters = dr.hand(drain[a:e], elev[a:e])
+assert np.array_equal(got_h.view(np.uint64), exp_h[r0:r1].view(np.uint64)), f"rank {rank}: hand differs"
 dr.close()
 grp.barrier()
 grp.close()
