@@ -59,6 +59,8 @@ struct SuperArgs {
   u32 edge_nstr;    // final pass: != 0 -> only the first and last of the edge_nstr supertile rows deliver
   u32 ntr, ntc;     // tiles per column / row (slots of tiles beyond them do not exist)
   u32 hcap;         // super-exits per hypertile that fit in LDS (HCAP; lowered by tests via PFD_TEST_HCAP)
+  u8 *sover;        // [nst] set by k_super<false>: the supertile holds more exits than the dense form keeps in LDS
+  u32 scap;         // that capacity (SCAP; lowered by tests via PFD_TEST_SCAP)
 };
 
 // level-3 (hypertile = 4x4 supertiles) solve arguments; node ids k = ht*HCAP + i, i < hcnt[ht]
@@ -229,7 +231,7 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (7 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf;
+  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;

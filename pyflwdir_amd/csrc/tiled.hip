@@ -591,13 +591,16 @@ __device__ __forceinline__ void flag_active(u64 *ctrl) {
 //   FINAL == true : exits start with their tile-local count + the flow entering the supertile
 //                   at them (xin, from level 3); every exit delivers its total to its tile entry
 // ---------------------------------------------------------------------------------------------
+// The positional form (LDS image indexed by slot: 96 KB, one workgroup per CU) only runs for the supertiles the
+// dense form below could not take (more than SCAP exits: s.sover[st] != 0) — contrived rasters only.
 template <bool FINAL>
-__global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
+__global__ void __launch_bounds__(1024) k_super_pos(SuperArgs s) {
   __shared__ u32 T[SSL];
   __shared__ uint16_t P[SSL];
   __shared__ u32 s_cnt, s_base;
   const u32 tid = threadIdx.x;
   const u32 st = blockIdx.x;
+  if (!s.sover[st]) return;
   const u32 base = st << SSHIFT;
   constexpr int SPT = SSL / 1024;  // slots per thread
   if (FINAL && s.edge_nstr) {
@@ -702,6 +705,205 @@ __global__ void __launch_bounds__(1024) k_super(SuperArgs s) {
   }
 }
 
+
+// The dense form: only the EXITS of the supertile (a third of its slots on real rasters) get an LDS word.  A slot's
+// dense index is the number of exits before it — per 64-slot chunk an exit bitmask (one wave ballot) and a prefix
+// count, 3 KB of LDS — so T and P shrink to SCAP entries (72 KB: two workgroups per CU, which lets the loads of
+// one supertile overlap the LDS rounds of another; the positional form was alone on its CU), the rounds run over
+// the exits only (no idle lanes), and only exits touch the per-slot arrays in HBM.
+#define SCAP 12288u
+template <bool FINAL>
+__global__ void __launch_bounds__(1024, 8) k_super(SuperArgs s) {
+  __shared__ u32 T[SCAP];
+  __shared__ uint16_t P[SCAP];
+  __shared__ u64 maskw[SSL / 64];
+  __shared__ u32 cbase[SSL / 64];
+  __shared__ u32 wsum[4], wtot[16];
+  __shared__ u32 s_base;
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 st = blockIdx.x;
+  const u32 base = st << SSHIFT;
+  constexpr int SPT = SSL / 1024;  // slots per thread
+  if (FINAL && s.edge_nstr) {
+    // row blocks, first solve: only the deliveries into the first and last TILE row are needed yet; they
+    // come from exits in tile rows 0..1 and ntr-2..ntr-1 -> supertile row 0 and the rows of those two
+    const u32 row = st / s.nstc;
+    if (row != 0 && row != (s.ntr - 1) / SG && row != (s.ntr >= 2 ? (s.ntr - 2) / SG : 0u)) return;
+  }
+  if (FINAL && s.sover[st]) return;  // (taken by k_super_pos; the first pass decided)
+  // slots of tiles beyond the raster edge (partial supertiles) hold nothing and are never read
+  auto slot_exists = [&](u32 i) -> bool {
+    const u32 tl = i >> 8;
+    return (st / s.nstc) * SG + (tl >> 3) < s.ntr && (st % s.nstc) * SG + (tl & 7) < s.ntc;
+  };
+  u32 exbits = 0, sxbits = 0;  // bit j: own slot j holds an exit / an exit that drains into another supertile
+  {
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+      const u32 i = tid + 1024u * j;
+      const u32 tgt = slot_exists(i) ? s.xtgt[base + i] : NONE32;
+      const bool ex = tgt != NONE32;
+      exbits |= ex ? 1u << j : 0u;
+      sxbits |= (ex && (tgt >> SSHIFT) != st) ? 1u << j : 0u;
+      const u64 m = __ballot(ex);
+      if (lane == 0) maskw[i >> 6] = m;
+    }
+    __syncthreads();
+    if (tid < SSL / 64) {  // exclusive prefix of the chunk counts (4 waves x 64 chunks)
+      const u32 c = (u32)__popcll(maskw[tid]);
+      u32 incl = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        const u32 y = __shfl_up(incl, o);
+        if (lane >= (u32)o) incl += y;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      cbase[tid] = incl - c;
+    }
+    __syncthreads();
+    if (tid < SSL / 64) {
+      u32 woff = 0;
+      for (u32 w = 0; w < wave; ++w) woff += wsum[w];
+      cbase[tid] += woff;
+    }
+    const u32 n0 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (!FINAL && tid == 0) s.sover[st] = n0 > s.scap ? 1 : 0;
+    if (n0 > s.scap) return;  // (uniform) k_super_pos takes this supertile
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < SPT; ++j) {  // (4 at a time: fully unrolled, the loads of all 16 slots in flight spill registers)
+      if (!(exbits & (1u << j))) continue;
+      const u32 i = tid + 1024u * j;
+      const u32 g = base + i;
+      const u32 tgt = s.xtgt[g];  // (again: 16 targets kept across the prefix would cost 16 registers of 64)
+      const u32 d = cbase[i >> 6] + (u32)__popcll(maskw[i >> 6] & ((1ull << (i & 63u)) - 1ull));
+      u32 t = (FINAL && s.bonly) ? 0u : s.xT[g];
+      if (FINAL) {
+        t += s.xin[g];
+      } else {
+        s.xin[g] = 0;  // accumulated by k_push3 before the final pass reads it
+      }
+      u32 p = d | SDONE;
+      if ((tgt >> SSHIFT) == st) {         // drains into a tile of this supertile
+        const u32 l = s.elink[tgt];        // exit reached from there (same tile => same supertile)
+        if (l != NONE32) {
+          const u32 li = l & (SSL - 1);
+          p = cbase[li >> 6] + (u32)__popcll(maskw[li >> 6] & ((1ull << (li & 63u)) - 1ull));
+        }
+      }
+      T[d] = t;
+      P[d] = (uint16_t)p;
+    }
+  }
+  const u32 n = wsum[0] + wsum[1] + wsum[2] + wsum[3];  // exits of the supertile
+  __syncthreads();
+  // ---- doubling over the exits (dense: thread t owns exits t, t + 1024, ...) ----
+  {
+    constexpr int DPT = SCAP / 1024;
+    u32 y[DPT];
+    u32 live = 0;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const u32 e = tid + 1024u * k;
+      y[k] = 0;
+      if (e < n) {
+        const u32 p = P[e];
+        y[k] = p & (SDONE - 1u);
+        if (!(p & SDONE)) live |= 1u << k;
+      }
+    }
+    for (int round = 0; round < MAXROUNDS_SUPER; ++round) {
+      u32 av[DPT], q[DPT];
+#pragma unroll
+      for (int k = 0; k < DPT; ++k) {
+        if (live & (1u << k)) {
+          av[k] = T[tid + 1024u * k];
+          q[k] = P[y[k]];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < DPT; ++k) {
+        if (live & (1u << k)) {
+          atomicAdd(&T[y[k]], av[k]);
+          P[tid + 1024u * k] = (uint16_t)q[k];
+          y[k] = q[k] & (SDONE - 1u);
+          if (q[k] & SDONE) live &= ~(1u << k);
+        }
+      }
+      if (!__syncthreads_or((int)live)) break;
+    }
+    if (live) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the supertile
+  }
+  auto dense = [&](u32 i) -> u32 { return cbase[i >> 6] + (u32)__popcll(maskw[i >> 6] & ((1ull << (i & 63u)) - 1ull)); };
+  if (FINAL) {
+#pragma unroll 4
+    for (int j = 0; j < SPT; ++j) {
+      if (!(exbits & (1u << j))) continue;
+      const u32 i = tid + 1024u * j;
+      atomicAdd(&s.inflow[s.xtgt[base + i]], T[dense(i)]);
+    }
+    return;
+  }
+  // ---- records of the pass: R2 = slot of the last exit of the path inside the supertile; super-exits get dense
+  //      ids (order is irrelevant) and start values for level 3
+  u32 pv[SPT / 2];  // the exits' saturated pointers (root | SDONE), two per register
+  u32 wcnt = 0;     // (wave-uniform) super-exits of this wave
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const u32 v = (exbits & (1u << j)) ? (u32)P[dense(tid + 1024u * j)] : 0u;
+    if (j & 1) pv[j >> 1] |= v << 16;
+    else pv[j >> 1] = v;
+    wcnt += (u32)__popcll(__ballot((sxbits >> j) & 1u));
+  }
+  if (lane == 0) wtot[wave] = wcnt;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {  // a root's word now names its slot
+    if (!(exbits & (1u << j))) continue;
+    const u32 i = tid + 1024u * j, d = dense(i);
+    if (((pv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) == (d | SDONE)) P[d] = (uint16_t)i;
+  }
+  const u32 ht = ((st / s.nstc) / HG) * s.nhtc + (st % s.nstc) / HG;
+  if (tid == 0) {
+    u32 tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      const u32 c = wtot[w];
+      wtot[w] = tot;
+      tot += c;
+    }
+    if (!tot) {
+      s_base = 0;
+    } else if (s.hmode) {  // ids of one hypertile are consecutive: its level-3 solve runs in LDS
+      const u32 b = atomicAdd(&s.hcnt[ht], tot);
+      if (b + tot > s.hcap) s.ctrl[T_OVERFLOW] = 1;  // host falls back to the flat id range
+      s_base = ht * HCAP + (b + tot > s.hcap ? 0u : b);
+    } else {
+      s_base = (u32)atomicAdd((unsigned long long *)&s.ctrl[T_NSUPER], (unsigned long long)tot);
+    }
+  }
+  __syncthreads();
+  u32 run = s_base + wtot[wave];
+#pragma unroll
+  for (int j = 0; j < SPT; ++j) {
+    const bool sx = (sxbits >> j) & 1u;
+    const u64 m = __ballot(sx);
+    if (exbits & (1u << j)) {  // (sxid and R2 are only ever read at exit slots)
+      const u32 i = tid + 1024u * j;
+      const u32 g = base + i;
+      const u32 r = (pv[j >> 1] >> (16 * (j & 1))) & (SDONE - 1u);
+      s.R2[g] = base + ((u32)P[r] & (SSL - 1));  // (masked: on a cycle r is no root and its word no slot; the pass is discarded)
+      u32 id = NONE32;
+      if (sx) {
+        id = run + (u32)__popcll(m & ((1ull << lane) - 1ull));
+        s.sx_slot[id] = g;
+        s.T3[id] = T[dense(i)];
+      }
+      s.sxid[g] = id;
+    }
+    run += (u32)__popcll(m);
+  }
+}
+
 // level 3 links: super-exit -> next super-exit on its path (through the supertile it enters)
 __device__ __forceinline__ bool sx_active(const SuperArgs &s, u32 k) {
   return !s.hmode || (k % HCAP) < s.hcnt[k / HCAP];
@@ -720,7 +922,9 @@ __global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__r
   const u32 n1 = s.elink[s.xtgt[e]];
   u32 j = k | XDONE;
   if (n1 != NONE32) {
-    const u32 id = s.sxid[s.R2[n1]];
+    // (sxid is only written at exit slots: on a raster with cycles R2 may name any slot — ask xtgt first)
+    const u32 r2 = s.R2[n1];
+    const u32 id = s.xtgt[r2] != NONE32 ? s.sxid[r2] : NONE32;
     if (id != NONE32) j = id;
   }
   J3[k] = j;
@@ -993,7 +1197,7 @@ struct LastExitArgs {
 };
 __device__ __forceinline__ u32 last_exit(const LastExitArgs &q, u32 f) {
   const u32 r2 = q.R2[f];
-  const u32 k = q.sxid[r2];
+  const u32 k = q.xtgt[r2] != NONE32 ? q.sxid[r2] : NONE32;  // (sxid is only written at exit slots)
   if (k == NONE32) return r2;  // the path ends inside this supertile
   u32 k3;
   if (q.hmode) {
@@ -1082,8 +1286,11 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{nst, xT, xtgt, elink, xin, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
-                 hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP};
+                 hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP, nullptr, SCAP};
+  PFDCHK(soverbuf.alloc((size_t)nst));
+  sa.sover = soverbuf.as<u8>();
   if (const char *e = pfd_knob("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
+  if (const char *e = pfd_knob("PFD_TEST_SCAP")) sa.scap = (u32)std::min<u32>((u32)atoi(e), SCAP);
   a.stamps = nullptr;
 #ifdef PFD_DEVTOOLS
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
@@ -1182,8 +1389,9 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
   sa.hmode = (nht > 1 && !force_flat && !pfd_knob("PFD_FLAT_L3")) ? 1 : 0;
   k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super_pos<false><<<nst, 1024, 0, h->stream>>>(sa);  // (only the supertiles the dense form flagged: normally none)
   KCHK();
-  ++*launches;
+  *launches += 2;
   if (!sa.hmode) {  // the flat level-3 rounds are sized by the number of super-exits
     u64 c[8];
     HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
@@ -1197,7 +1405,8 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   else if (nsuper)
     PFDCHK(level3_flat(launches));
   k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
-  ++*launches;
+  k_super_pos<true><<<nst, 1024, 0, h->stream>>>(sa);
+  *launches += 2;
   KCHK();
   return PFD_OK;
 }

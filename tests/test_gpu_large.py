@@ -130,6 +130,25 @@ def test_hypertile_overflow_fallback(gpu_lib, oracle, monkeypatch):
     assert np.array_equal(dist.upstream_area_blocks(d8, 2), exp)
 
 
+@pytest.mark.parametrize("scap", ["0", "5000"])
+def test_supertile_dense_capacity_fallback(gpu_lib, oracle, monkeypatch, scap):
+    """The level-2 solve keeps only the EXITS of a supertile in LDS (dense ids, SCAP of them); a supertile holding more
+    is taken by the positional kernel instead, decided on the device per supertile.  Forced here by lowering the
+    capacity: every supertile (0) / the fuller ones (5000) take the fallback; single handle, deferred, row blocks."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd import _hip, dist
+
+    d8 = oracle.synth_d8(2300, 2600, seed=8, tilt=100000, white=2, nodata_pct=10)
+    exp, _, _ = oracle.upstream_area_cell(d8)
+    monkeypatch.setenv("PFD_TEST_SCAP", scap)
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    assert np.array_equal(flw.upstream_area(), exp)
+    h = _hip.RasterHandle(d8, 2300, 2600, deferred=True)
+    assert np.array_equal(h.upstream_area_cell().reshape(2300, 2600), exp)
+    h.close()
+    assert np.array_equal(dist.upstream_area_blocks(d8, 3), exp)
+
+
 def test_level4_round_budget_miss(gpu_lib, oracle, monkeypatch):
     """Level 4 of the exit graph issues a fixed number of doubling rounds without asking the host;
     too few (forced here) must be noticed at the end of the pass and repaired by a longer re-run."""
