@@ -47,7 +47,8 @@ PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 B_ALG = {"upstream_area_cell": 29.0, "accuflux_f32": 33.0, "strahler": 18.0, "basins_u32": 18.0, "hand_f32": 35.0}
 B_ALG_PHASE = {"tile_local": 8.0, "exit_graph": 4.0, "tile_final": 17.0}
 # segment -> the kernel it times (names as rocprofv3 prints them); single-launch segments only
-KERNEL_OF = {"tile_local": "void k_tile<false, true, true>(TileArgs)", "tile_final": "void k_tile<true, false, false>(TileArgs)"}
+KERNEL_OF = {"tile_local": "void k_tile_local_fast<true, false>(TileArgs)", "tile_final": "void k_tile_final_fast<false>(TileArgs)"}
+B_FLOOR = 5.0  # absolute lower bound of upstream_area("cell"): 1 B/cell of codes in + 4 B/cell of counts out
 # synthetic regimes (oracle/pfd_oracle.c orc_synth_d8 and its device twin): tilt >> noise gives long
 # parallel rivers (max rank ~ nrow), small tilt a rough surface with many pits and meandering paths
 REGIMES = {"river": dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0),
@@ -55,22 +56,31 @@ REGIMES = {"river": dict(seed=0, tilt=1 << 26, white=2, nodata_pct=0),
            "meander": dict(seed=0, tilt=3000, white=2, nodata_pct=0)}
 
 
+def _pmc_table():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def measured_traffic(kernel, nrow, ncol):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this command at THIS raster size; tools/prof_pmc.sh
-    writes the table).  None when the size was not measured: never a number from another size."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            tab = json.load(f)
-    except (OSError, ValueError):
-        return None
-    e = tab.get(f"{kernel}|{nrow}x{ncol}")
+    writes the table).  None when the size was not measured: never a number from another size.
+    kernel "_whole_pass": all kernels of one timed step together; "_op:<tag>": one warm call of an operation."""
+    e = _pmc_table().get(f"{kernel}|{nrow}x{ncol}")
     return None if e is None else float(e["bytes_per_launch"])
 
 
 def roofline_upa(segs, n, nrow, ncol, ms_per_step, regime="river"):
     """Roofline object for the dominant KERNEL of the tiled pass (the tile pass that takes longest;
-    the exit graph is many small launches and is reported in phases_ms) + the whole pass."""
+    the exit graph is many small launches and is reported in phases_ms) + the whole pass.
+
+    Three fractions of the 8 TB/s HBM peak, so that the model cannot flatter: `frac` = SURVEY 8d's ALGORITHMIC bytes
+    (29 B/cell for the pass; the share of the phase for the kernel) / time; `frac_measured` = the bytes the PMC
+    counters saw (profiles/pmc_traffic.json, this size) / time — well below the model: the engine never materialises
+    the frontier the model charges for; `frac_floor` = the 5 B/cell no implementation can avoid / time."""
     cand = [s for s in segs if s["name"] in KERNEL_OF] or segs
     dom = max(cand, key=lambda s: s["ms"])
     b_alg = B_ALG_PHASE.get(dom["name"], B_ALG["upstream_area_cell"])
@@ -79,13 +89,21 @@ def roofline_upa(segs, n, nrow, ncol, ms_per_step, regime="river"):
     achieved = (b_alg * n / launches) / (avg_ms * 1e-3) / 1e9
     kname = KERNEL_OF.get(dom["name"], dom["name"])
     whole = B_ALG["upstream_area_cell"] * n / (ms_per_step * 1e-3) / 1e9
+    river = regime == "river"  # (the PMC passes ran on the river raster)
+    traffic = measured_traffic(kname, nrow, ncol) if river else None
+    traffic_pass = measured_traffic("_whole_pass", nrow, ncol) if river else None
+    floor = B_FLOOR * n / (ms_per_step * 1e-3) / 1e9
     return dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                frac=round(achieved / PEAK_HBM_GBS, 5),
-                traffic=measured_traffic(kname, nrow, ncol) if regime == "river" else None,  # (PMC passes: river raster)
+                frac=round(achieved / PEAK_HBM_GBS, 5), traffic=traffic,
+                frac_measured=None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
                 kernel=kname,
                 launches=dom["launches"], avg_launch_ms=round(avg_ms, 5), alg_bytes_per_cell=b_alg,
                 whole_pass=dict(alg_bytes_per_cell=B_ALG["upstream_area_cell"], achieved=round(whole, 2),
-                                frac=round(whole / PEAK_HBM_GBS, 5)),
+                                frac=round(whole / PEAK_HBM_GBS, 5), traffic=traffic_pass,
+                                measured_bytes_per_cell=None if traffic_pass is None else round(traffic_pass / n, 3),
+                                frac_measured=None if traffic_pass is None else
+                                round(traffic_pass / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                                floor_bytes_per_cell=B_FLOOR, frac_floor=round(floor / PEAK_HBM_GBS, 5)),
                 phases_ms={s["name"]: round(s["ms"], 3) for s in segs})
 
 
@@ -99,6 +117,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the raster given to the CPU baseline (0=auto)")
+    ap.add_argument("--ops", choices=["c3", "c5"], default=None,
+                    help="only the operation lines of configs[2] (30000^2) / configs[4] (36000x72000): what the PMC passes run")
     return ap.parse_args()
 
 
@@ -226,8 +246,9 @@ def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, ch
     out = dict(value=round(n * steps / total / 1e6, 2), ms_per_step=round(ms_per_step, 3),
                ms_per_step_median=round(statistics.median(per), 3), ms_per_step_min=round(min(per), 3),
                roofline=roofline_upa(segs, n, nrow, ncol, ms_per_step, regime))
-    cfg = dict(workload=label + ", upstream_area(unit='cell') int32 on 1 GPU; a step = decode + pit rule + validation "
-                                "+ tile pass + exit-graph solve + final tile pass on a fresh handle",
+    cfg = dict(workload=label + ", upstream_area(unit='cell') int32 on 1 GPU through the C-ABI (pfd_raster_create_deferred + "
+                                "pfd_upstream_area_cell: what FlwdirRaster.upstream_area calls, device-resident in and out); a step = "
+                                "decode + pit rule + validation + tile pass + exit-graph solve + final tile pass on a fresh handle",
                n_cells=n, n_valid=info["n_valid"], n_pits=info["n_pits"], parallelism="1 GPU")
     if checks:
         # graph statistics (outside the timed region): longest flow path, in-degree histogram, and the pointer-
@@ -307,27 +328,42 @@ def invariants(d8_buf, out_buf, nrow, ncol, info, device, samples=1_000_000):
     return res
 
 
-# ---- secondary lines: BASELINE.json configs[2] (float32 accuflux + Strahler at 30000 x 30000) + HAND ----
-def c3_lines(size, regime, steps, device):
-    """Wall time of a complete warm call of the exact (bit-identical to the serial loop) float32
-    accuflux and of the Strahler order, everything device-resident; the first call on the handle, which
-    also builds the sweep plan, is reported separately (the reference orders its cells once per object
-    too, flwdir.py:231-250)."""
-    n = size * size
-    d8_buf = _hip.synth_d8_device(size, size, device=device, **REGIMES[regime])
-    h = _hip.RasterHandle(d8_buf, size, size, device=device, memspace=_hip.PFD_DEVICE)
-    w = _hip.synth_weights_device(n, seed=1, device=device)
-    out_f = _hip.DeviceBuffer(n * 4, device)
-    out_b = _hip.DeviceBuffer(n, device)
-    lines = []
-    first = {}
+# ---- secondary lines: BASELINE.json configs[2] (float32 accuflux + Strahler at 30000 x 30000) and configs[4]
+#      (basins from 1000 outlets + HAND at a 72000 x 36000-cell tile) ----
+OP_TAG = {"accuflux(float32, direction='up')": "accuflux_f32_up", "stream_order(type='strahler')": "strahler",
+          "hand(drain, elevtn float32) -> float64": "hand_f32", "basins(1000 outlets) -> uint32": "basins_u32"}
 
-    def run(name, fn, b_alg, dtype):
+
+def pick_outlets(h, nrow, ncol, device, k=1000, seed=5):
+    """k outlets with large upstream areas: the maximum of k sampled rows (distinct cells, many nested in one
+    another's basins — BASELINE configs[4]: "basins() delineation from 1000 outlets")."""
+    upa = _hip.DeviceBuffer(nrow * ncol * 4, device)
+    h.upstream_area_cell(out=upa, memspace=_hip.PFD_DEVICE)
+    rng = np.random.default_rng(seed)
+    outl = []
+    for r in np.unique(rng.integers(0, nrow, k)):
+        row = upa.download(np.int32, (ncol,), offset_bytes=int(r) * ncol * 4)
+        outl.append(int(r) * ncol + int(np.argmax(row)))
+    upa.free()
+    outl = np.array(outl[:k], np.int64)
+    return outl, np.arange(1, outl.size + 1, dtype=np.uint32)
+
+
+def op_lines(nrow, ncol, synth, label, steps, device, ops=("accuflux", "strahler", "hand", "basins")):
+    """Wall time of complete warm calls of the order-sensitive operations (bit-identical to the reference's serial
+    loops) and of basins(), everything device-resident; the first call on the handle, which also builds the sweep
+    plan, is reported separately with its own roofline (the reference orders its cells once per object too,
+    flwdir.py:231-250: SURVEY 8d's byte model charges that build to every call — the warm call does not pay it)."""
+    n = nrow * ncol
+    d8_buf = _hip.synth_d8_device(nrow, ncol, device=device, **synth)
+    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE)
+    lines, bufs = [], [d8_buf]
+
+    def run(name, fn, b_alg, dtype, first_builds_plan):
         t0 = time.perf_counter()
         fn()  # first call on the handle: builds the plan of the exact-order engine (once per raster) + allocations
-        first.setdefault("ms", round((time.perf_counter() - t0) * 1e3, 2))
-        per = []
-        segs = None
+        first_ms = (time.perf_counter() - t0) * 1e3
+        per, segs = [], None
         h.set_profiling(True)
         for _ in range(steps):
             t1 = time.perf_counter()
@@ -338,28 +374,60 @@ def c3_lines(size, regime, steps, device):
         ms = statistics.median(per)
         sweep = [s for s in segs if s["name"].startswith(("sweep", "chain", "exact"))]
         achieved = b_alg * n / (ms * 1e-3) / 1e9
-        lines.append(dict(op=name, workload=f"{size}x{size} synthetic D8 ({regime} regime), {name}; warm call on a handle "
-                                               "whose sweep plan exists (built once per raster by the first call)",
-                          dtype=dtype, ms_per_call=round(ms, 3), ms_per_call_min=round(min(per), 3),
-                          value=round(n / ms / 1e3, 2), unit="Mcells/s", first_call_on_handle_ms=first["ms"],
-                          roofline=dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                                        frac=round(achieved / PEAK_HBM_GBS, 5), traffic=None, alg_bytes_per_cell=b_alg,
-                                        phases_ms={s["name"]: round(s["ms"], 3) for s in segs},
-                                        launches={s["name"]: s["launches"] for s in sweep})))
+        traffic = measured_traffic("_op:" + OP_TAG[name], nrow, ncol) if synth == REGIMES["river"] or nrow != ncol else None
+        line = dict(op=name, workload=f"{label}, {name}; warm call through the C-ABI on a handle whose sweep plan exists "
+                                      "(built once per raster by the first order-sensitive call)",
+                    dtype=dtype, ms_per_call=round(ms, 3), ms_per_call_min=round(min(per), 3),
+                    value=round(n / ms / 1e3, 2), unit="Mcells/s",
+                    roofline=dict(bound="hbm", achieved=round(achieved, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                  frac=round(achieved / PEAK_HBM_GBS, 5), traffic=traffic,
+                                  frac_measured=None if traffic is None else round(traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                                  alg_bytes_per_cell=b_alg,
+                                  phases_ms={s["name"]: round(s["ms"], 3) for s in segs},
+                                  launches={s["name"]: s["launches"] for s in sweep}))
+        if first_builds_plan:  # the same bytes against the call that also decodes, orders and plans
+            fa = b_alg * n / (first_ms * 1e-3) / 1e9
+            line["first_call_on_handle_ms"] = round(first_ms, 2)
+            line["roofline_first_call"] = dict(bound="hbm", achieved=round(fa, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                               frac=round(fa / PEAK_HBM_GBS, 5), alg_bytes_per_cell=b_alg,
+                                               note="first order-sensitive call on a fresh handle: plan build + sweep")
+        lines.append(line)
 
-    run("accuflux(float32, direction='up')",
-        lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, has_nodata=1, direction=_hip.PFD_UP, out=out_f,
-                           memspace=_hip.PFD_DEVICE), B_ALG["accuflux_f32"], "f32")
-    run("stream_order(type='strahler')", lambda: h.strahler(None, out=out_b, memspace=_hip.PFD_DEVICE),
-        B_ALG["strahler"], "u8")
-    # configs[4]'s second operation: height above the nearest drain, float32 elevation -> float64 (reference
-    # dem.height_above_nearest_drain, pyflwdir/dem.py:299-330); drain = the cells of Strahler order 1
-    elev = _hip.synth_elev_device(size, size, device=device, **REGIMES[regime])
-    out_d = _hip.DeviceBuffer(n * 8, device)
-    run("hand(drain, elevtn float32) -> float64", lambda: h.hand(out_b, elev, _hip.PFD_F32, out=out_d, memspace=_hip.PFD_DEVICE),
-        B_ALG["hand_f32"], "f64")
+    first = True
+    out_b = _hip.DeviceBuffer(n, device)
+    bufs.append(out_b)
+    if "accuflux" in ops:
+        w = _hip.synth_weights_device(n, seed=1, device=device)
+        out_f = _hip.DeviceBuffer(n * 4, device)
+        bufs += [w, out_f]
+        run("accuflux(float32, direction='up')",
+            lambda: h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, has_nodata=1, direction=_hip.PFD_UP, out=out_f,
+                               memspace=_hip.PFD_DEVICE), B_ALG["accuflux_f32"], "f32", first)
+        first = False
+    if "strahler" in ops or "hand" in ops:
+        run("stream_order(type='strahler')", lambda: h.strahler(None, out=out_b, memspace=_hip.PFD_DEVICE),
+            B_ALG["strahler"], "u8", first)
+        first = False
+    if "hand" in ops:
+        # height above the nearest drain, float32 elevation -> float64 (reference dem.height_above_nearest_drain,
+        # pyflwdir/dem.py:299-330); drain = the cells of Strahler order 1
+        elev = _hip.synth_elev_device(nrow, ncol, device=device, **synth)
+        out_d = _hip.DeviceBuffer(n * 8, device)
+        bufs += [elev, out_d]
+        run("hand(drain, elevtn float32) -> float64", lambda: h.hand(out_b, elev, _hip.PFD_F32, out=out_d, memspace=_hip.PFD_DEVICE),
+            B_ALG["hand_f32"], "f64", first)
+        first = False
+    if "basins" in ops:
+        outl, ids = pick_outlets(h, nrow, ncol, device)
+        lab = _hip.DeviceBuffer(n * 4, device)
+        bufs.append(lab)
+        run("basins(1000 outlets) -> uint32", lambda: h.basins(outl, ids, out=lab, memspace=_hip.PFD_DEVICE),
+            B_ALG["basins_u32"], "u32", False)
+        v = h.verify_basins(outl, ids, lab, memspace=_hip.PFD_DEVICE)  # every cell's local equation, on the device
+        lines[-1]["invariants"] = dict(all_cells_label_equals_downstream_label=bool(v["bad_cells"] == 0 and v["bad_nodata"] == 0),
+                                       labelled_cells=v["n_labelled"], outlets=int(outl.size))
     h.close()
-    for b in (d8_buf, w, out_f, out_b, elev, out_d):
+    for b in bufs:
         b.free()
     _hip.check(_hip.lib().pfd_trim(device))
     return lines
@@ -587,6 +655,15 @@ def main():
     if world > 1 or os.environ.get("PFD_BENCH_FORCE_DIST"):  # the env knob runs the RCCL path with 1 rank
         return run_distributed(a, rank, world, local)
     device = local
+    if a.ops:  # (tools/prof_pmc.sh: the operation lines alone, `steps` warm calls each)
+        if a.ops == "c3":
+            lines = op_lines(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", a.steps, device)
+        else:
+            lines = op_lines(36000, 72000, dict(seed=2, tilt=100000, white=2, nodata_pct=30),
+                             "36000x72000 synthetic D8 (rough regime, 30 % nodata: BASELINE configs[4] shape)", a.steps, device,
+                             ops=("hand", "basins"))
+        print(json.dumps(dict(ops=lines)))
+        return
     line, cfg = upa_line(a.size, a.size, a.regime, a.steps, a.warmup, device, cpu=not a.no_cpu_baseline,
                          cpu_rows=a.cpu_rows)
     out = dict(metric="Mcells/s upstream_area on D8 raster", value=line.pop("value"), unit="Mcells/s", n_gpus=1,
@@ -600,7 +677,11 @@ def main():
         sec.append(dict(op="upstream_area(unit='cell')", workload=c2["workload"], value=l2["value"], unit="Mcells/s",
                         ms_per_step=l2["ms_per_step"], ms_per_step_median=l2["ms_per_step_median"], dtype="int32",
                         n_valid=c2["n_valid"], n_pits=c2["n_pits"], roofline=l2["roofline"]))
-        sec += c3_lines(30000, a.regime, 3, device)
+        sec += op_lines(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", 3, device)
+        # configs[4]'s shape: a MERIT-Hydro-like 3-arcsec tile, 72000 x 36000 cells (36000 rows), rough terrain, 30 % ocean
+        sec += op_lines(36000, 72000, dict(seed=2, tilt=100000, white=2, nodata_pct=30),
+                        "36000x72000 synthetic D8 (rough regime, 30 % nodata: BASELINE configs[4] shape)", 2, device,
+                        ops=("hand", "basins"))
         # workload spread: the same pass on a rough surface, on a pit-riddled one, on a mosaic of the reference's real
         # Rhine raster and on the tile pass's worst case, with the graph statistics that explain the differences
         for reg in ("rough", "meander", "rhine_mosaic", "filled_mosaic", "serpentine"):

@@ -198,8 +198,9 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   const u32 live = (lv[0] ? 1u : 0u) + (lv[1] ? 1u : 0u) + (lv[2] ? 1u : 0u) + (lv[3] ? 1u : 0u);
   if ((a.ablate & 32) && tid == 0) {  // pfd_set_profiling(h, 2): rounds this tile needed (max and sum over the tiles)
     const unsigned long long r = (unsigned long long)min(round + 1, MAXROUNDS_TILE);
-    atomicMax((unsigned long long *)&a.ctrl[48], r);
-    atomicAdd((unsigned long long *)&a.ctrl[49], r);
+    const u32 w = (tr * a.ntc + tc) & 255u;
+    atomicMax((unsigned long long *)&a.rcnt[w], r);
+    atomicAdd((unsigned long long *)&a.rcnt[256 + w], r);
   }
   // a cell on or upstream of a cycle never reaches a root word: count their quads (normally zero)
   if (live) atomicAdd((unsigned long long *)&a.ctrl[T_UNSAT], (unsigned long long)live);
@@ -350,8 +351,9 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
   const u32 live = (lv[0] ? 1u : 0u) + (lv[1] ? 1u : 0u) + (lv[2] ? 1u : 0u) + (lv[3] ? 1u : 0u);
   if ((a.ablate & 32) && tid == 0) {
     const unsigned long long r = (unsigned long long)min(round + 1, MAXROUNDS_TILE);
-    atomicMax((unsigned long long *)&a.ctrl[50], r);
-    atomicAdd((unsigned long long *)&a.ctrl[51], r);
+    const u32 w = (tr * a.ntc + tc) & 255u;
+    atomicMax((unsigned long long *)&a.rcnt[512 + w], r);
+    atomicAdd((unsigned long long *)&a.rcnt[768 + w], r);
   }
   if (live) atomicAdd((unsigned long long *)&a.ctrl[T_UNSAT], (unsigned long long)live);
 

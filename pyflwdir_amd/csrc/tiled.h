@@ -103,6 +103,8 @@ struct TileArgs {
   i32 *out;
   u32 tr_lo, tr_hi, tc_lo, tc_hi;  // the rectangle of INTERIOR tiles [tr_lo, tr_hi) x [tc_lo, tc_hi) (k_tile_*_fast,
                    // tile_fast.h); k_tile runs on the frame around it (1-D grid, frame_tile())
+  u64 *rcnt;       // pfd_set_profiling(h, 2): [4][256] doubling rounds of the tile passes (local max, local sum, final
+                   // max, final sum), spread over 256 words by tile id — one same-address atomic per tile costs ~12 ns
   u64 *stamps;     // DEVTOOLS: [1024][8] cycle stamps, spread over 1024 rows against same-address atomics
   int ablate;      // profiling knob (env PFD_TILE_ABLATE): bit0 skip doubling, bit4 cycle stamps; bit5 (set by
                    // pfd_set_profiling(h, 2)) counts the doubling rounds per tile into ctrl[48..51]
@@ -231,7 +233,7 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (7 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf;
+  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;

@@ -393,8 +393,9 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
     }
     if ((a.ablate & 32) && tid == 0) {  // pfd_set_profiling(h, 2): rounds this tile needed (max and sum over the tiles)
       const unsigned long long r = (unsigned long long)min(round + 1, MAXROUNDS_TILE);
-      atomicMax((unsigned long long *)&a.ctrl[FINAL ? 50 : 48], r);
-      atomicAdd((unsigned long long *)&a.ctrl[FINAL ? 51 : 49], r);
+      const u32 w = (tr * a.ntc + tc) & 255u;
+      atomicMax((unsigned long long *)&a.rcnt[(FINAL ? 512 : 0) + w], r);
+      atomicAdd((unsigned long long *)&a.rcnt[(FINAL ? 768 : 256) + w], r);
     }
   }
   TSTAMP(2)
@@ -591,6 +592,22 @@ __device__ __forceinline__ void flag_active(u64 *ctrl) {
 //   FINAL == true : exits start with their tile-local count + the flow entering the supertile
 //                   at them (xin, from level 3); every exit delivers its total to its tile entry
 // ---------------------------------------------------------------------------------------------
+// "does any lane of the workgroup still move a pointer": wave leaders publish their ballot in one of two alternating
+// flag rows, everybody reads the row after ONE barrier (__syncthreads_or costs three)
+template <int NWAVES>
+__device__ __forceinline__ bool wg_vote(u32 (*s_flag)[NWAVES], int round, u32 tid, bool live) {
+  const bool any = __ballot(live) != 0ull;
+  if ((tid & 63u) == 0u) s_flag[round & 1][tid >> 6] = any ? 1u : 0u;
+  __syncthreads();
+  u32 acc = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVES; w += 4) {
+    const uint4 f = *(const uint4 *)&s_flag[round & 1][w];
+    acc |= f.x | f.y | f.z | f.w;
+  }
+  return acc != 0u;
+}
+
 // The positional form (LDS image indexed by slot: 96 KB, one workgroup per CU) only runs for the supertiles the
 // dense form below could not take (more than SCAP exits: s.sover[st] != 0) — contrived rasters only.
 template <bool FINAL>
@@ -719,6 +736,7 @@ __global__ void __launch_bounds__(1024, 8) k_super(SuperArgs s) {
   __shared__ u64 maskw[SSL / 64];
   __shared__ u32 cbase[SSL / 64];
   __shared__ u32 wsum[4], wtot[16];
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][16];
   __shared__ u32 s_base;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 st = blockIdx.x;
@@ -830,7 +848,7 @@ __global__ void __launch_bounds__(1024, 8) k_super(SuperArgs s) {
           if (q[k] & SDONE) live &= ~(1u << k);
         }
       }
-      if (!__syncthreads_or((int)live)) break;
+      if (!wg_vote<16>(s_flag, round, tid, live != 0u)) break;
     }
     if (live) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the supertile
   }
@@ -950,6 +968,7 @@ template <bool FINAL>
 __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
   __shared__ u32 T[HCAP];
   __shared__ uint16_t P[HCAP];
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][16];
   __shared__ u32 s_cnt, s_base;
   const u32 tid = threadIdx.x;
   const u32 ht = blockIdx.x;
@@ -1004,7 +1023,7 @@ __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
         if (q[j] & HDONE) live &= ~(1u << j);
       }
     }
-    if (!__syncthreads_or((int)live)) break;
+    if (!wg_vote<16>(s_flag, round, tid, live != 0u)) break;
   }
   if (live) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the hypertile
   if (FINAL) {
@@ -1300,7 +1319,12 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
     HIPCHK(hipMemsetAsync(a.stamps, 0, 8192 * sizeof(u64), h->stream));
   }
 #endif
-  if (h->count_rounds) a.ablate |= 32;
+  if (h->count_rounds) {
+    a.ablate |= 32;
+    PFDCHK(rcntbuf.alloc(1024 * sizeof(u64)));
+    HIPCHK(hipMemsetAsync(rcntbuf.p, 0, 1024 * sizeof(u64), h->stream));
+    a.rcnt = rcntbuf.as<u64>();
+  }
   is_block = h->halo_top || h->halo_bot;
   // interior tiles (tile_fast.h): the tile, its ring and 4 staging columns either side inside the device raster, and
   // none of those rows a halo row or a boundary row of a row block:  r0 >= row_first + 1,  r0 + TS <= row_last,
@@ -1438,6 +1462,8 @@ int TiledRun::phase_a() {
     if (have_i) {
       if (a.weights) k_tile_local_fast<true, true><<<gridi, 256, 0, h->stream>>>(a);
       else k_tile_local_fast<true, false><<<gridi, 256, 0, h->stream>>>(a);
+      pfd_seg_end(h, 1);
+      pfd_seg_begin(h, "tile_local_frame");
     }
     if (is_block)
       k_tile<false, true><<<gridf, 256, 0, h->stream>>>(a);
@@ -1445,19 +1471,21 @@ int TiledRun::phase_a() {
       k_tile<false, true, true><<<gridf, 256, 0, h->stream>>>(a);
     fused_norm = true;
     KCHK();
-    pfd_seg_end(h, have_i ? 2 : 1);
+    pfd_seg_end(h, 1);
     k_tile_counts<<<std::min<u32>(cdiv_u32((u64)ntr * ntc, 4096), 256u), 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);
   } else {
     if (have_i) {
       if (a.weights) k_tile_local_fast<false, true><<<gridi, 256, 0, h->stream>>>(a);
       else k_tile_local_fast<false, false><<<gridi, 256, 0, h->stream>>>(a);
+      pfd_seg_end(h, 1);
+      pfd_seg_begin(h, "tile_local_frame");
     }
     if (is_block)
       k_tile<false><<<gridf, 256, 0, h->stream>>>(a);
     else
       k_tile<false, false, true><<<gridf, 256, 0, h->stream>>>(a);
     KCHK();
-    pfd_seg_end(h, have_i ? 2 : 1);
+    pfd_seg_end(h, 1);
   }
 
   pfd_seg_begin(h, "exit_graph");
@@ -1505,18 +1533,28 @@ int TiledRun::phase_b(int *complete) {
   const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
   const bool have_i = gridi.x && gridi.y;
   pfd_seg_begin(h, "tile_final");
-  if (have_i) {
+  if (have_i) {  // (segments: the interior kernel alone, then the frame around it)
     if (a.weights) k_tile_final_fast<true><<<gridi, 256, 0, h->stream>>>(a);
     else k_tile_final_fast<false><<<gridi, 256, 0, h->stream>>>(a);
+    pfd_seg_end(h, 1);
+    pfd_seg_begin(h, "tile_final_frame");
   }
   k_tile<true><<<frame_tiles(ntr, ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi), 256, 0, h->stream>>>(a);
   KCHK();
-  pfd_seg_end(h, have_i ? 2 : 1);
+  pfd_seg_end(h, 1);
   u64 c0[48];
   HIPCHK(hipMemcpyAsync(c0, h->ctrl, sizeof(c0), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   const u64 *c = c0 + 8;
-  if (a.ablate & 32) HIPCHK(hipMemcpy(h->tile_rounds, h->ctrl + 48, 4 * sizeof(u64), hipMemcpyDeviceToHost));
+  if (a.ablate & 32) {
+    std::vector<u64> rc(1024);
+    HIPCHK(hipMemcpy(rc.data(), a.rcnt, 1024 * sizeof(u64), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) {
+      u64 v = 0;
+      for (int w = 0; w < 256; ++w) v = (k & 1) ? v + rc[256 * k + w] : std::max(v, rc[256 * k + w]);
+      h->tile_rounds[k] = (i64)v;
+    }
+  }
   if (fused_norm && !h->normalised) PFDCHK(pfd_adopt_counts(h, c0));  // bad codes / no pits surface here
   if (a.ablate & 16) {
     std::vector<u64> st(8192);

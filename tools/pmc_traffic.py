@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Fold a rocpd PMC summary (tools/rocpd_pmc_summary.py) into gpurun_out/pmc_traffic.json / profiles/pmc_traffic.json:
-per kernel and raster size the HBM bytes per launch = (FETCH_SIZE * fetch_factor + WRITE_SIZE) * 1024.
+"""Fold a rocpd PMC summary (tools/rocpd_pmc_summary.py) into profiles/pmc_traffic.json: per kernel and raster size the
+HBM bytes per launch = (FETCH_SIZE * fetch_factor + WRITE_SIZE) * 1024, plus
+  "_whole_pass|SxS"   all kernels of ONE timed upstream_area step together (tile passes, exit graph, memsets),
+  "_op:<tag>|RxC"     all kernels of ONE warm call of an operation (bench.py --ops c3|c5).
 
 FETCH_SIZE / WRITE_SIZE are in KB.  gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes for wide
 streaming reads (MI355X_MICROARCH.md, HBM); the factor for THIS access pattern is calibrated in the same
@@ -8,7 +10,7 @@ run on a kernel with a known read volume: k_verify_upa streams the int32 result 
 codes (1 B/cell, neighbours from cache) — 5 bytes per cell.  WRITE_SIZE was calibrated in round 1 (x1.00
 for coalesced dword/16-byte stores, x1.25 for byte stores; profiles/README.md).
 
-    python tools/pmc_traffic.py <pmc_fetch_write.csv> <size>
+    python tools/pmc_traffic.py <pmc_fetch_write.csv> <size | c3 | c5>
 """
 import csv
 import json
@@ -16,38 +18,69 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEP_KERNELS = ("k_tile", "k_super", "k_link3", "k_link4", "k_hyper", "k_push3", "k_push4", "k_coarse_round",
+                "k_check_saturated", "fillBuffer")
+# kernels of one warm call, by a substring of their (templated) names; calls per bench.py --ops run = steps + 1
+OPS = {"accuflux_f32_up": ("AccuUp<float",), "strahler": ("Strahler",), "hand_f32": ("Hand<float",),
+       "basins_u32": ("k_path<1", "k_xround<1", "k_xinit<1", "k_labels_out", "k_seed")}
+OP_SHAPE = {"c3": (30000, 30000), "c5": (36000, 72000)}
 
 
-def main(path, size):
-    rows = {}
+def main(path, what):
+    rows, calls, sums = {}, {}, {}
     with open(path) as f:
         for r in csv.DictReader(f):
             rows.setdefault(r["kernel"], {})[r["counter"]] = float(r["avg_value"])
-    n = size * size
-    cal = None
-    for k, v in rows.items():
-        if "k_verify_upa" in k and "FETCH_SIZE" in v:
-            cal = dict(kernel=k, known_bytes=5 * n, fetch_kb=v["FETCH_SIZE"],
-                       fetch_factor=round(5 * n / (v["FETCH_SIZE"] * 1024), 4))
-    factor = cal["fetch_factor"] if cal else 1.0
-    # the factor is a property of the request width: 1 (narrow requests) or 2 (128-byte requests counted as 64)
-    factor_used = 2.0 if factor > 1.5 else 1.0
+            calls[r["kernel"]] = int(r["dispatches"])
+            sums.setdefault(r["kernel"], {})[r["counter"]] = float(r["sum_value"])
     out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         tab = json.load(open(out_path))
     except (OSError, ValueError):
         tab = {}
+    if what in OP_SHAPE:
+        nrow, ncol = OP_SHAPE[what]
+        factor_used, cal = 1.0, None
+    else:
+        nrow = ncol = int(what)
+        n = nrow * ncol
+        cal = None
+        for k, v in rows.items():
+            if "k_verify_upa" in k and "FETCH_SIZE" in v:
+                cal = dict(kernel=k, known_bytes=5 * n, fetch_kb=v["FETCH_SIZE"],
+                           fetch_factor=round(5 * n / (v["FETCH_SIZE"] * 1024), 4))
+        factor = cal["fetch_factor"] if cal else 1.0
+        # the factor is a property of the request width: 1 (narrow requests) or 2 (128-byte requests counted as 64)
+        factor_used = 2.0 if factor > 1.5 else 1.0
+    size = f"{nrow}x{ncol}"
+
+    def total(k):
+        v = sums[k]
+        return (v.get("FETCH_SIZE", 0.0) * factor_used + v.get("WRITE_SIZE", 0.0)) * 1024
+
     for k, v in rows.items():
         if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
             continue
-        tab[f"{k}|{size}x{size}"] = dict(fetch_kb_raw=v["FETCH_SIZE"], write_kb_raw=v["WRITE_SIZE"],
-                                         fetch_factor=factor_used,
-                                         bytes_per_launch=(v["FETCH_SIZE"] * factor_used + v["WRITE_SIZE"]) * 1024)
-    tab[f"_calibration|{size}x{size}"] = cal
+        tab[f"{k}|{size}"] = dict(fetch_kb_raw=v["FETCH_SIZE"], write_kb_raw=v["WRITE_SIZE"], fetch_factor=factor_used,
+                                  dispatches=calls[k], bytes_per_launch=(v["FETCH_SIZE"] * factor_used + v["WRITE_SIZE"]) * 1024)
+    if what in OP_SHAPE:
+        for tag, pats in OPS.items():
+            ks = [k for k in sums if any(p in k for p in pats)]
+            if not ks:
+                continue
+            ncalls = 3  # bench.py --ops ... --steps 2: the first call + 2 warm calls run the same sweep kernels
+            tab[f"_op:{tag}|{size}"] = dict(bytes_per_launch=sum(total(k) for k in ks) / ncalls, calls=ncalls, kernels=sorted(ks))
+    else:
+        passes = max([calls[k] for k in calls if "k_tile_final_fast" in k] or [0])
+        if passes:
+            ks = [k for k in sums if any(p in k for p in STEP_KERNELS)]
+            tab[f"_whole_pass|{size}"] = dict(bytes_per_launch=sum(total(k) for k in ks) / passes, passes=passes,
+                                              kernels=sorted(ks))
+        tab[f"_calibration|{size}"] = cal
     json.dump(tab, open(out_path, "w"), indent=1, sort_keys=True)
-    print(json.dumps({k: v for k, v in tab.items() if k.endswith(f"{size}x{size}") and ("k_tile" in k or k[0] == "_")},
-                     indent=1))
+    print(json.dumps({k: (v if not isinstance(v, dict) else {a: b for a, b in v.items() if a != "kernels"})
+                      for k, v in tab.items() if k.endswith(size) and (k[0] == "_" or "k_tile" in k)}, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]))
+    main(sys.argv[1], sys.argv[2])
