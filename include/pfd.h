@@ -297,6 +297,15 @@ int pfd_floodplains(pfd_raster *h, int elev_dtype, const void *elevtn, const uin
  * dist_out = cells walked (float32 like the reference); max_hops < 0: unlimited. */
 int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k, const uint8_t *mask, int memspace,
                         int64_t max_hops, int64_t *idxs_out, float *dist_out);
+/* The general form of core.snap (reference pyflwdir/core.py:440-480, core._trace :308-366, Flwdir.snap
+ * flwdir.py:500-560): `idxs_us_main` == NULL walks downstream, else upstream along the caller's main upstream
+ * cells (HOST, n int64, negative = none); `step_lengths` == NULL counts cells, else adds metres from the HOST
+ * table [2*nrow - 1][3] float64 (row + next row; vertical, horizontal, diagonal step: gis_utils.distance
+ * evaluated by the host); `mask` (HOST, nullable) ends a walk on the first cell where it is set; with
+ * has_max_length a walk also ends before the step that would exceed max_length.  Distances accumulate in float64
+ * (the reference's Python float) and are stored as float32. */
+int pfd_snap(pfd_raster *h, const int64_t *idxs, int64_t k, const uint8_t *mask, const int64_t *idxs_us_main,
+             const double *step_lengths, int has_max_length, double max_length, int64_t *idxs_out, float *dist_out);
 
 /* ---- instrumentation ---------------------------------------------------------------------
  * HIP-event timing (events recorded on the handle's own stream) of the phases of the LAST

@@ -323,7 +323,48 @@ def gen_general_pits():
     print(f"[wide] general_pits: {len(store)} arrays")
 
 
-GENS = {"dem": gen_dem, "subgrid": gen_subgrid, "snap": gen_snap, "general": gen_general, "general_pits": gen_general_pits}
+def gen_snap2():
+    """Flwdir.snap upstream (along the main upstream cells) and in metres, with and without mask / max_length
+    (reference pyflwdir/flwdir.py:500-560, core.snap / core._trace core.py:308-366,440-480); accuflux of narrow
+    integer payloads (int8 / int16 / uint8 / uint16: the reference accumulates in the payload's own dtype,
+    streams.py:36 `data.copy()`)."""
+    from pyflwdir_amd._affine import Affine
+    import json
+
+    manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+    W = np.load(os.path.join(GOLD, "wide_snap.npz"))
+    store = {}
+    for name in ("flwdir0", "flwdir_large", "synth_rough_nodata_384x512", "rhine"):
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        ent = manifest[name]
+        flw = pyflwdir.from_array(z["d8"], ftype="d8", check_ftype=False, transform=Affine(*ent["transform"]),
+                                  latlon=ent["latlon"], cache=False)
+        idxs, streams = W[f"in_{name}_idxs"], W[f"in_{name}_streams"]
+        upa = flw.upstream_area()
+        heads = upa <= 2  # a mask for the upstream direction: stop at (near-)headwater cells
+        store[f"in_{name}_heads"] = heads
+        cases = dict(down_m=dict(mask=streams, unit="m"), down_m_max=dict(mask=streams, unit="m", max_length=2500.0),
+                     down_m_nomask=dict(unit="m"), up_cell=dict(direction="up"), up_cell_mask=dict(direction="up", mask=heads),
+                     up_cell_max=dict(direction="up", max_length=7), up_m=dict(direction="up", unit="m"),
+                     up_m_max=dict(direction="up", unit="m", mask=heads, max_length=4000.0))
+        for key, kw in cases.items():
+            i1, d1 = flw.snap(idxs=idxs, **kw)
+            store[f"out_{name}_{key}_idxs"], store[f"out_{name}_{key}_dist"] = i1, d1
+        if name in ("flwdir0", "flwdir_large"):
+            rng = np.random.default_rng(23)
+            for dt, lo, hi in ((np.int8, -3, 4), (np.int16, -20, 60), (np.uint8, 0, 3), (np.uint16, 0, 40)):
+                data = rng.integers(lo, hi, size=z["d8"].shape).astype(dt)
+                nm = np.dtype(dt).name
+                store[f"in_{name}_{nm}"] = data
+                with np.errstate(over="ignore"):
+                    store[f"out_{name}_{nm}_up"] = flw.accuflux(data, nodata=2)
+                    store[f"out_{name}_{nm}_down"] = flw.accuflux(data, nodata=-9999, direction="down")
+    np.savez_compressed(os.path.join(GOLD, "wide_snap2.npz"), **store)
+    print(f"[wide] snap2: {len(store)} arrays")
+
+
+GENS = {"dem": gen_dem, "subgrid": gen_subgrid, "snap": gen_snap, "snap2": gen_snap2, "general": gen_general,
+        "general_pits": gen_general_pits}
 
 def gen_arith():
     """Flwdir.upstream_sum (reference pyflwdir/flwdir.py:412-433, arithmetics.py:147-169) for int32 / int64 /

@@ -36,7 +36,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
 ]
 
 _lib = None
@@ -418,6 +418,17 @@ class RasterHandle:
         idxs = np.ascontiguousarray(idxs, dtype=np.int64).ravel()
         out, dist = np.empty(idxs.size, np.int64), np.empty(idxs.size, np.float32)
         check(lib().pfd_snap_downstream(self._h, ptr(idxs), idxs.size, ptr(mask), PFD_HOST, int(max_hops), ptr(out), ptr(dist)))
+        return out, dist
+
+    def snap(self, idxs, mask=None, idxs_us_main=None, step_lengths=None, max_length=None):
+        """core.snap: downstream, or upstream along ``idxs_us_main`` (int64, negative = none); cells, or metres from
+        the float64 ``step_lengths`` table; returns (idxs int64, dists float32)."""
+        idxs = np.ascontiguousarray(idxs, dtype=np.int64).ravel()
+        out, dist = np.empty(idxs.size, np.int64), np.empty(idxs.size, np.float32)
+        up = None if idxs_us_main is None else np.ascontiguousarray(idxs_us_main, dtype=np.int64).ravel()
+        tab = None if step_lengths is None else np.ascontiguousarray(step_lengths, dtype=np.float64)
+        check(lib().pfd_snap(self._h, ptr(idxs), idxs.size, ptr(mask), ptr(up), ptr(tab), 0 if max_length is None else 1,
+                             C.c_double(0.0 if max_length is None else float(max_length)), ptr(out), ptr(dist)))
         return out, dist
 
     def main_upstream(self, uparea, dtype_code, idx_dtype, upa_min=0.0, out=None, memspace=PFD_HOST):

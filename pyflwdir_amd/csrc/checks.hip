@@ -297,6 +297,82 @@ __global__ void __launch_bounds__(64) k_snap_down(const u8 *__restrict__ ncode, 
   out[t] = (i64)x;
   dist[t] = (float)d;
 }
+// The general form: downstream (decoded from the codes) or upstream along the MAIN upstream cells (`nxt_up`, the
+// caller's idxs_us_main: int64, -1 = none), in cells or in metres.  The reference's loop (core.py:348-366):
+//     while mask is None or not mask[idx0]:  idx1 = nxt[idx0];  if idx1 == idx0 or idx1 == mv: break
+//         d = real_length ? distance(idx0, idx1) : 1.0;  if max_length is not None and dist + d > max_length: break
+//         dist += d;  idx0 = idx1
+// with `dist` a Python float: float64 here, rounded to float32 when stored (core.snap: dists float32).  A step's
+// length depends on (row + row of the next cell, kind of step) only: `steps` = [2*nrow - 1][3] float64, evaluated
+// by the host in the reference's expression order (gis_utils.distance, gis_utils.py:452-486).
+__global__ void __launch_bounds__(64) k_snap(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ mask,
+                                             const i64 *__restrict__ nxt_up, const double *__restrict__ steps,
+                                             const i64 *__restrict__ idx0, u32 k, double max_length, int has_max,
+                                             i64 *__restrict__ out, float *__restrict__ dist) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k) return;
+  u32 x = (u32)idx0[t];
+  double d = 0.0;
+  for (u32 guard = 0; guard <= g.n; ++guard) {  // (a cycle in a caller's idxs_us_main must not hang the GPU)
+    if (mask && mask[x]) break;
+    u32 y;
+    if (nxt_up) {
+      const i64 v = nxt_up[x];
+      if (v < 0 || v == (i64)x || v >= (i64)g.n) break;
+      y = (u32)v;
+    } else {
+      const u32 c = ncode[x];
+      if (!d8_is_dir(c)) break;  // pit (or nodata: `idx1 == mv`)
+      y = d8_down(g, x, c);
+    }
+    double step = 1.0;
+    if (steps) {
+      const u32 r0 = geo_row(g, x), r1 = geo_row(g, y);
+      const u32 c0 = x - r0 * g.ncol, c1 = y - r1 * g.ncol;
+      const int kind = r0 == r1 ? 1 : (c0 == c1 ? 0 : 2);  // vertical, horizontal, diagonal
+      step = steps[(size_t)(r0 + r1) * 3 + kind];
+    }
+    if (has_max && d + step > max_length) break;
+    d += step;
+    x = y;
+  }
+  out[t] = (i64)x;
+  dist[t] = (float)d;
+}
+extern "C" int pfd_snap(pfd_raster *h, const int64_t *idxs, int64_t k, const uint8_t *mask, const int64_t *idxs_us_main,
+                        const double *step_lengths, int has_max_length, double max_length, int64_t *idxs_out,
+                        float *dist_out) {
+  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, "snap"));
+  PFDCHK(pfd_require_whole(h, "snap"));
+  if (k < 0 || (k > 0 && (!idxs || !idxs_out || !dist_out))) {
+    pfd_set_error("pfd_snap: bad arguments");
+    return PFD_EINVAL;
+  }
+  if (k == 0) return PFD_OK;
+  for (i64 i = 0; i < k; ++i)
+    if (idxs[i] < 0 || idxs[i] >= h->n) {
+      pfd_set_error("pfd_snap: index %lld outside the raster", (long long)idxs[i]);
+      return PFD_EINVAL;
+    }
+  InArg di, dm, du, ds;
+  PFDCHK(di.bind(idxs, (size_t)k * sizeof(i64), PFD_HOST, h->stream));
+  PFDCHK(dm.bind(mask, (size_t)h->n, PFD_HOST, h->stream));
+  PFDCHK(du.bind(idxs_us_main, (size_t)h->n * sizeof(i64), PFD_HOST, h->stream));
+  PFDCHK(ds.bind(step_lengths, (size_t)(2 * h->nrow - 1) * 3 * sizeof(double), PFD_HOST, h->stream));
+  DevBuf o, d;
+  PFDCHK(o.alloc((size_t)k * sizeof(i64)));
+  PFDCHK(d.alloc((size_t)k * sizeof(float)));
+  k_snap<<<cdiv_u32((u64)k, 64), 64, 0, h->stream>>>(h->ncode, h->geo, (const u8 *)dm.dev, (const i64 *)du.dev,
+                                                    (const double *)ds.dev, (const i64 *)di.dev, (u32)k, max_length,
+                                                    has_max_length, o.as<i64>(), d.as<float>());
+  KCHK();
+  HIPCHK(hipMemcpyAsync(idxs_out, o.p, (size_t)k * sizeof(i64), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(dist_out, d.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}
+
 extern "C" int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k, const uint8_t *mask, int memspace,
                                    int64_t max_hops, int64_t *idxs_out, float *dist_out) {
   PFDCHK(pfd_check_handle(h));

@@ -95,8 +95,8 @@ def degree_metres_x(lat):
     return (111412.84 * np.cos(radlat)) + (-93.5 * np.cos(3.0 * radlat)) + (0.118 * np.cos(5.0 * radlat))
 
 
-def step_length_table(nrow, latlon=False, transform=IDENTITY):
-    """float32 length of one D8 step as ``[2*nrow-1, 3]``: (row of the cell + row of its downstream
+def step_length_table(nrow, latlon=False, transform=IDENTITY, dtype=np.float32):
+    """Length of one D8 step (float32; float64 for core.snap, which adds Python floats) as ``[2*nrow-1, 3]``: (row of the cell + row of its downstream
     cell) x {vertical, horizontal, diagonal}.  ``gis_utils.distance(idx0, idx1, ncol, latlon,
     transform)`` (reference gis_utils.py:452-486) depends on nothing else, so the host evaluates it
     once per row pair — scalar by scalar, in the reference's own expression order (including its
@@ -105,7 +105,7 @@ def step_length_table(nrow, latlon=False, transform=IDENTITY):
     import math
 
     xres, yres, north = transform[0], transform[4], transform[5]
-    tab = np.zeros((max(1, 2 * nrow - 1), 3), np.float32)
+    tab = np.zeros((max(1, 2 * nrow - 1), 3), dtype)
     for s in range(2 * nrow - 1):
         for kind, (dr, dc) in enumerate(((1, 0), (0, 1), (1, 1))):
             if latlon:
@@ -114,7 +114,7 @@ def step_length_table(nrow, latlon=False, transform=IDENTITY):
                 dx = 0.0 if dc == 0 else degree_metres_x(lat) * xres
             else:
                 dy, dx = xres, yres
-            tab[s, kind] = np.float32(math.hypot(dy * dr, dx * dc))
+            tab[s, kind] = dtype(math.hypot(dy * dr, dx * dc))
     return tab
 
 

@@ -518,10 +518,39 @@ class FlwdirRaster(object):
             raise ValueError(f'Unknown flow direction: {direction}, select from ["up", "down"].')
         data = np.asarray(data)
         flat = self._check_data(data, "data")
+        dirc = _hip.PFD_UP if direction == "up" else _hip.PFD_DOWN
+        if flat.dtype in _NARROW_INT:
+            return self._accuflux_narrow(flat, nodata, dirc).reshape(data.shape)
         view, code, nd_i, nd_f, has_nd = _payload_args(flat, nodata)
-        out = self._h.accuflux(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd,
-                               direction=_hip.PFD_UP if direction == "up" else _hip.PFD_DOWN)
+        out = self._h.accuflux(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd, direction=dirc)
         return out.view(flat.dtype).reshape(data.shape)
+
+    def _accuflux_narrow(self, flat, nodata, dirc):
+        """int8 / int16 / uint8 / uint16 payloads.  The reference accumulates in the payload's own dtype
+        (streams.py:36 ``data.copy()``), wrap-around included; the device kernels exist for 32- and 64-bit integers.
+        Accumulating in int32 gives the same values — and the same answers to the running nodata tests — as long
+        as no partial sum leaves the narrow range, which is checked: non-negative data accumulate monotonically, so
+        the final values bound the partial sums; otherwise the accumulated magnitudes do.  A payload that WOULD wrap
+        (the reference then returns wrapped sums) is refused instead of being answered differently."""
+        dt = flat.dtype
+        info = np.iinfo(dt)
+        wide = flat.astype(np.int32)
+        try:
+            integral = float(nodata) == int(nodata)
+        except (OverflowError, ValueError):
+            integral = False
+        has_nd = 1 if integral and info.min <= int(nodata) <= info.max else 0
+        nd = int(nodata) if has_nd else 0
+        out = self._h.accuflux(wide, _hip.PFD_I32, nodata_i=nd, nodata_f=0.0, has_nodata=has_nd, direction=dirc)
+        if flat.size and int(wide.min()) >= 0:
+            ok = int(out.max()) <= info.max
+        else:
+            bound = self._h.accuflux(np.abs(wide), _hip.PFD_I32, nodata_i=0, nodata_f=0.0, has_nodata=0, direction=dirc)
+            ok = int(bound.max()) <= min(info.max, -int(info.min))
+        if not ok:
+            raise NotImplementedError(f"accuflux: the sums leave the range of the payload dtype {dt} (the reference "
+                                      "wraps around there); pass the data as int32 / int64")
+        return out.astype(dt)
 
     def upstream_sum(self, data, mv=-9999):
         """Sum of the values of the cells directly upstream; reference pyflwdir/flwdir.py:412-433,
@@ -706,23 +735,36 @@ class FlwdirRaster(object):
     def snap(self, idxs=None, xy=None, mask=None, max_length=None, unit="cell", direction="down"):
         """Snap points to the first downstream cell where ``mask`` is True (or the pit of their path);
         reference pyflwdir/pyflwdir.py:500-562, pyflwdir/flwdir.py:404-463, core.snap core.py:440-480.
-        The device path serves direction="down" with unit="cell" (what ``basins(streams=...)`` and
-        ``add_pits(streams=...)`` use); returns (idxs, dists)."""
+        One bounded walk per point on the device: downstream over the D8 codes or upstream along the main upstream
+        cells, in cells or in metres; returns (idxs, dists)."""
         if self._d8 is None:
             raise NotImplementedError("snap is not available on a general idxs_ds graph on the HIP path")
-        if direction != "down" or str(unit).lower() != "cell":
-            raise NotImplementedError("snap: the HIP path implements direction='down', unit='cell'")
+        unit = str(unit).lower()
+        if unit not in ["m", "cell"]:
+            raise ValueError(f'Unknown unit: {unit}, select from ["m", "cell"].')
+        direction = str(direction).lower()
+        if direction not in ["up", "down"]:
+            raise ValueError('Unknown flow direction: {direction}, select from ["up", "down"].')
         if (xy is not None and idxs is not None) or (xy is None and idxs is None):
             raise ValueError("Either idxs or xy should be provided.")
         if xy is not None:
             idxs = self.index(*xy)
         idxs = np.atleast_1d(idxs).ravel()
         mask = self._check_data(mask, "mask", optional=True)
-        m = np.zeros(self.size, np.uint8) if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
+        m = None if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
         if np.any(idxs < 0) or np.any(idxs >= self.size):
             raise IndexError("idxs outside domain")
-        out, dist = self._h.snap_downstream(idxs, m, -1 if max_length is None else int(max_length))
+        up = None
+        if direction == "up":  # along the main upstream cells (reference flwdir.py:551), the missing value = "none"
+            us = self.idxs_us_main
+            up = us.astype(np.int64)
+            up[us == self._mv] = -1
+        tab = gis.step_length_table(self.shape[0], self.latlon, self.transform, dtype=np.float64) if unit == "m" else None
+        out, dist = self._h.snap(idxs, mask=m, idxs_us_main=up, step_lengths=tab, max_length=max_length)
         return out.astype(idxs.dtype if idxs.dtype.kind in "iu" else np.int64), dist  # (core.snap: dtype of idxs0)
+
+
+_NARROW_INT = (np.dtype(np.int8), np.dtype(np.int16), np.dtype(np.uint8), np.dtype(np.uint16))
 
 
 def _payload_args(flat, nodata):
@@ -738,7 +780,7 @@ def _payload_args(flat, nodata):
         view, info = flat, (np.iinfo(dt) if dt.kind == "i" else None)
     else:
         raise NotImplementedError(f"payload dtype {dt} is not supported on the HIP path "
-                                  "(supported: int32, int64, uint32, uint64, float32, float64)")
+                                  "(supported: int8 ... int64, uint8 ... uint64, float32, float64)")
     view = np.ascontiguousarray(view)
     code = _PAYLOAD[view.dtype]
     if dt.kind == "f":
