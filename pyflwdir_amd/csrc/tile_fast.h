@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
     }                                                                                                             \
   }
   int round = 0;
+#ifndef FY_COPY
 #pragma nounroll
   for (; round < MAXROUNDS_TILE; round += 2) {
     FY_ROUND(pc, qn)
@@ -347,6 +348,14 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
       break;
     }
   }
+#else
+#pragma nounroll
+  for (; round < MAXROUNDS_TILE; ++round) {
+    FY_ROUND(pc, qn)
+    _Pragma("unroll") for (int i = 0; i < QPT * 4; ++i) pc[i] = qn[i];
+    if (!fx_vote(s_flag, round, tid, lv[0] | lv[1] | lv[2] | lv[3])) break;
+  }
+#endif
 #undef FY_ROUND
   const u32 live = (lv[0] ? 1u : 0u) + (lv[1] ? 1u : 0u) + (lv[2] ? 1u : 0u) + (lv[3] ? 1u : 0u);
   if ((a.ablate & 32) && tid == 0) {

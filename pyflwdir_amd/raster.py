@@ -641,7 +641,29 @@ class FlwdirRaster(object):
         idxs64 = idxs.astype(np.int64)
         if np.any(idxs64 < 0) or np.any(idxs64 >= self.size):
             raise IndexError("idxs outside domain")
+        nb = self._row_blocks_needed()
+        if nb > 1:  # beyond 32-bit cell indices: the row-block protocol of the multi-GPU path, blocks held by this process
+            from . import dist
+
+            return dist.basins_blocks(self._d8, nb, idxs64, ids).reshape(self.shape)
         return self._h.basins(idxs64, ids).reshape(self.shape)
+
+    def _row_blocks_needed(self):
+        """1, or the number of row blocks a raster beyond 2**32 - 2 cells is cut into for the operations whose engines
+        address cells with 32 bits (the reference's index ladder reaches int64, pyflwdir.py:105-127): basins and
+        hand then run the row-block protocols of pyflwdir_amd/dist.py inside this one process — same kernels,
+        bit-identical results.  (PFD_TEST_BIG_CELLS with PFD_ENABLE_KNOBS=1 lowers the threshold for tests.)"""
+        import os
+
+        limit = 4294967294
+        if self._d8 is None:
+            return 1
+        if os.environ.get("PFD_ENABLE_KNOBS") == "1" and os.environ.get("PFD_TEST_BIG_CELLS"):
+            limit = int(os.environ["PFD_TEST_BIG_CELLS"])
+        if self.size <= limit:
+            return 1
+        per_block = min(limit, 1 << 31)
+        return min(self.shape[0], -(-self.size // per_block))
 
     def hand(self, drain, elevtn):
         """Height above the nearest drain (float64); reference pyflwdir/pyflwdir.py:1485-1511."""
@@ -654,6 +676,11 @@ class FlwdirRaster(object):
             code, elevtn = _hip.PFD_F64, elevtn.astype(np.float64, copy=False)
         else:
             raise NotImplementedError(f"elevation dtype {elevtn.dtype} is not supported on the HIP path")
+        nb = self._row_blocks_needed()
+        if nb > 1:
+            from . import dist
+
+            return dist.hand_blocks(self._d8, nb, drain_u8, np.ascontiguousarray(elevtn))[0].reshape(self.shape)
         return self._h.hand(drain_u8, np.ascontiguousarray(elevtn), code).reshape(self.shape)
 
     def ucat_area(self, idxs_out, unit="cell"):

@@ -155,3 +155,28 @@ def test_hand_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblocks, edtype
 
     flw = pyflwdir.from_array(d8, ftype="d8")
     assert np.array_equal(flw.hand(drain.reshape(shape), elev.reshape(shape)).ravel().view(np.uint64), got.ravel().view(np.uint64))
+
+
+def test_front_end_cuts_huge_rasters_into_row_blocks(gpu_lib, oracle, monkeypatch):
+    """FlwdirRaster.basins / .hand on a raster beyond 32-bit cell indices run the row-block protocols inside the one
+    process (the threshold is lowered here): same results as the oracle on the whole raster, bit for bit."""
+    import pyflwdir_amd as pyflwdir
+
+    O = oracle
+    shape = (1500, 1100)
+    d8 = O.synth_d8(shape[0], shape[1], seed=61, tilt=100000, white=2, nodata_pct=15)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    upa = O.upstream_area_cell(d8)[0]
+    elev = O.synth_elev_f32(shape[0], shape[1], seed=61, tilt=100000, white=2, nodata_pct=15)
+    drain = upa > np.percentile(upa[upa > 0], 95)
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    monkeypatch.setenv("PFD_TEST_BIG_CELLS", "400000")  # 1.65 Mcells -> 5 row blocks
+    assert flw._row_blocks_needed() == 5
+    got = flw.hand(drain, elev)
+    exp = O.height_above_nearest_drain(idxs_ds, seq, drain.ravel(), elev.ravel())
+    assert np.array_equal(got.ravel().view(np.uint64), exp.view(np.uint64))
+    outl = np.argsort(upa.ravel())[-300:]
+    ids = (np.arange(outl.size) + 11).astype(np.uint32)
+    assert np.array_equal(flw.basins(idxs=outl, ids=ids).ravel(), O.basins(idxs_ds, outl.astype(idxs_ds.dtype), seq, ids))
+    assert np.array_equal(flw.basins().ravel(), O.basins(idxs_ds, idxs_pit, seq))
