@@ -184,9 +184,13 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
       if (lv[j]) {
+        // two jumps per round (a root word points at itself, so jumping from a root stays there): half the barriers
+        // and pointer write-backs per hop
         u32 q[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) q[b] = *(const uint16_t *)((const u8 *)P + pc[4 * j + b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[b] = *(const uint16_t *)((const u8 *)P + q[b]);
 #pragma unroll
         for (int b = 0; b < 4; ++b) pc[4 * j + b] = q[b];
         lv[j] = !(q[0] & q[1] & q[2] & q[3] & FX_SLOT0);
