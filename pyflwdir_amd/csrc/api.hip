@@ -294,6 +294,7 @@ static void free_handle(pfd_raster *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   pfd_free_pending(h);
   pfd_free_pending_basins(h);
+  pfd_free_hand_block(h);
   pfd_dfree(h->ncode);
   pfd_dfree(h->raw_owned);
   pfd_dfree(h->seq);

@@ -151,6 +151,7 @@ struct pfd_raster {
   size_t bytes_held = 0;
   void *pending = nullptr;  // split-phase multi-block pass in flight (dist.hip)
   void *pending_basins = nullptr;  // split-phase multi-block basins query in flight (paths.hip)
+  void *hand_block_state = nullptr;  // cells of a row block whose HAND is still unknown, between pfd_hand_block calls (sweeps.hip)
   // profiling
   bool profiling = false;
   bool count_rounds = false;  // pfd_set_profiling(h, 2): the tile passes also count their doubling rounds (two atomics per tile)
@@ -246,6 +247,7 @@ int pfd_basins_dev(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k
 int pfd_require_whole(pfd_raster *h, const char *what);          // order.hip
 void pfd_free_pending(pfd_raster *h);                            // dist.hip
 void pfd_free_pending_basins(pfd_raster *h);                     // paths.hip
+void pfd_free_hand_block(pfd_raster *h);                         // sweeps.hip
 int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
 void pfd_free_xplan(pfd_raster *h);                             // exact.hip
 void pfd_free_general(pfd_raster *h);                           // general.hip

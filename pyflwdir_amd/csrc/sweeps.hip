@@ -1163,9 +1163,22 @@ struct HandSeeded : Hand<E> {
 };
 
 // incremental form (update != 0): `out` holds the result of an earlier call for other seeds.  Only the cells that
-// are still unknown (-inf) can change — typically a few cells whose path weaves along the block edge — so instead
-// of sweeping the block again they are collected and relaxed (x <- hand[ds] + dz once hand[ds] is known: the very
-// addition the sweep would do) until nothing moves.  More than n / 16 unknown cells: a full sweep is cheaper.
+// are still unknown (-inf) can change — typically a few cells whose path weaves along the block edge.  The first call
+// collects them once (one scan of the block); every later call seeds the halo cells, relaxes the listed cells
+// (x <- hand[ds] + dz once hand[ds] is known: the very addition the sweep would do) until nothing moves, and drops the
+// resolved ones from the list: O(unknown cells), not O(block).  More than n / 16 unknown cells: no list, the next
+// call sweeps the block again.
+struct HandBlockState {
+  DevBuf list[2];
+  u32 m = 0, cap = 0;
+  unsigned long long unknown = 0;  // exact, also when the cells do not fit the list
+  int cur = 0;
+  bool valid = false;
+};
+void pfd_free_hand_block(pfd_raster *h) {
+  delete (HandBlockState *)h->hand_block_state;
+  h->hand_block_state = nullptr;
+}
 __global__ void __launch_bounds__(256) k_hb_seed(const u8 *__restrict__ ncode, u32 ncol, u32 nrow, u32 row_first,
                                                  u32 row_last, const double *__restrict__ seed, double *__restrict__ out) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1175,16 +1188,20 @@ __global__ void __launch_bounds__(256) k_hb_seed(const u8 *__restrict__ ncode, u
   const size_t x = (size_t)(side ? row_last + 1 : row_first - 1) * ncol + col;
   if (ncode[x] == D8_HALO) out[x] = seed[t];
 }
-__global__ void __launch_bounds__(256) k_hb_collect(const u8 *__restrict__ ncode, const double *__restrict__ out, u32 n,
-                                                    u32 cap, u32 *__restrict__ list, unsigned long long *__restrict__ cnt) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool u = x < n && ncode[x] != D8_HALO && out[x] == -HUGE_VAL;
+// append the cells of src (or, src == nullptr, of the whole block) that are still unknown; halo cells are never listed
+__global__ void __launch_bounds__(256) k_hb_collect(const u8 *__restrict__ ncode, const double *__restrict__ out,
+                                                    const u32 *__restrict__ src, u32 n, u32 cap, u32 *__restrict__ list,
+                                                    unsigned long long *__restrict__ cnt) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 x = i < n ? (src ? src[i] : i) : 0u;
+  const bool u = i < n && ncode[x] != D8_HALO && out[x] == -HUGE_VAL;
   const u64 m = __ballot(u);
   if (!m) return;
   const u32 lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
   u32 base = 0;
-  if (lane == (u32)(__ffsll((long long)m) - 1)) base = (u32)atomicAdd(cnt, (unsigned long long)__popcll(m));
-  base = __shfl(base, __ffsll((long long)m) - 1);
+  if ((int)lane == leader) base = (u32)atomicAdd(cnt, (unsigned long long)__popcll(m));
+  base = __shfl(base, leader);
   if (u) {
     const u32 pos = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
     if (pos < cap) list[pos] = x;
@@ -1206,44 +1223,76 @@ __global__ void __launch_bounds__(256) k_hb_relax(const u8 *__restrict__ ncode, 
   __hip_atomic_store(&out[x], drain[x] == 1 ? 0.0 : pv + (double)dz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (*changed == 0u) *changed = 1u;
 }
-__global__ void __launch_bounds__(256) k_hb_count(const double *__restrict__ out, size_t begin, size_t end,
+
+__global__ void __launch_bounds__(256) k_hb_count(const u8 *__restrict__ ncode, const double *__restrict__ out, u32 n,
                                                   unsigned long long *__restrict__ cnt) {
   unsigned long long c = 0;
-  for (size_t i = begin + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256) c += out[i] == -HUGE_VAL;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    c += ncode[i] != D8_HALO && out[i] == -HUGE_VAL;
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(cnt, c);
 }
-
-template <class E>
-static int hand_block_update(pfd_raster *h, const u8 *drain, const E *elev, const double *seed_dev, double *out, bool *did) {
-  const u32 n = h->geo.n, ncol = (u32)h->ncol;
-  const u32 rf = (u32)h->halo_top, rl = (u32)(h->halo_top + h->own_rows - 1);
-  const u32 cap = std::max<u32>(n / 16u, 1024u);
-  DevBuf list, ctr;
-  PFDCHK(list.alloc((size_t)cap * sizeof(u32)));
-  PFDCHK(ctr.alloc(80 * sizeof(unsigned long long)));
-  HIPCHK(hipMemsetAsync(ctr.p, 0, 80 * sizeof(unsigned long long), h->stream));
-  k_hb_seed<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(h->ncode, ncol, (u32)h->nrow, rf, rl, seed_dev, out);
-  k_hb_collect<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(h->ncode, out, n, cap, list.as<u32>(), ctr.as<unsigned long long>());
-  KCHK();
+// (re)build the list of unknown cells: from the whole block after a sweep (count first, so that the list is sized by
+// the unknown cells — a few thousand — and not by the block), from the previous list after an update
+static int hand_block_collect(pfd_raster *h, HandBlockState *st, const double *out, bool from_list) {
+  const u32 n = h->geo.n;
+  DevBuf ctr;
+  PFDCHK(ctr.alloc(sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(unsigned long long), h->stream));
   unsigned long long m = 0;
+  if (!from_list) {
+    k_hb_count<<<4096, 256, 0, h->stream>>>(h->ncode, out, n, ctr.as<unsigned long long>());
+    KCHK();
+    HIPCHK(hipMemcpyAsync(&m, ctr.p, sizeof(m), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    st->unknown = m;
+    st->valid = m <= (unsigned long long)std::max<u32>(n / 16u, 1024u);
+    st->m = 0;
+    if (!st->valid || m == 0) return PFD_OK;
+    if (m > st->cap) {
+      st->cap = (u32)m;
+      PFDCHK(st->list[0].alloc((size_t)st->cap * sizeof(u32)));
+      PFDCHK(st->list[1].alloc((size_t)st->cap * sizeof(u32)));
+    }
+    HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(unsigned long long), h->stream));
+  }
+  const int dst = from_list ? 1 - st->cur : st->cur;
+  const u32 cnt = from_list ? st->m : n;
+  if (cnt)
+    k_hb_collect<<<cdiv_u32(cnt, 256), 256, 0, h->stream>>>(h->ncode, out, from_list ? st->list[st->cur].as<u32>() : nullptr, cnt,
+                                                           st->cap, st->list[dst].as<u32>(), ctr.as<unsigned long long>());
+  KCHK();
   HIPCHK(hipMemcpyAsync(&m, ctr.p, sizeof(m), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  *did = m <= cap;
-  if (!*did || m == 0) return PFD_OK;
-  u32 *flags = (u32 *)(ctr.as<unsigned long long>() + 8);  // 64 round flags
+  st->cur = dst;
+  st->unknown = m;
+  st->m = (u32)std::min<unsigned long long>(m, st->cap);
+  return PFD_OK;
+}
+
+template <class E>
+static int hand_block_update(pfd_raster *h, HandBlockState *st, const u8 *drain, const E *elev, const double *seed_dev,
+                             double *out) {
+  const u32 ncol = (u32)h->ncol;
+  const u32 rf = (u32)h->halo_top, rl = (u32)(h->halo_top + h->own_rows - 1);
+  k_hb_seed<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(h->ncode, ncol, (u32)h->nrow, rf, rl, seed_dev, out);
+  KCHK();
+  if (st->m == 0) return PFD_OK;
+  DevBuf fl;
   const int BATCH = 64;
-  for (int guard = 0; guard < (1 << 20); guard += BATCH) {
-    HIPCHK(hipMemsetAsync(flags, 0, BATCH * sizeof(u32), h->stream));
+  PFDCHK(fl.alloc(BATCH * sizeof(u32)));
+  for (int guard = 0; guard < (1 << 22); guard += BATCH) {
+    HIPCHK(hipMemsetAsync(fl.p, 0, BATCH * sizeof(u32), h->stream));
     for (int r = 0; r < BATCH; ++r)
-      k_hb_relax<E><<<cdiv_u32((u32)m, 256), 256, 0, h->stream>>>(h->ncode, h->geo, drain, elev, list.as<u32>(), (u32)m, out, flags + r);
+      k_hb_relax<E><<<cdiv_u32(st->m, 256), 256, 0, h->stream>>>(h->ncode, h->geo, drain, elev, st->list[st->cur].as<u32>(), st->m, out,
+                                                                fl.as<u32>() + r);
     KCHK();
     u32 last = 0;
-    HIPCHK(hipMemcpyAsync(&last, flags + BATCH - 1, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&last, fl.as<u32>() + BATCH - 1, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (!last) break;  // the last round of the batch moved nothing: fixpoint
   }
-  return PFD_OK;
+  return hand_block_collect(h, st, out, true);  // drop what is known now
 }
 
 extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn,
@@ -1257,23 +1306,30 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
   PFDCHK(pfd_reject_general(h, "hand_block"));
   pfd_seg_clear(h);
   PFDCHK(pfd_order_cells_impl(h));  // (the level structure of the block: its halo cells are roots like its pits)
-  InArg dr, el, sd, prev;
+  InArg dr, el, sd;
   PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
   PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
   PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol * sizeof(double), PFD_HOST, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(double), memspace));
-  bool done = false;
-  if (update) {  // (host callers: the earlier result travels to the device first)
-    if (memspace == PFD_HOST) HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HandBlockState *st = (HandBlockState *)h->hand_block_state;
+  if (!st) h->hand_block_state = st = new HandBlockState();
+  // (the list describes the device copy of `out`: a host caller's earlier result travels to the device, its list is
+  //  rebuilt by a scan — host callers pay O(block) per call anyway)
+  const bool incremental = update && st->valid && memspace == PFD_DEVICE;
+  if (update && memspace == PFD_HOST) {
+    HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    PFDCHK(hand_block_collect(h, st, (const double *)o.dev, false));
+  }
+  if (update && st->valid) {
     pfd_seg_begin(h, "hand_block_update");
     if (elev_dtype == PFD_F32)
-      PFDCHK(hand_block_update<float>(h, (const u8 *)dr.dev, (const float *)el.dev, (const double *)sd.dev, (double *)o.dev, &done));
+      PFDCHK(hand_block_update<float>(h, st, (const u8 *)dr.dev, (const float *)el.dev, (const double *)sd.dev, (double *)o.dev));
     else
-      PFDCHK(hand_block_update<double>(h, (const u8 *)dr.dev, (const double *)el.dev, (const double *)sd.dev, (double *)o.dev, &done));
+      PFDCHK(hand_block_update<double>(h, st, (const u8 *)dr.dev, (const double *)el.dev, (const double *)sd.dev, (double *)o.dev));
     pfd_seg_end(h, 3);
-  }
-  if (!done) {
+  } else {
+    (void)incremental;
     pfd_seg_begin(h, "init");
     k_fill<double><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((double *)o.dev, h->geo.n, -9999.0);
     KCHK();
@@ -1286,19 +1342,10 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
       HandSeeded<double> op{{h->ncode, h->geo, (const u8 *)dr.dev, (const double *)el.dev, (double *)o.dev}, (const double *)sd.dev, rf, rl};
       PFDCHK(run_down(h, op, "sweep_hand_block"));
     }
+    PFDCHK(hand_block_collect(h, st, (const double *)o.dev, false));  // one scan: the unknown cells (own rows: never halo cells)
   }
   const size_t ncol = (size_t)h->ncol, own0 = (size_t)h->halo_top * ncol, own1 = own0 + (size_t)h->own_rows * ncol;
-  if (n_unknown) {
-    DevBuf c;
-    PFDCHK(c.alloc(sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(c.p, 0, sizeof(unsigned long long), h->stream));
-    k_hb_count<<<2048, 256, 0, h->stream>>>((const double *)o.dev, own0, own1, c.as<unsigned long long>());
-    KCHK();
-    unsigned long long v = 0;
-    HIPCHK(hipMemcpyAsync(&v, c.p, sizeof(v), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    *n_unknown = (int64_t)v;
-  }
+  if (n_unknown) *n_unknown = (int64_t)st->unknown;  // (the listed cells are own cells: halo cells are never listed)
   if (boundary_rows_host) {  // first and last OWN row: what the neighbouring blocks need as their halo heights
     HIPCHK(hipMemcpyAsync(boundary_rows_host, (const double *)o.dev + own0, ncol * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(boundary_rows_host + ncol, (const double *)o.dev + own1 - ncol, ncol * sizeof(double), hipMemcpyDeviceToHost,

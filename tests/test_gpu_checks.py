@@ -44,8 +44,10 @@ def test_stats_and_verifier(gpu_lib, oracle, shape, kw):
 
 def test_tile_round_statistics(gpu_lib):
     """pfd_set_profiling(h, 2) counts the pointer-doubling rounds of the tile passes (pfd_graph_stats[12..15]): a
-    raster whose every 64 x 64 tile is one 4096-cell path needs log2(4096) = 12 rounds in every tile, a raster of
-    isolated pits none beyond the first."""
+    raster whose every 64 x 64 tile is one 4096-cell path needs log2(4096) = 12 rounds of the value-carrying final pass
+    in every tile — and of the local pass in the frame tiles (general kernel: one pointer jump per round), fewer in the
+    interior tiles (two jumps per round, and a jump may use a pointer its owner has already advanced); a raster of
+    isolated pits needs none beyond the first."""
     from pyflwdir_amd import _hip
 
     t = np.empty((64, 64), np.uint8)
@@ -61,7 +63,7 @@ def test_tile_round_statistics(gpu_lib):
     st = h.graph_stats()["tile_rounds"]
     h.close()
     assert upa.max() == 4096 and st["local_max"] == st["final_max"] == 12
-    assert st["local_mean"] == st["final_mean"] == 12.0 and h is not None
+    assert st["final_mean"] == 12.0 and 6.0 <= st["local_mean"] < 12.0 and h is not None
     pits = np.zeros((130, 70), np.uint8)
     h = _hip.RasterHandle(pits, 130, 70, deferred=True)
     h.set_profiling(2)
