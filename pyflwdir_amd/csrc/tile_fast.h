@@ -27,6 +27,9 @@
 #define FX_SLOT0 (2u * TCELLS)              // local pass: P byte offset of the pointer word of perimeter slot 0
 #define FX_NOBODY (FX_SLOT0 + 2u * PSL)     // ... of the root nobody asks about (pit, nodata, cell of a cycle)
 #define FX_PN (TCELLS + PSL + 8)            // P entries of the local pass
+#ifndef FY_COMBINE
+#define FY_COMBINE true
+#endif
 #define FY_SINK0 (4u * TCELLS)              // final pass: A byte offset of sink word 0 (64 of them, one per lane)
 
 // step tables (selector k = position of the code's bit): E, SE, S, SW | W, NW, N, NE
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
   // ---- doubling: A[J(z)] += A(z); J(z) <- J(J(z)).  A saturated cell adds to its lane's sink word --------------
   // One round reads (own counts, the pointers of the ancestors), waits for everybody's reads, then writes.  Two
   // rounds per trip with the pointer registers swapping roles, so that no register copies are needed.
-#define FY_ROUND(PC, QN)                                                                                          \
+#define FY_ROUND(PC, QN, COMBINE)                                                                                       \
   {                                                                                                               \
     u32 av[QPT * 4];                                                                                              \
     _Pragma("unroll") for (int j = 0; j < QPT; ++j) {                                                             \
@@ -333,7 +336,23 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
     __syncthreads(); /* every read of this round precedes every write of this round */                           \
     _Pragma("unroll") for (int j = 0; j < QPT; ++j) {                                                             \
       if (lv[j]) {                                                                                                \
-        _Pragma("unroll") for (int b = 0; b < 4; ++b) atomicAdd((u32 *)((u8 *)A + PC[4 * j + b]), av[4 * j + b]); \
+        /* the four cells of a quad are neighbours in a row and, after a few rounds, mostly share their target: */ \
+        /* combine them in registers then (same-address LDS atomics are served one lane after the other)        */ \
+        if (COMBINE) {                                                                                            \
+          const u32 t0 = PC[4 * j], t1 = PC[4 * j + 1], t2 = PC[4 * j + 2], t3 = PC[4 * j + 3];                   \
+          u32 w0 = av[4 * j], w1 = av[4 * j + 1], w2 = av[4 * j + 2], w3 = av[4 * j + 3];                         \
+          const bool e10 = t1 == t0, e20 = t2 == t0, e21 = t2 == t1, e30 = t3 == t0, e31 = t3 == t1, e32 = t3 == t2; \
+          w0 += (e10 ? w1 : 0u) + (e20 ? w2 : 0u) + (e30 ? w3 : 0u);                                              \
+          w1 = e10 ? 0u : w1 + ((!e20 && e21) ? w2 : 0u) + ((!e30 && e31) ? w3 : 0u);                             \
+          w2 = (e20 || e21) ? 0u : w2 + ((!e30 && !e31 && e32) ? w3 : 0u);                                        \
+          w3 = (e30 || e31 || e32) ? 0u : w3;                                                                     \
+          atomicAdd((u32 *)((u8 *)A + t0), w0);                                                                   \
+          if (w1) atomicAdd((u32 *)((u8 *)A + t1), w1);                                                           \
+          if (w2) atomicAdd((u32 *)((u8 *)A + t2), w2);                                                           \
+          if (w3) atomicAdd((u32 *)((u8 *)A + t3), w3);                                                           \
+        } else {                                                                                                  \
+          _Pragma("unroll") for (int b = 0; b < 4; ++b) atomicAdd((u32 *)((u8 *)A + PC[4 * j + b]), av[4 * j + b]); \
+        }                                                                                                         \
         lv[j] = !(QN[4 * j + 0] & QN[4 * j + 1] & QN[4 * j + 2] & QN[4 * j + 3] & FY_SINK0);                      \
         *(uint2 *)&P[4u * tid + 1024u * j] =                                                                      \
             make_uint2(QN[4 * j + 0] | (QN[4 * j + 1] << 16), QN[4 * j + 2] | (QN[4 * j + 3] << 16));             \
@@ -344,9 +363,9 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
 #ifndef FY_COPY
 #pragma nounroll
   for (; round < MAXROUNDS_TILE; round += 2) {
-    FY_ROUND(pc, qn)
+    FY_ROUND(pc, qn, FY_COMBINE)
     if (!fx_vote(s_flag, 0, tid, lv[0] | lv[1] | lv[2] | lv[3])) break;
-    FY_ROUND(qn, pc)
+    FY_ROUND(qn, pc, FY_COMBINE)
     if (!fx_vote(s_flag, 1, tid, lv[0] | lv[1] | lv[2] | lv[3])) {
       ++round;
       break;
@@ -355,7 +374,7 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
 #else
 #pragma nounroll
   for (; round < MAXROUNDS_TILE; ++round) {
-    FY_ROUND(pc, qn)
+    FY_ROUND(pc, qn, FY_COMBINE)
     _Pragma("unroll") for (int i = 0; i < QPT * 4; ++i) pc[i] = qn[i];
     if (!fx_vote(s_flag, round, tid, lv[0] | lv[1] | lv[2] | lv[3])) break;
   }
