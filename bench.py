@@ -356,6 +356,14 @@ def op_lines(nrow, ncol, synth, label, steps, device, ops=("accuflux", "strahler
     flwdir.py:231-250: SURVEY 8d's byte model charges that build to every call — the warm call does not pay it)."""
     n = nrow * ncol
     d8_buf = _hip.synth_d8_device(nrow, ncol, device=device, **synth)
+    # (a throw-away handle first: its plan build pays the process's cold hipMallocs of the GB-sized plan and sort
+    #  buffers — seconds at this size — which the caching allocator then keeps; `first_call_on_handle_ms` below is the
+    #  first order-sensitive call on a FRESH handle in a warm process: plan build + sweep)
+    h0 = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE)
+    tmp = _hip.DeviceBuffer(n, device)
+    h0.strahler(None, out=tmp, memspace=_hip.PFD_DEVICE)
+    h0.close()
+    tmp.free()
     h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE)
     lines, bufs = [], [d8_buf]
 

@@ -256,6 +256,8 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   a.xtgt[sbase + tid] = tgt;
   a.elink[sbase + tid] = link;
   a.inflow[sbase + tid] = 0;  // accumulated by the exit-graph solve
+  const u64 xm = __ballot(tgt != NONE32);  // (a wave = 64 consecutive slots)
+  if ((tid & 63u) == 0u) a.xmask[(sbase + tid) >> 6] = xm;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

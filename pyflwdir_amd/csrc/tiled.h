@@ -45,6 +45,11 @@ __host__ __device__ inline void sslot_inv(u32 s, u32 nstc, u32 *tr, u32 *tc, u32
 struct SuperArgs {
   u32 nst;          // number of supertiles
   const u32 *xT, *xtgt, *elink;  // xT = start values of the solve
+  // exit lists, built once per pass by k_exit_lists (one entry per exit, in slot order, at offset st << SSHIFT):
+  const u64 *xmask;           // [nslots / 64] exit bitmasks written by the local tile pass
+  uint16_t *xl_slot;          // [nslots] slot of the e-th exit of the supertile (local: 14 bits)
+  uint16_t *xl_next;          // [nslots] list index of the exit its flow reaches next inside the supertile | SDONE
+  u32 *scount;                // [nst] exits of the supertile
   u32 *xin;         // [nslots] flow entering the supertile at this exit (from other supertiles)
   u32 *R2;          // [nslots] last exit (slot) of the exit's path inside its supertile
   u32 *sxid;        // [nslots] dense id of a super-exit (drains into another supertile), else NONE32
@@ -95,6 +100,8 @@ struct TileArgs {
   u32 *xtgt;       // [nslots] slot the exit drains into, NONE32 if the slot holds no exit
   u32 *elink;      // [nslots] slot of the exit an entry's in-tile path reaches, NONE32 if none
   u32 *inflow;     // [nslots] sum of the totals of the exits draining into this slot
+  u64 *xmask;      // [nslots / 64] bit = the slot holds an exit (one wave ballot per 64 slots of a tile): what the
+                   // exit lists of the supertile solve are built from (k_exit_lists)
   u32 *esink;      // [2*ntc*PSL] first/last tile row: halo sink an entry's in-tile path ends on
   u32 *brow_first; // [2*ncol] boundary rows: where the in-tile path of the cell ends (exit id / sink)
   u32 *haloA;      // [2*ncol] flow that reached a halo sink inside its tile
@@ -233,7 +240,7 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (7 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf;
+  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf, xmaskbuf, xlbuf, scountbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;

@@ -495,6 +495,8 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
     a.xtgt[sbase + tid] = tgt;
     a.elink[sbase + tid] = link;
     a.inflow[sbase + tid] = 0;  // accumulated by the exit-graph solve
+    const u64 xm = __ballot(tgt != NONE32);  // (tid < PSL = all 256 threads: a wave = 64 consecutive slots)
+    if ((tid & 63u) == 0u) a.xmask[(sbase + tid) >> 6] = xm;
     if (tr == 0) a.esink[(size_t)tc * PSL + tid] = esink;
     if (tr == a.ntr - 1 && a.ntr > 1) a.esink[((size_t)a.ntc + tc) * PSL + tid] = esink;
   }
@@ -608,227 +610,126 @@ __device__ __forceinline__ bool wg_vote(u32 (*s_flag)[NWAVES], int round, u32 ti
   return acc != 0u;
 }
 
-// The positional form (LDS image indexed by slot: 96 KB, one workgroup per CU) only runs for the supertiles the
-// dense form below could not take (more than SCAP exits: s.sover[st] != 0) — contrived rasters only.
-template <bool FINAL>
-__global__ void __launch_bounds__(1024) k_super_pos(SuperArgs s) {
-  __shared__ u32 T[SSL];
-  __shared__ uint16_t P[SSL];
-  __shared__ u32 s_cnt, s_base;
-  const u32 tid = threadIdx.x;
-  const u32 st = blockIdx.x;
-  if (!s.sover[st]) return;
+// The exit lists.  The supertile solve wants its exits — a third of the slots on real rasters — as a dense list: only
+// exits get an LDS word (72 KB instead of 96 KB: two workgroups per CU), the rounds run without idle lanes, and the
+// solve's own memory accesses become one coalesced, unpredicated, INDEPENDENT batch (round 3 measured the
+// positional kernel: of 79 us per supertile 17 went into streaming 64 KB of xtgt to find the exits, 25 into the
+// dependent loads xtgt -> elink[xtgt] of a third of the lanes, 19 into its scattered outputs).  The lists are built
+// once per pass by one workgroup per TILE (fully parallel, high occupancy): the list index of an exit is the number
+// of exits before it in the supertile — the local tile pass left one ballot word per 64 slots (xmask), a prefix over
+// the supertile's 256 words gives the index; the exit's next hop (elink[xtgt]) is resolved here as well, as the list
+// index of that exit, so that both passes of every solve of the pass (row blocks solve twice) just read it.
+#define XL_SX 0x8000u  // xl_slot: the exit drains into another supertile (slots use 14 bits)
+__global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
+  __shared__ u64 maskw[SSL / 64];
+  __shared__ u32 cbase[SSL / 64];
+  __shared__ u32 wsum[4];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 st = blockIdx.x >> 4, part = blockIdx.x & 15u;  // 16 workgroups per supertile, 1024 slots (4 tiles) each
   const u32 base = st << SSHIFT;
-  constexpr int SPT = SSL / 1024;  // slots per thread
-  if (FINAL && s.edge_nstr) {
-    // row blocks, first solve: only the deliveries into the first and last TILE row are needed yet; they
-    // come from exits in tile rows 0..1 and ntr-2..ntr-1 -> supertile row 0 and the rows of those two
-    const u32 row = st / s.nstc;
-    if (row != 0 && row != (s.ntr - 1) / SG && row != (s.ntr >= 2 ? (s.ntr - 2) / SG : 0u)) return;
-  }
-  if (tid == 0) s_cnt = 0;
-  u32 tg[SPT];
-  u32 y[SPT];
-  u32 live = 0;
-#pragma unroll
-  for (int j = 0; j < SPT; ++j) {
-    const u32 i = tid + 1024u * j;
-    const u32 g = base + i;
-    // slots of tiles beyond the raster edge (partial supertiles) hold nothing and are never read
-    const u32 tl = i >> 8;
-    const bool exists = (st / s.nstc) * SG + (tl >> 3) < s.ntr && (st % s.nstc) * SG + (tl & 7) < s.ntc;
-    const u32 tgt = exists ? s.xtgt[g] : NONE32;
-    u32 t = (!exists || (FINAL && s.bonly)) ? 0u : s.xT[g];
-    if (FINAL) {
-      t += s.xin[g];
-    } else {
-      s.xin[g] = 0;  // accumulated by k_push3 before the final pass reads it
+  const u32 i0 = (part << 10) + 4u * tid;  // own slots i0 .. i0 + 3
+  // (unconditional: slots of tiles beyond the raster edge are allocated, never written and have no mask bit)
+  const uint4 tg = *reinterpret_cast<const uint4 *>(s.xtgt + base + i0);
+  {
+    const u64 m = s.xmask[(base >> 6) + tid];  // the 256 ballot words of the supertile
+    maskw[tid] = m;
+    const u32 c = (u32)__popcll(m);
+    u32 incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+      const u32 y = __shfl_up(incl, o);
+      if (lane >= (u32)o) incl += y;
     }
-    u32 p = i | SDONE;
-    if (tgt != NONE32 && (tgt >> SSHIFT) == st) {  // drains into a tile of this supertile
-      const u32 l = s.elink[tgt];                  // exit reached from there (same tile => same supertile)
-      if (l != NONE32) p = l & (SSL - 1);
-    }
-    tg[j] = tgt;
-    T[i] = t;
-    P[i] = (uint16_t)p;
-    y[j] = p & (SSL - 1);
-    if (!(p & SDONE)) live |= 1u << j;
+    if (lane == 63) wsum[wave] = incl;
+    cbase[tid] = incl - c;
   }
   __syncthreads();
-  for (int round = 0; round < MAXROUNDS_SUPER; ++round) {
-    u32 av[SPT], q[SPT];
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-      if (live & (1u << j)) {
-        av[j] = T[tid + 1024u * j];
-        q[j] = P[y[j]];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-      if (live & (1u << j)) {
-        atomicAdd(&T[y[j]], av[j]);
-        P[tid + 1024u * j] = (uint16_t)q[j];
-        y[j] = q[j] & (SSL - 1);
-        if (q[j] & SDONE) live &= ~(1u << j);
-      }
-    }
-    if (!__syncthreads_or((int)live)) break;
+  {
+    u32 woff = 0;
+    for (u32 w = 0; w < wave; ++w) woff += wsum[w];
+    cbase[tid] += woff;
   }
-  if (live) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the supertile
-  if (FINAL) {
-#pragma unroll
-    for (int j = 0; j < SPT; ++j)
-      if (tg[j] != NONE32) atomicAdd(&s.inflow[tg[j]], T[tid + 1024u * j]);
-    return;
-  }
-  // super-exits get dense ids (order is irrelevant)
-  u32 rank[SPT];
-#pragma unroll
-  for (int j = 0; j < SPT; ++j) {
-    rank[j] = NONE32;
-    if (tg[j] != NONE32 && (tg[j] >> SSHIFT) != st) rank[j] = atomicAdd(&s_cnt, 1u);
+  if (part == 0 && tid == 0) {
+    const u32 n = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    s.scount[st] = n;
+    s.sover[st] = n > s.scap ? 1 : 0;  // more exits than the LDS form of the solve keeps: the full-size form takes it
   }
   __syncthreads();
-  const u32 ht = ((st / s.nstc) / HG) * s.nhtc + (st % s.nstc) / HG;
-  if (tid == 0) {
-    if (!s_cnt) {
-      s_base = 0;
-    } else if (s.hmode) {  // ids of one hypertile are consecutive: its level-3 solve runs in LDS
-      const u32 b = atomicAdd(&s.hcnt[ht], s_cnt);
-      if (b + s_cnt > s.hcap) s.ctrl[T_OVERFLOW] = 1;  // host falls back to the flat id range
-      s_base = ht * HCAP + (b + s_cnt > s.hcap ? 0u : b);
-    } else {
-      s_base = (u32)atomicAdd((unsigned long long *)&s.ctrl[T_NSUPER], (unsigned long long)s_cnt);
-    }
-  }
-  __syncthreads();
+  auto dense = [&](u32 i) -> u32 { return cbase[i >> 6] + (u32)__popcll(maskw[i >> 6] & ((1ull << (i & 63u)) - 1ull)); };
+  const u32 own = (u32)(maskw[i0 >> 6] >> (i0 & 63u)) & 15u;  // (4 | i0: the four bits sit in one word)
+  if (!own) return;
+  const u32 tgt[4] = {tg.x, tg.y, tg.z, tg.w};
+  u32 l[4];
 #pragma unroll
-  for (int j = 0; j < SPT; ++j) {
-    const u32 i = tid + 1024u * j;
-    const u32 g = base + i;
-    u32 id = NONE32;
-    if (tg[j] != NONE32) {
-      s.R2[g] = base + (P[i] & (SSL - 1));
-      if (rank[j] != NONE32) {
-        id = s_base + rank[j];
-        s.sx_slot[id] = g;
-        s.T3[id] = T[i];
-      }
-    }
-    s.sxid[g] = id;
+  for (int j = 0; j < 4; ++j) {  // the exit reached from the tile entry it drains into (same tile => same supertile)
+    l[j] = NONE32;
+    if (((own >> j) & 1u) && (tgt[j] >> SSHIFT) == st) l[j] = s.elink[tgt[j]];
+  }
+  u32 d = dense(i0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!((own >> j) & 1u)) continue;
+    const u32 nx = l[j] != NONE32 ? dense(l[j] & (SSL - 1)) : (d | SDONE);
+    s.xl_slot[base + d] = (uint16_t)((i0 + j) | ((tgt[j] >> SSHIFT) != st ? XL_SX : 0u));
+    s.xl_next[base + d] = (uint16_t)nx;
+    ++d;
   }
 }
 
-
-// The dense form: only the EXITS of the supertile (a third of its slots on real rasters) get an LDS word.  A slot's
-// dense index is the number of exits before it — per 64-slot chunk an exit bitmask (one wave ballot) and a prefix
-// count, 3 KB of LDS — so T and P shrink to SCAP entries (72 KB: two workgroups per CU, which lets the loads of
-// one supertile overlap the LDS rounds of another; the positional form was alone on its CU), the rounds run over
-// the exits only (no idle lanes), and only exits touch the per-slot arrays in HBM.
+// The supertile solve over its exit list.  CAP = exits kept in LDS: SCAP (72 KB, two workgroups per CU) for the
+// supertiles k_exit_lists did not flag, SSL (every slot an exit: 96 KB, one per CU) for the others — contrived
+// rasters only; same code.
 #define SCAP 12288u
-template <bool FINAL>
-__global__ void __launch_bounds__(1024, 8) k_super(SuperArgs s) {
-  __shared__ u32 T[SCAP];
-  __shared__ uint16_t P[SCAP];
-  __shared__ u64 maskw[SSL / 64];
-  __shared__ u32 cbase[SSL / 64];
-  __shared__ u32 wsum[4], wtot[16];
+template <bool FINAL, u32 CAP>
+__global__ void __launch_bounds__(1024, CAP == SCAP ? 8 : 4) k_super(SuperArgs s) {
+  __shared__ u32 T[CAP];
+  __shared__ uint16_t P[CAP];
+  __shared__ u32 wtot[16];
   __shared__ __attribute__((aligned(16))) u32 s_flag[2][16];
   __shared__ u32 s_base;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 st = blockIdx.x;
   const u32 base = st << SSHIFT;
-  constexpr int SPT = SSL / 1024;  // slots per thread
+  constexpr int DPT = CAP / 1024;  // exits per thread
   if (FINAL && s.edge_nstr) {
     // row blocks, first solve: only the deliveries into the first and last TILE row are needed yet; they
     // come from exits in tile rows 0..1 and ntr-2..ntr-1 -> supertile row 0 and the rows of those two
     const u32 row = st / s.nstc;
     if (row != 0 && row != (s.ntr - 1) / SG && row != (s.ntr >= 2 ? (s.ntr - 2) / SG : 0u)) return;
   }
-  if (FINAL && s.sover[st]) return;  // (taken by k_super_pos; the first pass decided)
-  // slots of tiles beyond the raster edge (partial supertiles) hold nothing and are never read
-  auto slot_exists = [&](u32 i) -> bool {
-    const u32 tl = i >> 8;
-    return (st / s.nstc) * SG + (tl >> 3) < s.ntr && (st % s.nstc) * SG + (tl & 7) < s.ntc;
-  };
-  u32 exbits = 0, sxbits = 0;  // bit j: own slot j holds an exit / an exit that drains into another supertile
-  {
-#pragma unroll
-    for (int j = 0; j < SPT; ++j) {
-      const u32 i = tid + 1024u * j;
-      const u32 tgt = slot_exists(i) ? s.xtgt[base + i] : NONE32;
-      const bool ex = tgt != NONE32;
-      exbits |= ex ? 1u << j : 0u;
-      sxbits |= (ex && (tgt >> SSHIFT) != st) ? 1u << j : 0u;
-      const u64 m = __ballot(ex);
-      if (lane == 0) maskw[i >> 6] = m;
-    }
-    __syncthreads();
-    if (tid < SSL / 64) {  // exclusive prefix of the chunk counts (4 waves x 64 chunks)
-      const u32 c = (u32)__popcll(maskw[tid]);
-      u32 incl = c;
-      for (int o = 1; o < 64; o <<= 1) {
-        const u32 y = __shfl_up(incl, o);
-        if (lane >= (u32)o) incl += y;
-      }
-      if (lane == 63) wsum[wave] = incl;
-      cbase[tid] = incl - c;
-    }
-    __syncthreads();
-    if (tid < SSL / 64) {
-      u32 woff = 0;
-      for (u32 w = 0; w < wave; ++w) woff += wsum[w];
-      cbase[tid] += woff;
-    }
-    const u32 n0 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (!FINAL && tid == 0) s.sover[st] = n0 > s.scap ? 1 : 0;
-    if (n0 > s.scap) return;  // (uniform) k_super_pos takes this supertile
-    __syncthreads();
+  if ((s.sover[st] != 0) != (CAP != SCAP)) return;  // (the other form's supertile)
+  const u32 n = s.scount[st];
+  // ---- the exits: list entry -> slot, then start value and next hop; all loads of a step are independent ----
+  u32 sxbits = 0;  // bit k: own exit k (tid + 1024 k) drains into another supertile
 #pragma unroll 4
-    for (int j = 0; j < SPT; ++j) {  // (4 at a time: fully unrolled, the loads of all 16 slots in flight spill registers)
-      if (!(exbits & (1u << j))) continue;
-      const u32 i = tid + 1024u * j;
-      const u32 g = base + i;
-      const u32 tgt = s.xtgt[g];  // (again: 16 targets kept across the prefix would cost 16 registers of 64)
-      const u32 d = cbase[i >> 6] + (u32)__popcll(maskw[i >> 6] & ((1ull << (i & 63u)) - 1ull));
-      u32 t = (FINAL && s.bonly) ? 0u : s.xT[g];
-      if (FINAL) {
-        t += s.xin[g];
-      } else {
-        s.xin[g] = 0;  // accumulated by k_push3 before the final pass reads it
-      }
-      u32 p = d | SDONE;
-      if ((tgt >> SSHIFT) == st) {         // drains into a tile of this supertile
-        const u32 l = s.elink[tgt];        // exit reached from there (same tile => same supertile)
-        if (l != NONE32) {
-          const u32 li = l & (SSL - 1);
-          p = cbase[li >> 6] + (u32)__popcll(maskw[li >> 6] & ((1ull << (li & 63u)) - 1ull));
-        }
-      }
-      T[d] = t;
-      P[d] = (uint16_t)p;
+  for (int k = 0; k < DPT; ++k) {
+    const u32 e = tid + 1024u * k;
+    if (e >= n) continue;
+    const u32 w = s.xl_slot[base + e];
+    const u32 g = base + (w & (SSL - 1));
+    u32 t = (FINAL && s.bonly) ? 0u : s.xT[g];
+    if (FINAL) {
+      t += s.xin[g];
+    } else {
+      s.xin[g] = 0;  // accumulated by k_push3 before the final pass reads it
+      sxbits |= (w & XL_SX) ? 1u << k : 0u;
     }
+    T[e] = t;
+    P[e] = s.xl_next[base + e];
   }
-  const u32 n = wsum[0] + wsum[1] + wsum[2] + wsum[3];  // exits of the supertile
   __syncthreads();
-  // ---- doubling over the exits (dense: thread t owns exits t, t + 1024, ...) ----
+  // ---- doubling over the exits ----
   {
-    constexpr int DPT = SCAP / 1024;
     u32 y[DPT];
     u32 live = 0;
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
       const u32 e = tid + 1024u * k;
-      y[k] = 0;
-      if (e < n) {
-        const u32 p = P[e];
-        y[k] = p & (SDONE - 1u);
-        if (!(p & SDONE)) live |= 1u << k;
-      }
+      u32 p = P[e];  // (unconditional, then a select: the branchy form made the compiler spill whole copies of y[])
+      p = e < n ? p : SDONE;
+      y[k] = p & (SDONE - 1u);
+      live |= (p & SDONE) ? 0u : 1u << k;
     }
+#pragma nounroll
     for (int round = 0; round < MAXROUNDS_SUPER; ++round) {
       u32 av[DPT], q[DPT];
 #pragma unroll
@@ -852,35 +753,21 @@ __global__ void __launch_bounds__(1024, 8) k_super(SuperArgs s) {
     }
     if (live) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the supertile
   }
-  auto dense = [&](u32 i) -> u32 { return cbase[i >> 6] + (u32)__popcll(maskw[i >> 6] & ((1ull << (i & 63u)) - 1ull)); };
-  if (FINAL) {
+  if (FINAL) {  // every exit delivers its total to the tile entry it drains into
 #pragma unroll 4
-    for (int j = 0; j < SPT; ++j) {
-      if (!(exbits & (1u << j))) continue;
-      const u32 i = tid + 1024u * j;
-      atomicAdd(&s.inflow[s.xtgt[base + i]], T[dense(i)]);
+    for (int k = 0; k < DPT; ++k) {
+      const u32 e = tid + 1024u * k;
+      if (e < n) atomicAdd(&s.inflow[s.xtgt[base + (s.xl_slot[base + e] & (SSL - 1))]], T[e]);
     }
     return;
   }
-  // ---- records of the pass: R2 = slot of the last exit of the path inside the supertile; super-exits get dense
-  //      ids (order is irrelevant) and start values for level 3
-  u32 pv[SPT / 2];  // the exits' saturated pointers (root | SDONE), two per register
-  u32 wcnt = 0;     // (wave-uniform) super-exits of this wave
+  // ---- records of the pass: super-exits (exits that drain into another supertile) get dense ids (order is
+  //      irrelevant) and start values for level 3; R2 = slot of the last exit of the path inside the supertile
+  u32 wcnt = 0;  // (wave-uniform) super-exits of this wave
 #pragma unroll
-  for (int j = 0; j < SPT; ++j) {
-    const u32 v = (exbits & (1u << j)) ? (u32)P[dense(tid + 1024u * j)] : 0u;
-    if (j & 1) pv[j >> 1] |= v << 16;
-    else pv[j >> 1] = v;
-    wcnt += (u32)__popcll(__ballot((sxbits >> j) & 1u));
-  }
+  for (int k = 0; k < DPT; ++k) wcnt += (u32)__popcll(__ballot((sxbits >> k) & 1u));
   if (lane == 0) wtot[wave] = wcnt;
   __syncthreads();
-#pragma unroll
-  for (int j = 0; j < SPT; ++j) {  // a root's word now names its slot
-    if (!(exbits & (1u << j))) continue;
-    const u32 i = tid + 1024u * j, d = dense(i);
-    if (((pv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) == (d | SDONE)) P[d] = (uint16_t)i;
-  }
   const u32 ht = ((st / s.nstc) / HG) * s.nhtc + (st % s.nstc) / HG;
   if (tid == 0) {
     u32 tot = 0;
@@ -901,24 +788,40 @@ __global__ void __launch_bounds__(1024, 8) k_super(SuperArgs s) {
   }
   __syncthreads();
   u32 run = s_base + wtot[wave];
+  u32 id[DPT];
+  uint16_t sl[DPT];  // slots of the own exits
 #pragma unroll
-  for (int j = 0; j < SPT; ++j) {
-    const bool sx = (sxbits >> j) & 1u;
+  for (int k = 0; k < DPT; ++k) {
+    const u32 e = tid + 1024u * k;
+    sl[k] = e < n ? (uint16_t)(s.xl_slot[base + e] & (SSL - 1)) : (uint16_t)0;
+  }
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) {
+    const bool sx = (sxbits >> k) & 1u;
     const u64 m = __ballot(sx);
-    if (exbits & (1u << j)) {  // (sxid and R2 are only ever read at exit slots)
-      const u32 i = tid + 1024u * j;
-      const u32 g = base + i;
-      const u32 r = (pv[j >> 1] >> (16 * (j & 1))) & (SDONE - 1u);
-      s.R2[g] = base + ((u32)P[r] & (SSL - 1));  // (masked: on a cycle r is no root and its word no slot; the pass is discarded)
-      u32 id = NONE32;
-      if (sx) {
-        id = run + (u32)__popcll(m & ((1ull << lane) - 1ull));
-        s.sx_slot[id] = g;
-        s.T3[id] = T[dense(i)];
-      }
-      s.sxid[g] = id;
+    id[k] = NONE32;
+    if (sx) {
+      id[k] = run + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      s.sx_slot[id[k]] = base + sl[k];
+      s.T3[id[k]] = T[tid + 1024u * k];
     }
     run += (u32)__popcll(m);
+  }
+  __syncthreads();  // (T has been read: it now holds the slot of every exit, for the roots' sake)
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) {
+    const u32 e = tid + 1024u * k;
+    if (e < n) T[e] = sl[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) {
+    const u32 e = tid + 1024u * k;
+    if (e >= n) continue;
+    const u32 g = base + sl[k];
+    // (masked: on a cycle the pointer is not saturated and its word no root; the pass is discarded then)
+    s.R2[g] = base + (T[min(P[e] & (SDONE - 1u), CAP - 1u)] & (SSL - 1));
+    s.sxid[g] = id[k];
   }
 }
 
@@ -1302,12 +1205,20 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   brow_sink = b + 3 * nb;
   brow_inflow = b + 4 * nb;
   a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, hcntbuf.as<u32>(), nht, nullptr, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
-               (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, esink.as<u32>(),
+               (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, nullptr, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
-  sa = SuperArgs{nst, xT, xtgt, elink, xin, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
+  sa = SuperArgs{nst, xT, xtgt, elink, nullptr, nullptr, nullptr, nullptr, xin, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
                  hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP, nullptr, SCAP};
   PFDCHK(soverbuf.alloc((size_t)nst));
   sa.sover = soverbuf.as<u8>();
+  PFDCHK(xmaskbuf.alloc(nslots / 64 * sizeof(u64)));
+  PFDCHK(xlbuf.alloc(2 * nslots * sizeof(uint16_t)));
+  PFDCHK(scountbuf.alloc((size_t)nst * sizeof(u32)));
+  a.xmask = xmaskbuf.as<u64>();
+  sa.xmask = xmaskbuf.as<u64>();
+  sa.xl_slot = xlbuf.as<uint16_t>();
+  sa.xl_next = xlbuf.as<uint16_t>() + nslots;
+  sa.scount = scountbuf.as<u32>();
   if (const char *e = pfd_knob("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
   if (const char *e = pfd_knob("PFD_TEST_SCAP")) sa.scap = (u32)std::min<u32>((u32)atoi(e), SCAP);
   a.stamps = nullptr;
@@ -1412,8 +1323,8 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   sa.T3 = Tc;
   // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
   sa.hmode = (nht > 1 && !force_flat && !pfd_knob("PFD_FLAT_L3")) ? 1 : 0;
-  k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
-  k_super_pos<false><<<nst, 1024, 0, h->stream>>>(sa);  // (only the supertiles the dense form flagged: normally none)
+  k_super<false, SCAP><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super<false, SSL><<<nst, 1024, 0, h->stream>>>(sa);  // (only the supertiles k_exit_lists flagged: normally none)
   KCHK();
   *launches += 2;
   if (!sa.hmode) {  // the flat level-3 rounds are sized by the number of super-exits
@@ -1428,8 +1339,8 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
     PFDCHK(level3_hyper(launches));
   else if (nsuper)
     PFDCHK(level3_flat(launches));
-  k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
-  k_super_pos<true><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super<true, SCAP><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super<true, SSL><<<nst, 1024, 0, h->stream>>>(sa);
   *launches += 2;
   KCHK();
   return PFD_OK;
@@ -1450,6 +1361,8 @@ int TiledRun::phase_a() {
     HIPCHK(hipMemsetAsync(brow_sink, 0xFF, nb * sizeof(u32), h->stream));
   }
   if (is_block) HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));  // read by the final tile pass
+  // exit bitmasks: tiles beyond the raster edge of a partial supertile write none (8 bytes per 64 slots)
+  HIPCHK(hipMemsetAsync(a.xmask, 0, nslots / 64 * sizeof(u64), h->stream));
   // interior tiles: k_tile_local_fast; the frame around them (raster edge, halo and boundary rows): k_tile
   const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
   const bool have_i = gridi.x && gridi.y;
@@ -1489,7 +1402,8 @@ int TiledRun::phase_a() {
   }
 
   pfd_seg_begin(h, "exit_graph");
-  i64 launches = 0;
+  i64 launches = 1;
+  k_exit_lists<<<nst * 16, 256, 0, h->stream>>>(sa);  // (valid for every solve of the pass)
   PFDCHK(solve_exits(xT, &launches, true, is_block));
   if (is_block) {  // what leaves through the halo rows, and where boundary-row inflow would leave
     HIPCHK(hipMemcpyAsync(haloL, haloA, nb * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
