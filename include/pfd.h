@@ -255,6 +255,24 @@ int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtype, const vo
                    const double *halo_seed_host, int update, double *out, int memspace, double *boundary_rows_host,
                    int64_t *n_unknown);
 
+/* Up-sweeps of a ROW BLOCK — accuflux (reference pyflwdir/streams.py:15-41, direction "up") and Strahler order
+ * (streams.py:228-269) — for rasters cut into row blocks (several GPUs, or one GPU and more than 2^32 - 2 cells).
+ * Like pfd_accuflux / pfd_strahler on the block's device raster (own rows + halo rows; data / mask / out cover all of
+ * them), except that a valid halo cell — the neighbouring block's boundary cell — has the value given in
+ * `halo_seed_host` (HOST, 2 * ncol elements of the result type: top halo row, bottom halo row).  A halo cell that drains
+ * into the block is added by its downstream cell in the serial loop's position (upstream cells in descending linear
+ * index), so floats come out bit-identical to the whole raster once the seeds are the neighbours' final rows.  The caller
+ * iterates (pyflwdir_amd/dist.py up_blocks): exchange the boundary rows and sweep again until no row changes.
+ *   by_row != 0: `data` holds one value per ROW of the device raster (HOST; upstream_area(unit="km2") on lat/lon grids).
+ *   verify != 0: nothing is computed; `out` holds a result, *n_bad receives the number of own cells whose value is not
+ *                the one their upstream cells (halo seeds included) give — the all-cell check of a blocked result.
+ *   boundary_rows_host (nullable): receives the first and the last OWN row (2 * ncol elements). */
+int pfd_accuflux_block(pfd_raster *h, int dtype, const void *data, int by_row, int64_t nodata_i, double nodata_f,
+                       int has_nodata, const void *halo_seed_host, int verify, void *out, int memspace,
+                       void *boundary_rows_host, int64_t *n_bad);
+int pfd_strahler_block(pfd_raster *h, const uint8_t *mask, const uint8_t *halo_seed_host, int verify, uint8_t *out,
+                       int memspace, uint8_t *boundary_rows_host, int64_t *n_bad);
+
 /* basins (reference pyflwdir/basins.py:12-18, core.py:120-146) on a raster row-tiled over several GPUs /
  * processes, split-phase like pfd_upstream_area_cell_begin/_finish (Multi-GPU): `outlets` are k
  * linear indices INTO THE BLOCK'S OWN ROWS (r * ncol + c, r counted from the block's first own row), `ids`

@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libpfd_hip.so")
 
 PFD_HOST, PFD_DEVICE = 0, 1
 PFD_I32, PFD_U32, PFD_I64, PFD_F32, PFD_F64 = 1, 2, 3, 4, 5
+_PAYLOAD_CODE = {np.dtype(np.int32): PFD_I32, np.dtype(np.int64): PFD_I64, np.dtype(np.float32): PFD_F32,
+                 np.dtype(np.float64): PFD_F64}
 PFD_UP, PFD_DOWN = 0, 1
 
 IDX_CODE = {np.dtype(np.int32): PFD_I32, np.dtype(np.uint32): PFD_U32, np.dtype(np.int64): PFD_I64}
@@ -36,7 +38,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
 ]
 
 _lib = None
@@ -90,6 +92,10 @@ def lib() -> C.CDLL:
         L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.pfd_accuflux_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_int, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
+        L.pfd_strahler_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.POINTER(C.c_int64)]
         L.pfd_hand_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_void_p, C.POINTER(C.c_int64)]
         L.pfd_verify_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
@@ -380,6 +386,31 @@ class RasterHandle:
         check(lib().pfd_hand_block(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(halo_seed), 1 if update else 0, ptr(out),
                                    memspace, ptr(brows), C.byref(unk)))
         return out, brows, int(unk.value)
+
+    def accuflux_block(self, data, dtype_code, halo_seed, out, nodata_i=0, nodata_f=0.0, has_nodata=0, by_row=False,
+                       verify=False, memspace=PFD_HOST):
+        """accuflux (direction "up") of a row block whose halo cells hold ``halo_seed`` (2 * ncol values of the result
+        type, host); data and ``out`` cover the block's device raster (own + halo rows), ``by_row``: one host value per
+        device row.  Returns (boundary rows [2, ncol], own cells failing their local equation — verify only)."""
+        halo_seed = np.ascontiguousarray(halo_seed)
+        assert halo_seed.size == 2 * self.ncol and _PAYLOAD_CODE[halo_seed.dtype] == dtype_code
+        brows = np.empty((2, self.ncol), halo_seed.dtype)
+        bad = C.c_int64(0)
+        check(lib().pfd_accuflux_block(self._h, dtype_code, ptr(data), 1 if by_row else 0, int(nodata_i), float(nodata_f),
+                                       int(has_nodata), ptr(halo_seed), 1 if verify else 0, ptr(out), memspace,
+                                       ptr(brows), C.byref(bad)))
+        return brows, int(bad.value)
+
+    def strahler_block(self, mask, halo_seed, out, verify=False, memspace=PFD_HOST):
+        """Strahler order of a row block whose halo cells hold ``halo_seed`` (2 * ncol uint8, host).  Returns
+        (boundary rows [2, ncol], own cells failing their local equation — verify only)."""
+        halo_seed = np.ascontiguousarray(halo_seed, dtype=np.uint8)
+        assert halo_seed.size == 2 * self.ncol
+        brows = np.empty((2, self.ncol), np.uint8)
+        bad = C.c_int64(0)
+        check(lib().pfd_strahler_block(self._h, ptr(mask), ptr(halo_seed), 1 if verify else 0, ptr(out), memspace,
+                                       ptr(brows), C.byref(bad)))
+        return brows, int(bad.value)
 
     def verify_basins(self, outlets, ids, labels, memspace=PFD_HOST) -> dict:
         """Local-equation check of a basins() result with uint32 ids (see include/pfd.h)."""

@@ -299,6 +299,7 @@ static void free_handle(pfd_raster *h) {
   pfd_dfree(h->raw_owned);
   pfd_dfree(h->seq);
   pfd_dfree(h->seq_kids2);  // (seq_kids / seq_own / cell_kids live in the same allocation)
+  pfd_dfree(h->halo_raw);
   pfd_free_xplan(h);
   pfd_free_general(h);
   pfd_dfree(h->pits);

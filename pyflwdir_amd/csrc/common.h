@@ -151,6 +151,7 @@ struct pfd_raster {
   size_t bytes_held = 0;
   void *pending = nullptr;  // split-phase multi-block pass in flight (dist.hip)
   void *pending_basins = nullptr;  // split-phase multi-block basins query in flight (paths.hip)
+  u8 *halo_raw = nullptr;  // row blocks: the D8 codes of the two halo rows as given (2 * ncol; the normalised codes hold sinks there)
   void *hand_block_state = nullptr;  // cells of a row block whose HAND is still unknown, between pfd_hand_block calls (sweeps.hip)
   // profiling
   bool profiling = false;

@@ -255,6 +255,22 @@ static int alloc_pits(pfd_raster *h) {
   return pfd_dmalloc((void **)&h->pits, (size_t)std::max<i64>(h->n_pits, 1) * sizeof(u32));
 }
 
+// the halo rows of a row block as given: the flow ENTERING the block from them is invisible in the normalised codes
+// (halo cells are sinks there); the seeded up-sweeps of a row block need it (sweeps.hip, pfd_accuflux_block)
+static int save_halo_rows(pfd_raster *h, const u8 *d8_dev) {
+  if (!(h->halo_top || h->halo_bot) || !d8_dev) return PFD_OK;
+  const size_t ncol = (size_t)h->ncol;
+  if (!h->halo_raw) PFDCHK(pfd_dmalloc((void **)&h->halo_raw, 2 * ncol));
+  HIPCHK(hipMemsetAsync(h->halo_raw, D8_MV, 2 * ncol, h->stream));
+  if (h->halo_top)
+    HIPCHK(hipMemcpyAsync(h->halo_raw, d8_dev + (size_t)(h->halo_top - 1) * ncol, ncol, hipMemcpyDeviceToDevice, h->stream));
+  if (h->halo_bot)
+    HIPCHK(hipMemcpyAsync(h->halo_raw + ncol, d8_dev + (size_t)(h->halo_top + h->own_rows) * ncol, ncol,
+                          hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}
+
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
   HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
   const u32 gy = std::min<u32>(cdiv_u32((u64)h->nrow, 16), 65535u);
@@ -262,6 +278,7 @@ int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev) {
   k_normalise<<<grid, 256, 0, h->stream>>>(d8_dev, h->geo, h->ncode, h->ctrl, (u32)h->halo_top,
                                            (u32)(h->halo_top + h->own_rows - 1));
   KCHK();
+  PFDCHK(save_halo_rows(h, d8_dev));
   u64 c[48];
   HIPCHK(hipMemcpyAsync(c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -295,6 +312,7 @@ int pfd_adopt_counts(pfd_raster *h, const u64 *c) {
   h->aux_ready = false;
   h->pits_ready = false;  // the ascending pit list is compacted on first use
   h->normalised = true;
+  if (!h->halo_raw) PFDCHK(save_halo_rows(h, h->raw));  // (a deferred handle decoded by the tile pass)
   h->raw = nullptr;
   if (h->raw_owned) {
     pfd_dfree(h->raw_owned);

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) k_seq_aux(const u8 *__restrict__ ncode, G
   }
   kids[j] = (u8)m;
   own[j] = ncode[x];
-  kids2[j] = m2;
+  if (kids2) kids2[j] = m2;
 }
 // the same child mask per CELL (2-hop up-sweeps look up the children of a child)
 __global__ void __launch_bounds__(256) k_cell_kids(const u8 *__restrict__ ncode, Geo g, u8 *__restrict__ kids) {
@@ -79,22 +79,50 @@ __global__ void __launch_bounds__(256) k_cell_kids(const u8 *__restrict__ ncode,
   kids[x] = (u8)kids_of(ncode, g, x);
 }
 
+// row blocks: the cells of the halo rows that drain INTO the block.  The normalised codes hold sinks there, so the
+// masks above miss them; the codes of the halo rows as given (halo_raw: top row, bottom row) tell.  One thread per
+// cell of the first / last own row.
+__global__ void __launch_bounds__(256) k_halo_kids(const u8 *__restrict__ ncode, const u8 *__restrict__ halo_raw, Geo g,
+                                                   u32 row_first, u32 row_last, u8 *__restrict__ kids) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * g.ncol) return;
+  const u32 side = t / g.ncol, c = t - side * g.ncol;
+  if ((side == 0 && row_first == 0) || (side == 1 && row_last + 1 >= g.nrow)) return;  // no halo row on this side
+  const u32 x = (side ? row_last : row_first) * g.ncol + c;
+  if (ncode[x] == D8_MV) return;
+  u32 m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (d8_dr(k) != (side ? 1 : -1)) continue;
+    const u32 cc = c + (u32)d8_dc(k);  // wraps to >= ncol when negative
+    if (cc < g.ncol && halo_raw[side * g.ncol + cc] == (1u << ((k + 4) & 7))) m |= 1u << k;
+  }
+  if (m) kids[x] |= (u8)m;
+}
+
 int pfd_ensure_seq_aux(pfd_raster *h) {
   if (h->aux_ready) return PFD_OK;
   if (h->seq_kids2) pfd_dfree(h->seq_kids2);
   h->seq_kids2 = nullptr;
   h->seq_kids = nullptr;
   // layout: kids2 u64[n_seq] | kids u8[n_seq] | own u8[n_seq] | cell_kids u8[n]
-  const size_t ns = (size_t)std::max<i64>(h->n_seq, 1);
-  PFDCHK(pfd_dmalloc((void **)&h->seq_kids2, ns * 10 + (size_t)h->n));
-  h->seq_kids = (u8 *)(h->seq_kids2 + ns);
+  // (row blocks sweep one level per launch and never read kids2: 8 of the 11 bytes per cell stay unallocated)
+  const bool block = h->halo_top || h->halo_bot;
+  const size_t ns = (size_t)std::max<i64>(h->n_seq, 1), ns2 = block ? 1 : ns;
+  PFDCHK(pfd_dmalloc((void **)&h->seq_kids2, ns2 * 8 + ns * 2 + (size_t)h->n));
+  h->seq_kids = (u8 *)(h->seq_kids2 + ns2);
   h->seq_own = h->seq_kids + ns;
   h->cell_kids = h->seq_own + ns;
   k_cell_kids<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->cell_kids);
   KCHK();
+  if (block && h->halo_raw) {
+    k_halo_kids<<<cdiv_u32(2 * (u64)h->ncol, 256), 256, 0, h->stream>>>(h->ncode, h->halo_raw, h->geo, (u32)h->halo_top,
+                                                                      (u32)(h->halo_top + h->own_rows - 1), h->cell_kids);
+    KCHK();
+  }
   if (h->n_seq) {
-    k_seq_aux<<<cdiv_u32((u64)h->n_seq, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, (u32)h->n_seq,
-                                                                   h->cell_kids, h->seq_kids, h->seq_own, h->seq_kids2);
+    k_seq_aux<<<cdiv_u32((u64)h->n_seq, 256), 256, 0, h->stream>>>(h->ncode, h->geo, h->seq, (u32)h->n_seq, h->cell_kids,
+                                                                   h->seq_kids, h->seq_own, block ? nullptr : h->seq_kids2);
     KCHK();
   }
   h->aux_ready = true;
@@ -181,6 +209,7 @@ static int run_up(pfd_raster *h, const Op &op, const char *name) {
   //  window, which spills: 100 loads per thread are too many registers)
   int maxk = pfd_knob("PFD_SINGLE_HOP") ? 1 : 2;
   if (const char *e = pfd_knob("PFD_UP_K")) maxk = std::max(1, std::min(3, atoi(e)));
+  if (h->halo_top || h->halo_bot) maxk = 1;  // (a row block: the value of a halo cell is given, never recomputed)
   for (i64 l = h->n_levels - 1; l >= 0;) {
     const u32 end = (u32)h->lvl_off[l + 1];
     int k = 1;  // levels l, l-1, .. l-k+1
@@ -1353,6 +1382,168 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   return o.finish(h->stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Up-sweeps of a ROW BLOCK (accuflux, Strahler): the mirror image of pfd_hand_block.  A halo cell that drains into the
+// block is one of the upstream cells of a boundary cell (k_halo_kids) and its value is GIVEN — the neighbouring
+// block's boundary row, `halo_seed_host` — so the boundary cell adds it where the serial loop would (upstream cells
+// in descending linear index): the same operands in the same order as on the whole raster, bit-identical for floats
+// once the seeds are the neighbour's final values.  The caller iterates to the fixpoint (pyflwdir_amd/dist.py
+// up_blocks): the blocks exchange their boundary rows until none of them changes; a value is final after as many
+// exchanges as its longest upstream path crosses block edges.
+// ---------------------------------------------------------------------------------------------
+template <class Op>
+struct OwnRows : Op {  // the op, storing into the own rows only: halo cells keep their seeds
+  u32 lo, n_own;
+  template <class VV>
+  __device__ __forceinline__ void store(u32 x, VV v) const {
+    if (x - lo < n_own) Op::store(x, v);
+  }
+};
+__device__ __forceinline__ u64 bits_of(double v) { return (u64)__double_as_longlong(v); }
+__device__ __forceinline__ u64 bits_of(float v) { return (u64)__float_as_uint(v); }
+__device__ __forceinline__ u64 bits_of(i64 v) { return (u64)v; }
+__device__ __forceinline__ u64 bits_of(i32 v) { return (u64)(u32)v; }
+__device__ __forceinline__ u64 bits_of(u8 v) { return (u64)v; }
+// local equations of every own cell against the values in place (halo rows = the neighbours' final rows): the
+// all-cell check of a result that was computed in blocks, and the fixpoint the iteration ends in
+template <class Op, class T>
+__global__ void __launch_bounds__(256) k_verify_up(Op op, const u8 *__restrict__ ncode, const u8 *__restrict__ kids,
+                                                   const T *__restrict__ out, u32 lo, u32 n_own,
+                                                   unsigned long long *__restrict__ bad) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool b = false;
+  if (i < n_own) {
+    const u32 x = lo + i;
+    if (ncode[x] != D8_MV) {
+      const T v = (T)op.combine(x, (u32)kids[x], [&](u32 nb, int) { return op.leaf(nb); });
+      b = bits_of(v) != bits_of(out[x]);  // (bitwise: -0.0 vs 0.0 and NaN payloads count)
+    }
+  }
+  const u64 m = __ballot(b);
+  if (m && (threadIdx.x & 63u) == 0u) atomicAdd(bad, (unsigned long long)__popcll(m));
+}
+template <class Op, class T>
+static int up_block_run(pfd_raster *h, const Op &op0, T *out_dev, const T *seed_dev, int verify, T *brows_host,
+                        int64_t *n_bad, const char *name) {
+  const size_t ncol = (size_t)h->ncol, own0 = (size_t)h->halo_top * ncol, nown = (size_t)h->own_rows * ncol;
+  if (h->halo_top)
+    HIPCHK(hipMemcpyAsync(out_dev + own0 - ncol, seed_dev, ncol * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+  if (h->halo_bot)
+    HIPCHK(hipMemcpyAsync(out_dev + own0 + nown, seed_dev + ncol, ncol * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+  OwnRows<Op> op{op0, (u32)own0, (u32)nown};
+  if (verify) {
+    PFDCHK(pfd_ensure_seq_aux(h));
+    pfd_seg_begin(h, "verify_up_block");
+    HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(u64), h->stream));
+    k_verify_up<OwnRows<Op>, T><<<cdiv_u32((u64)nown, 256), 256, 0, h->stream>>>(op, h->ncode, h->cell_kids, out_dev, (u32)own0,
+                                                                                (u32)nown, (unsigned long long *)h->ctrl);
+    KCHK();
+    pfd_seg_end(h, 1);
+    u64 bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, h->ctrl, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_bad) *n_bad = (int64_t)bad;
+  } else {
+    PFDCHK(run_up(h, op, name));
+  }
+  if (brows_host) {  // first and last OWN row: the neighbouring blocks' halo values
+    HIPCHK(hipMemcpyAsync(brows_host, out_dev + own0, ncol * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(brows_host + ncol, out_dev + own0 + nown - ncol, ncol * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return PFD_OK;
+}
+static int up_block_prepare(pfd_raster *h, const char *what) {
+  PFDCHK(pfd_check_handle(h));
+  PFDCHK(pfd_reject_general(h, what));
+  if (!(h->halo_top || h->halo_bot) && h->own_rows != h->nrow) {
+    pfd_set_error("%s: not a row-block handle", what);
+    return PFD_EINVAL;
+  }
+  if ((h->halo_top || h->halo_bot) && !h->halo_raw) {
+    pfd_set_error("%s: the D8 codes of the halo rows are not available on this handle", what);
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  return pfd_order_cells_impl(h);  // (the level structure of the block: its halo cells are roots like its pits)
+}
+template <class T>
+static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T nodata, int has_nodata, const void *seed_host,
+                            int verify, void *out, int memspace, void *brows_host, int64_t *n_bad) {
+  InArg d, sd;
+  if (by_row)
+    PFDCHK(d.bind(data, (size_t)h->nrow * sizeof(T), PFD_HOST, h->stream));
+  else
+    PFDCHK(d.bind(data, (size_t)h->n * sizeof(T), memspace, h->stream));
+  PFDCHK(sd.bind(seed_host, 2 * (size_t)h->ncol * sizeof(T), PFD_HOST, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * sizeof(T), memspace));
+  if (verify && memspace == PFD_HOST)
+    HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  if (!verify) {
+    pfd_seg_begin(h, "init");
+    if (by_row) {
+      k_fill_rows<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((const T *)d.dev, h->geo, (T *)o.dev);
+      KCHK();
+    } else {
+      HIPCHK(hipMemcpyAsync(o.dev, d.dev, (size_t)h->n * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    }
+    pfd_seg_end(h, 1);
+  }
+  if (by_row) {
+    AccuUp<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(up_block_run(h, op, (T *)o.dev, (const T *)sd.dev, verify, (T *)brows_host, n_bad, "sweep_accuflux_block"));
+  } else {
+    AccuUp<T> op{h->ncode, h->geo, CellData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(up_block_run(h, op, (T *)o.dev, (const T *)sd.dev, verify, (T *)brows_host, n_bad, "sweep_accuflux_block"));
+  }
+  return verify ? PFD_OK : o.finish(h->stream);
+}
+extern "C" int pfd_accuflux_block(pfd_raster *h, int dtype, const void *data, int by_row, int64_t nodata_i, double nodata_f,
+                                  int has_nodata, const void *halo_seed_host, int verify, void *out, int memspace,
+                                  void *boundary_rows_host, int64_t *n_bad) {
+  PFDCHK(up_block_prepare(h, "pfd_accuflux_block"));
+  if (!data || !out || !halo_seed_host) {
+    pfd_set_error("pfd_accuflux_block: bad arguments");
+    return PFD_EINVAL;
+  }
+  switch (dtype) {
+    case PFD_I32:
+      return accuflux_block_t<i32>(h, data, by_row != 0, (i32)nodata_i, has_nodata, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
+    case PFD_I64:
+      return accuflux_block_t<i64>(h, data, by_row != 0, (i64)nodata_i, has_nodata, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
+    case PFD_F32:
+      return accuflux_block_t<float>(h, data, by_row != 0, (float)nodata_f, has_nodata, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
+    case PFD_F64:
+      return accuflux_block_t<double>(h, data, by_row != 0, nodata_f, has_nodata, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
+    default:
+      pfd_set_error("pfd_accuflux_block: unsupported payload dtype code %d", dtype);
+      return PFD_EUNSUPPORTED;
+  }
+}
+extern "C" int pfd_strahler_block(pfd_raster *h, const uint8_t *mask, const uint8_t *halo_seed_host, int verify, uint8_t *out,
+                                  int memspace, uint8_t *boundary_rows_host, int64_t *n_bad) {
+  PFDCHK(up_block_prepare(h, "pfd_strahler_block"));
+  if (!out || !halo_seed_host) {
+    pfd_set_error("pfd_strahler_block: bad arguments");
+    return PFD_EINVAL;
+  }
+  InArg m, sd;
+  PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
+  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol, PFD_HOST, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n, memspace));
+  if (verify && memspace == PFD_HOST) HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  if (!verify) {
+    pfd_seg_begin(h, "init");
+    HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
+    pfd_seg_end(h, 1);
+  }
+  Strahler op{h->ncode, h->geo, (const u8 *)m.dev, (u8 *)o.dev};
+  PFDCHK(up_block_run(h, op, (u8 *)o.dev, (const u8 *)sd.dev, verify, boundary_rows_host, n_bad, "sweep_strahler_block"));
+  return verify ? PFD_OK : o.finish(h->stream);
 }
 
 extern "C" int pfd_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const void *elevtn, double *out,

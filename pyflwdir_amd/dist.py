@@ -149,6 +149,134 @@ def hand_blocks(d8: np.ndarray, nblocks: int, drain, elevtn, devices=None, max_i
             blk.close()
 
 
+class _UpBlock:
+    """Device-resident state of one row block of an up-sweep (accuflux, Strahler) between the exchanges: payload and
+    result stay in HBM; only the two boundary rows travel."""
+
+    def __init__(self, handle, kind, dtype, payload=None, by_row=False, nodata=(0, 0.0, 0), mask=None):
+        self.h, self.kind, self.dtype, self.by_row, self.nodata = handle, kind, np.dtype(dtype), by_row, nodata
+        ncol, dev = handle.ncol, handle.device
+        self.nrows_dev = handle.nrow + sum(handle.halo)
+        self.payload = self.mask = None
+        if kind == "accuflux":
+            payload = np.ascontiguousarray(payload, dtype=self.dtype)
+            assert payload.size == (self.nrows_dev if by_row else self.nrows_dev * ncol)
+            self.payload = payload if by_row else _hip.DeviceBuffer(payload.nbytes, dev).upload(payload)
+        elif mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mask.size == self.nrows_dev * ncol
+            self.mask = _hip.DeviceBuffer(mask.nbytes, dev).upload(mask)
+        self.out = _hip.DeviceBuffer(self.nrows_dev * ncol * self.dtype.itemsize, dev)
+        self.swept_with, self.brows = None, None
+
+    def _call(self, seed, verify):
+        if self.kind == "accuflux":
+            nd_i, nd_f, has_nd = self.nodata
+            return self.h.accuflux_block(self.payload, _hip._PAYLOAD_CODE[self.dtype], seed, self.out, nd_i, nd_f, has_nd,
+                                         by_row=self.by_row, verify=verify, memspace=_hip.PFD_DEVICE)
+        return self.h.strahler_block(self.mask, seed, self.out, verify=verify, memspace=_hip.PFD_DEVICE)
+
+    def sweep(self, seed):
+        """Sweep with these halo values; False if they are the ones of the last sweep (nothing can have changed)."""
+        bits = seed.view(np.uint8)
+        if self.swept_with is not None and np.array_equal(self.swept_with, bits):
+            return False
+        self.swept_with = bits.copy()
+        self.brows, _ = self._call(seed, False)
+        return True
+
+    def verify(self, seed):
+        """Own cells whose value is not the one their upstream cells (halo values included) give."""
+        return self._call(seed, True)[1]
+
+    def result(self):
+        ncol, sz = self.h.ncol, self.dtype.itemsize
+        return self.out.download(self.dtype, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol * sz)
+
+    def close(self, close_handle=True):
+        for b in (self.payload, self.mask, self.out):
+            if isinstance(b, _hip.DeviceBuffer):
+                b.free()
+        if close_handle:
+            self.h.close()
+
+
+def _up_blocks_run(blocks, ncol, dtype, max_iter=None, verify=False):
+    """Exchange boundary rows and sweep until no halo value changes: the fixpoint is the whole raster's result (the
+    graph is acyclic; a value is final after as many exchanges as its longest upstream path crosses block edges).
+    Returns the number of rounds in which some block swept."""
+    nb = len(blocks)
+    seeds = [np.zeros(2 * ncol, dtype) for _ in range(nb)]
+    it = 0
+    while True:
+        swept = [blk.sweep(seeds[b]) for b, blk in enumerate(blocks)]
+        if not any(swept):
+            break
+        it += 1
+        if max_iter is not None and it > max_iter:
+            raise RuntimeError("row blocks: the boundary rows did not settle (a cycle through the block edges?)")
+        for b in range(nb):  # halo rows = the neighbours' boundary rows
+            if b > 0:
+                seeds[b][:ncol] = blocks[b - 1].brows[1]
+            if b + 1 < nb:
+                seeds[b][ncol:] = blocks[b + 1].brows[0]
+    bad = sum(blk.verify(seeds[b]) for b, blk in enumerate(blocks)) if verify else None
+    return it, bad
+
+
+def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0), by_row=False, devices=None,
+                    verify=False):
+    """``accuflux(data, direction="up")`` (reference pyflwdir/streams.py:15-41) of a host raster computed as ``nblocks``
+    row blocks held by this one process — for rasters beyond 2**32 - 2 cells, and the in-process form of the
+    multi-GPU protocol.  ``data``: the payload raster (int32 / int64 / float32 / float64), or with ``by_row`` one value
+    per raster row (cell areas of a regular grid).  ``nodata_args`` = (nodata_i, nodata_f, has_nodata) as
+    raster._payload_args returns them.  Returns (result, rounds, bad cells or None).
+
+    Float sums are not associative: a boundary cell adds the values of the halo cells draining into it in the serial
+    loop's position, so every sum has the whole raster's operands in the whole raster's order (bit-identical)."""
+    d8 = np.ascontiguousarray(d8, dtype=np.uint8)
+    nrow, ncol = d8.shape
+    data = np.asarray(data)
+    dtype = data.dtype
+    if dtype not in _hip._PAYLOAD_CODE:
+        raise NotImplementedError(f"payload dtype {dtype} is not supported by the row-block accuflux")
+    data = data.reshape(nrow) if by_row else data.reshape(nrow, ncol)
+    devices = devices or [0] * nblocks
+    blocks = []
+    try:
+        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
+            a, e = block_slice(nrow, nblocks, b)
+            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
+            blocks.append(_UpBlock(h, "accuflux", dtype, payload=data[a:e], by_row=by_row, nodata=nodata_args))
+        it, bad = _up_blocks_run(blocks, ncol, dtype, verify=verify)
+        return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
+    finally:
+        for blk in blocks:
+            blk.close()
+
+
+def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verify=False):
+    """Strahler stream order (reference pyflwdir/streams.py:228-269) of a host raster computed as ``nblocks`` row
+    blocks held by this one process; ``mask`` (uint8, optional) as in ``stream_order``.  Returns (order, rounds,
+    bad cells or None)."""
+    d8 = np.ascontiguousarray(d8, dtype=np.uint8)
+    nrow, ncol = d8.shape
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(nrow, ncol)
+    devices = devices or [0] * nblocks
+    blocks = []
+    try:
+        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
+            a, e = block_slice(nrow, nblocks, b)
+            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
+            blocks.append(_UpBlock(h, "strahler", np.uint8, mask=None if mask is None else mask[a:e]))
+        it, bad = _up_blocks_run(blocks, ncol, np.uint8, verify=verify)
+        return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
+    finally:
+        for blk in blocks:
+            blk.close()
+
+
 class _HandBlock:
     """Device-resident state of one row block's HAND between the exchanges: drain, elevation and the heights stay in
     HBM; only the two boundary rows and the number of unknown cells travel."""
@@ -375,6 +503,60 @@ class DistributedRaster:
         finally:
             if blk is not None:
                 blk.close(close_handle=False)
+
+    def _up_collective(self, make_block, dtype, max_iter=None):
+        """Collective fixpoint of an up-sweep over the ranks' blocks (see :func:`_up_blocks_run`): per round one
+        all-gather of the two boundary rows and one agreement on whether any rank swept."""
+        ncol = self.handle.ncol
+        dtype = np.dtype(dtype)
+        seed = np.zeros(2 * ncol, dtype)
+        blk, err, it = None, None, 0
+        try:
+            blk = make_block()
+        except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
+            err = exc
+        try:
+            while True:
+                rec, mine = np.zeros(2 * ncol, dtype), -1
+                if err is None:
+                    try:
+                        mine = 1 if blk.sweep(seed) else 0
+                        rec = blk.brows.ravel()
+                    except Exception as exc:  # noqa: BLE001
+                        err = exc
+                parts = self.group.allgather(rec.tobytes())
+                flags = [int(x) for x in np.frombuffer(b"".join(self.group.allgather(np.int64(mine).tobytes())), np.int64)]
+                if err is not None:
+                    raise err
+                if min(flags) < 0:
+                    raise RuntimeError("another rank failed in the row-block sweep")
+                if max(flags) == 0:
+                    return blk.result(), it
+                it += 1
+                if max_iter is not None and it > max_iter:
+                    raise RuntimeError("row blocks: the boundary rows did not settle")
+                if self.rank > 0:
+                    seed[:ncol] = np.frombuffer(parts[self.rank - 1], dtype)[ncol:]
+                if self.rank + 1 < self.world:
+                    seed[ncol:] = np.frombuffer(parts[self.rank + 1], dtype)[:ncol]
+        finally:
+            if blk is not None:
+                blk.close(close_handle=False)
+
+    def accuflux(self, data_block, nodata_args=(0, 0.0, 0), by_row=False, max_iter=None):
+        """Collective ``accuflux(data, direction="up")`` (reference pyflwdir/streams.py:15-41): every rank passes the
+        payload of its block INCLUDING its halo rows (``by_row``: one value per device row); returns (the rank's own
+        rows, rounds).  Bit-identical to the whole raster, floats included: see :func:`accuflux_blocks`."""
+        data = np.asarray(data_block)
+        if data.dtype not in _hip._PAYLOAD_CODE:
+            raise NotImplementedError(f"payload dtype {data.dtype} is not supported by the row-block accuflux")
+        return self._up_collective(lambda: _UpBlock(self.handle, "accuflux", data.dtype, payload=data, by_row=by_row,
+                                                    nodata=nodata_args), data.dtype, max_iter)
+
+    def stream_order(self, mask_block=None, max_iter=None):
+        """Collective Strahler order (reference pyflwdir/streams.py:228-269); ``mask_block`` covers the block's device
+        rows.  Returns (uint8 orders of the rank's own rows, rounds)."""
+        return self._up_collective(lambda: _UpBlock(self.handle, "strahler", np.uint8, mask=mask_block), np.uint8, max_iter)
 
     def close(self):
         if self.handle is not None:

@@ -508,6 +508,13 @@ class FlwdirRaster(object):
         # (element for element the reference's  area / AREA_FACTORS[unit]) instead of an n-element grid
         rows = np.ascontiguousarray(gis.area_rows(self.transform, self.shape, self.latlon, unit="m2")
                                     / gis.AREA_FACTORS[unit])
+        nb = self._row_blocks_needed()
+        if nb > 1:  # beyond 32-bit cell indices: seeded row blocks (pyflwdir_amd/dist.py), bit-identical
+            from . import dist
+
+            out = dist.accuflux_blocks(self._d8, nb, rows, (-9999, -9999.0, 1), by_row=True)[0]
+            out[self._d8 == D8_MV] = -9999
+            return out
         out = self._h.accuflux_rows(rows, _PAYLOAD[rows.dtype], nodata_i=-9999, nodata_f=-9999.0, has_nodata=1,
                                     direction=_hip.PFD_UP, mask_invalid=1)
         return out.reshape(self.shape)
@@ -522,6 +529,12 @@ class FlwdirRaster(object):
         if flat.dtype in _NARROW_INT:
             return self._accuflux_narrow(flat, nodata, dirc).reshape(data.shape)
         view, code, nd_i, nd_f, has_nd = _payload_args(flat, nodata)
+        nb = self._row_blocks_needed()
+        if nb > 1 and direction == "up":
+            from . import dist
+
+            out = dist.accuflux_blocks(self._d8, nb, view, (nd_i, nd_f, has_nd))[0]
+            return out.view(flat.dtype).reshape(data.shape)
         out = self._h.accuflux(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd, direction=dirc)
         return out.view(flat.dtype).reshape(data.shape)
 
@@ -572,7 +585,13 @@ class FlwdirRaster(object):
                 strord = self._cached["strord"]
             else:
                 m = None if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
-                strord = self._h.strahler(m)
+                nb = self._row_blocks_needed()
+                if nb > 1:
+                    from . import dist
+
+                    strord = dist.strahler_blocks(self._d8, nb, m)[0].ravel()
+                else:
+                    strord = self._h.strahler(m)
                 if self.cache:
                     self._cached.update(strord=strord)
         elif type.lower() == "classic":  # reference pyflwdir/flwdir.py:540-543, streams.py:191-225
@@ -650,9 +669,9 @@ class FlwdirRaster(object):
 
     def _row_blocks_needed(self):
         """1, or the number of row blocks a raster beyond 2**32 - 2 cells is cut into for the operations whose engines
-        address cells with 32 bits (the reference's index ladder reaches int64, pyflwdir.py:105-127): basins and
-        hand then run the row-block protocols of pyflwdir_amd/dist.py inside this one process — same kernels,
-        bit-identical results.  (PFD_TEST_BIG_CELLS with PFD_ENABLE_KNOBS=1 lowers the threshold for tests.)"""
+        address cells with 32 bits (the reference's index ladder reaches int64, pyflwdir.py:105-127): basins, hand,
+        accuflux (up), upstream_area in area units and the Strahler order then run the row-block protocols of
+        pyflwdir_amd/dist.py inside this one process — same kernels, bit-identical results.  (PFD_TEST_BIG_CELLS with PFD_ENABLE_KNOBS=1 lowers the threshold for tests.)"""
         import os
 
         limit = 4294967294

@@ -180,3 +180,102 @@ def test_front_end_cuts_huge_rasters_into_row_blocks(gpu_lib, oracle, monkeypatc
     ids = (np.arange(outl.size) + 11).astype(np.uint32)
     assert np.array_equal(flw.basins(idxs=outl, ids=ids).ravel(), O.basins(idxs_ds, outl.astype(idxs_ds.dtype), seq, ids))
     assert np.array_equal(flw.basins().ravel(), O.basins(idxs_ds, idxs_pit, seq))
+    # the up-sweeps: float32 accuflux, upstream_area in km2 (float64 row areas of a lat/lon grid), Strahler order
+    data = (np.random.default_rng(5).random(shape) * 2.5).astype(np.float32)
+    exp = O.accuflux(idxs_ds, seq, data.ravel(), nodata=-9999)
+    assert np.array_equal(flw.accuflux(data).ravel().view(np.uint32), exp.view(np.uint32))
+    assert np.array_equal(flw.stream_order().ravel(), O.strahler_order(idxs_ds, seq))
+    monkeypatch.delenv("PFD_TEST_BIG_CELLS")
+    from pyflwdir_amd import gis
+
+    tr = gis.Affine(0.01, 0.0, 3.0, 0.0, -0.01, 52.0)  # 15 x 11 degrees around 45 N
+    whole = pyflwdir.from_array(d8, ftype="d8", cache=False, latlon=True, transform=tr)
+    blocked = pyflwdir.from_array(d8, ftype="d8", cache=False, latlon=True, transform=tr)
+    exp_km2 = whole.upstream_area("km2")
+    monkeypatch.setenv("PFD_TEST_BIG_CELLS", "400000")
+    got_km2 = blocked.upstream_area("km2")
+    assert got_km2.dtype == exp_km2.dtype and np.array_equal(got_km2.view(np.uint64), exp_km2.view(np.uint64))
+
+
+@pytest.mark.parametrize("shape,seed,kw,nblocks,dtype", [
+    ((900, 700), 71, dict(tilt=100000, white=2, nodata_pct=20), 2, np.float32),   # all 8 directions: flow crosses both ways
+    ((1200, 800), 72, dict(tilt=1 << 26, white=2, nodata_pct=0), 3, np.float32),
+    ((2100, 1500), 73, dict(tilt=3000, white=2, nodata_pct=5), 5, np.float64),
+    ((1600, 900), 74, dict(tilt=1 << 26, white=2, nodata_pct=10), 8, np.float32),
+    ((64, 300), 75, dict(tilt=100000, white=2, nodata_pct=0), 8, np.float32),    # 8 rows per block
+    ((700, 900), 76, dict(tilt=100000, white=2, nodata_pct=10), 4, np.int32),
+    ((700, 900), 77, dict(tilt=100000, white=2, nodata_pct=10), 3, np.int64),
+])
+def test_accuflux_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblocks, dtype):
+    """accuflux (direction "up", reference pyflwdir/streams.py:15-41) of a raster split into 2-8 row blocks == the
+    oracle on the whole raster BIT FOR BIT, floats included: a boundary cell adds the halo cells draining into it in
+    the serial loop's position.  With a nodata value in the payload, and the all-cell local-equation check."""
+    from pyflwdir_amd import dist
+
+    O = oracle
+    d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    rng = np.random.default_rng(seed)
+    if np.dtype(dtype).kind == "f":
+        data = (rng.random(d8.size) * 3.7 + 1e-3).astype(dtype)
+    else:
+        data = rng.integers(0, 1000, d8.size).astype(dtype)
+    data[rng.random(d8.size) < 0.001] = -9999  # nodata cells poison nothing: the reference skips the addition
+    exp = O.accuflux(idxs_ds, seq, data, nodata=-9999)
+    got, rounds, bad = dist.accuflux_blocks(d8, nblocks, data, (-9999, -9999.0, 1), verify=True)
+    assert got.dtype == dtype and rounds >= 1 and bad == 0
+    assert np.array_equal(got.ravel().view(np.uint8), exp.view(np.uint8)), rounds
+    # one value per row (upstream_area in area units): float64 areas of a lat/lon grid
+    if dtype == np.float64:
+        rows = np.cos(np.linspace(-1.2, 1.2, shape[0])) * 1234.5
+        exp = O.accuflux(idxs_ds, seq, np.repeat(rows, shape[1]), nodata=-9999)
+        got, _, bad = dist.accuflux_blocks(d8, nblocks, rows, (-9999, -9999.0, 1), by_row=True, verify=True)
+        assert bad == 0 and np.array_equal(got.ravel().view(np.uint64), exp.view(np.uint64))
+
+
+@pytest.mark.parametrize("shape,seed,kw,nblocks", [
+    ((900, 700), 81, dict(tilt=100000, white=2, nodata_pct=20), 2),
+    ((1200, 800), 82, dict(tilt=1 << 26, white=2, nodata_pct=0), 3),
+    ((1600, 900), 83, dict(tilt=3000, white=2, nodata_pct=10), 8),
+    ((40, 300), 84, dict(tilt=100000, white=2, nodata_pct=0), 8),
+])
+def test_strahler_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblocks):
+    """Strahler order (reference pyflwdir/streams.py:228-269) over row blocks == the oracle, with and without a mask."""
+    from pyflwdir_amd import dist
+
+    O = oracle
+    d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    upa = O.upstream_area_cell(d8)[0].ravel()
+    for mask in (None, (upa > 5).astype(np.uint8)):
+        exp = O.strahler_order(idxs_ds, seq, mask)
+        got, rounds, bad = dist.strahler_blocks(d8, nblocks, mask, verify=True)
+        assert got.dtype == np.uint8 and bad == 0
+        assert np.array_equal(got.ravel(), exp), rounds
+
+
+def test_up_block_verifier_sees_a_wrong_cell(gpu_lib, oracle):
+    """The local-equation check of a blocked result is not vacuous: one changed own cell is reported (itself and the
+    cell it drains into)."""
+    from pyflwdir_amd import _hip, dist
+
+    O = oracle
+    d8 = O.synth_d8(500, 400, seed=91, tilt=100000, white=2, nodata_pct=5)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    data = np.random.default_rng(1).random(d8.size).astype(np.float32)
+    exp = O.accuflux(idxs_ds, O.idxs_seq(idxs_ds, idxs_pit), data, nodata=-9999).reshape(d8.shape)
+    a, e = dist.block_slice(500, 2, 1)
+    h = _hip.RasterHandle(d8[a:e], 500 - (a + 1), 400, halo=dist.halo_of(1, 2))
+    try:
+        out = np.ascontiguousarray(exp[a:e]).copy()
+        seed = np.concatenate([exp[a], np.zeros(400, np.float32)])
+        payload = np.ascontiguousarray(data.reshape(d8.shape)[a:e])
+        code = _hip._PAYLOAD_CODE[np.dtype(np.float32)]
+        assert h.accuflux_block(payload, code, seed, out, -9999, -9999.0, 1, verify=True)[1] == 0
+        r, c = np.argwhere((d8[a + 1:e] != 247) & (d8[a + 1:e] != 0))[1234]
+        out[r + 1, c] += np.float32(1.0)
+        assert h.accuflux_block(payload, code, seed, out, -9999, -9999.0, 1, verify=True)[1] == 2
+    finally:
+        h.close()

@@ -1,5 +1,6 @@
 """One rank of a 2+-process check of the collective entry points over the torch-free TCP group:
-DistributedRaster.upstream_area, .basins and .hand of a row block against the oracle on the whole raster.
+DistributedRaster.upstream_area, .basins, .hand, .accuflux and .stream_order of a row block against the oracle on the
+whole raster.
 Launched by tests/test_gpu_dist.py (all ranks on the one GPU of the test box, records through the host).
 
     RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tools/dist_check.py"""
@@ -38,6 +39,13 @@ drain = upa > np.percentile(upa[upa > 0], 97)
 exp_h = O.height_above_nearest_drain(idxs_ds, seq, drain.ravel(), elev.ravel()).reshape(shape)
 got_h, iters = dr.hand(drain[a:e], elev[a:e])
 assert np.array_equal(got_h.view(np.uint64), exp_h[r0:r1].view(np.uint64)), f"rank {rank}: hand differs"
+# collective float32 accuflux and Strahler order (seeded up-sweeps)
+data = (np.random.default_rng(7).random(shape) * 1.7).astype(np.float32)
+exp_a = O.accuflux(idxs_ds, seq, data.ravel(), nodata=-9999).reshape(shape)
+got_a, rounds = dr.accuflux(data[a:e], (-9999, -9999.0, 1))
+assert np.array_equal(got_a.view(np.uint32), exp_a[r0:r1].view(np.uint32)), f"rank {rank}: accuflux differs"
+got_s, _ = dr.stream_order()
+assert np.array_equal(got_s, O.strahler_order(idxs_ds, seq).reshape(shape)[r0:r1]), f"rank {rank}: stream order differs"
 dr.close()
 grp.barrier()
 grp.close()
