@@ -7,6 +7,9 @@ is compared cell by cell; beyond that the size-independent properties of the dom
        own invariant, tests/test_streams_basins.py:24-27) — on an acyclic raster these equations have one
        solution; the first rows against the oracle; and the 8-row-block run (the multi-GPU protocol, blocks
        held by this process) must produce the same checksum and pass the same checks block by block.
+ * C4 again, the order-sensitive sweeps (level engine, 32-bit cell addressing): three row blocks of 2.7 Gcells with
+       seeded halo rows — int32 accuflux of ones == the tiled engine's upstream area block by block, float32
+       accuflux of row areas and the Strahler order pass every own cell's local equation, first rows vs the oracle.
  * the uint32 rung of the index ladder (2^31 .. 2^32 cells, reference pyflwdir.py:105-127): idxs_ds /
    idxs_pit exports against the oracle on sampled row bands.
 """
@@ -142,6 +145,77 @@ def test_c4_90000_properties_and_blocks(gpu_lib, oracle):
     assert np.array_equal(up3[0].astype(np.int64), exp)
     for hh in handles:
         hh.close()
+
+
+def test_c4_90000_order_sensitive_sweeps_in_row_blocks(gpu_lib, oracle):
+    """Float accuflux, area-unit upstream_area and the Strahler order at 8.1 Gcells: beyond 2^32 - 2 cells the level
+    engine cannot address the raster, so it is cut into row blocks whose halo cells carry the neighbours' values
+    (pfd_accuflux_block / pfd_strahler_block, pyflwdir_amd/dist.py).  Checked here with everything device-resident:
+      * int32 accuflux of ones over the blocks == upstream_area("cell") of the tiled engine on the whole raster
+        (independent engines; checksum of every block's rows);
+      * float32 accuflux of one value per row (what upstream_area("ha") sums on a projected grid) and the Strahler
+        order: the iteration reaches its fixpoint and EVERY own cell satisfies its local equation bit for bit against
+        the values in place (halo rows = the neighbours' final rows) — on an acyclic raster these equations have
+        one solution; the first 1200 rows against the oracle."""
+    from pyflwdir_amd import _hip
+    from pyflwdir_amd import dist as pdist
+
+    size, nblocks = 90000, 3
+    rows_of = pdist.block_rows(size, nblocks)
+    d8_buf = _hip.synth_d8_device(size, size, **RIVER)
+    out = _hip.DeviceBuffer(size * size * 4)
+    h = _hip.RasterHandle(d8_buf, size, size, memspace=_hip.PFD_DEVICE, deferred=True)
+    h.upstream_area_cell(out=out, memspace=_hip.PFD_DEVICE)
+    whole = [_hip.checksum_i32(out.addr + r0 * size * 4, (r1 - r0) * size) for r0, r1 in rows_of]
+    h.close()
+    out.free()
+    top_rows = 1200
+    d8_top = d8_buf.download(np.uint8, (top_rows + 1, size))
+    assert not np.isin(d8_top[top_rows], (32, 64, 128)).any()  # nothing below drains up into the first rows
+    d8_buf.free()
+    idxs_ds, idxs_pit, _ = oracle.from_array(d8_top[:top_rows])
+    seq = oracle.idxs_seq(idxs_ds, idxs_pit)
+    handles, bufs = [], []
+    for b, (r0, r1) in enumerate(rows_of):
+        top, bot = pdist.halo_of(b, nblocks)
+        assert ((r1 - r0) + top + bot) * size <= 4294967294
+        bufs.append(_hip.synth_d8_device(size, size, row0=r0 - top, nrows=(r1 - r0) + top + bot, **RIVER))
+        handles.append(_hip.RasterHandle(bufs[-1], r1 - r0, size, memspace=_hip.PFD_DEVICE, halo=(top, bot)))
+
+    def run(kind, dtype, row_values=None):
+        blocks = []
+        try:
+            for b, hh in enumerate(handles):
+                a, e = pdist.block_slice(size, nblocks, b)
+                blocks.append(pdist._UpBlock(hh, kind, dtype, payload=None if row_values is None else row_values[a:e],
+                                             by_row=True, nodata=(-9999, -9999.0, 1)))
+            rounds, bad = pdist._up_blocks_run(blocks, size, dtype, verify=True)
+            sums = None
+            if dtype == np.int32:
+                sums = [_hip.checksum_i32(blk.out.addr + hh.halo[0] * size * 4, hh.nrow * size)
+                        for blk, hh in zip(blocks, handles)]
+            first = blocks[0].out.download(dtype, (top_rows, size))
+            return rounds, bad, sums, first
+        finally:
+            for blk in blocks:
+                blk.close(close_handle=False)
+
+    try:
+        rounds, bad, sums, first = run("accuflux", np.int32, np.ones(size, np.int32))
+        assert bad == 0 and rounds >= 2 and sums == whole
+        areas = (np.cos(np.linspace(-0.9, 0.9, size)) * 0.81).astype(np.float32)  # "hectares" per cell of a row
+        rounds, bad, _, first = run("accuflux", np.float32, areas)
+        assert bad == 0 and rounds >= 2
+        exp = oracle.accuflux(idxs_ds, seq, np.repeat(areas[:top_rows], size), nodata=-9999)
+        assert np.array_equal(first.ravel().view(np.uint32), exp.view(np.uint32))
+        rounds, bad, _, first = run("strahler", np.uint8)
+        assert bad == 0 and rounds >= 2
+        assert np.array_equal(first.ravel(), oracle.strahler_order(idxs_ds, seq))
+    finally:
+        for hh in handles:
+            hh.close()
+        for bb in bufs:
+            bb.free()
 
 
 def test_uint32_index_rung(gpu_lib, oracle):
