@@ -18,7 +18,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STEP_KERNELS = ("k_tile", "k_super", "k_link3", "k_link4", "k_hyper", "k_push3", "k_push4", "k_coarse_round",
+STEP_KERNELS = ("k_tile", "k_exit_lists", "k_super", "k_link3", "k_link4", "k_hyper", "k_push3", "k_push4", "k_coarse_round",
                 "k_check_saturated", "fillBuffer")
 # kernels of one warm call, by a substring of their (templated) names; calls per bench.py --ops run = steps + 1
 OPS = {"accuflux_f32_up": ("AccuUp<float",), "strahler": ("Strahler",), "hand_f32": ("Hand<float",),
