@@ -609,10 +609,11 @@ def rank_environments(n, n_devices, port, base_env=None):
     return envs
 
 
-def spawn_ranks(a, argv=None, n_devices=None, timeout=3000.0, script=None):
+def spawn_ranks(a, argv=None, n_devices=None, timeout=3000.0, script=None, extra_env=None, out=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks as plain processes (one per GPU), pass rank
-    0's JSON line through on stdout, return the first non-zero exit code.  A rank that dies takes the others down
-    (each child is killed by its own PID) instead of leaving them waiting in a collective."""
+    0's JSON line through on stdout (or write it to the file object ``out``), return the first non-zero exit code.
+    A rank that dies takes the others down (each child is killed by its own PID) instead of leaving them waiting in a
+    collective."""
     import subprocess
 
     n_devices = _hip.device_count() if n_devices is None else n_devices
@@ -622,9 +623,10 @@ def spawn_ranks(a, argv=None, n_devices=None, timeout=3000.0, script=None):
     envs = rank_environments(a.gpus, n_devices, free_port())
     procs = []
     for r, e in enumerate(envs):
+        e.update(extra_env or {})
         # rank 0 owns stdout (the one JSON line); whatever another rank prints goes to stderr
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=e,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=out if r == 0 else sys.stderr))
     deadline = time.time() + timeout
     rc = 0
     live = list(procs)
@@ -650,6 +652,33 @@ def spawn_ranks(a, argv=None, n_devices=None, timeout=3000.0, script=None):
     return rc
 
 
+def spawn_with_fallback(a, spawn=spawn_ranks, first_timeout=900.0):
+    """The self-spawned N-GPU run, made robust for its first contact with real multi-GPU hardware: rank 0's line is
+    collected in a file and only printed once the attempt has succeeded; if the attempt with the automatic transport
+    (RCCL all-gather over xGMI) fails or does not finish in `first_timeout` seconds, the same job runs once more with
+    the boundary records travelling through the host group (PFD_DIST_TRANSPORT=host; the line says which transport
+    ran).  An explicitly chosen transport is not second-guessed."""
+    import tempfile
+
+    attempts = [({}, first_timeout)]
+    if not os.environ.get("PFD_DIST_TRANSPORT"):
+        attempts.append((dict(PFD_DIST_TRANSPORT="host", PFD_BENCH_RETRY="1"), 3000.0))
+    rc = 1
+    for extra, tmo in attempts:
+        with tempfile.TemporaryFile(mode="w+") as f:
+            rc = spawn(a, timeout=tmo, extra_env=extra, out=f)
+            f.seek(0)
+            text = f.read()
+        if rc == 0 and text.strip():
+            sys.stdout.write(text)
+            sys.stdout.flush()
+            return 0
+        print(f"bench.py: the {a.gpus}-rank run failed (exit code {rc})"
+              + ("; retrying with the host transport" if extra == {} and len(attempts) > 1 else ""), file=sys.stderr)
+        rc = rc or 1
+    return rc
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -659,7 +688,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if a.gpus > 1 and world == 1:
         # no launcher (this is how the driver calls it): bench.py starts its own ranks
-        raise SystemExit(spawn_ranks(a))
+        raise SystemExit(spawn_with_fallback(a))
     if world > 1 or os.environ.get("PFD_BENCH_FORCE_DIST"):  # the env knob runs the RCCL path with 1 rank
         return run_distributed(a, rank, world, local)
     device = local

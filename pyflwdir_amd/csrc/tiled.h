@@ -50,6 +50,7 @@ struct SuperArgs {
   uint16_t *xl_slot;          // [nslots] slot of the e-th exit of the supertile (local: 14 bits)
   uint16_t *xl_next;          // [nslots] list index of the exit its flow reaches next inside the supertile | SDONE
   u32 *scount;                // [nst] exits of the supertile
+  u32 *nflag, *flagged;       // supertiles with more exits than scap (contrived rasters): count, list
   u32 *xin;         // [nslots] flow entering the supertile at this exit (from other supertiles)
   u32 *R2;          // [nslots] last exit (slot) of the exit's path inside its supertile
   u32 *sxid;        // [nslots] dense id of a super-exit (drains into another supertile), else NONE32
@@ -240,7 +241,7 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (7 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf, xmaskbuf, xlbuf, scountbuf;
+  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf, xmaskbuf, xlbuf, scountbuf, flaggedbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;

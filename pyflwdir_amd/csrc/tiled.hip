@@ -652,6 +652,7 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
     const u32 n = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     s.scount[st] = n;
     s.sover[st] = n > s.scap ? 1 : 0;  // more exits than the LDS form of the solve keeps: the full-size form takes it
+    if (n > s.scap) s.flagged[atomicAdd(s.nflag, 1u)] = st;
   }
   __syncthreads();
   auto dense = [&](u32 i) -> u32 { return cbase[i >> 6] + (u32)__popcll(maskw[i >> 6] & ((1ull << (i & 63u)) - 1ull)); };
@@ -680,14 +681,13 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
 // rasters only; same code.
 #define SCAP 12288u
 template <bool FINAL, u32 CAP>
-__global__ void __launch_bounds__(1024, CAP == SCAP ? 8 : 4) k_super(SuperArgs s) {
+__device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
   __shared__ u32 T[CAP];
   __shared__ uint16_t P[CAP];
   __shared__ u32 wtot[16];
   __shared__ __attribute__((aligned(16))) u32 s_flag[2][16];
   __shared__ u32 s_base;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const u32 st = blockIdx.x;
   const u32 base = st << SSHIFT;
   constexpr int DPT = CAP / 1024;  // exits per thread
   if (FINAL && s.edge_nstr) {
@@ -696,7 +696,6 @@ __global__ void __launch_bounds__(1024, CAP == SCAP ? 8 : 4) k_super(SuperArgs s
     const u32 row = st / s.nstc;
     if (row != 0 && row != (s.ntr - 1) / SG && row != (s.ntr >= 2 ? (s.ntr - 2) / SG : 0u)) return;
   }
-  if ((s.sover[st] != 0) != (CAP != SCAP)) return;  // (the other form's supertile)
   const u32 n = s.scount[st];
   // ---- the exits: list entry -> slot, then start value and next hop; all loads of a step are independent ----
   u32 sxbits = 0;  // bit k: own exit k (tid + 1024 k) drains into another supertile
@@ -822,6 +821,23 @@ __global__ void __launch_bounds__(1024, CAP == SCAP ? 8 : 4) k_super(SuperArgs s
     // (masked: on a cycle the pointer is not saturated and its word no root; the pass is discarded then)
     s.R2[g] = base + (T[min(P[e] & (SDONE - 1u), CAP - 1u)] & (SSL - 1));
     s.sxid[g] = id[k];
+  }
+}
+
+template <bool FINAL>
+__global__ void __launch_bounds__(1024, 8) k_super(SuperArgs s) {
+  if (s.sover[blockIdx.x]) return;  // (more exits than SCAP: k_super_flagged takes it)
+  super_solve<FINAL, SCAP>(s, blockIdx.x);
+}
+// the supertiles k_exit_lists flagged (contrived rasters only: normally none, and a grid of this 96 KB kernel over all
+// supertiles costs 60-90 us just to find that out): a small fixed grid walks their list
+#define SFLAG_GRID 64u
+template <bool FINAL>
+__global__ void __launch_bounds__(1024, 4) k_super_flagged(SuperArgs s) {
+  const u32 nf = *s.nflag;
+  for (u32 f = blockIdx.x; f < nf; f += gridDim.x) {
+    super_solve<FINAL, SSL>(s, s.flagged[f]);
+    __syncthreads();  // (the LDS image is reused)
   }
 }
 
@@ -1207,11 +1223,11 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, hcntbuf.as<u32>(), nht, nullptr, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, nullptr, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
-  sa = SuperArgs{nst, xT, xtgt, elink, nullptr, nullptr, nullptr, nullptr, xin, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
+  sa = SuperArgs{nst, xT, xtgt, elink, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xin, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
                  hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP, nullptr, SCAP};
   PFDCHK(soverbuf.alloc((size_t)nst));
   sa.sover = soverbuf.as<u8>();
-  PFDCHK(xmaskbuf.alloc(nslots / 64 * sizeof(u64)));
+  PFDCHK(xmaskbuf.alloc(nslots / 64 * sizeof(u64) + 8));  // (+ the count of flagged supertiles: one memset clears both)
   PFDCHK(xlbuf.alloc(2 * nslots * sizeof(uint16_t)));
   PFDCHK(scountbuf.alloc((size_t)nst * sizeof(u32)));
   a.xmask = xmaskbuf.as<u64>();
@@ -1219,6 +1235,9 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   sa.xl_slot = xlbuf.as<uint16_t>();
   sa.xl_next = xlbuf.as<uint16_t>() + nslots;
   sa.scount = scountbuf.as<u32>();
+  sa.nflag = (u32 *)(xmaskbuf.as<u64>() + nslots / 64);
+  PFDCHK(flaggedbuf.alloc((size_t)nst * sizeof(u32)));
+  sa.flagged = flaggedbuf.as<u32>();
   if (const char *e = pfd_knob("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
   if (const char *e = pfd_knob("PFD_TEST_SCAP")) sa.scap = (u32)std::min<u32>((u32)atoi(e), SCAP);
   a.stamps = nullptr;
@@ -1323,8 +1342,8 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   sa.T3 = Tc;
   // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
   sa.hmode = (nht > 1 && !force_flat && !pfd_knob("PFD_FLAT_L3")) ? 1 : 0;
-  k_super<false, SCAP><<<nst, 1024, 0, h->stream>>>(sa);
-  k_super<false, SSL><<<nst, 1024, 0, h->stream>>>(sa);  // (only the supertiles k_exit_lists flagged: normally none)
+  k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super_flagged<false><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);  // (normally none)
   KCHK();
   *launches += 2;
   if (!sa.hmode) {  // the flat level-3 rounds are sized by the number of super-exits
@@ -1339,8 +1358,8 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
     PFDCHK(level3_hyper(launches));
   else if (nsuper)
     PFDCHK(level3_flat(launches));
-  k_super<true, SCAP><<<nst, 1024, 0, h->stream>>>(sa);
-  k_super<true, SSL><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super_flagged<true><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);
   *launches += 2;
   KCHK();
   return PFD_OK;
@@ -1362,7 +1381,7 @@ int TiledRun::phase_a() {
   }
   if (is_block) HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));  // read by the final tile pass
   // exit bitmasks: tiles beyond the raster edge of a partial supertile write none (8 bytes per 64 slots)
-  HIPCHK(hipMemsetAsync(a.xmask, 0, nslots / 64 * sizeof(u64), h->stream));
+  HIPCHK(hipMemsetAsync(a.xmask, 0, nslots / 64 * sizeof(u64) + 8, h->stream));
   // interior tiles: k_tile_local_fast; the frame around them (raster edge, halo and boundary rows): k_tile
   const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
   const bool have_i = gridi.x && gridi.y;
@@ -1453,6 +1472,8 @@ int TiledRun::phase_b(int *complete) {
     pfd_seg_end(h, 1);
     pfd_seg_begin(h, "tile_final_frame");
   }
+  // (tried: the frame kernels on a side stream under the interior ones — the fork / join costs what the overlap
+  //  saves: 5.132 vs 5.135 ms at 30000^2, 3.05 vs 2.95 ms for phase A of an 11250 x 90000 row block)
   k_tile<true><<<frame_tiles(ntr, ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi), 256, 0, h->stream>>>(a);
   KCHK();
   pfd_seg_end(h, 1);

@@ -89,3 +89,29 @@ def test_plain_call_does_not_ask_for_a_launcher():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          timeout=120)
     assert out.returncode != 0 and "no HIP device" in out.stderr and "torch.distributed.run" not in out.stderr
+
+
+def test_spawn_falls_back_to_the_host_transport(tmp_path, capfd, monkeypatch):
+    """First contact with real multi-GPU hardware: if the run with the automatic transport (RCCL) fails, the same job
+    runs once more with PFD_DIST_TRANSPORT=host, and only the successful attempt's line reaches stdout."""
+    import functools
+
+    b = _bench()
+    monkeypatch.delenv("PFD_DIST_TRANSPORT", raising=False)
+    script = _script(tmp_path, """
+        import os, sys
+        if os.environ["RANK"] == "0":
+            print("line of rank 0 with transport", os.environ.get("PFD_DIST_TRANSPORT", "auto"), flush=True)
+        if os.environ.get("PFD_DIST_TRANSPORT") != "host":
+            sys.exit(3)  # (after rank 0 has printed: that line must not get out)
+        """)
+    spawn = functools.partial(b.spawn_ranks, argv=[], n_devices=2, script=script)
+    rc = b.spawn_with_fallback(types.SimpleNamespace(gpus=2), spawn=spawn, first_timeout=60)
+    out, err = capfd.readouterr()
+    assert rc == 0 and out.strip() == "line of rank 0 with transport host"
+    assert "retrying with the host transport" in err
+    # an explicitly chosen transport is not second-guessed
+    monkeypatch.setenv("PFD_DIST_TRANSPORT", "rccl")
+    rc = b.spawn_with_fallback(types.SimpleNamespace(gpus=2), spawn=spawn, first_timeout=60)
+    out, _ = capfd.readouterr()
+    assert rc == 3 and out.strip() == ""

@@ -1,8 +1,8 @@
 """In-process multi-block timing on ONE GPU (the phases of the multi-GPU protocol, serially).
 
     python tools/bench_blocks.py ROWS_PER_BLOCK NBLOCKS [NCOL]      (NCOL defaults to ROWS_PER_BLOCK)"""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyflwdir_amd import _hip, dist
 L = _hip.lib()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
