@@ -10,6 +10,10 @@ What can run without a GPU is the host side of the multi-GPU path and the PROTOC
    oracle as the per-block solver and dist.all_gather as the transport.  Its result must equal
    the oracle on the whole raster.  (The same protocol with the HIP kernels is tested on the GPU
    box in tests/test_gpu_blocks.py.)
+ * the seeded up-sweep protocol (float accuflux over row blocks): the real collective driver
+   DistributedRaster._up_collective — agreement, seed routing, termination at the fixpoint — around a numpy block
+   sweep that adds the halo cells draining into a boundary cell in the serial loop's position; bit-identical
+   float32 sums against the oracle on the whole raster.
 """
 import os
 import sys
@@ -135,6 +139,91 @@ def _worker(rank, world, port, tmpdir):
             res = np.where(blk[top:top + (r1 - r0)] == 247, -9999, acc1).astype(np.int32)
             exp = O.upstream_area_cell(d8)[0][r0:r1]
             assert np.array_equal(res, exp), f"rank {rank}: block protocol differs from the oracle"
+        # 2b) seeded up-sweeps: the collective driver of pyflwdir_amd/dist.py around a numpy block sweep
+        import types
+
+        DR = {1: (0, 1), 2: (1, 1), 4: (1, 0), 8: (1, -1), 16: (0, -1), 32: (-1, -1), 64: (-1, 0), 128: (-1, 1)}
+
+        class NumpyUpBlock:
+            """float32 accuflux of one row block; its halo cells hold the seeds (same interface as dist._UpBlock)."""
+
+            def __init__(self, blk, top, nown, data):
+                self.blk, self.top, self.nown, self.data = blk, top, nown, data
+                self.nr, self.nc = blk.shape
+                self.out = data.copy()
+                self.swept_with = self.brows = None
+                own = lambda r: top <= r < top + nown
+                self.kids = {}   # own cell -> upstream cells (own cells and halo cells), descending linear index
+                self.ds = {}
+                for r in range(self.nr):
+                    for c in range(self.nc):
+                        code = int(blk[r, c])
+                        if code not in DR:
+                            continue
+                        rr, cc = r + DR[code][0], c + DR[code][1]
+                        if 0 <= rr < self.nr and 0 <= cc < self.nc and own(rr) and blk[rr, cc] != 247:
+                            self.kids.setdefault((rr, cc), []).append((r, c))
+                            if own(r):
+                                self.ds[(r, c)] = (rr, cc)
+                for k in self.kids.values():
+                    k.sort(reverse=True)
+                # own cells, upstream cells first (Kahn over the links between own cells)
+                indeg = {}
+                for x, d in self.ds.items():
+                    indeg[d] = indeg.get(d, 0) + 1
+                cells = [(r, c) for r in range(top, top + nown) for c in range(self.nc) if blk[r, c] != 247]
+                stack = [x for x in cells if indeg.get(x, 0) == 0]
+                self.order = []
+                while stack:
+                    x = stack.pop()
+                    self.order.append(x)
+                    d = self.ds.get(x)
+                    if d is not None:
+                        indeg[d] -= 1
+                        if indeg[d] == 0:
+                            stack.append(d)
+                assert len(self.order) == len(cells)
+
+            def sweep(self, seed):
+                bits = seed.view(np.uint8)
+                if self.swept_with is not None and np.array_equal(self.swept_with, bits):
+                    return False
+                self.swept_with = bits.copy()
+                out = self.data.copy()
+                if self.top:
+                    out[self.top - 1] = seed[:self.nc]
+                if self.top + self.nown < self.nr:
+                    out[self.top + self.nown] = seed[self.nc:]
+                for x in self.order:
+                    acc = self.data[x]
+                    for k in self.kids.get(x, ()):
+                        if acc != np.float32(-9999) and out[k] != np.float32(-9999):
+                            acc = np.float32(acc + out[k])
+                    out[x] = acc
+                self.out = out
+                self.brows = np.stack([out[self.top], out[self.top + self.nown - 1]])
+                return True
+
+            def result(self):
+                return self.out[self.top:self.top + self.nown]
+
+            def close(self, close_handle=True):
+                pass
+
+        for shape, seed, kw in [((64, 75), 31, dict(tilt=100000, white=2, nodata_pct=10)),
+                                ((40, 90), 32, dict(tilt=3000, white=2, nodata_pct=0))]:
+            d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+            idxs_ds, idxs_pit, _ = O.from_array(d8)
+            data = (np.random.default_rng(seed).random(shape) * 3).astype(np.float32)
+            data[5, 7] = -9999
+            exp = O.accuflux(idxs_ds, O.idxs_seq(idxs_ds, idxs_pit), data.ravel(), nodata=-9999).reshape(shape)
+            r0, r1 = pdist.block_rows(shape[0], world)[rank]
+            a, e = pdist.block_slice(shape[0], world, rank)
+            dr = object.__new__(pdist.DistributedRaster)
+            dr.group, dr.rank, dr.world, dr.handle = grp, rank, world, types.SimpleNamespace(ncol=shape[1])
+            got, rounds = dr._up_collective(lambda: NumpyUpBlock(d8[a:e], pdist.halo_of(rank, world)[0], r1 - r0, data[a:e]),
+                                            np.float32)
+            assert rounds >= 1 and np.array_equal(got.view(np.uint32), exp[r0:r1].view(np.uint32)), f"rank {rank}: seeded up-sweep"
         # 3) bench-style timing reduction: MAX over ranks
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
