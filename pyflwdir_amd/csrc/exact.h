@@ -43,7 +43,7 @@ struct ExactPlan {
   u32 ntr = 0, ntc = 0;
   u8 *lh = nullptr;       // [n] leaf step (0..XCAP), XL_TRUNK, XL_NODATA
   u8 *kids = nullptr;     // [n] mask of the neighbour slots draining into the cell
-  uint16_t *tord = nullptr;  // [ntiles * 4096] leaf cells of the tile (local index), ordered by step
+  uint16_t *tord = nullptr;  // [ntiles * 4096] leaf cells of the tile, ordered by step: local index | downstream slot << 12 | pit << 15
   uint16_t *toff = nullptr;  // [ntiles * XOFF] start of step s in tord; entries past the last step = total
   u32 *scell = nullptr;   // [nslot]
   uint16_t *sinfo = nullptr;  // [nslot]

@@ -129,7 +129,15 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
       lh[g] = (u8)cnt[l];
       kids_out[g] = (u8)mykids[j];
     }
-    tord[tile * XTC + l] = l < total ? ord[l] : (uint16_t)0;
+    // entry = the leaf's cell (12 bits) | slot of its downstream cell << 12 | "is a pit" << 15: the down-sweep of a
+    // tile then needs no code lookup per leaf (k_xtile_down)
+    uint16_t ent = 0;
+    if (l < total) {
+      const u32 x = ord[l];
+      const u32 c = CODE((int)(x >> 6), (int)(x & 63u));
+      ent = (uint16_t)(x | (d8_is_dir(c) ? (u32)d8_slot(c) << 12 : 0x8000u));
+    }
+    tord[tile * XTC + l] = ent;
   }
   if (tid < XOFF) toff[tile * XOFF + tid] = off[tid];
 }

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_xtile_up(Op op, XTileArgs a) {
     const u32 b = off[s], e = off[s + 1];
     if (b >= total) break;
     for (u32 j = b + tid; j < e; j += 256u) {
-      const u32 x = ord[j];
+      const u32 x = ord[j] & 0xFFFu;  // (the upper bits serve the down-sweep)
       val[x] = op.tile_combine(x, (u32)K[x], val);
     }
     __syncthreads();
@@ -645,6 +645,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   }
   __syncthreads();  // (F is cleared)
   u32 mycodes[4];
+  auto general_init = [&](u32 (&mycodes)[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const u32 l0 = 4u * tid + 1024u * j;
@@ -691,25 +692,84 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     }
     if (Op::DTILE_FLAG && fl) atomicOr(&F[l0 >> 5], fl << (l0 & 31u));
   }
-  const u32 total = off[XOFF - 1];
+  };
+  if constexpr (Op::DTILE4) {
+    // quads inside the raster: three load phases (codes + leaf steps; everything that depends on them, unconditionally;
+    // the final values of quads holding a trunk cell), each with the loads of all four quads in flight together
+    if (r0 + XT <= (i64)a.nrow && c0 + XT <= (i64)a.ncol) {
+      u32 c4s[4], l4s[4];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const u32 i = tid + 256u * j;
-    u32 w = 0;
-    if (i < total) {
-      const u32 x = a.tord[tile * XTC + i];
-      const int lr = x >> 6, lc = x & 63;
-      const u32 code = a.ncode[(size_t)(r0 + lr) * a.ncol + (size_t)(c0 + lc)];  // (a line this tile just read)
-      const bool root = !d8_is_dir(code);
-      int pr = lr, pc = lc;
-      if (!root) {
-        const int k = d8_slot(code);
-        pr += d8_dr(k);
-        pc += d8_dc(k);
+      for (int j = 0; j < 4; ++j) {
+        const u32 l0 = 4u * tid + 1024u * j;
+        const u32 g0 = (u32)((r0 + (l0 >> 6)) * (i64)a.ncol + c0 + (l0 & 63));
+        __builtin_memcpy(&c4s[j], a.ncode + g0, 4);
+        l4s[j] = XL_TRUNK * 0x01010101u;
+        if (INPL) __builtin_memcpy(&l4s[j], a.lh + g0, 4);
       }
-      w = x | ((u32)((pr + 1) * XHW + pc + 1) << 12) | (root ? 1u << 25 : 0u);
+      typename Op::DQuad dq[4];
+      V vq[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 l0 = 4u * tid + 1024u * j;
+        const u32 g0 = (u32)((r0 + (l0 >> 6)) * (i64)a.ncol + c0 + (l0 & 63));
+        op.dtile4_load(g0, c4s[j], dq[j]);
+        bool trunk = !INPL;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          vq[j][b] = V();
+          trunk |= ((l4s[j] >> (8 * b)) & 0xFFu) == XL_TRUNK;
+        }
+        if (trunk) op.top4(g0, vq[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 l0 = 4u * tid + 1024u * j;
+        const int lr = l0 >> 6, lc = l0 & 63;
+        const u32 c4 = c4s[j], l4 = l4s[j];
+        mycodes[j] = c4;
+        u32 fl = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const u32 code = (c4 >> (8 * b)) & 0xFFu;
+          const bool leaf = ((l4 >> (8 * b)) & 0xFFu) <= (u32)XCAP;
+          Elem e = Elem();
+          bool f = false;
+          if (code != D8_MV && (!INPL || leaf)) e = op.dtile4_get(dq[j], b, f);
+          fl |= f ? 1u << b : 0u;
+          V v = vq[j][b];
+          if (INPL) {
+            if (leaf) __builtin_memcpy(&v, &e, sizeof(V));  // (Elem is V)
+          } else {
+            De[l0 + b] = e;
+          }
+          val[(lr + 1) * XHW + lc + b + 1] = v;
+        }
+        if (Op::DTILE_FLAG && fl) atomicOr(&F[l0 >> 5], fl << (l0 & 31u));
+      }
+    } else {
+      general_init(mycodes);
     }
-    ord[i] = w;
+  } else {
+    general_init(mycodes);
+  }
+  const u32 total = off[XOFF - 1];
+  {
+    uint2 o4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_memcpy(&o4[j], a.tord + tile * XTC + 4u * tid + 1024u * j, 8);  // (zeros past `total`)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 e4[4] = {o4[j].x & 0xFFFFu, o4[j].x >> 16, o4[j].y & 0xFFFFu, o4[j].y >> 16};
+      u32 w4[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const u32 x = e4[b] & 0xFFFu, root = e4[b] >> 15;
+        const int k = (int)((e4[b] >> 12) & 7u);
+        const int pr = (int)(x >> 6) + (root ? 0 : d8_dr(k)), pc = (int)(x & 63u) + (root ? 0 : d8_dc(k));
+        w4[b] = x | ((u32)((pr + 1) * XHW + pc + 1) << 12) | (root << 25);
+      }
+      *(uint4 *)&ord[4u * tid + 1024u * j] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
   }
   __syncthreads();
   int last = 0;

@@ -500,6 +500,7 @@ struct AccuDown {
   // tile image of the element (exact_sweep.h, k_xtile_down): the element itself, no flag
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
+  static constexpr bool DTILE4 = false;
   __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
   __device__ __forceinline__ T dtroot(DElem e, bool) const { return droot(e); }
   __device__ __forceinline__ T dtfold(DElem e, bool, T pv) const { return dfold(e, pv); }
@@ -737,6 +738,23 @@ struct Hand {
   // (already widened: the tile image of a leaf then has the type of the result and lives in the result's LDS word)
   typedef double DTile;
   static constexpr bool DTILE_FLAG = true;
+  // the same for a whole quad inside the raster, loads only — unconditional, so that k_xtile_down has the loads of all
+  // its 16 cells in flight at once (a load inside a per-cell branch is waited for on the spot: 32 round trips)
+  static constexpr bool DTILE4 = true;
+  struct DQuad {
+    u32 d4;
+    E ev[4], dn[4];
+  };
+  __device__ __forceinline__ void dtile4_load(u32 x0, u32 c4, DQuad &q) const {
+    __builtin_memcpy(&q.d4, drain + x0, 4);
+    __builtin_memcpy(q.ev, elev + x0, 4 * sizeof(E));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) q.dn[b] = elev[d8_down(g, x0 + b, (c4 >> (8 * b)) & 0xFFu)];  // (itself unless a direction)
+  }
+  __device__ __forceinline__ double dtile4_get(const DQuad &q, int b, bool &is_drain) const {
+    is_drain = ((q.d4 >> (8 * b)) & 0xFFu) == 1u;
+    return (double)(E)(q.ev[b] - q.dn[b]);
+  }
   __device__ __forceinline__ double dtile(u32 x, u32 code, bool &is_drain) const {
     is_drain = drain[x] == 1;
     return (double)(E)(elev[x] - elev[d8_down(g, x, code)]);
@@ -778,6 +796,7 @@ struct Flood {
   };
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
+  static constexpr bool DTILE4 = false;
   static constexpr bool FAST = false;
   __device__ __forceinline__ FloodV top(u32 p) const { return state[p]; }
   __device__ __forceinline__ void top4(u32 x0, FloodV (&v)[4]) const {
@@ -1656,6 +1675,7 @@ struct Classic {
   // tile image of the element (exact_sweep.h, k_xtile_down): the element itself, no flag
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
+  static constexpr bool DTILE4 = false;
   __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
   __device__ __forceinline__ u32 dtroot(DElem e, bool) const { return droot(e); }
   __device__ __forceinline__ u32 dtfold(DElem e, bool, u32 pv) const { return dfold(e, pv); }
@@ -1709,6 +1729,7 @@ struct Dist {
   // tile image of the element (exact_sweep.h, k_xtile_down): the element itself, no flag
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
+  static constexpr bool DTILE4 = false;
   __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
   __device__ __forceinline__ T dtroot(DElem e, bool) const { return droot(e); }
   __device__ __forceinline__ T dtfold(DElem e, bool, T pv) const { return dfold(e, pv); }
