@@ -375,8 +375,9 @@ __global__ void __launch_bounds__(256) k_xtrunk_dpre(Op op, const u32 *__restric
                                                      u32 s0, u32 s1, typename Op::DElem *__restrict__ E) {
   const u32 s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= s1) return;
-  if (sinfo[s] & XS_POST) return;
-  const u32 x = scell[s];
+  const u32 info = sinfo[s];
+  const u32 x = scell[s];  // (a post slot names the light upstream cell: a valid cell as well)
+  if (info & XS_POST) return;
   E[s] = op.dpre(x, (u32)ncode[x]);
 }
 
@@ -595,8 +596,10 @@ __global__ void __launch_bounds__(256) k_xtrunk_dscatter(Op op, const u32 *__res
                                                          const typename Op::V *__restrict__ R) {
   const u32 s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= s1) return;
-  if (sinfo[s] & XS_POST) return;
-  op.store(scell[s], R[s]);
+  const u32 info = sinfo[s];  // (three independent loads, then the decision)
+  const u32 x = scell[s];
+  const typename Op::V v = R[s];
+  if (!(info & XS_POST)) op.store(x, v);
 }
 
 // ---- leaves, down -------------------------------------------------------------------------------
