@@ -29,7 +29,9 @@
 
 #define XT 64            // tile edge
 #define XTC (XT * XT)    // 4096 cells
+#ifndef XCAP
 #define XCAP 30          // highest leaf step; toff holds XCAP + 2 = 32 u16 per tile
+#endif
 #define XOFF (XCAP + 2)
 #define XL_TRUNK 255u    // lh[] marks
 #define XL_NODATA 254u
