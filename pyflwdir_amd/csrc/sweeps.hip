@@ -500,7 +500,12 @@ struct AccuDown {
   // tile image of the element (exact_sweep.h, k_xtile_down): the element itself, no flag
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
-  static constexpr bool DTILE4 = false;
+  static constexpr bool DTILE4 = true;  // (quad form, loads only: see Hand)
+  struct DQuad {
+    T d[4];
+  };
+  __device__ __forceinline__ void dtile4_load(u32 x0, u32, DQuad &q) const { data.load4(x0, q.d); }
+  __device__ __forceinline__ T dtile4_get(const DQuad &q, int b, bool &) const { return q.d[b]; }
   __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
   __device__ __forceinline__ T dtroot(DElem e, bool) const { return droot(e); }
   __device__ __forceinline__ T dtfold(DElem e, bool, T pv) const { return dfold(e, pv); }
