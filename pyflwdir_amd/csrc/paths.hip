@@ -38,7 +38,7 @@ struct PathArgs {
   u32 *xtgt;        // [nslots] slot the exit on this slot drains into, NONE32 if no exit
   u32 *elink;       // [nslots] entry: slot of the exit its in-tile path reaches, NONE32 if it ends in the tile
   u32 *eval;        // [nslots] entry: hops to the end of its in-tile path (rank) / outlet met there (label)
-  const u32 *xres;  // [nslots] pass 2: rank of the exit cell / outlet the exit finally reaches
+  const u64 *xres;  // [nslots] pass 2: low word = rank of the exit cell / outlet the exit finally reaches
   const u32 *seed;  // [n] label mode: outlet number (1-based) seeded on the cell, 0 = none
   u32 *out;         // [n] pass 2: rank (KEY_INVALID on nodata) / outlet number per cell
   u64 *ctrl;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
       int plr, plc;
       pslot_inv((int)tid, &plr, &plc);
       const u32 l = (u32)(plr * TS + plc);
-      if (exit_slot_of(l) != NONE32) V[l] = a.xres[sbase + tid];
+      if (exit_slot_of(l) != NONE32) V[l] = (u32)a.xres[sbase + tid];
     }
     __syncthreads();
     u32 mx = 0;
@@ -258,10 +258,17 @@ __device__ __forceinline__ void flag_active_p(u64 *ctrl) {
   }
 }
 
+// The exit graph of a path query: per perimeter slot ONE 64-bit word (value | pointer << 32), doubled IN PLACE.  A
+// word always states "the value holds up to the slot the pointer names" (rank: hops; label: no outlet met yet), so
+// composing it with ANY consistent word of that slot — old or already advanced by this very round — gives another
+// true statement: no ping-pong buffers, no copy of the finished two thirds of the slots per round (round 2's form
+// moved 32 bytes per slot and round; this one reads 8 and writes 8 where something moved), and pointers that were
+// advanced earlier in the round shorten the path further.  8-byte relaxed atomic accesses keep the pairs untorn.
+__device__ __forceinline__ u64 wj_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wj_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int MODE>
 __global__ void __launch_bounds__(256) k_xinit(const u32 *__restrict__ xtgt, const u32 *__restrict__ elink,
-                                               const u32 *__restrict__ eval, u32 *__restrict__ W,
-                                               u32 *__restrict__ J, u32 nslots, u64 *ctrl) {
+                                               const u32 *__restrict__ eval, u64 *__restrict__ WJ, u32 nslots, u64 *ctrl) {
   const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
   const u32 q = xtgt[s];
@@ -276,34 +283,28 @@ __global__ void __launch_bounds__(256) k_xinit(const u32 *__restrict__ xtgt, con
       if (!w && l != NONE32) j = l;
     }
   }
-  W[s] = w;
-  J[s] = j;
+  WJ[s] = (u64)w | ((u64)j << 32);
   if (!(j & XDONE)) flag_active_p(ctrl);
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256) k_xround(const u32 *__restrict__ Wo, u32 *__restrict__ Wn,
-                                                const u32 *__restrict__ Jo, u32 *__restrict__ Jn, u32 nslots,
-                                                u64 *ctrl) {
+__global__ void __launch_bounds__(256) k_xround(u64 *__restrict__ WJ, u32 nslots, u64 *ctrl) {
   const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslots) return;
-  const u32 j = Jo[s];
-  u32 w = Wo[s];
-  if (j & XDONE) {
-    Wn[s] = w;
-    Jn[s] = j;
-    return;
-  }
-  const u32 wj = Wo[j];
-  u32 q = Jo[j];
+  const u64 own = wj_load(WJ + s);
+  const u32 j = (u32)(own >> 32);
+  if (j & XDONE) return;
+  u32 w = (u32)own;
+  const u64 oth = wj_load(WJ + j);
+  const u32 wj = (u32)oth;
+  u32 q = (u32)(oth >> 32);
   if (MODE == MODE_RANK) {
     w += wj;
   } else if (wj) {  // the first outlet on the path wins; the chain ends there
     w = wj;
     q = s | XDONE;
   }
-  Wn[s] = w;
-  Jn[s] = q;
+  wj_store(WJ + s, (u64)w | ((u64)q << 32));
   if (!(q & XDONE)) flag_active_p(ctrl);
 }
 
@@ -318,10 +319,10 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   const size_t nslots = (size_t)cdiv_u32(ntr, SG) * nstc * SSL;
   if (nslots >= 0x3FFFFFFFull || ntr > 65535u) return PFD_OK;
   DevBuf buf;
-  PFDCHK(buf.alloc(7 * nslots * sizeof(u32)));
+  PFDCHK(buf.alloc(5 * nslots * sizeof(u32)));
   u32 *b = buf.as<u32>();
-  u32 *xtgt = b, *elink = b + nslots, *eval = b + 2 * nslots;
-  u32 *Wc = b + 3 * nslots, *Wn = b + 4 * nslots, *Jc = b + 5 * nslots, *Jn = b + 6 * nslots;
+  u32 *xtgt = b + 2 * nslots, *elink = b + 3 * nslots, *eval = b + 4 * nslots;
+  u64 *WJ = buf.as<u64>();  // (first: 8-byte aligned)
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 8 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(xtgt, 0xFF, nslots * sizeof(u32), h->stream));  // slots of tiles that do not exist
   PathArgs a{codes, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, h->ctrl};
@@ -329,7 +330,7 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   i64 launches = 2;
   k_path<MODE, false><<<grid, 256, 0, h->stream>>>(a);
   const u32 sgrid = cdiv_u32(nslots, 256);
-  k_xinit<MODE><<<sgrid, 256, 0, h->stream>>>(xtgt, elink, eval, Wc, Jc, (u32)nslots, h->ctrl);
+  k_xinit<MODE><<<sgrid, 256, 0, h->stream>>>(xtgt, elink, eval, WJ, (u32)nslots, h->ctrl);
   KCHK();
   bool done = false;
   int batch = 2;
@@ -338,9 +339,7 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
     u64 zero = 0;
     HIPCHK(hipMemcpyAsync(h->ctrl + P_XACTIVE, &zero, sizeof(u64), hipMemcpyHostToDevice, h->stream));
     for (int r = 0; r < batch; ++r, ++rounds) {
-      k_xround<MODE><<<sgrid, 256, 0, h->stream>>>(Wc, Wn, Jc, Jn, (u32)nslots, h->ctrl);
-      std::swap(Wc, Wn);
-      std::swap(Jc, Jn);
+      k_xround<MODE><<<sgrid, 256, 0, h->stream>>>(WJ, (u32)nslots, h->ctrl);
       ++launches;
     }
     KCHK();
@@ -352,7 +351,7 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
     done = active == 0;
     batch = 2;
   }
-  a.xres = Wc;
+  a.xres = WJ;
   k_path<MODE, true><<<grid, 256, 0, h->stream>>>(a);
   KCHK();
   u64 c[6];
