@@ -201,10 +201,20 @@ class _UpBlock:
             self.h.close()
 
 
-def _up_blocks_run(blocks, ncol, dtype, max_iter=None, verify=False):
+MAX_ROUNDS = 256  # default bound of the fixpoint iterations below (sharded HAND needs 11 on the roughest test raster)
+
+
+def _not_settled(rounds):
+    return NotImplementedError(f"row blocks: the boundary rows did not settle in {rounds} rounds — a cycle through "
+                               "the block edges (the reference leaves cells on cycles untouched; blocks cannot), or a "
+                               "path that crosses block edges more often than that (pass max_iter)")
+
+
+def _up_blocks_run(blocks, ncol, dtype, max_iter=MAX_ROUNDS, verify=False):
     """Exchange boundary rows and sweep until no halo value changes: the fixpoint is the whole raster's result (the
     graph is acyclic; a value is final after as many exchanges as its longest upstream path crosses block edges).
-    Returns the number of rounds in which some block swept."""
+    Returns the number of rounds in which some block swept.  A cycle through the block edges never settles (its sums
+    grow with every round): the iteration is bounded by ``max_iter`` and raises."""
     nb = len(blocks)
     seeds = [np.zeros(2 * ncol, dtype) for _ in range(nb)]
     it = 0
@@ -214,7 +224,7 @@ def _up_blocks_run(blocks, ncol, dtype, max_iter=None, verify=False):
             break
         it += 1
         if max_iter is not None and it > max_iter:
-            raise RuntimeError("row blocks: the boundary rows did not settle (a cycle through the block edges?)")
+            raise _not_settled(max_iter)
         for b in range(nb):  # halo rows = the neighbours' boundary rows
             if b > 0:
                 seeds[b][:ncol] = blocks[b - 1].brows[1]
@@ -225,7 +235,7 @@ def _up_blocks_run(blocks, ncol, dtype, max_iter=None, verify=False):
 
 
 def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0), by_row=False, devices=None,
-                    verify=False):
+                    verify=False, max_iter=MAX_ROUNDS):
     """``accuflux(data, direction="up")`` (reference pyflwdir/streams.py:15-41) of a host raster computed as ``nblocks``
     row blocks held by this one process — for rasters beyond 2**32 - 2 cells, and the in-process form of the
     multi-GPU protocol.  ``data``: the payload raster (int32 / int64 / float32 / float64), or with ``by_row`` one value
@@ -248,17 +258,18 @@ def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0),
             a, e = block_slice(nrow, nblocks, b)
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
             blocks.append(_UpBlock(h, "accuflux", dtype, payload=data[a:e], by_row=by_row, nodata=nodata_args))
-        it, bad = _up_blocks_run(blocks, ncol, dtype, verify=verify)
+        it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
         for blk in blocks:
             blk.close()
 
 
-def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verify=False):
+def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verify=False, max_iter=MAX_ROUNDS):
     """Strahler stream order (reference pyflwdir/streams.py:228-269) of a host raster computed as ``nblocks`` row
     blocks held by this one process; ``mask`` (uint8, optional) as in ``stream_order``.  Returns (order, rounds,
-    bad cells or None)."""
+    bad cells or None).  The raster must be acyclic: on a cycle through a block edge the orders can settle on values
+    the reference never assigns (FlwdirRaster checks with one rank query before it cuts a raster into blocks)."""
     d8 = np.ascontiguousarray(d8, dtype=np.uint8)
     nrow, ncol = d8.shape
     if mask is not None:
@@ -270,7 +281,7 @@ def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verif
             a, e = block_slice(nrow, nblocks, b)
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
             blocks.append(_UpBlock(h, "strahler", np.uint8, mask=None if mask is None else mask[a:e]))
-        it, bad = _up_blocks_run(blocks, ncol, np.uint8, verify=verify)
+        it, bad = _up_blocks_run(blocks, ncol, np.uint8, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
         for blk in blocks:
@@ -504,7 +515,7 @@ class DistributedRaster:
             if blk is not None:
                 blk.close(close_handle=False)
 
-    def _up_collective(self, make_block, dtype, max_iter=None):
+    def _up_collective(self, make_block, dtype, max_iter=MAX_ROUNDS):
         """Collective fixpoint of an up-sweep over the ranks' blocks (see :func:`_up_blocks_run`): per round one
         all-gather of the two boundary rows and one agreement on whether any rank swept."""
         ncol = self.handle.ncol
@@ -534,7 +545,7 @@ class DistributedRaster:
                     return blk.result(), it
                 it += 1
                 if max_iter is not None and it > max_iter:
-                    raise RuntimeError("row blocks: the boundary rows did not settle")
+                    raise _not_settled(max_iter)
                 if self.rank > 0:
                     seed[:ncol] = np.frombuffer(parts[self.rank - 1], dtype)[ncol:]
                 if self.rank + 1 < self.world:
@@ -543,7 +554,7 @@ class DistributedRaster:
             if blk is not None:
                 blk.close(close_handle=False)
 
-    def accuflux(self, data_block, nodata_args=(0, 0.0, 0), by_row=False, max_iter=None):
+    def accuflux(self, data_block, nodata_args=(0, 0.0, 0), by_row=False, max_iter=MAX_ROUNDS):
         """Collective ``accuflux(data, direction="up")`` (reference pyflwdir/streams.py:15-41): every rank passes the
         payload of its block INCLUDING its halo rows (``by_row``: one value per device row); returns (the rank's own
         rows, rounds).  Bit-identical to the whole raster, floats included: see :func:`accuflux_blocks`."""
@@ -553,7 +564,7 @@ class DistributedRaster:
         return self._up_collective(lambda: _UpBlock(self.handle, "accuflux", data.dtype, payload=data, by_row=by_row,
                                                     nodata=nodata_args), data.dtype, max_iter)
 
-    def stream_order(self, mask_block=None, max_iter=None):
+    def stream_order(self, mask_block=None, max_iter=MAX_ROUNDS):
         """Collective Strahler order (reference pyflwdir/streams.py:228-269); ``mask_block`` covers the block's device
         rows.  Returns (uint8 orders of the rank's own rows, rounds)."""
         return self._up_collective(lambda: _UpBlock(self.handle, "strahler", np.uint8, mask=mask_block), np.uint8, max_iter)

@@ -279,3 +279,38 @@ def test_up_block_verifier_sees_a_wrong_cell(gpu_lib, oracle):
         assert h.accuflux_block(payload, code, seed, out, -9999, -9999.0, 1, verify=True)[1] == 2
     finally:
         h.close()
+
+
+def test_up_blocks_report_a_cycle_through_the_block_edges(gpu_lib, oracle):
+    """A cycle that crosses a block edge never settles (its sums grow with every exchange): the iteration is bounded
+    and says so; a cycle inside one block is harmless (its cells are in no ordering and keep their input, like in the
+    reference)."""
+    from pyflwdir_amd import dist
+
+    d8 = oracle.synth_d8(200, 120, seed=5, tilt=100000, white=2, nodata_pct=0)
+    data = np.ones(d8.shape, np.float32)
+    inside = d8.copy()
+    inside[40, 50], inside[40, 51] = 1, 16        # E <-> W inside block 0
+    got, _, bad = dist.accuflux_blocks(inside, 2, data, (-9999, -9999.0, 1), verify=True)
+    idxs_ds, idxs_pit, _ = oracle.from_array(inside)
+    exp = oracle.accuflux(idxs_ds, oracle.idxs_seq(idxs_ds, idxs_pit), data.ravel(), nodata=-9999)
+    assert np.array_equal(got.ravel().view(np.uint32), exp.view(np.uint32))
+    assert bad > 0  # (the cells on the cycle keep their input: the local equations do not hold there, and the check says so)
+    across = d8.copy()
+    across[99, 50], across[100, 50] = 4, 64       # S <-> N across the edge between the blocks (rows 99 | 100)
+    with pytest.raises(NotImplementedError, match="did not settle"):
+        dist.accuflux_blocks(across, 2, data, (-9999, -9999.0, 1), max_iter=12)
+    # (a Strahler order can settle on such a cycle, with values where the reference has none: the front end therefore
+    #  refuses rasters with cycles before it cuts them into blocks)
+    import pyflwdir_amd as pyflwdir
+
+    flw = pyflwdir.from_array(across, ftype="d8", cache=False)
+    import os
+    os.environ["PFD_TEST_BIG_CELLS"] = "10000"
+    try:
+        assert flw._row_blocks_needed() > 1
+        for call in (lambda: flw.stream_order(), lambda: flw.accuflux(data), lambda: flw.upstream_area("km2")):
+            with pytest.raises(NotImplementedError, match="cycle"):
+                call()
+    finally:
+        del os.environ["PFD_TEST_BIG_CELLS"]
