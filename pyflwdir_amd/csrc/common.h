@@ -151,6 +151,11 @@ struct pfd_raster {
   size_t bytes_held = 0;
   void *pending = nullptr;  // split-phase multi-block pass in flight (dist.hip)
   void *pending_basins = nullptr;  // split-phase multi-block basins query in flight (paths.hip)
+  // row blocks, exact-order up-sweeps: the given values of the halo rows (2 * ncol elements, device) are put back into
+  // the result right after the tile pass has written every cell (run_exact_up); set by the caller around the sweep
+  const void *xseed = nullptr;
+  void *xseed_out = nullptr;
+  size_t xseed_elem = 0;
   u8 *halo_raw = nullptr;  // row blocks: the D8 codes of the two halo rows as given (2 * ncol; the normalised codes hold sinks there)
   void *hand_block_state = nullptr;  // cells of a row block whose HAND is still unknown, between pfd_hand_block calls (sweeps.hip)
   // profiling

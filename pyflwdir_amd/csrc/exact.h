@@ -35,6 +35,7 @@
 #define XOFF (XCAP + 2)
 #define XL_TRUNK 255u    // lh[] marks
 #define XL_NODATA 254u
+#define XL_HALO 253u     // cell of a halo row of a row block: its value is GIVEN (the neighbouring block's), never computed
 // sinfo (u16 per slot): bits 0-7 child mask, 8-11 slot of the heavy child (8 = none: chain head),
 // 12-14 number of post slots that follow, 15 = this is a post slot (scell = the upstream cell it carries)
 #define XS_POST 0x8000u
@@ -43,7 +44,7 @@
 
 struct ExactPlan {
   u32 ntr = 0, ntc = 0;
-  u8 *lh = nullptr;       // [n] leaf step (0..XCAP), XL_TRUNK, XL_NODATA
+  u8 *lh = nullptr;       // [n] leaf step (0..XCAP), XL_TRUNK, XL_NODATA, XL_HALO
   u8 *kids = nullptr;     // [n] mask of the neighbour slots draining into the cell
   uint16_t *tord = nullptr;  // [ntiles * 4096] leaf cells of the tile, ordered by step: local index | downstream slot << 12 | pit << 15
   uint16_t *toff = nullptr;  // [ntiles * XOFF] start of step s in tord; entries past the last step = total

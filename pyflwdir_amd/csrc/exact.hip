@@ -26,9 +26,14 @@ int pfd_path_labels(pfd_raster *h, const u8 *codes, const u32 *seed_dev, u32 *ou
 // in LDS: a finished cell decrements its downstream cell; a cell whose counter reaches zero joins the
 // next step.  A cell with an upstream cell outside the tile never starts counting down ("blocked").
 // ---------------------------------------------------------------------------------------------
+// Row blocks (halo_raw != nullptr): a cell of a halo row is neither leaf nor trunk — its value is given (XL_HALO) —
+// but where its code AS GIVEN points at a valid own cell it is one of that cell's upstream cells (the normalised codes
+// hold sinks in the halo rows): the staged image is patched with those directions, and a cell with an upstream halo
+// cell never starts counting down (blocked -> trunk), like one with an upstream cell outside the tile.
 __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode, u32 nrow, u32 ncol, u32 ntc,
                                                    u8 *__restrict__ lh, u8 *__restrict__ kids_out,
-                                                   uint16_t *__restrict__ tord, uint16_t *__restrict__ toff) {
+                                                   uint16_t *__restrict__ tord, uint16_t *__restrict__ toff,
+                                                   const u8 *__restrict__ halo_raw, u32 row_first, u32 row_last) {
   __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
   __shared__ u32 cnt[XTC];         // unresolved upstream cells | 0x100 blocked | 0x200 nodata
   __shared__ uint16_t ord[XTC];
@@ -45,6 +50,27 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
   if (tid == 0) s_n = 0;
   if (tid < XOFF) off[tid] = 0;
   __syncthreads();
+  // image rows that are halo rows of the block (-2: none)
+  int hrow[2] = {-2, -2};
+  if (halo_raw) {
+    if (row_first > 0 && (i64)row_first - 1 >= r0 - 1 && (i64)row_first - 1 <= r0 + XT) hrow[0] = (int)((i64)row_first - 1 - r0);
+    if (row_last + 1 < nrow && (i64)row_last + 1 >= r0 - 1 && (i64)row_last + 1 <= r0 + XT) hrow[1] = (int)((i64)row_last + 1 - r0);
+    for (u32 t = tid; t < 2u * (XT + 2); t += 256u) {
+      const int side = (int)(t / (XT + 2)), lc = (int)(t % (XT + 2)) - 1, lr = hrow[side];
+      const i64 gc = c0 + lc;
+      if (lr == -2 || gc < 0 || gc >= (i64)ncol) continue;
+      const u32 raw = halo_raw[(size_t)side * ncol + (size_t)gc];
+      if (!d8_is_dir(raw)) continue;
+      const int k = d8_slot(raw);
+      if (d8_dr(k) != (side ? -1 : 1)) continue;  // (only a step into the own rows links the halo cell to the block)
+      const int tr_ = lr + d8_dr(k), tc_ = lc + d8_dc(k);
+      const i64 tgc = gc + d8_dc(k);
+      if (tr_ < -1 || tr_ > XT || tgc < 0 || tgc >= (i64)ncol) continue;
+      if (CODE(lr, lc) != D8_MV && CODE(tr_, tc_) != D8_MV) CODE(lr, lc) = (u8)raw;
+    }
+    __syncthreads();
+  }
+  auto is_halo_row = [&](int lr) { return lr == hrow[0] || lr == hrow[1]; };
   u32 mykids[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -57,15 +83,20 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
       const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
       if (CODE(nr, nc) == (1u << ((k + 4) & 7))) {
         m |= 1u << k;
-        if ((unsigned)nr >= XT || (unsigned)nc >= XT) blocked = 0x100u;
+        if ((unsigned)nr >= XT || (unsigned)nc >= XT || is_halo_row(nr)) blocked = 0x100u;
       }
+    }
+    const u32 nkids = (u32)__popc(m);  // (a halo cell keeps its count: the leaves draining into it count it down)
+    if (is_halo_row(lr)) {
+      m = 0;
+      blocked = 0x400u;
     }
     if (c == D8_MV) {
       m = 0;
       blocked = 0x200u;
     }
     mykids[j] = m;
-    const u32 v = (u32)__popc(m) | blocked;
+    const u32 v = (c == D8_MV ? 0u : nkids) | blocked;
     cnt[l] = v;
     if (v == 0) ord[atomicAdd(&s_n, 1u)] = (uint16_t)l;  // headwater: step 0
   }
@@ -109,7 +140,7 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const u32 l = tid + 256u * j;
-    cnt[l] = (cnt[l] & 0x200u) ? XL_NODATA : XL_TRUNK;
+    cnt[l] = (cnt[l] & 0x200u) ? XL_NODATA : ((cnt[l] & 0x400u) ? XL_HALO : XL_TRUNK);
   }
   __syncthreads();
   for (u32 j = tid; j < total; j += 256u) {
@@ -192,7 +223,8 @@ __global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode
     if (d8_is_dir(c)) {
       const u32 p = d8_down(g, x, c);
       const u32 ps = heavy_slot(lh, upa, g, p, kids[p]);
-      heavy = ps < 8 && ((d8_slot(c) + 4) & 7) == (int)ps;  // the slot of p that holds x
+      // (a halo cell of a row block is in no chain: the cell draining into it ends its own)
+      heavy = ps < 8 && ((d8_slot(c) + 4) & 7) == (int)ps && lh[p] != XL_HALO;  // the slot of p that holds x
     }
     hc = heavy ? c : 0u;
     sd = heavy ? 0u : x + 1u;
@@ -254,7 +286,7 @@ __global__ void __launch_bounds__(256) k_plan_tails(const u8 *__restrict__ ncode
   const u32 x = tails[j];
   u32 d = 0, p = NONE32;
   const u32 c = ncode[x];
-  if (d8_is_dir(c)) {
+  if (d8_is_dir(c) && ncode[d8_down(g, x, c)] != D8_HALO) {  // (into a halo cell of a row block: like a pit, nothing to join)
     d = 1;
     p = tidx_at[tailnum[d8_down(g, x, c)] - 1u];  // the end of the chain this one joins (a trunk cell: never 0)
   }
@@ -437,7 +469,11 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if (h->xplan_state != 0) return PFD_OK;
   h->xplan_state = -1;
   if (h->gen) return PFD_OK;
-  if (h->n > 4294967294ll || h->halo_top || h->halo_bot || pfd_knob("PFD_EXACT_LEVELS")) return PFD_OK;
+  if (h->n > 4294967294ll || pfd_knob("PFD_EXACT_LEVELS")) return PFD_OK;
+  const bool block = h->halo_top || h->halo_bot;
+  // (row blocks: the cells of the halo rows hold given values, see k_plan_tile; the codes of the halo rows as given
+  //  must still be around)
+  if (block && (!h->halo_raw || pfd_knob("PFD_BLOCK_LEVELS"))) return PFD_OK;
   if (h->acyclic < 0) return PFD_OK;
   const u32 n = h->geo.n;
   const u32 ntr = cdiv_u32((u64)h->nrow, XT), ntc = cdiv_u32((u64)h->ncol, XT);
@@ -450,7 +486,10 @@ int pfd_ensure_xplan(pfd_raster *h) {
   {
     const bool prof = h->profiling;  // (the tiled pass records its own segments: keep ours intact)
     h->profiling = false;
-    const int rc = pfd_upstream_area_cell_tiled(h, (i32 *)upa.p, &complete);
+    // (a row block: the count inside the block, nothing entering from the neighbours — the heavy links only need SOME
+    //  consistent weight; the result covers the own rows, the halo rows stay 0 and are never heavy)
+    if (block) HIPCHK(hipMemsetAsync(upa.p, 0, (size_t)n * sizeof(u32), h->stream));
+    const int rc = pfd_upstream_area_cell_tiled(h, (i32 *)upa.p + (size_t)h->halo_top * (size_t)h->ncol, &complete);
     h->profiling = prof;
     PFDCHK(rc);
   }
@@ -475,7 +514,8 @@ int pfd_ensure_xplan(pfd_raster *h) {
   if ((rc = pfd_dmalloc((void **)&p->tord, ntiles * XTC * sizeof(uint16_t))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->toff, ntiles * XOFF * sizeof(uint16_t))) != PFD_OK) return fail(rc);
   k_plan_tile<<<dim3(ntc, ntr), 256, 0, h->stream>>>(h->ncode, (u32)h->nrow, (u32)h->ncol, ntc, p->lh, p->kids, p->tord,
-                                                     p->toff);
+                                                     p->toff, block ? h->halo_raw : nullptr, (u32)h->halo_top,
+                                                     (u32)(h->halo_top + h->own_rows - 1));
   XDBG(h, "k_plan_tile");
   xdigest(h, "upa", upa.p, (size_t)n * 4);
   xdigest(h, "ncode", h->ncode, (size_t)n);

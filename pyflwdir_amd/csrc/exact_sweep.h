@@ -344,6 +344,14 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
   k_xtile_up<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a);
   KCHK();
   XDBG(h, "tile_up");
+  if (h->xseed && h->xseed_out) {  // row block: the tile pass wrote the halo cells like any other; their values are given
+    const size_t rowb = (size_t)h->ncol * h->xseed_elem;
+    if (h->halo_top)
+      HIPCHK(hipMemcpyAsync((char *)h->xseed_out + (size_t)(h->halo_top - 1) * rowb, h->xseed, rowb, hipMemcpyDeviceToDevice, h->stream));
+    if (h->halo_bot)
+      HIPCHK(hipMemcpyAsync((char *)h->xseed_out + (size_t)(h->halo_top + h->own_rows) * rowb, (const char *)h->xseed + rowb, rowb,
+                            hipMemcpyDeviceToDevice, h->stream));
+  }
   DevBuf E, R;
   PFDCHK(E.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(Elem) + 64));
   PFDCHK(R.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(V) + 64));
@@ -608,6 +616,8 @@ __global__ void __launch_bounds__(256) k_xtrunk_dscatter(Op op, const u32 *__res
 // apply() would read from memory: gathered up front, quad by quad).  Writes every own cell once.
 // (LDS per workgroup decides how many tiles a CU overlaps, and the step loop is latency: keep it small.)
 #define XHW (XT + 2)
+// cells whose final value is in place before the tile kernel runs: trunk cells, and the halo cells of a row block
+__device__ __forceinline__ bool xl_given(u32 m) { return m == XL_TRUNK || m == XL_HALO; }
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   typedef typename Op::V V;
@@ -663,7 +673,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
       if (INPL) __builtin_memcpy(&l4, a.lh + g0, 4);
       bool trunk = !INPL;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) trunk |= ((l4 >> (8 * b)) & 0xFFu) == XL_TRUNK;
+      for (int b = 0; b < 4; ++b) trunk |= xl_given((l4 >> (8 * b)) & 0xFFu);
       if (trunk) op.top4(g0, v);
     } else if (gr < (i64)a.nrow) {
 #pragma unroll
@@ -720,7 +730,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           vq[j][b] = V();
-          trunk |= ((l4s[j] >> (8 * b)) & 0xFFu) == XL_TRUNK;
+          trunk |= xl_given((l4s[j] >> (8 * b)) & 0xFFu);
         }
         if (trunk) op.top4(g0, vq[j]);
       }

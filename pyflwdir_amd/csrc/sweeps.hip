@@ -1358,7 +1358,9 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
   }
   PFDCHK(pfd_reject_general(h, "hand_block"));
   pfd_seg_clear(h);
-  PFDCHK(pfd_order_cells_impl(h));  // (the level structure of the block: its halo cells are roots like its pits)
+  // the structure the block sweeps on: the exact-order plan (its halo cells are cells with given values), or the level
+  // structure (its halo cells are roots like its pits)
+  PFDCHK(ensure_sweep_structure(h));
   InArg dr, el, sd;
   PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
   PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
@@ -1388,7 +1390,18 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
     KCHK();
     pfd_seg_end(h, 1);
     const u32 rf = (u32)h->halo_top, rl = (u32)(h->halo_top + h->own_rows - 1);
-    if (elev_dtype == PFD_F32) {
+    if (h->xplan_state == 1) {  // exact-order engine: the halo cells hold their given heights from the start
+      k_hb_seed<<<cdiv_u32(2 * (u64)h->ncol, 256), 256, 0, h->stream>>>(h->ncode, (u32)h->ncol, (u32)h->nrow, rf, rl,
+                                                                      (const double *)sd.dev, (double *)o.dev);
+      KCHK();
+      if (elev_dtype == PFD_F32) {
+        Hand<float> op{h->ncode, h->geo, (const u8 *)dr.dev, (const float *)el.dev, (double *)o.dev};
+        PFDCHK(run_exact_down(h, op, "exact_hand_block"));
+      } else {
+        Hand<double> op{h->ncode, h->geo, (const u8 *)dr.dev, (const double *)el.dev, (double *)o.dev};
+        PFDCHK(run_exact_down(h, op, "exact_hand_block"));
+      }
+    } else if (elev_dtype == PFD_F32) {
       HandSeeded<float> op{{h->ncode, h->geo, (const u8 *)dr.dev, (const float *)el.dev, (double *)o.dev}, (const double *)sd.dev, rf, rl};
       PFDCHK(run_down(h, op, "sweep_hand_block"));
     } else {
@@ -1458,10 +1471,16 @@ static int up_block_run(pfd_raster *h, const Op &op0, T *out_dev, const T *seed_
     HIPCHK(hipMemcpyAsync(out_dev + own0 + nown, seed_dev + ncol, ncol * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
   OwnRows<Op> op{op0, (u32)own0, (u32)nown};
   if (verify) {
-    PFDCHK(pfd_ensure_seq_aux(h));
+    const u8 *kids = nullptr;  // per cell: the neighbours draining into it, halo cells included
+    if (h->xplan_state == 1) {
+      kids = ((ExactPlan *)h->xplan)->kids;
+    } else {
+      PFDCHK(pfd_ensure_seq_aux(h));
+      kids = h->cell_kids;
+    }
     pfd_seg_begin(h, "verify_up_block");
     HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(u64), h->stream));
-    k_verify_up<OwnRows<Op>, T><<<cdiv_u32((u64)nown, 256), 256, 0, h->stream>>>(op, h->ncode, h->cell_kids, out_dev, (u32)own0,
+    k_verify_up<OwnRows<Op>, T><<<cdiv_u32((u64)nown, 256), 256, 0, h->stream>>>(op, h->ncode, kids, out_dev, (u32)own0,
                                                                                 (u32)nown, (unsigned long long *)h->ctrl);
     KCHK();
     pfd_seg_end(h, 1);
@@ -1469,6 +1488,13 @@ static int up_block_run(pfd_raster *h, const Op &op0, T *out_dev, const T *seed_
     HIPCHK(hipMemcpyAsync(&bad, h->ctrl, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (n_bad) *n_bad = (int64_t)bad;
+  } else if (h->xplan_state == 1) {
+    // exact-order engine: the tile pass writes every cell, the halo cells among them; their given values go back in
+    // before the trunk rounds read them (run_exact_up)
+    h->xseed = seed_dev, h->xseed_out = out_dev, h->xseed_elem = sizeof(T);
+    const int rc = run_exact_up(h, op0, "exact_up_block");
+    h->xseed = nullptr, h->xseed_out = nullptr, h->xseed_elem = 0;
+    PFDCHK(rc);
   } else {
     PFDCHK(run_up(h, op, name));
   }
@@ -1491,7 +1517,7 @@ static int up_block_prepare(pfd_raster *h, const char *what) {
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  return pfd_order_cells_impl(h);  // (the level structure of the block: its halo cells are roots like its pits)
+  return ensure_sweep_structure(h);  // (the exact-order plan of the block, or its level structure)
 }
 template <class T>
 static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T nodata, int has_nodata, const void *seed_host,
