@@ -314,3 +314,41 @@ def test_up_blocks_report_a_cycle_through_the_block_edges(gpu_lib, oracle):
                 call()
     finally:
         del os.environ["PFD_TEST_BIG_CELLS"]
+
+
+def test_row_blocks_on_the_level_engine(gpu_lib, oracle, monkeypatch):
+    """Row blocks sweep with the exact-order engine by default; the level engine stays the fallback (a block whose plan
+    cannot be built: a cycle inside the block, PFD_BLOCK_LEVELS) and must give the same bits."""
+    from pyflwdir_amd import dist
+
+    O = oracle
+    shape = (900, 700)
+    d8 = O.synth_d8(shape[0], shape[1], seed=97, tilt=100000, white=2, nodata_pct=10)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    upa = O.upstream_area_cell(d8)[0].ravel()
+    elev = O.synth_elev_f32(shape[0], shape[1], seed=97, tilt=100000, white=2, nodata_pct=10).ravel()
+    drain = upa > np.percentile(upa[upa > 0], 97)
+    data = (np.random.default_rng(3).random(d8.size) * 2).astype(np.float32)
+    exp_h = O.height_above_nearest_drain(idxs_ds, seq, drain, elev)
+    exp_a = O.accuflux(idxs_ds, seq, data, nodata=-9999)
+    exp_s = O.strahler_order(idxs_ds, seq)
+    for knob in (None, "1"):
+        if knob:
+            monkeypatch.setenv("PFD_BLOCK_LEVELS", knob)
+        got_h, _ = dist.hand_blocks(d8, 3, drain, elev)
+        got_a, _, bad_a = dist.accuflux_blocks(d8, 3, data, (-9999, -9999.0, 1), verify=True)
+        got_s, _, bad_s = dist.strahler_blocks(d8, 3, verify=True)
+        assert np.array_equal(got_h.ravel().view(np.uint64), exp_h.view(np.uint64)), knob
+        assert bad_a == 0 and np.array_equal(got_a.ravel().view(np.uint32), exp_a.view(np.uint32)), knob
+        assert bad_s == 0 and np.array_equal(got_s.ravel(), exp_s), knob
+    monkeypatch.delenv("PFD_BLOCK_LEVELS")
+    # a cycle inside one block: no plan for that block (level engine there), the other blocks keep theirs
+    cyc = d8.copy()
+    r, c = np.argwhere((d8[100:200, 100:600] != 247))[50] + (100, 100)
+    cyc[r, c], cyc[r, c + 1] = 1, 16
+    idxs_ds, idxs_pit, _ = O.from_array(cyc)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    exp_h = O.height_above_nearest_drain(idxs_ds, seq, drain, elev)
+    got_h, _ = dist.hand_blocks(cyc, 3, drain, elev)
+    assert np.array_equal(got_h.ravel().view(np.uint64), exp_h.view(np.uint64))
