@@ -41,6 +41,7 @@ struct PathArgs {
   const u64 *xres;  // [nslots] pass 2: low word = rank of the exit cell / outlet the exit finally reaches
   const u32 *seed;  // [n] label mode: outlet number (1-based) seeded on the cell, 0 = none
   u32 *out;         // [n] pass 2: rank (KEY_INVALID on nodata) / outlet number per cell
+  const u32 *ids32; // label mode, nullable: the outlets' 32-bit labels — `out` then receives ids32[number - 1] (0: none)
   u64 *ctrl;
 };
 
@@ -182,6 +183,8 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
           }
         } else {
           val = V[root];  // outlet at the end of the in-tile path (the cell's own seed, or what the exit reaches)
+          // (32-bit labels straight from the table: saves the pass that maps numbers to labels — 8 bytes per cell)
+          if (a.ids32) val = val ? a.ids32[val - 1u] : 0u;
         }
         o4[b] = val;
       }
@@ -311,7 +314,7 @@ __global__ void __launch_bounds__(256) k_xround(u64 *__restrict__ WJ, u32 nslots
 // one complete path query; on return *complete = 0 means cycles were found (caller falls back)
 template <int MODE>
 static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *complete, u32 *maxrank,
-                     const u8 *codes = nullptr) {
+                     const u8 *codes = nullptr, const u32 *ids32 = nullptr) {
   *complete = 0;
   if (!codes) codes = h->ncode;  // (exact.hip queries a derived forest: heavy links only)
   const u32 ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
@@ -325,7 +328,7 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   u64 *WJ = buf.as<u64>();  // (first: 8-byte aligned)
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 8 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(xtgt, 0xFF, nslots * sizeof(u32), h->stream));  // slots of tiles that do not exist
-  PathArgs a{codes, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, h->ctrl};
+  PathArgs a{codes, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, ids32, h->ctrl};
   const dim3 grid(ntc, ntr);
   i64 launches = 2;
   k_path<MODE, false><<<grid, 256, 0, h->stream>>>(a);
@@ -723,7 +726,8 @@ int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32
   const u32 n = h->geo.n;
   DevBuf seed, num;
   PFDCHK(seed.alloc((size_t)n * sizeof(u32) + 64));  // + slack: quads are loaded 16 bytes at a time
-  PFDCHK(num.alloc((size_t)n * sizeof(u32)));
+  const bool direct = id_size == 4;  // 32-bit labels: the final tile pass writes them itself
+  if (!direct) PFDCHK(num.alloc((size_t)n * sizeof(u32)));
   // The label query stops at the first outlet, so an outlet on (or downstream of) a cycle would hide the
   // cycle and label cells that never reach a pit — cells the reference never visits (they are not in
   // idxs_seq; found by the randomised stress test).  The tiled path is only taken on rasters known to
@@ -745,9 +749,14 @@ int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32
   }
   int complete = 0;
   pfd_seg_begin(h, "tile_labels");
-  PFDCHK(run_paths<MODE_LABEL>(h, seed.as<u32>(), num.as<u32>(), &complete, nullptr));
+  PFDCHK(run_paths<MODE_LABEL>(h, seed.as<u32>(), direct ? (u32 *)out_dev : num.as<u32>(), &complete, nullptr, nullptr,
+                               direct ? (const u32 *)ids_dev : nullptr));
   pfd_seg_end(h, 2);
   if (!complete) return PFD_OK;
+  if (direct) {
+    *ok = 1;
+    return PFD_OK;
+  }
   const u32 grid = cdiv_u32(n, 256);
   switch (id_size) {
     case 1: k_labels_out<u8><<<grid, 256, 0, h->stream>>>(num.as<u32>(), (const u8 *)ids_dev, n, (u8 *)out_dev); break;
