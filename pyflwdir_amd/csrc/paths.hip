@@ -41,6 +41,7 @@ struct PathArgs {
   const u64 *xres;  // [nslots] pass 2: low word = rank of the exit cell / outlet the exit finally reaches
   const u32 *seed;  // [n] label mode: outlet number (1-based) seeded on the cell, 0 = none
   u32 *out;         // [n] pass 2: rank (KEY_INVALID on nodata) / outlet number per cell
+  const u8 *tflag;  // label mode, nullable: [ntr * ntc] tile holds a seed; the seeds of the other tiles are never read
   const u32 *ids32; // label mode, nullable: the outlets' 32-bit labels — `out` then receives ids32[number - 1] (0: none)
   u64 *ctrl;
 };
@@ -62,6 +63,9 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
   __syncthreads();
 
   // ---- initial pointers / values -----------------------------------------------------------------
+  // (a few outlets on a large raster: most tiles hold none, and 4 bytes of seed per cell and pass are a third of the
+  //  query's traffic — the caller flags the tiles that hold one and zeroes only those)
+  const bool seeded = MODE == MODE_LABEL && (a.tflag == nullptr || a.tflag[(size_t)tr * a.ntc + tc] != 0);
   u32 pc[QPT * 4];
   u32 live = 0;
 #pragma unroll
@@ -70,7 +74,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
     const int lr = l0 >> 6, lc0 = l0 & 63;
     const u32 c4 = *(const u32 *)&CODE(lr, lc0);
     u32 s4[4] = {0, 0, 0, 0};
-    if (MODE == MODE_LABEL) {  // outlets seeded on the cells of this quad (nodata cells may be seeded too)
+    if (MODE == MODE_LABEL && seeded) {  // outlets seeded on the cells of this quad (nodata cells may be seeded too)
       const i64 gr = r0 + lr, gc0 = c0 + lc0;
       const i64 crr = gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr;
       const i64 ccs = gc0 >= (i64)a.ncol ? (i64)a.ncol - 1 : gc0;
@@ -314,7 +318,7 @@ __global__ void __launch_bounds__(256) k_xround(u64 *__restrict__ WJ, u32 nslots
 // one complete path query; on return *complete = 0 means cycles were found (caller falls back)
 template <int MODE>
 static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *complete, u32 *maxrank,
-                     const u8 *codes = nullptr, const u32 *ids32 = nullptr) {
+                     const u8 *codes = nullptr, const u32 *ids32 = nullptr, const u8 *tflag = nullptr) {
   *complete = 0;
   if (!codes) codes = h->ncode;  // (exact.hip queries a derived forest: heavy links only)
   const u32 ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
@@ -328,7 +332,7 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   u64 *WJ = buf.as<u64>();  // (first: 8-byte aligned)
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 8 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(xtgt, 0xFF, nslots * sizeof(u32), h->stream));  // slots of tiles that do not exist
-  PathArgs a{codes, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, ids32, h->ctrl};
+  PathArgs a{codes, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, tflag, ids32, h->ctrl};
   const dim3 grid(ntc, ntr);
   i64 launches = 2;
   k_path<MODE, false><<<grid, 256, 0, h->stream>>>(a);
@@ -712,6 +716,25 @@ __global__ void k_seed_numbers(const i64 *__restrict__ idx, u32 k, u32 *__restri
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < k) seed[idx[t]] = t + 1;
 }
+// sparse seeding: flag the 64 x 64 tiles that hold an outlet, zero the seeds of those tiles only
+__global__ void k_flag_seed_tiles(const i64 *__restrict__ idx, u32 k, u32 ncol, u32 ntc, u8 *__restrict__ tflag) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k) return;
+  const u32 x = (u32)idx[t], r = x / ncol, c = x - r * ncol;
+  tflag[(size_t)(r >> 6) * ntc + (c >> 6)] = 1;
+}
+__global__ void __launch_bounds__(256) k_zero_seed_tiles(const u8 *__restrict__ tflag, u32 nrow, u32 ncol, u32 ntc,
+                                                         u32 *__restrict__ seed) {
+  const u32 tc = blockIdx.x, tr = blockIdx.y;
+  if (!tflag[(size_t)tr * ntc + tc]) return;
+  for (u32 i = threadIdx.x; i < TS * TS / 4; i += 256u) {  // quads of the tile
+    const u32 r = tr * TS + (i >> 4), c = tc * TS + 4u * (i & 15u);
+    if (r >= nrow) break;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (c + b < ncol) seed[(size_t)r * ncol + c + b] = 0;
+  }
+}
 template <class L>
 __global__ void k_labels_out(const u32 *__restrict__ num, const L *__restrict__ ids, u32 n, L *__restrict__ out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -742,15 +765,20 @@ int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32
     h->acyclic = ok_rank ? 1 : -1;
   }
   if (h->acyclic < 0) return PFD_OK;
-  HIPCHK(hipMemsetAsync(seed.p, 0, (size_t)n * sizeof(u32), h->stream));
+  const u32 ptr_ = cdiv_u32((u64)h->nrow, TS), ptc_ = cdiv_u32((u64)h->ncol, TS);
+  DevBuf tflag;
+  PFDCHK(tflag.alloc((size_t)ptr_ * ptc_));
+  HIPCHK(hipMemsetAsync(tflag.p, 0, (size_t)ptr_ * ptc_, h->stream));
   if (k) {
+    k_flag_seed_tiles<<<cdiv_u32(k, 256), 256, 0, h->stream>>>(idx_dev, k, (u32)h->ncol, ptc_, tflag.as<u8>());
+    k_zero_seed_tiles<<<dim3(ptc_, ptr_), 256, 0, h->stream>>>(tflag.as<u8>(), (u32)h->nrow, (u32)h->ncol, ptc_, seed.as<u32>());
     k_seed_numbers<<<cdiv_u32(k, 256), 256, 0, h->stream>>>(idx_dev, k, seed.as<u32>());
     KCHK();
   }
   int complete = 0;
   pfd_seg_begin(h, "tile_labels");
   PFDCHK(run_paths<MODE_LABEL>(h, seed.as<u32>(), direct ? (u32 *)out_dev : num.as<u32>(), &complete, nullptr, nullptr,
-                               direct ? (const u32 *)ids_dev : nullptr));
+                               direct ? (const u32 *)ids_dev : nullptr, tflag.as<u8>()));
   pfd_seg_end(h, 2);
   if (!complete) return PFD_OK;
   if (direct) {
