@@ -105,38 +105,74 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
   __syncthreads();
 
   // ---- gather doubling ---------------------------------------------------------------------------
-  for (int round = 0; round < MAXROUNDS_TILE; ++round) {
-    u32 q[QPT * 4], dv[QPT * 4];
+  // "does any pointer still move": wave leaders publish a flag, everybody reads the four flags after ONE barrier (two
+  // alternating rows: a wave reaches the write of round r + 2 only after every wave has read round r's row) — a
+  // __syncthreads_or is three barriers and a reduction
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
+  auto vote = [&](int round) -> bool {
+    const bool any = __ballot(live != 0u) != 0ull;
+    if ((tid & 63u) == 0u) s_flag[round & 1][tid >> 6] = any ? 1u : 0u;
+    __syncthreads();
+    const uint4 f = *(const uint4 *)s_flag[round & 1];
+    return (f.x | f.y | f.z | f.w) != 0u;
+  };
+  if (MODE == MODE_LABEL) {
+    // labels travel with the ROOT (read at the end), so the loop moves pointers only: every value a pointer ever holds
+    // is an ancestor of its cell, whoever advanced it when — no barrier between reads and writes, and two jumps per
+    // round (4 rounds instead of 6 on a river raster)
+    for (int round = 0; round < MAXROUNDS_TILE; ++round) {
 #pragma unroll
-    for (int j = 0; j < QPT; ++j) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (live & (1u << (4 * j + b))) {
-          q[4 * j + b] = P[pc[4 * j + b]];
-          if (MODE == MODE_RANK) dv[4 * j + b] = V[pc[4 * j + b]];
-        }
-      }
-    }
-    __syncthreads();  // every read of this round precedes every write of this round
-#pragma unroll
-    for (int j = 0; j < QPT; ++j) {
-      if (live & (0xFu << (4 * j))) {
-        const u32 l0 = 4u * tid + 1024u * j;
-        uint4 v4;
-        if (MODE == MODE_RANK) v4 = *(const uint4 *)&V[l0];
+      for (int j = 0; j < QPT; ++j) {
+        if (!(live & (0xFu << (4 * j)))) continue;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           if (live & (1u << (4 * j + b))) {
-            if (MODE == MODE_RANK) ((u32 *)&v4)[b] += dv[4 * j + b];
-            pc[4 * j + b] = q[4 * j + b];
-            if (q[4 * j + b] & PDONE) live &= ~(1u << (4 * j + b));
+            u32 q = P[pc[4 * j + b]];
+            if (!(q & PDONE)) q = P[q];
+            pc[4 * j + b] = q;
           }
         }
-        if (MODE == MODE_RANK) *(uint4 *)&V[l0] = v4;
-        *(uint2 *)&P[l0] = make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if ((live & (1u << (4 * j + b))) && (pc[4 * j + b] & PDONE)) live &= ~(1u << (4 * j + b));
+        *(uint2 *)&P[4u * tid + 1024u * j] =
+            make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
       }
+      if (!vote(round)) break;
     }
-    if (!__syncthreads_or((int)live)) break;
+  } else {
+    for (int round = 0; round < MAXROUNDS_TILE; ++round) {
+      u32 q[QPT * 4], dv[QPT * 4];
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (live & (1u << (4 * j + b))) {
+            q[4 * j + b] = P[pc[4 * j + b]];
+            dv[4 * j + b] = V[pc[4 * j + b]];
+          }
+        }
+      }
+      __syncthreads();  // every read of this round precedes every write of this round
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        if (live & (0xFu << (4 * j))) {
+          const u32 l0 = 4u * tid + 1024u * j;
+          uint4 v4 = *(const uint4 *)&V[l0];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (live & (1u << (4 * j + b))) {
+              ((u32 *)&v4)[b] += dv[4 * j + b];
+              pc[4 * j + b] = q[4 * j + b];
+              if (q[4 * j + b] & PDONE) live &= ~(1u << (4 * j + b));
+            }
+          }
+          *(uint4 *)&V[l0] = v4;
+          *(uint2 *)&P[l0] = make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
+        }
+      }
+      if (!vote(round)) break;
+    }
   }
   if (live) atomicAdd((unsigned long long *)&a.ctrl[P_UNSAT], (unsigned long long)__popc(live));  // cycles
   __syncthreads();
