@@ -726,25 +726,24 @@ def main():
 
 def secondary_lines(a, device):
     """The side lines of the N = 1 run (see the module docstring)."""
-    if True:
-        sec = []
-        l2, c2 = upa_line(10000, 10000, a.regime, 20, 5, device, cpu=False, checks=False)
-        sec.append(dict(op="upstream_area(unit='cell')", workload=c2["workload"], value=l2["value"], unit="Mcells/s",
-                        ms_per_step=l2["ms_per_step"], ms_per_step_median=l2["ms_per_step_median"], dtype="int32",
-                        n_valid=c2["n_valid"], n_pits=c2["n_pits"], roofline=l2["roofline"]))
-        sec += op_lines(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", 3, device)
-        # configs[4]'s shape: a MERIT-Hydro-like 3-arcsec tile, 72000 x 36000 cells (36000 rows), rough terrain, 30 % ocean
-        sec += op_lines(36000, 72000, dict(seed=2, tilt=100000, white=2, nodata_pct=30),
-                        "36000x72000 synthetic D8 (rough regime, 30 % nodata: BASELINE configs[4] shape)", 2, device,
-                        ops=("hand", "basins"))
-        # workload spread: the same pass on a rough surface, on a pit-riddled one, on a mosaic of the reference's real
-        # Rhine raster and on the tile pass's worst case, with the graph statistics that explain the differences
-        for reg in ("rough", "meander", "rhine_mosaic", "filled_mosaic", "serpentine"):
-            if reg == a.regime:
-                continue
-            l3, c3 = upa_line(10000, 10000, reg, 10, 2, device, cpu=False, checks=True)
-            sec.append(dict(op="upstream_area(unit='cell')", **c3, **l3, unit="Mcells/s", dtype="int32"))
-        return sec
+    sec = []
+    l2, c2 = upa_line(10000, 10000, a.regime, 20, 5, device, cpu=False, checks=False)
+    sec.append(dict(op="upstream_area(unit='cell')", workload=c2["workload"], value=l2["value"], unit="Mcells/s",
+                    ms_per_step=l2["ms_per_step"], ms_per_step_median=l2["ms_per_step_median"], dtype="int32",
+                    n_valid=c2["n_valid"], n_pits=c2["n_pits"], roofline=l2["roofline"]))
+    sec += op_lines(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", 3, device)
+    # configs[4]'s shape: a MERIT-Hydro-like 3-arcsec tile, 72000 x 36000 cells (36000 rows), rough terrain, 30 % ocean
+    sec += op_lines(36000, 72000, dict(seed=2, tilt=100000, white=2, nodata_pct=30),
+                    "36000x72000 synthetic D8 (rough regime, 30 % nodata: BASELINE configs[4] shape)", 2, device,
+                    ops=("hand", "basins"))
+    # workload spread: the same pass on a rough surface, on a pit-riddled one, on a mosaic of the reference's real
+    # Rhine raster and on the tile pass's worst case, with the graph statistics that explain the differences
+    for reg in ("rough", "meander", "rhine_mosaic", "filled_mosaic", "serpentine"):
+        if reg == a.regime:
+            continue
+        l3, c3 = upa_line(10000, 10000, reg, 10, 2, device, cpu=False, checks=True)
+        sec.append(dict(op="upstream_area(unit='cell')", **c3, **l3, unit="Mcells/s", dtype="int32"))
+    return sec
 
 
 if __name__ == "__main__":
