@@ -263,12 +263,14 @@ int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtype, const vo
  * into the block is added by its downstream cell in the serial loop's position (upstream cells in descending linear
  * index), so floats come out bit-identical to the whole raster once the seeds are the neighbours' final rows.  The caller
  * iterates (pyflwdir_amd/dist.py up_blocks): exchange the boundary rows and sweep again until no row changes.
+ *   direction:   PFD_UP, or PFD_DOWN (streams.accuflux_ds, streams.py:44-70: values travel upstream; a halo cell the
+ *                block drains into then holds the neighbour's value, and the same exchange-until-stable applies).
  *   by_row != 0: `data` holds one value per ROW of the device raster (HOST; upstream_area(unit="km2") on lat/lon grids).
  *   verify != 0: nothing is computed; `out` holds a result, *n_bad receives the number of own cells whose value is not
  *                the one their upstream cells (halo seeds included) give — the all-cell check of a blocked result.
  *   boundary_rows_host (nullable): receives the first and the last OWN row (2 * ncol elements). */
 int pfd_accuflux_block(pfd_raster *h, int dtype, const void *data, int by_row, int64_t nodata_i, double nodata_f,
-                       int has_nodata, const void *halo_seed_host, int verify, void *out, int memspace,
+                       int has_nodata, int direction, const void *halo_seed_host, int verify, void *out, int memspace,
                        void *boundary_rows_host, int64_t *n_bad);
 int pfd_strahler_block(pfd_raster *h, const uint8_t *mask, const uint8_t *halo_seed_host, int verify, uint8_t *out,
                        int memspace, uint8_t *boundary_rows_host, int64_t *n_bad);

@@ -92,8 +92,8 @@ def lib() -> C.CDLL:
         L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
-        L.pfd_accuflux_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_int, C.c_void_p,
-                                         C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
+        L.pfd_accuflux_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
         L.pfd_strahler_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                          C.POINTER(C.c_int64)]
         L.pfd_hand_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -388,8 +388,8 @@ class RasterHandle:
         return out, brows, int(unk.value)
 
     def accuflux_block(self, data, dtype_code, halo_seed, out, nodata_i=0, nodata_f=0.0, has_nodata=0, by_row=False,
-                       verify=False, memspace=PFD_HOST):
-        """accuflux (direction "up") of a row block whose halo cells hold ``halo_seed`` (2 * ncol values of the result
+                       verify=False, memspace=PFD_HOST, direction=PFD_UP):
+        """accuflux (either direction) of a row block whose halo cells hold ``halo_seed`` (2 * ncol values of the result
         type, host); data and ``out`` cover the block's device raster (own + halo rows), ``by_row``: one host value per
         device row.  Returns (boundary rows [2, ncol], own cells failing their local equation — verify only)."""
         halo_seed = np.ascontiguousarray(halo_seed)
@@ -397,8 +397,8 @@ class RasterHandle:
         brows = np.empty((2, self.ncol), halo_seed.dtype)
         bad = C.c_int64(0)
         check(lib().pfd_accuflux_block(self._h, dtype_code, ptr(data), 1 if by_row else 0, int(nodata_i), float(nodata_f),
-                                       int(has_nodata), ptr(halo_seed), 1 if verify else 0, ptr(out), memspace,
-                                       ptr(brows), C.byref(bad)))
+                                       int(has_nodata), int(direction), ptr(halo_seed), 1 if verify else 0, ptr(out),
+                                       memspace, ptr(brows), C.byref(bad)))
         return brows, int(bad.value)
 
     def strahler_block(self, mask, halo_seed, out, verify=False, memspace=PFD_HOST):

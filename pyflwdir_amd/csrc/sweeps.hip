@@ -1334,14 +1334,17 @@ static int hand_block_update(pfd_raster *h, HandBlockState *st, const u8 *drain,
   DevBuf fl;
   const int BATCH = 64;
   PFDCHK(fl.alloc(BATCH * sizeof(u32)));
-  for (int guard = 0; guard < (1 << 22); guard += BATCH) {
+  // rounds are issued in batches (a launch is ~3 us, a host round trip ~30; a first batch of 16 was tried: the unknown
+  // stretches are longer than that more often than not, and the extra round trip costs more than 48 idle launches)
+  const int batch = BATCH;
+  for (int guard = 0; guard < (1 << 22); guard += batch) {
     HIPCHK(hipMemsetAsync(fl.p, 0, BATCH * sizeof(u32), h->stream));
-    for (int r = 0; r < BATCH; ++r)
+    for (int r = 0; r < batch; ++r)
       k_hb_relax<E><<<cdiv_u32(st->m, 256), 256, 0, h->stream>>>(h->ncode, h->geo, drain, elev, st->list[st->cur].as<u32>(), st->m, out,
                                                                 fl.as<u32>() + r);
     KCHK();
     u32 last = 0;
-    HIPCHK(hipMemcpyAsync(&last, fl.as<u32>() + BATCH - 1, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&last, fl.as<u32>() + batch - 1, sizeof(u32), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (!last) break;  // the last round of the batch moved nothing: fixpoint
   }
@@ -1519,9 +1522,77 @@ static int up_block_prepare(pfd_raster *h, const char *what) {
   pfd_seg_clear(h);
   return ensure_sweep_structure(h);  // (the exact-order plan of the block, or its level structure)
 }
+// ---- down-sweeps of a row block (accuflux direction "down"): the halo cells a block drains into hold given values ----
+template <class Op>
+struct HaloSeeded : Op {  // level engine: a halo cell is a root of the block's ordering; its value is its seed
+  const typename Op::V *seed;
+  u32 row_last;
+  __device__ __forceinline__ typename Op::V apply(u32 x, u32 code, bool root, typename Op::V pv) const {
+    if (code == D8_HALO) {
+      const u32 r = geo_row(this->g, x);
+      return seed[(r > row_last ? this->g.ncol : 0u) + (x - r * this->g.ncol)];
+    }
+    return Op::apply(x, code, root, pv);
+  }
+};
+template <class Op, class T>
+__global__ void __launch_bounds__(256) k_verify_down(Op op, const u8 *__restrict__ ncode, Geo g, const T *__restrict__ out, u32 lo,
+                                                     u32 n_own, unsigned long long *__restrict__ bad) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool b = false;
+  if (i < n_own) {
+    const u32 x = lo + i;
+    const u32 code = ncode[x];
+    if (code != D8_MV) {
+      const bool root = !d8_is_dir(code);
+      const T v = (T)op.apply(x, code, root, root ? T() : out[d8_down(g, x, code)]);
+      b = bits_of(v) != bits_of(out[x]);
+    }
+  }
+  const u64 m = __ballot(b);
+  if (m && (threadIdx.x & 63u) == 0u) atomicAdd(bad, (unsigned long long)__popcll(m));
+}
+template <class Op, class T>
+static int down_block_run(pfd_raster *h, const Op &op0, T *out_dev, const T *seed_dev, int verify, T *brows_host,
+                          int64_t *n_bad, const char *name) {
+  const size_t ncol = (size_t)h->ncol, own0 = (size_t)h->halo_top * ncol, nown = (size_t)h->own_rows * ncol;
+  auto seed_rows = [&]() -> int {
+    if (h->halo_top)
+      HIPCHK(hipMemcpyAsync(out_dev + own0 - ncol, seed_dev, ncol * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    if (h->halo_bot)
+      HIPCHK(hipMemcpyAsync(out_dev + own0 + nown, seed_dev + ncol, ncol * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    return PFD_OK;
+  };
+  PFDCHK(seed_rows());
+  if (verify) {
+    pfd_seg_begin(h, "verify_down_block");
+    HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(u64), h->stream));
+    k_verify_down<Op, T><<<cdiv_u32((u64)nown, 256), 256, 0, h->stream>>>(op0, h->ncode, h->geo, out_dev, (u32)own0, (u32)nown,
+                                                                        (unsigned long long *)h->ctrl);
+    KCHK();
+    pfd_seg_end(h, 1);
+    u64 bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, h->ctrl, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_bad) *n_bad = (int64_t)bad;
+  } else if (h->xplan_state == 1) {
+    PFDCHK(run_exact_down(h, op0, "exact_down_block"));  // (halo cells: given values, loaded and written back unchanged)
+  } else {
+    HaloSeeded<Op> op{op0, seed_dev, (u32)(h->halo_top + h->own_rows - 1)};
+    PFDCHK(run_down(h, op, name));
+    PFDCHK(seed_rows());  // (the level engine stored the seeds of the VALID halo cells only)
+  }
+  if (brows_host) {
+    HIPCHK(hipMemcpyAsync(brows_host, out_dev + own0, ncol * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(brows_host + ncol, out_dev + own0 + nown - ncol, ncol * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return PFD_OK;
+}
+
 template <class T>
-static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T nodata, int has_nodata, const void *seed_host,
-                            int verify, void *out, int memspace, void *brows_host, int64_t *n_bad) {
+static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T nodata, int has_nodata, int direction,
+                            const void *seed_host, int verify, void *out, int memspace, void *brows_host, int64_t *n_bad) {
   InArg d, sd;
   if (by_row)
     PFDCHK(d.bind(data, (size_t)h->nrow * sizeof(T), PFD_HOST, h->stream));
@@ -1542,7 +1613,13 @@ static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T noda
     }
     pfd_seg_end(h, 1);
   }
-  if (by_row) {
+  if (direction == PFD_DOWN && by_row) {
+    AccuDown<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(down_block_run(h, op, (T *)o.dev, (const T *)sd.dev, verify, (T *)brows_host, n_bad, "sweep_accuflux_down_block"));
+  } else if (direction == PFD_DOWN) {
+    AccuDown<T> op{h->ncode, h->geo, CellData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(down_block_run(h, op, (T *)o.dev, (const T *)sd.dev, verify, (T *)brows_host, n_bad, "sweep_accuflux_down_block"));
+  } else if (by_row) {
     AccuUp<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
     PFDCHK(up_block_run(h, op, (T *)o.dev, (const T *)sd.dev, verify, (T *)brows_host, n_bad, "sweep_accuflux_block"));
   } else {
@@ -1552,22 +1629,22 @@ static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T noda
   return verify ? PFD_OK : o.finish(h->stream);
 }
 extern "C" int pfd_accuflux_block(pfd_raster *h, int dtype, const void *data, int by_row, int64_t nodata_i, double nodata_f,
-                                  int has_nodata, const void *halo_seed_host, int verify, void *out, int memspace,
-                                  void *boundary_rows_host, int64_t *n_bad) {
+                                  int has_nodata, int direction, const void *halo_seed_host, int verify, void *out,
+                                  int memspace, void *boundary_rows_host, int64_t *n_bad) {
   PFDCHK(up_block_prepare(h, "pfd_accuflux_block"));
-  if (!data || !out || !halo_seed_host) {
+  if (!data || !out || !halo_seed_host || (direction != PFD_UP && direction != PFD_DOWN)) {
     pfd_set_error("pfd_accuflux_block: bad arguments");
     return PFD_EINVAL;
   }
   switch (dtype) {
     case PFD_I32:
-      return accuflux_block_t<i32>(h, data, by_row != 0, (i32)nodata_i, has_nodata, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
+      return accuflux_block_t<i32>(h, data, by_row != 0, (i32)nodata_i, has_nodata, direction, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
     case PFD_I64:
-      return accuflux_block_t<i64>(h, data, by_row != 0, (i64)nodata_i, has_nodata, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
+      return accuflux_block_t<i64>(h, data, by_row != 0, (i64)nodata_i, has_nodata, direction, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
     case PFD_F32:
-      return accuflux_block_t<float>(h, data, by_row != 0, (float)nodata_f, has_nodata, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
+      return accuflux_block_t<float>(h, data, by_row != 0, (float)nodata_f, has_nodata, direction, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
     case PFD_F64:
-      return accuflux_block_t<double>(h, data, by_row != 0, nodata_f, has_nodata, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
+      return accuflux_block_t<double>(h, data, by_row != 0, nodata_f, has_nodata, direction, halo_seed_host, verify, out, memspace, boundary_rows_host, n_bad);
     default:
       pfd_set_error("pfd_accuflux_block: unsupported payload dtype code %d", dtype);
       return PFD_EUNSUPPORTED;

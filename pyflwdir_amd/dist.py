@@ -153,8 +153,9 @@ class _UpBlock:
     """Device-resident state of one row block of an up-sweep (accuflux, Strahler) between the exchanges: payload and
     result stay in HBM; only the two boundary rows travel."""
 
-    def __init__(self, handle, kind, dtype, payload=None, by_row=False, nodata=(0, 0.0, 0), mask=None):
+    def __init__(self, handle, kind, dtype, payload=None, by_row=False, nodata=(0, 0.0, 0), mask=None, direction=_hip.PFD_UP):
         self.h, self.kind, self.dtype, self.by_row, self.nodata = handle, kind, np.dtype(dtype), by_row, nodata
+        self.direction = direction
         ncol, dev = handle.ncol, handle.device
         self.nrows_dev = handle.nrow + sum(handle.halo)
         self.payload = self.mask = None
@@ -173,7 +174,8 @@ class _UpBlock:
         if self.kind == "accuflux":
             nd_i, nd_f, has_nd = self.nodata
             return self.h.accuflux_block(self.payload, _hip._PAYLOAD_CODE[self.dtype], seed, self.out, nd_i, nd_f, has_nd,
-                                         by_row=self.by_row, verify=verify, memspace=_hip.PFD_DEVICE)
+                                         by_row=self.by_row, verify=verify, memspace=_hip.PFD_DEVICE,
+                                         direction=self.direction)
         return self.h.strahler_block(self.mask, seed, self.out, verify=verify, memspace=_hip.PFD_DEVICE)
 
     def sweep(self, seed):
@@ -235,8 +237,8 @@ def _up_blocks_run(blocks, ncol, dtype, max_iter=MAX_ROUNDS, verify=False):
 
 
 def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0), by_row=False, devices=None,
-                    verify=False, max_iter=MAX_ROUNDS):
-    """``accuflux(data, direction="up")`` (reference pyflwdir/streams.py:15-41) of a host raster computed as ``nblocks``
+                    verify=False, max_iter=MAX_ROUNDS, direction="up"):
+    """``accuflux(data, direction)`` (reference pyflwdir/streams.py:15-41, :44-70) of a host raster computed as ``nblocks``
     row blocks held by this one process — for rasters beyond 2**32 - 2 cells, and the in-process form of the
     multi-GPU protocol.  ``data``: the payload raster (int32 / int64 / float32 / float64), or with ``by_row`` one value
     per raster row (cell areas of a regular grid).  ``nodata_args`` = (nodata_i, nodata_f, has_nodata) as
@@ -257,7 +259,8 @@ def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0),
         for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
             a, e = block_slice(nrow, nblocks, b)
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
-            blocks.append(_UpBlock(h, "accuflux", dtype, payload=data[a:e], by_row=by_row, nodata=nodata_args))
+            blocks.append(_UpBlock(h, "accuflux", dtype, payload=data[a:e], by_row=by_row, nodata=nodata_args,
+                                   direction=_hip.PFD_UP if direction == "up" else _hip.PFD_DOWN))
         it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -554,15 +557,16 @@ class DistributedRaster:
             if blk is not None:
                 blk.close(close_handle=False)
 
-    def accuflux(self, data_block, nodata_args=(0, 0.0, 0), by_row=False, max_iter=MAX_ROUNDS):
+    def accuflux(self, data_block, nodata_args=(0, 0.0, 0), by_row=False, max_iter=MAX_ROUNDS, direction="up"):
         """Collective ``accuflux(data, direction="up")`` (reference pyflwdir/streams.py:15-41): every rank passes the
         payload of its block INCLUDING its halo rows (``by_row``: one value per device row); returns (the rank's own
         rows, rounds).  Bit-identical to the whole raster, floats included: see :func:`accuflux_blocks`."""
         data = np.asarray(data_block)
         if data.dtype not in _hip._PAYLOAD_CODE:
             raise NotImplementedError(f"payload dtype {data.dtype} is not supported by the row-block accuflux")
+        dirc = _hip.PFD_UP if direction == "up" else _hip.PFD_DOWN
         return self._up_collective(lambda: _UpBlock(self.handle, "accuflux", data.dtype, payload=data, by_row=by_row,
-                                                    nodata=nodata_args), data.dtype, max_iter)
+                                                    nodata=nodata_args, direction=dirc), data.dtype, max_iter)
 
     def stream_order(self, mask_block=None, max_iter=MAX_ROUNDS):
         """Collective Strahler order (reference pyflwdir/streams.py:228-269); ``mask_block`` covers the block's device

@@ -531,11 +531,11 @@ class FlwdirRaster(object):
             return self._accuflux_narrow(flat, nodata, dirc).reshape(data.shape)
         view, code, nd_i, nd_f, has_nd = _payload_args(flat, nodata)
         nb = self._row_blocks_needed()
-        if nb > 1 and direction == "up":
+        if nb > 1:
             from . import dist
 
             self._refuse_cycles_in_blocks("accuflux")
-            out = dist.accuflux_blocks(self._d8, nb, view, (nd_i, nd_f, has_nd))[0]
+            out = dist.accuflux_blocks(self._d8, nb, view, (nd_i, nd_f, has_nd), direction=direction)[0]
             return out.view(flat.dtype).reshape(data.shape)
         out = self._h.accuflux(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd, direction=dirc)
         return out.view(flat.dtype).reshape(data.shape)
@@ -673,7 +673,7 @@ class FlwdirRaster(object):
     def _row_blocks_needed(self):
         """1, or the number of row blocks a raster beyond 2**32 - 2 cells is cut into for the operations whose engines
         address cells with 32 bits (the reference's index ladder reaches int64, pyflwdir.py:105-127): basins, hand,
-        accuflux (up), upstream_area in area units and the Strahler order then run the row-block protocols of
+        accuflux, upstream_area in area units and the Strahler order then run the row-block protocols of
         pyflwdir_amd/dist.py inside this one process — same kernels, bit-identical results.  (PFD_TEST_BIG_CELLS with PFD_ENABLE_KNOBS=1 lowers the threshold for tests.)"""
         import os
 

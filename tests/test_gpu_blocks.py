@@ -185,6 +185,8 @@ def test_front_end_cuts_huge_rasters_into_row_blocks(gpu_lib, oracle, monkeypatc
     exp = O.accuflux(idxs_ds, seq, data.ravel(), nodata=-9999)
     assert np.array_equal(flw.accuflux(data).ravel().view(np.uint32), exp.view(np.uint32))
     assert np.array_equal(flw.stream_order().ravel(), O.strahler_order(idxs_ds, seq))
+    exp = O.accuflux(idxs_ds, seq, data.ravel(), nodata=-9999, direction="down")
+    assert np.array_equal(flw.accuflux(data, direction="down").ravel().view(np.uint32), exp.view(np.uint32))
     monkeypatch.delenv("PFD_TEST_BIG_CELLS")
     from pyflwdir_amd import gis
 
@@ -339,6 +341,9 @@ def test_row_blocks_on_the_level_engine(gpu_lib, oracle, monkeypatch):
         got_h, _ = dist.hand_blocks(d8, 3, drain, elev)
         got_a, _, bad_a = dist.accuflux_blocks(d8, 3, data, (-9999, -9999.0, 1), verify=True)
         got_s, _, bad_s = dist.strahler_blocks(d8, 3, verify=True)
+        got_d, _, bad_d = dist.accuflux_blocks(d8, 3, data, (-9999, -9999.0, 1), verify=True, direction="down")
+        assert bad_d == 0 and np.array_equal(got_d.ravel().view(np.uint32),
+                                             O.accuflux(idxs_ds, seq, data, nodata=-9999, direction="down").view(np.uint32)), knob
         assert np.array_equal(got_h.ravel().view(np.uint64), exp_h.view(np.uint64)), knob
         assert bad_a == 0 and np.array_equal(got_a.ravel().view(np.uint32), exp_a.view(np.uint32)), knob
         assert bad_s == 0 and np.array_equal(got_s.ravel(), exp_s), knob
@@ -352,3 +357,27 @@ def test_row_blocks_on_the_level_engine(gpu_lib, oracle, monkeypatch):
     exp_h = O.height_above_nearest_drain(idxs_ds, seq, drain, elev)
     got_h, _ = dist.hand_blocks(cyc, 3, drain, elev)
     assert np.array_equal(got_h.ravel().view(np.uint64), exp_h.view(np.uint64))
+
+
+@pytest.mark.parametrize("shape,seed,kw,nblocks,dtype", [
+    ((900, 700), 101, dict(tilt=100000, white=2, nodata_pct=20), 2, np.float32),
+    ((1600, 900), 102, dict(tilt=1 << 26, white=2, nodata_pct=10), 8, np.float32),
+    ((1100, 800), 103, dict(tilt=3000, white=2, nodata_pct=5), 5, np.float64),
+    ((64, 300), 104, dict(tilt=100000, white=2, nodata_pct=0), 8, np.int32),
+])
+def test_accuflux_down_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblocks, dtype):
+    """accuflux(direction="down") (reference pyflwdir/streams.py:44-70: every cell adds the value of its downstream
+    cell) over row blocks == the oracle on the whole raster, bit for bit; every cell's local equation checked."""
+    from pyflwdir_amd import dist
+
+    O = oracle
+    d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    rng = np.random.default_rng(seed)
+    data = (rng.random(d8.size) * 3.1).astype(dtype) if np.dtype(dtype).kind == "f" else rng.integers(0, 50, d8.size).astype(dtype)
+    data[rng.random(d8.size) < 0.001] = -9999
+    exp = O.accuflux(idxs_ds, seq, data, nodata=-9999, direction="down")
+    got, rounds, bad = dist.accuflux_blocks(d8, nblocks, data, (-9999, -9999.0, 1), verify=True, direction="down")
+    assert got.dtype == dtype and rounds >= 1 and bad == 0
+    assert np.array_equal(got.ravel().view(np.uint8), exp.view(np.uint8)), rounds
