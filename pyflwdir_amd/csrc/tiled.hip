@@ -902,25 +902,41 @@ __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
   constexpr int SPT = HCAP / 1024;
   if (tid == 0) s_cnt = 0;
   u32 y[SPT], ext = 0, live = 0;  // ext bit j: node drains into another hypertile
+  // (this workgroup has its CU to itself — 144 KB of LDS — so nobody fills the gaps of a load that is waited for under
+  //  its `if (i < n)`: 24 serialised round trips were most of the kernel.  Loads are unconditional — the id range of a
+  //  hypertile is allocated in full — in batches of 8, slices of 1024 ids past n are skipped as a whole)
 #pragma unroll
-  for (int j = 0; j < SPT; ++j) {
-    const u32 i = tid + 1024u * j;
-    u32 p = i | HDONE, t = 0;
-    if (i < n) {
-      const u32 j3 = s.J3[base + i];
-      t = s.T3[base + i];
-      if (FINAL) t += s.xin3[base + i];
-      if (!(j3 & XDONE)) {
-        if (j3 / HCAP == ht)
-          p = j3 % HCAP;
-        else
-          ext |= 1u << j;
+  for (int j0 = 0; j0 < SPT; j0 += 8) {
+    u32 j3s[8], ts[8];
+    if (1024u * j0 < n) {  // (uniform)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const u32 i = tid + 1024u * (j0 + q);
+        j3s[q] = s.J3[base + i];
+        ts[q] = s.T3[base + i];
+        if (FINAL) ts[q] += s.xin3[base + i];
       }
     }
-    T[i] = t;
-    P[i] = (uint16_t)p;
-    y[j] = p & 0x7FFFu;
-    if (!(p & HDONE)) live |= 1u << j;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q;
+      const u32 i = tid + 1024u * j;
+      u32 p = i | HDONE, t = 0;
+      if (i < n) {
+        const u32 j3 = j3s[q];
+        t = ts[q];
+        if (!(j3 & XDONE)) {
+          if (j3 / HCAP == ht)
+            p = j3 % HCAP;
+          else
+            ext |= 1u << j;
+        }
+      }
+      T[i] = t;
+      P[i] = (uint16_t)p;
+      y[j] = p & 0x7FFFu;
+      if (!(p & HDONE)) live |= 1u << j;
+    }
   }
   __syncthreads();
   for (int round = 0; round < 16; ++round) {
