@@ -224,7 +224,10 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
         } else {
           val = V[root];  // outlet at the end of the in-tile path (the cell's own seed, or what the exit reaches)
           // (32-bit labels straight from the table: saves the pass that maps numbers to labels — 8 bytes per cell)
-          if (a.ids32) val = val ? a.ids32[val - 1u] : 0u;
+          if (a.ids32) {  // (unconditional load from a clamped index, then the select: 16 loads in flight, not 16 round trips)
+            const u32 id = a.ids32[val ? val - 1u : 0u];
+            val = val ? id : 0u;
+          }
         }
         o4[b] = val;
       }
@@ -814,7 +817,7 @@ int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32
   int complete = 0;
   pfd_seg_begin(h, "tile_labels");
   PFDCHK(run_paths<MODE_LABEL>(h, seed.as<u32>(), direct ? (u32 *)out_dev : num.as<u32>(), &complete, nullptr, nullptr,
-                               direct ? (const u32 *)ids_dev : nullptr, tflag.as<u8>()));
+                               (direct && k) ? (const u32 *)ids_dev : nullptr, tflag.as<u8>()));
   pfd_seg_end(h, 2);
   if (!complete) return PFD_OK;
   if (direct) {
