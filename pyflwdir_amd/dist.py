@@ -347,6 +347,34 @@ def _default_group(rank, world):
     return _GROUP
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: a caller's stdout (bench.py: ONE JSON line) stays clean
+    whatever a native library prints while it initialises."""
+
+    def __enter__(self):
+        import os
+        import sys
+
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        import os
+        import sys
+
+        sys.stdout.flush()
+        try:  # (the library printed through C stdio, which buffers when stdout is a pipe: flush it while fd 1 is stderr)
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _try_rccl(uid, rank, world, device, timeout):
     """Create the RCCL communicator in a watchdog thread: a bootstrap that cannot reach its peers
     blocks forever instead of failing.  A creation that finishes after the watchdog gave up destroys its
@@ -402,9 +430,10 @@ class DistributedRaster:
             err = exc
         self.comm = None
         if transport in ("auto", "rccl"):
-            uid = exchange_unique_id(rank, world, self.group)
-            if err is None:
-                self.comm = _try_rccl(uid, rank, world, device, rccl_timeout)
+            with _stdout_to_stderr():  # (RCCL prints a banner — host name, library path — on stdout when it comes up)
+                uid = exchange_unique_id(rank, world, self.group)
+                if err is None:
+                    self.comm = _try_rccl(uid, rank, world, device, rccl_timeout)
             ok = self.group.allreduce(1 if self.comm is not None else 0, "min")
             if ok == 0:
                 if self.comm is not None:
