@@ -274,6 +274,13 @@ int pfd_accuflux_block(pfd_raster *h, int dtype, const void *data, int by_row, i
                        void *boundary_rows_host, int64_t *n_bad);
 int pfd_strahler_block(pfd_raster *h, const uint8_t *mask, const uint8_t *halo_seed_host, int verify, uint8_t *out,
                        int memspace, uint8_t *boundary_rows_host, int64_t *n_bad);
+/* stream_distance (reference pyflwdir/streams.py:272-315) of a row block, like pfd_accuflux_block in direction "down":
+ * the halo cells the block drains into hold the neighbour's distances (`halo_seed_host`: 2 * ncol int32, or float32
+ * when real_length != 0); `step_lengths` covers the rows of the block's device raster (3 * (2 * nrow - 1) floats: the
+ * slice of the whole raster's table that starts at the block's first device row). */
+int pfd_stream_distance_block(pfd_raster *h, const uint8_t *mask, int real_length, const float *step_lengths,
+                              const void *halo_seed_host, int verify, void *out, int memspace, void *boundary_rows_host,
+                              int64_t *n_bad);
 
 /* basins (reference pyflwdir/basins.py:12-18, core.py:120-146) on a raster row-tiled over several GPUs /
  * processes, split-phase like pfd_upstream_area_cell_begin/_finish (Multi-GPU): `outlets` are k

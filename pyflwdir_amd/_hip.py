@@ -38,7 +38,7 @@ SYMBOLS = [
     "pfd_add_pits", "pfd_idxs_ds", "pfd_idxs_pit", "pfd_upstream_count", "pfd_order_cells", "pfd_idxs_seq",
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
-    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
+    "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
 ]
 
 _lib = None
@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_accuflux_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_int, C.c_int,
                                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
+        L.pfd_stream_distance_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
         L.pfd_strahler_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                          C.POINTER(C.c_int64)]
         L.pfd_hand_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -399,6 +401,22 @@ class RasterHandle:
         check(lib().pfd_accuflux_block(self._h, dtype_code, ptr(data), 1 if by_row else 0, int(nodata_i), float(nodata_f),
                                        int(has_nodata), int(direction), ptr(halo_seed), 1 if verify else 0, ptr(out),
                                        memspace, ptr(brows), C.byref(bad)))
+        return brows, int(bad.value)
+
+    def stream_distance_block(self, mask, step_lengths, halo_seed, out, verify=False, memspace=PFD_HOST):
+        """stream_distance of a row block whose halo cells hold ``halo_seed`` (2 * ncol int32, or float32 with
+        ``step_lengths``: the table rows of the block's device raster).  Returns (boundary rows, failing own cells)."""
+        real = step_lengths is not None
+        dt = np.float32 if real else np.int32
+        halo_seed = np.ascontiguousarray(halo_seed, dtype=dt)
+        assert halo_seed.size == 2 * self.ncol
+        if real:
+            step_lengths = np.ascontiguousarray(step_lengths, dtype=np.float32)
+            assert step_lengths.size == 3 * (2 * (self.nrow + sum(self.halo)) - 1)
+        brows = np.empty((2, self.ncol), dt)
+        bad = C.c_int64(0)
+        check(lib().pfd_stream_distance_block(self._h, ptr(mask), int(real), ptr(step_lengths), ptr(halo_seed),
+                                              1 if verify else 0, ptr(out), memspace, ptr(brows), C.byref(bad)))
         return brows, int(bad.value)
 
     def strahler_block(self, mask, halo_seed, out, verify=False, memspace=PFD_HOST):

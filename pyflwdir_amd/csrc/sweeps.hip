@@ -2041,6 +2041,45 @@ extern "C" int pfd_stream_distance(pfd_raster *h, const uint8_t *mask, int real_
   return o.finish(h->stream);  // (synchronises: the staged table may be released afterwards)
 }
 
+// stream_distance of a ROW BLOCK (see pfd_accuflux_block, direction "down"): the halo cells the block drains into hold
+// the neighbour's distances (`halo_seed_host`: 2 * ncol int32 / float32); `step_lengths` covers the rows of the block's
+// device raster (3 * (2 * nrow - 1) floats, the slice of the whole raster's table that starts at its first device row).
+extern "C" int pfd_stream_distance_block(pfd_raster *h, const uint8_t *mask, int real_length, const float *step_lengths,
+                                         const void *halo_seed_host, int verify, void *out, int memspace,
+                                         void *boundary_rows_host, int64_t *n_bad) {
+  PFDCHK(up_block_prepare(h, "pfd_stream_distance_block"));
+  if (!out || !halo_seed_host || (real_length && !step_lengths)) {
+    pfd_set_error("pfd_stream_distance_block: bad arguments");
+    return PFD_EINVAL;
+  }
+  InArg m, tab, sd;
+  PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
+  if (real_length) PFDCHK(tab.bind(step_lengths, 3 * (size_t)(2 * h->nrow - 1) * sizeof(float), PFD_HOST, h->stream));
+  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol * 4, PFD_HOST, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n * 4, memspace));
+  if (verify && memspace == PFD_HOST) HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));
+  if (!verify && h->xplan_state != 1) {
+    pfd_seg_begin(h, "init");
+    if (real_length)
+      k_fill<float><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((float *)o.dev, h->geo.n, -9999.0f);
+    else
+      k_fill<i32><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((i32 *)o.dev, h->geo.n, -9999);
+    KCHK();
+    pfd_seg_end(h, 1);
+  }
+  if (real_length) {
+    Dist<float> op{h->ncode, h->geo, (const u8 *)m.dev, (const float *)tab.dev, (float *)o.dev};
+    PFDCHK(down_block_run(h, op, (float *)o.dev, (const float *)sd.dev, verify, (float *)boundary_rows_host, n_bad,
+                          "sweep_stream_distance_block"));
+  } else {
+    Dist<i32> op{h->ncode, h->geo, (const u8 *)m.dev, nullptr, (i32 *)o.dev};
+    PFDCHK(down_block_run(h, op, (i32 *)o.dev, (const i32 *)sd.dev, verify, (i32 *)boundary_rows_host, n_bad,
+                          "sweep_stream_distance_block"));
+  }
+  return verify ? PFD_OK : o.finish(h->stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // dem.floodplains (reference pyflwdir/dem.py:333-379; FlwdirRaster.floodplains pyflwdir.py:1513-1545)
 // ---------------------------------------------------------------------------------------------

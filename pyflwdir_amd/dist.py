@@ -167,6 +167,8 @@ class _UpBlock:
             mask = np.ascontiguousarray(mask, dtype=np.uint8)
             assert mask.size == self.nrows_dev * ncol
             self.mask = _hip.DeviceBuffer(mask.nbytes, dev).upload(mask)
+        if kind == "distance":
+            self.payload = None if payload is None else np.ascontiguousarray(payload, dtype=np.float32)  # step-length rows
         self.out = _hip.DeviceBuffer(self.nrows_dev * ncol * self.dtype.itemsize, dev)
         self.swept_with, self.brows = None, None
 
@@ -176,6 +178,8 @@ class _UpBlock:
             return self.h.accuflux_block(self.payload, _hip._PAYLOAD_CODE[self.dtype], seed, self.out, nd_i, nd_f, has_nd,
                                          by_row=self.by_row, verify=verify, memspace=_hip.PFD_DEVICE,
                                          direction=self.direction)
+        if self.kind == "distance":
+            return self.h.stream_distance_block(self.mask, self.payload, seed, self.out, verify=verify, memspace=_hip.PFD_DEVICE)
         return self.h.strahler_block(self.mask, seed, self.out, verify=verify, memspace=_hip.PFD_DEVICE)
 
     def sweep(self, seed):
@@ -261,6 +265,32 @@ def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0),
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
             blocks.append(_UpBlock(h, "accuflux", dtype, payload=data[a:e], by_row=by_row, nodata=nodata_args,
                                    direction=_hip.PFD_UP if direction == "up" else _hip.PFD_DOWN))
+        it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
+        return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
+    finally:
+        for blk in blocks:
+            blk.close()
+
+
+def stream_distance_blocks(d8: np.ndarray, nblocks: int, mask=None, step_lengths=None, devices=None, verify=False,
+                           max_iter=MAX_ROUNDS):
+    """``stream_distance`` (reference pyflwdir/streams.py:272-315) of a host raster computed as ``nblocks`` row blocks
+    held by this one process: int32 cell counts, or float32 metres with ``step_lengths`` (the whole raster's table,
+    [2 * nrow - 1, 3]: gis.step_length_table).  Returns (distances, rounds, bad cells or None)."""
+    d8 = np.ascontiguousarray(d8, dtype=np.uint8)
+    nrow, ncol = d8.shape
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(nrow, ncol)
+    tab = None if step_lengths is None else np.ascontiguousarray(step_lengths, dtype=np.float32).reshape(2 * nrow - 1, 3)
+    dtype = np.int32 if tab is None else np.float32
+    devices = devices or [0] * nblocks
+    blocks = []
+    try:
+        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
+            a, e = block_slice(nrow, nblocks, b)
+            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
+            rows = None if tab is None else tab[2 * a:2 * a + 2 * (e - a) - 1]  # (row sums 2a .. 2(e-1): the block's steps)
+            blocks.append(_UpBlock(h, "distance", dtype, payload=rows, mask=None if mask is None else mask[a:e]))
         it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:

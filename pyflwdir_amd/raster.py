@@ -620,6 +620,12 @@ class FlwdirRaster(object):
             return self._h.stream_distance(m, tab, per_cell=True).reshape(self.shape)
         else:
             tab = gis.step_length_table(self.shape[0], self.latlon, self.transform)
+        nb = self._row_blocks_needed()
+        if nb > 1:
+            from . import dist
+
+            self._refuse_cycles_in_blocks("stream_distance")
+            return dist.stream_distance_blocks(self._d8, nb, m, tab)[0]
         return self._h.stream_distance(m, tab).reshape(self.shape)
 
     def main_upstream(self, uparea=None):
@@ -673,7 +679,7 @@ class FlwdirRaster(object):
     def _row_blocks_needed(self):
         """1, or the number of row blocks a raster beyond 2**32 - 2 cells is cut into for the operations whose engines
         address cells with 32 bits (the reference's index ladder reaches int64, pyflwdir.py:105-127): basins, hand,
-        accuflux, upstream_area in area units and the Strahler order then run the row-block protocols of
+        accuflux, upstream_area in area units, the Strahler order and stream_distance then run the row-block protocols of
         pyflwdir_amd/dist.py inside this one process — same kernels, bit-identical results.  (PFD_TEST_BIG_CELLS with PFD_ENABLE_KNOBS=1 lowers the threshold for tests.)"""
         import os
 

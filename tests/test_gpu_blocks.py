@@ -187,6 +187,7 @@ def test_front_end_cuts_huge_rasters_into_row_blocks(gpu_lib, oracle, monkeypatc
     assert np.array_equal(flw.stream_order().ravel(), O.strahler_order(idxs_ds, seq))
     exp = O.accuflux(idxs_ds, seq, data.ravel(), nodata=-9999, direction="down")
     assert np.array_equal(flw.accuflux(data, direction="down").ravel().view(np.uint32), exp.view(np.uint32))
+    assert np.array_equal(flw.stream_distance().ravel(), O.stream_distance(idxs_ds, seq, shape[1], real_length=False))
     monkeypatch.delenv("PFD_TEST_BIG_CELLS")
     from pyflwdir_amd import gis
 
@@ -197,6 +198,10 @@ def test_front_end_cuts_huge_rasters_into_row_blocks(gpu_lib, oracle, monkeypatc
     monkeypatch.setenv("PFD_TEST_BIG_CELLS", "400000")
     got_km2 = blocked.upstream_area("km2")
     assert got_km2.dtype == exp_km2.dtype and np.array_equal(got_km2.view(np.uint64), exp_km2.view(np.uint64))
+    got_m = blocked.stream_distance(unit="m")
+    monkeypatch.delenv("PFD_TEST_BIG_CELLS")
+    exp_m = whole.stream_distance(unit="m")
+    assert got_m.dtype == np.float32 and np.array_equal(got_m.view(np.uint32), exp_m.view(np.uint32))
 
 
 @pytest.mark.parametrize("shape,seed,kw,nblocks,dtype", [
@@ -344,6 +349,8 @@ def test_row_blocks_on_the_level_engine(gpu_lib, oracle, monkeypatch):
         got_d, _, bad_d = dist.accuflux_blocks(d8, 3, data, (-9999, -9999.0, 1), verify=True, direction="down")
         assert bad_d == 0 and np.array_equal(got_d.ravel().view(np.uint32),
                                              O.accuflux(idxs_ds, seq, data, nodata=-9999, direction="down").view(np.uint32)), knob
+        got_l, _, _ = dist.stream_distance_blocks(d8, 3)
+        assert np.array_equal(got_l.ravel(), O.stream_distance(idxs_ds, seq, shape[1], real_length=False)), knob
         assert np.array_equal(got_h.ravel().view(np.uint64), exp_h.view(np.uint64)), knob
         assert bad_a == 0 and np.array_equal(got_a.ravel().view(np.uint32), exp_a.view(np.uint32)), knob
         assert bad_s == 0 and np.array_equal(got_s.ravel(), exp_s), knob
@@ -381,3 +388,32 @@ def test_accuflux_down_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblock
     got, rounds, bad = dist.accuflux_blocks(d8, nblocks, data, (-9999, -9999.0, 1), verify=True, direction="down")
     assert got.dtype == dtype and rounds >= 1 and bad == 0
     assert np.array_equal(got.ravel().view(np.uint8), exp.view(np.uint8)), rounds
+
+
+@pytest.mark.parametrize("shape,seed,kw,nblocks", [
+    ((900, 700), 111, dict(tilt=100000, white=2, nodata_pct=20), 2),
+    ((1600, 900), 112, dict(tilt=1 << 26, white=2, nodata_pct=10), 8),
+    ((64, 300), 113, dict(tilt=100000, white=2, nodata_pct=0), 8),
+])
+def test_stream_distance_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblocks):
+    """stream_distance (reference pyflwdir/streams.py:272-315) over row blocks == the oracle on the whole raster: cell
+    counts and float32 metres on a lat/lon grid (row-dependent step lengths: every block gets its slice of the table),
+    with and without a mask; every cell's local equation checked."""
+    from pyflwdir_amd import dist, gis
+
+    O = oracle
+    d8 = O.synth_d8(shape[0], shape[1], seed=seed, **kw)
+    idxs_ds, idxs_pit, _ = O.from_array(d8)
+    seq = O.idxs_seq(idxs_ds, idxs_pit)
+    upa = O.upstream_area_cell(d8)[0].ravel()
+    tr = gis.Affine(0.01, 0.0, 3.0, 0.0, -0.01, 52.0)
+    tab = gis.step_length_table(shape[0], True, tr)
+    for mask in (None, (upa > 30).astype(np.uint8)):
+        exp = O.stream_distance(idxs_ds, seq, shape[1], mask=mask, real_length=False)
+        got, rounds, bad = dist.stream_distance_blocks(d8, nblocks, mask)
+        assert got.dtype == np.int32 and bad is None and rounds >= 1
+        assert np.array_equal(got.ravel(), exp)
+        exp = O.stream_distance(idxs_ds, seq, shape[1], mask=mask, real_length=True, latlon=True, transform=tuple(tr)[:6])
+        got, _, bad = dist.stream_distance_blocks(d8, nblocks, mask, tab, verify=True)
+        assert got.dtype == np.float32 and bad == 0
+        assert np.array_equal(got.ravel().view(np.uint32), exp.view(np.uint32))
