@@ -627,6 +627,14 @@ class DistributedRaster:
         return self._up_collective(lambda: _UpBlock(self.handle, "accuflux", data.dtype, payload=data, by_row=by_row,
                                                     nodata=nodata_args, direction=dirc), data.dtype, max_iter)
 
+    def stream_distance(self, mask_block=None, step_lengths_block=None, max_iter=MAX_ROUNDS):
+        """Collective ``stream_distance`` (reference pyflwdir/streams.py:272-315): int32 cell counts, or float32 metres
+        with ``step_lengths_block`` = the rows of the whole raster's step-length table that belong to the block's device
+        rows ([2 * rows - 1, 3], see :func:`stream_distance_blocks`).  Returns (distances of the own rows, rounds)."""
+        dtype = np.int32 if step_lengths_block is None else np.float32
+        return self._up_collective(lambda: _UpBlock(self.handle, "distance", dtype, payload=step_lengths_block,
+                                                    mask=mask_block), dtype, max_iter)
+
     def stream_order(self, mask_block=None, max_iter=MAX_ROUNDS):
         """Collective Strahler order (reference pyflwdir/streams.py:228-269); ``mask_block`` covers the block's device
         rows.  Returns (uint8 orders of the rank's own rows, rounds)."""

@@ -1,5 +1,5 @@
 """One rank of a 2+-process check of the collective entry points over the torch-free TCP group:
-DistributedRaster.upstream_area, .basins, .hand, .accuflux and .stream_order of a row block against the oracle on the
+DistributedRaster.upstream_area, .basins, .hand, .accuflux, .stream_distance and .stream_order of a row block against the oracle on the
 whole raster.
 Launched by tests/test_gpu_dist.py (all ranks on the one GPU of the test box, records through the host).
 
@@ -44,6 +44,8 @@ data = (np.random.default_rng(7).random(shape) * 1.7).astype(np.float32)
 exp_a = O.accuflux(idxs_ds, seq, data.ravel(), nodata=-9999).reshape(shape)
 got_a, rounds = dr.accuflux(data[a:e], (-9999, -9999.0, 1))
 assert np.array_equal(got_a.view(np.uint32), exp_a[r0:r1].view(np.uint32)), f"rank {rank}: accuflux differs"
+got_l, _ = dr.stream_distance()
+assert np.array_equal(got_l, O.stream_distance(idxs_ds, seq, shape[1], real_length=False).reshape(shape)[r0:r1]), f"rank {rank}: stream distance differs"
 got_s, _ = dr.stream_order()
 assert np.array_equal(got_s, O.strahler_order(idxs_ds, seq).reshape(shape)[r0:r1]), f"rank {rank}: stream order differs"
 dr.close()
