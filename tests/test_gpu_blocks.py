@@ -417,3 +417,41 @@ def test_stream_distance_blocks_vs_oracle(gpu_lib, oracle, shape, seed, kw, nblo
         got, _, bad = dist.stream_distance_blocks(d8, nblocks, mask, tab, verify=True)
         assert got.dtype == np.float32 and bad == 0
         assert np.array_equal(got.ravel().view(np.uint32), exp.view(np.uint32))
+
+
+def test_block_sweeps_edge_cases(gpu_lib, oracle):
+    """Degenerate shapes of the row-block sweeps: one and three columns, one row per block, a single block, blocks that
+    start on a tile edge, a block of nothing but nodata, nodata rows along a block edge — accuflux (both directions),
+    Strahler, stream distance and HAND == the oracle on the whole raster."""
+    from pyflwdir_amd import dist
+
+    O = oracle
+    rng = np.random.default_rng(5)
+
+    def check(d8, nb, tag):
+        idxs_ds, idxs_pit, _ = O.from_array(d8)
+        seq = O.idxs_seq(idxs_ds, idxs_pit)
+        data = (rng.random(d8.size) * 3).astype(np.float32)
+        for direction in ("up", "down"):
+            exp = O.accuflux(idxs_ds, seq, data, nodata=-9999, direction=direction)
+            got, _, bad = dist.accuflux_blocks(d8, nb, data, (-9999, -9999.0, 1), verify=True, direction=direction)
+            assert bad == 0 and np.array_equal(got.ravel().view(np.uint32), exp.view(np.uint32)), (tag, d8.shape, direction)
+        got, _, bad = dist.strahler_blocks(d8, nb, verify=True)
+        assert bad == 0 and np.array_equal(got.ravel(), O.strahler_order(idxs_ds, seq)), (tag, d8.shape)
+        got, _, _ = dist.stream_distance_blocks(d8, nb)
+        assert np.array_equal(got.ravel(), O.stream_distance(idxs_ds, seq, d8.shape[1], real_length=False)), (tag, d8.shape)
+        elev = rng.random(d8.size).astype(np.float32) * 100
+        drain = O.upstream_area_cell(d8)[0].ravel() > 3
+        got, _ = dist.hand_blocks(d8, nb, drain, elev)
+        exp = O.height_above_nearest_drain(idxs_ds, seq, drain, elev)
+        assert np.array_equal(got.ravel().view(np.uint64), exp.view(np.uint64)), (tag, d8.shape)
+
+    for shape, nb in (((40, 1), 4), ((40, 3), 5), ((9, 200), 9), ((130, 65), 2), ((300, 5), 7), ((64, 64), 1), ((129, 129), 3)):
+        check(O.synth_d8(shape[0], shape[1], seed=int(rng.integers(1, 999)), tilt=100000, white=2, nodata_pct=10), nb, "random")
+    d8 = O.synth_d8(300, 200, seed=7, tilt=100000, white=2, nodata_pct=0)
+    d8[100:200] = 247
+    check(d8, 3, "middle block all nodata")
+    d8 = O.synth_d8(300, 200, seed=8, tilt=100000, white=2, nodata_pct=0)
+    d8[99:101] = 247
+    check(d8, 3, "nodata rows at the first edge")
+    check(O.synth_d8(256, 256, seed=9, tilt=1 << 26, white=2, nodata_pct=0), 4, "tile-aligned blocks")
