@@ -559,6 +559,7 @@ def run_distributed(a, rank, world, local):
                                parallelism=f"{world} row blocks, 1 all-gather/pass", transport=transport,
                                rccl_world_size=rccl_world, host_group=type(grp).__name__,
                                launcher="self-spawned" if os.environ.get("PFD_BENCH_SPAWNED") else "external",
+                               retried_with_host_transport=bool(os.environ.get("PFD_BENCH_RETRY")),
                                devices_visible=_hip.device_count()),
                    roofline=roof,
                    invariants=dict(result_checksum=csum,
