@@ -24,6 +24,8 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 #include "tiled.h"
@@ -701,7 +703,7 @@ __global__ void k_level_offsets(const u32 *__restrict__ keys, u32 nseq, i64 *__r
 int pfd_order_cells_by_rank(pfd_raster *h, int *ok) {
   *ok = 0;
   const u32 n = h->geo.n;
-  DevBuf keys, keys2, vals;
+  DevBuf keys, keys2;
   PFDCHK(keys.alloc((size_t)n * sizeof(u32)));
   int complete = 0;
   u32 maxrank = 0;
@@ -709,7 +711,6 @@ int pfd_order_cells_by_rank(pfd_raster *h, int *ok) {
   h->acyclic = complete ? 1 : -1;  // (too large for the slot ids also lands here: the level engine serves it)
   if (!complete) return PFD_OK;  // cycles (or raster too large for the slot ids): breadth-first build instead
   PFDCHK(keys2.alloc((size_t)n * sizeof(u32)));
-  PFDCHK(vals.alloc((size_t)n * sizeof(u32)));
   if (h->seq) {  // sorted values need n entries (nodata cells sort to the tail)
     pfd_dfree(h->seq);
     h->bytes_held -= (size_t)h->n_valid * sizeof(u32);
@@ -717,20 +718,20 @@ int pfd_order_cells_by_rank(pfd_raster *h, int *ok) {
   }
   PFDCHK(pfd_dmalloc((void **)&h->seq, (size_t)n * sizeof(u32)));
   h->bytes_held += (size_t)n * sizeof(u32);
-  k_iota<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(vals.as<u32>(), n);
-  KCHK();
-  // nodata keys (0xFFFFFFFF) become maxrank+1, so that sorting on the low `bits` bits is enough
+  // nodata keys (0xFFFFFFFF) become maxrank+1, so that sorting on the low `bits` bits is enough; the clamp and the
+  // cell numbers ride the sort's first pass as iterators (two streaming kernels less: 1.9 of 24.6 ms at 30000^2)
   int bits = 1;
   while ((1ull << bits) <= (u64)maxrank + 1) ++bits;
-  k_clamp_keys<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(keys.as<u32>(), n, maxrank + 1);
-  KCHK();
+  const u32 inval = maxrank + 1;
+  auto keys_in = rocprim::make_transform_iterator(keys.as<u32>(), [inval] __device__(u32 k) { return k > inval ? inval : k; });
+  rocprim::counting_iterator<u32> cells(0u);
   size_t tmp_bytes = 0;
-  HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<u32>(), keys2.as<u32>(), vals.as<u32>(), h->seq, (size_t)n,
-                                   0u, (unsigned)bits, h->stream));
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys2.as<u32>(), cells, h->seq, (size_t)n, 0u, (unsigned)bits,
+                                   h->stream));
   DevBuf tmp;
   PFDCHK(tmp.alloc(tmp_bytes));
-  HIPCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<u32>(), keys2.as<u32>(), vals.as<u32>(), h->seq, (size_t)n, 0u,
-                                   (unsigned)bits, h->stream));
+  HIPCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in, keys2.as<u32>(), cells, h->seq, (size_t)n, 0u, (unsigned)bits,
+                                   h->stream));
   const i64 nlev = (i64)maxrank + 1;
   DevBuf lo;
   PFDCHK(lo.alloc((size_t)(nlev + 1) * sizeof(i64)));
