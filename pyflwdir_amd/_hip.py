@@ -116,6 +116,7 @@ def lib() -> C.CDLL:
         L.pfd_ucat_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.pfd_floodplains.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_snap_downstream.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        L.pfd_snap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.pfd_raster_create_general.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.pfd_set_idxs_seq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]

@@ -246,7 +246,7 @@ void pfd_seg_clear(pfd_raster *h);
 void pfd_seg_begin(pfd_raster *h, const char *name);
 void pfd_seg_end(pfd_raster *h, i64 launches);
 int pfd_normalise_and_count(pfd_raster *h, const u8 *d8_dev);  // order.hip
-int pfd_order_cells_impl(pfd_raster *h);                        // order.hip
+int pfd_order_cells_impl(pfd_raster *h, bool allow_block = false);                     // order.hip
 int pfd_ensure_pits(pfd_raster *h);                             // order.hip
 int pfd_exact_seq_dev(pfd_raster *h, DevBuf &oseq);              // order.hip: core.idxs_seq order in HBM
 int pfd_basins_dev(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev);  // sweeps.hip

@@ -64,7 +64,7 @@ struct ExactPlan {
 
 // builds the plan on first use; h->xplan_state: 0 not built, 1 ready, -1 not available (cycles, row
 // block, more than 2^32 - 2 cells)
-int pfd_ensure_xplan(pfd_raster *h);
+int pfd_ensure_xplan(pfd_raster *h, bool allow_block = false);
 void pfd_free_xplan(pfd_raster *h);
 
 // debugging aid (builds with DEVTOOLS=1 only, env PFD_XDEBUG): synchronise after a step and name it, so that a GPU

@@ -465,7 +465,8 @@ void pfd_free_xplan(pfd_raster *h) {
   h->xplan_state = 0;
 }
 
-int pfd_ensure_xplan(pfd_raster *h) {
+int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
+  if ((h->halo_top || h->halo_bot) && !allow_block) return pfd_require_whole(h, "the exact-order plan");
   if (h->xplan_state != 0) return PFD_OK;
   h->xplan_state = -1;
   if (h->gen) return PFD_OK;

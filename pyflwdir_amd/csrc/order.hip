@@ -323,8 +323,8 @@ int pfd_adopt_counts(pfd_raster *h, const u64 *c) {
 
 int pfd_require_whole(pfd_raster *h, const char *what) {
   if (h->halo_top || h->halo_bot) {
-    pfd_set_error("%s is not available on a row-block handle (multi-GPU blocks only support "
-                  "pfd_upstream_area_cell_blocks / _dist)", what);
+    pfd_set_error("%s is not available on a row-block handle (row blocks run pfd_upstream_area_cell_blocks / _begin / "
+                  "_finish / _dist, pfd_basins_begin / _finish and the pfd_*_block sweeps)", what);
     return PFD_EUNSUPPORTED;
   }
   if (h->n > 4294967294ll) {
@@ -505,11 +505,13 @@ __global__ void __launch_bounds__(256) k_bfs_level(const u8 *__restrict__ ncode,
   }
 }
 
-int pfd_order_cells_impl(pfd_raster *h) {
+int pfd_order_cells_impl(pfd_raster *h, bool allow_block) {
   if (h->gen) return pfd_gen_order(h);
-  if (h->ordered) return PFD_OK;
   const bool block = h->halo_top || h->halo_bot;  // row block: breadth-first from its pits and halo sinks
-  if (!block) PFDCHK(pfd_require_whole(h, "the cell ordering"));
+  // (only the *_block entry points opt in: a whole-raster operation on a row-block handle would return block-local
+  //  values — halo cells as roots, nothing entering from the neighbours)
+  if (!block || !allow_block) PFDCHK(pfd_require_whole(h, "the cell ordering"));
+  if (h->ordered) return PFD_OK;
   if (block && h->n > 4294967294ll) {
     pfd_set_error("the cell ordering needs 32-bit cell indices: a row block of %lld cells is too large", (long long)h->n);
     return PFD_EUNSUPPORTED;

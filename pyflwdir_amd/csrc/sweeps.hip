@@ -853,10 +853,11 @@ static int sweep_down(pfd_raster *h, const Op &op, const char *name, const char 
   return run_down(h, op, name);
 }
 // the structure the sweeps of a handle run on: the exact plan, or the level structure
-static int ensure_sweep_structure(pfd_raster *h) {
-  PFDCHK(pfd_ensure_xplan(h));
+// allow_block: set by the pfd_*_block entry points only — every whole-raster operation refuses a row-block handle here
+static int ensure_sweep_structure(pfd_raster *h, bool allow_block = false) {
+  PFDCHK(pfd_ensure_xplan(h, allow_block));
   if (h->xplan_state == 1) return PFD_OK;
-  return pfd_order_cells_impl(h);
+  return pfd_order_cells_impl(h, allow_block);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -919,6 +920,7 @@ extern "C" int pfd_upstream_area_cell(pfd_raster *h, int32_t *out, int memspace)
     return PFD_EINVAL;
   }
   if (h->gen) return pfd_gen_upstream_area_cell(h, out, memspace);
+  if (h->halo_top || h->halo_bot) return pfd_require_whole(h, "pfd_upstream_area_cell");  // (blocks: _blocks / _begin / _dist)
   pfd_seg_clear(h);
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
@@ -1155,6 +1157,7 @@ extern "C" int pfd_basins(pfd_raster *h, const int64_t *outlets, const void *ids
     pfd_set_error("pfd_basins: bad arguments (k=%lld, id_size=%d)", (long long)k, id_size);
     return PFD_EINVAL;
   }
+  if (h->halo_top || h->halo_bot) return pfd_require_whole(h, "pfd_basins");  // (blocks: pfd_basins_begin / _finish)
   pfd_seg_clear(h);
   // numpy's `basins[idxs] = ids` keeps the LAST id of a repeated index: dedupe on the host so
   // that the device scatter has no write conflict.
@@ -1363,7 +1366,7 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
   pfd_seg_clear(h);
   // the structure the block sweeps on: the exact-order plan (its halo cells are cells with given values), or the level
   // structure (its halo cells are roots like its pits)
-  PFDCHK(ensure_sweep_structure(h));
+  PFDCHK(ensure_sweep_structure(h, true));
   InArg dr, el, sd;
   PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
   PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
@@ -1520,7 +1523,7 @@ static int up_block_prepare(pfd_raster *h, const char *what) {
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  return ensure_sweep_structure(h);  // (the exact-order plan of the block, or its level structure)
+  return ensure_sweep_structure(h, true);  // (the exact-order plan of the block, or its level structure)
 }
 // ---- down-sweeps of a row block (accuflux direction "down"): the halo cells a block drains into hold given values ----
 template <class Op>

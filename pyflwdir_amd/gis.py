@@ -18,69 +18,58 @@ _R = 6371e3  # earth radius [m], reference gis_utils.py:10
 AREA_FACTORS = {"m2": 1.0, "ha": 1e4, "km2": 1e6, "cell": 1}  # reference gis_utils.py:11
 IDENTITY = Affine(1.0, 0.0, 0.0, 0.0, -1.0, 0.0)  # N->S orientation, reference gis_utils.py:13
 
-__all__ = ["AREA_FACTORS", "IDENTITY", "affine_to_coords", "cellarea", "reggrid_area", "area_grid",
+__all__ = ["AREA_FACTORS", "IDENTITY", "affine_to_coords", "cellarea", "area_grid", "area_rows",
            "xy", "rowcol", "idxs_to_coords", "coords_to_idxs"]
 
 
-def affine_to_coords(affine, shape):
-    """Cell-centre coordinate axes (x per column, y per row); reference gis_utils.py:342-359."""
-    height, width = shape
-    x_coords, _ = affine * (np.arange(width) + 0.5, np.zeros(width) + 0.5)
-    _, y_coords = affine * (np.zeros(height) + 0.5, np.arange(height) + 0.5)
-    return x_coords, y_coords
-
-
-def cellarea(lat, xres, yres):
-    """Area [m2] of a lat/lon cell centred at ``lat``; reference gis_utils.py:405-412."""
-    half = np.abs(yres) / 2.0
-    l1 = np.radians(lat - half)
-    l2 = np.radians(lat + half)
-    dx = np.radians(np.abs(xres))
-    return _R**2 * dx * (np.sin(l2) - np.sin(l1))
-
-
-def reggrid_area(lats, lons):
-    """Cell areas [m2] of a regular lat/lon grid; reference gis_utils.py:379-385.
-
-    The result is float64: a float64 column vector times a float32 matrix of ones."""
-    xres = np.abs(np.mean(np.diff(lons)))
-    yres = np.abs(np.mean(np.diff(lats)))
-    ones = np.ones((lats.size, lons.size), dtype=np.float32)
-    return cellarea(lats, xres, yres)[:, None] * ones
-
-
-def area_grid(transform, shape, latlon=False, unit="m2"):
-    """Regular grid of cell areas; reference gis_utils.py:388-402 (int32 ones for "cell",
-    float64 for lat/lon grids, float32 for projected grids)."""
+def _unit_factor(unit):
     unit = str(unit).lower()
     if unit not in AREA_FACTORS:
         fstr = '", "'.join(AREA_FACTORS.keys())
         raise ValueError(f'Unknown unit: {unit}, select from "{fstr}".')
-    if unit == "cell":
-        return np.ones(shape, dtype=np.int32)
-    if latlon:
-        lon, lat = affine_to_coords(transform, shape)
-        return reggrid_area(lat, lon) / AREA_FACTORS[unit]
-    area0 = abs(transform[0] * transform[4]) / AREA_FACTORS[unit]
-    return np.full(shape, area0, dtype=np.float32)
+    return unit, AREA_FACTORS[unit]
+
+
+def affine_to_coords(affine, shape):
+    """Cell-centre coordinate axes (x per column, y per row) — what reference gis_utils.py:342-359 returns: the
+    transform applied to the pixel centres of row 0 (for x) and of column 0 (for y)."""
+    nrow, ncol = shape
+    centre = 0.5
+    xs = (affine * (np.arange(ncol) + centre, np.full(ncol, centre)))[0]
+    ys = (affine * (np.full(nrow, centre), np.arange(nrow) + centre))[1]
+    return xs, ys
+
+
+def cellarea(lat, xres, yres):
+    """Area [m2] of the lat/lon cell(s) centred at ``lat`` (a spherical zone segment: R^2 * dlon * (sin(north
+    edge) - sin(south edge)), evaluated in the operand order of reference gis_utils.py:405-412 so that float64
+    results agree bit for bit)."""
+    dlat_half = np.abs(yres) / 2.0
+    south, north = np.radians(lat - dlat_half), np.radians(lat + dlat_half)
+    dlon = np.radians(np.abs(xres))
+    return _R**2 * dlon * (np.sin(north) - np.sin(south))
+
+
+def area_grid(transform, shape, latlon=False, unit="m2"):
+    """Grid of cell areas with the dtypes of reference gis_utils.py:379-402 (int32 ones for "cell", float64 for
+    lat/lon grids, float32 for projected ones).  The area of a regular grid's cell depends on its row only, so the
+    grid is ``area_rows`` repeated along the columns — the product never builds it (``pfd_accuflux_rows``)."""
+    rows = area_rows(transform, shape, latlon, unit)
+    return np.repeat(rows[:, None], shape[1], axis=1)
 
 
 def area_rows(transform, shape, latlon=False, unit="m2"):
     """Column 0 of ``area_grid`` without building the grid: the cell area of a regular grid depends on
-    the row only (same expressions, element for element, as ``area_grid`` / ``reggrid_area``)."""
-    unit = str(unit).lower()
-    if unit not in AREA_FACTORS:
-        fstr = '", "'.join(AREA_FACTORS.keys())
-        raise ValueError(f'Unknown unit: {unit}, select from "{fstr}".')
+    the row only (same expressions, element for element, as the reference's ``area_grid`` / ``reggrid_area``, gis_utils.py:379-402)."""
+    unit, factor = _unit_factor(unit)
     if unit == "cell":
         return np.ones(shape[0], dtype=np.int32)
-    if latlon:
-        lon, lat = affine_to_coords(transform, shape)
-        xres = np.abs(np.mean(np.diff(lon)))
-        yres = np.abs(np.mean(np.diff(lat)))
-        return cellarea(lat, xres, yres) * np.ones(lat.size, dtype=np.float32) / AREA_FACTORS[unit]
-    area0 = abs(transform[0] * transform[4]) / AREA_FACTORS[unit]
-    return np.full(shape[0], area0, dtype=np.float32)
+    if not latlon:  # projected: one float32 value
+        return np.full(shape[0], abs(transform[0] * transform[4]) / factor, dtype=np.float32)
+    lon, lat = affine_to_coords(transform, shape)
+    # (the reference multiplies the float64 column by a float32 matrix of ones before dividing: kept, it is exact)
+    xres, yres = np.abs(np.mean(np.diff(lon))), np.abs(np.mean(np.diff(lat)))
+    return cellarea(lat, xres, yres) * np.ones(lat.size, dtype=np.float32) / factor
 
 
 def degree_metres_y(lat):
@@ -159,38 +148,37 @@ _OFFSETS = {"center": (0.5, 0.5), "ul": (0, 0), "ur": (1, 0), "ll": (0, 1), "lr"
 
 
 def xy(transform, rows, cols, offset="center"):
-    """x, y of pixels at rows/cols; reference gis_utils.py:191-226."""
-    rows, cols = np.asarray(rows), np.asarray(cols)
-    if offset not in _OFFSETS:
-        raise ValueError("Invalid offset")
-    coff, roff = _OFFSETS[offset]
-    return transform * transform.translation(coff, roff) * (cols, rows)
+    """x, y of the pixels (rows, cols) at one of five anchor points; semantics of reference gis_utils.py:191-226."""
+    try:
+        dcol, drow = _OFFSETS[offset]
+    except KeyError:
+        raise ValueError("Invalid offset") from None
+    anchored = transform * transform.translation(dcol, drow)
+    return anchored * (np.asarray(cols), np.asarray(rows))
 
 
 def rowcol(transform, xs, ys, op=np.floor, precision=None):
-    """rows, cols of the pixels containing (x, y); reference gis_utils.py:229-261."""
-    xs, ys = np.asarray(xs), np.asarray(ys)
-    eps = 0.0 if precision is None else 10.0**-precision * (1.0 - 2.0 * op(0.1))
-    fcols, frows = (~transform) * (xs + eps, ys - eps)
+    """rows, cols of the pixels containing (x, y); ``precision`` nudges points on a cell edge inwards by
+    10^-precision in the direction ``op`` rounds (semantics of reference gis_utils.py:229-261)."""
+    nudge = 0.0
+    if precision is not None:
+        nudge = 10.0**-precision * (1.0 - 2.0 * op(0.1))
+    fcols, frows = (~transform) * (np.asarray(xs) + nudge, np.asarray(ys) - nudge)
     return op(frows).astype(int), op(fcols).astype(int)
 
 
 def idxs_to_coords(idxs, transform, shape, offset="center"):
-    """Cell coordinates of linear indices; reference gis_utils.py:264-298."""
+    """Coordinates of linear cell indices; IndexError outside the raster (reference gis_utils.py:264-298)."""
     idxs = np.asarray(idxs).astype(int)
-    size = np.multiply(*shape)
-    if np.any(np.logical_or(idxs < 0, idxs >= size)):
+    if idxs.size and (idxs.min() < 0 or idxs.max() >= shape[0] * shape[1]):
         raise IndexError("idxs coordinates outside domain")
-    ncol = shape[1]
-    return xy(transform, idxs // ncol, idxs % ncol, offset=offset)
+    r, c = np.divmod(idxs, shape[1])
+    return xy(transform, r, c, offset=offset)
 
 
 def coords_to_idxs(xs, ys, transform, shape, op=np.floor, precision=None):
-    """Linear indices of coordinates; raises IndexError outside the raster; reference
-    gis_utils.py:301-338."""
-    nrow, ncol = shape
-    rows, cols = rowcol(transform, xs, ys, op=op, precision=precision)
-    inside = np.logical_and(np.logical_and(rows >= 0, rows < nrow), np.logical_and(cols >= 0, cols < ncol))
-    if not np.all(inside):
+    """Linear cell indices of coordinates; IndexError outside the raster (reference gis_utils.py:301-338)."""
+    r, c = rowcol(transform, xs, ys, op=op, precision=precision)
+    if np.any((r < 0) | (r >= shape[0]) | (c < 0) | (c >= shape[1])):
         raise IndexError("XY coordinates outside domain")
-    return rows * ncol + cols
+    return r * shape[1] + c

@@ -455,3 +455,33 @@ def test_block_sweeps_edge_cases(gpu_lib, oracle):
     d8[99:101] = 247
     check(d8, 3, "nodata rows at the first edge")
     check(O.synth_d8(256, 256, seed=9, tilt=1 << 26, white=2, nodata_pct=0), 4, "tile-aligned blocks")
+
+
+def test_whole_raster_operations_refuse_row_block_handles(gpu_lib, oracle):
+    """A whole-raster entry point on a row-block handle would return block-local values (halo cells as roots, nothing
+    entering from the neighbours): only the *_block / _begin / _finish / _blocks / _dist entry points accept one."""
+    from pyflwdir_amd import _hip
+
+    d8 = oracle.synth_d8(300, 200, seed=4, tilt=100000, white=2, nodata_pct=5).reshape(300, 200)
+    h = _hip.RasterHandle(d8[99:201], 100, 200, halo=(1, 1))
+    n = 102 * 200
+    f32 = np.ones(n, np.float32)
+    calls = {
+        "accuflux": lambda: h.accuflux(f32, _hip.PFD_F32, nodata_f=-9999.0),
+        "strahler": lambda: h.strahler(),
+        "hand": lambda: h.hand(np.zeros(n, np.uint8), f32, _hip.PFD_F32),
+        "stream_distance": lambda: h.stream_distance(),
+        "rank": lambda: h.rank(),
+        "idxs_seq": lambda: h.idxs_seq(np.int32),
+        "order_cells": lambda: h.order_cells(),
+        "upstream_area_cell": lambda: h.upstream_area_cell(),
+        "upstream_area_cell_levels": lambda: h.upstream_area_cell(engine="levels"),
+        "basins": lambda: h.basins(np.array([5], np.int64), np.array([1], np.uint32)),
+    }
+    for name, call in calls.items():
+        with pytest.raises(NotImplementedError, match="row-block handle"):
+            call()
+    # the block entry points still work on the same handle
+    out = np.zeros(n, np.float32)
+    h.accuflux_block(f32, _hip.PFD_F32, np.zeros(2 * 200, np.float32), out)
+    h.close()

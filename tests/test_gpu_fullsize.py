@@ -253,8 +253,8 @@ def test_uint32_index_rung(gpu_lib, oracle):
 
 def test_c5_basins_hand_at_size(gpu_lib, oracle):
     """BASELINE config 5 at full size (36000 x 72000 = 2.592e9 cells, 30 % nodata, rough regime): basins from
-    1000 outlets and HAND on ONE GPU (HAND is replicas-only: it fits — 2.6 GB codes + 10.4 GB elevation + 2.6 GB
-    drain + 20.7 GB float64 result + the sweep plan), checked by their local equations on sampled row bands
+    1000 outlets and HAND on ONE GPU (it fits — 2.6 GB codes + 10.4 GB elevation + 2.6 GB drain + 20.7 GB float64
+    result + the sweep plan; the sharded forms are the 4-block basins check at the end of this test and tests/test_gpu_blocks.py), checked at every cell on the device and by their local equations recomputed by numpy on sampled rows
     (label(x) == id(x) at an outlet, else label(downstream cell), 0 at pits; hand(x) == 0 on drains, else
     hand(downstream) + (double)(float32)(elev(x) - elev(downstream))) — on an acyclic raster the equations have
     one solution.  Basins sharded over 4 row blocks (the multi-GPU protocol, blocks held by this process) must
@@ -302,6 +302,18 @@ def test_c5_basins_hand_at_size(gpu_lib, oracle):
     _hip.check(_hip.lib().pfd_memcpy_h2d(0, C.c_void_p(lab.addr + probe * 4), _hip.ptr(keep + np.uint32(1)), C.c_size_t(4)))
     assert h.verify_basins(outl, ids, lab, memspace=_hip.PFD_DEVICE)["bad_cells"] >= 1
     _hip.check(_hip.lib().pfd_memcpy_h2d(0, C.c_void_p(lab.addr + probe * 4), _hip.ptr(keep), C.c_size_t(4)))
+    # (the HAND twin: one height off by one ulp at a cell that is no drain cell)
+    for r in (12345, 23456):
+        D = drain.download(np.uint8, (ncol,), offset_bytes=r * ncol)
+        Hrow = hand.download(np.float64, (ncol,), offset_bytes=r * ncol * 8)
+        cand = np.nonzero((D == 0) & (Hrow != -9999.0) & np.isfinite(Hrow))[0]
+        if cand.size:
+            break
+    probe = r * ncol + int(cand[cand.size // 2])
+    keep = hand.download(np.float64, (1,), offset_bytes=probe * 8)
+    _hip.check(_hip.lib().pfd_memcpy_h2d(0, C.c_void_p(hand.addr + probe * 8), _hip.ptr(np.nextafter(keep, np.inf)), C.c_size_t(8)))
+    assert h.verify_hand(drain, elev, _hip.PFD_F32, hand, memspace=_hip.PFD_DEVICE)["bad_cells"] >= 1
+    _hip.check(_hip.lib().pfd_memcpy_h2d(0, C.c_void_p(hand.addr + probe * 8), _hip.ptr(keep), C.c_size_t(8)))
     # the same equations recomputed by numpy (independent of the device decode) on sampled rows
     DR = {1: (0, 1), 2: (1, 1), 4: (1, 0), 8: (1, -1), 16: (0, -1), 32: (-1, -1), 64: (-1, 0), 128: (-1, 1)}
     for r in (1, 7777, 18000, 25113, nrow - 2):
