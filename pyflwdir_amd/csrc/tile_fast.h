@@ -64,6 +64,40 @@ __device__ __forceinline__ bool fx_vote(u32 (*s_flag)[4], int round, u32 tid, bo
   return (f.x | f.y | f.z | f.w) != 0u;
 }
 
+// Where the neighbours of perimeter cell p that lie OUTSIDE the tile live: per slot p up to 5 candidates (3 along an
+// edge, 5 at a corner), each 12 bits pslot | tile delta << 8 (xr_t12) plus the direction k << 12; unused entries name
+// the cell's own slot with k = 8 (a bit no source mask has).  A per-lane constant of the final pass (16 bytes): an
+// entry pulls the totals of the exits that drain into it, and because the candidates are known up front all five
+// loads go out with the first instructions of the kernel — speculatively, the record's source mask (loaded beside them)
+// picks the ones that count.
+struct NbrTab {
+  uint16_t v[PSL][8];
+};
+constexpr NbrTab make_nbr_tab() {
+  NbrTab t{};
+  for (int p = 0; p < PSL; ++p) {
+    int lr = 0, lc = 0;  // pslot_inv
+    if (p < TS) lr = 0, lc = p;
+    else if (p < 2 * TS) lr = TS - 1, lc = p - TS;
+    else if (p < 2 * TS + (TS - 2)) lr = p - 2 * TS + 1, lc = 0;
+    else lr = p - (2 * TS + (TS - 2)) + 1, lc = TS - 1;
+    int cnt = 0;
+    for (int k = 0; k < 8 && p < NPERIM; ++k) {
+      const int dr = (k >= 1 && k <= 3) ? 1 : (k >= 5 ? -1 : 0);
+      const int dc = (k == 0 || k == 1 || k == 7) ? 1 : ((k >= 3 && k <= 5) ? -1 : 0);
+      const int nr = lr + dr, nc = lc + dc;
+      if (nr >= 0 && nr < TS && nc >= 0 && nc < TS) continue;
+      const int qr = nr & (TS - 1), qc = nc & (TS - 1);  // pslot
+      const int ps = qr == 0 ? qc : (qr == TS - 1 ? TS + qc : (qc == 0 ? 2 * TS + (qr - 1) : 2 * TS + (TS - 2) + (qr - 1)));
+      const int d = 3 * ((nr < 0 ? -1 : (nr >= TS ? 1 : 0)) + 1) + (nc < 0 ? -1 : (nc >= TS ? 1 : 0)) + 1;
+      t.v[p][cnt++] = (uint16_t)(ps | (d << 8) | (k << 12));
+    }
+    for (; cnt < 8; ++cnt) t.v[p][cnt] = (uint16_t)((p < NPERIM ? p : 0) | (4 << 8) | (8 << 12));
+  }
+  return t;
+}
+static __device__ __constant__ const NbrTab NBR_TAB = make_nbr_tab();
+
 // ---------------------------------------------------------------------------------------------------------------
 // local pass of an interior tile
 // ---------------------------------------------------------------------------------------------------------------
@@ -150,7 +184,7 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   if (RAW && tid == 0) a.tcnt[(size_t)tr * a.ntc + tc] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 
   // ---- one thread per perimeter slot: an exit's pointer word names its slot -----------------------------------
-  u32 tgt = NONE32;
+  u32 xt12 = XR_NONE;  // target of the exit on this slot (xr_t12)
   int plr = 0, plc = 0;
   if (tid < NPERIM) {
     pslot_inv((int)tid, &plr, &plc);
@@ -158,9 +192,8 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
     if (d8_is_dir(c)) {
       const int k = d8_slot(c);
       const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
-      if ((unsigned)nr >= TS || (unsigned)nc >= TS) {  // inside the raster and valid (normalised codes)
-        const i64 gr = r0 + nr, gc = c0 + nc;
-        tgt = sslot_base((u32)(gr >> 6), (u32)(gc >> 6), a.nstc) + (u32)pslot((int)(gr & 63), (int)(gc & 63));
+      if ((unsigned)nr >= TS || (unsigned)nc >= TS) {  // (the target is inside the raster and valid: normalised codes)
+        xt12 = xr_t12(nr, nc);
         P[PHYS((u32)(plr * TS + plc))] = (uint16_t)(FX_SLOT0 + 2u * tid);
       }
     }
@@ -232,31 +265,28 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   __syncthreads();
 
   // ---- perimeter records for the exit graph -------------------------------------------------------------------
-  u32 xt = 0, link = NONE32;
+  u32 xt = 0, link = XR_NONE, inmask = 0;
   if (tid < NPERIM) {
-    if (tgt != NONE32) {
+    if (xt12 != XR_NONE) {
       const uint4 lo = *(const uint4 *)&A[tid * PREP], hi = *(const uint4 *)&A[tid * PREP + 4];
       xt = lo.x + lo.y + lo.z + lo.w + hi.x + hi.y + hi.z + hi.w;
     }
     const u32 c = CODE(plr, plc);
-    bool entry = false;
-    if (c != D8_MV) {  // entry?  (a neighbour outside the tile drains into this cell)
+    if (c != D8_MV) {  // entry?  (neighbours outside the tile that drain into this cell: the sources of its inflow)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
-        if (((unsigned)nr >= TS || (unsigned)nc >= TS) && CODE(nr, nc) == (1u << ((k + 4) & 7))) entry = true;
+        if (((unsigned)nr >= TS || (unsigned)nc >= TS) && CODE(nr, nc) == (1u << ((k + 4) & 7))) inmask |= 1u << k;
       }
     }
-    if (entry) {  // the exit its in-tile path reaches
+    if (inmask) {  // the exit its in-tile path reaches
       const u32 x = (u32)P[PHYS((u32)(plr * TS + plc))] - FX_SLOT0;
-      if (x < 2u * PSL) link = sbase + (x >> 1);
+      if (x < 2u * PSL) link = x >> 1;
     }
   }
   a.xT[sbase + tid] = xt;
-  a.xtgt[sbase + tid] = tgt;
-  a.elink[sbase + tid] = link;
-  a.inflow[sbase + tid] = 0;  // accumulated by the exit-graph solve
-  const u64 xm = __ballot(tgt != NONE32);  // (a wave = 64 consecutive slots)
+  a.xrec[sbase + tid] = xr_pack(xt12 & 0xFFu, xt12 >> 8, link, inmask);
+  const u64 xm = __ballot(xt12 != XR_NONE);  // (a wave = 64 consecutive slots)
   if ((tid & 63u) == 0u) a.xmask[(sbase + tid) >> 6] = xm;
 }
 
@@ -277,7 +307,23 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
 #pragma unroll
   for (int j = 0; j < QPT; ++j)
     __builtin_memcpy(&cq[j], a.ncode + (size_t)(r0 + (tid >> 4) + 16u * j) * a.ncol + (size_t)(c0 + lcq), 4);
-  const u32 inf = a.inflow[sbase + tid];
+  // flow entering at this perimeter cell: pulled from the exits that drain into it.  All candidates are loaded right
+  // away (NBR_TAB: no load waits for another), the record's source mask selects after the decode below.
+  const u32 rec = a.xrec[sbase + tid];  // (256 slots per tile; slots 252..255 carry no source mask)
+  u32 xc[5], xk[5];
+  {
+    const uint4 nb = *reinterpret_cast<const uint4 *>(NBR_TAB.v[tid]);
+    // slot base of the neighbouring tile with delta code (lane & 15), fetched per candidate with a lane permute
+    const u32 dl = min(tid & 15u, 8u), ql = (dl * 11u) >> 5;
+    const u32 nbase = sslot_base(tr + ql - 1u, tc + (dl - 3u * ql) - 1u, a.nstc);
+    const u32 e5[5] = {nb.x & 0xFFFFu, nb.x >> 16, nb.y & 0xFFFFu, nb.y >> 16, nb.z & 0xFFFFu};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const u32 bs = (u32)__shfl((int)nbase, (int)(((tid & 48u) | ((e5[i] >> 8) & 15u))));
+      xc[i] = a.xtot[bs + (e5[i] & 0xFFu)];
+      xk[i] = e5[i] >> 12;
+    }
+  }
   const u32 sink = FY_SINK0 + 4u * (tid & 63u);
   if (tid < 64u) P[TCELLS + tid] = (uint16_t)sink;  // a sink's pointer word points at the sink
 
@@ -313,11 +359,17 @@ __global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
     *(uint2 *)&P[l0] = make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
     lv[j] = !(pc[4 * j + 0] & pc[4 * j + 1] & pc[4 * j + 2] & pc[4 * j + 3] & FY_SINK0);
   }
+  u32 inf = 0;
+  {
+    const u32 m = (rec >> 16) & 0xFFu;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) inf += ((m >> xk[i]) & 1u) ? xc[i] : 0u;
+  }
   __syncthreads();
-  if (tid < NPERIM && inf) {  // flow entering the tile from its neighbours
-    int lr, lc;
-    pslot_inv((int)tid, &lr, &lc);
-    A[PHYS((u32)(lr * TS + lc))] += inf;
+  if (inf) {  // (one slot per perimeter cell: no two threads share a word)
+    int plr, plc;
+    pslot_inv((int)tid, &plr, &plc);
+    A[PHYS((u32)(plr * TS + plc))] += inf;
   }
   __syncthreads();
 

@@ -41,32 +41,59 @@ __host__ __device__ inline void sslot_inv(u32 s, u32 nstc, u32 *tr, u32 *tc, u32
   *p = s & 255;
 }
 
+// Per-slot record of the local tile pass (one u32, xrec):
+//   bits 0..7   EXIT sitting on this perimeter slot: perimeter slot (0..251) of the cell it drains into, inside the
+//               neighbouring tile named by bits 24..27; XR_NONE if the slot holds no exit
+//   bits 8..15  ENTRY: local slot (0..251) of the exit its in-tile path reaches, XR_NONE if none (no entry, or the
+//               path ends in a pit / halo sink)
+//   bits 16..23 ENTRY: mask of the neighbour positions k OUTSIDE the tile whose cell drains into this one — the
+//               exits whose totals the final tile pass pulls (slot_inflow()); no delivery pass, no atomics
+//   bits 24..27 EXIT: the tile it drains into, 3 * (dtr + 1) + (dtc + 1)
+#define XR_NONE 0xFFu
+__host__ __device__ inline u32 xr_pack(u32 tslot, u32 tdelta, u32 link, u32 inmask) {
+  return tslot | (link << 8) | (inmask << 16) | (tdelta << 24);
+}
+// target slot of an exit of tile (tr, tc) from the 12 bits that describe it: pslot | delta << 8
+__host__ __device__ inline u32 xr_target12(u32 tr, u32 tc, u32 t12, u32 nstc);
+
+__host__ __device__ inline u32 xr_target12(u32 tr, u32 tc, u32 t12, u32 nstc) {
+  const u32 d = t12 >> 8;  // 3 * (dtr + 1) + (dtc + 1)
+  const u32 q = (d * 11u) >> 5;  // d / 3 for d < 9
+  return sslot_base(tr + q - 1u, tc + (d - 3u * q) - 1u, nstc) + (t12 & 0xFFu);
+}
+
 // level-2 (supertile) solve arguments
 struct SuperArgs {
   u32 nst;          // number of supertiles
-  const u32 *xT, *xtgt, *elink;  // xT = start values of the solve
-  // exit lists, built once per pass by k_exit_lists (one entry per exit, in slot order, at offset st << SSHIFT):
+  const u32 *xT;    // [nslots] start values of the solve (tile-local count of the exit on the slot)
+  const u32 *xrec;  // [nslots] records of the local tile pass (above)
+  // exit lists, built once per pass by k_exit_lists (one entry per exit, in slot order, at offset st << SSHIFT).
+  // Everything the solves keep PER EXIT lives in list order (dense, coalesced), not per slot:
   const u64 *xmask;           // [nslots / 64] exit bitmasks written by the local tile pass
-  uint16_t *xl_slot;          // [nslots] slot of the e-th exit of the supertile (local: 14 bits)
+  uint16_t *xcb;              // [nslots / 64] exits of the supertile before this 64-slot word: list index of a slot =
+                              // xcb[slot >> 6] + popcount(xmask[slot >> 6] below the slot)  (xl_index())
+  uint16_t *xl_slot;          // [nslots] slot of the e-th exit of the supertile (local: 14 bits) | XL_SX
   uint16_t *xl_next;          // [nslots] list index of the exit its flow reaches next inside the supertile | SDONE
   u32 *scount;                // [nst] exits of the supertile
   u32 *nflag, *flagged;       // supertiles with more exits than scap (contrived rasters): count, list
-  u32 *xin;         // [nslots] flow entering the supertile at this exit (from other supertiles)
-  u32 *R2;          // [nslots] last exit (slot) of the exit's path inside its supertile
-  u32 *sxid;        // [nslots] dense id of a super-exit (drains into another supertile), else NONE32
+  u32 *xinL;        // [nslots, list order] flow entering the supertile at this exit (from other supertiles)
+  uint16_t *R2L;    // [nslots, list order] list index of the last exit of the exit's path inside its supertile
+  u32 *sxidL;       // [nslots, list order] dense id of a super-exit (drains into another supertile), else NONE32
   u32 *sx_slot;     // [nsuper] slot of the super-exit
+  u32 *sx_n1;       // [nsuper] list position (global: supertile base + list index) of the exit the flow through the
+                    // super-exit reaches first in the supertile it enters, NONE32 if none; written by k_link3
   u32 *T3;          // [nsuper] level-3 start value (= supertile-local total of the super-exit)
-  u32 *inflow;      // [nslots] (final pass) flow delivered to the tile entries
+  u32 *xtot;        // [nslots] (final pass) total of the exit on the slot: pulled by the tile entries it drains into
   u64 *ctrl;
   u32 nstc, nhtc;   // supertiles / hypertiles per row
   u32 *hcnt;        // [nht] super-exits per hypertile (hmode 1: ids = ht*HCAP + rank)
   int hmode;        // 1: per-hypertile ids (level 3 solved in LDS), 0: one flat id range
-  int bonly;        // final pass over the flow entering from other row blocks only (xT ignored)
-  u32 edge_nstr;    // final pass: != 0 -> only the first and last of the edge_nstr supertile rows deliver
+  u32 edge_nstr;    // final pass: != 0 -> only the first and last of the edge_nstr supertile rows are solved
   u32 ntr, ntc;     // tiles per column / row (slots of tiles beyond them do not exist)
   u32 hcap;         // super-exits per hypertile that fit in LDS (HCAP; lowered by tests via PFD_TEST_HCAP)
-  u8 *sover;        // [nst] set by k_super<false>: the supertile holds more exits than the dense form keeps in LDS
+  u8 *sover;        // [nst] set by k_exit_lists: the supertile holds more exits than the dense form keeps in LDS
   u32 scap;         // that capacity (SCAP; lowered by tests via PFD_TEST_SCAP)
+  int ablate;       // DEVTOOLS experiments (PFD_SUPER_ABLATE): 1 skip the rounds, 2 skip the outputs, 4 no start-value gather
 };
 
 // level-3 (hypertile = 4x4 supertiles) solve arguments; node ids k = ht*HCAP + i, i < hcnt[ht]
@@ -98,9 +125,8 @@ struct TileArgs {
   u32 row_first, row_last;  // owned rows (inclusive) of the device raster; the rest are halo rows
   u32 nstc;        // supertiles per row; slot ids are supertile-major (sslot_base)
   u32 *xT;         // [nslots] tile-local count of the exit sitting on this perimeter slot
-  u32 *xtgt;       // [nslots] slot the exit drains into, NONE32 if the slot holds no exit
-  u32 *elink;      // [nslots] slot of the exit an entry's in-tile path reaches, NONE32 if none
-  u32 *inflow;     // [nslots] sum of the totals of the exits draining into this slot
+  u32 *xrec;       // [nslots] exit direction | entry link | entry source mask (xr_pack, above)
+  const u32 *xtot; // [nslots] (final pass) totals of the exits, pulled by the entries they drain into
   u64 *xmask;      // [nslots / 64] bit = the slot holds an exit (one wave ballot per 64 slots of a tile): what the
                    // exit lists of the supertile solve are built from (k_exit_lists)
   u32 *esink;      // [2*ntc*PSL] first/last tile row: halo sink an entry's in-tile path ends on
@@ -163,6 +189,38 @@ __device__ __forceinline__ void pslot_inv(int p, int *lr, int *lc) {
     *lr = p - (2 * TS + (TS - 2)) + 1;
     *lc = TS - 1;
   }
+}
+
+// slot of the cell that neighbours perimeter cell (lr, lc) of tile (tr, tc) in direction k and lies OUTSIDE the tile
+// (the caller knows it does): the cell sits on the perimeter of one of the 8 neighbouring tiles
+__device__ __forceinline__ u32 nbr_slot(u32 tr, u32 tc, int lr, int lc, int k, u32 nstc) {
+  const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);  // in [-1, TS]
+  const u32 ttr = tr + (u32)(nr >> 6), ttc = tc + (u32)(nc >> 6);  // (arithmetic shift: -1 -> -1, 0..63 -> 0, 64 -> 1)
+  return sslot_base(ttr, ttc, nstc) + (u32)pslot(nr & (TS - 1), nc & (TS - 1));
+}
+// the 12 bits that name the cell an exit drains into: perimeter slot inside its tile | tile delta << 8
+__device__ __forceinline__ u32 xr_t12(int nr, int nc) {  // (nr, nc) in [-1, TS], outside [0, TS)
+  return (u32)pslot(nr & (TS - 1), nc & (TS - 1)) | ((u32)(3 * ((nr >> 6) + 1) + (nc >> 6) + 1) << 8);
+}
+// target slot of the exit on slot `s` with record `rec`
+__device__ __forceinline__ u32 xr_target(u32 s, u32 rec, u32 nstc) {
+  u32 tr, tc, p;
+  sslot_inv(s, nstc, &tr, &tc, &p);
+  return xr_target12(tr, tc, (rec & 0xFFu) | ((rec >> 16) & 0xF00u), nstc);
+}
+// flow entering the tile at perimeter cell (lr, lc): the totals of the exits named by the record's source mask
+__device__ __forceinline__ u32 slot_inflow(const u32 *__restrict__ xtot, u32 rec, u32 tr, u32 tc, int lr, int lc, u32 nstc) {
+  u32 m = (rec >> 16) & 0xFFu, v = 0;
+  while (m) {
+    const int k = __ffs((int)m) - 1;
+    m &= m - 1u;
+    v += xtot[nbr_slot(tr, tc, lr, lc, k, nstc)];
+  }
+  return v;
+}
+// list index (inside its supertile) of the exit on slot s
+__device__ __forceinline__ u32 xl_index(const u64 *__restrict__ xmask, const uint16_t *__restrict__ xcb, u32 s) {
+  return (u32)xcb[s >> 6] + (u32)__popcll(xmask[s >> 6] & ((1ull << (s & 63u)) - 1ull));
 }
 
 // LDS layout of the staged codes: 66 rows (1-cell halo) x 72 bytes; column lc in [-1, 64] lives
@@ -241,12 +299,13 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (7 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf, xmaskbuf, xlbuf, scountbuf, flaggedbuf;
+  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf, xmaskbuf, xlbuf, scountbuf, flaggedbuf, xcbbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;
-  u32 *xT = nullptr, *xtgt = nullptr, *elink = nullptr, *inflow = nullptr, *xin = nullptr,
-      *R2 = nullptr, *sxid = nullptr, *sx_slot = nullptr;
+  u32 *xT = nullptr, *xrec = nullptr, *xtot = nullptr, *xinL = nullptr, *sxidL = nullptr, *sx_slot = nullptr,
+      *sx_n1 = nullptr;
+  uint16_t *R2L = nullptr;
   SuperArgs sa{};
   u32 *brow_first = nullptr, *haloA = nullptr, *haloL = nullptr, *brow_sink = nullptr, *brow_inflow = nullptr;
   u32 *Tc = nullptr, *Tn = nullptr, *Jc = nullptr, *Jn = nullptr, *xin3 = nullptr, *R3 = nullptr, *hx_id = nullptr;

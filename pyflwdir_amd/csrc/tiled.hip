@@ -136,7 +136,11 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
       }
     }
     u32 inf = 0;
-    if (FINAL) inf = a.inflow[sbase + tid];  // 256 slots per tile: always in bounds
+    if (FINAL && tid < NPERIM) {  // flow entering at this perimeter cell: pulled from the exits that drain into it
+      int lr, lc;
+      pslot_inv((int)tid, &lr, &lc);
+      inf = slot_inflow(a.xtot, a.xrec[sbase + tid], tr, tc, lr, lc, a.nstc);
+    }
     if (!FINAL) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
@@ -437,8 +441,7 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
 
   if (a.ablate & 8) return;
   // ---- perimeter records for the coarse graph ------------------------------------------------
-  u32 xt = 0, tgt = NONE32;
-  bool entry = false;
+  u32 xt = 0, xt12 = XR_NONE, inmask = 0;  // xt12: target of the exit (xr_t12)
   int plr = 0, plc = 0;
   if (tid < NPERIM) {
     pslot_inv((int)tid, &plr, &plc);
@@ -447,9 +450,8 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
       if (d8_is_dir(c)) {  // exit?
         const int k = d8_slot(c);
         const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
-        if ((unsigned)nr >= TS || (unsigned)nc >= TS) {
-          const i64 gr = r0 + nr, gc = c0 + nc;  // inside the raster and valid (normalised codes)
-          tgt = sslot_base((u32)(gr >> 6), (u32)(gc >> 6), a.nstc) + (u32)pslot((int)(gr & 63), (int)(gc & 63));
+        if ((unsigned)nr >= TS || (unsigned)nc >= TS) {  // (the target is inside the raster and valid: normalised codes)
+          xt12 = xr_t12(nr, nc);
           if (!PERIM) {
             xt = A[PHYS((u32)(plr * TS + plc))];
           } else {
@@ -464,10 +466,11 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
       for (int k = 0; k < 8; ++k) {
         const int nr = plr + d8_dr(k), nc = plc + d8_dc(k);
         if (((unsigned)nr >= TS || (unsigned)nc >= TS) && CODE(nr, nc) == (1u << ((k + 4) & 7)))
-          entry = true;
+          inmask |= 1u << k;
       }
     }
   }
+  const bool entry = inmask != 0u;
   __syncthreads();
   // where does the in-tile path of a cell end?  -> exit slot, halo sink (row block), or nothing
   auto path_end = [&](u32 l) -> u32 {
@@ -492,10 +495,8 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, u32 *A, uint16_t *P
         link = e;  // slot of the exit the entry's path reaches
     }
     a.xT[sbase + tid] = xt;
-    a.xtgt[sbase + tid] = tgt;
-    a.elink[sbase + tid] = link;
-    a.inflow[sbase + tid] = 0;  // accumulated by the exit-graph solve
-    const u64 xm = __ballot(tgt != NONE32);  // (tid < PSL = all 256 threads: a wave = 64 consecutive slots)
+    a.xrec[sbase + tid] = xr_pack(xt12 & 0xFFu, xt12 >> 8, link != NONE32 ? link - sbase : XR_NONE, inmask);
+    const u64 xm = __ballot(xt12 != XR_NONE);  // (tid < PSL = all 256 threads: a wave = 64 consecutive slots)
     if ((tid & 63u) == 0u) a.xmask[(sbase + tid) >> 6] = xm;
     if (tr == 0) a.esink[(size_t)tc * PSL + tid] = esink;
     if (tr == a.ntr - 1 && a.ntr > 1) a.esink[((size_t)a.ntc + tc) * PSL + tid] = esink;
@@ -629,7 +630,7 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
   const u32 base = st << SSHIFT;
   const u32 i0 = (part << 10) + 4u * tid;  // own slots i0 .. i0 + 3
   // (unconditional: slots of tiles beyond the raster edge are allocated, never written and have no mask bit)
-  const uint4 tg = *reinterpret_cast<const uint4 *>(s.xtgt + base + i0);
+  const uint4 rc = *reinterpret_cast<const uint4 *>(s.xrec + base + i0);
   {
     const u64 m = s.xmask[(base >> 6) + tid];  // the 256 ballot words of the supertile
     maskw[tid] = m;
@@ -647,6 +648,7 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
     u32 woff = 0;
     for (u32 w = 0; w < wave; ++w) woff += wsum[w];
     cbase[tid] += woff;
+    if (part == 0) s.xcb[(base >> 6) + tid] = (uint16_t)cbase[tid];  // slot -> list index for everybody else (xl_index)
   }
   if (part == 0 && tid == 0) {
     const u32 n = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -658,19 +660,28 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
   auto dense = [&](u32 i) -> u32 { return cbase[i >> 6] + (u32)__popcll(maskw[i >> 6] & ((1ull << (i & 63u)) - 1ull)); };
   const u32 own = (u32)(maskw[i0 >> 6] >> (i0 & 63u)) & 15u;  // (4 | i0: the four bits sit in one word)
   if (!own) return;
-  const u32 tgt[4] = {tg.x, tg.y, tg.z, tg.w};
-  u32 l[4];
+  // the four slots share their tile: position of the tile, perimeter cell of the first slot
+  const u32 tl = i0 >> 8;
+  const u32 tr = (st / s.nstc) * SG + (tl >> 3), tc = (st % s.nstc) * SG + (tl & 7u);
+  const u32 rec[4] = {rc.x, rc.y, rc.z, rc.w};
+  u32 tgt[4], l[4], t12[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {  // the exit reached from the tile entry it drains into (same tile => same supertile)
-    l[j] = NONE32;
-    if (((own >> j) & 1u) && (tgt[j] >> SSHIFT) == st) l[j] = s.elink[tgt[j]];
+  for (int j = 0; j < 4; ++j) {  // the exit reached from the tile entry it drains into
+    tgt[j] = NONE32, l[j] = XR_NONE;
+    t12[j] = (rec[j] & 0xFFu) | ((rec[j] >> 16) & 0xF00u);
+    if ((own >> j) & 1u) {
+      tgt[j] = xr_target12(tr, tc, t12[j], s.nstc);
+      if ((tgt[j] >> SSHIFT) == st) l[j] = (s.xrec[tgt[j]] >> 8) & 0xFFu;
+    }
   }
   u32 d = dense(i0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (!((own >> j) & 1u)) continue;
-    const u32 nx = l[j] != NONE32 ? dense(l[j] & (SSL - 1)) : (d | SDONE);
-    s.xl_slot[base + d] = (uint16_t)((i0 + j) | ((tgt[j] >> SSHIFT) != st ? XL_SX : 0u));
+    const bool sx = (tgt[j] >> SSHIFT) != st;
+    // (a super-exit is a root of its supertile: its entry carries the 12 bits that name the exit's target instead)
+    const u32 nx = sx ? (SDONE | t12[j]) : (l[j] != XR_NONE ? dense((tgt[j] & (SSL - 1) & ~255u) | l[j]) : (d | SDONE));
+    s.xl_slot[base + d] = (uint16_t)((i0 + j) | (sx ? XL_SX : 0u));
     s.xl_next[base + d] = (uint16_t)nx;
     ++d;
   }
@@ -691,29 +702,32 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
   const u32 base = st << SSHIFT;
   constexpr int DPT = CAP / 1024;  // exits per thread
   if (FINAL && s.edge_nstr) {
-    // row blocks, first solve: only the deliveries into the first and last TILE row are needed yet; they
-    // come from exits in tile rows 0..1 and ntr-2..ntr-1 -> supertile row 0 and the rows of those two
+    // row blocks, first solve: only the totals pulled by the first and last TILE row are needed yet; they
+    // belong to exits in tile rows 0..1 and ntr-2..ntr-1 -> supertile row 0 and the rows of those two
     const u32 row = st / s.nstc;
     if (row != 0 && row != (s.ntr - 1) / SG && row != (s.ntr >= 2 ? (s.ntr - 2) / SG : 0u)) return;
   }
   const u32 n = s.scount[st];
-  // ---- the exits: list entry -> slot, then start value and next hop; all loads of a step are independent ----
+  // ---- the exits: list entry -> slot, start value, next hop; dense loads but for the start value ----
   u32 sxbits = 0;  // bit k: own exit k (tid + 1024 k) drains into another supertile
 #pragma unroll 4
   for (int k = 0; k < DPT; ++k) {
     const u32 e = tid + 1024u * k;
     if (e >= n) continue;
     const u32 w = s.xl_slot[base + e];
-    const u32 g = base + (w & (SSL - 1));
-    u32 t = (FINAL && s.bonly) ? 0u : s.xT[g];
+    u32 nx = s.xl_next[base + e];
+    u32 t = (s.ablate & 4) ? 1u : s.xT[base + (w & (SSL - 1))];
     if (FINAL) {
-      t += s.xin[g];
+      t += s.xinL[base + e];
     } else {
-      s.xin[g] = 0;  // accumulated by k_push3 before the final pass reads it
-      sxbits |= (w & XL_SX) ? 1u << k : 0u;
+      s.xinL[base + e] = 0;  // accumulated by k_push3 before the final pass reads it
+    }
+    if (w & XL_SX) {  // a super-exit is a root; its list entry names its target instead of a next hop
+      if (!FINAL) sxbits |= 1u << k;
+      nx = e | SDONE;
     }
     T[e] = t;
-    P[e] = s.xl_next[base + e];
+    P[e] = (uint16_t)nx;
   }
   __syncthreads();
   // ---- doubling over the exits ----
@@ -728,46 +742,74 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
       y[k] = p & (SDONE - 1u);
       live |= (p & SDONE) ? 0u : 1u << k;
     }
+    if (!FINAL) {
+      // The first solve only needs ROOTS (the last exit of every path inside the supertile) and the total per root
+      // (the start value of a super-exit at level 3) — like the local tile pass it jumps pointers without values:
+      // gather-only, two jumps per round, one barrier per round (a read that sees a pointer its owner has already
+      // advanced just jumps further), and every exit adds its start value to its root afterwards.
+      u32 nonroot = live;
 #pragma nounroll
-    for (int round = 0; round < MAXROUNDS_SUPER; ++round) {
-      u32 av[DPT], q[DPT];
+      for (int round = 0; round < ((s.ablate & 1) ? 0 : MAXROUNDS_SUPER); ++round) {
 #pragma unroll
-      for (int k = 0; k < DPT; ++k) {
-        if (live & (1u << k)) {
-          av[k] = T[tid + 1024u * k];
-          q[k] = P[y[k]];
+        for (int k = 0; k < DPT; ++k) {
+          if (live & (1u << k)) {
+            u32 q = P[y[k]];
+            q = P[q & (SDONE - 1u)];
+            P[tid + 1024u * k] = (uint16_t)q;
+            y[k] = q & (SDONE - 1u);
+            if (q & SDONE) live &= ~(1u << k);
+          }
         }
+        if (!wg_vote<16>(s_flag, round, tid, live != 0u)) break;
       }
+#pragma unroll
+      for (int k = 0; k < DPT; ++k)  // (nobody adds to the word of an exit that is no root: reading it here is safe)
+        if (nonroot & ~live & (1u << k)) atomicAdd(&T[y[k]], T[tid + 1024u * k]);
       __syncthreads();
+    } else {
+#pragma nounroll
+      for (int round = 0; round < ((s.ablate & 1) ? 0 : MAXROUNDS_SUPER); ++round) {
+        u32 av[DPT], q[DPT];
 #pragma unroll
-      for (int k = 0; k < DPT; ++k) {
-        if (live & (1u << k)) {
-          atomicAdd(&T[y[k]], av[k]);
-          P[tid + 1024u * k] = (uint16_t)q[k];
-          y[k] = q[k] & (SDONE - 1u);
-          if (q[k] & SDONE) live &= ~(1u << k);
+        for (int k = 0; k < DPT; ++k) {
+          if (live & (1u << k)) {
+            av[k] = T[tid + 1024u * k];
+            q[k] = P[y[k]];
+          }
         }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DPT; ++k) {
+          if (live & (1u << k)) {
+            atomicAdd(&T[y[k]], av[k]);
+            P[tid + 1024u * k] = (uint16_t)q[k];
+            y[k] = q[k] & (SDONE - 1u);
+            if (q[k] & SDONE) live &= ~(1u << k);
+          }
+        }
+        if (!wg_vote<16>(s_flag, round, tid, live != 0u)) break;
       }
-      if (!wg_vote<16>(s_flag, round, tid, live != 0u)) break;
     }
-    if (live) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the supertile
+    if (live && !(s.ablate & 1)) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the supertile
   }
-  if (FINAL) {  // every exit delivers its total to the tile entry it drains into
+  if (s.ablate & 2) return;
+  if (FINAL) {  // the total of every exit, where the tile entries it drains into will pull it
 #pragma unroll 4
     for (int k = 0; k < DPT; ++k) {
       const u32 e = tid + 1024u * k;
-      if (e < n) atomicAdd(&s.inflow[s.xtgt[base + (s.xl_slot[base + e] & (SSL - 1))]], T[e]);
+      if (e < n) s.xtot[base + (s.xl_slot[base + e] & (SSL - 1))] = T[e];
     }
     return;
   }
   // ---- records of the pass: super-exits (exits that drain into another supertile) get dense ids (order is
-  //      irrelevant) and start values for level 3; R2 = slot of the last exit of the path inside the supertile
+  //      irrelevant) and start values for level 3; per exit (list order) the last exit of its path inside the supertile
   u32 wcnt = 0;  // (wave-uniform) super-exits of this wave
 #pragma unroll
   for (int k = 0; k < DPT; ++k) wcnt += (u32)__popcll(__ballot((sxbits >> k) & 1u));
   if (lane == 0) wtot[wave] = wcnt;
   __syncthreads();
-  const u32 ht = ((st / s.nstc) / HG) * s.nhtc + (st % s.nstc) / HG;
+  const u32 str = st / s.nstc, stc = st % s.nstc;
+  const u32 ht = (str / HG) * s.nhtc + stc / HG;
   if (tid == 0) {
     u32 tot = 0;
     for (int w = 0; w < 16; ++w) {
@@ -787,40 +829,26 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
   }
   __syncthreads();
   u32 run = s_base + wtot[wave];
-  u32 id[DPT];
-  uint16_t sl[DPT];  // slots of the own exits
 #pragma unroll
   for (int k = 0; k < DPT; ++k) {
     const u32 e = tid + 1024u * k;
-    sl[k] = e < n ? (uint16_t)(s.xl_slot[base + e] & (SSL - 1)) : (uint16_t)0;
-  }
-#pragma unroll
-  for (int k = 0; k < DPT; ++k) {
     const bool sx = (sxbits >> k) & 1u;
     const u64 m = __ballot(sx);
-    id[k] = NONE32;
+    u32 id = NONE32;
     if (sx) {
-      id[k] = run + (u32)__popcll(m & ((1ull << lane) - 1ull));
-      s.sx_slot[id[k]] = base + sl[k];
-      s.T3[id[k]] = T[tid + 1024u * k];
+      id = run + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      const u32 sl = (u32)s.xl_slot[base + e] & (SSL - 1);
+      s.sx_slot[id] = base + sl;
+      // (sx_n1 doubles as the target slot of the super-exit until k_link3 turns it into a list position)
+      s.sx_n1[id] = xr_target12(str * SG + (sl >> 11), stc * SG + ((sl >> 8) & 7u), (u32)s.xl_next[base + e] & 0xFFFu, s.nstc);
+      s.T3[id] = T[e];
     }
     run += (u32)__popcll(m);
-  }
-  __syncthreads();  // (T has been read: it now holds the slot of every exit, for the roots' sake)
-#pragma unroll
-  for (int k = 0; k < DPT; ++k) {
-    const u32 e = tid + 1024u * k;
-    if (e < n) T[e] = sl[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < DPT; ++k) {
-    const u32 e = tid + 1024u * k;
-    if (e >= n) continue;
-    const u32 g = base + sl[k];
-    // (masked: on a cycle the pointer is not saturated and its word no root; the pass is discarded then)
-    s.R2[g] = base + (T[min(P[e] & (SDONE - 1u), CAP - 1u)] & (SSL - 1));
-    s.sxid[g] = id[k];
+    if (e < n) {
+      // (on a cycle the pointer is not saturated and names an ancestor instead of a root; the pass is discarded then)
+      s.R2L[base + e] = (uint16_t)(P[e] & (SDONE - 1u));
+      s.sxidL[base + e] = id;
+    }
   }
 }
 
@@ -855,26 +883,28 @@ __global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__r
     J3[k] = k | XDONE;
     return;
   }
-  const u32 e = s.sx_slot[k];
-  const u32 n1 = s.elink[s.xtgt[e]];
-  u32 j = k | XDONE;
-  if (n1 != NONE32) {
-    // (sxid is only written at exit slots: on a raster with cycles R2 may name any slot — ask xtgt first)
-    const u32 r2 = s.R2[n1];
-    const u32 id = s.xtgt[r2] != NONE32 ? s.sxid[r2] : NONE32;
+  const u32 tgt = s.sx_n1[k];                    // target slot (left there by the supertile solve)
+  const u32 xe = (s.xrec[tgt] >> 8) & 0xFFu;     // exit the target entry's in-tile path reaches
+  u32 j = k | XDONE, pos = NONE32;
+  if (xe != XR_NONE) {
+    const u32 n1 = (tgt & ~255u) | xe, b1 = n1 & ~(u32)(SSL - 1);
+    pos = b1 + xl_index(s.xmask, s.xcb, n1);
+    const u32 id = s.sxidL[b1 + s.R2L[pos]];    // the supertile's last exit on that path: a super-exit?
     if (id != NONE32) j = id;
   }
+  s.sx_n1[k] = pos;
   J3[k] = j;
 }
 // flow through a super-exit enters the next supertile at the exit its target entry leads to
+// (the super-exit's own total reaches the tile entry it drains into through xtot, like any exit's)
 __global__ void __launch_bounds__(256) k_push3(SuperArgs s, u32 nsuper, const u32 *__restrict__ T3final) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nsuper || (s.hmode && s.ctrl[T_OVERFLOW]) || !sx_active(s, k)) return;
-  const u32 tgt = s.xtgt[s.sx_slot[k]];
-  const u32 n1 = s.elink[tgt];
-  // (the delivery to the tile entry itself happens in the final supertile pass, where the
-  // super-exit's total is T3final again)
-  if (n1 != NONE32) atomicAdd(&s.xin[n1], T3final[k]);
+  const u32 pos = s.sx_n1[k];
+  if (pos != NONE32) {
+    if (s.ablate & 8) s.xinL[pos] = T3final[k];
+    else atomicAdd(&s.xinL[pos], T3final[k]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1128,31 +1158,37 @@ int pfd_doubling_rounds(pfd_raster *h, u32 *T[3], u32 *J[2], u32 n, int first_ba
 // ---------------------------------------------------------------------------------------------
 // flow collected by a halo sink = what reached it inside its tile (haloA) + the inflow of the
 // tile entries whose in-tile path ends on it
-__global__ void __launch_bounds__(256) k_halo_collect(const u32 *__restrict__ esink, const u32 *__restrict__ inflow,
-                                                      u32 ntc, u32 ntr, u32 nstc, u32 ncol, u32 *__restrict__ haloL,
-                                                      u32 n) {
+__global__ void __launch_bounds__(256) k_halo_collect(const u32 *__restrict__ esink, const u32 *__restrict__ xrec,
+                                                      const u32 *__restrict__ xtot, u32 ntc, u32 ntr, u32 nstc, u32 ncol,
+                                                      u32 *__restrict__ haloL, u32 n) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const u32 e = esink[t];
   if (e == NONE32) return;
   // region 0 = tile row 0, region 1 = last tile row
   const u32 reg = t / (ntc * PSL), tc = (t % (ntc * PSL)) / PSL, p = t % PSL;
-  const u32 v = inflow[sslot_base(reg ? ntr - 1 : 0, tc, nstc) + p];
+  const u32 tr = reg ? ntr - 1 : 0;
+  int lr, lc;
+  pslot_inv((int)p, &lr, &lc);
+  const u32 v = slot_inflow(xtot, xrec[sslot_base(tr, tc, nstc) + p], tr, tc, lr, lc, nstc);
   if (v) atomicAdd(&haloL[((e & ENC_SIDE1) ? ncol : 0u) + (e & ENC_COL)], v);
 }
-// last exit on the path of exit f, by O(1) lookups in the hierarchy built by the solve:
+// last exit on the path of the exit on slot f, by O(1) lookups in the hierarchy built by the solve:
 // supertile root -> (level 3) last super-exit [-> (level 4) last hyper-exit -> hypertile root] ->
 // the supertile the path finally enters -> its root
 struct LastExitArgs {
-  const u32 *R2, *sxid, *sx_slot, *xtgt, *elink;
+  const u64 *xmask;
+  const uint16_t *xcb, *xl_slot, *R2L;
+  const u32 *sxidL, *sx_slot, *sx_n1, *xrec;
   const u32 *J3;       // hyper mode: level-3 links; flat mode: saturated level-3 pointers
   const u32 *R3, *hx_id, *hx_node, *J4fin;  // hyper mode only
   int hmode;
 };
 __device__ __forceinline__ u32 last_exit(const LastExitArgs &q, u32 f) {
-  const u32 r2 = q.R2[f];
-  const u32 k = q.xtgt[r2] != NONE32 ? q.sxid[r2] : NONE32;  // (sxid is only written at exit slots)
-  if (k == NONE32) return r2;  // the path ends inside this supertile
+  const u32 b = f & ~(u32)(SSL - 1);
+  const u32 r2 = q.R2L[b + xl_index(q.xmask, q.xcb, f)];  // list index of the supertile's last exit on the path
+  const u32 k = q.sxidL[b + r2];
+  if (k == NONE32) return b + (q.xl_slot[b + r2] & (SSL - 1));  // the path ends inside this supertile
   u32 k3;
   if (q.hmode) {
     k3 = q.R3[k];  // last super-exit inside the hypertile
@@ -1164,9 +1200,10 @@ __device__ __forceinline__ u32 last_exit(const LastExitArgs &q, u32 f) {
   } else {
     k3 = q.J3[k] & ~XDONE;
   }
-  const u32 e = q.sx_slot[k3];
-  const u32 n1 = q.elink[q.xtgt[e]];
-  return (n1 == NONE32) ? e : q.R2[n1];
+  const u32 pos = q.sx_n1[k3];  // where the flow through that super-exit enters the next supertile
+  if (pos == NONE32) return q.sx_slot[k3];
+  const u32 b2 = pos & ~(u32)(SSL - 1);
+  return b2 + (q.xl_slot[b2 + q.R2L[pos]] & (SSL - 1));
 }
 // where does the flow entering at a boundary-row cell leave the block?  (halo sink or nowhere)
 __global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_first, LastExitArgs q,
@@ -1177,8 +1214,9 @@ __global__ void __launch_bounds__(256) k_brow_sink(const u32 *__restrict__ brow_
   if (q.hmode && ctrl[T_OVERFLOW]) return;  // the hierarchy is only partly built: the pass is redone flat
   u32 f = brow_first[t];
   if (f != NONE32 && !(f & ENC_SINK)) {
+    const u32 le = last_exit(q, f);
     u32 tr, tc, p;
-    sslot_inv(q.xtgt[last_exit(q, f)], nstc, &tr, &tc, &p);
+    sslot_inv(xr_target(le, q.xrec[le], nstc), nstc, &tr, &tc, &p);
     f = NONE32;
     if (tr == 0)
       f = esink[(size_t)tc * PSL + p];
@@ -1216,20 +1254,23 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   const size_t sxcap = (size_t)nst * 4 * SG * TS;  // super-exits sit on the supertile perimeter
   n3cap = std::max(sxcap, (size_t)nht * HCAP);
   n4cap = (size_t)nht * 4 * HG * SG * TS;           // hyper-exits sit on the hypertile perimeter
-  PFDCHK(slots.alloc(7 * nslots * sizeof(u32)));
-  PFDCHK(l3.alloc(8 * n3cap * sizeof(u32)));
+  // per slot: xT | xrec | xtot (u32, slot order), xinL | sxidL (u32, list order), R2L (u16, list order)
+  PFDCHK(slots.alloc(5 * nslots * sizeof(u32) + nslots * sizeof(uint16_t)));
+  PFDCHK(l3.alloc(9 * n3cap * sizeof(u32)));
   PFDCHK(l4.alloc(6 * n4cap * sizeof(u32)));
   PFDCHK(hcntbuf.alloc((size_t)nht * sizeof(u32)));
   PFDCHK(esink.alloc(2 * (size_t)ntc * PSL * sizeof(u32)));
   PFDCHK(bnd.alloc(5 * nb * sizeof(u32)));  // brow_first | haloA | haloL | brow_sink | brow_inflow
   u32 *q = slots.as<u32>();
-  xtgt = q, elink = q + nslots, sxid = q + 2 * nslots;              // 0xFF-initialised
-  xT = q + 3 * nslots, inflow = q + 4 * nslots, xin = q + 5 * nslots;  // zero-initialised
-  R2 = q + 6 * nslots;                                                // written before read
+  // (nothing needs clearing: every tile writes its 256 slots, the list-order arrays are written before they are read,
+  //  xtot is only read where an entry's source mask names an exit)
+  xT = q, xrec = q + nslots, xtot = q + 2 * nslots, xinL = q + 3 * nslots, sxidL = q + 4 * nslots;
+  R2L = (uint16_t *)(q + 5 * nslots);
   u32 *x = l3.as<u32>();
   sx_slot = x;
   Tc = x + n3cap, Tn = x + 2 * n3cap, Jc = x + 3 * n3cap, Jn = x + 4 * n3cap;
   xin3 = x + 5 * n3cap, R3 = x + 6 * n3cap, hx_id = x + 7 * n3cap;
+  sx_n1 = x + 8 * n3cap;
   u32 *b = bnd.as<u32>();
   brow_first = b;
   haloA = b + nb;
@@ -1237,15 +1278,19 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   brow_sink = b + 3 * nb;
   brow_inflow = b + 4 * nb;
   a = TileArgs{h->ncode, nullptr, h->ncode, nullptr, (u64)h->n, hcntbuf.as<u32>(), nht, nullptr, (u32)h->nrow, (u32)h->ncol, ntr, ntc, (u32)h->halo_top,
-               (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xtgt, elink, inflow, nullptr, esink.as<u32>(),
+               (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xrec, xtot, nullptr, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
-  sa = SuperArgs{nst, xT, xtgt, elink, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xin, R2, sxid, sx_slot, Tc, inflow, h->ctrl, nstc, nhtc,
-                 hcntbuf.as<u32>(), 0, 0, 0, ntr, ntc, HCAP, nullptr, SCAP};
+  sa = SuperArgs{};
+  sa.nst = nst, sa.xT = xT, sa.xrec = xrec, sa.xinL = xinL, sa.R2L = R2L, sa.sxidL = sxidL, sa.sx_slot = sx_slot,
+  sa.sx_n1 = sx_n1, sa.T3 = Tc, sa.xtot = xtot, sa.ctrl = h->ctrl, sa.nstc = nstc, sa.nhtc = nhtc,
+  sa.hcnt = hcntbuf.as<u32>(), sa.ntr = ntr, sa.ntc = ntc, sa.hcap = HCAP, sa.scap = SCAP;
   PFDCHK(soverbuf.alloc((size_t)nst));
   sa.sover = soverbuf.as<u8>();
   PFDCHK(xmaskbuf.alloc(nslots / 64 * sizeof(u64) + 8));  // (+ the count of flagged supertiles: one memset clears both)
   PFDCHK(xlbuf.alloc(2 * nslots * sizeof(uint16_t)));
   PFDCHK(scountbuf.alloc((size_t)nst * sizeof(u32)));
+  PFDCHK(xcbbuf.alloc(nslots / 64 * sizeof(uint16_t)));
+  sa.xcb = xcbbuf.as<uint16_t>();
   a.xmask = xmaskbuf.as<u64>();
   sa.xmask = xmaskbuf.as<u64>();
   sa.xl_slot = xlbuf.as<uint16_t>();
@@ -1256,6 +1301,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   sa.flagged = flaggedbuf.as<u32>();
   if (const char *e = pfd_knob("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
   if (const char *e = pfd_knob("PFD_TEST_SCAP")) sa.scap = (u32)std::min<u32>((u32)atoi(e), SCAP);
+  if (const char *e = pfd_knob("PFD_SUPER_ABLATE")) sa.ablate = atoi(e);
   a.stamps = nullptr;
 #ifdef PFD_DEVTOOLS
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
@@ -1443,9 +1489,9 @@ int TiledRun::phase_a() {
   if (is_block) {  // what leaves through the halo rows, and where boundary-row inflow would leave
     HIPCHK(hipMemcpyAsync(haloL, haloA, nb * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
     const u32 ne = (ntr > 1 ? 2u : 1u) * ntc * PSL;
-    k_halo_collect<<<cdiv_u32(ne, 256), 256, 0, h->stream>>>(esink.as<u32>(), inflow, ntc, ntr, nstc, (u32)h->ncol,
+    k_halo_collect<<<cdiv_u32(ne, 256), 256, 0, h->stream>>>(esink.as<u32>(), xrec, xtot, ntc, ntr, nstc, (u32)h->ncol,
                                                             haloL, ne);
-    LastExitArgs le{R2, sxid, sx_slot, xtgt, elink, Jc, R3, hx_id, l4.as<u32>(), J4fin, sa.hmode};
+    LastExitArgs le{sa.xmask, sa.xcb, sa.xl_slot, R2L, sxidL, sx_slot, sx_n1, xrec, Jc, R3, hx_id, l4.as<u32>(), J4fin, sa.hmode};
     k_brow_sink<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, le, esink.as<u32>(), ntc, ntr, nstc, (u32)h->ncol,
                                                          brow_sink, h->ctrl);
     launches += 3;
@@ -1462,20 +1508,12 @@ int TiledRun::phase_b(int *complete) {
   if (is_block) {
     // The flow entering from the other row blocks is one more set of start values on the same exit
     // graph (added to the local counts of the exits it reaches first): the graph is solved once more,
-    // now with the full down-pass.  The first solve delivered to the edge supertile rows only (that
-    // is all the halo sinks needed); those deliveries are cleared and made again.
+    // now with the full down-pass.  The first solve left totals in the edge supertile rows only (that
+    // is all the halo sinks needed); every exit's total is written again.
     pfd_seg_begin(h, "block_inflow");
-    i64 launches = 3;
+    i64 launches = 1;
     k_brow_scatter<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, xT);
     KCHK();
-    const u32 nstr = cdiv_u32(ntr, SG);
-    const size_t rowslots = (size_t)nstc * SSL;
-    // (an exit of an edge row may drain into the neighbouring supertile row: rows 0-1 and n-2..n-1)
-    // (deliveries of the first solve: by supertile row 0 and the rows of the last two tile rows, each
-    //  into itself or a neighbouring row)
-    const u32 top = std::min<u32>(2u, nstr), bot = nstr > 2 ? std::min<u32>(3u, nstr - 2) : 0u;
-    HIPCHK(hipMemsetAsync(inflow, 0, (size_t)top * rowslots * sizeof(u32), h->stream));
-    if (bot) HIPCHK(hipMemsetAsync(inflow + (size_t)(nstr - bot) * rowslots, 0, (size_t)bot * rowslots * sizeof(u32), h->stream));
     PFDCHK(solve_exits(xT, &launches));
     pfd_seg_end(h, launches);
   }
