@@ -50,6 +50,9 @@ __host__ __device__ inline void sslot_inv(u32 s, u32 nstc, u32 *tr, u32 *tc, u32
 //               exits whose totals the final tile pass pulls (slot_inflow()); no delivery pass, no atomics
 //   bits 24..27 EXIT: the tile it drains into, 3 * (dtr + 1) + (dtc + 1)
 #define XR_NONE 0xFFu
+#define SBN 2048u            // cells on the boundary of a supertile (4 * 512 - 4), padded
+#define SB_VALID 0x80000000u
+#define SC (SG * TS)         // supertile edge in cells (512)
 __host__ __device__ inline u32 xr_pack(u32 tslot, u32 tdelta, u32 link, u32 inmask) {
   return tslot | (link << 8) | (inmask << 16) | (tdelta << 24);
 }
@@ -60,6 +63,18 @@ __host__ __device__ inline u32 xr_target12(u32 tr, u32 tc, u32 t12, u32 nstc) {
   const u32 d = t12 >> 8;  // 3 * (dtr + 1) + (dtc + 1)
   const u32 q = (d * 11u) >> 5;  // d / 3 for d < 9
   return sslot_base(tr + q - 1u, tc + (d - 3u * q) - 1u, nstc) + (t12 & 0xFFu);
+}
+
+// the cells on the boundary of a supertile, numbered like the perimeter slots of a tile: row 0, row SC-1, then the
+// inner cells of column 0 and of column SC-1
+__host__ __device__ inline u32 sb_index(u32 R, u32 C) {
+  return R == 0u ? C : (R == SC - 1u ? SC + C : (C == 0u ? 2u * SC + (R - 1u) : 2u * SC + (SC - 2u) + (R - 1u)));
+}
+__host__ __device__ inline void sb_cell(u32 t, u32 *R, u32 *C) {  // (t < 4 * SC - 4; the padding maps into row SC-1.. harmlessly)
+  if (t < SC) *R = 0u, *C = t;
+  else if (t < 2u * SC) *R = SC - 1u, *C = t - SC;
+  else if (t < 2u * SC + (SC - 2u)) *R = t - 2u * SC + 1u, *C = 0u;
+  else *R = (t - (2u * SC + (SC - 2u)) + 1u) & (SC - 1u), *C = SC - 1u;
 }
 
 // level-2 (supertile) solve arguments
@@ -76,7 +91,8 @@ struct SuperArgs {
   uint16_t *xl_next;          // [nslots] list index of the exit its flow reaches next inside the supertile | SDONE
   u32 *scount;                // [nst] exits of the supertile
   u32 *nflag, *flagged;       // supertiles with more exits than scap (contrived rasters): count, list
-  u32 *xinL;        // [nslots, list order] flow entering the supertile at this exit (from other supertiles)
+  u32 *sb;          // [nst * SBN] per cell of the supertile's boundary (index: sb_index) that receives flow from OUTSIDE
+                    // the supertile: SB_VALID | source mask << 16 | list index of the exit its in-tile path reaches; else 0
   uint16_t *R2L;    // [nslots, list order] list index of the last exit of the exit's path inside its supertile
   u32 *sxidL;       // [nslots, list order] dense id of a super-exit (drains into another supertile), else NONE32
   u32 *sx_slot;     // [nsuper] slot of the super-exit
@@ -98,6 +114,8 @@ struct SuperArgs {
 
 // level-3 (hypertile = 4x4 supertiles) solve arguments; node ids k = ht*HCAP + i, i < hcnt[ht]
 struct HyperArgs {
+  const u32 *sx_slot;  // [nht*HCAP] slot of the super-exit
+  u32 *xtot;           // (final) the total of a super-exit also goes to its slot: the supertile it drains into pulls it
   u32 nht;
   const u32 *hcnt;
   const u32 *T3;    // [nht*HCAP] start value (supertile-local total of the super-exit)
@@ -299,11 +317,11 @@ struct TiledRun {
   bool supported = false, is_block = false, coarse_done = false, force_flat = false;
   DevBuf slots, sx, esink, bnd;  // per-slot arrays (7 x nslots), per-super-exit arrays (5 x cap)
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
-  DevBuf l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf, xmaskbuf, xlbuf, scountbuf, flaggedbuf, xcbbuf;
+  DevBuf sbbuf, l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf, xmaskbuf, xlbuf, scountbuf, flaggedbuf, xcbbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;
-  u32 *xT = nullptr, *xrec = nullptr, *xtot = nullptr, *xinL = nullptr, *sxidL = nullptr, *sx_slot = nullptr,
+  u32 *xT = nullptr, *xrec = nullptr, *xtot = nullptr, *sxidL = nullptr, *sx_slot = nullptr,
       *sx_n1 = nullptr;
   uint16_t *R2L = nullptr;
   SuperArgs sa{};

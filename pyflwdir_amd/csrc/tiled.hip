@@ -659,11 +659,11 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
   __syncthreads();
   auto dense = [&](u32 i) -> u32 { return cbase[i >> 6] + (u32)__popcll(maskw[i >> 6] & ((1ull << (i & 63u)) - 1ull)); };
   const u32 own = (u32)(maskw[i0 >> 6] >> (i0 & 63u)) & 15u;  // (4 | i0: the four bits sit in one word)
-  if (!own) return;
-  // the four slots share their tile: position of the tile, perimeter cell of the first slot
+  // the four slots share their tile: position of the tile
   const u32 tl = i0 >> 8;
   const u32 tr = (st / s.nstc) * SG + (tl >> 3), tc = (st % s.nstc) * SG + (tl & 7u);
   const u32 rec[4] = {rc.x, rc.y, rc.z, rc.w};
+  if (!own) return;
   u32 tgt[4], l[4], t12[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {  // the exit reached from the tile entry it drains into
@@ -687,6 +687,28 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
   }
 }
 
+// Cells on a supertile's boundary that receive flow from outside the supertile: the final solve pulls the totals of
+// those super-exits itself, so every boundary cell gets one record (sb) naming its sources and the list index of the
+// exit its in-tile path reaches.  One thread per boundary cell, after k_exit_lists (xcb).
+__global__ void __launch_bounds__(256) k_boundary_records(SuperArgs s) {
+  const u32 st = blockIdx.x >> 3, t = ((blockIdx.x & 7u) << 8) + threadIdx.x;
+  u32 v = 0;
+  if (t < 4u * SC - 4u) {
+    u32 R, C;
+    sb_cell(t, &R, &C);
+    const u32 trl = R >> 6, tcl = C >> 6;
+    const u32 tr = (st / s.nstc) * SG + trl, tc = (st % s.nstc) * SG + tcl;
+    if (tr < s.ntr && tc < s.ntc) {  // (tiles beyond the raster edge hold nothing)
+      const u32 slot0 = (st << SSHIFT) | (((trl << 3) | tcl) << 8);
+      const u32 rec = s.xrec[slot0 + (u32)pslot((int)(R & 63u), (int)(C & 63u))];
+      const u32 out = (R == 0u ? 0xE0u : 0u) | (R == SC - 1u ? 0x0Eu : 0u) | (C == 0u ? 0x38u : 0u) | (C == SC - 1u ? 0x83u : 0u);
+      const u32 m = (rec >> 16) & out, xe = (rec >> 8) & 0xFFu;
+      if (m && xe != XR_NONE) v = SB_VALID | (m << 16) | xl_index(s.xmask, s.xcb, slot0 | xe);
+    }
+  }
+  s.sb[(size_t)st * SBN + t] = v;
+}
+
 // The supertile solve over its exit list.  CAP = exits kept in LDS: SCAP (72 KB, two workgroups per CU) for the
 // supertiles k_exit_lists did not flag, SSL (every slot an exit: 96 KB, one per CU) for the others — contrived
 // rasters only; same code.
@@ -708,6 +730,8 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
     if (row != 0 && row != (s.ntr - 1) / SG && row != (s.ntr >= 2 ? (s.ntr - 2) / SG : 0u)) return;
   }
   const u32 n = s.scount[st];
+  u32 sbr[2] = {0u, 0u};  // FINAL: the boundary records of the supertile (asked for first: their totals are a dependent load)
+  if (FINAL) sbr[0] = s.sb[(size_t)st * SBN + tid], sbr[1] = s.sb[(size_t)st * SBN + 1024u + tid];
   // ---- the exits: list entry -> slot, start value, next hop; dense loads but for the start value ----
   u32 sxbits = 0;  // bit k: own exit k (tid + 1024 k) drains into another supertile
 #pragma unroll 4
@@ -716,12 +740,7 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
     if (e >= n) continue;
     const u32 w = s.xl_slot[base + e];
     u32 nx = s.xl_next[base + e];
-    u32 t = (s.ablate & 4) ? 1u : s.xT[base + (w & (SSL - 1))];
-    if (FINAL) {
-      t += s.xinL[base + e];
-    } else {
-      s.xinL[base + e] = 0;  // accumulated by k_push3 before the final pass reads it
-    }
+    const u32 t = (s.ablate & 4) ? 1u : s.xT[base + (w & (SSL - 1))];
     if (w & XL_SX) {  // a super-exit is a root; its list entry names its target instead of a next hop
       if (!FINAL) sxbits |= 1u << k;
       nx = e | SDONE;
@@ -730,6 +749,26 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
     P[e] = (uint16_t)nx;
   }
   __syncthreads();
+  if (FINAL) {
+    // flow entering the supertile: the totals of the super-exits that drain into its boundary cells (left on their
+    // slots by the level-3 solve), added to the exit the cell's in-tile path reaches
+    const u32 str = st / s.nstc, stc = st % s.nstc;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32 r = sbr[h];
+      if (!(r & SB_VALID)) continue;
+      u32 R, C;
+      sb_cell(tid + 1024u * h, &R, &C);
+      u32 m = (r >> 16) & 0xFFu, v = 0;
+      while (m) {
+        const int k = __ffs((int)m) - 1;
+        m &= m - 1u;
+        v += s.xtot[nbr_slot(str * SG + (R >> 6), stc * SG + (C >> 6), (int)(R & 63u), (int)(C & 63u), k, s.nstc)];
+      }
+      atomicAdd(&T[r & (SSL - 1)], v);
+    }
+    __syncthreads();
+  }
   // ---- doubling over the exits ----
   {
     u32 y[DPT];
@@ -895,16 +934,11 @@ __global__ void __launch_bounds__(256) k_link3(SuperArgs s, u32 nsuper, u32 *__r
   s.sx_n1[k] = pos;
   J3[k] = j;
 }
-// flow through a super-exit enters the next supertile at the exit its target entry leads to
-// (the super-exit's own total reaches the tile entry it drains into through xtot, like any exit's)
-__global__ void __launch_bounds__(256) k_push3(SuperArgs s, u32 nsuper, const u32 *__restrict__ T3final) {
+// flat level 3: the total of every super-exit goes to its slot, where the supertile it drains into pulls it
+// (hyper mode: k_hyper<true> does this itself)
+__global__ void __launch_bounds__(256) k_sx_totals(SuperArgs s, u32 nsuper, const u32 *__restrict__ T3final) {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nsuper || (s.hmode && s.ctrl[T_OVERFLOW]) || !sx_active(s, k)) return;
-  const u32 pos = s.sx_n1[k];
-  if (pos != NONE32) {
-    if (s.ablate & 8) s.xinL[pos] = T3final[k];
-    else atomicAdd(&s.xinL[pos], T3final[k]);
-  }
+  if (k < nsuper) s.xtot[s.sx_slot[k]] = T3final[k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -995,7 +1029,10 @@ __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
       const u32 i = tid + 1024u * j;
-      if (i < n) s.T3out[base + i] = T[i];
+      if (i < n) {
+        s.T3out[base + i] = T[i];
+        s.xtot[s.sx_slot[base + i]] = T[i];  // (the supertile the super-exit drains into pulls it from there)
+      }
     }
     return;
   }
@@ -1054,14 +1091,15 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
   // order) and issues one global atomic per distinct target.
   __shared__ u32 hk[512], hv[512];
   const u32 tid = threadIdx.x;
-  hk[tid] = NONE32, hk[tid + 256u] = NONE32;
-  hv[tid] = 0, hv[tid + 256u] = 0;
-  const u32 e = blockIdx.x * blockDim.x + tid;
   if (ncnt) {
     // device-side node count (level 4).  After a hypertile overflow the level-4 graph is only
     // partly built (the pass is about to be redone flat): touch nothing.
     nexits = ctrl[T_OVERFLOW] ? 0u : min(nexits, (u32)*ncnt);
   }
+  if (blockIdx.x * blockDim.x >= nexits) return;  // (the grid is sized for the capacity: most workgroups hold no node)
+  hk[tid] = NONE32, hk[tid + 256u] = NONE32;
+  hv[tid] = 0, hv[tid + 256u] = 0;
+  const u32 e = blockIdx.x * blockDim.x + tid;
   __syncthreads();
   bool moving = false;
   if (e < nexits) {
@@ -1254,8 +1292,9 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   const size_t sxcap = (size_t)nst * 4 * SG * TS;  // super-exits sit on the supertile perimeter
   n3cap = std::max(sxcap, (size_t)nht * HCAP);
   n4cap = (size_t)nht * 4 * HG * SG * TS;           // hyper-exits sit on the hypertile perimeter
-  // per slot: xT | xrec | xtot (u32, slot order), xinL | sxidL (u32, list order), R2L (u16, list order)
-  PFDCHK(slots.alloc(5 * nslots * sizeof(u32) + nslots * sizeof(uint16_t)));
+  // per slot: xT | xrec | xtot (u32, slot order), sxidL (u32, list order), R2L (u16, list order)
+  PFDCHK(slots.alloc(4 * nslots * sizeof(u32) + nslots * sizeof(uint16_t)));
+  PFDCHK(sbbuf.alloc((size_t)nst * SBN * sizeof(u32)));
   PFDCHK(l3.alloc(9 * n3cap * sizeof(u32)));
   PFDCHK(l4.alloc(6 * n4cap * sizeof(u32)));
   PFDCHK(hcntbuf.alloc((size_t)nht * sizeof(u32)));
@@ -1264,8 +1303,8 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   u32 *q = slots.as<u32>();
   // (nothing needs clearing: every tile writes its 256 slots, the list-order arrays are written before they are read,
   //  xtot is only read where an entry's source mask names an exit)
-  xT = q, xrec = q + nslots, xtot = q + 2 * nslots, xinL = q + 3 * nslots, sxidL = q + 4 * nslots;
-  R2L = (uint16_t *)(q + 5 * nslots);
+  xT = q, xrec = q + nslots, xtot = q + 2 * nslots, sxidL = q + 3 * nslots;
+  R2L = (uint16_t *)(q + 4 * nslots);
   u32 *x = l3.as<u32>();
   sx_slot = x;
   Tc = x + n3cap, Tn = x + 2 * n3cap, Jc = x + 3 * n3cap, Jn = x + 4 * n3cap;
@@ -1281,7 +1320,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
                (u32)(h->halo_top + h->own_rows - 1), nstc, xT, xrec, xtot, nullptr, esink.as<u32>(),
                brow_first, haloA, brow_inflow, h->ctrl, out_dev, 0};
   sa = SuperArgs{};
-  sa.nst = nst, sa.xT = xT, sa.xrec = xrec, sa.xinL = xinL, sa.R2L = R2L, sa.sxidL = sxidL, sa.sx_slot = sx_slot,
+  sa.nst = nst, sa.xT = xT, sa.xrec = xrec, sa.sb = sbbuf.as<u32>(), sa.R2L = R2L, sa.sxidL = sxidL, sa.sx_slot = sx_slot,
   sa.sx_n1 = sx_n1, sa.T3 = Tc, sa.xtot = xtot, sa.ctrl = h->ctrl, sa.nstc = nstc, sa.nhtc = nhtc,
   sa.hcnt = hcntbuf.as<u32>(), sa.ntr = ntr, sa.ntc = ntc, sa.hcap = HCAP, sa.scap = SCAP;
   PFDCHK(soverbuf.alloc((size_t)nst));
@@ -1343,7 +1382,7 @@ int TiledRun::level3_flat(i64 *launches) {
   PFDCHK(pfd_doubling_rounds(h, T, J, nsuper, batch + 2, true, &done3, &rounds, launches, nullptr));
   Tc = T[0], Tn = T[1], Jc = J[0], Jn = J[1];
   coarse_done = coarse_done && done3;
-  k_push3<<<g3, 256, 0, h->stream>>>(sa, nsuper, Tc);
+  k_sx_totals<<<g3, 256, 0, h->stream>>>(sa, nsuper, Tc);
   ++*launches;
   KCHK();
   return PFD_OK;
@@ -1358,7 +1397,7 @@ int TiledRun::level3_hyper(i64 *launches) {
   u32 *hx_node = y, *T4c = y + n4cap, *J4c = y + 3 * n4cap;
   u32 *T4[3] = {y + n4cap, y + 2 * n4cap, y + 5 * n4cap}, *J4[2] = {y + 3 * n4cap, y + 4 * n4cap};
   k_link3<<<g3, 256, 0, h->stream>>>(sa, n3, J3, xin3);
-  HyperArgs ha{nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl,
+  HyperArgs ha{sx_slot, xtot, nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl,
                edge_down_now ? cdiv_u32(ntr, SG) : 0u, nhtc};
   k_hyper<false><<<nht, 1024, 0, h->stream>>>(ha);
   KCHK();
@@ -1380,8 +1419,7 @@ int TiledRun::level3_hyper(i64 *launches) {
     *launches += 2;
   }
   k_hyper<true><<<nht, 1024, 0, h->stream>>>(ha);
-  k_push3<<<g3, 256, 0, h->stream>>>(sa, n3, T3out);
-  *launches += 2;
+  *launches += 1;
   KCHK();
   return PFD_OK;
 }
@@ -1485,6 +1523,8 @@ int TiledRun::phase_a() {
   pfd_seg_begin(h, "exit_graph");
   i64 launches = 1;
   k_exit_lists<<<nst * 16, 256, 0, h->stream>>>(sa);  // (valid for every solve of the pass)
+  k_boundary_records<<<nst * (SBN / 256), 256, 0, h->stream>>>(sa);
+  ++launches;
   PFDCHK(solve_exits(xT, &launches, true, is_block));
   if (is_block) {  // what leaves through the halo rows, and where boundary-row inflow would leave
     HIPCHK(hipMemcpyAsync(haloL, haloA, nb * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
