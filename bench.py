@@ -117,6 +117,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the raster given to the CPU baseline (0=auto)")
+    ap.add_argument("--op", choices=["upstream_area", "hand", "basins"], default="upstream_area",
+                    help="hand / basins: BASELINE configs[4] — the sharded collective on the 36000 x 72000 tile (rows x cols; "
+                         "--rows / --cols override), one row block per GPU, boundary rows over RCCL send/recv")
+    ap.add_argument("--rows", type=int, default=36000)
+    ap.add_argument("--cols", type=int, default=72000)
     ap.add_argument("--ops", choices=["c3", "c5"], default=None,
                     help="only the operation lines of configs[2] (30000^2) / configs[4] (36000x72000): what the PMC passes run")
     return ap.parse_args()
@@ -577,6 +582,142 @@ def run_distributed(a, rank, world, local):
     grp.close()
 
 
+C5_SYNTH = dict(seed=2, tilt=100000, white=2, nodata_pct=30)  # the configs[4]-shaped raster of the secondary lines
+
+
+def run_distributed_op(a, rank, world, local):
+    """`--op hand|basins` (BASELINE configs[4]): the sharded collective on a rows x cols tile cut into `world` row blocks,
+    one per rank / GPU; boundary rows (hand) travel device to device over RCCL send/recv between neighbours, the basins
+    records in one RCCL all-gather (host group when RCCL cannot come up: the line says which).  A step = one complete
+    collective call on device-resident inputs (the block's sweep plan is built by the warm-up call); value = cells of the
+    whole tile per second, max over the ranks."""
+    from pyflwdir_amd import dist as pdist
+    from pyflwdir_amd import hostgroup
+
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)
+    grp = hostgroup.HostGroup(rank, world)
+    device = local % max(1, _hip.device_count())
+    nrow_total, ncol = a.rows, a.cols
+    r0, r1 = pdist.block_rows(nrow_total, world)[rank]
+    own = r1 - r0
+    top, bot = pdist.halo_of(rank, world)
+    ndev = own + top + bot
+    d8_buf = _hip.synth_d8_device(nrow_total, ncol, row0=r0 - top, nrows=ndev, device=device, **C5_SYNTH)
+    dr = pdist.DistributedRaster(d8_buf, own, ncol, rank, world, device, memspace=_hip.PFD_DEVICE, group=grp,
+                                 transport=os.environ.get("PFD_DIST_TRANSPORT", "auto"))
+    # upstream area of the own rows (collective), for the drain mask / the outlets
+    upa = _hip.DeviceBuffer(own * ncol * 4, device)
+    dr.upstream_area(out=upa, memspace=_hip.PFD_DEVICE)
+    res = None
+    if a.op == "hand":
+        import ctypes as C
+
+        elev = _hip.synth_elev_device(nrow_total, ncol, row0=r0 - top, nrows=ndev, device=device, **C5_SYNTH)
+        drain = _hip.DeviceBuffer(ndev * ncol, device)
+        _hip.check(_hip.lib().pfd_memcpy_h2d(device, C.c_void_p(drain.addr), _hip.ptr(np.zeros(ncol, np.uint8)), C.c_size_t(ncol)))
+        _hip.check(_hip.lib().pfd_memcpy_h2d(device, C.c_void_p(drain.addr + (ndev - 1) * ncol), _hip.ptr(np.zeros(ncol, np.uint8)),
+                                             C.c_size_t(ncol)))
+        band = 2000
+        for b0 in range(0, own, band):  # drain = more than 100 upstream cells (rivers), built band by band on the host
+            rows = min(band, own - b0)
+            u = upa.download(np.int32, (rows, ncol), offset_bytes=b0 * ncol * 4)
+            _hip.check(_hip.lib().pfd_memcpy_h2d(device, C.c_void_p(drain.addr + (top + b0) * ncol),
+                                                 _hip.ptr(np.ascontiguousarray(u > 100).view(np.uint8)), C.c_size_t(rows * ncol)))
+        iters = [0]
+
+        def step():
+            nonlocal res
+            if res is not None:
+                res.free()
+            res, iters[0] = dr.hand(drain, elev, elev_code=_hip.PFD_F32)
+
+        def checksum():
+            return _hip.checksum_i32(_hip.ptr(res).value + top * ncol * 8, own * ncol * 2, device)
+        label, dtype, extra_bytes = "hand(drain = upstream cells > 100, elevtn float32) -> float64", "f64", 8
+    else:
+        # 1000 outlets of the whole tile: the largest upstream area of sampled rows (every rank offers its rows' maxima)
+        rng = np.random.default_rng(5)
+        rows_g = np.unique(rng.integers(0, nrow_total, 1000))
+        mine = []
+        for r in rows_g[(rows_g >= r0) & (rows_g < r1)]:
+            row = upa.download(np.int32, (ncol,), offset_bytes=int(r - r0) * ncol * 4)
+            mine.append(int(r) * ncol + int(np.argmax(row)))
+        parts = grp.allgather(np.array(mine, np.int64).tobytes())
+        outl = np.concatenate([np.frombuffer(p, np.int64) for p in parts])
+        ids = np.arange(1, outl.size + 1, dtype=np.uint32)
+        res = _hip.DeviceBuffer(own * ncol * 4, device)
+        iters = [1]
+
+        def step():
+            dr.basins(outl, ids, nrow_total, out=res, memspace=_hip.PFD_DEVICE)
+
+        def checksum():
+            return _hip.checksum_i32(res, own * ncol, device)
+        label, dtype, extra_bytes = f"basins({outl.size} outlets) -> uint32", "u32", 4
+    upa.free()
+    for _ in range(max(1, a.warmup)):  # (the first call builds the block's sweep plan / pays the cold allocations)
+        step()
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    dr.exchanges.clear()
+    grp.barrier()
+    t0 = time.perf_counter()
+    per = []
+    for _ in range(a.steps):
+        t1 = time.perf_counter()
+        step()
+        per.append((time.perf_counter() - t1) * 1e3)
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    grp.barrier()
+    dt = grp.allreduce(time.perf_counter() - t0, "max")
+    csum = grp.allreduce(int(checksum()), "sum") & ((1 << 64) - 1)
+    n_ex = len(dr.exchanges) // a.steps
+    kinds = sorted({k for k, _ in dr.exchanges})
+    ex_bytes = sum(b for _, b in dr.exchanges) // a.steps
+    if rank == 0:
+        n = nrow_total * ncol
+        ms = dt / a.steps * 1e3
+        b_alg = B_ALG["hand_f32" if a.op == "hand" else "basins_u32"]
+        per_gpu = b_alg * n / (ms * 1e-3) / 1e9 / world
+        out = dict(metric=f"Mcells/s {a.op} on D8 raster", value=round(n * a.steps / dt / 1e6, 2), unit="Mcells/s", n_gpus=world,
+                   steps=a.steps, warmup=max(1, a.warmup), ms_per_step=round(ms, 3), ms_per_step_rank0=[round(x, 3) for x in per],
+                   higher_is_better=True, scaling="strong", vs_baseline=None, dtype=dtype, data="synthetic",
+                   config=dict(workload=f"{nrow_total}x{ncol} synthetic D8 (rough regime, 30 % nodata: BASELINE configs[4] shape) in "
+                                        f"{world} row blocks, {label}; a step = one collective call on device-resident inputs, the "
+                                        "block's sweep plan built by the warm-up call",
+                               n_cells=n, parallelism=f"{world} row blocks", transport=dr.transport,
+                               rccl_world_size=dr.comm.info()["nranks"] if dr.comm is not None else None,
+                               exchanges_per_step=n_ex, exchange_kinds=kinds, exchange_bytes_per_rank_per_step=ex_bytes,
+                               iterations=iters[0], devices_visible=_hip.device_count(),
+                               launcher="self-spawned" if os.environ.get("PFD_BENCH_SPAWNED") else "external"),
+                   roofline=dict(bound="hbm", achieved=round(per_gpu, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                 frac=round(per_gpu / PEAK_HBM_GBS, 5), alg_bytes_per_cell=b_alg, per_gpu=True, traffic=None),
+                   invariants=dict(result_checksum=csum))
+        rec_path = os.path.join(ROOT, f".bench_n1_{a.op}.json")
+        if world == 1:
+            try:
+                with open(rec_path, "w") as f:
+                    json.dump(dict(rows=nrow_total, cols=ncol, ms_per_step=ms, result_checksum=csum), f)
+            except OSError:
+                pass
+        else:
+            try:
+                with open(rec_path) as f:
+                    n1 = json.load(f)
+                if n1.get("rows") == nrow_total and n1.get("cols") == ncol:
+                    out["speedup_vs_n1"] = round(n1["ms_per_step"] / ms, 3)
+                    out["n1_ms_per_step"] = round(n1["ms_per_step"], 3)
+                    out["invariants"]["result_checksum_equals_n1"] = bool(n1["result_checksum"] == csum)
+            except (OSError, ValueError):
+                pass
+        print(json.dumps(out))
+    grp.barrier()
+    if res is not None:
+        res.free()
+    dr.close()
+    grp.close()
+
+
 def free_port():
     """A TCP port on 127.0.0.1 with 64 free ports above it (MASTER_PORT; the host group listens on MASTER_PORT + 23)."""
     import socket
@@ -696,6 +837,8 @@ def main():
     if a.gpus > 1 and world == 1:
         # no launcher (this is how the driver calls it): bench.py starts its own ranks
         raise SystemExit(spawn_with_fallback(a))
+    if a.op != "upstream_area":  # configs[4]: the sharded collectives (also with one rank: the N = 1 reference line)
+        return run_distributed_op(a, rank, world, local)
     if world > 1 or os.environ.get("PFD_BENCH_FORCE_DIST"):  # the env knob runs the RCCL path with 1 rank
         return run_distributed(a, rank, world, local)
     device = local

@@ -232,6 +232,26 @@ int pfd_comm_destroy(pfd_comm *c);
 /* what RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) */
 int pfd_comm_info(pfd_comm *c, int *nranks, int *rank, int *device);
 int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int memspace);
+
+/* The exchange step of the iterated row-block collectives (sharded HAND, float accuflux, area-unit upstream_area,
+ * Strahler, stream_distance: pyflwdir_amd/dist.py DistributedRaster), device to device over RCCL — SURVEY 8e's
+ * "ncclSend/ncclRecv pairs in one ncclGroup": rank k sends the first OWN row of `result_dev` to rank k-1 and the
+ * last OWN row to rank k+1 and receives their boundary rows as its new halo values.
+ *   result_dev  the block's result on the device (own + halo rows, elem_bytes per cell)
+ *   seed_dev    DEVICE, 2 * ncol elements: the halo values of the next sweep (top halo row, bottom halo row), updated
+ *               in place; sides without a neighbour keep their content
+ *   counters    in: two local counts; out: [0], [1] their sums over the ranks (one ncclAllReduce), [2] 1 if a
+ *               received row differs (bitwise) from the halo values it replaces, [3] the sum of [2] over the ranks
+ * No row travels through the host: one stream synchronisation and a 32-byte read-back per exchange.  Every rank
+ * must call it (collective).  The block sweeps read `halo_seed_host` from the DEVICE after pfd_set_block_io(h,
+ * PFD_DEVICE). */
+int pfd_comm_exchange_rows(pfd_comm *comm, pfd_raster *h, const void *result_dev, int elem_bytes, void *seed_dev,
+                           int64_t counters[4]);
+/* all-gather of `nbytes` host bytes per rank through the device and RCCL (the one-shot boundary records of the sharded
+ * basins): out_host receives world * nbytes bytes in rank order.  Collective. */
+int pfd_comm_allgather_host(pfd_comm *comm, pfd_raster *h, const void *in_host, size_t nbytes, void *out_host);
+/* where the pfd_*_block entry points read their `halo_seed_host` argument from: PFD_HOST (default) or PFD_DEVICE */
+int pfd_set_block_io(pfd_raster *h, int seed_memspace);
 /* Split-phase form for callers that move the boundary records themselves (MPI, gloo, shared memory ...):
  * begin() runs the local phase and returns this block's record (4*ncol uint32, host memory); finish()
  * takes the records of all blocks in block order (nblocks*4*ncol uint32, host) and completes the pass.

@@ -39,6 +39,7 @@ SYMBOLS = [
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
+    "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io",
 ]
 
 _lib = None
@@ -122,6 +123,9 @@ def lib() -> C.CDLL:
         L.pfd_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.pfd_last_timing.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_int)]
+        L.pfd_comm_exchange_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.pfd_comm_allgather_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.pfd_set_block_io.argtypes = [C.c_void_p, C.c_int]
         L.pfd_malloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
         L.pfd_free.argtypes = [C.c_int, C.c_void_p]
         L.pfd_memcpy_h2d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -272,6 +276,10 @@ class RasterHandle:
         return dict(bad_cells=int(a[0]), bad_nodata=int(a[1]), pit_sum=int(a[2]), n_pits=int(a[3]), checksum=int(a[4]),
                     n_valid=int(a[5]))
 
+    def set_block_io(self, seed_memspace):
+        """Where the ``*_block`` sweeps read their halo seeds from (PFD_HOST / PFD_DEVICE)."""
+        check(lib().pfd_set_block_io(self._h, int(seed_memspace)))
+
     def set_profiling(self, on=True):  # (2: also count the doubling rounds of the tile passes, see graph_stats)
         check(lib().pfd_set_profiling(self._h, int(on)))
 
@@ -379,12 +387,14 @@ class RasterHandle:
         """HAND of a row block whose halo cells take their height from ``halo_seed`` (2 * ncol float64, host); drain,
         elevtn and the result cover the block's device raster (own + halo rows).  ``update``: ``out`` holds an earlier
         result, only its unknown (-inf) cells are recomputed.  Returns (out, boundary rows [2, ncol], unknown own cells)."""
-        halo_seed = np.ascontiguousarray(halo_seed, dtype=np.float64)
-        assert halo_seed.size == 2 * self.ncol
+        brows = None
+        if not isinstance(halo_seed, DeviceBuffer):  # (a DeviceBuffer: pfd_set_block_io(PFD_DEVICE), rows stay on the device)
+            halo_seed = np.ascontiguousarray(halo_seed, dtype=np.float64)
+            assert halo_seed.size == 2 * self.ncol
+            brows = np.empty((2, self.ncol), np.float64)
         if memspace == PFD_HOST and out is None:
             assert not update
             out = np.empty((self.nrow + sum(self.halo)) * self.ncol, np.float64)
-        brows = np.empty((2, self.ncol), np.float64)
         unk = C.c_int64(0)
         check(lib().pfd_hand_block(self._h, ptr(drain), elev_code, ptr(elevtn), ptr(halo_seed), 1 if update else 0, ptr(out),
                                    memspace, ptr(brows), C.byref(unk)))
@@ -395,9 +405,11 @@ class RasterHandle:
         """accuflux (either direction) of a row block whose halo cells hold ``halo_seed`` (2 * ncol values of the result
         type, host); data and ``out`` cover the block's device raster (own + halo rows), ``by_row``: one host value per
         device row.  Returns (boundary rows [2, ncol], own cells failing their local equation — verify only)."""
-        halo_seed = np.ascontiguousarray(halo_seed)
-        assert halo_seed.size == 2 * self.ncol and _PAYLOAD_CODE[halo_seed.dtype] == dtype_code
-        brows = np.empty((2, self.ncol), halo_seed.dtype)
+        brows = None
+        if not isinstance(halo_seed, DeviceBuffer):
+            halo_seed = np.ascontiguousarray(halo_seed)
+            assert halo_seed.size == 2 * self.ncol and _PAYLOAD_CODE[halo_seed.dtype] == dtype_code
+            brows = np.empty((2, self.ncol), halo_seed.dtype)
         bad = C.c_int64(0)
         check(lib().pfd_accuflux_block(self._h, dtype_code, ptr(data), 1 if by_row else 0, int(nodata_i), float(nodata_f),
                                        int(has_nodata), int(direction), ptr(halo_seed), 1 if verify else 0, ptr(out),
@@ -409,12 +421,14 @@ class RasterHandle:
         ``step_lengths``: the table rows of the block's device raster).  Returns (boundary rows, failing own cells)."""
         real = step_lengths is not None
         dt = np.float32 if real else np.int32
-        halo_seed = np.ascontiguousarray(halo_seed, dtype=dt)
-        assert halo_seed.size == 2 * self.ncol
+        dev_seed = isinstance(halo_seed, DeviceBuffer)
+        if not dev_seed:
+            halo_seed = np.ascontiguousarray(halo_seed, dtype=dt)
+            assert halo_seed.size == 2 * self.ncol
         if real:
             step_lengths = np.ascontiguousarray(step_lengths, dtype=np.float32)
             assert step_lengths.size == 3 * (2 * (self.nrow + sum(self.halo)) - 1)
-        brows = np.empty((2, self.ncol), dt)
+        brows = None if dev_seed else np.empty((2, self.ncol), dt)
         bad = C.c_int64(0)
         check(lib().pfd_stream_distance_block(self._h, ptr(mask), int(real), ptr(step_lengths), ptr(halo_seed),
                                               1 if verify else 0, ptr(out), memspace, ptr(brows), C.byref(bad)))
@@ -423,9 +437,11 @@ class RasterHandle:
     def strahler_block(self, mask, halo_seed, out, verify=False, memspace=PFD_HOST):
         """Strahler order of a row block whose halo cells hold ``halo_seed`` (2 * ncol uint8, host).  Returns
         (boundary rows [2, ncol], own cells failing their local equation — verify only)."""
-        halo_seed = np.ascontiguousarray(halo_seed, dtype=np.uint8)
-        assert halo_seed.size == 2 * self.ncol
-        brows = np.empty((2, self.ncol), np.uint8)
+        brows = None
+        if not isinstance(halo_seed, DeviceBuffer):
+            halo_seed = np.ascontiguousarray(halo_seed, dtype=np.uint8)
+            assert halo_seed.size == 2 * self.ncol
+            brows = np.empty((2, self.ncol), np.uint8)
         bad = C.c_int64(0)
         check(lib().pfd_strahler_block(self._h, ptr(mask), ptr(halo_seed), 1 if verify else 0, ptr(out), memspace,
                                        ptr(brows), C.byref(bad)))
@@ -594,6 +610,21 @@ class Communicator:
             out = np.empty(handle.n, np.int32)
         check(lib().pfd_upstream_area_cell_dist(handle._h, self._c, ptr(out), memspace))
         return out
+
+    def exchange_rows(self, handle, result_buf, itemsize: int, seed_buf, c0: int = 0, c1: int = 0):
+        """Neighbour exchange of the block's boundary rows, device to device (pfd_comm_exchange_rows): returns
+        (sum of c0 over the ranks, sum of c1, my halo values changed, ranks whose halo values changed)."""
+        a = (C.c_int64 * 4)(int(c0), int(c1), 0, 0)
+        check(lib().pfd_comm_exchange_rows(self._c, handle._h, ptr(result_buf), int(itemsize), ptr(seed_buf), a))
+        return int(a[0]), int(a[1]), bool(a[2]), int(a[3])
+
+    def allgather_host(self, handle, data: bytes) -> list:
+        """All-gather of equally sized host byte strings through the device and RCCL."""
+        n = len(data)
+        src = np.frombuffer(data, np.uint8)
+        out = np.empty(n * self.world, np.uint8)
+        check(lib().pfd_comm_allgather_host(self._c, handle._h, ptr(np.ascontiguousarray(src)), n, ptr(out)))
+        return [out[i * n:(i + 1) * n].tobytes() for i in range(self.world)]
 
     def close(self):
         if self._c:

@@ -480,6 +480,15 @@ void pfd_seg_end(pfd_raster *h, i64 launches) {
   (void)hipEventRecord(s.e1, h->stream);
 }
 
+extern "C" int pfd_set_block_io(pfd_raster *h, int seed_memspace) {
+  if (!h || (seed_memspace != PFD_HOST && seed_memspace != PFD_DEVICE)) {
+    pfd_set_error("pfd_set_block_io: bad arguments");
+    return PFD_EINVAL;
+  }
+  h->block_seed_space = seed_memspace;
+  return PFD_OK;
+}
+
 extern "C" int pfd_set_profiling(pfd_raster *h, int enable) {
   PFDCHK(pfd_check_handle_lazy(h));
   h->profiling = enable != 0;

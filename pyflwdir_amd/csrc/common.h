@@ -156,6 +156,7 @@ struct pfd_raster {
   const void *xseed = nullptr;
   void *xseed_out = nullptr;
   size_t xseed_elem = 0;
+  int block_seed_space = PFD_HOST;  // where the pfd_*_block entry points read their halo seeds (pfd_set_block_io)
   u8 *halo_raw = nullptr;  // row blocks: the D8 codes of the two halo rows as given (2 * ncol; the normalised codes hold sinks there)
   void *hand_block_state = nullptr;  // cells of a row block whose HAND is still unknown, between pfd_hand_block calls (sweeps.hip)
   // profiling

@@ -32,6 +32,11 @@ struct pfd_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   int *flag_dev = nullptr;  // two agreement words, allocated with the communicator (no allocation on the collective path)
+  // neighbour exchange (pfd_comm_exchange_rows): receive buffer for the two halo rows, counters; grown on demand, which
+  // every rank does in the same call (the row size is the same everywhere)
+  void *xbuf = nullptr;
+  size_t xcap = 0;
+  long long *cnt_dev = nullptr;  // 8 words: [0..3] in, [4..7] out
 };
 
 #define NCCLCHK(expr)                                                                       \
@@ -86,6 +91,8 @@ extern "C" int pfd_comm_destroy(pfd_comm *c) {
   if (c) {
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->flag_dev) (void)hipFree(c->flag_dev);
+    if (c->xbuf) (void)hipFree(c->xbuf);
+    if (c->cnt_dev) (void)hipFree(c->cnt_dev);
     delete c;
   }
   return PFD_OK;
@@ -103,6 +110,111 @@ extern "C" int pfd_comm_info(pfd_comm *c, int *nranks, int *rank, int *device) {
   if (nranks) *nranks = n;
   if (rank) *rank = r;
   if (device) *device = d;
+  return PFD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// neighbour exchange of the iterated row-block collectives: boundary rows device to device
+// ---------------------------------------------------------------------------------------------
+template <class W>
+__global__ void __launch_bounds__(256) k_seed_update(const W *__restrict__ recv, W *__restrict__ seed, size_t n,
+                                                     long long *__restrict__ changed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool diff = false;
+  if (i < n) {
+    const W v = recv[i];
+    diff = v != seed[i];  // (bit patterns: W is an unsigned integer type)
+    if (diff) seed[i] = v;
+  }
+  if (__any((int)diff) && (threadIdx.x & 63u) == 0u) *changed = 1;  // (racing stores of the same value)
+}
+__global__ void k_cnt_pack(long long *c) {  // the local "changed" flag joins the counts that are summed
+  c[3] = c[2];
+}
+
+static int comm_reserve(pfd_comm *c, size_t bytes) {
+  if (!c->cnt_dev) HIPCHK(hipMalloc((void **)&c->cnt_dev, 8 * sizeof(long long)));
+  if (bytes > c->xcap) {
+    if (c->xbuf) (void)hipFree(c->xbuf);
+    c->xbuf = nullptr, c->xcap = 0;
+    HIPCHK(hipMalloc(&c->xbuf, bytes));
+    c->xcap = bytes;
+  }
+  return PFD_OK;
+}
+
+extern "C" int pfd_comm_exchange_rows(pfd_comm *c, pfd_raster *h, const void *result_dev, int elem_bytes, void *seed_dev,
+                                      int64_t counters[4]) {
+  if (!c || !c->comm || !h || !result_dev || !seed_dev || !counters || (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8)) {
+    pfd_set_error("pfd_comm_exchange_rows: bad arguments");
+    return PFD_EINVAL;
+  }
+  HIPCHK(hipSetDevice(h->device));
+  const int rank = c->rank, world = c->world;
+  if (h->halo_top != (rank > 0) || h->halo_bot != (rank + 1 < world)) {
+    pfd_set_error("pfd_comm_exchange_rows: rank %d of %d must hold %d top / %d bottom halo rows", rank, world, rank > 0,
+                  rank + 1 < world);
+    return PFD_EINVAL;
+  }
+  const size_t rowb = (size_t)h->ncol * (size_t)elem_bytes;
+  // (an allocation failure here leaves the other ranks in the collective: the buffers are a few hundred KB and are
+  //  kept with the communicator, so this can only happen in the very first exchange)
+  PFDCHK(comm_reserve(c, 2 * rowb));
+  hipStream_t st = h->stream;
+  const char *res = (const char *)result_dev;
+  const char *first = res + (size_t)h->halo_top * rowb, *last = res + (size_t)(h->halo_top + h->own_rows - 1) * rowb;
+  char *rtop = (char *)c->xbuf, *rbot = (char *)c->xbuf + rowb;
+  long long in[4] = {(long long)counters[0], (long long)counters[1], 0, 0};
+  HIPCHK(hipMemcpyAsync(c->cnt_dev, in, sizeof(in), hipMemcpyHostToDevice, st));
+  if (world > 1) {
+    NCCLCHK(ncclGroupStart());
+    ncclResult_t r = ncclSuccess;
+    if (rank > 0) {
+      if (r == ncclSuccess) r = ncclSend(first, rowb, ncclUint8, rank - 1, c->comm, st);
+      if (r == ncclSuccess) r = ncclRecv(rtop, rowb, ncclUint8, rank - 1, c->comm, st);
+    }
+    if (rank + 1 < world) {
+      if (r == ncclSuccess) r = ncclSend(last, rowb, ncclUint8, rank + 1, c->comm, st);
+      if (r == ncclSuccess) r = ncclRecv(rbot, rowb, ncclUint8, rank + 1, c->comm, st);
+    }
+    const ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) {
+      pfd_set_error("pfd_comm_exchange_rows: ncclSend/ncclRecv failed: %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
+      return PFD_ECOMM;
+    }
+    auto update = [&](const char *recv, char *seed) {
+      if (elem_bytes == 1)
+        k_seed_update<u8><<<cdiv_u32(rowb, 256), 256, 0, st>>>((const u8 *)recv, (u8 *)seed, rowb, c->cnt_dev + 2);
+      else
+        k_seed_update<u32><<<cdiv_u32(rowb / 4, 256), 256, 0, st>>>((const u32 *)recv, (u32 *)seed, rowb / 4, c->cnt_dev + 2);
+    };
+    if (rank > 0) update(rtop, (char *)seed_dev);
+    if (rank + 1 < world) update(rbot, (char *)seed_dev + rowb);
+    KCHK();
+  }
+  k_cnt_pack<<<1, 1, 0, st>>>(c->cnt_dev);
+  NCCLCHK(ncclAllReduce(c->cnt_dev, c->cnt_dev + 4, 4, ncclInt64, ncclSum, c->comm, st));
+  long long out[4] = {0, 0, 0, 0}, mine = 0;
+  HIPCHK(hipMemcpyAsync(out, c->cnt_dev + 4, sizeof(out), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&mine, c->cnt_dev + 2, sizeof(mine), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  counters[0] = out[0], counters[1] = out[1], counters[2] = mine, counters[3] = out[3];
+  return PFD_OK;
+}
+
+extern "C" int pfd_comm_allgather_host(pfd_comm *c, pfd_raster *h, const void *in_host, size_t nbytes, void *out_host) {
+  if (!c || !c->comm || !h || !in_host || !out_host || nbytes == 0) {
+    pfd_set_error("pfd_comm_allgather_host: bad arguments");
+    return PFD_EINVAL;
+  }
+  HIPCHK(hipSetDevice(h->device));
+  DevBuf in, all;
+  PFDCHK(in.alloc(nbytes));
+  PFDCHK(all.alloc(nbytes * (size_t)c->world));
+  HIPCHK(hipMemcpyAsync(in.p, in_host, nbytes, hipMemcpyHostToDevice, h->stream));
+  NCCLCHK(ncclAllGather(in.p, all.p, nbytes, ncclUint8, c->comm, h->stream));
+  HIPCHK(hipMemcpyAsync(out_host, all.p, nbytes * (size_t)c->world, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   return PFD_OK;
 }
 

@@ -1370,7 +1370,7 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
   InArg dr, el, sd;
   PFDCHK(dr.bind(drain, (size_t)h->n, memspace, h->stream));
   PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
-  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol * sizeof(double), PFD_HOST, h->stream));
+  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol * sizeof(double), h->block_seed_space, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(double), memspace));
   HandBlockState *st = (HandBlockState *)h->hand_block_state;
@@ -1601,7 +1601,7 @@ static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T noda
     PFDCHK(d.bind(data, (size_t)h->nrow * sizeof(T), PFD_HOST, h->stream));
   else
     PFDCHK(d.bind(data, (size_t)h->n * sizeof(T), memspace, h->stream));
-  PFDCHK(sd.bind(seed_host, 2 * (size_t)h->ncol * sizeof(T), PFD_HOST, h->stream));
+  PFDCHK(sd.bind(seed_host, 2 * (size_t)h->ncol * sizeof(T), h->block_seed_space, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(T), memspace));
   if (verify && memspace == PFD_HOST)
@@ -1662,7 +1662,7 @@ extern "C" int pfd_strahler_block(pfd_raster *h, const uint8_t *mask, const uint
   }
   InArg m, sd;
   PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
-  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol, PFD_HOST, h->stream));
+  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol, h->block_seed_space, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n, memspace));
   if (verify && memspace == PFD_HOST) HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
@@ -2058,7 +2058,7 @@ extern "C" int pfd_stream_distance_block(pfd_raster *h, const uint8_t *mask, int
   InArg m, tab, sd;
   PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
   if (real_length) PFDCHK(tab.bind(step_lengths, 3 * (size_t)(2 * h->nrow - 1) * sizeof(float), PFD_HOST, h->stream));
-  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol * 4, PFD_HOST, h->stream));
+  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol * 4, h->block_seed_space, h->stream));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * 4, memspace));
   if (verify && memspace == PFD_HOST) HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n * 4, hipMemcpyHostToDevice, h->stream));

@@ -191,6 +191,11 @@ class _UpBlock:
         self.brows, _ = self._call(seed, False)
         return True
 
+    def sweep_dev(self, seed_buf):
+        """Sweep with the halo values in the DEVICE buffer ``seed_buf`` (the handle reads device seeds:
+        ``set_block_io(PFD_DEVICE)``); the boundary rows stay in ``self.out`` for the RCCL exchange."""
+        self._call(seed_buf, False)
+
     def verify(self, seed):
         """Own cells whose value is not the one their upstream cells (halo values included) give."""
         return self._call(seed, True)[1]
@@ -330,12 +335,17 @@ class _HandBlock:
         ncol = handle.ncol
         self.nrows_dev = handle.nrow + sum(handle.halo)
         dev = handle.device
-        drain_rows = np.ascontiguousarray(drain_rows)
-        elevtn_rows = np.ascontiguousarray(elevtn_rows)
-        assert drain_rows.size == elevtn_rows.size == self.nrows_dev * ncol
-        self.drain = _hip.DeviceBuffer(drain_rows.nbytes, dev).upload(drain_rows)
-        self.elev = _hip.DeviceBuffer(elevtn_rows.nbytes, dev).upload(elevtn_rows)
+        self.owned = not isinstance(drain_rows, _hip.DeviceBuffer)  # (device-resident inputs stay the caller's)
+        if self.owned:
+            drain_rows = np.ascontiguousarray(drain_rows)
+            elevtn_rows = np.ascontiguousarray(elevtn_rows)
+            assert drain_rows.size == elevtn_rows.size == self.nrows_dev * ncol
+            self.drain = _hip.DeviceBuffer(drain_rows.nbytes, dev).upload(drain_rows)
+            self.elev = _hip.DeviceBuffer(elevtn_rows.nbytes, dev).upload(elevtn_rows)
+        else:
+            self.drain, self.elev = drain_rows, elevtn_rows
         self.out = _hip.DeviceBuffer(self.nrows_dev * ncol * 8, dev)
+        self.keep_out = False  # (result_device(): the caller takes the result buffer)
         self.swept_with, self.brows, self.unknown = None, None, None
 
     def sweep(self, seed):
@@ -346,12 +356,22 @@ class _HandBlock:
         _, self.brows, self.unknown = self.h.hand_block(self.drain, self.elev, self.code, seed, out=self.out,
                                                         memspace=_hip.PFD_DEVICE, update=update)
 
+    def sweep_dev(self, seed_buf, update):
+        """Sweep (or, ``update``, relax the unknown cells) with the halo heights in the DEVICE buffer ``seed_buf``."""
+        _, _, self.unknown = self.h.hand_block(self.drain, self.elev, self.code, seed_buf, out=self.out,
+                                               memspace=_hip.PFD_DEVICE, update=update)
+
     def result(self):
         ncol = self.h.ncol
         return self.out.download(np.float64, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol * 8)
 
+    def result_device(self):
+        """The device buffer of the block's result (own + halo rows); the caller frees it."""
+        self.keep_out = True
+        return self.out
+
     def close(self, close_handle=True):
-        for b in (self.drain, self.elev, self.out):
+        for b in ((self.drain, self.elev) if self.owned else ()) + (() if self.keep_out else (self.out,)):
             b.free()
         if close_handle:
             self.h.close()
@@ -477,6 +497,7 @@ class DistributedRaster:
         if all_ok == 0:
             raise RuntimeError("another rank could not create its row block")
         self.transport = "rccl" if self.comm is not None else "host"
+        self.exchanges = []  # (transport, bytes) of every boundary exchange of the collectives below: what a caller reports
 
     def upstream_area(self, out=None, memspace=_hip.PFD_HOST):
         if self.comm is not None:
@@ -508,7 +529,8 @@ class DistributedRaster:
 
     def basins(self, idxs_global, ids, nrow_total: int, out=None, memspace=_hip.PFD_HOST):
         """Collective ``basins``: every rank passes the same outlets (global linear indices) and ids; returns
-        the labels of this rank's rows.  The 6*ncol-word boundary records travel through the host group."""
+        the labels of this rank's rows.  The 6*ncol-word boundary records travel in one all-gather — RCCL when the
+        communicator exists (``pfd_comm_allgather_host``), else the host group."""
         ncol = self.handle.ncol
         mine = _split_outlets(idxs_global, ids, nrow_total, ncol, self.world)[self.rank]
         err, res, ok = None, out, False
@@ -517,7 +539,7 @@ class DistributedRaster:
             res, rec = _hip.basins_begin(self.handle, mine[0], mine[1], out=out, memspace=memspace)
         except Exception as exc:  # noqa: BLE001 - the failure travels with the final agreement
             err = exc
-        parts = self.group.allgather(rec.tobytes())
+        parts = self._allgather(rec.tobytes())
         if err is None:
             try:
                 ok = _hip.basins_finish(self.handle, np.stack([np.frombuffer(p, np.uint32) for p in parts]), self.world,
@@ -531,14 +553,21 @@ class DistributedRaster:
             raise NotImplementedError("a row block failed or the raster holds a cycle through several row blocks")
         return res.reshape(self.handle.nrow, ncol) if memspace == _hip.PFD_HOST else res
 
-    def hand(self, drain_block, elevtn_block, max_iter=None):
+    def hand(self, drain_block, elevtn_block, max_iter=None, elev_code=None):
         """Collective ``hand(drain, elevtn)`` (reference pyflwdir/dem.py:299-330): every rank passes the rows of its
         block INCLUDING its halo rows (like the D8 codes); returns (float64 heights of the rank's own rows,
-        iterations).  Bit-identical to the whole raster: see :func:`hand_blocks`.  Per iteration one all-gather of
-        the two boundary rows (2 * ncol doubles per rank) and one agreement on the number of unknown cells."""
+        iterations).  Bit-identical to the whole raster: see :func:`hand_blocks`.  Per iteration the two boundary
+        rows travel — device to device between neighbours with the RCCL transport, through one all-gather of the host
+        group otherwise — plus one agreement on the number of unknown cells.  Device-resident inputs
+        (``_hip.DeviceBuffer`` + ``elev_code``) are used in place and the result stays on the device (a DeviceBuffer
+        covering own + halo rows, owned by the caller)."""
         h = self.handle
         ncol = h.ncol
-        drain, elevtn, code = _hand_inputs(drain_block, elevtn_block)
+        self._device_io = isinstance(drain_block, _hip.DeviceBuffer)
+        if self._device_io:
+            drain, elevtn, code = drain_block, elevtn_block, elev_code
+        else:
+            drain, elevtn, code = _hand_inputs(drain_block, elevtn_block)
         seed = np.full(2 * ncol, -np.inf)
         unknown_before, it = None, 0
         blk, err = None, None
@@ -546,6 +575,8 @@ class DistributedRaster:
             blk = _HandBlock(h, drain, elevtn, code)
         except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
             err = exc
+        if self.comm is not None:
+            return self._hand_rccl(blk, err, seed, max_iter)
         try:
             while True:
                 it += 1
@@ -557,6 +588,7 @@ class DistributedRaster:
                     except Exception as exc:  # noqa: BLE001
                         err = exc
                 parts = self.group.allgather(rec.tobytes())
+                self.exchanges.append(("host_allgather", rec.nbytes))
                 counts = [int(x) for x in np.frombuffer(b"".join(self.group.allgather(np.int64(mine).tobytes())), np.int64)]
                 if err is not None:
                     raise err
@@ -564,7 +596,7 @@ class DistributedRaster:
                     raise RuntimeError("another rank failed in hand()")
                 unknown = sum(counts)
                 if unknown == 0:
-                    return blk.result(), it
+                    return (blk.result_device() if self._device_io else blk.result()), it
                 if unknown == unknown_before or (max_iter is not None and it >= max_iter):
                     raise NotImplementedError("hand: heights that depend on each other through several row blocks "
                                               "(a cycle through the block edges)")
@@ -573,6 +605,97 @@ class DistributedRaster:
                     seed[:ncol] = np.frombuffer(parts[self.rank - 1], np.float64)[ncol:]
                 if self.rank + 1 < self.world:
                     seed[ncol:] = np.frombuffer(parts[self.rank + 1], np.float64)[:ncol]
+        finally:
+            if blk is not None:
+                blk.close(close_handle=False)
+
+    def _allgather(self, data: bytes):
+        """One-shot all-gather of a boundary record: RCCL (through the device) when the communicator exists."""
+        if self.comm is not None:
+            self.exchanges.append(("rccl_allgather", len(data)))
+            return self.comm.allgather_host(self.handle, data)
+        self.exchanges.append(("host_allgather", len(data)))
+        return self.group.allgather(data)
+
+    def _agree_ready(self, err):
+        """Before an RCCL loop: a rank whose block could not be set up has no device rows to exchange — one host
+        agreement per CALL (not per exchange), then every rank raises together."""
+        bad = self.group.allreduce(1 if err is not None else 0, "sum")
+        if err is not None:
+            raise err
+        if bad:
+            raise RuntimeError("another rank could not set up its row block")
+
+    def _hand_rccl(self, blk, err, seed0, max_iter):
+        """hand(): the exchange loop with the boundary rows travelling device to device (ncclSend / ncclRecv between
+        neighbours, one ncclAllReduce of the unknown / failed / changed counts per exchange; nothing but 32 bytes of
+        counts crosses PCIe per exchange)."""
+        h, ncol = self.handle, self.handle.ncol
+        try:
+            self._agree_ready(err)
+            seed = _hip.DeviceBuffer(seed0.nbytes, h.device).upload(seed0)
+            h.set_block_io(_hip.PFD_DEVICE)
+            try:
+                it, unknown_before, changed = 0, None, True
+                while True:
+                    it += 1
+                    mine, fail = 0, None
+                    try:
+                        if it == 1 or changed:
+                            blk.sweep_dev(seed, update=it > 1)
+                        mine = blk.unknown
+                    except Exception as exc:  # noqa: BLE001 - travels with the counts: nobody is left waiting
+                        fail = exc
+                    unknown, nfail, changed, _ = self.comm.exchange_rows(h, blk.out, 8, seed, 0 if fail else mine, 1 if fail else 0)
+                    self.exchanges.append(("rccl_sendrecv", 2 * ncol * 8))
+                    if fail is not None:
+                        raise fail
+                    if nfail:
+                        raise RuntimeError("another rank failed in hand()")
+                    if unknown == 0:
+                        return (blk.result_device() if self._device_io else blk.result()), it
+                    if unknown == unknown_before or (max_iter is not None and it >= max_iter):
+                        raise NotImplementedError("hand: heights that depend on each other through several row blocks "
+                                                  "(a cycle through the block edges)")
+                    unknown_before = unknown
+            finally:
+                h.set_block_io(_hip.PFD_HOST)
+                seed.free()
+        finally:
+            if blk is not None:
+                blk.close(close_handle=False)
+
+    def _up_rccl(self, blk, err, dtype, max_iter):
+        """The fixpoint loop of an up-sweep with the boundary rows travelling device to device (see _hand_rccl)."""
+        h, ncol = self.handle, self.handle.ncol
+        try:
+            self._agree_ready(err)
+            seed = _hip.DeviceBuffer(2 * ncol * dtype.itemsize, h.device).upload(np.zeros(2 * ncol, dtype))
+            h.set_block_io(_hip.PFD_DEVICE)
+            try:
+                it, changed = 0, True
+                while True:
+                    swept, fail = 0, None
+                    try:
+                        if changed:  # (the halo values differ from the ones of the last sweep; first round: sweep)
+                            blk.sweep_dev(seed)
+                            swept = 1
+                    except Exception as exc:  # noqa: BLE001
+                        fail = exc
+                    nswept, nfail, changed, _ = self.comm.exchange_rows(h, blk.out, dtype.itemsize, seed, swept, 1 if fail else 0)
+                    self.exchanges.append(("rccl_sendrecv", 2 * ncol * dtype.itemsize))
+                    if fail is not None:
+                        raise fail
+                    if nfail:
+                        raise RuntimeError("another rank failed in the row-block sweep")
+                    if nswept == 0:
+                        return blk.result(), it
+                    it += 1
+                    if max_iter is not None and it > max_iter:
+                        raise _not_settled(max_iter)
+            finally:
+                h.set_block_io(_hip.PFD_HOST)
+                seed.free()
         finally:
             if blk is not None:
                 blk.close(close_handle=False)
@@ -588,6 +711,8 @@ class DistributedRaster:
             blk = make_block()
         except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
             err = exc
+        if self.comm is not None:
+            return self._up_rccl(blk, err, dtype, max_iter)
         try:
             while True:
                 rec, mine = np.zeros(2 * ncol, dtype), -1
@@ -598,6 +723,7 @@ class DistributedRaster:
                     except Exception as exc:  # noqa: BLE001
                         err = exc
                 parts = self.group.allgather(rec.tobytes())
+                self.exchanges.append(("host_allgather", rec.nbytes))
                 flags = [int(x) for x in np.frombuffer(b"".join(self.group.allgather(np.int64(mine).tobytes())), np.int64)]
                 if err is not None:
                     raise err

@@ -55,8 +55,15 @@ class HostGroup:
         # 16-byte job token (optional shared secret PFD_HOSTGROUP_TOKEN): a connection that does not present it is
         # dropped at accept time instead of becoming a rank
         import hashlib
+        import hmac
 
-        token = hashlib.sha256(("pfd-hostgroup:" + os.environ.get("PFD_HOSTGROUP_TOKEN", "")).encode()).digest()[:16]
+        secret = os.environ.get("PFD_HOSTGROUP_TOKEN", "")
+        token = hashlib.sha256(("pfd-hostgroup:" + secret).encode()).digest()[:16]
+        if not secret and self.rank == 0 and addr not in ("127.0.0.1", "localhost", "::1"):
+            import warnings
+
+            warnings.warn("HostGroup: no PFD_HOSTGROUP_TOKEN is set — the job token is derived from an empty secret and "
+                          f"authenticates nothing on the non-loopback address {addr}", RuntimeWarning, stacklevel=2)
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -74,7 +81,7 @@ class HostGroup:
                     except (OSError, ConnectionError):  # not one of ours (port scan, wrong protocol)
                         conn.close()
                         continue
-                    if not (1 <= r < self.world) or r in self._peers or tok != token:
+                    if not (1 <= r < self.world) or r in self._peers or not hmac.compare_digest(tok, token):
                         conn.close()  # out of range / duplicate rank / wrong job: never part of the group
                         continue
                     self._peers[r] = conn

@@ -221,6 +221,7 @@ def _worker(rank, world, port, tmpdir):
             a, e = pdist.block_slice(shape[0], world, rank)
             dr = object.__new__(pdist.DistributedRaster)
             dr.group, dr.rank, dr.world, dr.handle = grp, rank, world, types.SimpleNamespace(ncol=shape[1])
+            dr.comm, dr.exchanges = None, []  # (host transport: the boundary rows travel through the group)
             got, rounds = dr._up_collective(lambda: NumpyUpBlock(d8[a:e], pdist.halo_of(rank, world)[0], r1 - r0, data[a:e]),
                                             np.float32)
             assert rounds >= 1 and np.array_equal(got.view(np.uint32), exp[r0:r1].view(np.uint32)), f"rank {rank}: seeded up-sweep"

@@ -108,3 +108,39 @@ def test_collective_upstream_area_and_basins_over_tcp(gpu_lib, world):
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     assert all("ok (host)" in o[0] for o in outs)
+
+
+def test_collectives_over_rccl_with_one_rank(gpu_lib):
+    """The RCCL transport of every sharded collective (neighbour ncclSend/ncclRecv in one group, ncclAllReduce of the
+    unknown / changed counts, ncclAllGather of the basins records) with a communicator of ONE rank — all the test box
+    can host: device-resident halo seeds, no boundary row through the host group, results against the oracle."""
+    e = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29733",
+             HSA_ENABLE_IPC_MODE_LEGACY="0", PFD_DIST_TRANSPORT="rccl")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_check.py")], env=e, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "ok (rccl)" in out.stdout and "rccl_sendrecv" in out.stdout and "rccl_allgather" in out.stdout
+
+
+@pytest.mark.parametrize("op", ["hand", "basins"])
+def test_bench_op_lines_one_and_two_ranks(gpu_lib, op):
+    """`bench.py --op hand|basins` (BASELINE configs[4], here on a small tile): one rank over RCCL (world 1: device-resident
+    halo seeds, ncclAllReduce of the counts), then two self-spawned ranks (on the one GPU of the test box: host transport);
+    the result checksum must not depend on the number of row blocks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    args = ["--op", op, "--rows", "2600", "--cols", "3100", "--steps", "2", "--warmup", "1"]
+    lines = []
+    for gpus in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + args, capture_output=True,
+                             text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-2500:]
+        js = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(js) == 1
+        lines.append(json.loads(js[0]))
+    one, two = lines
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and one["metric"].startswith("Mcells/s " + op)
+    assert one["config"]["transport"] == "rccl" and all(k.startswith("rccl") for k in one["config"]["exchange_kinds"])
+    assert one["invariants"]["result_checksum"] == two["invariants"]["result_checksum"]
+    assert two["invariants"]["result_checksum_equals_n1"] is True and two["speedup_vs_n1"] > 0
+    if op == "hand":
+        assert two["config"]["iterations"] >= 2 and two["config"]["exchanges_per_step"] == two["config"]["iterations"]

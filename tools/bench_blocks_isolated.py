@@ -12,6 +12,7 @@ L = _hip.lib()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 11250
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ncol = int(sys.argv[3]) if len(sys.argv) > 3 else n
+PHASES = os.environ.get("PFD_BLOCK_PHASES") == "1"  # HIP-event segments of the middle block (costs a little)
 bufs = []
 for b in range(nb):
     top, bot = dist.halo_of(b, nb)
@@ -23,14 +24,17 @@ for it in range(3):
     for b in range(nb):
         sync(); t0 = time.perf_counter()
         h = _hip.RasterHandle(bufs[b], n, ncol, device=0, memspace=_hip.PFD_DEVICE, halo=dist.halo_of(b, nb), deferred=True)
+        if PHASES and b == nb // 2: h.set_profiling(True)
         _, rec = _hip.upstream_area_cell_begin(h, out=outs[b], memspace=_hip.PFD_DEVICE)
         sync(); ta.append(1e3 * (time.perf_counter() - t0))
+        if PHASES and b == nb // 2: print("  begin :", [(s["name"], round(s["ms"], 3), s["launches"]) for s in h.last_timing()])
         hs.append(h); recs.append(rec)
     allrec = np.ascontiguousarray(np.stack(recs))
     for b in range(nb):
         sync(); t0 = time.perf_counter()
         ok = _hip.upstream_area_cell_finish(hs[b], allrec, nb, b)
         sync(); tb.append(1e3 * (time.perf_counter() - t0))
+        if PHASES and b == nb // 2: print("  finish:", [(s["name"], round(s["ms"], 3), s["launches"]) for s in hs[b].last_timing()])
         assert ok
     for h in hs: h.close()
     tot = [x + y for x, y in zip(ta, tb)]

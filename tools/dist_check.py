@@ -1,7 +1,9 @@
 """One rank of a 2+-process check of the collective entry points over the torch-free TCP group:
 DistributedRaster.upstream_area, .basins, .hand, .accuflux, .stream_distance and .stream_order of a row block against the oracle on the
 whole raster.
-Launched by tests/test_gpu_dist.py (all ranks on the one GPU of the test box, records through the host).
+Launched by tests/test_gpu_dist.py (all ranks on the one GPU of the test box, records through the host; with
+WORLD_SIZE=1 and PFD_DIST_TRANSPORT=rccl the RCCL code path of every collective — ncclSend/ncclRecv group,
+ncclAllReduce of the counts, ncclAllGather of the basins records — runs with a communicator of one rank).
 
     RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tools/dist_check.py"""
 import os
@@ -48,7 +50,10 @@ got_l, _ = dr.stream_distance()
 assert np.array_equal(got_l, O.stream_distance(idxs_ds, seq, shape[1], real_length=False).reshape(shape)[r0:r1]), f"rank {rank}: stream distance differs"
 got_s, _ = dr.stream_order()
 assert np.array_equal(got_s, O.strahler_order(idxs_ds, seq).reshape(shape)[r0:r1]), f"rank {rank}: stream order differs"
+kinds = sorted({k for k, _ in dr.exchanges})
+if dr.transport == "rccl":  # no boundary row may have travelled through the host group
+    assert kinds and all(k.startswith("rccl") for k in kinds), kinds
 dr.close()
 grp.barrier()
 grp.close()
-print(f"rank {rank} of {world}: ok ({dr.transport})")
+print(f"rank {rank} of {world}: ok ({dr.transport}); {len(dr.exchanges)} boundary exchanges: {kinds}; hand {iters} iterations, accuflux {rounds} rounds")
