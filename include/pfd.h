@@ -402,6 +402,10 @@ int pfd_synth_d8(int device, uint64_t seed, int64_t nrow, int64_t ncol, int64_t 
                  int32_t nodata_pct, int64_t row0, int64_t nrows, uint8_t *out_dev);
 int pfd_synth_elev_f32(int device, uint64_t seed, int64_t nrow, int64_t ncol, int64_t tilt,
                        int64_t white, int32_t nodata_pct, int64_t row0, int64_t nrows, float *out_dev);
+/* a host base raster (brow x bcol D8 codes) tiled over nrow x ncol cells in HBM, every copy inside a one-cell nodata
+ * frame: bench.py's realistic regime (the reference's Rhine sub-basin) at sizes that are never shipped over PCIe */
+int pfd_synth_mosaic(int device, const uint8_t *base_host, int64_t brow, int64_t bcol, int64_t nrow, int64_t ncol,
+                     uint8_t *out_dev);
 int pfd_synth_weights_f32(int device, uint64_t seed, int64_t i0, int64_t n, float *out_dev);
 
 #ifdef __cplusplus

@@ -39,7 +39,7 @@ SYMBOLS = [
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
-    "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io",
+    "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic",
 ]
 
 _lib = None
@@ -644,6 +644,15 @@ def synth_d8_device(nrow, ncol, seed=0, tilt=1 << 26, white=2, nodata_pct=0, row
     nrows = nrow - row0 if nrows is None else nrows
     buf = DeviceBuffer(nrows * ncol, device)
     check(lib().pfd_synth_d8(device, seed, nrow, ncol, tilt, white, nodata_pct, row0, nrows, C.c_void_p(buf.addr)))
+    return buf
+
+
+def synth_mosaic_device(base: np.ndarray, nrow, ncol, device=0):
+    """A host base raster tiled over nrow x ncol cells in HBM (nodata frame per copy): pfd_synth_mosaic."""
+    base = np.ascontiguousarray(base, dtype=np.uint8)
+    buf = DeviceBuffer(int(nrow) * int(ncol), device)
+    check(lib().pfd_synth_mosaic(device, ptr(base), C.c_int64(base.shape[0]), C.c_int64(base.shape[1]), C.c_int64(nrow),
+                                 C.c_int64(ncol), C.c_void_p(buf.addr)))
     return buf
 
 

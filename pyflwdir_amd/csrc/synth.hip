@@ -119,6 +119,39 @@ extern "C" int pfd_synth_d8(int device, uint64_t seed, int64_t nrow, int64_t nco
   return PFD_OK;
 }
 
+// a small base raster tiled over nrow x ncol cells, every copy inside a one-cell nodata frame (flow that left the
+// base raster stays an outlet — the pit rule — instead of entering the neighbouring copy): the realistic regime of
+// bench.py at sizes that are never shipped over PCIe
+__global__ void __launch_bounds__(256) k_synth_mosaic(const u8 *__restrict__ base, i64 brow, i64 bcol, i64 row0, i64 nrows,
+                                                      i64 ncol, u8 *__restrict__ out) {
+  const i64 c = (i64)blockIdx.x * 64 + (threadIdx.x & 63);
+  const i64 rl = (i64)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (rl >= nrows || c >= ncol) return;
+  const i64 rr = (row0 + rl) % (brow + 2), cc = c % (bcol + 2);
+  const bool frame = rr == 0 || rr == brow + 1 || cc == 0 || cc == bcol + 1;
+  out[rl * ncol + c] = frame ? (u8)D8_MV : base[(rr - 1) * bcol + (cc - 1)];
+}
+extern "C" int pfd_synth_mosaic(int device, const uint8_t *base_host, int64_t brow, int64_t bcol, int64_t nrow, int64_t ncol,
+                                uint8_t *out_dev) {
+  if (!base_host || !out_dev || brow <= 0 || bcol <= 0 || nrow <= 0 || ncol <= 0) {
+    pfd_set_error("pfd_synth_mosaic: bad arguments");
+    return PFD_EINVAL;
+  }
+  HIPCHK(hipSetDevice(device));
+  DevBuf base;
+  PFDCHK(base.alloc((size_t)(brow * bcol)));
+  HIPCHK(hipMemcpy(base.p, base_host, (size_t)(brow * bcol), hipMemcpyHostToDevice));
+  const i64 SLAB = 65535LL * 4;
+  for (i64 r0 = 0; r0 < nrow; r0 += SLAB) {
+    const i64 nr = std::min(SLAB, nrow - r0);
+    dim3 grid(cdiv_u32((u64)ncol, 64), cdiv_u32((u64)nr, 4));
+    k_synth_mosaic<<<grid, 256>>>(base.as<u8>(), brow, bcol, r0, nr, ncol, out_dev + r0 * ncol);
+  }
+  KCHK();
+  HIPCHK(hipDeviceSynchronize());
+  return PFD_OK;
+}
+
 extern "C" int pfd_synth_elev_f32(int device, uint64_t seed, int64_t nrow, int64_t ncol, int64_t tilt,
                                   int64_t white, int32_t nodata_pct, int64_t row0, int64_t nrows, float *out_dev) {
   PFDCHK(synth_common(device, nrow, ncol, row0, nrows, out_dev));

@@ -330,7 +330,7 @@ class _HandBlock:
     """Device-resident state of one row block's HAND between the exchanges: drain, elevation and the heights stay in
     HBM; only the two boundary rows and the number of unknown cells travel."""
 
-    def __init__(self, handle, drain_rows, elevtn_rows, code):
+    def __init__(self, handle, drain_rows, elevtn_rows, code, out=None):
         self.h, self.code = handle, code
         ncol = handle.ncol
         self.nrows_dev = handle.nrow + sum(handle.halo)
@@ -344,8 +344,8 @@ class _HandBlock:
             self.elev = _hip.DeviceBuffer(elevtn_rows.nbytes, dev).upload(elevtn_rows)
         else:
             self.drain, self.elev = drain_rows, elevtn_rows
-        self.out = _hip.DeviceBuffer(self.nrows_dev * ncol * 8, dev)
-        self.keep_out = False  # (result_device(): the caller takes the result buffer)
+        self.out = out if out is not None else _hip.DeviceBuffer(self.nrows_dev * ncol * 8, dev)
+        self.keep_out = out is not None  # (the caller's buffer, or result_device(): the caller takes the result buffer)
         self.swept_with, self.brows, self.unknown = None, None, None
 
     def sweep(self, seed):
@@ -553,14 +553,14 @@ class DistributedRaster:
             raise NotImplementedError("a row block failed or the raster holds a cycle through several row blocks")
         return res.reshape(self.handle.nrow, ncol) if memspace == _hip.PFD_HOST else res
 
-    def hand(self, drain_block, elevtn_block, max_iter=None, elev_code=None):
+    def hand(self, drain_block, elevtn_block, max_iter=None, elev_code=None, out=None):
         """Collective ``hand(drain, elevtn)`` (reference pyflwdir/dem.py:299-330): every rank passes the rows of its
         block INCLUDING its halo rows (like the D8 codes); returns (float64 heights of the rank's own rows,
         iterations).  Bit-identical to the whole raster: see :func:`hand_blocks`.  Per iteration the two boundary
         rows travel — device to device between neighbours with the RCCL transport, through one all-gather of the host
         group otherwise — plus one agreement on the number of unknown cells.  Device-resident inputs
         (``_hip.DeviceBuffer`` + ``elev_code``) are used in place and the result stays on the device (a DeviceBuffer
-        covering own + halo rows, owned by the caller)."""
+        covering own + halo rows, owned by the caller; ``out``: use this device buffer for it)."""
         h = self.handle
         ncol = h.ncol
         self._device_io = isinstance(drain_block, _hip.DeviceBuffer)
@@ -572,7 +572,7 @@ class DistributedRaster:
         unknown_before, it = None, 0
         blk, err = None, None
         try:
-            blk = _HandBlock(h, drain, elevtn, code)
+            blk = _HandBlock(h, drain, elevtn, code, out=out)
         except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
             err = exc
         if self.comm is not None:
