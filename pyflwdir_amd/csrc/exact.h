@@ -33,7 +33,7 @@
 #define XCAP 30          // highest leaf step; toff holds XCAP + 2 = 32 u16 per tile
 #endif
 #define XOFF (XCAP + 2)
-#define XL_TRUNK 255u    // lh[] marks
+#define XL_TRUNK 240u    // lh[] marks: trunk cell = XL_TRUNK + the number of post slots behind its slot (0..7), see xl_trunk()
 #define XL_NODATA 254u
 #define XL_HALO 253u     // cell of a halo row of a row block: its value is GIVEN (the neighbouring block's), never computed
 // sinfo (u16 per slot): bits 0-7 child mask, 8-11 slot of the heavy child (8 = none: chain head),
@@ -42,12 +42,15 @@
 #define XC_LEN 0x1FFFFFFFu  // clen: length bits
 #define XLONG 512u          // a chain of at least this many slots is folded by a whole wave (see k_xtrunk_scan)
 
+__host__ __device__ inline bool xl_trunk(u32 m) { return (m & 0xF8u) == XL_TRUNK; }
+
 struct ExactPlan {
   u32 ntr = 0, ntc = 0;
-  u8 *lh = nullptr;       // [n] leaf step (0..XCAP), XL_TRUNK, XL_NODATA, XL_HALO
+  u8 *lh = nullptr;       // [n] leaf step (0..XCAP), XL_TRUNK + post slots, XL_NODATA, XL_HALO
   u8 *kids = nullptr;     // [n] mask of the neighbour slots draining into the cell
   uint16_t *tord = nullptr;  // [ntiles * 4096] leaf cells of the tile, ordered by step: local index | downstream slot << 12 | pit << 15
   uint16_t *toff = nullptr;  // [ntiles * XOFF] start of step s in tord; entries past the last step = total
+  u32 *cslot = nullptr;   // [n] slot of a trunk cell (its real slot; post slots follow it); undefined elsewhere
   u32 *scell = nullptr;   // [nslot]
   uint16_t *sinfo = nullptr;  // [nslot]
   u32 *spost = nullptr;   // [nslot / 32 + 4] bit s = slot s is a post slot (what the serial fold needs of sinfo)

@@ -189,7 +189,7 @@ __device__ __forceinline__ u32 heavy_slot(const u8 *__restrict__ lh, const u32 *
     const u32 jj = (u32)(j < 0 ? 0 : (j >= (i64)g.n ? (i64)g.n - 1 : j));
     const u32 a = upa[jj];
     const u32 t = lh[jj];
-    if ((kids & (1u << k)) && t == XL_TRUNK && a > best) {
+    if ((kids & (1u << k)) && xl_trunk(t) && a > best) {
       best = a;
       arg = (u32)k;
     }
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = x < g.n;
   u32 hc = D8_MV, sd = 0, info = 0;
-  if (in && lh[x] == XL_TRUNK) {
+  if (in && xl_trunk(lh[x])) {
     const u32 c = ncode[x];
     const u32 m = kids[x];
     const u32 hs = heavy_slot(lh, upa, g, x, m);
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) k_plan_len(const u8 *__restrict__ lh, con
                                                   const u32 *__restrict__ hops, const u32 *__restrict__ tailnum,
                                                   const u32 *__restrict__ tidx_at, u32 n, u32 *__restrict__ len_of) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n || lh[x] != XL_TRUNK || ((hinfo[x] >> 8) & 0xFu) != 8u) return;
+  if (x >= n || !xl_trunk(lh[x]) || ((hinfo[x] >> 8) & 0xFu) != 8u) return;
   const u32 tn = tailnum[x];
   if (tn) len_of[tidx_at[tn - 1]] = hops[x] + 1;
 }
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const u8 *__restrict__ lh,
                                                       const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos,
                                                       u32 n, u32 *__restrict__ ucell, u32 *__restrict__ w) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n || lh[x] != XL_TRUNK) return;
+  if (x >= n || !xl_trunk(lh[x])) return;
   const u32 tn = tailnum[x];
   if (!tn) return;
   const u32 c = rank_of[tidx_at[tn - 1]];
@@ -391,7 +391,8 @@ __global__ void __launch_bounds__(256) k_plan_expand(const u32 *__restrict__ uce
                                                      const u32 *__restrict__ tailnum, const u32 *__restrict__ tidx_at,
                                                      const u32 *__restrict__ rank_of, const u32 *__restrict__ adj,
                                                      Geo g, u32 npos, u32 *__restrict__ scell,
-                                                     uint16_t *__restrict__ sinfo, u32 *__restrict__ spost) {
+                                                     uint16_t *__restrict__ sinfo, u32 *__restrict__ spost,
+                                                     u32 *__restrict__ cslot, u8 *__restrict__ lh) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npos) return;
   const u32 x = ucell[p];
@@ -399,6 +400,8 @@ __global__ void __launch_bounds__(256) k_plan_expand(const u32 *__restrict__ uce
   u32 s = S[p] + adj[rank_of[tidx_at[tailnum[x] - 1u]]];
   scell[s] = x;
   sinfo[s] = (uint16_t)info;
+  cslot[x] = s;  // (the sweeps find a trunk cell's value in chain order through it: no scatter pass per round)
+  if ((info >> 12) & 7u) lh[x] = (u8)(XL_TRUNK + ((info >> 12) & 7u));  // (up-sweeps: the value sits behind the post slots)
   const u32 hs = (info >> 8) & 0xFu;
   if (hs < 8 && (info >> 12)) {
     const i64 hoff = (i64)d8_dr((int)hs) * (i64)g.ncol + d8_dc((int)hs);
@@ -452,6 +455,7 @@ void pfd_free_xplan(pfd_raster *h) {
     pfd_dfree(p->kids);
     pfd_dfree(p->tord);
     pfd_dfree(p->toff);
+    pfd_dfree(p->cslot);
     pfd_dfree(p->scell);
     pfd_dfree(p->sinfo);
     pfd_dfree(p->spost);
@@ -694,6 +698,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   const size_t nwords = nsl / 32 + 4;
   if ((rc = pfd_dmalloc((void **)&p->scell, nsl * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->sinfo, nsl * sizeof(uint16_t) + 16)) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->cslot, ((size_t)n + 64) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->spost, nwords * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->cstart, std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->clen, std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
@@ -710,7 +715,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
     k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<u32>(), w.as<u32>(), hinfo.as<uint16_t>(),
                                                               tailnum.as<u32>(), tidx_at, rank_of.as<u32>(), adj.as<u32>(), h->geo,
                                                               (u32)npos,
-                                                              p->scell, p->sinfo, p->spost);
+                                                              p->scell, p->sinfo, p->spost, p->cslot, p->lh);
   XDBG(h, "k_plan_expand");
   xdigest(h, "ucell", ucell.p, (size_t)npos * 4);
   xdigest(h, "scell", p->scell, (size_t)p->nslot * 4);
@@ -741,7 +746,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
       p->b_long[b] = (i64)(std::lower_bound(lc.begin(), lc.end(), (u32)std::min<i64>(p->b_chain[b], 0xFFFFFFFFll)) - lc.begin());
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(PFD_EHIP);
-  p->bytes = 2 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)p->nslot / 8 + (size_t)nchain * 8;
+  p->bytes = 6 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)p->nslot / 8 + (size_t)nchain * 8;
   h->bytes_held += p->bytes;
   h->xplan_state = 1;
   pfd_seg_end(h, 14);

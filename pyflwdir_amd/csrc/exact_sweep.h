@@ -24,6 +24,10 @@ struct XTileArgs {
   u32 nrow, ncol, ntc;
   const u8 *lh, *kids, *ncode;
   const uint16_t *tord, *toff;
+  // down-sweeps: the values of the trunk cells stay in chain order (R, indexed through cslot) — the tile pass picks
+  // them up from there and writes every cell of the raster once; no scatter pass per round
+  const u32 *cslot;
+  const void *R;
 };
 
 // ---- leaves, up ---------------------------------------------------------------------------------
@@ -367,6 +371,53 @@ __global__ void __launch_bounds__(256) k_xtrunk_scatter(Op op, const u32 *__rest
   op.store(scell[s], R[s + ((info >> 12) & 7u)]);  // the cell's value = the running value after its last post slot
 }
 
+// Between the rounds only the END of a chain is read from the raster (as a light upstream cell of a later round's
+// slot): one store per chain.  Every other trunk cell reaches the raster in one pass in RASTER order at the end
+// (k_xtrunk_unscatter): coalesced reads of the marks and slot numbers, partial but sector-local writes — the per-slot
+// scatter in chain order paid a whole sector per 4-byte value.
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_ends(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
+                                                     u32 c0, u32 c1, const u32 *__restrict__ scell,
+                                                     const typename Op::V *__restrict__ R) {
+  const u32 c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c1) return;
+  const u32 cl = clen[c], np = cl >> 29;
+  const u32 s = cstart[c] + (cl & XC_LEN) - 1u - np;  // slot of the chain's last cell; its value follows its post slots
+  op.store(scell[s], R[s + np]);
+}
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, const u8 *__restrict__ lh, const u32 *__restrict__ cslot, u32 n,
+                                                          const typename Op::V *__restrict__ R) {
+  const u32 x0 = 4u * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (x0 >= n) return;
+  u32 l4 = 0;
+  if (x0 + 3u < n) {
+    __builtin_memcpy(&l4, lh + x0, 4);
+  } else {
+    for (u32 b = 0; x0 + b < n; ++b) l4 |= (u32)lh[x0 + b] << (8 * b);
+  }
+  u32 tm = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) tm |= xl_trunk((l4 >> (8 * b)) & 0xFFu) ? 1u << b : 0u;
+  if (!tm) return;
+  uint4 c4 = make_uint4(0u, 0u, 0u, 0u);
+  if (x0 + 3u < n) {
+    __builtin_memcpy(&c4, cslot + x0, 16);
+  } else {
+    u32 t[4] = {0u, 0u, 0u, 0u};
+    for (u32 b = 0; x0 + b < n; ++b) t[b] = cslot[x0 + b];
+    c4 = make_uint4(t[0], t[1], t[2], t[3]);
+  }
+  const u32 cs[4] = {c4.x, c4.y, c4.z, c4.w};
+  typename Op::V v[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)  // (the mark carries the number of post slots: the cell's value sits behind them)
+    v[b] = R[(tm >> b) & 1u ? cs[b] + ((l4 >> (8 * b)) & 7u) : 0u];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if ((tm >> b) & 1u) op.store(x0 + b, v[b]);
+}
+
 template <class Op>
 static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
   typedef typename Op::Elem Elem;
@@ -374,7 +425,7 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
   ExactPlan *p = (ExactPlan *)h->xplan;
   pfd_seg_begin(h, name);
   i64 launches = 1;
-  XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff};
+  XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff, nullptr, nullptr};
   k_xtile_up<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a);
   KCHK();
   XDBG(h, "tile_up");
@@ -400,9 +451,15 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
                                                                         p->longc + p->b_long[b], nl, p->spost,
                                                                         E.as<Elem>(), R.as<V>());
     XDBG(h, "scan");
-    k_xtrunk_scatter<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, R.as<V>());
-    XDBG(h, "scatter");
+    k_xtrunk_ends<Op><<<cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, R.as<V>());
+    XDBG(h, "ends");
     launches += 3;
+  }
+  if (p->nslot) {
+    k_xtrunk_unscatter<Op><<<cdiv_u32(cdiv_u32((u64)h->geo.n, 4), 256), 256, 0, h->stream>>>(op, p->lh, p->cslot, h->geo.n,
+                                                                                         R.as<V>());
+    XDBG(h, "unscatter");
+    ++launches;
   }
   KCHK();
   pfd_seg_end(h, launches);
@@ -431,11 +488,15 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
                                                      u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
                                                      const u32 *__restrict__ scell,
                                                      const u32 *__restrict__ spost, const u8 *__restrict__ ncode, Geo g,
+                                                     const u8 *__restrict__ lh, const u32 *__restrict__ cslot,
                                                      const typename Op::DElem *__restrict__ E,
-                                                     typename Op::V *__restrict__ R) {
+                                                     typename Op::V *R) {
   typedef typename Op::DElem Elem;
   typedef typename Op::V V;
   constexpr int G = XBlk<Elem>::G;
+  // the value of a chain's downstream cell: a trunk cell of a later round — final, in chain order — or (row blocks) a
+  // halo cell, whose value is given in the raster
+  auto top_of = [&](u32 pc) -> V { return xl_trunk(lh[pc]) ? R[cslot[pc]] : op.top(pc); };
   if (blockIdx.x < nlong) {  // a long chain: the whole wave (see k_xtrunk_scan), blocks of 64 groups from the top
     __shared__ XVec4<Elem> sE[64];
     __shared__ XVec4<V> sR[64];
@@ -454,7 +515,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
       const u32 x = scell[s0 + tail];
       const u32 code = ncode[x];
       const Elem e = E[s0 + tail];
-      t = d8_is_dir(code) ? op.dfold(e, op.top(d8_down(g, x, code))) : op.droot(e);
+      t = d8_is_dir(code) ? op.dfold(e, top_of(d8_down(g, x, code))) : op.droot(e);
     }
     auto gload = [&](i32 gi, XVec4<Elem> &e, u32 &bits) {
       const u32 gg = gi > 0 ? (u32)gi : 0u;
@@ -550,7 +611,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
     const u32 x = scell[s0 + tail];
     const u32 code = ncode[x];
     const Elem e = E[s0 + tail];
-    t = d8_is_dir(code) ? op.dfold(e, op.top(d8_down(g, x, code))) : op.droot(e);
+    t = d8_is_dir(code) ? op.dfold(e, top_of(d8_down(g, x, code))) : op.droot(e);
   }
   // blocks of G groups, counted from the top: block q holds the groups [lo, lo + G), lo = ng - (q+1) G
   // (groups below 0 do not exist: the top block of a chain may be partial)
@@ -651,7 +712,7 @@ __global__ void __launch_bounds__(256) k_xtrunk_dscatter(Op op, const u32 *__res
 // (LDS per workgroup decides how many tiles a CU overlaps, and the step loop is latency: keep it small.)
 #define XHW (XT + 2)
 // cells whose final value is in place before the tile kernel runs: trunk cells, and the halo cells of a row block
-__device__ __forceinline__ bool xl_given(u32 m) { return m == XL_TRUNK || m == XL_HALO; }
+__device__ __forceinline__ bool xl_given(u32 m) { return xl_trunk(m) || m == XL_HALO; }
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   typedef typename Op::V V;
@@ -673,6 +734,16 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   const i64 r0 = (i64)tr * XT, c0 = (i64)tc * XT;
   if (tid < XOFF) off[tid] = a.toff[tile * XOFF + tid];
   if (tid < XTC / 32) F[tid] = 0;
+  // a value that is in place before this kernel runs: a trunk cell's in chain order (R through cslot: the rounds do
+  // not scatter), a halo cell's (row blocks) in the raster.  Loads are unconditional, the mark selects.
+  const V *__restrict__ Rv = (const V *)a.R;
+  auto given = [&](u32 x) -> V {
+    const bool tk = xl_trunk(a.lh[x]);
+    const u32 cs = a.cslot[x];
+    const V rv = Rv[tk ? cs : 0u];
+    const V ov = op.top(x);
+    return tk ? rv : ov;
+  };
   // the ring: 2 x 66 + 2 x 64 cells of the neighbouring tiles (trunk cells there are final)
   for (u32 i = tid; i < 4u * XT + 4u; i += 256u) {
     int rr, cc;
@@ -687,7 +758,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     }
     const i64 gr = r0 + rr, gc = c0 + cc;
     V v = V();
-    if (gr >= 0 && gr < (i64)a.nrow && gc >= 0 && gc < (i64)a.ncol) v = op.top((u32)(gr * (i64)a.ncol + gc));
+    if (gr >= 0 && gr < (i64)a.nrow && gc >= 0 && gc < (i64)a.ncol) v = given((u32)(gr * (i64)a.ncol + gc));
     val[(rr + 1) * XHW + cc + 1] = v;
   }
   __syncthreads();  // (F is cleared)
@@ -699,24 +770,23 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     const int lr = l0 >> 6, lc = l0 & 63;
     const i64 gr = r0 + lr, gc = c0 + lc;
     u32 c4 = D8_MV * 0x01010101u;
-    u32 l4 = XL_TRUNK * 0x01010101u;  // INPL: the leaf steps of the quad (a leaf needs no final value, a trunk cell no image)
+    u32 l4 = XL_NODATA * 0x01010101u;  // the marks of the quad: leaf steps, trunk, halo (cells off the raster: nothing)
     V v[4] = {V(), V(), V(), V()};
     if (gr < (i64)a.nrow && gc + 3 < (i64)a.ncol) {
       const u32 g0 = (u32)(gr * (i64)a.ncol + gc);
       __builtin_memcpy(&c4, a.ncode + g0, 4);
-      if (INPL) __builtin_memcpy(&l4, a.lh + g0, 4);
-      bool trunk = !INPL;
+      __builtin_memcpy(&l4, a.lh + g0, 4);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) trunk |= xl_given((l4 >> (8 * b)) & 0xFFu);
-      if (trunk) op.top4(g0, v);
+      for (int b = 0; b < 4; ++b)
+        if (xl_given((l4 >> (8 * b)) & 0xFFu)) v[b] = given(g0 + (u32)b);
     } else if (gr < (i64)a.nrow) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         if (gc + b < (i64)a.ncol) {
           const u32 g = (u32)(gr * (i64)a.ncol + gc + b);
           c4 = (c4 & ~(0xFFu << (8 * b))) | ((u32)a.ncode[g] << (8 * b));
-          if (INPL) l4 = (l4 & ~(0xFFu << (8 * b))) | ((u32)a.lh[g] << (8 * b));
-          v[b] = op.top(g);
+          l4 = (l4 & ~(0xFFu << (8 * b))) | ((u32)a.lh[g] << (8 * b));
+          if (xl_given((u32)a.lh[g])) v[b] = given(g);
         }
       }
     }
@@ -750,23 +820,48 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
         const u32 l0 = 4u * tid + 1024u * j;
         const u32 g0 = (u32)((r0 + (l0 >> 6)) * (i64)a.ncol + c0 + (l0 & 63));
         __builtin_memcpy(&c4s[j], a.ncode + g0, 4);
-        l4s[j] = XL_TRUNK * 0x01010101u;
-        if (INPL) __builtin_memcpy(&l4s[j], a.lh + g0, 4);
+        __builtin_memcpy(&l4s[j], a.lh + g0, 4);
       }
       typename Op::DQuad dq[4];
       V vq[4][4];
+      uint4 cs4[4];
+      u32 tmask[4], hmask[4];  // trunk cells / halo cells of the quad
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32 l0 = 4u * tid + 1024u * j;
         const u32 g0 = (u32)((r0 + (l0 >> 6)) * (i64)a.ncol + c0 + (l0 & 63));
         op.dtile4_load(g0, c4s[j], dq[j]);
-        bool trunk = !INPL;
+        tmask[j] = hmask[j] = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          vq[j][b] = V();
-          trunk |= xl_given((l4s[j] >> (8 * b)) & 0xFFu);
+          const u32 mk = (l4s[j] >> (8 * b)) & 0xFFu;
+          tmask[j] |= xl_trunk(mk) ? 1u << b : 0u;
+          hmask[j] |= mk == XL_HALO ? 1u << b : 0u;
         }
-        if (trunk) op.top4(g0, vq[j]);
+        cs4[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (tmask[j]) __builtin_memcpy(&cs4[j], a.cslot + g0, 16);  // (slot numbers of the quad's trunk cells)
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 l0 = 4u * tid + 1024u * j;
+        const u32 g0 = (u32)((r0 + (l0 >> 6)) * (i64)a.ncol + c0 + (l0 & 63));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) vq[j][b] = V();
+        if (tmask[j]) {  // trunk values from chain order: four loads, the marks select
+          const u32 cs[4] = {cs4[j].x, cs4[j].y, cs4[j].z, cs4[j].w};
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const V rv = Rv[(tmask[j] >> b) & 1u ? cs[b] : 0u];
+            if ((tmask[j] >> b) & 1u) vq[j][b] = rv;
+          }
+        }
+        if (hmask[j]) {  // (row blocks: the given values of halo cells are in the raster)
+          V hv[4];
+          op.top4(g0, hv);
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if ((hmask[j] >> b) & 1u) vq[j][b] = hv[b];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -880,11 +975,11 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
     k_xtrunk_dscan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
                                                                          p->longc + p->b_long[b], nl, p->scell, p->spost,
-                                                                         h->ncode, h->geo, E.as<Elem>(), R.as<V>());
-    k_xtrunk_dscatter<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, R.as<V>());
-    launches += 3;
+                                                                         h->ncode, h->geo, p->lh, p->cslot, E.as<Elem>(),
+                                                                         R.as<V>());
+    launches += 2;  // (no scatter: the next rounds and the tile pass read the trunk values in chain order)
   }
-  XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff};
+  XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff, p->cslot, R.p};
   k_xtile_down<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a);
   KCHK();
   pfd_seg_end(h, launches);
