@@ -385,37 +385,63 @@ __global__ void __launch_bounds__(256) k_xtrunk_ends(Op op, const u32 *__restric
   const u32 s = cstart[c] + (cl & XC_LEN) - 1u - np;  // slot of the chain's last cell; its value follows its post slots
   op.store(scell[s], R[s + np]);
 }
+// (One workgroup per 64 x 64 TILE, not per strip of a raster row: a chain crosses a tile in a run of ~64 consecutive
+//  slots, so the workgroup's scattered accesses in chain order fall into a few hundred bytes per chain and the L2
+//  serves all but the first touch of a sector — a row strip meets every chain once and pays a sector per value.)
 template <class Op>
-__global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, const u8 *__restrict__ lh, const u32 *__restrict__ cslot, u32 n,
-                                                          const typename Op::V *__restrict__ R) {
-  const u32 x0 = 4u * (blockIdx.x * blockDim.x + threadIdx.x);
-  if (x0 >= n) return;
-  u32 l4 = 0;
-  if (x0 + 3u < n) {
-    __builtin_memcpy(&l4, lh + x0, 4);
-  } else {
-    for (u32 b = 0; x0 + b < n; ++b) l4 |= (u32)lh[x0 + b] << (8 * b);
+__global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, const typename Op::V *__restrict__ R) {
+  const u32 tid = threadIdx.x;
+  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  u32 l4s[4], x0s[4];
+  uint4 c4s[4];
+  bool full[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 gr = r0 + (l0 >> 6), gc = c0 + (l0 & 63);
+    full[j] = gr < a.nrow && gc + 3 < a.ncol;
+    x0s[j] = gr * a.ncol + gc;
+    l4s[j] = XL_NODATA * 0x01010101u;
+    if (full[j]) {
+      __builtin_memcpy(&l4s[j], a.lh + x0s[j], 4);
+    } else if (gr < a.nrow) {
+      for (u32 b = 0; b < 4u && gc + b < a.ncol; ++b) l4s[j] = (l4s[j] & ~(0xFFu << (8 * b))) | ((u32)a.lh[x0s[j] + b] << (8 * b));
+    }
   }
-  u32 tm = 0;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) tm |= xl_trunk((l4 >> (8 * b)) & 0xFFu) ? 1u << b : 0u;
-  if (!tm) return;
-  uint4 c4 = make_uint4(0u, 0u, 0u, 0u);
-  if (x0 + 3u < n) {
-    __builtin_memcpy(&c4, cslot + x0, 16);
-  } else {
-    u32 t[4] = {0u, 0u, 0u, 0u};
-    for (u32 b = 0; x0 + b < n; ++b) t[b] = cslot[x0 + b];
-    c4 = make_uint4(t[0], t[1], t[2], t[3]);
+  for (int j = 0; j < 4; ++j) {
+    u32 tm = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) tm |= xl_trunk((l4s[j] >> (8 * b)) & 0xFFu) ? 1u << b : 0u;
+    c4s[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (tm) {
+      if (full[j]) {
+        __builtin_memcpy(&c4s[j], a.cslot + x0s[j], 16);
+      } else {
+        u32 t[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if ((tm >> b) & 1u) t[b] = a.cslot[x0s[j] + b];
+        c4s[j] = make_uint4(t[0], t[1], t[2], t[3]);
+      }
+    }
   }
-  const u32 cs[4] = {c4.x, c4.y, c4.z, c4.w};
-  typename Op::V v[4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b)  // (the mark carries the number of post slots: the cell's value sits behind them)
-    v[b] = R[(tm >> b) & 1u ? cs[b] + ((l4 >> (8 * b)) & 7u) : 0u];
+  for (int j = 0; j < 4; ++j) {
+    const u32 l4 = l4s[j];
+    u32 tm = 0;
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
-    if ((tm >> b) & 1u) op.store(x0 + b, v[b]);
+    for (int b = 0; b < 4; ++b) tm |= xl_trunk((l4 >> (8 * b)) & 0xFFu) ? 1u << b : 0u;
+    if (!tm) continue;
+    const u32 cs[4] = {c4s[j].x, c4s[j].y, c4s[j].z, c4s[j].w};
+    typename Op::V v[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)  // (the mark carries the number of post slots: the cell's value sits behind them)
+      v[b] = R[(tm >> b) & 1u ? cs[b] + ((l4 >> (8 * b)) & 7u) : 0u];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if ((tm >> b) & 1u) op.store(x0s[j] + b, v[b]);
+  }
 }
 
 template <class Op>
@@ -456,8 +482,8 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
     launches += 3;
   }
   if (p->nslot) {
-    k_xtrunk_unscatter<Op><<<cdiv_u32(cdiv_u32((u64)h->geo.n, 4), 256), 256, 0, h->stream>>>(op, p->lh, p->cslot, h->geo.n,
-                                                                                         R.as<V>());
+    a.cslot = p->cslot;
+    k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, R.as<V>());
     XDBG(h, "unscatter");
     ++launches;
   }
@@ -478,6 +504,34 @@ __global__ void __launch_bounds__(256) k_xtrunk_dpre(Op op, const u32 *__restric
   const u32 x = scell[s];  // (a post slot names the light upstream cell: a valid cell as well)
   if (info & XS_POST) return;
   E[s] = op.dpre(x, (u32)ncode[x]);
+}
+
+// The same gather for ALL rounds at once, one workgroup per TILE (see k_xtrunk_unscatter): the operation's loads
+// run in raster order, the stores into chain order fall into the few runs of slots that cross the tile.
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_demit(Op op, XTileArgs a, typename Op::DElem *__restrict__ E) {
+  const u32 tid = threadIdx.x;
+  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 gr = r0 + (l0 >> 6), gc = c0 + (l0 & 63);
+    if (gr >= a.nrow) continue;
+    const u32 x0 = gr * a.ncol + gc;
+    u32 l4 = XL_NODATA * 0x01010101u, c4 = 0;
+    if (gc + 3 < a.ncol) {
+      __builtin_memcpy(&l4, a.lh + x0, 4);
+      __builtin_memcpy(&c4, a.ncode + x0, 4);
+    } else {
+      for (u32 b = 0; b < 4u && gc + b < a.ncol; ++b) {
+        l4 = (l4 & ~(0xFFu << (8 * b))) | ((u32)a.lh[x0 + b] << (8 * b));
+        c4 |= (u32)a.ncode[x0 + b] << (8 * b);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (xl_trunk((l4 >> (8 * b)) & 0xFFu)) E[a.cslot[x0 + b]] = op.dpre(x0 + (u32)b, (c4 >> (8 * b)) & 0xFFu);
+  }
 }
 
 // the chain is walked from its last cell (slot `tail`, possibly followed by its post slots) upstream;
@@ -966,20 +1020,21 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
   DevBuf E, R;
   PFDCHK(E.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(Elem) + 64));
   PFDCHK(R.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(V) + 64));
+  XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff, p->cslot, R.p};
+  if (p->nslot) {  // what the folds read from memory, for every trunk cell at once (the rounds only fold)
+    k_xtrunk_demit<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, E.as<Elem>());
+    ++launches;
+  }
   for (int b = 31; b >= 0; --b) {
-    const u32 s0 = (u32)p->b_slot[b], s1 = (u32)p->b_slot[b + 1];
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
     if (c1 == c0) continue;
-    k_xtrunk_dpre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, h->ncode, s0, s1,
-                                                                     E.as<Elem>());
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
     k_xtrunk_dscan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
                                                                          p->longc + p->b_long[b], nl, p->scell, p->spost,
                                                                          h->ncode, h->geo, p->lh, p->cslot, E.as<Elem>(),
                                                                          R.as<V>());
-    launches += 2;  // (no scatter: the next rounds and the tile pass read the trunk values in chain order)
+    ++launches;  // (no gather, no scatter: the rounds and the tile pass read the trunk values in chain order)
   }
-  XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff, p->cslot, R.p};
   k_xtile_down<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a);
   KCHK();
   pfd_seg_end(h, launches);
