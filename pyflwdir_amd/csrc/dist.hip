@@ -278,7 +278,11 @@ static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u3
   bool done = false;
   i64 launches = 1;
   int rounds = 0;
-  PFDCHK(pfd_doubling_rounds(h, T, J, nn, 4, true, &done, &rounds, &launches));
+  // (a path crosses at most 2 * nblocks interface cells when it runs straight through the blocks: that many hops
+  //  saturate in log2 rounds, one more shows that nothing moved — sized so that the first host look is the last)
+  int batch = 2;
+  for (u32 span = 1; span < 2u * nblocks; span <<= 1) ++batch;
+  PFDCHK(pfd_doubling_rounds(h, T, J, nn, batch, true, &done, &rounds, &launches));
   k_iface_inflow<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(T[0], nblocks, ncol, blk, run.brow_inflow);
   KCHK();
   pfd_seg_end(h, launches + 1);
