@@ -236,10 +236,6 @@ __global__ void __launch_bounds__(256) k_iface_build(const u32 *__restrict__ rec
     if (s != NONE32) j = ((u32)owner * 2 + ((s & ENC_SIDE1) ? 1u : 0u)) * ncol + (s & ENC_COL);
   }
   J[id] = j;
-  if (!(j & XDONE)) {
-    if (__hip_atomic_load(&ctrl[T_XACTIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-      __hip_atomic_store(&ctrl[T_XACTIVE], (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 // flow entering the own boundary rows: first row <- bottom halo of block-1, last row <- top halo of block+1
 __global__ void __launch_bounds__(256) k_iface_inflow(const u32 *__restrict__ F, u32 nblocks, u32 ncol, u32 blk,
@@ -260,6 +256,31 @@ __global__ void k_pack_record(const u32 *__restrict__ haloL, const u32 *__restri
   rec[2 * ncol + t] = brow_sink[t];
 }
 
+// One doubling round of the interface forest (see k_coarse_round, tiled.hip, for the rotation of the three T buffers).
+// The forest is thin — a path meets a handful of interface cells, a target collects a few pushes — so the pushes go
+// to memory directly; the workgroup-wide combine of the level-4 rounds costs more here than it saves.
+__global__ void __launch_bounds__(256) k_iface_round(const u32 *__restrict__ Told, u32 *__restrict__ Tnew, u32 *__restrict__ Tzero,
+                                                     const u32 *__restrict__ Jold, u32 *__restrict__ Jnew, u32 n) {
+  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) {
+    const u32 j = Jold[e], t = Told[e];
+    Tzero[e] = 0;
+    if (t) atomicAdd(&Tnew[e], t);
+    u32 q = j;
+    if (!(j & XDONE)) {
+      q = Jold[j];
+      if (t) atomicAdd(&Tnew[j], t);
+    }
+    Jnew[e] = q;
+  }
+}
+// "is any pointer still unsaturated?" — asked once per batch of rounds (a flag raised by every wave of every round
+// makes thousands of waves touch ONE address: ~27 us per launch, see k_check_saturated in tiled.hip)
+__global__ void __launch_bounds__(256) k_iface_check(const u32 *__restrict__ J, u32 n, u64 *ctrl) {
+  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n && !(J[e] & XDONE)) ctrl[T_XACTIVE] = 1;  // (rare: only while the batch was too short)
+}
+
 // solve the interface forest from the gathered records (on the handle's device/stream) and
 // leave the inflow of block `blk` in run.brow_inflow
 static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u32 blk) {
@@ -272,17 +293,34 @@ static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u3
   u32 *J[2] = {buf.as<u32>() + 3 * (size_t)nn, buf.as<u32>() + 4 * (size_t)nn};
   u32 *Tc = T[0], *Jc = J[0];
   pfd_seg_begin(h, "interface_solve");
-  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
   k_iface_build<<<cdiv_u32(nn, 256), 256, 0, h->stream>>>(allrec_dev, nblocks, ncol, Tc, Jc, h->ctrl);
   KCHK();
   bool done = false;
   i64 launches = 1;
-  int rounds = 0;
   // (a path crosses at most 2 * nblocks interface cells when it runs straight through the blocks: that many hops
   //  saturate in log2 rounds, one more shows that nothing moved — sized so that the first host look is the last)
-  int batch = 2;
+  int batch = 1, rounds = 0;
   for (u32 span = 1; span < 2u * nblocks; span <<= 1) ++batch;
-  PFDCHK(pfd_doubling_rounds(h, T, J, nn, batch, true, &done, &rounds, &launches));
+  HIPCHK(hipMemsetAsync(T[1], 0, (size_t)nn * sizeof(u32), h->stream));
+  while (rounds < 64 && !done) {
+    for (int b = 0; b < batch; ++b) {
+      ++rounds;
+      k_iface_round<<<cdiv_u32(nn, 256), 256, 0, h->stream>>>(T[0], T[1], T[2], J[0], J[1], nn);
+      ++launches;
+      u32 *t0 = T[0];
+      T[0] = T[1], T[1] = T[2], T[2] = t0;
+      std::swap(J[0], J[1]);
+    }
+    HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+    k_iface_check<<<cdiv_u32(nn, 256), 256, 0, h->stream>>>(J[0], nn, h->ctrl);
+    ++launches;
+    KCHK();
+    u64 last = 0;
+    HIPCHK(hipMemcpyAsync(&last, h->ctrl + T_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    done = last == 0;  // every pointer is saturated
+    batch = 2;
+  }
   k_iface_inflow<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(T[0], nblocks, ncol, blk, run.brow_inflow);
   KCHK();
   pfd_seg_end(h, launches + 1);
