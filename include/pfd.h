@@ -406,6 +406,10 @@ int pfd_synth_elev_f32(int device, uint64_t seed, int64_t nrow, int64_t ncol, in
  * frame: bench.py's realistic regime (the reference's Rhine sub-basin) at sizes that are never shipped over PCIe */
 int pfd_synth_mosaic(int device, const uint8_t *base_host, int64_t brow, int64_t bcol, int64_t nrow, int64_t ncol,
                      uint8_t *out_dev);
+/* measurement aid: one streaming pass over nbytes of buf_dev with `width`-byte accesses per lane (1, 4, 8, 16), reading or
+ * writing — a kernel with a known byte count, for calibrating the rocprofv3 FETCH_SIZE / WRITE_SIZE counters per access
+ * width (tools/prof_calib.sh) */
+int pfd_calib_traffic(int device, void *buf_dev, size_t nbytes, int width, int write);
 int pfd_synth_weights_f32(int device, uint64_t seed, int64_t i0, int64_t n, float *out_dev);
 
 #ifdef __cplusplus

@@ -4,11 +4,13 @@ HBM bytes per launch = (FETCH_SIZE * fetch_factor + WRITE_SIZE) * 1024, plus
   "_whole_pass|SxS"   all kernels of ONE timed upstream_area step together (tile passes, exit graph, memsets),
   "_op:<tag>|RxC"     all kernels of ONE warm call of an operation (bench.py --ops c3|c5).
 
-FETCH_SIZE / WRITE_SIZE are in KB.  gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes for wide
-streaming reads (MI355X_MICROARCH.md, HBM); the factor for THIS access pattern is calibrated in the same
-run on a kernel with a known read volume: k_verify_upa streams the int32 result once (4 B/cell) plus the
-codes (1 B/cell, neighbours from cache) — 5 bytes per cell.  WRITE_SIZE was calibrated in round 1 (x1.00
-for coalesced dword/16-byte stores, x1.25 for byte stores; profiles/README.md).
+FETCH_SIZE / WRITE_SIZE are in KB.  gfx950's FETCH_SIZE tallies 128-byte requests at 64 bytes
+(MI355X_MICROARCH.md, HBM).  Round 4 calibrated it on known-bytes streaming kernels per access width
+(tools/prof_calib.sh, `_calibration_widths` in the table): coalesced reads of 1, 4, 8 and 16 bytes per lane ALL report
+exactly half their bytes (factor 2.00); a scattered 4-byte read reports one 64-byte request (its true size is 64 or
+128 bytes: x2 is an upper bound there); WRITE_SIZE is exact (x1.00; x0.985 for byte stores).  The table therefore
+doubles FETCH_SIZE.  (Rounds 1-3 used k_verify_upa as the known-bytes kernel and found x0.95: that kernel re-reads
+neighbouring rows of the result from HBM, so its "known" 5 B/cell was too low — recorded below as a cross-check only.)
 
     python tools/pmc_traffic.py <pmc_fetch_write.csv> <size | c3 | c5>
 """
@@ -18,7 +20,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STEP_KERNELS = ("k_tile", "k_exit_lists", "k_super", "k_link3", "k_link4", "k_hyper", "k_push3", "k_push4", "k_coarse_round",
+STEP_KERNELS = ("k_tile", "k_exit_lists", "k_boundary_records", "k_super", "k_link3", "k_link4", "k_hyper", "k_sx_totals", "k_push4", "k_coarse_round",
                 "k_check_saturated", "fillBuffer")
 # kernels of one warm call, by a substring of their (templated) names; calls per bench.py --ops run = steps + 1
 OPS = {"accuflux_f32_up": ("AccuUp<float",), "strahler": ("Strahler",), "hand_f32": ("Hand<float",),
@@ -40,7 +42,7 @@ def main(path, what):
         tab = {}
     if what in OP_SHAPE:
         nrow, ncol = OP_SHAPE[what]
-        factor_used, cal = 1.0, None
+        cal = None
     else:
         nrow = ncol = int(what)
         n = nrow * ncol
@@ -49,9 +51,8 @@ def main(path, what):
             if "k_verify_upa" in k and "FETCH_SIZE" in v:
                 cal = dict(kernel=k, known_bytes=5 * n, fetch_kb=v["FETCH_SIZE"],
                            fetch_factor=round(5 * n / (v["FETCH_SIZE"] * 1024), 4))
-        factor = cal["fetch_factor"] if cal else 1.0
-        # the factor is a property of the request width: 1 (narrow requests) or 2 (128-byte requests counted as 64)
-        factor_used = 2.0 if factor > 1.5 else 1.0
+    widths = tab.get("_calibration_widths", {})
+    factor_used = float(widths.get("read_16B", {}).get("factor", 2.0))  # (2.00 for every coalesced width measured)
     size = f"{nrow}x{ncol}"
 
     def total(k):
