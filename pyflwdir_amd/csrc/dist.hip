@@ -37,6 +37,11 @@ struct pfd_comm {
   void *xbuf = nullptr;
   size_t xcap = 0;
   long long *cnt_dev = nullptr;  // 8 words: [0..3] in, [4..7] out
+  // boundary records of pfd_upstream_area_cell_dist, kept between passes: once they exist (every rank allocates them
+  // in the same pass, behind a set-up agreement) a pass needs no set-up agreement — a rank whose local set-up fails
+  // still owns what it needs to reach every collective
+  u32 *rec_dev = nullptr, *allrec_dev = nullptr;
+  size_t rec_words = 0;
 };
 
 #define NCCLCHK(expr)                                                                       \
@@ -93,6 +98,8 @@ extern "C" int pfd_comm_destroy(pfd_comm *c) {
     if (c->flag_dev) (void)hipFree(c->flag_dev);
     if (c->xbuf) (void)hipFree(c->xbuf);
     if (c->cnt_dev) (void)hipFree(c->cnt_dev);
+    if (c->rec_dev) (void)hipFree(c->rec_dev);
+    if (c->allrec_dev) (void)hipFree(c->allrec_dev);
     delete c;
   }
   return PFD_OK;
@@ -499,12 +506,11 @@ extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_
   const size_t recw = 4 * (size_t)ncol;
   pfd_seg_clear(h);
   // Every rank reaches every collective whatever happens locally (a rank that returned early would leave the
-  // others waiting in RCCL forever).  Local set-up (all allocations) comes first and is followed by an
-  // agreement: if it failed anywhere, all ranks return before any data collective starts.  After that, local
-  // failures - also of the collectives themselves - are carried to the final agreement.
+  // others waiting in RCCL forever).  The buffers the collectives need belong to the communicator and are
+  // allocated once, behind an agreement; after that a pass costs ONE all-gather and ONE final agreement — a local
+  // failure, set-up included, sends a zero record and is carried to the final agreement.
   OutArg o;
   TiledRun run;
-  DevBuf rec, allrec;
   int rc = o.bind(out, (size_t)h->own_rows * ncol * sizeof(i32), memspace);
   if (rc == PFD_OK) rc = run.init(h, (i32 *)o.dev);
   if (rc == PFD_OK && !run.supported) {
@@ -512,41 +518,57 @@ extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_
     rc = PFD_EUNSUPPORTED;
   }
   int *flag = comm->flag_dev;
-  if (world > 1) {
-    if (rc == PFD_OK) rc = rec.alloc(recw * sizeof(u32));
-    if (rc == PFD_OK) rc = allrec.alloc((size_t)world * recw * sizeof(u32));
-    int ready = rc == PFD_OK ? 1 : 0, ready_all = 0;
+  if (world > 1 && comm->rec_words < recw) {
+    // first pass with this raster width: the communicator's record buffers are allocated behind an agreement (if an
+    // allocation failed anywhere, all ranks return before any data collective starts)
+    int arc = PFD_OK;
+    if (comm->rec_dev) (void)hipFree(comm->rec_dev);
+    if (comm->allrec_dev) (void)hipFree(comm->allrec_dev);
+    comm->rec_dev = comm->allrec_dev = nullptr;
+    comm->rec_words = 0;
+    if (hipMalloc((void **)&comm->rec_dev, recw * sizeof(u32)) != hipSuccess ||
+        hipMalloc((void **)&comm->allrec_dev, (size_t)world * recw * sizeof(u32)) != hipSuccess) {
+      (void)hipGetLastError();
+      pfd_set_error("pfd_upstream_area_cell_dist: the record buffers could not be allocated");
+      arc = PFD_ENOMEM;
+    }
+    int ready = arc == PFD_OK ? 1 : 0, ready_all = 0;
     bool comm_ok = hipMemcpyAsync(flag, &ready, sizeof(int), hipMemcpyHostToDevice, h->stream) == hipSuccess;
     comm_ok = ncclAllReduce(flag, flag + 8, 1, ncclInt32, ncclMin, comm->comm, h->stream) == ncclSuccess && comm_ok;
     comm_ok = hipMemcpyAsync(&ready_all, flag + 8, sizeof(int), hipMemcpyDeviceToHost, h->stream) == hipSuccess && comm_ok;
     comm_ok = hipStreamSynchronize(h->stream) == hipSuccess && comm_ok;
-    if (rc != PFD_OK) return rc;  // (every rank leaves here: ready_all is 0 everywhere)
+    if (arc != PFD_OK) return arc;  // (every rank leaves here: ready_all is 0 everywhere)
     if (!comm_ok) {
       pfd_set_error("pfd_upstream_area_cell_dist: the set-up agreement (ncclAllReduce) failed");
       return PFD_ECOMM;
     }
     if (!ready_all) {
-      pfd_set_error("pfd_upstream_area_cell_dist: another rank could not set up its block (out of memory or unsupported size)");
-      return PFD_EUNSUPPORTED;
+      pfd_set_error("pfd_upstream_area_cell_dist: another rank could not allocate its record buffers");
+      return PFD_ENOMEM;
     }
-  } else if (rc != PFD_OK) {
+    comm->rec_words = recw;
+  } else if (world == 1 && rc != PFD_OK) {
     return rc;
   }
-  rc = run.phase_a_checked();
+  // From here on every rank reaches every collective whatever happens locally: a local failure (set-up included)
+  // sends a zero record and travels with the final agreement.
+  u32 *rec = comm->rec_dev, *allrec = comm->allrec_dev;
+  if (rc == PFD_OK)
+    rc = run.phase_a_checked();
   if (world > 1) {
     pfd_seg_begin(h, "allgather");
     if (rc == PFD_OK) {
-      k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(run.haloL, run.brow_sink, ncol, rec.as<u32>());
+      k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(run.haloL, run.brow_sink, ncol, rec);
     } else {
-      (void)hipMemsetAsync(rec.p, 0, recw * sizeof(u32), h->stream);
+      (void)hipMemsetAsync(rec, 0, recw * sizeof(u32), h->stream);
     }
-    const ncclResult_t r1 = ncclAllGather(rec.p, allrec.p, recw, ncclUint32, comm->comm, h->stream);
+    const ncclResult_t r1 = ncclAllGather(rec, allrec, recw, ncclUint32, comm->comm, h->stream);
     pfd_seg_end(h, 2);
     if (r1 != ncclSuccess && rc == PFD_OK) {
       pfd_set_error("ncclAllGather failed: %s", ncclGetErrorString(r1));
       rc = PFD_ECOMM;
     }
-    if (rc == PFD_OK) rc = interface_solve(run, allrec.as<u32>(), (u32)world, (u32)rank);
+    if (rc == PFD_OK) rc = interface_solve(run, allrec, (u32)world, (u32)rank);
   }
   int complete = 0;
   if (rc == PFD_OK) rc = run.phase_b(&complete);
