@@ -367,7 +367,7 @@ int pfd_last_timing(pfd_raster *h, int max_seg, double *ms, int64_t *launches, c
 
 /* Graph statistics a benchmark reports next to every number: stats[0] = n_valid,
  * [1] = n_pits, [2] = max rank = longest flow path in cells (reference core.rank, pyflwdir/core.py:17-47;
- * -1 if the raster holds cycles or is a row block), [3..11] = number of valid cells with 0..8
+ * -1 if the raster holds cycles or is a row block, -2 if it is beyond the slot ids of the tiled rank query: unknown), [3..11] = number of valid cells with 0..8
  * upstream cells (reference core.upstream_count, pyflwdir/core.py:50-61); [12..15] = pointer-doubling rounds
  * of the last upstream_area("cell") pass this handle ran under pfd_set_profiling(h, 2): max and sum over the tiles of the
  * local pass, max and sum of the final pass (0 if there was none).  Works on rasters beyond 2^32 cells. */

@@ -261,7 +261,7 @@ class RasterHandle:
         return dict(zip(keys, [int(v) for v in a]))
 
     def graph_stats(self) -> dict:
-        """n_valid, n_pits, max_rank (longest flow path, -1 with cycles) and the in-degree histogram."""
+        """n_valid, n_pits, max_rank (longest flow path; -1 with cycles, -2 unknown: beyond the tiled query) and the in-degree histogram."""
         a = (C.c_int64 * 16)()
         check(lib().pfd_graph_stats(self._h, a))
         ntiles = max(1, -(-self.nrow // 64) * -(-self.ncol // 64))

@@ -896,10 +896,17 @@ extern "C" int pfd_graph_stats(pfd_raster *h, int64_t stats[16]) {
   for (int k = 0; k < 9; ++k) stats[3 + k] = (int64_t)hh[k];
   for (int k = 0; k < 4; ++k) stats[12 + k] = h->tile_rounds[k];
   if (!h->halo_top && !h->halo_bot) {  // longest flow path (cells): max rank over the raster
-    int complete = 0;
-    u32 maxrank = 0;
-    PFDCHK(run_paths<MODE_RANK>(h, nullptr, nullptr, &complete, &maxrank));
-    if (complete) stats[2] = (int64_t)maxrank;
+    // (-1: the raster holds cycles; -2: the raster is beyond the slot ids of the tiled query — nothing is known)
+    const u32 ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
+    const size_t nslots = (size_t)cdiv_u32(ntr, SG) * cdiv_u32(ntc, SG) * SSL;
+    if (nslots >= 0x3FFFFFFFull || ntr > 65535u) {
+      stats[2] = -2;
+    } else {
+      int complete = 0;
+      u32 maxrank = 0;
+      PFDCHK(run_paths<MODE_RANK>(h, nullptr, nullptr, &complete, &maxrank));
+      if (complete) stats[2] = (int64_t)maxrank;
+    }
   }
   return PFD_OK;
 }

@@ -99,6 +99,11 @@ def _hand_inputs(drain, elevtn):
     elevtn = np.ascontiguousarray(elevtn)
     if elevtn.dtype not in _ELEV_CODE:
         raise NotImplementedError(f"elevation dtype {elevtn.dtype} is not supported on the HIP path")
+    # the row-block protocol marks "height not known yet" with -inf: an elevation difference of +-inf or NaN could produce
+    # that very value (or turn an unknown into NaN) and the blocks would never agree that they are done
+    if not np.isfinite(elevtn).all():
+        raise NotImplementedError("hand over row blocks needs finite elevations (-inf marks heights that are not known "
+                                  "yet); mask or fill inf / NaN cells first")
     return drain, elevtn, _ELEV_CODE[elevtn.dtype]
 
 

@@ -526,27 +526,32 @@ class FlwdirRaster(object):
             raise ValueError(f'Unknown flow direction: {direction}, select from ["up", "down"].')
         data = np.asarray(data)
         flat = self._check_data(data, "data")
-        dirc = _hip.PFD_UP if direction == "up" else _hip.PFD_DOWN
         if flat.dtype in _NARROW_INT:
-            return self._accuflux_narrow(flat, nodata, dirc).reshape(data.shape)
+            return self._accuflux_narrow(flat, nodata, direction).reshape(data.shape)
         view, code, nd_i, nd_f, has_nd = _payload_args(flat, nodata)
+        out = self._accuflux_dev(view, code, nd_i, nd_f, has_nd, direction)
+        return out.view(flat.dtype).reshape(data.shape)
+
+    def _accuflux_dev(self, view, code, nd_i, nd_f, has_nd, direction):
+        """accuflux of a 32- / 64-bit payload on the device: one handle, or row blocks beyond 2**32 - 2 cells."""
         nb = self._row_blocks_needed()
         if nb > 1:
             from . import dist
 
             self._refuse_cycles_in_blocks("accuflux")
-            out = dist.accuflux_blocks(self._d8, nb, view, (nd_i, nd_f, has_nd), direction=direction)[0]
-            return out.view(flat.dtype).reshape(data.shape)
-        out = self._h.accuflux(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd, direction=dirc)
-        return out.view(flat.dtype).reshape(data.shape)
+            return dist.accuflux_blocks(self._d8, nb, view, (nd_i, nd_f, has_nd), direction=direction)[0].ravel()
+        dirc = _hip.PFD_UP if direction == "up" else _hip.PFD_DOWN
+        return self._h.accuflux(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd, direction=dirc)
 
-    def _accuflux_narrow(self, flat, nodata, dirc):
+    def _accuflux_narrow(self, flat, nodata, direction):
         """int8 / int16 / uint8 / uint16 payloads.  The reference accumulates in the payload's own dtype
         (streams.py:36 ``data.copy()``), wrap-around included; the device kernels exist for 32- and 64-bit integers.
         Accumulating in int32 gives the same values — and the same answers to the running nodata tests — as long
         as no partial sum leaves the narrow range, which is checked: non-negative data accumulate monotonically, so
-        the final values bound the partial sums; otherwise the accumulated magnitudes do.  A payload that WOULD wrap
-        (the reference then returns wrapped sums) is refused instead of being answered differently."""
+        the final values bound the partial sums; otherwise the accumulated magnitudes of the cells that take part do
+        (the nodata rule only ever leaves operands out, so the magnitudes with the nodata cells set to zero bound every
+        partial sum).  A payload that WOULD wrap (the reference then returns wrapped sums) is refused instead of being
+        answered differently.  Rasters beyond 2**32 - 2 cells take the row-block path like the wide dtypes."""
         dt = flat.dtype
         info = np.iinfo(dt)
         wide = flat.astype(np.int32)
@@ -556,11 +561,13 @@ class FlwdirRaster(object):
             integral = False
         has_nd = 1 if integral and info.min <= int(nodata) <= info.max else 0
         nd = int(nodata) if has_nd else 0
-        out = self._h.accuflux(wide, _hip.PFD_I32, nodata_i=nd, nodata_f=0.0, has_nodata=has_nd, direction=dirc)
-        if flat.size and int(wide.min()) >= 0:
-            ok = int(out.max()) <= info.max
+        out = self._accuflux_dev(wide, _hip.PFD_I32, nd, 0.0, has_nd, direction)
+        takes_part = wide != nd if has_nd else np.ones(wide.shape, bool)
+        if flat.size and int(wide[takes_part].min(initial=0)) >= 0:
+            ok = int(out[takes_part].max(initial=0)) <= info.max
         else:
-            bound = self._h.accuflux(np.abs(wide), _hip.PFD_I32, nodata_i=0, nodata_f=0.0, has_nodata=0, direction=dirc)
+            mag = np.where(takes_part, np.abs(wide), 0).astype(np.int32)
+            bound = self._accuflux_dev(mag, _hip.PFD_I32, 0, 0.0, 0, direction)
             ok = int(bound.max()) <= min(info.max, -int(info.min))
         if not ok:
             raise NotImplementedError(f"accuflux: the sums leave the range of the payload dtype {dt} (the reference "
@@ -696,8 +703,10 @@ class FlwdirRaster(object):
     def _refuse_cycles_in_blocks(self, what):
         """The seeded up-sweeps over row blocks iterate to a fixpoint, which a cycle through a block edge does not have
         (sums grow for ever; a Strahler order may settle on values the reference never assigns: it leaves cells on or
-        above a cycle untouched).  One tiled rank query on the whole raster tells."""
-        if self._h.graph_stats()["max_rank"] < 0:
+        above a cycle untouched).  One tiled rank query on the whole raster tells; a raster even beyond that query's slot
+        ids (max_rank -2: more than ~4e9 perimeter slots or 65535 tile rows) is left to the iteration bound of the
+        fixpoint (``max_iter``: a cycle through a block edge never settles and raises there)."""
+        if self._h.graph_stats()["max_rank"] == -1:
             raise NotImplementedError(f"{what}: the raster holds a cycle and is too large for one ordering "
                                       "(beyond 2**32 - 2 cells the operation runs in row blocks, which need an acyclic raster)")
 

@@ -485,3 +485,13 @@ def test_whole_raster_operations_refuse_row_block_handles(gpu_lib, oracle):
     out = np.zeros(n, np.float32)
     h.accuflux_block(f32, _hip.PFD_F32, np.zeros(2 * 200, np.float32), out)
     h.close()
+
+
+def test_hand_blocks_refuse_non_finite_elevations(gpu_lib, oracle):
+    from pyflwdir_amd import dist
+
+    d8 = oracle.synth_d8(120, 90, seed=1, tilt=100000, white=2).reshape(120, 90)
+    elev = np.ones((120, 90), np.float32)
+    elev[50, 40] = np.inf
+    with pytest.raises(NotImplementedError, match="finite elevations"):
+        dist.hand_blocks(d8, 2, np.zeros((120, 90), np.uint8), elev)

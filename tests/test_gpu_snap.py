@@ -90,3 +90,22 @@ def test_accuflux_narrow_integer_payloads(gpu_lib, name):
             exact += 1
             assert got.dtype == exp.dtype and np.array_equal(got, exp), (nm, key)
     assert exact >= 3
+
+
+def test_accuflux_int16_with_negative_nodata_is_not_refused(gpu_lib, oracle):
+    """The usual int16 payload: small values, -9999 on missing cells.  The range check honours the nodata rule (a
+    missing cell never enters a sum), so only a real overflow is refused; the result is the int32 accumulation."""
+    import pyflwdir_amd as pyflwdir
+
+    d8 = oracle.synth_d8(300, 260, seed=9, tilt=100000, white=2, nodata_pct=10).reshape(300, 260)
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 3, d8.shape).astype(np.int16)
+    data[rng.random(d8.shape) < 0.05] = -9999
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    for direction in ("up", "down"):
+        got = flw.accuflux(data, nodata=-9999, direction=direction)
+        exp = flw.accuflux(data.astype(np.int32), nodata=-9999, direction=direction)
+        assert got.dtype == np.int16 and np.array_equal(got.astype(np.int32), exp)
+    big = np.where(data == -9999, data, 30000).astype(np.int16)  # (sums beyond int16: the reference would wrap)
+    with pytest.raises(NotImplementedError, match="leave the range"):
+        flw.accuflux(big, nodata=-9999)
