@@ -333,6 +333,8 @@ struct TiledRun {
   bool edge_down_now = false;
   int level3_flat(i64 *launches);
   int level3_hyper(i64 *launches);
+  int level4_down(i64 *launches);
+  int resolve_with_inflow(i64 *launches);
   TileArgs a{};
   int init(pfd_raster *hh, i32 *out_dev);
   bool overflowed = false;

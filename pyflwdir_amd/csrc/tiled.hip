@@ -1296,7 +1296,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   PFDCHK(slots.alloc(4 * nslots * sizeof(u32) + nslots * sizeof(uint16_t)));
   PFDCHK(sbbuf.alloc((size_t)nst * SBN * sizeof(u32)));
   PFDCHK(l3.alloc(9 * n3cap * sizeof(u32)));
-  PFDCHK(l4.alloc(6 * n4cap * sizeof(u32)));
+  PFDCHK(l4.alloc(7 * n4cap * sizeof(u32)));  // hx_node | T4 x2 | J4 x2 | T4 | saved level-4 start values (row blocks)
   PFDCHK(hcntbuf.alloc((size_t)nht * sizeof(u32)));
   PFDCHK(esink.alloc(2 * (size_t)ntc * PSL * sizeof(u32)));
   PFDCHK(bnd.alloc(5 * nb * sizeof(u32)));  // brow_first | haloA | haloL | brow_sink | brow_inflow
@@ -1394,14 +1394,26 @@ int TiledRun::level3_hyper(i64 *launches) {
   const u32 g3 = cdiv_u32(n3, 256);
   u32 *T3 = Tc, *J3 = Jc, *T3out = Tn;  // Jn is free: level 4 has its own buffers
   u32 *y = l4.as<u32>();
-  u32 *hx_node = y, *T4c = y + n4cap, *J4c = y + 3 * n4cap;
-  u32 *T4[3] = {y + n4cap, y + 2 * n4cap, y + 5 * n4cap}, *J4[2] = {y + 3 * n4cap, y + 4 * n4cap};
+  u32 *hx_node = y, *T4c = y + n4cap;
   k_link3<<<g3, 256, 0, h->stream>>>(sa, n3, J3, xin3);
   HyperArgs ha{sx_slot, xtot, nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl,
                edge_down_now ? cdiv_u32(ntr, SG) : 0u, nhtc};
   k_hyper<false><<<nht, 1024, 0, h->stream>>>(ha);
   KCHK();
   *launches += 2;
+  if (is_block)  // (the second solve of a row block starts level 4 from these values plus what enters the block)
+    HIPCHK(hipMemcpyAsync(y + 6 * n4cap, T4c, n4cap * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
+  return level4_down(launches);
+}
+
+// level 4 (global doubling over the hyper-exits, start values in place) and the way down through level 3
+int TiledRun::level4_down(i64 *launches) {
+  u32 *T3 = Tc, *J3 = Jc, *T3out = Tn;
+  u32 *y = l4.as<u32>();
+  u32 *hx_node = y, *T4c = y + n4cap, *J4c = y + 3 * n4cap;
+  u32 *T4[3] = {y + n4cap, y + 2 * n4cap, y + 5 * n4cap}, *J4[2] = {y + 3 * n4cap, y + 4 * n4cap};
+  HyperArgs ha{sx_slot, xtot, nht, hcntbuf.as<u32>(), T3, J3, xin3, T3out, R3, hx_id, hx_node, T4c, h->ctrl,
+               edge_down_now ? cdiv_u32(ntr, SG) : 0u, nhtc};
   {  // level 4: the number of hyper-exits stays on the device (grids are sized for the capacity)
     const u32 cap4 = (u32)std::min<size_t>(n4cap, 0x7FFFFFFF);
     const u32 g4 = cdiv_u32(cap4, 256);
@@ -1420,6 +1432,47 @@ int TiledRun::level3_hyper(i64 *launches) {
   }
   k_hyper<true><<<nht, 1024, 0, h->stream>>>(ha);
   *launches += 1;
+  KCHK();
+  return PFD_OK;
+}
+
+// Second solve of a row block (the flow entering from the other blocks as extra start values), when the first solve
+// built the hierarchy per hypertile: roots, ids and links do not depend on the start values, so levels 2 and 3 are
+// not solved upwards again — the inflow of every boundary-row cell is added to the start value of the super-exit
+// its path leaves its supertile through (T3) and of the hyper-exit that path leaves its hypertile through (T4), by
+// O(1) lookups; then level 4 runs again and the totals come down as usual.
+__global__ void __launch_bounds__(256) k_brow_delta(const u32 *__restrict__ brow_first, const u32 *__restrict__ brow_inflow,
+                                                    u32 ncol, const u64 *__restrict__ xmask, const uint16_t *__restrict__ xcb,
+                                                    const uint16_t *__restrict__ R2L, const u32 *__restrict__ sxidL,
+                                                    u32 *__restrict__ T3, const u32 *__restrict__ R3,
+                                                    const u32 *__restrict__ hx_id, u32 *__restrict__ T4start) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncol) return;
+  const u32 v = brow_inflow[t], e = brow_first[t];
+  if (!v || e == NONE32 || (e & ENC_SINK)) return;
+  const u32 b = e & ~(u32)(SSL - 1);
+  const u32 id = sxidL[b + R2L[b + xl_index(xmask, xcb, e)]];  // the super-exit the path leaves the supertile through
+  if (id == NONE32) return;
+  atomicAdd(&T3[id], v);
+  const u32 m = hx_id[R3[id]];  // ... and the hyper-exit it leaves the hypertile through
+  if (m != NONE32) atomicAdd(&T4start[m], v);
+}
+int TiledRun::resolve_with_inflow(i64 *launches) {
+  edge_down_now = false;
+  sa.edge_nstr = 0;
+  sa.xT = xT;
+  const size_t nb = 2 * (size_t)h->ncol;
+  u32 *y = l4.as<u32>();
+  k_brow_delta<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, sa.xmask, sa.xcb, R2L, sxidL, Tc,
+                                                        R3, hx_id, y + 6 * n4cap);
+  HIPCHK(hipMemcpyAsync(y + n4cap, y + 6 * n4cap, n4cap * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(xin3, 0, (size_t)nht * HCAP * sizeof(u32), h->stream));
+  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
+  *launches += 4;
+  PFDCHK(level4_down(launches));
+  k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super_flagged<true><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);
+  *launches += 2;
   KCHK();
   return PFD_OK;
 }
@@ -1554,7 +1607,10 @@ int TiledRun::phase_b(int *complete) {
     i64 launches = 1;
     k_brow_scatter<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, xT);
     KCHK();
-    PFDCHK(solve_exits(xT, &launches));
+    if (sa.hmode && !pfd_knob("PFD_BLOCK_FULL_RESOLVE"))
+      PFDCHK(resolve_with_inflow(&launches));  // (structure of the first solve reused: values only)
+    else
+      PFDCHK(solve_exits(xT, &launches));
     pfd_seg_end(h, launches);
   }
   const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
