@@ -30,6 +30,12 @@
 #ifndef FY_COMBINE
 #define FY_COMBINE true
 #endif
+#ifndef FX_COMBINE
+#define FX_COMBINE true
+#endif
+#ifndef FXP
+#define FXP 4  // count words per perimeter slot (replicas picked by lane: a wave's atomics on one word are serialised)
+#endif
 #define FY_SINK0 (4u * TCELLS)              // final pass: A byte offset of sink word 0 (64 of them, one per lane)
 
 // step tables (selector k = position of the code's bit): E, SE, S, SW | W, NW, N, NE
@@ -103,7 +109,7 @@ static __device__ __constant__ const NbrTab NBR_TAB = make_nbr_tab();
 // ---------------------------------------------------------------------------------------------------------------
 template <bool RAW, bool WEIGHTS>
 __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
-  __shared__ __attribute__((aligned(16))) u32 A[PSL * PREP];     // PREP count words per perimeter slot
+  __shared__ __attribute__((aligned(16))) u32 A[PSL * FXP];      // FXP count words per perimeter slot
   __shared__ __attribute__((aligned(16))) uint16_t P[FX_PN];     // byte offset into P of an ancestor / of a root word
   __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
   __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
@@ -117,8 +123,8 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
     stage_load_interior(RAW ? a.raw : a.ncode, a.ncol, r0, c0, tid, v);
     stage_store(code, tid, v);
   }
-  *(uint4 *)&A[PREP * tid] = make_uint4(0u, 0u, 0u, 0u);
-  *(uint4 *)&A[PREP * tid + 4] = make_uint4(0u, 0u, 0u, 0u);
+  *(uint4 *)&A[FXP * tid] = make_uint4(0u, 0u, 0u, 0u);
+  if (FXP == 8) *(uint4 *)&A[FXP * tid + 4] = make_uint4(0u, 0u, 0u, 0u);
   P[TCELLS + tid] = (uint16_t)(FX_SLOT0 + 2u * tid);  // a root word points at itself
   if (tid == 0) P[TCELLS + PSL] = (uint16_t)FX_NOBODY;
   __syncthreads();
@@ -246,21 +252,32 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   if (live) atomicAdd((unsigned long long *)&a.ctrl[T_UNSAT], (unsigned long long)live);
 
   // ---- every cell adds its weight to the counter of its exit (PREP replicas per slot, picked by lane) ---------
-  const u32 rep = 4u * (tid & (PREP - 1u));
+  // The four cells of a quad are neighbours in a row and mostly share their exit: they are combined in registers
+  // first (a wave's atomics on one counter word are served one lane after the other, and a tile has few exits that
+  // collect most of its cells).
+  const u32 rep = 4u * (tid & (FXP - 1u));
 #pragma unroll
   for (int j = 0; j < QPT; ++j) {
+    u32 x[4], w[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const u32 x = pc[4 * j + s] - FX_SLOT0;  // 2 x slot; >= 2 * PSL: nobody asks (a nodata cell is its own root)
-      if (x < 2u * PSL) {
-        u32 w = 1u;
-        if (WEIGHTS) {
-          const u32 lr = (tid >> 4) + 16u * j;
-          w = (u32)a.weights[(size_t)(r0 + lr) * a.ncol + (size_t)(c0 + lcq + (sh[s] >> 3))];
-        }
-        atomicAdd((u32 *)((u8 *)A + (x << 4) + rep), w);  // word slot * PREP + replica
+      x[s] = pc[4 * j + s] - FX_SLOT0;  // 2 x slot; >= 2 * PSL: nobody asks (a nodata cell is its own root)
+      w[s] = x[s] < 2u * PSL ? 1u : 0u;
+      if (WEIGHTS) {
+        const u32 lr = (tid >> 4) + 16u * j;
+        w[s] = x[s] < 2u * PSL ? (u32)a.weights[(size_t)(r0 + lr) * a.ncol + (size_t)(c0 + lcq + (sh[s] >> 3))] : 0u;
       }
     }
+    if (FX_COMBINE) {
+      const bool e10 = x[1] == x[0], e20 = x[2] == x[0], e21 = x[2] == x[1], e30 = x[3] == x[0], e31 = x[3] == x[1], e32 = x[3] == x[2];
+      w[0] += (e10 ? w[1] : 0u) + (e20 ? w[2] : 0u) + (e30 ? w[3] : 0u);
+      w[1] = e10 ? 0u : w[1] + ((!e20 && e21) ? w[2] : 0u) + ((!e30 && e31) ? w[3] : 0u);
+      w[2] = (e20 || e21) ? 0u : w[2] + ((!e30 && !e31 && e32) ? w[3] : 0u);
+      w[3] = (e30 || e31 || e32) ? 0u : w[3];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (w[s]) atomicAdd((u32 *)((u8 *)A + (x[s] << (FXP == 8 ? 4 : 3)) + rep), w[s]);  // word slot * FXP + replica
   }
   __syncthreads();
 
@@ -268,8 +285,12 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   u32 xt = 0, link = XR_NONE, inmask = 0;
   if (tid < NPERIM) {
     if (xt12 != XR_NONE) {
-      const uint4 lo = *(const uint4 *)&A[tid * PREP], hi = *(const uint4 *)&A[tid * PREP + 4];
-      xt = lo.x + lo.y + lo.z + lo.w + hi.x + hi.y + hi.z + hi.w;
+      const uint4 lo = *(const uint4 *)&A[tid * FXP];
+      xt = lo.x + lo.y + lo.z + lo.w;
+      if (FXP == 8) {
+        const uint4 hi = *(const uint4 *)&A[tid * FXP + 4];
+        xt += hi.x + hi.y + hi.z + hi.w;
+      }
     }
     const u32 c = CODE(plr, plc);
     if (c != D8_MV) {  // entry?  (neighbours outside the tile that drain into this cell: the sources of its inflow)
@@ -294,7 +315,7 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
 // final pass of an interior tile: the doubling with values; entries start with 1 + inflow
 // ---------------------------------------------------------------------------------------------------------------
 template <bool WEIGHTS>
-__global__ void __launch_bounds__(256) k_tile_final_fast(TileArgs a) {
+__global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
   __shared__ __attribute__((aligned(16))) u32 A[TCELLS + 64];        // running count of the cell; 64 sink words
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS + 64];   // A byte offset of an ancestor / of a sink word
   __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
