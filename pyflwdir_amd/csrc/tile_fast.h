@@ -104,6 +104,20 @@ constexpr NbrTab make_nbr_tab() {
 }
 static __device__ __constant__ const NbrTab NBR_TAB = make_nbr_tab();
 
+template <int NW>
+__device__ __forceinline__ bool fx_vote_n(u32 (*s_flag)[8], int round, u32 tid, bool live) {
+  const bool any = __ballot(live) != 0ull;
+  if ((tid & 63u) == 0u) s_flag[round & 1][tid >> 6] = any ? 1u : 0u;
+  __syncthreads();
+  const uint4 f = *(const uint4 *)s_flag[round & 1];
+  u32 acc = f.x | f.y | f.z | f.w;
+  if (NW == 8) {
+    const uint4 g = *(const uint4 *)&s_flag[round & 1][4];
+    acc |= g.x | g.y | g.z | g.w;
+  }
+  return acc != 0u;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // local pass of an interior tile
 // ---------------------------------------------------------------------------------------------------------------
@@ -314,26 +328,31 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // final pass of an interior tile: the doubling with values; entries start with 1 + inflow
 // ---------------------------------------------------------------------------------------------------------------
-template <bool WEIGHTS>
-__global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
+template <bool WEIGHTS, int NT>
+__global__ void __launch_bounds__(NT, NT == 256 ? 6 : 8) k_tile_final_fast(TileArgs a) {
+  constexpr int QF = TCELLS / 4 / NT;   // quads per thread (4 with 256 threads, 2 with 512)
+  constexpr u32 QSTR = 4u * NT;         // cells between a thread's quads
+  constexpr u32 RSTR = NT / 16;         // rows between them
+  constexpr int NW = NT / 64;
   __shared__ __attribute__((aligned(16))) u32 A[TCELLS + 64];        // running count of the cell; 64 sink words
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS + 64];   // A byte offset of an ancestor / of a sink word
-  __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][8];
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x + a.tc_lo, tr = blockIdx.y + a.tr_lo;
   const u32 sbase = sslot_base(tr, tc, a.nstc);
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   const u32 lcq = 4u * (tid & 15u);
-  u32 cq[QPT];
+  u32 cq[QF];
 #pragma unroll
-  for (int j = 0; j < QPT; ++j)
-    __builtin_memcpy(&cq[j], a.ncode + (size_t)(r0 + (tid >> 4) + 16u * j) * a.ncol + (size_t)(c0 + lcq), 4);
+  for (int j = 0; j < QF; ++j)
+    __builtin_memcpy(&cq[j], a.ncode + (size_t)(r0 + (tid >> 4) + RSTR * j) * a.ncol + (size_t)(c0 + lcq), 4);
   // flow entering at this perimeter cell: pulled from the exits that drain into it.  All candidates are loaded right
   // away (NBR_TAB: no load waits for another), the record's source mask selects after the decode below.
-  const u32 rec = a.xrec[sbase + tid];  // (256 slots per tile; slots 252..255 carry no source mask)
+  const u32 ptid = tid & 255u;  // (NT = 512: threads 256.. repeat the loads of 0..255 and drop them)
+  const u32 rec = tid < 256u ? a.xrec[sbase + ptid] : 0u;  // (256 slots per tile; slots 252..255 carry no source mask)
   u32 xc[5], xk[5];
   {
-    const uint4 nb = *reinterpret_cast<const uint4 *>(NBR_TAB.v[tid]);
+    const uint4 nb = *reinterpret_cast<const uint4 *>(NBR_TAB.v[ptid]);
     // slot base of the neighbouring tile with delta code (lane & 15), fetched per candidate with a lane permute
     const u32 dl = min(tid & 15u, 8u), ql = (dl * 11u) >> 5;
     const u32 nbase = sslot_base(tr + ql - 1u, tc + (dl - 3u * ql) - 1u, a.nstc);
@@ -356,14 +375,14 @@ __global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
     sh[s] = 8u * b;
     cm[s] = fx_colmask(lcq + b);
   }
-  u32 pc[QPT * 4], qn[QPT * 4];
-  bool lv[QPT];
+  u32 pc[QF * 4], qn[QF * 4];
+  bool lv[QF];
 #pragma unroll
-  for (int j = 0; j < QPT; ++j) {
-    const u32 lr = (tid >> 4) + 16u * j;
-    const u32 l0 = 4u * tid + 1024u * j;
+  for (int j = 0; j < QF; ++j) {
+    const u32 lr = (tid >> 4) + RSTR * j;
+    const u32 l0 = 4u * tid + QSTR * j;
     const u32 c4 = cq[j];
-    const u32 rm = (j == 0 || j == QPT - 1) ? fx_rowmask(lr) : 0u;
+    const u32 rm = (j == 0 || j == QF - 1) ? fx_rowmask(lr) : 0u;
     u32 w4[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -389,7 +408,7 @@ __global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
   __syncthreads();
   if (inf) {  // (one slot per perimeter cell: no two threads share a word)
     int plr, plc;
-    pslot_inv((int)tid, &plr, &plc);
+    pslot_inv((int)ptid, &plr, &plc);
     A[PHYS((u32)(plr * TS + plc))] += inf;
   }
   __syncthreads();
@@ -399,17 +418,17 @@ __global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
   // rounds per trip with the pointer registers swapping roles, so that no register copies are needed.
 #define FY_ROUND(PC, QN, COMBINE)                                                                                       \
   {                                                                                                               \
-    u32 av[QPT * 4];                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < QPT; ++j) {                                                             \
+    u32 av[QF * 4];                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < QF; ++j) {                                                              \
       if (lv[j]) {                                                                                                \
-        const uint4 a4 = *(const uint4 *)&A[4u * tid + 1024u * j];                                                \
+        const uint4 a4 = *(const uint4 *)&A[4u * tid + QSTR * j];                                                  \
         av[4 * j + 0] = a4.x, av[4 * j + 1] = a4.y, av[4 * j + 2] = a4.z, av[4 * j + 3] = a4.w;                   \
         _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                             \
             QN[4 * j + b] = *(const uint16_t *)((const u8 *)P + (PC[4 * j + b] >> 1));                           \
       }                                                                                                           \
     }                                                                                                             \
     __syncthreads(); /* every read of this round precedes every write of this round */                           \
-    _Pragma("unroll") for (int j = 0; j < QPT; ++j) {                                                             \
+    _Pragma("unroll") for (int j = 0; j < QF; ++j) {                                                              \
       if (lv[j]) {                                                                                                \
         /* the four cells of a quad are neighbours in a row and, after a few rounds, mostly share their target: */ \
         /* combine them in registers then (same-address LDS atomics are served one lane after the other)        */ \
@@ -429,19 +448,24 @@ __global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
           _Pragma("unroll") for (int b = 0; b < 4; ++b) atomicAdd((u32 *)((u8 *)A + PC[4 * j + b]), av[4 * j + b]); \
         }                                                                                                         \
         lv[j] = !(QN[4 * j + 0] & QN[4 * j + 1] & QN[4 * j + 2] & QN[4 * j + 3] & FY_SINK0);                      \
-        *(uint2 *)&P[4u * tid + 1024u * j] =                                                                      \
+        *(uint2 *)&P[4u * tid + QSTR * j] =                                                                       \
             make_uint2(QN[4 * j + 0] | (QN[4 * j + 1] << 16), QN[4 * j + 2] | (QN[4 * j + 3] << 16));             \
       }                                                                                                           \
     }                                                                                                             \
   }
+  auto anylive = [&]() {
+    bool v = false;
+    _Pragma("unroll") for (int j = 0; j < QF; ++j) v |= lv[j];
+    return v;
+  };
   int round = 0;
 #ifndef FY_COPY
 #pragma nounroll
   for (; round < MAXROUNDS_TILE; round += 2) {
     FY_ROUND(pc, qn, FY_COMBINE)
-    if (!fx_vote(s_flag, 0, tid, lv[0] | lv[1] | lv[2] | lv[3])) break;
+    if (!fx_vote_n<NW>(s_flag, 0, tid, anylive())) break;
     FY_ROUND(qn, pc, FY_COMBINE)
-    if (!fx_vote(s_flag, 1, tid, lv[0] | lv[1] | lv[2] | lv[3])) {
+    if (!fx_vote_n<NW>(s_flag, 1, tid, anylive())) {
       ++round;
       break;
     }
@@ -450,12 +474,13 @@ __global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
 #pragma nounroll
   for (; round < MAXROUNDS_TILE; ++round) {
     FY_ROUND(pc, qn, FY_COMBINE)
-    _Pragma("unroll") for (int i = 0; i < QPT * 4; ++i) pc[i] = qn[i];
-    if (!fx_vote(s_flag, round, tid, lv[0] | lv[1] | lv[2] | lv[3])) break;
+    _Pragma("unroll") for (int i = 0; i < QF * 4; ++i) pc[i] = qn[i];
+    if (!fx_vote_n<NW>(s_flag, round, tid, anylive())) break;
   }
 #endif
 #undef FY_ROUND
-  const u32 live = (lv[0] ? 1u : 0u) + (lv[1] ? 1u : 0u) + (lv[2] ? 1u : 0u) + (lv[3] ? 1u : 0u);
+  u32 live = 0;
+  _Pragma("unroll") for (int j = 0; j < QF; ++j) live += lv[j] ? 1u : 0u;
   if ((a.ablate & 32) && tid == 0) {
     const unsigned long long r = (unsigned long long)min(round + 1, MAXROUNDS_TILE);
     const u32 w = (tr * a.ntc + tc) & 255u;
@@ -466,8 +491,8 @@ __global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
 
   // ---- write the finished tile (16 B per lane) -----------------------------------------------------------------
 #pragma unroll
-  for (int j = 0; j < QPT; ++j) {
-    const u32 l0 = 4u * tid + 1024u * j;
+  for (int j = 0; j < QF; ++j) {
+    const u32 l0 = 4u * tid + QSTR * j;
     const u32 c4 = cq[j];
     const uint4 a4 = *(const uint4 *)&A[l0];
     const u32 x0 = (qs & 1u) ? a4.y : a4.x, x1 = (qs & 1u) ? a4.x : a4.y;  // undo the swizzle: logical cell k sits in slot k ^ qs
@@ -477,7 +502,7 @@ __global__ void __launch_bounds__(256, 6) k_tile_final_fast(TileArgs a) {
 #pragma unroll
     for (int b = 0; b < 4; ++b)
       if (((c4 >> (8 * b)) & 0xFFu) == D8_MV) o4[b] = -9999;
-    i32 *dst = a.out + (size_t)(r0 + (tid >> 4) + 16u * j - a.row_first) * a.ncol + (size_t)(c0 + lcq);
+    i32 *dst = a.out + (size_t)(r0 + (tid >> 4) + RSTR * j - a.row_first) * a.ncol + (size_t)(c0 + lcq);
     if ((((size_t)dst) & 15) == 0) {
       *(int4 *)dst = make_int4(o4[0], o4[1], o4[2], o4[3]);
     } else {

@@ -536,6 +536,9 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
   tile_body<FINAL, RAW, false, PERIM>(a, A, P, code, s_cnt, tr, tc);
 }
 
+#ifndef FY_NT
+#define FY_NT 256  // threads of the final pass of an interior tile (tile_fast.h; 512 = 8 waves per tile was measured: 20.5 vs 17.6 ms — tiles in flight per CU count, not waves)
+#endif
 #include "tile_fast.h"
 
 // per-tile counts of a raw pass -> the counters k_normalise would have left in ctrl
@@ -1617,8 +1620,8 @@ int TiledRun::phase_b(int *complete) {
   const bool have_i = gridi.x && gridi.y;
   pfd_seg_begin(h, "tile_final");
   if (have_i) {  // (segments: the interior kernel alone, then the frame around it)
-    if (a.weights) k_tile_final_fast<true><<<gridi, 256, 0, h->stream>>>(a);
-    else k_tile_final_fast<false><<<gridi, 256, 0, h->stream>>>(a);
+    if (a.weights) k_tile_final_fast<true, FY_NT><<<gridi, FY_NT, 0, h->stream>>>(a);
+    else k_tile_final_fast<false, FY_NT><<<gridi, FY_NT, 0, h->stream>>>(a);
     pfd_seg_end(h, 1);
     pfd_seg_begin(h, "tile_final_frame");
   }
