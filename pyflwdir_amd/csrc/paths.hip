@@ -332,28 +332,39 @@ __global__ void __launch_bounds__(256) k_xinit(const u32 *__restrict__ xtgt, con
     }
   }
   WJ[s] = (u64)w | ((u64)j << 32);
-  if (!(j & XDONE)) flag_active_p(ctrl);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) k_xround(u64 *__restrict__ WJ, u32 nslots, u64 *ctrl) {
+// FLAG: the round reports whether a pointer is still moving — only the LAST round of a batch does (the flag word is
+// one address for every wave that has something to report: not free, and an earlier round's report says nothing about
+// the state after the batch)
+template <int MODE, bool FLAG>
+__global__ void __launch_bounds__(256) k_xround(u64 *__restrict__ WJ, u32 nslots, u64 *ctrl, u8 *__restrict__ wdone) {
   const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nslots) return;
-  const u64 own = wj_load(WJ + s);
-  const u32 j = (u32)(own >> 32);
-  if (j & XDONE) return;
-  u32 w = (u32)own;
-  const u64 oth = wj_load(WJ + j);
-  const u32 wj = (u32)oth;
-  u32 q = (u32)(oth >> 32);
-  if (MODE == MODE_RANK) {
-    w += wj;
-  } else if (wj) {  // the first outlet on the path wins; the chain ends there
-    w = wj;
-    q = s | XDONE;
+  // a wave whose 64 slots are all saturated (or hold no exit) has nothing left to do in any later round: one byte per
+  // wave instead of 512 bytes of slot words (two thirds of the slots hold no exit, and most chains are short)
+  if (wdone[s >> 6]) return;  // (wave-uniform: nslots is a multiple of 64)
+  bool moving = false;
+  if (s < nslots) {
+    const u64 own = wj_load(WJ + s);
+    const u32 j = (u32)(own >> 32);
+    if (!(j & XDONE)) {
+      u32 w = (u32)own;
+      const u64 oth = wj_load(WJ + j);
+      const u32 wj = (u32)oth;
+      u32 q = (u32)(oth >> 32);
+      if (MODE == MODE_RANK) {
+        w += wj;
+      } else if (wj) {  // the first outlet on the path wins; the chain ends there
+        w = wj;
+        q = s | XDONE;
+      }
+      wj_store(WJ + s, (u64)w | ((u64)q << 32));
+      moving = !(q & XDONE);
+    }
   }
-  wj_store(WJ + s, (u64)w | ((u64)q << 32));
-  if (!(q & XDONE)) flag_active_p(ctrl);
+  const bool any = __ballot(moving) != 0ull;
+  if (!any && (threadIdx.x & 63u) == 0u) wdone[s >> 6] = 1;
+  if (FLAG && any) flag_active_p(ctrl);
 }
 
 // one complete path query; on return *complete = 0 means cycles were found (caller falls back)
@@ -380,19 +391,22 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   const u32 sgrid = cdiv_u32(nslots, 256);
   k_xinit<MODE><<<sgrid, 256, 0, h->stream>>>(xtgt, elink, eval, WJ, (u32)nslots, h->ctrl);
   KCHK();
+  DevBuf wdone;  // one byte per 64 slots: the wave's slots are saturated (k_xround)
+  PFDCHK(wdone.alloc(nslots / 64 + 64));
+  HIPCHK(hipMemsetAsync(wdone.p, 0, nslots / 64 + 64, h->stream));
   bool done = false;
   int batch = 2;
   for (u32 span = 1; span < ntr + ntc; span <<= 1) ++batch;
   for (int rounds = 0; rounds < 40 && !done;) {
-    u64 zero = 0;
-    HIPCHK(hipMemcpyAsync(h->ctrl + P_XACTIVE, &zero, sizeof(u64), hipMemcpyHostToDevice, h->stream));
-    for (int r = 0; r < batch; ++r, ++rounds) {
-      k_xround<MODE><<<sgrid, 256, 0, h->stream>>>(WJ, (u32)nslots, h->ctrl);
+    for (int r = 0; r + 1 < batch; ++r, ++rounds) {
+      k_xround<MODE, false><<<sgrid, 256, 0, h->stream>>>(WJ, (u32)nslots, h->ctrl, wdone.as<u8>());
       ++launches;
     }
+    // the last round of the batch reports: saturated iff it left no pointer moving
+    HIPCHK(hipMemsetAsync(h->ctrl + P_XACTIVE, 0, sizeof(u64), h->stream));
+    k_xround<MODE, true><<<sgrid, 256, 0, h->stream>>>(WJ, (u32)nslots, h->ctrl, wdone.as<u8>());
+    ++launches, ++rounds;
     KCHK();
-    // the flag raised by the LAST round of the batch decides; earlier rounds may have raised it too,
-    // which only costs one more (idempotent) batch
     u64 active = 0;
     HIPCHK(hipMemcpyAsync(&active, h->ctrl + P_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
