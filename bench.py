@@ -47,7 +47,7 @@ PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 B_ALG = {"upstream_area_cell": 29.0, "accuflux_f32": 33.0, "strahler": 18.0, "basins_u32": 18.0, "hand_f32": 35.0}
 B_ALG_PHASE = {"tile_local": 8.0, "exit_graph": 4.0, "tile_final": 17.0}
 # segment -> the kernel it times (names as rocprofv3 prints them); single-launch segments only
-KERNEL_OF = {"tile_local": "void k_tile_local_fast<true, false>(TileArgs)", "tile_final": "void k_tile_final_fast<false>(TileArgs)"}
+KERNEL_OF = {"tile_local": "void k_tile_local_fast<true, false>(TileArgs)", "tile_final": "void k_tile_final_fast<false, 256>(TileArgs)"}
 B_FLOOR = 5.0  # absolute lower bound of upstream_area("cell"): 1 B/cell of codes in + 4 B/cell of counts out
 # synthetic regimes (oracle/pfd_oracle.c orc_synth_d8 and its device twin): tilt >> noise gives long
 # parallel rivers (max rank ~ nrow), small tilt a rough surface with many pits and meandering paths
