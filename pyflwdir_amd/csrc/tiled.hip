@@ -715,17 +715,27 @@ __global__ void __launch_bounds__(256) k_boundary_records(SuperArgs s) {
 // The supertile solve over its exit list.  CAP = exits kept in LDS: SCAP (72 KB, two workgroups per CU) for the
 // supertiles k_exit_lists did not flag, SSL (every slot an exit: 96 KB, one per CU) for the others — contrived
 // rasters only; same code.
-#define SCAP 12288u
-template <bool FINAL, u32 CAP>
+// SCAP / SNT: exits kept in LDS and threads of the regular form.  8192 exits (48 KB) and 512 threads run THREE supertiles per
+// CU (24 waves) where 12288 exits and 1024 threads ran two (32 waves): what these barrier-synchronised chains of LDS
+// round trips respond to is workgroups in flight (§5).  Natural rasters hold 5500-7200 exits per supertile (33-44 % of
+// the slots; synthetic regimes: max 7144); fuller supertiles take the flagged form.
+#ifndef SCAP
+#define SCAP 8192u
+#endif
+#ifndef SNT
+#define SNT 512u
+#endif
+template <bool FINAL, u32 CAP, u32 NT>
 __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
+  constexpr int NW = NT / 64;
   __shared__ u32 T[CAP];
   __shared__ uint16_t P[CAP];
-  __shared__ u32 wtot[16];
-  __shared__ __attribute__((aligned(16))) u32 s_flag[2][16];
+  __shared__ u32 wtot[NW];
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][NW];
   __shared__ u32 s_base;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 base = st << SSHIFT;
-  constexpr int DPT = CAP / 1024;  // exits per thread
+  constexpr int DPT = CAP / NT;  // exits per thread
   if (FINAL && s.edge_nstr) {
     // row blocks, first solve: only the totals pulled by the first and last TILE row are needed yet; they
     // belong to exits in tile rows 0..1 and ntr-2..ntr-1 -> supertile row 0 and the rows of those two
@@ -733,13 +743,15 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
     if (row != 0 && row != (s.ntr - 1) / SG && row != (s.ntr >= 2 ? (s.ntr - 2) / SG : 0u)) return;
   }
   const u32 n = s.scount[st];
-  u32 sbr[2] = {0u, 0u};  // FINAL: the boundary records of the supertile (asked for first: their totals are a dependent load)
-  if (FINAL) sbr[0] = s.sb[(size_t)st * SBN + tid], sbr[1] = s.sb[(size_t)st * SBN + 1024u + tid];
+  constexpr int NSB = SBN / NT;
+  u32 sbr[NSB];  // FINAL: the boundary records of the supertile (asked for first: their totals are a dependent load)
+#pragma unroll
+  for (int hh = 0; hh < NSB; ++hh) sbr[hh] = FINAL ? s.sb[(size_t)st * SBN + NT * hh + tid] : 0u;
   // ---- the exits: list entry -> slot, start value, next hop; dense loads but for the start value ----
   u32 sxbits = 0;  // bit k: own exit k (tid + 1024 k) drains into another supertile
 #pragma unroll 4
   for (int k = 0; k < DPT; ++k) {
-    const u32 e = tid + 1024u * k;
+    const u32 e = tid + NT * k;
     if (e >= n) continue;
     const u32 w = s.xl_slot[base + e];
     u32 nx = s.xl_next[base + e];
@@ -757,11 +769,11 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
     // slots by the level-3 solve), added to the exit the cell's in-tile path reaches
     const u32 str = st / s.nstc, stc = st % s.nstc;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NSB; ++h) {
       const u32 r = sbr[h];
       if (!(r & SB_VALID)) continue;
       u32 R, C;
-      sb_cell(tid + 1024u * h, &R, &C);
+      sb_cell(tid + NT * h, &R, &C);
       u32 m = (r >> 16) & 0xFFu, v = 0;
       while (m) {
         const int k = __ffs((int)m) - 1;
@@ -778,7 +790,7 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
     u32 live = 0;
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
-      const u32 e = tid + 1024u * k;
+      const u32 e = tid + NT * k;
       u32 p = P[e];  // (unconditional, then a select: the branchy form made the compiler spill whole copies of y[])
       p = e < n ? p : SDONE;
       y[k] = p & (SDONE - 1u);
@@ -797,16 +809,16 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
           if (live & (1u << k)) {
             u32 q = P[y[k]];
             q = P[q & (SDONE - 1u)];
-            P[tid + 1024u * k] = (uint16_t)q;
+            P[tid + NT * k] = (uint16_t)q;
             y[k] = q & (SDONE - 1u);
             if (q & SDONE) live &= ~(1u << k);
           }
         }
-        if (!wg_vote<16>(s_flag, round, tid, live != 0u)) break;
+        if (!wg_vote<NW>(s_flag, round, tid, live != 0u)) break;
       }
 #pragma unroll
       for (int k = 0; k < DPT; ++k)  // (nobody adds to the word of an exit that is no root: reading it here is safe)
-        if (nonroot & ~live & (1u << k)) atomicAdd(&T[y[k]], T[tid + 1024u * k]);
+        if (nonroot & ~live & (1u << k)) atomicAdd(&T[y[k]], T[tid + NT * k]);
       __syncthreads();
     } else {
 #pragma nounroll
@@ -815,7 +827,7 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
 #pragma unroll
         for (int k = 0; k < DPT; ++k) {
           if (live & (1u << k)) {
-            av[k] = T[tid + 1024u * k];
+            av[k] = T[tid + NT * k];
             q[k] = P[y[k]];
           }
         }
@@ -824,12 +836,12 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
         for (int k = 0; k < DPT; ++k) {
           if (live & (1u << k)) {
             atomicAdd(&T[y[k]], av[k]);
-            P[tid + 1024u * k] = (uint16_t)q[k];
+            P[tid + NT * k] = (uint16_t)q[k];
             y[k] = q[k] & (SDONE - 1u);
             if (q[k] & SDONE) live &= ~(1u << k);
           }
         }
-        if (!wg_vote<16>(s_flag, round, tid, live != 0u)) break;
+        if (!wg_vote<NW>(s_flag, round, tid, live != 0u)) break;
       }
     }
     if (live && !(s.ablate & 1)) atomicAdd((unsigned long long *)&s.ctrl[T_SLIVE], 1ull);  // a cycle inside the supertile
@@ -838,7 +850,7 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
   if (FINAL) {  // the total of every exit, where the tile entries it drains into will pull it
 #pragma unroll 4
     for (int k = 0; k < DPT; ++k) {
-      const u32 e = tid + 1024u * k;
+      const u32 e = tid + NT * k;
       if (e < n) s.xtot[base + (s.xl_slot[base + e] & (SSL - 1))] = T[e];
     }
     return;
@@ -854,7 +866,7 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
   const u32 ht = (str / HG) * s.nhtc + stc / HG;
   if (tid == 0) {
     u32 tot = 0;
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const u32 c = wtot[w];
       wtot[w] = tot;
       tot += c;
@@ -873,7 +885,7 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
   u32 run = s_base + wtot[wave];
 #pragma unroll
   for (int k = 0; k < DPT; ++k) {
-    const u32 e = tid + 1024u * k;
+    const u32 e = tid + NT * k;
     const bool sx = (sxbits >> k) & 1u;
     const u64 m = __ballot(sx);
     u32 id = NONE32;
@@ -895,9 +907,9 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
 }
 
 template <bool FINAL>
-__global__ void __launch_bounds__(1024, 8) k_super(SuperArgs s) {
+__global__ void __launch_bounds__(SNT, SNT == 512u ? 6 : 8) k_super(SuperArgs s) {
   if (s.sover[blockIdx.x]) return;  // (more exits than SCAP: k_super_flagged takes it)
-  super_solve<FINAL, SCAP>(s, blockIdx.x);
+  super_solve<FINAL, SCAP, SNT>(s, blockIdx.x);
 }
 // the supertiles k_exit_lists flagged (contrived rasters only: normally none, and a grid of this 96 KB kernel over all
 // supertiles costs 60-90 us just to find that out): a small fixed grid walks their list
@@ -906,7 +918,7 @@ template <bool FINAL>
 __global__ void __launch_bounds__(1024, 4) k_super_flagged(SuperArgs s) {
   const u32 nf = *s.nflag;
   for (u32 f = blockIdx.x; f < nf; f += gridDim.x) {
-    super_solve<FINAL, SSL>(s, s.flagged[f]);
+    super_solve<FINAL, SSL, 1024u>(s, s.flagged[f]);
     __syncthreads();  // (the LDS image is reused)
   }
 }
@@ -1473,7 +1485,7 @@ int TiledRun::resolve_with_inflow(i64 *launches) {
   HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
   *launches += 4;
   PFDCHK(level4_down(launches));
-  k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super<true><<<nst, SNT, 0, h->stream>>>(sa);
   k_super_flagged<true><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);
   *launches += 2;
   KCHK();
@@ -1498,7 +1510,7 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   sa.T3 = Tc;
   // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
   sa.hmode = (nht > 1 && !force_flat && !pfd_knob("PFD_FLAT_L3")) ? 1 : 0;
-  k_super<false><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super<false><<<nst, SNT, 0, h->stream>>>(sa);
   k_super_flagged<false><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);  // (normally none)
   KCHK();
   *launches += 2;
@@ -1514,7 +1526,7 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
     PFDCHK(level3_hyper(launches));
   else if (nsuper)
     PFDCHK(level3_flat(launches));
-  k_super<true><<<nst, 1024, 0, h->stream>>>(sa);
+  k_super<true><<<nst, SNT, 0, h->stream>>>(sa);
   k_super_flagged<true><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);
   *launches += 2;
   KCHK();
