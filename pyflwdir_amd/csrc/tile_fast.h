@@ -23,6 +23,7 @@
 //  * one (local) / two (final) barriers per round: the "is any pointer still moving" vote goes through two
 //    alternating LDS flag rows written by the wave leaders instead of three barriers of __syncthreads_or.
 #pragma once
+#include <type_traits>
 
 #define FX_SLOT0 (2u * TCELLS)              // local pass: P byte offset of the pointer word of perimeter slot 0
 #define FX_NOBODY (FX_SLOT0 + 2u * PSL)     // ... of the root nobody asks about (pit, nodata, cell of a cycle)
@@ -132,16 +133,26 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   const u32 tc = blockIdx.x + a.tc_lo, tr = blockIdx.y + a.tr_lo;
   const u32 sbase = sslot_base(tr, tc, a.nstc);
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
+  bool mvq = false;  // RAW: one of the staged bytes is nodata (zero-byte test of v ^ 247 x 4)
   {
     u32 v[5];
     stage_load_interior(RAW ? a.raw : a.ncode, a.ncol, r0, c0, tid, v);
+    if (RAW) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const u32 x = v[k] ^ 0xF7F7F7F7u;
+        mvq |= ((x - 0x01010101u) & ~x & 0x80808080u) != 0u;
+      }
+    }
     stage_store(code, tid, v);
   }
   *(uint4 *)&A[FXP * tid] = make_uint4(0u, 0u, 0u, 0u);
   if (FXP == 8) *(uint4 *)&A[FXP * tid + 4] = make_uint4(0u, 0u, 0u, 0u);
   P[TCELLS + tid] = (uint16_t)(FX_SLOT0 + 2u * tid);  // a root word points at itself
   if (tid == 0) P[TCELLS + PSL] = (uint16_t)FX_NOBODY;
-  __syncthreads();
+  // a tile without a nodata byte in its staging area (most tiles of a land raster) has no "flow into nodata ends
+  // here" to look for: its decode skips the per-cell read of the target's code
+  const bool tile_mv = RAW ? (__syncthreads_or(mvq ? 1 : 0) != 0) : (__syncthreads(), false);
 
   // ---- decode (+ normalise) the thread's 4 quads, initial pointers ------------------------------------------
   const u32 qs = (tid >> 3) & 3u;      // register slot s of a quad holds logical cell s ^ qs (swizzle, see k_tile)
@@ -154,6 +165,8 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
     cm[s] = fx_colmask(lcq + b);
   }
   u32 ndir = 0, npit = 0, nbad = 0;
+  auto decode = [&](auto chk) {
+  constexpr bool CHKMV = decltype(chk)::value;
 #pragma unroll
   for (int j = 0; j < QPT; ++j) {
     const u32 lr = (tid >> 4) + 16u * j;
@@ -169,8 +182,10 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
       const u32 pcnt = __popc(c);
       bool isdir = pcnt == 1u;
       if (RAW) {
-        const u32 t = code[(u32)((int)(ca0 + (sh[s] >> 3)) + fx_sext8(__builtin_amdgcn_perm(FX_TC_HI, FX_TC_LO, k)))];
-        isdir = isdir && t != D8_MV;  // flow into nodata ends here (interior tile: never off the raster)
+        if (CHKMV) {
+          const u32 t = code[(u32)((int)(ca0 + (sh[s] >> 3)) + fx_sext8(__builtin_amdgcn_perm(FX_TC_HI, FX_TC_LO, k)))];
+          isdir = isdir && t != D8_MV;  // flow into nodata ends here (interior tile: never off the raster)
+        }
         const u32 t0 = __builtin_amdgcn_perm(FX_T0_HI, FX_T0_LO, pcnt);
         const u32 n = isdir ? c : t0;
         badq |= t0 & ~c;  // != 0 exactly for a byte that is neither a code nor 247 (247 & ~c == 0 <=> c in {247, 255})
@@ -195,6 +210,9 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
       __builtin_memcpy(a.ncode_w + (size_t)(r0 + lr) * a.ncol + (size_t)(c0 + lcq), &n4, 4);  // possibly unaligned dword
     }
   }
+  };
+  if (RAW && tile_mv) decode(std::true_type{});
+  else decode(std::false_type{});
   if (RAW) {  // counts of the tile -> tcnt (summed by k_tile_counts: no same-address atomics)
     u64 pk = (u64)(ndir + npit) | ((u64)npit << 16) | ((u64)nbad << 32);
     for (int o = 32; o > 0; o >>= 1) pk += __shfl_down(pk, o);
