@@ -289,6 +289,16 @@ int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtype, const vo
  *   verify != 0: nothing is computed; `out` holds a result, *n_bad receives the number of own cells whose value is not
  *                the one their upstream cells (halo seeds included) give — the all-cell check of a blocked result.
  *   boundary_rows_host (nullable): receives the first and the last OWN row (2 * ncol elements). */
+/* Repeated up-sweeps of one block (the exchange-until-stable iteration above) — what the next pfd_accuflux_block
+ * (direction PFD_UP) / pfd_strahler_block call on `h` keeps or reuses, with result and payload in DEVICE memory:
+ *   0 (default)  nothing is kept (a kept sweep is released);
+ *   1            a full sweep whose per-chain arrays and seeds stay on the handle (8-16 bytes per trunk slot);
+ *   2            `out` still holds the result of the kept sweep of the same operation, payload and mask: only the
+ *                chains below a halo seed that CHANGED are folded again (no tile pass, no pass over the raster: the
+ *                cost follows the cells the changed seeds reach).  Falls back to mode 1 when there is no kept sweep
+ *                of this operation into this buffer.  Results are the full sweep's, bit for bit.
+ * Handles whose block has no exact-order plan (PFD_BLOCK_LEVELS) ignore the mode. */
+int pfd_set_block_update(pfd_raster *h, int mode);
 int pfd_accuflux_block(pfd_raster *h, int dtype, const void *data, int by_row, int64_t nodata_i, double nodata_f,
                        int has_nodata, int direction, const void *halo_seed_host, int verify, void *out, int memspace,
                        void *boundary_rows_host, int64_t *n_bad);

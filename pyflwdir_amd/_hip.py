@@ -39,7 +39,7 @@ SYMBOLS = [
     "pfd_rank", "pfd_upstream_area_cell", "pfd_upstream_area_cell_levels", "pfd_accuflux", "pfd_strahler",
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
-    "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic",
+    "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic", "pfd_set_block_update",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def lib() -> C.CDLL:
         L.pfd_comm_exchange_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.pfd_comm_allgather_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.pfd_set_block_io.argtypes = [C.c_void_p, C.c_int]
+        L.pfd_set_block_update.argtypes = [C.c_void_p, C.c_int]
         L.pfd_malloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
         L.pfd_free.argtypes = [C.c_int, C.c_void_p]
         L.pfd_memcpy_h2d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -279,6 +280,11 @@ class RasterHandle:
     def set_block_io(self, seed_memspace):
         """Where the ``*_block`` sweeps read their halo seeds from (PFD_HOST / PFD_DEVICE)."""
         check(lib().pfd_set_block_io(self._h, int(seed_memspace)))
+
+    def set_block_update(self, mode):
+        """What the next up-sweep of this block keeps / reuses (include/pfd.h pfd_set_block_update): 0 nothing, 1 keep
+        the sweep, 2 update the kept sweep's result for the halo seeds that changed."""
+        check(lib().pfd_set_block_update(self._h, int(mode)))
 
     def set_profiling(self, on=True):  # (2: also count the doubling rounds of the tile passes, see graph_stats)
         check(lib().pfd_set_profiling(self._h, int(on)))

@@ -489,6 +489,16 @@ extern "C" int pfd_set_block_io(pfd_raster *h, int seed_memspace) {
   return PFD_OK;
 }
 
+extern "C" int pfd_set_block_update(pfd_raster *h, int mode) {
+  if (!h || mode < 0 || mode > 2) {
+    pfd_set_error("pfd_set_block_update: bad arguments");
+    return PFD_EINVAL;
+  }
+  h->block_update = mode;
+  if (mode == 0 && h->xplan) pfd_xinc_drop(h);
+  return PFD_OK;
+}
+
 extern "C" int pfd_set_profiling(pfd_raster *h, int enable) {
   PFDCHK(pfd_check_handle_lazy(h));
   h->profiling = enable != 0;

@@ -156,6 +156,7 @@ struct pfd_raster {
   const void *xseed = nullptr;
   void *xseed_out = nullptr;
   size_t xseed_elem = 0;
+  int block_update = 0;  // pfd_set_block_update: 0 = block up-sweeps keep nothing, 1 = keep the sweep for updates, 2 = update
   int block_seed_space = PFD_HOST;  // where the pfd_*_block entry points read their halo seeds (pfd_set_block_io)
   u8 *halo_raw = nullptr;  // row blocks: the D8 codes of the two halo rows as given (2 * ncol; the normalised codes hold sinks there)
   void *hand_block_state = nullptr;  // cells of a row block whose HAND is still unknown, between pfd_hand_block calls (sweeps.hip)
@@ -257,6 +258,7 @@ void pfd_free_pending_basins(pfd_raster *h);                     // paths.hip
 void pfd_free_hand_block(pfd_raster *h);                         // sweeps.hip
 int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
 void pfd_free_xplan(pfd_raster *h);                             // exact.hip
+void pfd_xinc_drop(pfd_raster *h);                               // exact.hip: releases a kept block sweep
 void pfd_free_general(pfd_raster *h);                           // general.hip
 int pfd_handle_alloc(i64 nrow, i64 ncol, int device, pfd_raster **out);  // api.hip: empty handle (stream, code raster, ctrl)
 // general.hip: the entry points of a general idxs_ds graph (h->gen != nullptr)

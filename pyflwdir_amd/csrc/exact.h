@@ -63,7 +63,22 @@ struct ExactPlan {
   i64 b_chain[33] = {0};  // chains of round b = [b_chain[b], b_chain[b+1])
   i64 b_slot[33] = {0};   // slots  of round b = [b_slot[b],  b_slot[b+1])
   size_t bytes = 0;
+  // ---- incremental re-sweeps of a row block (run_exact_up, pfd_set_block_update) ------------------------------
+  // A block's up-sweep is repeated with other halo seeds until the boundary rows settle; from the second sweep on
+  // only the chains below a CHANGED seed are folded again: the element / value arrays of the last sweep are kept,
+  // a chain is dirty when a halo cell with another seed drains into it, or when the chain that ends in it was dirty.
+  u32 *schain = nullptr;  // [nslot] chain of a slot (built on first use)
+  u32 *dchain = nullptr;  // [nchain] chain of the cell the chain's last cell drains into (0xFFFFFFFF: none)
+  u32 *hfeed = nullptr;   // [2 * ncol] chain of the own cell a halo cell drains into (0xFFFFFFFF: none)
+  u8 *dirty = nullptr;    // [nchain]
+  void *incE = nullptr, *incR = nullptr, *incSeed = nullptr;
+  size_t inc_tag = 0, inc_bytes = 0;  // operation of the kept sweep (type hash); bytes of incE + incR + incSeed
+  const void *inc_out = nullptr;      // its result buffer
+  bool inc_valid = false;
 };
+int pfd_xinc_prepare(pfd_raster *h);  // builds schain / dchain / hfeed / dirty (once per plan)
+void pfd_xinc_drop(pfd_raster *h);    // releases the kept sweep (incE / incR / incSeed)
+int pfd_xinc_mark(pfd_raster *h, const void *seed_dev, size_t elem);  // dirty <- chains below a changed seed; keeps the seeds
 
 // builds the plan on first use; h->xplan_state: 0 not built, 1 ready, -1 not available (cycles, row
 // block, more than 2^32 - 2 cells)

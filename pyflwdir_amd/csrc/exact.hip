@@ -448,9 +448,152 @@ static void xdigest(pfd_raster *h, const char *name, const void *p, size_t bytes
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// incremental re-sweeps of a row block (exact.h): chain of a slot, chain below a chain, chain below a halo cell
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_xinc_schain(const u32 *__restrict__ cstart, u32 nchain, u32 nslot, u32 *__restrict__ schain) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslot) return;
+  u32 lo = 0, hi = nchain;  // the last chain that starts at or before s (cstart ascends; padding belongs to the chain before it)
+  while (hi - lo > 1u) {
+    const u32 mid = (lo + hi) >> 1;
+    if (cstart[mid] <= s) lo = mid;
+    else hi = mid;
+  }
+  schain[s] = lo;
+}
+__global__ void __launch_bounds__(256) k_xinc_dchain(const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
+                                                     const u32 *__restrict__ scell, const u8 *__restrict__ ncode,
+                                                     const u8 *__restrict__ lh, const u32 *__restrict__ cslot,
+                                                     const u32 *__restrict__ schain, Geo g, u32 nchain, u32 *__restrict__ dchain) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nchain) return;
+  const u32 cl = clen[c], np = cl >> 29;
+  const u32 x = scell[cstart[c] + (cl & XC_LEN) - 1u - np];  // the chain's last cell
+  const u32 code = ncode[x];
+  u32 d = 0xFFFFFFFFu;
+  if (d8_is_dir(code)) {
+    const u32 y = d8_down(g, x, code);
+    if (xl_trunk(lh[y])) d = schain[cslot[y]];  // (a halo cell or a pit below: nothing to fold again)
+  }
+  dchain[c] = d;
+}
+// ctrl[0] counts halo cells that drain into an own cell which is no trunk cell (k_plan_tile blocks those: must stay 0)
+__global__ void __launch_bounds__(256) k_xinc_hfeed(const u8 *__restrict__ halo_raw, const u8 *__restrict__ ncode,
+                                                    const u8 *__restrict__ lh, const u32 *__restrict__ cslot,
+                                                    const u32 *__restrict__ schain, u32 ncol, u32 halo_top, u32 halo_bot,
+                                                    u32 own_rows, u32 *__restrict__ hfeed, unsigned long long *__restrict__ ctrl) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2u * ncol) return;
+  const u32 side = i >= ncol ? 1u : 0u, gc = i - side * ncol;
+  u32 f = 0xFFFFFFFFu;
+  if (side ? halo_bot : halo_top) {
+    const u32 hr = side ? halo_top + own_rows : halo_top - 1u;
+    const u32 raw = halo_raw[i];
+    const u32 x = hr * ncol + gc;
+    if (ncode[x] != D8_MV && d8_is_dir(raw)) {
+      const int k = d8_slot(raw);
+      const int tgc = (int)gc + d8_dc(k);
+      if (d8_dr(k) == (side ? -1 : 1) && tgc >= 0 && tgc < (int)ncol) {  // (only a step into the own rows links the halo cell)
+        const u32 y = (u32)((int)hr + d8_dr(k)) * ncol + (u32)tgc;
+        if (ncode[y] != D8_MV) {
+          if (xl_trunk(lh[y])) f = schain[cslot[y]];
+          else atomicAdd(ctrl, 1ull);
+        }
+      }
+    }
+  }
+  hfeed[i] = f;
+}
+template <class W>
+__global__ void __launch_bounds__(256) k_xinc_mark(const W *__restrict__ seed, W *__restrict__ prev, const u32 *__restrict__ hfeed,
+                                                   u32 n2, u8 *__restrict__ dirty) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  const W v = seed[i];
+  if (v == prev[i]) return;  // (bitwise: W is an unsigned integer of the element's size)
+  prev[i] = v;
+  const u32 f = hfeed[i];
+  if (f != 0xFFFFFFFFu) dirty[f] = 1;
+}
+
+void pfd_xinc_drop(pfd_raster *h) {
+  ExactPlan *p = (ExactPlan *)h->xplan;
+  if (!p) return;
+  pfd_dfree(p->incE);
+  pfd_dfree(p->incR);
+  pfd_dfree(p->incSeed);
+  p->incE = p->incR = p->incSeed = nullptr;
+  h->bytes_held -= std::min(h->bytes_held, p->inc_bytes);
+  p->inc_bytes = 0;
+  p->inc_valid = false;
+  p->inc_out = nullptr;
+}
+int pfd_xinc_prepare(pfd_raster *h) {
+  ExactPlan *p = (ExactPlan *)h->xplan;
+  if (!p || h->xplan_state != 1 || !h->halo_raw) {
+    pfd_set_error("incremental block sweeps need the exact-order plan of a row block");
+    return PFD_EINVAL;
+  }
+  if (p->schain) return PFD_OK;
+  const size_t nsl = std::max<size_t>((size_t)p->nslot, 4), nch = std::max<size_t>((size_t)p->nchain, 1);
+  int rc;
+  if ((rc = pfd_dmalloc((void **)&p->schain, nsl * sizeof(u32))) != PFD_OK ||
+      (rc = pfd_dmalloc((void **)&p->dchain, nch * sizeof(u32))) != PFD_OK ||
+      (rc = pfd_dmalloc((void **)&p->hfeed, 2 * (size_t)h->ncol * sizeof(u32))) != PFD_OK ||
+      (rc = pfd_dmalloc((void **)&p->dirty, nch)) != PFD_OK) {
+    pfd_dfree(p->schain), pfd_dfree(p->dchain), pfd_dfree(p->hfeed), pfd_dfree(p->dirty);
+    p->schain = p->dchain = p->hfeed = nullptr, p->dirty = nullptr;
+    return rc;
+  }
+  const size_t add = nsl * 4 + nch * 5 + 2 * (size_t)h->ncol * 4;
+  p->bytes += add, h->bytes_held += add;
+  pfd_seg_begin(h, "xinc_prepare");
+  HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(u64), h->stream));
+  HIPCHK(hipMemsetAsync(p->schain, 0, nsl * sizeof(u32), h->stream));
+  if (p->nchain) {
+    k_xinc_schain<<<cdiv_u32((u64)p->nslot, 256), 256, 0, h->stream>>>(p->cstart, (u32)p->nchain, (u32)p->nslot, p->schain);
+    k_xinc_dchain<<<cdiv_u32((u64)p->nchain, 256), 256, 0, h->stream>>>(p->cstart, p->clen, p->scell, h->ncode, p->lh, p->cslot,
+                                                                        p->schain, h->geo, (u32)p->nchain, p->dchain);
+  }
+  k_xinc_hfeed<<<cdiv_u32(2 * (u64)h->ncol, 256), 256, 0, h->stream>>>(h->halo_raw, h->ncode, p->lh, p->cslot, p->schain,
+                                                                       (u32)h->ncol, (u32)h->halo_top, (u32)h->halo_bot,
+                                                                       (u32)h->own_rows, p->hfeed, (unsigned long long *)h->ctrl);
+  KCHK();
+  pfd_seg_end(h, 3);
+  u64 odd = 0;
+  HIPCHK(hipMemcpyAsync(&odd, h->ctrl, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (odd) {
+    pfd_set_error("internal: %llu halo cells drain into a cell that is not a trunk cell of the block's plan", (unsigned long long)odd);
+    return PFD_EUNSUPPORTED;
+  }
+  return PFD_OK;
+}
+int pfd_xinc_mark(pfd_raster *h, const void *seed_dev, size_t elem) {
+  ExactPlan *p = (ExactPlan *)h->xplan;
+  const u32 n2 = 2u * (u32)h->ncol;
+  HIPCHK(hipMemsetAsync(p->dirty, 0, std::max<size_t>((size_t)p->nchain, 1), h->stream));
+  const u32 grid = cdiv_u32(n2, 256);
+  if (elem == 1) k_xinc_mark<u8><<<grid, 256, 0, h->stream>>>((const u8 *)seed_dev, (u8 *)p->incSeed, p->hfeed, n2, p->dirty);
+  else if (elem == 4) k_xinc_mark<u32><<<grid, 256, 0, h->stream>>>((const u32 *)seed_dev, (u32 *)p->incSeed, p->hfeed, n2, p->dirty);
+  else if (elem == 8) k_xinc_mark<u64><<<grid, 256, 0, h->stream>>>((const u64 *)seed_dev, (u64 *)p->incSeed, p->hfeed, n2, p->dirty);
+  else {
+    pfd_set_error("incremental block sweep: element size %zu", elem);
+    return PFD_EINVAL;
+  }
+  KCHK();
+  return PFD_OK;
+}
+
 void pfd_free_xplan(pfd_raster *h) {
   ExactPlan *p = (ExactPlan *)h->xplan;
   if (p) {
+    pfd_xinc_drop(h);
+    pfd_dfree(p->schain);
+    pfd_dfree(p->dchain);
+    pfd_dfree(p->hfeed);
+    pfd_dfree(p->dirty);
     pfd_dfree(p->lh);
     pfd_dfree(p->kids);
     pfd_dfree(p->tord);

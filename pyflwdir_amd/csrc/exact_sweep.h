@@ -17,6 +17,7 @@
 //   V droot(DElem) / V dfold(DElem, V pv);  V top(p);  void store(x, V);  V dnodata(x) value of a nodata cell
 #pragma once
 #include <type_traits>
+#include <typeinfo>
 
 #include "exact.h"
 
@@ -181,16 +182,18 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
                                                     u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
                                                     const u32 *__restrict__ spost,
                                                     const typename Op::Elem *__restrict__ E,
-                                                    typename Op::V *__restrict__ R) {
+                                                    typename Op::V *__restrict__ R, const u8 *__restrict__ dirty = nullptr) {
   typedef typename Op::Elem Elem;
   typedef typename Op::V V;
   constexpr int G = XBlk<Elem>::G;
+  // (dirty != nullptr: an incremental re-sweep of a row block — only the chains marked there are folded again)
   if (blockIdx.x < nlong) {
     __shared__ XVec4<Elem> sE[64];
     __shared__ XVec4<V> sR[64];
     __shared__ u32 sB[64];
     const u32 lane = threadIdx.x;
     const u32 cc = longc[blockIdx.x];
+    if (dirty && !dirty[cc]) return;
     const u32 s0 = cstart[cc];
     const u32 ng = ((clen[cc] & XC_LEN) + 3u) >> 2;
     const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
     return;
   }
   const u32 c = c0 + (blockIdx.x - nlong) * blockDim.x + threadIdx.x;
-  const bool active = c < c1;
+  const bool active = c < c1 && (!dirty || dirty[c]);
   const u32 s0 = active ? cstart[c] : 0u;
   u32 m = active ? (clen[c] & XC_LEN) : 0u;
   if (m >= XLONG) m = 0;  // folded by a wave of its own (above)
@@ -444,11 +447,93 @@ __global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, co
   }
 }
 
+// ---- incremental re-sweep of a row block (ExactPlan::schain ...): the same three steps for the dirty chains only ----
 template <class Op>
-static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
+__global__ void __launch_bounds__(256) k_xtrunk_pre_inc(Op op, const u32 *__restrict__ scell, const uint16_t *__restrict__ sinfo,
+                                                        const u32 *__restrict__ schain, const u8 *__restrict__ dirty, u32 s0,
+                                                        u32 s1, typename Op::Elem *__restrict__ E) {
+  const u32 s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= s1 || !dirty[schain[s]]) return;
+  const u32 info = sinfo[s];
+  const u32 x = scell[s];
+  E[s] = (info & XS_POST) ? op.pre_post(x) : op.pre_real(x, info & 0xFFu, (info >> 8) & 0xFu);
+}
+// the end of a dirty chain goes to the raster (a later round reads it) and makes the chain it drains into dirty
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_ends_inc(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
+                                                         u32 c0, u32 c1, const u32 *__restrict__ scell,
+                                                         const typename Op::V *__restrict__ R, const u32 *__restrict__ dchain,
+                                                         u8 *__restrict__ dirty) {
+  const u32 c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c1 || !dirty[c]) return;
+  const u32 cl = clen[c], np = cl >> 29;
+  const u32 s = cstart[c] + (cl & XC_LEN) - 1u - np;
+  op.store(scell[s], R[s + np]);
+  const u32 d = dchain[c];
+  if (d != 0xFFFFFFFFu) dirty[d] = 1;  // (always a chain of a later round)
+}
+// the cells of the dirty chains, in chain order (a sector per value — but only below the seeds that changed)
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_scatter_inc(Op op, const u32 *__restrict__ scell, const uint16_t *__restrict__ sinfo,
+                                                            const u32 *__restrict__ schain, const u8 *__restrict__ dirty, u32 nslot,
+                                                            const typename Op::V *__restrict__ R) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslot || !dirty[schain[s]]) return;
+  const u32 info = sinfo[s];
+  if (info & XS_POST) return;  // (padding slots are post slots)
+  op.store(scell[s], R[s + ((info >> 12) & 7u)]);
+}
+// an update request (pfd_set_block_update(h, 2)) can be served: the kept sweep is this operation's, into this buffer
+static inline bool xinc_applies(pfd_raster *h, const void *out_dev, size_t tag) {
+  const ExactPlan *p = (const ExactPlan *)h->xplan;
+  return h->block_update == 2 && h->xplan_state == 1 && p && p->inc_valid && p->inc_tag == tag && p->inc_out == out_dev;
+}
+template <class Op>
+static int run_exact_up_inc(pfd_raster *h, const Op &op) {
   typedef typename Op::Elem Elem;
   typedef typename Op::V V;
   ExactPlan *p = (ExactPlan *)h->xplan;
+  pfd_seg_begin(h, "exact_up_block_update");
+  PFDCHK(pfd_xinc_mark(h, h->xseed, h->xseed_elem));
+  i64 launches = 2;
+  Elem *E = (Elem *)p->incE;
+  V *R = (V *)p->incR;
+  for (int b = 0; b < 32; ++b) {
+    const u32 s0 = (u32)p->b_slot[b], s1 = (u32)p->b_slot[b + 1];
+    const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
+    if (c1 == c0) continue;
+    k_xtrunk_pre_inc<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, p->schain, p->dirty, s0, s1, E);
+    const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
+    k_xtrunk_scan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->longc + p->b_long[b], nl,
+                                                                        p->spost, E, R, p->dirty);
+    k_xtrunk_ends_inc<Op><<<cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, R, p->dchain,
+                                                                         p->dirty);
+    launches += 3;
+  }
+  if (p->nslot) {
+    k_xtrunk_scatter_inc<Op><<<cdiv_u32((u64)p->nslot, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, p->schain, p->dirty,
+                                                                                 (u32)p->nslot, R);
+    ++launches;
+  }
+  KCHK();
+  pfd_seg_end(h, launches);
+  return PFD_OK;
+}
+
+// keep: 0 = a sweep that leaves nothing behind; 1 = row block: keep the element / value arrays for updates;
+// 2 = row block: `out` holds the result of the kept sweep for other halo seeds — fold only what the changed seeds reach
+// (a full sweep, kept, when there is nothing to update from)
+template <class Op>
+static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep = 0) {
+  typedef typename Op::Elem Elem;
+  typedef typename Op::V V;
+  ExactPlan *p = (ExactPlan *)h->xplan;
+  const size_t tag = typeid(Op).hash_code();
+  if (!(h->xseed && h->xseed_out && h->halo_raw)) keep = 0;
+  // (the caller has put the seeds into the halo rows of `out`)
+  if (keep == 2 && xinc_applies(h, h->xseed_out, tag)) return run_exact_up_inc(h, op);
+  pfd_xinc_drop(h);
+  if (keep && pfd_xinc_prepare(h) != PFD_OK) keep = 0;
   pfd_seg_begin(h, name);
   i64 launches = 1;
   XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff, nullptr, nullptr};
@@ -463,33 +548,51 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name) {
       HIPCHK(hipMemcpyAsync((char *)h->xseed_out + (size_t)(h->halo_top + h->own_rows) * rowb, (const char *)h->xseed + rowb, rowb,
                             hipMemcpyDeviceToDevice, h->stream));
   }
-  DevBuf E, R;
-  PFDCHK(E.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(Elem) + 64));
-  PFDCHK(R.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(V) + 64));
+  DevBuf Eb, Rb;
+  const size_t ebytes = std::max<size_t>((size_t)p->nslot, 1) * sizeof(Elem) + 64, rbytes = std::max<size_t>((size_t)p->nslot, 1) * sizeof(V) + 64;
+  const size_t sbytes = 2 * (size_t)h->ncol * h->xseed_elem;
+  if (keep) {
+    int rc;
+    if ((rc = pfd_dmalloc(&p->incE, ebytes)) != PFD_OK || (rc = pfd_dmalloc(&p->incR, rbytes)) != PFD_OK ||
+        (rc = pfd_dmalloc(&p->incSeed, sbytes)) != PFD_OK) {
+      pfd_xinc_drop(h);
+      return rc;
+    }
+    p->inc_bytes = ebytes + rbytes + sbytes;
+    h->bytes_held += p->inc_bytes;
+  } else {
+    PFDCHK(Eb.alloc(ebytes));
+    PFDCHK(Rb.alloc(rbytes));
+  }
+  Elem *E = keep ? (Elem *)p->incE : Eb.as<Elem>();
+  V *R = keep ? (V *)p->incR : Rb.as<V>();
   for (int b = 0; b < 32; ++b) {
     const u32 s0 = (u32)p->b_slot[b], s1 = (u32)p->b_slot[b + 1];
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
     if (c1 == c0) continue;
-    k_xtrunk_pre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, E.as<Elem>());
+    k_xtrunk_pre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, E);
     XDBG(h, "pre");
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
     k_xtrunk_scan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
-                                                                        p->longc + p->b_long[b], nl, p->spost,
-                                                                        E.as<Elem>(), R.as<V>());
+                                                                        p->longc + p->b_long[b], nl, p->spost, E, R);
     XDBG(h, "scan");
-    k_xtrunk_ends<Op><<<cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, R.as<V>());
+    k_xtrunk_ends<Op><<<cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, R);
     XDBG(h, "ends");
     launches += 3;
   }
   if (p->nslot) {
     a.cslot = p->cslot;
-    k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, R.as<V>());
+    k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, R);
     XDBG(h, "unscatter");
     ++launches;
   }
   KCHK();
   pfd_seg_end(h, launches);
-  HIPCHK(hipStreamSynchronize(h->stream));  // E / R are released on return
+  if (keep) {  // what an update starts from: this sweep's arrays, seeds and result buffer
+    HIPCHK(hipMemcpyAsync(p->incSeed, h->xseed, sbytes, hipMemcpyDeviceToDevice, h->stream));
+    p->inc_valid = true, p->inc_tag = tag, p->inc_out = h->xseed_out;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));  // E / R are released on return (unless kept)
   return PFD_OK;
 }
 

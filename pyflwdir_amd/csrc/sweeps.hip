@@ -1498,7 +1498,7 @@ static int up_block_run(pfd_raster *h, const Op &op0, T *out_dev, const T *seed_
     // exact-order engine: the tile pass writes every cell, the halo cells among them; their given values go back in
     // before the trunk rounds read them (run_exact_up)
     h->xseed = seed_dev, h->xseed_out = out_dev, h->xseed_elem = sizeof(T);
-    const int rc = run_exact_up(h, op0, "exact_up_block");
+    const int rc = run_exact_up(h, op0, "exact_up_block", h->block_update);
     h->xseed = nullptr, h->xseed_out = nullptr, h->xseed_elem = 0;
     PFDCHK(rc);
   } else {
@@ -1606,7 +1606,11 @@ static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T noda
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(T), memspace));
   if (verify && memspace == PFD_HOST)
     HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n * sizeof(T), hipMemcpyHostToDevice, h->stream));
-  if (!verify) {
+  // (an update — pfd_set_block_update(h, 2) after a kept sweep of the same operation into the same buffer — starts
+  //  from the result in `out`)
+  const bool upd = direction == PFD_UP && xinc_applies(h, o.dev, by_row ? typeid(AccuUp<T, RowData<T>>).hash_code()
+                                                                        : typeid(AccuUp<T>).hash_code());
+  if (!verify && !upd) {
     pfd_seg_begin(h, "init");
     if (by_row) {
       k_fill_rows<T><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((const T *)d.dev, h->geo, (T *)o.dev);
@@ -1666,7 +1670,7 @@ extern "C" int pfd_strahler_block(pfd_raster *h, const uint8_t *mask, const uint
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n, memspace));
   if (verify && memspace == PFD_HOST) HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
-  if (!verify) {
+  if (!verify && !xinc_applies(h, o.dev, typeid(Strahler).hash_code())) {
     pfd_seg_begin(h, "init");
     HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
     pfd_seg_end(h, 1);

@@ -176,8 +176,15 @@ class _UpBlock:
             self.payload = None if payload is None else np.ascontiguousarray(payload, dtype=np.float32)  # step-length rows
         self.out = _hip.DeviceBuffer(self.nrows_dev * ncol * self.dtype.itemsize, dev)
         self.swept_with, self.brows = None, None
+        # accuflux "up" and Strahler: from the second sweep on only the chains below a changed halo seed are folded
+        # again (pfd_set_block_update; the down-sweeps of accuflux "down" / stream_distance sweep the block each time)
+        self.incremental = kind == "strahler" or (kind == "accuflux" and direction == _hip.PFD_UP)
+        self.sweeps = 0
 
     def _call(self, seed, verify):
+        if self.incremental and not verify:
+            self.h.set_block_update(2 if self.sweeps else 1)
+            self.sweeps += 1
         if self.kind == "accuflux":
             nd_i, nd_f, has_nd = self.nodata
             return self.h.accuflux_block(self.payload, _hip._PAYLOAD_CODE[self.dtype], seed, self.out, nd_i, nd_f, has_nd,
@@ -215,6 +222,8 @@ class _UpBlock:
                 b.free()
         if close_handle:
             self.h.close()
+        elif self.incremental and self.sweeps:
+            self.h.set_block_update(0)  # (releases the kept sweep)
 
 
 MAX_ROUNDS = 256  # default bound of the fixpoint iterations below (sharded HAND needs 11 on the roughest test raster)

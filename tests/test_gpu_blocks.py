@@ -495,3 +495,83 @@ def test_hand_blocks_refuse_non_finite_elevations(gpu_lib, oracle):
     elev[50, 40] = np.inf
     with pytest.raises(NotImplementedError, match="finite elevations"):
         dist.hand_blocks(d8, 2, np.zeros((120, 90), np.uint8), elev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,dtype", [("accuflux", np.float32), ("accuflux", np.float64), ("strahler", np.uint8)])
+def test_block_updates_fold_only_below_changed_seeds(gpu_lib, oracle, kind, dtype):
+    """pfd_set_block_update: the second and later sweeps of a block (other halo seeds, result in place) take the update
+    path — no tile pass, only the chains below a changed seed — and give the full sweep's bits; an update request
+    without a kept sweep of the operation, or into another buffer, is a full sweep."""
+    from pyflwdir_amd import _hip, dist
+
+    O = oracle
+    nrow, ncol, nb = 900, 700, 3
+    d8 = O.synth_d8(nrow, ncol, seed=171, tilt=100000, white=2, nodata_pct=10)
+    rng = np.random.default_rng(3)
+    data = (rng.random(d8.shape) * 2.5 + 1e-3).astype(dtype) if kind == "accuflux" else None
+
+    def run(incremental):
+        blocks, names = [], []
+        for b, (r0, r1) in enumerate(dist.block_rows(nrow, nb)):
+            a, e = dist.block_slice(nrow, nb, b)
+            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, halo=dist.halo_of(b, nb))
+            h.set_profiling(True)
+            blk = dist._UpBlock(h, kind, dtype, payload=None if data is None else data[a:e], nodata=(-9999, -9999.0, 1))
+            blk.incremental = incremental
+            blocks.append(blk)
+        try:
+            seeds = [np.zeros(2 * ncol, dtype) for _ in range(nb)]
+            for it in range(16):
+                swept = []
+                for b, blk in enumerate(blocks):
+                    swept.append(blk.sweep(seeds[b]))
+                    if swept[-1]:
+                        names.append((it, [s["name"] for s in blk.h.last_timing()]))
+                if not any(swept):
+                    break
+                for b in range(nb):
+                    if b > 0:
+                        seeds[b][:ncol] = blocks[b - 1].brows[1]
+                    if b + 1 < nb:
+                        seeds[b][ncol:] = blocks[b + 1].brows[0]
+            bad = sum(blk.verify(seeds[b]) for b, blk in enumerate(blocks))
+            return np.concatenate([blk.result() for blk in blocks], axis=0), names, bad
+        finally:
+            for blk in blocks:
+                blk.close()
+
+    full, names_full, bad_full = run(False)
+    inc, names_inc, bad_inc = run(True)
+    assert bad_full == 0 and bad_inc == 0
+    assert np.array_equal(full.view(np.uint8), inc.view(np.uint8))
+    assert all("exact_up_block_update" not in n for _, n in names_full)
+    assert all(("exact_up_block_update" in n) == (it > 0) for it, n in names_inc), names_inc
+    assert any(it > 0 for it, _ in names_inc)
+    # an update request with nothing kept, and one into another buffer: full sweeps with the same result
+    a, e = dist.block_slice(nrow, nb, 1)
+    h = _hip.RasterHandle(d8[a:e], dist.block_rows(nrow, nb)[1][1] - dist.block_rows(nrow, nb)[1][0], ncol, halo=dist.halo_of(1, nb))
+    try:
+        h.set_profiling(True)
+        blk = dist._UpBlock(h, kind, dtype, payload=None if data is None else data[a:e], nodata=(-9999, -9999.0, 1))
+        blk.sweeps = 1  # (asks for an update straight away)
+        seed = np.zeros(2 * ncol, dtype)
+        seed[:ncol] = full[a]  # the final row above the block; the row below stays 0
+        blk.sweep(seed)
+        assert "exact_up_block_update" not in [s["name"] for s in h.last_timing()]
+        first = blk.result().copy()
+        other = _hip.DeviceBuffer(blk.out.nbytes, h.device)
+        keep, blk.out = blk.out, other
+        blk.swept_with = None
+        blk.sweep(seed)
+        assert "exact_up_block_update" not in [s["name"] for s in h.last_timing()]
+        assert np.array_equal(blk.result().view(np.uint8), first.view(np.uint8))
+        blk.swept_with = None
+        seed[:ncol] = 0
+        blk.sweep(seed)  # now an update of the sweep kept for `other`
+        assert "exact_up_block_update" in [s["name"] for s in h.last_timing()]
+        blk.out = keep
+        other.free()
+        blk.close(close_handle=False)
+    finally:
+        h.close()

@@ -30,6 +30,8 @@ for kind, dtype in (("accuflux", np.float32), ("strahler", np.uint8)):
         a, e = dist.block_slice(nrow, nb, b)
         hh = _hip.RasterHandle(d8.addr + a * ncol, r1 - r0, ncol, memspace=_hip.PFD_DEVICE, halo=dist.halo_of(b, nb))
         blocks.append(dist._UpBlock(hh, kind, dtype, payload=rows[a:e] if kind == "accuflux" else None, by_row=True, nodata=(-9999, -9999.0, 1)))
+    if os.environ.get("PFD_UP_FULL"):  # A/B: every round sweeps the whole block (the behaviour before round 4)
+        for blk in blocks: blk.incremental = False
     seeds = [np.zeros(2 * ncol, dtype) for _ in range(nb)]
     times = []
     for it in range(64):
