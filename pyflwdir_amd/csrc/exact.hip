@@ -37,7 +37,8 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
   __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
   __shared__ u32 cnt[XTC];         // unresolved upstream cells | 0x100 blocked | 0x200 nodata
   __shared__ uint16_t ord[XTC];
-  __shared__ u32 s_n;              // entries in ord
+  __shared__ u32 s_n;              // entries in ord after the headwaters
+  __shared__ u32 s_add[XOFF];      // entries appended by step s (a counter per step: one barrier per step)
   __shared__ uint16_t off[XOFF];
   const u32 tid = threadIdx.x;
   const u32 tc = blockIdx.x, tr = blockIdx.y;
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
     stage_store(code, tid, v);
   }
   if (tid == 0) s_n = 0;
-  if (tid < XOFF) off[tid] = 0;
+  if (tid < XOFF) off[tid] = 0, s_add[tid] = 0;
   __syncthreads();
   // image rows that are halo rows of the block (-2: none)
   int hrow[2] = {-2, -2};
@@ -71,6 +72,17 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
     __syncthreads();
   }
   auto is_halo_row = [&](int lr) { return lr == hrow[0] || lr == hrow[1]; };
+  // append to ord, one LDS atomic per wave (every lane of the wave calls it: same-address atomics with a return value
+  // are served one lane after the other)
+  const u32 lane = tid & 63u;
+  auto append = [&](bool f, u32 val, u32 *counter, u32 first) {
+    const u64 bm = __ballot(f);
+    if (!bm) return;
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(counter, (u32)__popcll(bm));
+    base = first + (u32)__shfl((int)base, 0);
+    if (f) ord[base + (u32)__popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)val;
+  };
   u32 mykids[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -97,58 +109,46 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
     }
     mykids[j] = m;
     const u32 v = (c == D8_MV ? 0u : nkids) | blocked;
-    cnt[l] = v;
-    if (v == 0) ord[atomicAdd(&s_n, 1u)] = (uint16_t)l;  // headwater: step 0
+    cnt[l] = v == 0 ? 0x1000u : v;  // (0x1000 | step: the cell is a leaf of that step — headwaters: step 0)
+    append(v == 0, l, &s_n, 0u);
   }
   __syncthreads();
   u32 begin = 0, end = s_n;
   int s = 0;
-  __syncthreads();  // every thread has read s_n before the first step appends to the list
   // (off[0] = 0 already)
   while (end > begin && s < XCAP) {
     if (tid == 0) off[s + 1] = (uint16_t)end;
-    for (u32 j = begin + tid; j < end; j += 256u) {
-      const u32 x = ord[j];
-      const int lr = x >> 6, lc = x & 63;
-      const u32 c = CODE(lr, lc);
-      if (d8_is_dir(c)) {
-        const int k = d8_slot(c);
-        const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
-        if ((unsigned)nr < XT && (unsigned)nc < XT) {
-          const u32 p = (u32)(nr * XT + nc);
-          if (atomicSub(&cnt[p], 1u) == 1u) ord[atomicAdd(&s_n, 1u)] = (uint16_t)p;  // last upstream cell done
+    for (u32 jb = begin; jb < end; jb += 256u) {  // (uniform trip count: append() is called by whole waves)
+      const u32 j = jb + tid;
+      bool last = false;
+      u32 p = 0;
+      if (j < end) {
+        const u32 x = ord[j];
+        const int lr = x >> 6, lc = x & 63;
+        const u32 c = CODE(lr, lc);
+        if (d8_is_dir(c)) {
+          const int k = d8_slot(c);
+          const int nr = lr + d8_dr(k), nc = lc + d8_dc(k);
+          if ((unsigned)nr < XT && (unsigned)nc < XT) {
+            p = (u32)(nr * XT + nc);
+            last = atomicSub(&cnt[p], 1u) == 1u;  // last upstream cell done: nobody else touches cnt[p] any more
+            if (last) cnt[p] = 0x1000u | (u32)(s + 1);
+          }
         }
       }
+      append(last, p, &s_add[s], end);
     }
     __syncthreads();
     begin = end;
-    end = s_n;
+    end += s_add[s];  // (the next step counts in its own word: no second barrier)
     ++s;
-    __syncthreads();
   }
   // cells appended by the last executed step (step index s) stay leaves only if s <= XCAP: the loop
   // stops at s == XCAP with [begin, end) = the cells of step XCAP, which are kept; their parents are not
   // appended any more (the loop did not run for them) -> trunk.
   const u32 total = end;
-  if (tid == 0) off[s + 1 <= XOFF - 1 ? s + 1 : XOFF - 1] = (uint16_t)total;
-  __syncthreads();
-  // steps of the leaves: position in ord -> step by the offsets
-  // lhl: reuse cnt[] as the per-cell step (0xFFFF.. = not a leaf)
-  const int nsteps = s + 1;  // steps 0 .. s hold cells ([off[t], off[t+1]) ), off[s+1] = total
-  if (tid >= (u32)nsteps + 1 && tid < XOFF) off[tid] = (uint16_t)total;
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const u32 l = tid + 256u * j;
-    cnt[l] = (cnt[l] & 0x200u) ? XL_NODATA : ((cnt[l] & 0x400u) ? XL_HALO : XL_TRUNK);
-  }
-  __syncthreads();
-  for (u32 j = tid; j < total; j += 256u) {
-    // step of entry j: largest t with off[t] <= j
-    int t = 0;
-    for (int q = 1; q < nsteps; ++q) t += (j >= (u32)off[q]) ? 1 : 0;
-    cnt[ord[j]] = (u32)t;
-  }
+  // steps 0 .. s hold cells ([off[t], off[t+1])), off[s+1] = total and so are the entries behind it
+  if (tid >= (u32)s + 1u && tid < XOFF) off[tid] = (uint16_t)total;
   __syncthreads();
   const size_t tile = (size_t)tr * ntc + tc;
 #pragma unroll
@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
     const i64 gr = r0 + (l >> 6), gc = c0 + (l & 63);
     if (gr < (i64)nrow && gc < (i64)ncol) {
       const size_t g = (size_t)gr * ncol + (size_t)gc;
-      lh[g] = (u8)cnt[l];
+      const u32 v = cnt[l];
+      lh[g] = (u8)((v & 0x1000u) ? (v & 0xFFu) : ((v & 0x200u) ? XL_NODATA : ((v & 0x400u) ? XL_HALO : XL_TRUNK)));
       kids_out[g] = (u8)mykids[j];
     }
     // entry = the leaf's cell (12 bits) | slot of its downstream cell << 12 | "is a pit" << 15: the down-sweep of a
@@ -181,31 +182,34 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
 __device__ __forceinline__ u32 heavy_slot(const u8 *__restrict__ lh, const u32 *__restrict__ upa, const Geo &g, u32 x,
                                           u32 kids) {
   u32 best = 0, arg = 8;
+  u32 a[8], t[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {  // (only the cells that drain into x are looked at: 1-3 of the 8 for most trunk cells)
+    const int k = PFD_SLOT_ASC[q];
+    a[q] = 0, t[q] = 0;
+    if (kids & (1u << k)) {
+      const u32 j = (u32)((i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k));
+      a[q] = upa[j];
+      t[q] = lh[j];
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const int k = PFD_SLOT_ASC[q];
-    // unconditional loads from clamped addresses, masked afterwards
-    const i64 j = (i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k);
-    const u32 jj = (u32)(j < 0 ? 0 : (j >= (i64)g.n ? (i64)g.n - 1 : j));
-    const u32 a = upa[jj];
-    const u32 t = lh[jj];
-    if ((kids & (1u << k)) && xl_trunk(t) && a > best) {
-      best = a;
-      arg = (u32)k;
+    if (xl_trunk(t[q]) && a[q] > best) {
+      best = a[q];
+      arg = (u32)PFD_SLOT_ASC[q];
     }
   }
   return arg;
 }
 
-__global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ lh,
-                                                    const u8 *__restrict__ kids, const u32 *__restrict__ upa,
-                                                    u8 *__restrict__ hcode, u32 *__restrict__ seed,
-                                                    uint16_t *__restrict__ hinfo, u32 *__restrict__ bcount) {
+// pass 1: per trunk cell its upstream-cell mask, heavy slot and post count (hinfo)
+__global__ void __launch_bounds__(256) k_plan_hinfo(Geo g, const u8 *__restrict__ lh, const u8 *__restrict__ kids,
+                                                    const u32 *__restrict__ upa, uint16_t *__restrict__ hinfo) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in = x < g.n;
-  u32 hc = D8_MV, sd = 0, info = 0;
-  if (in && xl_trunk(lh[x])) {
-    const u32 c = ncode[x];
+  if (x >= g.n) return;
+  u32 info = 0;
+  if (xl_trunk(lh[x])) {
     const u32 m = kids[x];
     const u32 hs = heavy_slot(lh, upa, g, x, m);
     // post cells: upstream cells the serial loop adds after the heavy one = those of lower linear index
@@ -219,12 +223,25 @@ __global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode
       }
     }
     info = m | (hs << 8) | (npost << 12);
+  }
+  hinfo[x] = (uint16_t)info;
+}
+// pass 2: the heavy links (x is heavy when the heavy slot of its downstream cell holds x: one look at that cell's hinfo)
+__global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ lh,
+                                                    const uint16_t *__restrict__ hinfo, u8 *__restrict__ hcode,
+                                                    u32 *__restrict__ seed, u32 *__restrict__ bcount) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in = x < g.n;
+  u32 hc = D8_MV, sd = 0;
+  if (in && xl_trunk(lh[x])) {
+    const u32 c = ncode[x];
     bool heavy = false;
     if (d8_is_dir(c)) {
       const u32 p = d8_down(g, x, c);
-      const u32 ps = heavy_slot(lh, upa, g, p, kids[p]);
-      // (a halo cell of a row block is in no chain: the cell draining into it ends its own)
-      heavy = ps < 8 && ((d8_slot(c) + 4) & 7) == (int)ps && lh[p] != XL_HALO;  // the slot of p that holds x
+      // (a halo cell of a row block is in no chain — its hinfo is 0, heavy slot 0 = E, so it is asked for by name:
+      //  the cell draining into it ends its own chain)
+      const u32 ps = ((u32)hinfo[p] >> 8) & 0xFu;
+      heavy = ps < 8 && ((d8_slot(c) + 4) & 7) == (int)ps && xl_trunk(lh[p]);  // the slot of p that holds x
     }
     hc = heavy ? c : 0u;
     sd = heavy ? 0u : x + 1u;
@@ -232,7 +249,6 @@ __global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode
   if (in) {
     hcode[x] = (u8)hc;
     seed[x] = sd;
-    hinfo[x] = (uint16_t)info;
   }
   // chain ends per workgroup: what the raster-ordered list of chain ends (k_plan_tail_list) is offset by
   const u32 cnt = (u32)__syncthreads_count(sd != 0u);
@@ -345,16 +361,20 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const u8 *__restrict__ lh,
                                                       const u32 *__restrict__ hops, const u32 *__restrict__ tailnum,
                                                       const u32 *__restrict__ tidx_at, const u32 *__restrict__ rank_of,
                                                       const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos,
-                                                      u32 n, u32 *__restrict__ ucell, u32 *__restrict__ w) {
+                                                      u32 n, uint4 *__restrict__ urec) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= n || !xl_trunk(lh[x])) return;
   const u32 tn = tailnum[x];
   if (!tn) return;
   const u32 c = rank_of[tidx_at[tn - 1]];
   const u32 p = cpos[c] + clen_pos[c] - 1 - hops[x];
-  ucell[p] = x;
-  w[p] = 1u + ((hinfo[x] >> 12) & 7u);
+  // one 16-byte record per position — cell, chain, hinfo (never 0 for a trunk cell) — so that k_plan_expand, which runs
+  // in position order, finds everything in one coalesced load instead of five dependent gathers per cell
+  urec[p] = make_uint4(x, c, (u32)hinfo[x], 0u);
 }
+struct XRecSlots {  // slots a position needs: 1 + its post slots (0 for a position nobody wrote)
+  __device__ u32 operator()(const uint4 &r) const { return r.z ? 1u + ((r.z >> 12) & 7u) : 0u; }
+};
 
 // chain c occupies the unpadded slots [S[cpos], S[cpos + len)); every chain starts on a multiple of 4 slots
 // (the lane that folds it loads and stores 4 slots per instruction): cpad = its padded length
@@ -386,18 +406,16 @@ __global__ void __launch_bounds__(256) k_plan_chains(const u32 *__restrict__ cpo
   clen[c] = (S[p + l] - u0) | ((((u32)hinfo[t] >> 12) & 7u) << 29);
   adj[c] = cstart_pad[c] - u0;
 }
-__global__ void __launch_bounds__(256) k_plan_expand(const u32 *__restrict__ ucell, const u32 *__restrict__ S,
-                                                     const uint16_t *__restrict__ hinfo,
-                                                     const u32 *__restrict__ tailnum, const u32 *__restrict__ tidx_at,
-                                                     const u32 *__restrict__ rank_of, const u32 *__restrict__ adj,
-                                                     Geo g, u32 npos, u32 *__restrict__ scell,
+__global__ void __launch_bounds__(256) k_plan_expand(const uint4 *__restrict__ urec, const u32 *__restrict__ S,
+                                                     const u32 *__restrict__ adj, Geo g, u32 npos, u32 *__restrict__ scell,
                                                      uint16_t *__restrict__ sinfo, u32 *__restrict__ spost,
                                                      u32 *__restrict__ cslot, u8 *__restrict__ lh) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npos) return;
-  const u32 x = ucell[p];
-  const u32 info = hinfo[x];
-  u32 s = S[p] + adj[rank_of[tidx_at[tailnum[x] - 1u]]];
+  const uint4 rec = urec[p];
+  const u32 x = rec.x;
+  const u32 info = rec.z;
+  u32 s = S[p] + adj[rec.y];
   scell[s] = x;
   sinfo[s] = (uint16_t)info;
   cslot[x] = s;  // (the sweeps find a trunk cell's value in chain order through it: no scatter pass per round)
@@ -679,8 +697,9 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   DevBuf bcount;
   if ((rc = bcount.alloc(((size_t)grid + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemsetAsync(bcount.as<u32>() + grid, 0, sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_heavy<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, p->lh, p->kids, upa.as<u32>(), hcode.as<u8>(),
-                                            seed.as<u32>(), hinfo.as<uint16_t>(), bcount.as<u32>());
+  k_plan_hinfo<<<grid, 256, 0, h->stream>>>(h->geo, p->lh, p->kids, upa.as<u32>(), hinfo.as<uint16_t>());
+  k_plan_heavy<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, p->lh, hinfo.as<uint16_t>(), hcode.as<u8>(), seed.as<u32>(),
+                                            bcount.as<u32>());
   XDBG(h, "k_plan_heavy");
   xdigest(h, "hcode", hcode.p, (size_t)n);
   xdigest(h, "seed", seed.p, (size_t)n * 4);
@@ -799,20 +818,20 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   p->ntrunk = (i64)npos;
   p->nchain = (i64)nchain;
   upa.alloc(0);  // (the list of chain ends is no longer needed: ctail holds them in layout order)
-  if ((rc = ucell.alloc(std::max<size_t>(npos, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = ucell.alloc((npos + 1) * sizeof(uint4))) != PFD_OK) return fail(rc);
   if ((rc = w.alloc((npos + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
-  if (hipMemsetAsync(w.p, 0, (npos + 1) * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
+  if (hipMemsetAsync(ucell.p, 0, (npos + 1) * sizeof(uint4), h->stream) != hipSuccess) return fail(PFD_EHIP);
   k_plan_scatter<<<grid, 256, 0, h->stream>>>(p->lh, hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at,
-                                              rank_of.as<u32>(), cpos.as<u32>(), clenp.as<u32>(), n, ucell.as<u32>(),
-                                              w.as<u32>());
+                                              rank_of.as<u32>(), cpos.as<u32>(), clenp.as<u32>(), n, ucell.as<uint4>());
   XDBG(h, "k_plan_scatter");
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   // slot of a position = exclusive scan of the slots the positions before it need (in place)
-  if (rocprim::exclusive_scan(nullptr, tmp_bytes, w.as<u32>(), w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
+  auto wneed = rocprim::make_transform_iterator((const uint4 *)ucell.p, XRecSlots());
+  if (rocprim::exclusive_scan(nullptr, tmp_bytes, wneed, w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
                               h->stream) != hipSuccess)
     return fail(PFD_EHIP);
   if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
-  if (rocprim::exclusive_scan(tmp.p, tmp_bytes, w.as<u32>(), w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
+  if (rocprim::exclusive_scan(tmp.p, tmp_bytes, wneed, w.as<u32>(), 0u, (size_t)npos + 1, rocprim::plus<u32>(),
                               h->stream) != hipSuccess)
     return fail(PFD_EHIP);
   // padded chain starts: exclusive scan of the padded chain lengths; round offsets = starts of their first chains
@@ -855,12 +874,10 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
                                                                 w.as<u32>(), cpad.as<u32>(), hinfo.as<uint16_t>(),
                                                                 (u32)nchain, p->cstart, p->clen, adj.as<u32>());
   XDBG(h, "k_plan_chains");
-    k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<u32>(), w.as<u32>(), hinfo.as<uint16_t>(),
-                                                              tailnum.as<u32>(), tidx_at, rank_of.as<u32>(), adj.as<u32>(), h->geo,
-                                                              (u32)npos,
+    k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<uint4>(), w.as<u32>(), adj.as<u32>(), h->geo, (u32)npos,
                                                               p->scell, p->sinfo, p->spost, p->cslot, p->lh);
   XDBG(h, "k_plan_expand");
-  xdigest(h, "ucell", ucell.p, (size_t)npos * 4);
+  xdigest(h, "ucell", ucell.p, (size_t)npos * 16);
   xdigest(h, "scell", p->scell, (size_t)p->nslot * 4);
   xdigest(h, "sinfo", p->sinfo, (size_t)p->nslot * 2);
   xdigest(h, "spost", p->spost, (size_t)(p->nslot / 32) * 4);
