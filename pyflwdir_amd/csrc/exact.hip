@@ -19,6 +19,7 @@
 
 int pfd_path_rank(pfd_raster *h, const u8 *codes, u32 *out_dev, int *complete);                         // paths.hip
 int pfd_path_labels(pfd_raster *h, const u8 *codes, const u32 *seed_dev, u32 *out_dev, int *complete);  // paths.hip
+int pfd_path_rank_tails(pfd_raster *h, const u8 *codes, u32 *hops_dev, u32 *tails_dev, int *complete);   // paths.hip
 
 // ---------------------------------------------------------------------------------------------
 // P2: leaf steps of one tile.  A cell is a leaf of step s if all its upstream cells lie in the tile and
@@ -707,9 +708,8 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   if ((rc = hops.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = tailnum.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  if ((rc = pfd_path_rank(h, hcode.as<u8>(), hops.as<u32>(), &complete)) != PFD_OK) return fail(rc);
-  if (!complete) return fail(PFD_OK);
-  if ((rc = pfd_path_labels(h, hcode.as<u8>(), seed.as<u32>(), tailnum.as<u32>(), &complete)) != PFD_OK) return fail(rc);
+  // hops to the end of the chain and the end itself (its index + 1: what `seed` holds there), one path query for both
+  if ((rc = pfd_path_rank_tails(h, hcode.as<u8>(), hops.as<u32>(), tailnum.as<u32>(), &complete)) != PFD_OK) return fail(rc);
   if (!complete) return fail(PFD_OK);
   xdigest(h, "hops", hops.p, (size_t)n * 4);
   xdigest(h, "tailnum", tailnum.p, (size_t)n * 4);

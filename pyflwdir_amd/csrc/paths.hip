@@ -46,9 +46,14 @@ struct PathArgs {
   const u8 *tflag;  // label mode, nullable: [ntr * ntc] tile holds a seed; the seeds of the other tiles are never read
   const u32 *ids32; // label mode, nullable: the outlets' 32-bit labels — `out` then receives ids32[number - 1] (0: none)
   u64 *ctrl;
+  // rank mode with TAIL (the chains of exact.hip): the END of every cell's path as well — linear index + 1 of the pit
+  // it reaches — from the same doubling: an entry whose in-tile path ends in the tile records that pit (eend), the exit
+  // rounds leave in every exit's pointer the LAST exit of its chain, whose target entry holds the pit
+  u32 *eend;        // [nslots]
+  u32 *out2;        // [n]
 };
 
-template <int MODE, bool FINAL>
+template <int MODE, bool FINAL, bool TAIL = false>
 __global__ void __launch_bounds__(256) k_path(PathArgs a) {
   __shared__ __attribute__((aligned(16))) u32 V[TCELLS];       // rank: hops so far; label: seed number
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2^k-th ancestor | PDONE once saturated
@@ -243,6 +248,50 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
           if (gc0 + b < (i64)a.ncol) dst[b] = o4[b];
       }
     }
+    if (TAIL) {
+      __syncthreads();  // every rank is out: V is free
+      // a root names the end of its path: itself when it is a pit ...
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const u32 l0 = 4u * tid + 1024u * j;
+        const int lr = l0 >> 6, lc0 = l0 & 63;
+        const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const u32 l = l0 + b;
+          if ((P[l] & 0xFFFu) == l)
+            V[l] = ((c4 >> (8 * b)) & 0xFFu) == 0u ? (u32)((r0 + lr) * (i64)a.ncol + c0 + lc0 + b) + 1u : 0u;
+        }
+      }
+      __syncthreads();
+      // ... or, for an exit, what the entry behind the last exit of its chain recorded
+      if (tid < NPERIM) {
+        int plr, plc;
+        pslot_inv((int)tid, &plr, &plc);
+        const u32 l = (u32)(plr * TS + plc);
+        if (exit_slot_of(l) != NONE32) V[l] = a.eend[a.xtgt[(u32)(a.xres[sbase + tid] >> 32) & ~XDONE]];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const u32 l0 = 4u * tid + 1024u * j;
+        const int lr = l0 >> 6, lc0 = l0 & 63;
+        const i64 gr = r0 + lr, gc0 = c0 + lc0;
+        if (gr >= (i64)a.nrow || gc0 >= (i64)a.ncol) continue;
+        const u32 c4 = *(const u32 *)&CODE(lr, lc0);
+        u32 o4[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o4[b] = ((c4 >> (8 * b)) & 0xFFu) != D8_MV ? V[P[l0 + b] & 0xFFFu] : 0u;
+        u32 *dst = a.out2 + (size_t)gr * a.ncol + (size_t)gc0;
+        if (gc0 + 3 < (i64)a.ncol && (((size_t)dst) & 15) == 0) {
+          *(uint4 *)dst = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (gc0 + b < (i64)a.ncol) dst[b] = o4[b];
+        }
+      }
+    }
     if (MODE == MODE_RANK) {
       // the longest path: one candidate per tile, and the atomic only if it can still raise the maximum (same-address
       // global atomics are served one after the other: four per tile cost 10 ms at 30000^2)
@@ -261,7 +310,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
 
   // ---- pass 1: perimeter records ------------------------------------------------------------------
   if (tid < PSL) {
-    u32 tgt = NONE32, link = NONE32, ev = 0;
+    u32 tgt = NONE32, link = NONE32, ev = 0, end = 0;
     if (tid < NPERIM) {
       int plr, plc;
       pslot_inv((int)tid, &plr, &plc);
@@ -286,12 +335,15 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
           const u32 root = P[l] & 0xFFFu;
           link = exit_slot_of(root);
           ev = (MODE == MODE_RANK) ? V[l] : V[root];
+          if (TAIL && link == NONE32 && CODE((int)(root >> 6), (int)(root & 63u)) == 0u)
+            end = (u32)((r0 + (i64)(root >> 6)) * (i64)a.ncol + c0 + (i64)(root & 63u)) + 1u;
         }
       }
     }
     a.xtgt[sbase + tid] = tgt;
     a.elink[sbase + tid] = link;
     a.eval[sbase + tid] = ev;
+    if (TAIL) a.eend[sbase + tid] = end;
   }
 }
 
@@ -370,7 +422,8 @@ __global__ void __launch_bounds__(256) k_xround(u64 *__restrict__ WJ, u32 nslots
 // one complete path query; on return *complete = 0 means cycles were found (caller falls back)
 template <int MODE>
 static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *complete, u32 *maxrank,
-                     const u8 *codes = nullptr, const u32 *ids32 = nullptr, const u8 *tflag = nullptr) {
+                     const u8 *codes = nullptr, const u32 *ids32 = nullptr, const u8 *tflag = nullptr, u32 *tails_dev = nullptr) {
+  const bool tail = MODE == MODE_RANK && tails_dev != nullptr;  // (see PathArgs::eend)
   *complete = 0;
   if (!codes) codes = h->ncode;  // (exact.hip queries a derived forest: heavy links only)
   const u32 ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
@@ -378,16 +431,18 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   const size_t nslots = (size_t)cdiv_u32(ntr, SG) * nstc * SSL;
   if (nslots >= 0x3FFFFFFFull || ntr > 65535u) return PFD_OK;
   DevBuf buf;
-  PFDCHK(buf.alloc(5 * nslots * sizeof(u32)));
+  PFDCHK(buf.alloc((tail ? 6 : 5) * nslots * sizeof(u32)));
   u32 *b = buf.as<u32>();
   u32 *xtgt = b + 2 * nslots, *elink = b + 3 * nslots, *eval = b + 4 * nslots;
   u64 *WJ = buf.as<u64>();  // (first: 8-byte aligned)
   HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 8 * sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(xtgt, 0xFF, nslots * sizeof(u32), h->stream));  // slots of tiles that do not exist
-  PathArgs a{codes, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, tflag, ids32, h->ctrl};
+  PathArgs a{codes, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed_dev, out_dev, tflag, ids32, h->ctrl,
+             tail ? b + 5 * nslots : nullptr, tails_dev};
   const dim3 grid(ntc, ntr);
   i64 launches = 2;
-  k_path<MODE, false><<<grid, 256, 0, h->stream>>>(a);
+  if (tail) k_path<MODE_RANK, false, true><<<grid, 256, 0, h->stream>>>(a);
+  else k_path<MODE, false><<<grid, 256, 0, h->stream>>>(a);
   const u32 sgrid = cdiv_u32(nslots, 256);
   k_xinit<MODE><<<sgrid, 256, 0, h->stream>>>(xtgt, elink, eval, WJ, (u32)nslots, h->ctrl);
   KCHK();
@@ -414,7 +469,8 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
     batch = 2;
   }
   a.xres = WJ;
-  k_path<MODE, true><<<grid, 256, 0, h->stream>>>(a);
+  if (tail) k_path<MODE_RANK, true, true><<<grid, 256, 0, h->stream>>>(a);
+  else k_path<MODE, true><<<grid, 256, 0, h->stream>>>(a);
   KCHK();
   u64 c[6];
   HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
@@ -689,6 +745,10 @@ extern "C" int pfd_basins_finish(pfd_raster *h, const uint32_t *all_records_host
 // path queries over a derived code raster (same shape as the handle's), for exact.hip
 int pfd_path_rank(pfd_raster *h, const u8 *codes, u32 *out_dev, int *complete) {
   return run_paths<MODE_RANK>(h, nullptr, out_dev, complete, nullptr, codes);
+}
+// hops to the end of the path AND the end itself (linear index + 1 of the pit; 0 on cells that are no path cells) in one query
+int pfd_path_rank_tails(pfd_raster *h, const u8 *codes, u32 *hops_dev, u32 *tails_dev, int *complete) {
+  return run_paths<MODE_RANK>(h, nullptr, hops_dev, complete, nullptr, codes, nullptr, nullptr, tails_dev);
 }
 int pfd_path_labels(pfd_raster *h, const u8 *codes, const u32 *seed_dev, u32 *out_dev, int *complete) {
   return run_paths<MODE_LABEL>(h, seed_dev, out_dev, complete, nullptr, codes);
