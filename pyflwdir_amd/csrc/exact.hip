@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
 // ---------------------------------------------------------------------------------------------
 // P3: heavy links of the trunk.  heavy child of x = its upstream TRUNK cell with the largest upstream
 // area (first maximum in ascending index).  hcode = the forest of heavy links only (light trunk cells
-// and pits become path ends, everything else nodata); seed marks the chain ends for the label query.
+// and pits become path ends, everything else nodata): a chain end is a pit of that forest.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 heavy_slot(const u8 *__restrict__ lh, const u32 *__restrict__ upa, const Geo &g, u32 x,
                                           u32 kids) {
@@ -230,10 +230,11 @@ __global__ void __launch_bounds__(256) k_plan_hinfo(Geo g, const u8 *__restrict_
 // pass 2: the heavy links (x is heavy when the heavy slot of its downstream cell holds x: one look at that cell's hinfo)
 __global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ lh,
                                                     const uint16_t *__restrict__ hinfo, u8 *__restrict__ hcode,
-                                                    u32 *__restrict__ seed, u32 *__restrict__ bcount) {
+                                                    u32 *__restrict__ bcount) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = x < g.n;
-  u32 hc = D8_MV, sd = 0;
+  u32 hc = D8_MV;
+  bool sd = false;  // the cell ends its chain (a pit of the heavy forest: hcode 0)
   if (in && xl_trunk(lh[x])) {
     const u32 c = ncode[x];
     bool heavy = false;
@@ -245,24 +246,21 @@ __global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode
       heavy = ps < 8 && ((d8_slot(c) + 4) & 7) == (int)ps && xl_trunk(lh[p]);  // the slot of p that holds x
     }
     hc = heavy ? c : 0u;
-    sd = heavy ? 0u : x + 1u;
+    sd = !heavy;
   }
-  if (in) {
-    hcode[x] = (u8)hc;
-    seed[x] = sd;
-  }
+  if (in) hcode[x] = (u8)hc;
   // chain ends per workgroup: what the raster-ordered list of chain ends (k_plan_tail_list) is offset by
-  const u32 cnt = (u32)__syncthreads_count(sd != 0u);
+  const u32 cnt = (u32)__syncthreads_count(sd);
   if (threadIdx.x == 0) bcount[blockIdx.x] = cnt;
 }
 // the chain ends in raster order: position = ends in the workgroups before (exclusive scan of k_plan_heavy's counts)
 // + ends before the cell in its own workgroup.  (Same grid as k_plan_heavy.  A rocprim::select over the 4-byte
-// seeds took 10.3 ms at 30000 x 30000; the count rides k_plan_heavy and this pass reads the seeds once: 1.3 ms.)
-__global__ void __launch_bounds__(256) k_plan_tail_list(const u32 *__restrict__ seed, u32 n, const u32 *__restrict__ boff,
+// seeds took 10.3 ms at 30000 x 30000; the count rides k_plan_heavy and this pass reads one byte per cell.)
+__global__ void __launch_bounds__(256) k_plan_tail_list(const u8 *__restrict__ hcode, u32 n, const u32 *__restrict__ boff,
                                                         u32 *__restrict__ tails) {
   __shared__ u32 wcnt[4];
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool f = x < n && seed[x] != 0u;
+  const bool f = x < n && hcode[x] == 0u;
   const u64 m = __ballot(f);
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (lane == 0) wcnt[wave] = (u32)__popcll(m);
@@ -284,7 +282,7 @@ __global__ void __launch_bounds__(256) k_plan_len(const u8 *__restrict__ lh, con
                                                   const u32 *__restrict__ hops, const u32 *__restrict__ tailnum,
                                                   const u32 *__restrict__ tidx_at, u32 n, u32 *__restrict__ len_of) {
   const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n || !xl_trunk(lh[x]) || ((hinfo[x] >> 8) & 0xFu) != 8u) return;
+  if (x >= n || (((u32)hinfo[x] >> 8) & 0xFu) != 8u) return;  // (hinfo is 0 on cells that are no trunk cells)
   const u32 tn = tailnum[x];
   if (tn) len_of[tidx_at[tn - 1]] = hops[x] + 1;
 }
@@ -343,7 +341,8 @@ __global__ void __launch_bounds__(256) k_plan_keys(u32 nt, const u32 *__restrict
 __global__ void __launch_bounds__(256) k_plan_chain_lens(const u32 *__restrict__ cj, u32 nchain,
                                                          const u32 *__restrict__ tails, const u32 *__restrict__ len_of,
                                                          u32 *__restrict__ rank_of, u32 *__restrict__ ctail,
-                                                         u32 *__restrict__ clen_pos, u32 *__restrict__ cpos_in) {
+                                                         u32 *__restrict__ clen_pos, u32 *__restrict__ cpos_in,
+                                                         u32 *__restrict__ tidx_at) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c > nchain) return;
   u32 l = 0;
@@ -353,6 +352,7 @@ __global__ void __launch_bounds__(256) k_plan_chain_lens(const u32 *__restrict__
     rank_of[j] = c;
     ctail[c] = tails[j];
     clen_pos[c] = l;
+    tidx_at[tails[j]] = c;  // (from here on the chain end's cell names its chain, not its list number)
   }
   cpos_in[c] = l;  // (exclusive scan in place -> first position of the chain)
 }
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const u8 *__restrict__ lh,
   if (x >= n || !xl_trunk(lh[x])) return;
   const u32 tn = tailnum[x];
   if (!tn) return;
-  const u32 c = rank_of[tidx_at[tn - 1]];
+  const u32 c = tidx_at[tn - 1];  // (chain ids since k_plan_chain_lens)
   const u32 p = cpos[c] + clen_pos[c] - 1 - hops[x];
   // one 16-byte record per position — cell, chain, hinfo (never 0 for a trunk cell) — so that k_plan_expand, which runs
   // in position order, finds everything in one coalesced load instead of five dependent gathers per cell
@@ -690,32 +690,29 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   xdigest(h, "kids", p->kids, (size_t)n);
   xdigest(h, "toff", p->toff, ntiles * XOFF * 2);
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
-  DevBuf hcode, seed, hinfo, hops, tailnum;
+  DevBuf hcode, tidxbuf, hinfo, hops, tailnum;
   if ((rc = hcode.alloc((size_t)n + 64)) != PFD_OK) return fail(rc);
-  if ((rc = seed.alloc((size_t)n * sizeof(u32) + 64)) != PFD_OK) return fail(rc);
+  if ((rc = tidxbuf.alloc((size_t)n * sizeof(u32) + 64)) != PFD_OK) return fail(rc);  // (written at the chain ends only)
   if ((rc = hinfo.alloc((size_t)n * sizeof(uint16_t))) != PFD_OK) return fail(rc);
   const u32 grid = cdiv_u32(n, 256);
   DevBuf bcount;
   if ((rc = bcount.alloc(((size_t)grid + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemsetAsync(bcount.as<u32>() + grid, 0, sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
   k_plan_hinfo<<<grid, 256, 0, h->stream>>>(h->geo, p->lh, p->kids, upa.as<u32>(), hinfo.as<uint16_t>());
-  k_plan_heavy<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, p->lh, hinfo.as<uint16_t>(), hcode.as<u8>(), seed.as<u32>(),
-                                            bcount.as<u32>());
+  k_plan_heavy<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, p->lh, hinfo.as<uint16_t>(), hcode.as<u8>(), bcount.as<u32>());
   XDBG(h, "k_plan_heavy");
   xdigest(h, "hcode", hcode.p, (size_t)n);
-  xdigest(h, "seed", seed.p, (size_t)n * 4);
   xdigest(h, "hinfo", hinfo.p, (size_t)n * 2);
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   if ((rc = hops.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = tailnum.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
-  // hops to the end of the chain and the end itself (its index + 1: what `seed` holds there), one path query for both
+  // hops to the end of the chain and the end itself (its index + 1), one path query for both
   if ((rc = pfd_path_rank_tails(h, hcode.as<u8>(), hops.as<u32>(), tailnum.as<u32>(), &complete)) != PFD_OK) return fail(rc);
   if (!complete) return fail(PFD_OK);
   xdigest(h, "hops", hops.p, (size_t)n * 4);
   xdigest(h, "tailnum", tailnum.p, (size_t)n * 4);
-  hcode.alloc(0);
-  // the chain ends, in raster order (selection by scan: no same-address atomics).  The list lives in the
-  // upstream-area buffer, which is no longer needed; tidx_at takes over the seed buffer afterwards.
+  // the chain ends (pits of the heavy forest), in raster order (selection by scan: no same-address atomics).  The list
+  // lives in the upstream-area buffer, which is no longer needed.
   DevBuf dA, dB, pA, pB, tmp, cnt, len_of, rank_of;
   u32 *tails = upa.as<u32>();
   if ((rc = cnt.alloc(64 * sizeof(u32))) != PFD_OK) return fail(rc);
@@ -728,16 +725,17 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
     if (rocprim::exclusive_scan(tmp.p, tmp_bytes, bcount.as<u32>(), bcount.as<u32>(), 0u, (size_t)grid + 1, rocprim::plus<u32>(),
                                 h->stream) != hipSuccess)
       return fail(PFD_EHIP);
-    k_plan_tail_list<<<grid, 256, 0, h->stream>>>(seed.as<u32>(), n, bcount.as<u32>(), tails);
+    k_plan_tail_list<<<grid, 256, 0, h->stream>>>(hcode.as<u8>(), n, bcount.as<u32>(), tails);
     if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   }
+  hcode.alloc(0);
   u32 nt32 = 0;
   if (hipMemcpyAsync(&nt32, bcount.as<u32>() + grid, sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
     return fail(PFD_EHIP);
   const unsigned long long nchain = nt32;
   const size_t nc1 = std::max<size_t>(nchain, 1);
-  u32 *tidx_at = seed.as<u32>();
+  u32 *tidx_at = tidxbuf.as<u32>();
   if (nchain) k_plan_tidx<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(tails, nt32, tidx_at);
   XDBG(h, "k_plan_tidx");
   // rounds of the chains (see k_plan_tails)
@@ -790,7 +788,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   }
   k_plan_chain_lens<<<cdiv_u32(nchain + 1, 256), 256, 0, h->stream>>>(cj.as<u32>(), nt32, tails, len_of.as<u32>(),
                                                                      rank_of.as<u32>(), ctail.as<u32>(), clenp.as<u32>(),
-                                                                     cpos.as<u32>());
+                                                                     cpos.as<u32>(), tidx_at);
   XDBG(h, "k_plan_chain_lens");
   xdigest(h, "cj", cj.p, (size_t)nchain * 4);
   xdigest(h, "ctail", ctail.p, (size_t)nchain * 4);
