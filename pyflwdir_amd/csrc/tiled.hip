@@ -1111,12 +1111,14 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
     // partly built (the pass is about to be redone flat): touch nothing.
     nexits = ctrl[T_OVERFLOW] ? 0u : min(nexits, (u32)*ncnt);
   }
-  if (blockIdx.x * blockDim.x >= nexits) return;  // (the grid is sized for the capacity: most workgroups hold no node)
+  // (the node count is only known on the device and the capacity is ~10x the count at 90000^2: a bounded grid strides
+  //  over the nodes — a grid sized for the capacity spent 40 of a round's 49 us dispatching workgroups without a node)
+  bool moving = false;
+  for (u32 base = blockIdx.x * blockDim.x; base < nexits; base += gridDim.x * blockDim.x) {
   hk[tid] = NONE32, hk[tid + 256u] = NONE32;
   hv[tid] = 0, hv[tid + 256u] = 0;
-  const u32 e = blockIdx.x * blockDim.x + tid;
+  const u32 e = base + tid;
   __syncthreads();
-  bool moving = false;
   if (e < nexits) {
     const u32 j = Jold[e];
     const u32 t = Told[e];
@@ -1127,7 +1129,7 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
     } else {
       const u32 q = Jold[j];
       Jnew[e] = q;
-      moving = !(q & XDONE);
+      moving |= !(q & XDONE);
       if (t) {
         u32 slot = (j * 2654435761u) >> 23;  // 9 bits
         for (;;) {
@@ -1147,6 +1149,8 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
     const u32 key = hk[tid + 256u * k], val = hv[tid + 256u * k];
     if (key != NONE32 && val) atomicAdd(&Tnew[key], val);
   }
+  __syncthreads();  // (the table is reused by the next stride)
+  }
   if (round && moving) {  // at most one store per wave, none once this round's mark is visible
     const u64 m = __ballot(1);
     if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) {
@@ -1160,9 +1164,9 @@ __global__ void __launch_bounds__(256) k_coarse_round(const u32 *__restrict__ To
 // mark themselves make ~1000 waves load and store ONE address: measured 27 us in a 34 us kernel)
 __global__ void __launch_bounds__(256) k_check_saturated(const u32 *__restrict__ J, u32 nexits, u64 *ctrl,
                                                          const u64 *__restrict__ ncnt, u32 mark) {
-  const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
   if (ncnt) nexits = ctrl[T_OVERFLOW] ? 0u : min(nexits, (u32)*ncnt);
-  if (e < nexits && !(J[e] & XDONE)) ctrl[T_XACTIVE] = (u64)mark;  // (rare: only when the budget was short)
+  for (u32 e = blockIdx.x * blockDim.x + threadIdx.x; e < nexits; e += gridDim.x * blockDim.x)
+    if (!(J[e] & XDONE)) ctrl[T_XACTIVE] = (u64)mark;  // (rare: only when the budget was short)
 }
 
 // generic pointer doubling driver on T[3] / J[2] rotating buffers (T[0], J[0] hold the input; on
@@ -1173,7 +1177,7 @@ __global__ void __launch_bounds__(256) k_check_saturated(const u32 *__restrict__
 // with the returned round count at its next synchronisation.
 int pfd_doubling_rounds(pfd_raster *h, u32 *T[3], u32 *J[2], u32 n, int first_batch, bool check, bool *done,
                         int *rounds_issued, i64 *launches, const u64 *ncnt, bool prepared) {
-  const u32 grid = cdiv_u32(n, 256);
+  const u32 grid = std::min(cdiv_u32(n, 256), 4096u);  // (the kernels stride)
   *done = false;
   if (!prepared) {  // (prepared: the caller's kernels have cleared T[1] and the round mark already)
     HIPCHK(hipMemsetAsync(T[1], 0, (size_t)n * sizeof(u32), h->stream));
