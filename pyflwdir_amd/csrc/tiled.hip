@@ -1074,18 +1074,21 @@ __global__ void __launch_bounds__(1024) k_hyper(HyperArgs s) {
 }
 // level-4 links: hyper-exit -> next hyper-exit on its path (through the hypertile it enters)
 __global__ void __launch_bounds__(256) k_link4(HyperArgs s, u32 cap, u32 *__restrict__ J4, u32 *__restrict__ Tnext) {
-  const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= min(cap, (u32)s.ctrl[T_NHYPER]) || s.ctrl[T_OVERFLOW]) return;
-  Tnext[m] = 0;  // the first round accumulates into a cleared buffer (pfd_doubling_rounds, prepared)
-  const u32 n1 = s.J3[s.hx_node[m]];  // first node inside the entered hypertile
-  const u32 id = s.hx_id[s.R3[n1]];
-  const u32 j = (id != NONE32) ? id : (m | XDONE);
-  J4[m] = j;
+  if (s.ctrl[T_OVERFLOW]) return;
+  const u32 n = min(cap, (u32)s.ctrl[T_NHYPER]);  // (device-side count, bounded grid: see k_coarse_round)
+  for (u32 m = blockIdx.x * blockDim.x + threadIdx.x; m < n; m += gridDim.x * blockDim.x) {
+    Tnext[m] = 0;  // the first round accumulates into a cleared buffer (pfd_doubling_rounds, prepared)
+    const u32 n1 = s.J3[s.hx_node[m]];  // first node inside the entered hypertile
+    const u32 id = s.hx_id[s.R3[n1]];
+    const u32 j = (id != NONE32) ? id : (m | XDONE);
+    J4[m] = j;
+  }
 }
 __global__ void __launch_bounds__(256) k_push4(HyperArgs s, u32 cap, const u32 *__restrict__ T4final, u32 *xin3) {
-  const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= min(cap, (u32)s.ctrl[T_NHYPER]) || s.ctrl[T_OVERFLOW]) return;
-  atomicAdd(&xin3[s.J3[s.hx_node[m]]], T4final[m]);
+  if (s.ctrl[T_OVERFLOW]) return;
+  const u32 n = min(cap, (u32)s.ctrl[T_NHYPER]);
+  for (u32 m = blockIdx.x * blockDim.x + threadIdx.x; m < n; m += gridDim.x * blockDim.x)
+    atomicAdd(&xin3[s.J3[s.hx_node[m]]], T4final[m]);
 }
 
 // round prologue: Tnew = Told (the adds of the round go on top) and reset the activity flag
@@ -1435,7 +1438,7 @@ int TiledRun::level4_down(i64 *launches) {
                edge_down_now ? cdiv_u32(ntr, SG) : 0u, nhtc};
   {  // level 4: the number of hyper-exits stays on the device (grids are sized for the capacity)
     const u32 cap4 = (u32)std::min<size_t>(n4cap, 0x7FFFFFFF);
-    const u32 g4 = cdiv_u32(cap4, 256);
+    const u32 g4 = std::min(cdiv_u32(cap4, 256), 4096u);  // (the kernels stride over the device-side count)
     k_link4<<<g4, 256, 0, h->stream>>>(ha, cap4, J4c, T4[1]);
     // No host round trip here: a fixed number of rounds is issued (rounds past saturation are
     // idempotent) and the "last round that moved a pointer" mark is compared with it at the pass's
