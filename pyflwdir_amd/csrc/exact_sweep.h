@@ -182,11 +182,22 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
                                                     u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
                                                     const u32 *__restrict__ spost,
                                                     const typename Op::Elem *__restrict__ E,
-                                                    typename Op::V *__restrict__ R, const u8 *__restrict__ dirty = nullptr) {
+                                                    typename Op::V *__restrict__ R, const u32 *__restrict__ scell,
+                                                    u8 *__restrict__ dirty = nullptr, const u32 *__restrict__ dchain = nullptr) {
   typedef typename Op::Elem Elem;
   typedef typename Op::V V;
   constexpr int G = XBlk<Elem>::G;
   // (dirty != nullptr: an incremental re-sweep of a row block — only the chains marked there are folded again)
+  // The END of a chain is the only trunk cell a later round reads from the raster (as a light upstream cell): whoever
+  // folds the chain stores it — its value follows its post slots, so it is the value of the chain's last slot — and,
+  // in a re-sweep, marks the chain that end drains into (always a chain of a later round).
+  auto finish = [&](u32 c, u32 s0, u32 cl, V endv) {
+    op.store(scell[s0 + (cl & XC_LEN) - 1u - (cl >> 29)], endv);
+    if (dchain) {
+      const u32 d = dchain[c];
+      if (d != 0xFFFFFFFFu) dirty[d] = 1;
+    }
+  };
   if (blockIdx.x < nlong) {
     __shared__ XVec4<Elem> sE[64];
     __shared__ XVec4<V> sR[64];
@@ -279,6 +290,10 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
       }
       __syncthreads();
       if (g0 + lane < ng) R4[g0 + lane] = sR[lane];
+      if (lane == 0 && g0 + 64u >= ng) {  // the block that holds the chain's last slot
+        const u32 last = (clen[cc] & XC_LEN) - 1u;
+        finish(cc, s0, clen[cc], sR[(last >> 2) - g0].v[last & 3u]);
+      }
     }
     return;
   }
@@ -361,6 +376,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
     load(g0 + 6 * G, ec, bc);
     fold(g0 + 3 * G, ed, bd);
   }
+  if (m) finish(c, s0, clen[c], R[s0 + m - 1u]);  // (the lane reads back what it stored itself)
 }
 
 template <class Op>
@@ -375,19 +391,9 @@ __global__ void __launch_bounds__(256) k_xtrunk_scatter(Op op, const u32 *__rest
 }
 
 // Between the rounds only the END of a chain is read from the raster (as a light upstream cell of a later round's
-// slot): one store per chain.  Every other trunk cell reaches the raster in one pass in RASTER order at the end
-// (k_xtrunk_unscatter): coalesced reads of the marks and slot numbers, partial but sector-local writes — the per-slot
-// scatter in chain order paid a whole sector per 4-byte value.
-template <class Op>
-__global__ void __launch_bounds__(256) k_xtrunk_ends(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
-                                                     u32 c0, u32 c1, const u32 *__restrict__ scell,
-                                                     const typename Op::V *__restrict__ R) {
-  const u32 c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= c1) return;
-  const u32 cl = clen[c], np = cl >> 29;
-  const u32 s = cstart[c] + (cl & XC_LEN) - 1u - np;  // slot of the chain's last cell; its value follows its post slots
-  op.store(scell[s], R[s + np]);
-}
+// slot): the scan stores it (k_xtrunk_scan, finish).  Every other trunk cell reaches the raster in one pass in RASTER
+// order at the end (k_xtrunk_unscatter): coalesced reads of the marks and slot numbers, partial but sector-local writes —
+// the per-slot scatter in chain order paid a whole sector per 4-byte value.
 // (One workgroup per 64 x 64 TILE, not per strip of a raster row: a chain crosses a tile in a run of ~64 consecutive
 //  slots, so the workgroup's scattered accesses in chain order fall into a few hundred bytes per chain and the L2
 //  serves all but the first touch of a sector — a row strip meets every chain once and pays a sector per value.)
@@ -447,7 +453,7 @@ __global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, co
   }
 }
 
-// ---- incremental re-sweep of a row block (ExactPlan::schain ...): the same three steps for the dirty chains only ----
+// ---- incremental re-sweep of a row block (ExactPlan::schain ...): the same steps for the dirty chains only ----
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_pre_inc(Op op, const u32 *__restrict__ scell, const uint16_t *__restrict__ sinfo,
                                                         const u32 *__restrict__ schain, const u8 *__restrict__ dirty, u32 s0,
@@ -457,20 +463,6 @@ __global__ void __launch_bounds__(256) k_xtrunk_pre_inc(Op op, const u32 *__rest
   const u32 info = sinfo[s];
   const u32 x = scell[s];
   E[s] = (info & XS_POST) ? op.pre_post(x) : op.pre_real(x, info & 0xFFu, (info >> 8) & 0xFu);
-}
-// the end of a dirty chain goes to the raster (a later round reads it) and makes the chain it drains into dirty
-template <class Op>
-__global__ void __launch_bounds__(256) k_xtrunk_ends_inc(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
-                                                         u32 c0, u32 c1, const u32 *__restrict__ scell,
-                                                         const typename Op::V *__restrict__ R, const u32 *__restrict__ dchain,
-                                                         u8 *__restrict__ dirty) {
-  const u32 c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= c1 || !dirty[c]) return;
-  const u32 cl = clen[c], np = cl >> 29;
-  const u32 s = cstart[c] + (cl & XC_LEN) - 1u - np;
-  op.store(scell[s], R[s + np]);
-  const u32 d = dchain[c];
-  if (d != 0xFFFFFFFFu) dirty[d] = 1;  // (always a chain of a later round)
 }
 // the cells of the dirty chains, in chain order (a sector per value — but only below the seeds that changed)
 template <class Op>
@@ -505,10 +497,8 @@ static int run_exact_up_inc(pfd_raster *h, const Op &op) {
     k_xtrunk_pre_inc<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, p->schain, p->dirty, s0, s1, E);
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
     k_xtrunk_scan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->longc + p->b_long[b], nl,
-                                                                        p->spost, E, R, p->dirty);
-    k_xtrunk_ends_inc<Op><<<cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, R, p->dchain,
-                                                                         p->dirty);
-    launches += 3;
+                                                                        p->spost, E, R, p->scell, p->dirty, p->dchain);
+    launches += 2;
   }
   if (p->nslot) {
     k_xtrunk_scatter_inc<Op><<<cdiv_u32((u64)p->nslot, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, p->schain, p->dirty,
@@ -574,11 +564,9 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
     XDBG(h, "pre");
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
     k_xtrunk_scan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
-                                                                        p->longc + p->b_long[b], nl, p->spost, E, R);
+                                                                        p->longc + p->b_long[b], nl, p->spost, E, R, p->scell);
     XDBG(h, "scan");
-    k_xtrunk_ends<Op><<<cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1, p->scell, R);
-    XDBG(h, "ends");
-    launches += 3;
+    launches += 2;
   }
   if (p->nslot) {
     a.cslot = p->cslot;
