@@ -117,9 +117,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the raster given to the CPU baseline (0=auto)")
-    ap.add_argument("--op", choices=["upstream_area", "hand", "basins"], default="upstream_area",
+    ap.add_argument("--op", choices=["upstream_area", "hand", "basins", "accuflux", "strahler"], default="upstream_area",
                     help="hand / basins: BASELINE configs[4] — the sharded collective on the 36000 x 72000 tile (rows x cols; "
-                         "--rows / --cols override), one row block per GPU, boundary rows over RCCL send/recv")
+                         "--rows / --cols override), one row block per GPU, boundary rows over RCCL send/recv; accuflux "
+                         "(float32 cell areas per row = upstream_area in area units) / strahler: the seeded up-sweeps on the "
+                         "same tile (incremental from the second exchange on)")
     ap.add_argument("--rows", type=int, default=36000)
     ap.add_argument("--cols", type=int, default=72000)
     ap.add_argument("--ops", choices=["c3", "c5"], default=None,
@@ -640,6 +642,25 @@ def run_distributed_op(a, rank, world, local):
         def checksum():
             return _hip.checksum_i32(_hip.ptr(res).value + top * ncol * 8, own * ncol * 2, device)
         label, dtype, extra_bytes = "hand(drain = upstream cells > 100, elevtn float32) -> float64", "f64", 8
+    elif a.op in ("accuflux", "strahler"):
+        # the seeded up-sweeps: float32 accuflux of one cell area per ROW (upstream_area in area units on a lat/lon grid)
+        # / the Strahler order; exchange-until-stable, every exchange after the first folds only the chains below a
+        # halo value that changed (pfd_set_block_update)
+        f32 = a.op == "accuflux"
+        areas = (np.cos(np.linspace(-0.9, 0.9, nrow_total)) * 0.81).astype(np.float32)[r0 - top:r0 - top + ndev]
+        res = _hip.DeviceBuffer(ndev * ncol * (4 if f32 else 1), device)
+        iters = [0]
+
+        def step():
+            if f32:
+                _, iters[0] = dr.accuflux(areas, (-9999, -9999.0, 1), by_row=True, out=res)
+            else:
+                _, iters[0] = dr.stream_order(out=res)
+
+        def checksum():
+            return _hip.checksum_i32(_hip.ptr(res).value + top * ncol * (4 if f32 else 1), own * ncol // (1 if f32 else 4), device)
+        label, dtype, extra_bytes = ("accuflux(float32 cell area per row, direction='up') -> float32", "f32", 4) if f32 else \
+                                    ("stream_order(type='strahler') -> uint8", "u8", 1)
     else:
         # 1000 outlets of the whole tile: the largest upstream area of sampled rows (every rank offers its rows' maxima)
         rng = np.random.default_rng(5)
@@ -682,7 +703,7 @@ def run_distributed_op(a, rank, world, local):
     if rank == 0:
         n = nrow_total * ncol
         ms = dt / a.steps * 1e3
-        b_alg = B_ALG["hand_f32" if a.op == "hand" else "basins_u32"]
+        b_alg = B_ALG[{"hand": "hand_f32", "basins": "basins_u32", "accuflux": "accuflux_f32", "strahler": "strahler"}[a.op]]
         per_gpu = b_alg * n / (ms * 1e-3) / 1e9 / world
         out = dict(metric=f"Mcells/s {a.op} on D8 raster", value=round(n * a.steps / dt / 1e6, 2), unit="Mcells/s", n_gpus=world,
                    steps=a.steps, warmup=max(1, a.warmup), ms_per_step=round(ms, 3), ms_per_step_rank0=[round(x, 3) for x in per],

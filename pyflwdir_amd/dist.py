@@ -158,7 +158,8 @@ class _UpBlock:
     """Device-resident state of one row block of an up-sweep (accuflux, Strahler) between the exchanges: payload and
     result stay in HBM; only the two boundary rows travel."""
 
-    def __init__(self, handle, kind, dtype, payload=None, by_row=False, nodata=(0, 0.0, 0), mask=None, direction=_hip.PFD_UP):
+    def __init__(self, handle, kind, dtype, payload=None, by_row=False, nodata=(0, 0.0, 0), mask=None, direction=_hip.PFD_UP,
+                 out=None):
         self.h, self.kind, self.dtype, self.by_row, self.nodata = handle, kind, np.dtype(dtype), by_row, nodata
         self.direction = direction
         ncol, dev = handle.ncol, handle.device
@@ -174,7 +175,12 @@ class _UpBlock:
             self.mask = _hip.DeviceBuffer(mask.nbytes, dev).upload(mask)
         if kind == "distance":
             self.payload = None if payload is None else np.ascontiguousarray(payload, dtype=np.float32)  # step-length rows
-        self.out = _hip.DeviceBuffer(self.nrows_dev * ncol * self.dtype.itemsize, dev)
+        # (``out``: the caller's DEVICE buffer for the result over the block's device rows — stays resident, is not freed here,
+        #  and ``result()`` hands it back instead of a host copy)
+        self.out_given = out is not None
+        if self.out_given:
+            assert out.nbytes >= self.nrows_dev * ncol * self.dtype.itemsize
+        self.out = out if self.out_given else _hip.DeviceBuffer(self.nrows_dev * ncol * self.dtype.itemsize, dev)
         self.swept_with, self.brows = None, None
         # accuflux "up" and Strahler: from the second sweep on only the chains below a changed halo seed are folded
         # again (pfd_set_block_update; the down-sweeps of accuflux "down" / stream_distance sweep the block each time)
@@ -213,11 +219,13 @@ class _UpBlock:
         return self._call(seed, True)[1]
 
     def result(self):
+        if self.out_given:
+            return self.out
         ncol, sz = self.h.ncol, self.dtype.itemsize
         return self.out.download(self.dtype, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol * sz)
 
     def close(self, close_handle=True):
-        for b in (self.payload, self.mask, self.out):
+        for b in (self.payload, self.mask, None if self.out_given else self.out):
             if isinstance(b, _hip.DeviceBuffer):
                 b.free()
         if close_handle:
@@ -756,16 +764,17 @@ class DistributedRaster:
             if blk is not None:
                 blk.close(close_handle=False)
 
-    def accuflux(self, data_block, nodata_args=(0, 0.0, 0), by_row=False, max_iter=MAX_ROUNDS, direction="up"):
+    def accuflux(self, data_block, nodata_args=(0, 0.0, 0), by_row=False, max_iter=MAX_ROUNDS, direction="up", out=None):
         """Collective ``accuflux(data, direction="up")`` (reference pyflwdir/streams.py:15-41): every rank passes the
         payload of its block INCLUDING its halo rows (``by_row``: one value per device row); returns (the rank's own
-        rows, rounds).  Bit-identical to the whole raster, floats included: see :func:`accuflux_blocks`."""
+        rows, rounds).  Bit-identical to the whole raster, floats included: see :func:`accuflux_blocks`.  ``out``: a
+        DEVICE buffer over the block's device rows (own + halo) that receives the result and is returned instead."""
         data = np.asarray(data_block)
         if data.dtype not in _hip._PAYLOAD_CODE:
             raise NotImplementedError(f"payload dtype {data.dtype} is not supported by the row-block accuflux")
         dirc = _hip.PFD_UP if direction == "up" else _hip.PFD_DOWN
         return self._up_collective(lambda: _UpBlock(self.handle, "accuflux", data.dtype, payload=data, by_row=by_row,
-                                                    nodata=nodata_args, direction=dirc), data.dtype, max_iter)
+                                                    nodata=nodata_args, direction=dirc, out=out), data.dtype, max_iter)
 
     def stream_distance(self, mask_block=None, step_lengths_block=None, max_iter=MAX_ROUNDS):
         """Collective ``stream_distance`` (reference pyflwdir/streams.py:272-315): int32 cell counts, or float32 metres
@@ -775,10 +784,11 @@ class DistributedRaster:
         return self._up_collective(lambda: _UpBlock(self.handle, "distance", dtype, payload=step_lengths_block,
                                                     mask=mask_block), dtype, max_iter)
 
-    def stream_order(self, mask_block=None, max_iter=MAX_ROUNDS):
+    def stream_order(self, mask_block=None, max_iter=MAX_ROUNDS, out=None):
         """Collective Strahler order (reference pyflwdir/streams.py:228-269); ``mask_block`` covers the block's device
-        rows.  Returns (uint8 orders of the rank's own rows, rounds)."""
-        return self._up_collective(lambda: _UpBlock(self.handle, "strahler", np.uint8, mask=mask_block), np.uint8, max_iter)
+        rows.  Returns (uint8 orders of the rank's own rows, rounds); ``out`` as in :meth:`accuflux`."""
+        return self._up_collective(lambda: _UpBlock(self.handle, "strahler", np.uint8, mask=mask_block, out=out), np.uint8,
+                                   max_iter)
 
     def close(self):
         if self.handle is not None:

@@ -122,7 +122,7 @@ def test_collectives_over_rccl_with_one_rank(gpu_lib):
     assert "ok (rccl)" in out.stdout and "rccl_sendrecv" in out.stdout and "rccl_allgather" in out.stdout
 
 
-@pytest.mark.parametrize("op", ["hand", "basins"])
+@pytest.mark.parametrize("op", ["hand", "basins", "accuflux", "strahler"])
 def test_bench_op_lines_one_and_two_ranks(gpu_lib, op):
     """`bench.py --op hand|basins` (BASELINE configs[4], here on a small tile): one rank over RCCL (world 1: device-resident
     halo seeds, ncclAllReduce of the counts), then two self-spawned ranks (on the one GPU of the test box: host transport);
@@ -144,3 +144,5 @@ def test_bench_op_lines_one_and_two_ranks(gpu_lib, op):
     assert two["invariants"]["result_checksum_equals_n1"] is True and two["speedup_vs_n1"] > 0
     if op == "hand":
         assert two["config"]["iterations"] >= 2 and two["config"]["exchanges_per_step"] == two["config"]["iterations"]
+    if op in ("accuflux", "strahler"):  # (the seeded up-sweeps: at least one exchange that changed a halo value, then one that did not)
+        assert two["config"]["iterations"] >= 1 and two["config"]["exchanges_per_step"] >= 2

@@ -24,7 +24,7 @@ SQ_SIZE=10000 bash tools/prof_sq.sh "k_tile|k_super" > $O/sq_counters.csv 2>&1; 
 bash tools/run_ops.sh ${T}_ops > /dev/null 2>&1; cp gpurun_out/${T}_ops/*.txt $O/
 python tools/bench_blocks.py 11250 8 90000 > $O/blocks8_c4.txt 2>&1
 PFD_BLOCK_PHASES=1 python tools/bench_blocks_isolated.py 11250 8 90000 > $O/blocks8_isolated.txt 2>&1
-for op in hand basins; do for g in 1 4; do python bench.py --gpus $g --op $op --steps 2 --warmup 1 > $O/op_${op}_n$g.json 2>/dev/null; done; done
+for op in hand basins accuflux strahler; do for g in 1 4; do python bench.py --gpus $g --op $op --steps 2 --warmup 1 > $O/op_${op}_n$g.json 2>/dev/null; done; done
 python tools/bench_blocks.py 10000 4 > $O/blocks4.txt 2>&1
 python tools/bench_hand_blocks.py 36000 72000 4 > $O/hand_blocks_c5.txt 2>&1
 python tools/bench_hand_blocks.py 30000 30000 4 0 67108864 100 > $O/hand_blocks_30k.txt 2>&1
