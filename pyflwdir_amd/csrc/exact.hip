@@ -180,95 +180,181 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
 // area (first maximum in ascending index).  hcode = the forest of heavy links only (light trunk cells
 // and pits become path ends, everything else nodata): a chain end is a pit of that forest.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 heavy_slot(const u8 *__restrict__ lh, const u32 *__restrict__ upa, const Geo &g, u32 x,
-                                          u32 kids) {
-  u32 best = 0, arg = 8;
-  u32 a[8], t[8];
+// One workgroup per 64 x 64 tile: upstream areas and marks of the tile and TWO rings in LDS (the heavy flag of a cell
+// asks for the heavy slot of its downstream cell, which may lie in the first ring, whose own upstream cells reach into
+// the second), coalesced loads instead of up to 34 gathers per trunk cell in raster order (10.9 ms at 30000^2; as two
+// raster-order passes with gathers only of the cells that drain in: 8.9 ms; this form: see DESIGN.md 4.5).
+#define HPW (XT + 4)  // staged edge with two rings
+#define HRW (XT + 2)  // region whose heavy slots are computed: the tile and one ring
+__global__ void __launch_bounds__(256) k_plan_heavy_tile(const u8 *__restrict__ ncode, u32 nrow, u32 ncol,
+                                                         const u8 *__restrict__ lh, const u8 *__restrict__ kids,
+                                                         const u32 *__restrict__ upa, uint16_t *__restrict__ hinfo,
+                                                         u8 *__restrict__ hcode) {
+  __shared__ u32 sU[HPW * HPW];
+  __shared__ u8 sL[HPW * HPW];
+  __shared__ u8 sK[HRW * HRW], sH[HRW * HRW];
+  const u32 tid = threadIdx.x;
+  const i64 r0 = (i64)blockIdx.y * XT, c0 = (i64)blockIdx.x * XT;
+  // (all loads of the staging first, from clamped addresses: one round trip, not one per loop iteration)
+  constexpr int NU = (HPW * HPW + 255) / 256, NK = (HRW * HRW + 255) / 256;
+  u32 ua[NU], la[NU], ka[NK];
+  u32 inu = 0, ink = 0;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {  // (only the cells that drain into x are looked at: 1-3 of the 8 for most trunk cells)
-    const int k = PFD_SLOT_ASC[q];
-    a[q] = 0, t[q] = 0;
-    if (kids & (1u << k)) {
-      const u32 j = (u32)((i64)x + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k));
-      a[q] = upa[j];
-      t[q] = lh[j];
+  for (int i = 0; i < NU; ++i) {
+    const u32 idx = tid + 256u * (u32)i;
+    const i64 gr = r0 - 2 + (i64)(idx / HPW), gc = c0 - 2 + (i64)(idx % HPW);
+    const bool inb = idx < HPW * HPW && gr >= 0 && gr < (i64)nrow && gc >= 0 && gc < (i64)ncol;
+    const size_t g = inb ? (size_t)gr * ncol + (size_t)gc : 0;
+    ua[i] = upa[g];
+    la[i] = lh[g];
+    inu |= inb ? 1u << i : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    const u32 idx = tid + 256u * (u32)i;
+    const i64 gr = r0 - 1 + (i64)(idx / HRW), gc = c0 - 1 + (i64)(idx % HRW);
+    const bool inb = idx < HRW * HRW && gr >= 0 && gr < (i64)nrow && gc >= 0 && gc < (i64)ncol;
+    ka[i] = kids[inb ? (size_t)gr * ncol + (size_t)gc : 0];
+    ink |= inb ? 1u << i : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const u32 idx = tid + 256u * (u32)i;
+    if (idx < HPW * HPW) {
+      const bool inb = (inu >> i) & 1u;
+      sU[idx] = inb ? ua[i] : 0u;
+      sL[idx] = (u8)(inb ? la[i] : XL_NODATA);
     }
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    if (xl_trunk(t[q]) && a[q] > best) {
-      best = a[q];
-      arg = (u32)PFD_SLOT_ASC[q];
-    }
+  for (int i = 0; i < NK; ++i) {
+    const u32 idx = tid + 256u * (u32)i;
+    if (idx < HRW * HRW) sK[idx] = (u8)(((ink >> i) & 1u) ? ka[i] : 0u);
   }
-  return arg;
-}
-
-// pass 1: per trunk cell its upstream-cell mask, heavy slot and post count (hinfo)
-__global__ void __launch_bounds__(256) k_plan_hinfo(Geo g, const u8 *__restrict__ lh, const u8 *__restrict__ kids,
-                                                    const u32 *__restrict__ upa, uint16_t *__restrict__ hinfo) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= g.n) return;
-  u32 info = 0;
-  if (xl_trunk(lh[x])) {
-    const u32 m = kids[x];
-    const u32 hs = heavy_slot(lh, upa, g, x, m);
-    // post cells: upstream cells the serial loop adds after the heavy one = those of lower linear index
-    u32 npost = 0;
-    if (hs < 8) {
-      const i64 hoff = (i64)d8_dr((int)hs) * (i64)g.ncol + d8_dc((int)hs);
+  __syncthreads();
+  // heavy slot of every cell of the region: its upstream TRUNK cell with the largest upstream area, first maximum in
+  // ascending linear index (8: none, or no trunk cell)
+  for (u32 idx = tid; idx < HRW * HRW; idx += 256u) {
+    const u32 lr = idx / HRW + 1u, lc = idx % HRW + 1u;  // staged coordinates
+    u32 hs = 8;
+    if (xl_trunk(sL[lr * HPW + lc])) {
+      const u32 m = sK[idx];
+      u32 best = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const i64 off = (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k);
-        if ((m & (1u << k)) && off < hoff) ++npost;
+      for (int q = 0; q < 8; ++q) {
+        const int k = PFD_SLOT_ASC[q];
+        if (m & (1u << k)) {
+          const u32 j = (u32)((int)lr + d8_dr(k)) * HPW + (u32)((int)lc + d8_dc(k));
+          if (xl_trunk(sL[j]) && sU[j] > best) best = sU[j], hs = (u32)k;
+        }
       }
     }
-    info = m | (hs << 8) | (npost << 12);
+    sH[idx] = (u8)hs;
   }
-  hinfo[x] = (uint16_t)info;
-}
-// pass 2: the heavy links (x is heavy when the heavy slot of its downstream cell holds x: one look at that cell's hinfo)
-__global__ void __launch_bounds__(256) k_plan_heavy(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ lh,
-                                                    const uint16_t *__restrict__ hinfo, u8 *__restrict__ hcode,
-                                                    u32 *__restrict__ bcount) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in = x < g.n;
-  u32 hc = D8_MV;
-  bool sd = false;  // the cell ends its chain (a pit of the heavy forest: hcode 0)
-  if (in && xl_trunk(lh[x])) {
-    const u32 c = ncode[x];
-    bool heavy = false;
-    if (d8_is_dir(c)) {
-      const u32 p = d8_down(g, x, c);
-      // (a halo cell of a row block is in no chain — its hinfo is 0, heavy slot 0 = E, so it is asked for by name:
-      //  the cell draining into it ends its own chain)
-      const u32 ps = ((u32)hinfo[p] >> 8) & 0xFu;
-      heavy = ps < 8 && ((d8_slot(c) + 4) & 7) == (int)ps && xl_trunk(lh[p]);  // the slot of p that holds x
+  __syncthreads();
+  u32 ca[16];
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {  // (the codes of the thread's cells, loaded together)
+    const u32 l = tid + 256u * (u32)jj;
+    const i64 gr = r0 + (l >> 6), gc = c0 + (l & 63u);
+    ca[jj] = ncode[(gr < (i64)nrow && gc < (i64)ncol) ? (size_t)gr * ncol + (size_t)gc : 0];
+  }
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const u32 l = tid + 256u * (u32)jj;
+    const u32 lr = l >> 6, lc = l & 63u;
+    const i64 gr = r0 + lr, gc = c0 + lc;
+    if (gr >= (i64)nrow || gc >= (i64)ncol) continue;
+    const size_t g = (size_t)gr * ncol + (size_t)gc;
+    u32 info = 0, hc = D8_MV;
+    if (xl_trunk(sL[(lr + 2u) * HPW + lc + 2u])) {
+      const u32 ri = (lr + 1u) * HRW + lc + 1u;
+      const u32 m = sK[ri], hs = sH[ri];
+      // post cells: upstream cells the serial loop adds after the heavy one = those of lower linear index
+      u32 npost = 0;
+      if (hs < 8) {
+        const i64 hoff = (i64)d8_dr((int)hs) * (i64)ncol + d8_dc((int)hs);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const i64 off = (i64)d8_dr(k) * (i64)ncol + d8_dc(k);
+          if ((m & (1u << k)) && off < hoff) ++npost;
+        }
+      }
+      info = m | (hs << 8) | (npost << 12);
+      // heavy link: the heavy slot of the downstream cell holds this cell (a halo cell of a row block is in no chain —
+      // it is no trunk cell: the cell draining into it ends its own chain)
+      const u32 c = ca[jj];
+      bool heavy = false;
+      if (d8_is_dir(c)) {
+        const int k = d8_slot(c);
+        const u32 pr = (u32)((int)lr + 1 + d8_dr(k)), pc = (u32)((int)lc + 1 + d8_dc(k));  // region coordinates
+        const u32 ps = sH[pr * HRW + pc];
+        heavy = ps < 8 && ((k + 4) & 7) == (int)ps && xl_trunk(sL[(pr + 1u) * HPW + pc + 1u]);
+      }
+      hc = heavy ? c : 0u;
     }
-    hc = heavy ? c : 0u;
-    sd = !heavy;
+    hinfo[g] = (uint16_t)info;
+    hcode[g] = (u8)hc;
   }
-  if (in) hcode[x] = (u8)hc;
-  // chain ends per workgroup: what the raster-ordered list of chain ends (k_plan_tail_list) is offset by
-  const u32 cnt = (u32)__syncthreads_count(sd);
-  if (threadIdx.x == 0) bcount[blockIdx.x] = cnt;
 }
-// the chain ends in raster order: position = ends in the workgroups before (exclusive scan of k_plan_heavy's counts)
-// + ends before the cell in its own workgroup.  (Same grid as k_plan_heavy.  A rocprim::select over the 4-byte
-// seeds took 10.3 ms at 30000 x 30000; the count rides k_plan_heavy and this pass reads one byte per cell.)
+// chain ends (pits of the heavy forest: hcode 0) per 4096 cells in raster order — what the list of chain ends is offset by
+// — and the list itself: position = ends in the groups before (exclusive scan of the counts) + ends before the cell in
+// its own group.  16 cells (one 16-byte load) per thread: with one byte per thread the two passes cost 2.1 + 1.8 ms at
+// 30000 x 30000, most of it dispatching 3.5 M workgroups.  (hcode carries 64 bytes of slack behind its n cells.)
+#define TLG 4096u
+__device__ __forceinline__ u32 zero_bytes(u32 x) {  // bit 7 of every byte that is 0 (exact: no carry crosses a byte)
+  return ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x)) & 0x80808080u;
+}
+__device__ __forceinline__ void tl_load(const u8 *__restrict__ hcode, u32 n, u32 x0, u32 (&z)[4]) {
+  uint4 v = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+  if (x0 < n) v = *reinterpret_cast<const uint4 *>(hcode + x0);  // (x0 is a multiple of 16: aligned)
+  const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    z[i] = zero_bytes(w[i]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (x0 + 4u * i + b >= n) z[i] &= ~(0x80u << (8 * b));  // (cells past the raster)
+  }
+}
+__global__ void __launch_bounds__(256) k_plan_count_ends(const u8 *__restrict__ hcode, u32 n, u32 *__restrict__ bcount) {
+  __shared__ u32 wcnt[4];
+  const u32 x0 = blockIdx.x * TLG + 16u * threadIdx.x;
+  u32 z[4];
+  tl_load(hcode, n, x0, z);
+  u32 c = (u32)__popc(z[0]) + (u32)__popc(z[1]) + (u32)__popc(z[2]) + (u32)__popc(z[3]);
+  for (int o = 32; o > 0; o >>= 1) c += (u32)__shfl_down((int)c, o);
+  if ((threadIdx.x & 63u) == 0u) wcnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) bcount[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
 __global__ void __launch_bounds__(256) k_plan_tail_list(const u8 *__restrict__ hcode, u32 n, const u32 *__restrict__ boff,
                                                         u32 *__restrict__ tails) {
   __shared__ u32 wcnt[4];
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool f = x < n && hcode[x] == 0u;
-  const u64 m = __ballot(f);
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (lane == 0) wcnt[wave] = (u32)__popcll(m);
+  const u32 x0 = blockIdx.x * TLG + 16u * threadIdx.x;
+  u32 z[4];
+  tl_load(hcode, n, x0, z);
+  const u32 c = (u32)__popc(z[0]) + (u32)__popc(z[1]) + (u32)__popc(z[2]) + (u32)__popc(z[3]);
+  u32 incl = c;  // inclusive prefix over the wave's lanes
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 y = (u32)__shfl_up((int)incl, o);
+    if (lane >= (u32)o) incl += y;
+  }
+  if (lane == 63u) wcnt[wave] = incl;
   __syncthreads();
-  if (!f) return;
-  u32 pos = boff[blockIdx.x] + (u32)__popcll(m & ((1ull << lane) - 1ull));
+  if (!c) return;
+  u32 pos = boff[blockIdx.x] + incl - c;
   for (u32 w = 0; w < wave; ++w) pos += wcnt[w];
-  tails[pos] = x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u32 m = z[i];
+    while (m) {
+      const u32 b = (u32)__ffs((int)m) - 1u;  // bit 7 of byte b / 8
+      tails[pos++] = x0 + 4u * (u32)i + (b >> 3);
+      m &= m - 1u;
+    }
+  }
 }
 
 // the head of a chain (a trunk cell without heavy child) knows the length of its chain
@@ -696,10 +782,12 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if ((rc = hinfo.alloc((size_t)n * sizeof(uint16_t))) != PFD_OK) return fail(rc);
   const u32 grid = cdiv_u32(n, 256);
   DevBuf bcount;
-  if ((rc = bcount.alloc(((size_t)grid + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
-  if (hipMemsetAsync(bcount.as<u32>() + grid, 0, sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_hinfo<<<grid, 256, 0, h->stream>>>(h->geo, p->lh, p->kids, upa.as<u32>(), hinfo.as<uint16_t>());
-  k_plan_heavy<<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, p->lh, hinfo.as<uint16_t>(), hcode.as<u8>(), bcount.as<u32>());
+  const u32 gridT = cdiv_u32(n, TLG);  // (the chain-end count / list kernels: 4096 cells per workgroup)
+  if ((rc = bcount.alloc(((size_t)gridT + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if (hipMemsetAsync(bcount.as<u32>() + gridT, 0, sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
+  k_plan_heavy_tile<<<dim3(ntc, ntr), 256, 0, h->stream>>>(h->ncode, (u32)h->nrow, (u32)h->ncol, p->lh, p->kids, upa.as<u32>(),
+                                                           hinfo.as<uint16_t>(), hcode.as<u8>());
+  k_plan_count_ends<<<gridT, 256, 0, h->stream>>>(hcode.as<u8>(), n, bcount.as<u32>());
   XDBG(h, "k_plan_heavy");
   xdigest(h, "hcode", hcode.p, (size_t)n);
   xdigest(h, "hinfo", hinfo.p, (size_t)n * 2);
@@ -718,19 +806,19 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if ((rc = cnt.alloc(64 * sizeof(u32))) != PFD_OK) return fail(rc);
   size_t tmp_bytes = 0;
   {
-    if (rocprim::exclusive_scan(nullptr, tmp_bytes, bcount.as<u32>(), bcount.as<u32>(), 0u, (size_t)grid + 1, rocprim::plus<u32>(),
+    if (rocprim::exclusive_scan(nullptr, tmp_bytes, bcount.as<u32>(), bcount.as<u32>(), 0u, (size_t)gridT + 1, rocprim::plus<u32>(),
                                 h->stream) != hipSuccess)
       return fail(PFD_EHIP);
     if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
-    if (rocprim::exclusive_scan(tmp.p, tmp_bytes, bcount.as<u32>(), bcount.as<u32>(), 0u, (size_t)grid + 1, rocprim::plus<u32>(),
+    if (rocprim::exclusive_scan(tmp.p, tmp_bytes, bcount.as<u32>(), bcount.as<u32>(), 0u, (size_t)gridT + 1, rocprim::plus<u32>(),
                                 h->stream) != hipSuccess)
       return fail(PFD_EHIP);
-    k_plan_tail_list<<<grid, 256, 0, h->stream>>>(hcode.as<u8>(), n, bcount.as<u32>(), tails);
+    k_plan_tail_list<<<gridT, 256, 0, h->stream>>>(hcode.as<u8>(), n, bcount.as<u32>(), tails);
     if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   }
   hcode.alloc(0);
   u32 nt32 = 0;
-  if (hipMemcpyAsync(&nt32, bcount.as<u32>() + grid, sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+  if (hipMemcpyAsync(&nt32, bcount.as<u32>() + gridT, sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
     return fail(PFD_EHIP);
   const unsigned long long nchain = nt32;
