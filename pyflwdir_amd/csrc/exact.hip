@@ -367,21 +367,22 @@ __global__ void __launch_bounds__(256) k_plan_tidx(const u32 *__restrict__ tails
 // (8 cells = one 16-byte load of hinfo per thread: with one cell per thread the pass spent most of its 2.2 ms at
 //  30000 x 30000 dispatching 3.5 M workgroups for 1.8 GB)
 __device__ __forceinline__ void hinfo8(const uint16_t *__restrict__ hinfo, u32 x0, u32 n, u32 (&inf)[8]) {
-  if (x0 + 8u <= n) {
+  if ((u64)x0 + 8ull <= (u64)n) {
     const uint4 v = *reinterpret_cast<const uint4 *>(hinfo + x0);  // (x0 is a multiple of 8: aligned)
     const u32 d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) inf[2 * i] = d[i] & 0xFFFFu, inf[2 * i + 1] = d[i] >> 16;
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) inf[i] = x0 + (u32)i < n ? (u32)hinfo[x0 + i] : 0u;
+    for (int i = 0; i < 8; ++i) inf[i] = (u64)x0 + (u64)i < (u64)n ? (u32)hinfo[x0 + i] : 0u;
   }
 }
 __global__ void __launch_bounds__(256) k_plan_len(const uint16_t *__restrict__ hinfo, const u32 *__restrict__ hops,
                                                   const u32 *__restrict__ tailnum, const u32 *__restrict__ tidx_at, u32 n,
                                                   u32 *__restrict__ len_of) {
-  const u32 x0 = 8u * (blockIdx.x * blockDim.x + threadIdx.x);
-  if (x0 >= n) return;
+  const u64 x64 = 8ull * ((u64)blockIdx.x * blockDim.x + threadIdx.x);  // (n may lie within 2048 cells of 2^32)
+  if (x64 >= (u64)n) return;
+  const u32 x0 = (u32)x64;
   u32 inf[8];
   hinfo8(hinfo, x0, n, inf);
 #pragma unroll
