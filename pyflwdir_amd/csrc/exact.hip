@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
   const i64 r0 = (i64)tr * XT, c0 = (i64)tc * XT;
   {
     u32 v[5];
-    stage_load(ncode, nrow, ncol, r0, c0, tid, v);
+    stage_load_auto(ncode, nrow, ncol, r0, c0, tid, v);
     stage_store(code, tid, v);
   }
   if (tid == 0) s_n = 0;

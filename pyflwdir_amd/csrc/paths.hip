@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   {
     u32 v[5];
-    stage_load(a.ncode, a.nrow, a.ncol, r0, c0, tid, v);
+    stage_load_auto(a.ncode, a.nrow, a.ncol, r0, c0, tid, v);
     stage_store(code, tid, v);
   }
   __syncthreads();

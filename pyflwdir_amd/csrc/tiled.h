@@ -301,6 +301,12 @@ __device__ __forceinline__ void stage_load_interior(const u8 *__restrict__ ncode
     __builtin_memcpy(&v[k], base + (size_t)hr * ncol + 4u * d, 4);
   }
 }
+// the cheap form wherever the staging window lies inside the raster (a workgroup-uniform branch), else the general one
+__device__ __forceinline__ void stage_load_auto(const u8 *__restrict__ ncode, u32 nrow, u32 ncol, i64 r0, i64 c0, u32 tid,
+                                                u32 (&v)[5]) {
+  if (r0 >= 1 && c0 >= 4 && r0 + TS + 1 <= (i64)nrow && c0 + TS + 4 <= (i64)ncol) stage_load_interior(ncode, ncol, r0, c0, tid, v);
+  else stage_load(ncode, nrow, ncol, r0, c0, tid, v);
+}
 __device__ __forceinline__ void stage_store(u8 *code, u32 tid, const u32 (&v)[5]) {
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
