@@ -253,3 +253,49 @@ def test_two_process_gloo(tmp_path):
     for r, p in enumerate(procs):
         assert p.exitcode == 0, f"rank {r} failed (exit code {p.exitcode})"
         assert (tmp_path / f"ok{r}").exists()
+
+
+def test_up_block_asks_for_updates_from_the_second_sweep_on():
+    """Host logic of the incremental block up-sweeps (no GPU): the first sweep of a block keeps its sweep
+    (pfd_set_block_update mode 1), every later one asks for an update (mode 2), verification does not touch the mode,
+    a block whose handle lives on releases the kept sweep when it is closed, and the down-sweeps never ask."""
+    from pyflwdir_amd import _hip, dist
+
+    calls = []
+
+    class Handle:
+        nrow, ncol, device, halo = 6, 5, 0, (1, 1)
+
+        def set_block_update(self, mode):
+            calls.append(("mode", mode))
+
+        def accuflux_block(self, *a, **k):
+            calls.append(("sweep", k.get("verify", False)))
+            return np.zeros((2, 5), np.float32), 0
+
+        def close(self):
+            calls.append(("close",))
+
+    def block(direction):
+        b = dist._UpBlock.__new__(dist._UpBlock)
+        b.h, b.kind, b.dtype, b.by_row, b.nodata, b.direction = Handle(), "accuflux", np.dtype(np.float32), True, (0, 0.0, 0), direction
+        b.payload, b.mask, b.out, b.out_given = np.zeros(8, np.float32), None, None, True
+        b.swept_with, b.brows, b.sweeps = None, None, 0
+        b.incremental = direction == _hip.PFD_UP
+        return b
+
+    b = block(_hip.PFD_UP)
+    seed = np.zeros(10, np.float32)
+    assert b.sweep(seed) and not b.sweep(seed)  # (same seeds: nothing can have changed, no call at all)
+    seed[3] = 1.0
+    assert b.sweep(seed)
+    b.verify(seed)
+    b.close(close_handle=False)
+    assert calls == [("mode", 1), ("sweep", False), ("mode", 2), ("sweep", False), ("sweep", True), ("mode", 0)]
+    del calls[:]
+    d = block(_hip.PFD_DOWN)
+    assert d.sweep(seed)
+    seed[4] = 2.0
+    assert d.sweep(seed)
+    d.close(close_handle=True)
+    assert calls == [("sweep", False), ("sweep", False), ("close",)]
