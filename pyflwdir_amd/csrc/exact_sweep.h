@@ -260,20 +260,40 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
             }
             sR[0] = r;
           }
+          if (!Op::FAST_CONST) {
 #pragma unroll 4
-          for (u32 gq = q0; gq < cnt; ++gq) {
-            const XVec4<Elem> e = sE[gq];
-            XVec4<V> r;
+            for (u32 gq = q0; gq < cnt; ++gq) {
+              const XVec4<Elem> e = sE[gq];
+              XVec4<V> r;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              tt = op.fold_fast(tt, e.v[j]);
-              r.v[j] = tt;
+              for (int j = 0; j < 4; ++j) {
+                tt = op.fold_fast(tt, e.v[j]);
+                r.v[j] = tt;
+              }
+              sR[gq] = r;
             }
-            sR[gq] = r;
           }
         }
-        __syncthreads();
         bool bad = false;
+        if constexpr (Op::FAST_CONST) {
+          // the speculative fold leaves the running value as it is (Strahler along a main stem): no serial loop at all —
+          // every lane fills its own group with the value that entered the block and checks its four operands
+          static_assert(!Op::FAST_CONST || sizeof(V) == 4, "broadcast of the running value");
+          u32 tb;
+          __builtin_memcpy(&tb, &tt, 4);
+          tb = (u32)__shfl((int)tb, 0);
+          __builtin_memcpy(&tt, &tb, 4);
+          if (lane >= q0 && lane < cnt) {
+            const XVec4<Elem> e = sE[lane];
+            XVec4<V> r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.v[j] = tt;
+            sR[lane] = r;
+            bad = (int)op.special(tt, e.v[0]) | (int)op.special(tt, e.v[1]) | (int)op.special(tt, e.v[2]) |
+                  (int)op.special(tt, e.v[3]);
+          }
+        } else {
+        __syncthreads();
         if (lane >= q0 && lane < cnt) {
           const XVec4<Elem> e = sE[lane];
           const XVec4<V> r = sR[lane];
@@ -281,6 +301,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
           if (lane) prev = sR[lane - 1u].v[3];
           bad = (int)op.special(prev, e.v[0]) | (int)op.special(r.v[0], e.v[1]) | (int)op.special(r.v[1], e.v[2]) |
                 (int)op.special(r.v[2], e.v[3]);
+        }
         }
         if (__any((int)bad)) {
           __syncthreads();

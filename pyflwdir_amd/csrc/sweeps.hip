@@ -467,6 +467,7 @@ struct AccuUp {
   __device__ __forceinline__ T fold(T t, T e, bool post) const { return join(post ? t : e, post ? e : t); }
   // speculative form (exact_sweep.h): a plain add is the exact result whenever neither operand is the nodata value
   static constexpr bool FAST = true;
+  static constexpr bool FAST_CONST = false;  // (fold_fast leaves the running value unchanged whatever the element)
   __device__ __forceinline__ bool special(T t, T e) const { return has_nodata && ((t == nodata) | (e == nodata)); }
   __device__ __forceinline__ T fold_fast(T t, T e) const { return Num<T>::add(e, t); }
 };
@@ -514,6 +515,7 @@ struct AccuDown {
     for (int b = 0; b < 4; ++b) v[b] = top(x0 + b);
   }
   static constexpr bool FAST = true;
+  static constexpr bool FAST_CONST = false;  // (fold_fast leaves the running value unchanged whatever the element)
   __device__ __forceinline__ bool dspecial(T e, T pv) const { return has_nodata && ((pv == nodata) | (e == nodata)); }
   __device__ __forceinline__ T dfold_fast(T e, T pv) const { return Num<T>::add(e, pv); }
   __device__ __forceinline__ T dneutral() const { return Num<T>::neutral(); }  // dfold_fast(dneutral(), pv) == pv
@@ -679,6 +681,7 @@ struct Strahler {
   // speculative block fold: along a main stem nearly every slot leaves the order unchanged (the heavy cell is
   // inside the mask and its order exceeds that of the light cells); anything else redoes the block exactly
   static constexpr bool FAST = true;
+  static constexpr bool FAST_CONST = true;   // (fold_fast leaves the running value unchanged whatever the element)
   __device__ __forceinline__ bool special(u32 t, u32 e) const {
     return !(e & 0x80000000u) && !((e & (1u << 10)) && t > (e & 0xFFu));
   }
@@ -769,6 +772,7 @@ struct Hand {
   __device__ __forceinline__ void top4(u32 x0, double (&v)[4]) const { __builtin_memcpy(v, out + x0, 32); }
   // speculative block fold (exact_sweep.h): a drain cell on a chain is rare; everything else is one add
   static constexpr bool FAST = true;
+  static constexpr bool FAST_CONST = false;  // (fold_fast leaves the running value unchanged whatever the element)
   __device__ __forceinline__ bool dspecial(const DElem &e, double) const { return e.is_drain != 0u; }
   __device__ __forceinline__ double dfold_fast(const DElem &e, double pv) const { return pv + (double)e.dz; }
   __device__ __forceinline__ DElem dneutral() const { return DElem{(E)-0.0, 0u}; }  // pv + (-0.0) == pv for every pv
@@ -803,6 +807,7 @@ struct Flood {
   static constexpr bool DTILE_FLAG = false;
   static constexpr bool DTILE4 = false;
   static constexpr bool FAST = false;
+  static constexpr bool FAST_CONST = false;  // (fold_fast leaves the running value unchanged whatever the element)
   __device__ __forceinline__ FloodV top(u32 p) const { return state[p]; }
   __device__ __forceinline__ void top4(u32 x0, FloodV (&v)[4]) const {
 #pragma unroll
@@ -1799,6 +1804,7 @@ struct Classic {
     for (int b = 0; b < 4; ++b) v[b] = top(x0 + b);
   }
   static constexpr bool FAST = false;
+  static constexpr bool FAST_CONST = false;  // (fold_fast leaves the running value unchanged whatever the element)
   __device__ __forceinline__ bool dspecial(u32, u32) const { return false; }
   __device__ __forceinline__ u32 dfold_fast(u32, u32 pv) const { return pv; }
   __device__ __forceinline__ u32 droot(u32 e) const { return (e & 2u) ? 0u : 1u; }
@@ -1853,6 +1859,7 @@ struct Dist {
     for (int b = 0; b < 4; ++b) v[b] = top(x0 + b);
   }
   static constexpr bool FAST = false;
+  static constexpr bool FAST_CONST = false;  // (fold_fast leaves the running value unchanged whatever the element)
   __device__ __forceinline__ bool dspecial(T, T) const { return false; }
   __device__ __forceinline__ T dfold_fast(T, T pv) const { return pv; }
   __device__ __forceinline__ T droot(T) const { return (T)0; }
