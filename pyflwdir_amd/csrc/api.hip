@@ -210,6 +210,13 @@ static void release_stream(int device, hipStream_t s) {
   p.idle[device].push_back(s);
 }
 
+int pfd_aux_stream(pfd_raster *h) {
+  if (!h->stream2) PFDCHK(acquire_stream(h->device, &h->stream2));
+  if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  if (!h->ev_join) HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  return PFD_OK;
+}
+
 static int select_device(int device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -304,6 +311,12 @@ static void free_handle(pfd_raster *h) {
   pfd_free_general(h);
   pfd_dfree(h->pits);
   pfd_dfree(h->ctrl);
+  if (h->stream2) {
+    (void)hipStreamSynchronize(h->stream2);
+    release_stream(h->device, h->stream2);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->stream) {
     if (g_have_stream && g_cur_stream == h->stream) g_have_stream = false;
     release_stream(h->device, h->stream);

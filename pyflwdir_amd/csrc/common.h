@@ -119,6 +119,10 @@ struct PfdSegment {
 struct pfd_raster {
   int device = 0;
   hipStream_t stream = nullptr;
+  // a second stream + two events (pfd_aux_stream, created on first use): work that may run beside the latency-bound last
+  // rounds of an exact-order up-sweep (run_exact_up)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   i64 nrow = 0, ncol = 0, n = 0;  // device raster incl. halo rows (row blocks of a multi-GPU job)
   i64 halo_top = 0, halo_bot = 0, own_rows = 0;  // owned rows = [halo_top, halo_top + own_rows)
   Geo geo{};
@@ -257,6 +261,7 @@ void pfd_free_pending(pfd_raster *h);                            // dist.hip
 void pfd_free_pending_basins(pfd_raster *h);                     // paths.hip
 void pfd_free_hand_block(pfd_raster *h);                         // sweeps.hip
 int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
+int pfd_aux_stream(pfd_raster *h);                                // api.hip: h->stream2 / ev_fork / ev_join exist afterwards
 void pfd_free_xplan(pfd_raster *h);                             // exact.hip
 void pfd_xinc_drop(pfd_raster *h);                               // exact.hip: releases a kept block sweep
 void pfd_free_general(pfd_raster *h);                           // general.hip

@@ -419,7 +419,8 @@ __global__ void __launch_bounds__(256) k_xtrunk_scatter(Op op, const u32 *__rest
 //  slots, so the workgroup's scattered accesses in chain order fall into a few hundred bytes per chain and the L2
 //  serves all but the first touch of a sector — a row strip meets every chain once and pays a sector per value.)
 template <class Op>
-__global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, const typename Op::V *__restrict__ R) {
+__global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, const typename Op::V *__restrict__ R,
+                                                          u32 s_limit = 0xFFFFFFFFu) {  // only the cells of slots below s_limit
   const u32 tid = threadIdx.x;
   const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
   u32 l4s[4], x0s[4];
@@ -464,6 +465,9 @@ __global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, co
     for (int b = 0; b < 4; ++b) tm |= xl_trunk((l4 >> (8 * b)) & 0xFFu) ? 1u << b : 0u;
     if (!tm) continue;
     const u32 cs[4] = {c4s[j].x, c4s[j].y, c4s[j].z, c4s[j].w};
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (cs[b] >= s_limit) tm &= ~(1u << b);  // (the chains of the last rounds are scattered when they are done)
     typename Op::V v[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)  // (the mark carries the number of post slots: the cell's value sits behind them)
@@ -577,10 +581,31 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
   }
   Elem *E = keep ? (Elem *)p->incE : Eb.as<Elem>();
   V *R = keep ? (V *)p->incR : Rb.as<V>();
+  // The last two rounds hold the main stems and their largest tributaries: a few thousand chains, the longest as long
+  // as the longest flow path, folded serially — 0.5 ms each at 30000 x 30000 with most of the chip idle.  The raster-order
+  // pass that writes the trunk cells (k_xtrunk_unscatter, bandwidth) therefore starts BESIDE them, on the handle's
+  // second stream, for every chain of the earlier rounds; the chains of the last two rounds — a few per cent of the
+  // slots — are scattered in chain order when they are done.
+  int bsplit = -1;
+  {
+    int nb = 0, rounds[32];
+    for (int b = 0; b < 32; ++b)
+      if (p->b_chain[b + 1] > p->b_chain[b]) rounds[nb++] = b;
+    if (nb >= 4 && (p->nslot - p->b_slot[rounds[nb - 2]]) * 8 <= p->nslot && pfd_aux_stream(h) == PFD_OK) bsplit = rounds[nb - 2];
+  }
+  const u32 s_split = bsplit >= 0 ? (u32)p->b_slot[bsplit] : 0xFFFFFFFFu;
   for (int b = 0; b < 32; ++b) {
     const u32 s0 = (u32)p->b_slot[b], s1 = (u32)p->b_slot[b + 1];
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
     if (c1 == c0) continue;
+    if (b == bsplit) {
+      a.cslot = p->cslot;
+      HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+      HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+      k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream2>>>(op, a, R, s_split);
+      HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+      ++launches;
+    }
     k_xtrunk_pre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, E);
     XDBG(h, "pre");
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
@@ -589,7 +614,12 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
     XDBG(h, "scan");
     launches += 2;
   }
-  if (p->nslot) {
+  if (bsplit >= 0) {
+    k_xtrunk_scatter<Op><<<cdiv_u32((u32)p->nslot - s_split, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s_split,
+                                                                                     (u32)p->nslot, R);
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    ++launches;
+  } else if (p->nslot) {
     a.cslot = p->cslot;
     k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, R);
     XDBG(h, "unscatter");
