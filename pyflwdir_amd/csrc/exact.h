@@ -59,6 +59,9 @@ struct ExactPlan {
   u32 *longc = nullptr;   // [nlong] ids of the chains of >= XLONG slots, ascending (= by round)
   i64 nlong = 0;
   i64 b_long[33] = {0};   // long chains of round b = longc[b_long[b] .. b_long[b+1])
+  u32 b_maxlen[32] = {0}; // slots of the longest chain of round b (0: no chain of XLONG slots or more)
+  // The rounds at the END of the layout hold the main stems: where their longest chain has this many slots the round is
+  // latency (one wave folds it serially), and the sweeps run a bandwidth pass beside them (xplan_tail_split)
   i64 nslot = 0, nchain = 0, ntrunk = 0;
   i64 b_chain[33] = {0};  // chains of round b = [b_chain[b], b_chain[b+1])
   i64 b_slot[33] = {0};   // slots  of round b = [b_slot[b],  b_slot[b+1])
@@ -76,6 +79,18 @@ struct ExactPlan {
   const void *inc_out = nullptr;      // its result buffer
   bool inc_valid = false;
 };
+#define XTAIL_LONG 16384u
+// first of the (at most two) last rounds that are latency-bound and hold at most an eighth of the slots, or -1
+inline int xplan_tail_split(const ExactPlan *p) {
+  int nb = 0, rounds[32];
+  for (int b = 0; b < 32; ++b)
+    if (p->b_chain[b + 1] > p->b_chain[b]) rounds[nb++] = b;
+  if (nb < 4) return -1;
+  const int b2 = rounds[nb - 2], b1 = rounds[nb - 1];
+  if (p->b_maxlen[b1] < XTAIL_LONG && p->b_maxlen[b2] < XTAIL_LONG) return -1;
+  if ((p->nslot - p->b_slot[b2]) * 8 > p->nslot) return -1;
+  return b2;
+}
 int pfd_xinc_prepare(pfd_raster *h);  // builds schain / dchain / hfeed / dirty (once per plan)
 void pfd_xinc_drop(pfd_raster *h);    // releases the kept sweep (incE / incR / incSeed)
 int pfd_xinc_mark(pfd_raster *h, const void *seed_dev, size_t elem);  // dirty <- chains below a changed seed; keeps the seeds

@@ -546,6 +546,11 @@ __global__ void __launch_bounds__(256) k_plan_expand(const uint4 *__restrict__ u
     }
   }
 }
+__global__ void __launch_bounds__(256) k_plan_long_lens(const u32 *__restrict__ longc, u32 nl, const u32 *__restrict__ clen,
+                                                        u32 *__restrict__ out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nl) out[i] = clen[longc[i]] & XC_LEN;
+}
 __global__ void k_plan_pick(const u32 *__restrict__ S, const u32 *__restrict__ idx, u32 k, u32 *__restrict__ out) {
   const u32 t = threadIdx.x;
   if (t < k) out[t] = S[idx[t]];
@@ -1012,6 +1017,18 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
     if (nl && hipMemcpy(lc.data(), p->longc, (size_t)nl * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return fail(PFD_EHIP);
     for (int b = 0; b <= 32; ++b)
       p->b_long[b] = (i64)(std::lower_bound(lc.begin(), lc.end(), (u32)std::min<i64>(p->b_chain[b], 0xFFFFFFFFll)) - lc.begin());
+    // the longest chain of every round (what a round costs when it is latency: see run_exact_up / run_exact_down)
+    if (nl) {
+      DevBuf ll;
+      if ((rc = ll.alloc((size_t)nl * sizeof(u32))) != PFD_OK) return fail(rc);
+      k_plan_long_lens<<<cdiv_u32(nl, 256), 256, 0, h->stream>>>(p->longc, nl, p->clen, ll.as<u32>());
+      std::vector<u32> lens(nl);
+      if (hipMemcpyAsync(lens.data(), ll.p, (size_t)nl * sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+          hipStreamSynchronize(h->stream) != hipSuccess)
+        return fail(PFD_EHIP);
+      for (int b = 0; b < 32; ++b)
+        for (i64 i = p->b_long[b]; i < p->b_long[b + 1]; ++i) p->b_maxlen[b] = std::max(p->b_maxlen[b], lens[(size_t)i]);
+    }
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(PFD_EHIP);
   p->bytes = 6 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)p->nslot / 8 + (size_t)nchain * 8;

@@ -586,13 +586,8 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
   // pass that writes the trunk cells (k_xtrunk_unscatter, bandwidth) therefore starts BESIDE them, on the handle's
   // second stream, for every chain of the earlier rounds; the chains of the last two rounds — a few per cent of the
   // slots — are scattered in chain order when they are done.
-  int bsplit = -1;
-  {
-    int nb = 0, rounds[32];
-    for (int b = 0; b < 32; ++b)
-      if (p->b_chain[b + 1] > p->b_chain[b]) rounds[nb++] = b;
-    if (nb >= 4 && (p->nslot - p->b_slot[rounds[nb - 2]]) * 8 <= p->nslot && pfd_aux_stream(h) == PFD_OK) bsplit = rounds[nb - 2];
-  }
+  int bsplit = xplan_tail_split(p);
+  if (bsplit >= 0 && pfd_aux_stream(h) != PFD_OK) bsplit = -1;
   const u32 s_split = bsplit >= 0 ? (u32)p->b_slot[bsplit] : 0xFFFFFFFFu;
   for (int b = 0; b < 32; ++b) {
     const u32 s0 = (u32)p->b_slot[b], s1 = (u32)p->b_slot[b + 1];
@@ -650,8 +645,9 @@ __global__ void __launch_bounds__(256) k_xtrunk_dpre(Op op, const u32 *__restric
 
 // The same gather for ALL rounds at once, one workgroup per TILE (see k_xtrunk_unscatter): the operation's loads
 // run in raster order, the stores into chain order fall into the few runs of slots that cross the tile.
-template <class Op>
-__global__ void __launch_bounds__(256) k_xtrunk_demit(Op op, XTileArgs a, typename Op::DElem *__restrict__ E) {
+template <class Op, bool LIMIT = false>
+__global__ void __launch_bounds__(256) k_xtrunk_demit(Op op, XTileArgs a, typename Op::DElem *__restrict__ E,
+                                                      u32 s_limit = 0xFFFFFFFFu) {  // LIMIT: only the slots below s_limit
   const u32 tid = threadIdx.x;
   const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
 #pragma unroll
@@ -671,8 +667,14 @@ __global__ void __launch_bounds__(256) k_xtrunk_demit(Op op, XTileArgs a, typena
       }
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-      if (xl_trunk((l4 >> (8 * b)) & 0xFFu)) E[a.cslot[x0 + b]] = op.dpre(x0 + (u32)b, (c4 >> (8 * b)) & 0xFFu);
+    for (int b = 0; b < 4; ++b) {
+      if (xl_trunk((l4 >> (8 * b)) & 0xFFu)) {
+        // (the element first, whatever the slot: its loads must not wait for the slot number)
+        const typename Op::DElem e = op.dpre(x0 + (u32)b, (c4 >> (8 * b)) & 0xFFu);
+        const u32 sl = a.cslot[x0 + b];
+        if (!LIMIT || sl < s_limit) E[sl] = e;
+      }
+    }
   }
 }
 
@@ -1163,13 +1165,33 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
   PFDCHK(E.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(Elem) + 64));
   PFDCHK(R.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(V) + 64));
   XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff, p->cslot, R.p};
-  if (p->nslot) {  // what the folds read from memory, for every trunk cell at once (the rounds only fold)
+  // The rounds start with the main stems and their largest tributaries (the last two rounds of the layout): a few
+  // thousand long chains, folded serially — 0.7 ms each for HAND at 30000 x 30000 with most of the chip idle.  Their
+  // operands are gathered in chain order first (a few per cent of the slots); the raster-order gather of everything
+  // else (k_xtrunk_demit: bandwidth) runs BESIDE those two rounds on the handle's second stream.
+  int bsplit = xplan_tail_split(p);
+  if (bsplit >= 0 && pfd_aux_stream(h) != PFD_OK) bsplit = -1;
+  if (bsplit >= 0) {
+    const u32 s_split = (u32)p->b_slot[bsplit];
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    k_xtrunk_demit<Op, true><<<dim3(p->ntc, p->ntr), 256, 0, h->stream2>>>(op, a, E.as<Elem>(), s_split);
+    HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+    k_xtrunk_dpre<Op><<<cdiv_u32((u32)p->nslot - s_split, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, h->ncode, s_split,
+                                                                                  (u32)p->nslot, E.as<Elem>());
+    launches += 2;
+  } else if (p->nslot) {  // what the folds read from memory, for every trunk cell at once (the rounds only fold)
     k_xtrunk_demit<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, E.as<Elem>());
     ++launches;
   }
+  bool joined = bsplit < 0;
   for (int b = 31; b >= 0; --b) {
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
     if (c1 == c0) continue;
+    if (!joined && b < bsplit) {  // (from here on the rounds need the raster-order gather)
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+      joined = true;
+    }
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
     k_xtrunk_dscan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
                                                                          p->longc + p->b_long[b], nl, p->scell, p->spost,
@@ -1177,6 +1199,7 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
                                                                          R.as<V>());
     ++launches;  // (no gather, no scatter: the rounds and the tile pass read the trunk values in chain order)
   }
+  if (!joined) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   k_xtile_down<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a);
   KCHK();
   pfd_seg_end(h, launches);
