@@ -126,7 +126,27 @@ def parse():
     ap.add_argument("--cols", type=int, default=72000)
     ap.add_argument("--ops", choices=["c3", "c5"], default=None,
                     help="only the operation lines of configs[2] (30000^2) / configs[4] (36000x72000): what the PMC passes run")
+    ap.add_argument("--rccl-loopback", action="store_true",
+                    help="REHEARSAL on a box with fewer GPUs than ranks: the self-spawned ranks preload the test-only stand-in "
+                         "for RCCL (tests/rccl_loopback) so that the world > 1 RCCL branches of the library run with ranks "
+                         "sharing a GPU; the line names the binding (config.rccl_binding = 'loopback stand-in'); no timing "
+                         "claim can rest on it")
     return ap.parse_args()
+
+
+LOOPBACK_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "rccl_loopback", "librccl_loopback.so")
+
+
+def rccl_binding():
+    """What the library's ncclXxx calls are bound to in THIS process: 'rccl', or 'loopback stand-in' when the test-only
+    interposer of tests/rccl_loopback is preloaded (it exports a marker symbol)."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).pfd_rccl_loopback_active
+        return "loopback stand-in (tests/rccl_loopback, ranks share a GPU)"
+    except (AttributeError, OSError):
+        return "rccl"
 
 
 def one_step(d8_buf, out_buf, nrow, ncol, device, profile=False):
@@ -571,7 +591,8 @@ def run_distributed(a, rank, world, local):
                                         "the boundary records + interface solve + final pass on fresh handles",
                                n_cells=n, n_valid=n_valid, n_pits=n_pits,
                                parallelism=f"{world} row blocks, 1 all-gather/pass", transport=transport,
-                               rccl_world_size=rccl_world, host_group=type(grp).__name__,
+                               rccl_world_size=rccl_world, rccl_binding=rccl_binding() if comm is not None else None,
+                               host_group=type(grp).__name__,
                                launcher="self-spawned" if os.environ.get("PFD_BENCH_SPAWNED") else "external",
                                retried_with_host_transport=bool(os.environ.get("PFD_BENCH_RETRY")),
                                devices_visible=_hip.device_count()),
@@ -713,6 +734,7 @@ def run_distributed_op(a, rank, world, local):
                                         "block's sweep plan built by the warm-up call",
                                n_cells=n, parallelism=f"{world} row blocks", transport=dr.transport,
                                rccl_world_size=dr.comm.info()["nranks"] if dr.comm is not None else None,
+                               rccl_binding=rccl_binding() if dr.comm is not None else None,
                                exchanges_per_step=n_ex, exchange_kinds=kinds, exchange_bytes_per_rank_per_step=ex_bytes,
                                iterations=iters[0], devices_visible=_hip.device_count(),
                                launcher="self-spawned" if os.environ.get("PFD_BENCH_SPAWNED") else "external"),
@@ -765,7 +787,7 @@ def free_port():
     raise RuntimeError("no free TCP port pair on 127.0.0.1")
 
 
-def rank_environments(n, n_devices, port, base_env=None):
+def rank_environments(n, n_devices, port, base_env=None, loopback=False):
     """Environment of each of the n ranks `bench.py --gpus n` starts itself: the variables a launcher would set
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), the torch-free TCP host group, dmabuf IPC for RCCL.
     LOCAL_RANK is the GPU index; with fewer GPUs than ranks (test boxes) the ranks share GPUs and the boundary
@@ -777,7 +799,10 @@ def rank_environments(n, n_devices, port, base_env=None):
                  PFD_BENCH_SPAWNED="1")
         e.setdefault("PFD_BENCH_GROUP", "tcp")
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if n_devices < n:
+        if loopback:  # (--rccl-loopback: the stand-in is interposed in front of librccl.so, the RCCL transport is forced)
+            e["LD_PRELOAD"] = LOOPBACK_SO + (":" + e["LD_PRELOAD"] if e.get("LD_PRELOAD") else "")
+            e["PFD_DIST_TRANSPORT"] = "rccl"
+        elif n_devices < n:
             e.setdefault("PFD_DIST_TRANSPORT", "host")
         envs.append(e)
     return envs
@@ -794,7 +819,10 @@ def spawn_ranks(a, argv=None, n_devices=None, timeout=3000.0, script=None, extra
     if n_devices < 1:
         raise SystemExit("bench.py: no HIP device visible")
     argv = sys.argv[1:] if argv is None else argv
-    envs = rank_environments(a.gpus, n_devices, free_port())
+    loopback = bool(getattr(a, "rccl_loopback", False))
+    if loopback and not os.path.exists(LOOPBACK_SO):
+        raise SystemExit("bench.py --rccl-loopback: build tests/rccl_loopback first (make -C tests/rccl_loopback)")
+    envs = rank_environments(a.gpus, n_devices, free_port(), loopback=loopback)
     procs = []
     for r, e in enumerate(envs):
         e.update(extra_env or {})
@@ -835,7 +863,7 @@ def spawn_with_fallback(a, spawn=spawn_ranks, first_timeout=900.0):
     import tempfile
 
     attempts = [({}, first_timeout)]
-    if not os.environ.get("PFD_DIST_TRANSPORT"):
+    if not os.environ.get("PFD_DIST_TRANSPORT") and not getattr(a, "rccl_loopback", False):
         attempts.append((dict(PFD_DIST_TRANSPORT="host", PFD_BENCH_RETRY="1"), 3000.0))
     rc = 1
     for extra, tmo in attempts:

@@ -297,7 +297,8 @@ int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtype, const vo
  *                chains below a halo seed that CHANGED are folded again (no tile pass, no pass over the raster: the
  *                cost follows the cells the changed seeds reach).  Falls back to mode 1 when there is no kept sweep
  *                of this operation into this buffer.  Results are the full sweep's, bit for bit.
- * Handles whose block has no exact-order plan (PFD_BLOCK_LEVELS) ignore the mode. */
+ * Handles whose block has no exact-order plan (PFD_BLOCK_LEVELS) ignore the mode.  With mode 1 or 2 a call whose
+ * memspace is not PFD_DEVICE returns PFD_EINVAL (the kept sweep refers to `out` by address). */
 int pfd_set_block_update(pfd_raster *h, int mode);
 int pfd_accuflux_block(pfd_raster *h, int dtype, const void *data, int by_row, int64_t nodata_i, double nodata_f,
                        int has_nodata, int direction, const void *halo_seed_host, int verify, void *out, int memspace,

@@ -74,6 +74,9 @@ struct ExactPlan {
   u32 *dchain = nullptr;  // [nchain] chain of the cell the chain's last cell drains into (0xFFFFFFFF: none)
   u32 *hfeed = nullptr;   // [2 * ncol] chain of the own cell a halo cell drains into (0xFFFFFFFF: none)
   u8 *dirty = nullptr;    // [nchain]
+  bool xinc_ready = false;    // the four maps above are built AND checked (pfd_xinc_prepare)
+  bool xinc_refused = false;  // they cannot be: a halo cell drains into a non-trunk cell of this plan
+  size_t xinc_map_bytes = 0;
   void *incE = nullptr, *incR = nullptr, *incSeed = nullptr;
   size_t inc_tag = 0, inc_bytes = 0;  // operation of the kept sweep (type hash); bytes of incE + incR + incSeed
   const void *inc_out = nullptr;      // its result buffer

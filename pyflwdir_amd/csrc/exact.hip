@@ -662,25 +662,15 @@ void pfd_xinc_drop(pfd_raster *h) {
   p->inc_valid = false;
   p->inc_out = nullptr;
 }
-int pfd_xinc_prepare(pfd_raster *h) {
-  ExactPlan *p = (ExactPlan *)h->xplan;
-  if (!p || h->xplan_state != 1 || !h->halo_raw) {
-    pfd_set_error("incremental block sweeps need the exact-order plan of a row block");
-    return PFD_EINVAL;
-  }
-  if (p->schain) return PFD_OK;
-  const size_t nsl = std::max<size_t>((size_t)p->nslot, 4), nch = std::max<size_t>((size_t)p->nchain, 1);
-  int rc;
-  if ((rc = pfd_dmalloc((void **)&p->schain, nsl * sizeof(u32))) != PFD_OK ||
-      (rc = pfd_dmalloc((void **)&p->dchain, nch * sizeof(u32))) != PFD_OK ||
-      (rc = pfd_dmalloc((void **)&p->hfeed, 2 * (size_t)h->ncol * sizeof(u32))) != PFD_OK ||
-      (rc = pfd_dmalloc((void **)&p->dirty, nch)) != PFD_OK) {
-    pfd_dfree(p->schain), pfd_dfree(p->dchain), pfd_dfree(p->hfeed), pfd_dfree(p->dirty);
-    p->schain = p->dchain = p->hfeed = nullptr, p->dirty = nullptr;
-    return rc;
-  }
-  const size_t add = nsl * 4 + nch * 5 + 2 * (size_t)h->ncol * 4;
-  p->bytes += add, h->bytes_held += add;
+// releases the static maps of the incremental sweeps (a failed or half-run prepare must not look like a finished one)
+static void xinc_free_maps(pfd_raster *h, ExactPlan *p) {
+  pfd_dfree(p->schain), pfd_dfree(p->dchain), pfd_dfree(p->hfeed), pfd_dfree(p->dirty);
+  p->schain = p->dchain = p->hfeed = nullptr, p->dirty = nullptr;
+  p->bytes -= std::min(p->bytes, p->xinc_map_bytes), h->bytes_held -= std::min(h->bytes_held, p->xinc_map_bytes);
+  p->xinc_map_bytes = 0;
+  p->xinc_ready = false;
+}
+static int xinc_build_maps(pfd_raster *h, ExactPlan *p, size_t nsl, size_t nch, u64 *odd) {
   pfd_seg_begin(h, "xinc_prepare");
   HIPCHK(hipMemsetAsync(h->ctrl, 0, sizeof(u64), h->stream));
   HIPCHK(hipMemsetAsync(p->schain, 0, nsl * sizeof(u32), h->stream));
@@ -694,13 +684,47 @@ int pfd_xinc_prepare(pfd_raster *h) {
                                                                        (u32)h->own_rows, p->hfeed, (unsigned long long *)h->ctrl);
   KCHK();
   pfd_seg_end(h, 3);
-  u64 odd = 0;
-  HIPCHK(hipMemcpyAsync(&odd, h->ctrl, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(odd, h->ctrl, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}
+int pfd_xinc_prepare(pfd_raster *h) {
+  ExactPlan *p = (ExactPlan *)h->xplan;
+  if (!p || h->xplan_state != 1 || !h->halo_raw) {
+    pfd_set_error("incremental block sweeps need the exact-order plan of a row block");
+    return PFD_EINVAL;
+  }
+  if (p->xinc_ready) return PFD_OK;  // (set only after the maps were built AND checked)
+  if (p->xinc_refused) {             // (a property of the plan: asking again builds the same maps)
+    pfd_set_error("incremental block sweeps: a halo cell drains into a cell that is not a trunk cell of the block's plan");
+    return PFD_EUNSUPPORTED;
+  }
+  xinc_free_maps(h, p);  // (whatever an earlier, failed attempt left)
+  const size_t nsl = std::max<size_t>((size_t)p->nslot, 4), nch = std::max<size_t>((size_t)p->nchain, 1);
+  int rc;
+  if ((rc = pfd_dmalloc((void **)&p->schain, nsl * sizeof(u32))) != PFD_OK ||
+      (rc = pfd_dmalloc((void **)&p->dchain, nch * sizeof(u32))) != PFD_OK ||
+      (rc = pfd_dmalloc((void **)&p->hfeed, 2 * (size_t)h->ncol * sizeof(u32))) != PFD_OK ||
+      (rc = pfd_dmalloc((void **)&p->dirty, nch)) != PFD_OK) {
+    xinc_free_maps(h, p);
+    return rc;
+  }
+  p->xinc_map_bytes = nsl * 4 + nch * 5 + 2 * (size_t)h->ncol * 4;
+  p->bytes += p->xinc_map_bytes, h->bytes_held += p->xinc_map_bytes;
+  u64 odd = 0;
+  rc = xinc_build_maps(h, p, nsl, nch, &odd);
+  if (rc != PFD_OK) {
+    (void)hipStreamSynchronize(h->stream);  // (nothing may still write the maps when they are freed)
+    xinc_free_maps(h, p);
+    return rc;
+  }
   if (odd) {
+    xinc_free_maps(h, p);
+    p->xinc_refused = true;
     pfd_set_error("internal: %llu halo cells drain into a cell that is not a trunk cell of the block's plan", (unsigned long long)odd);
     return PFD_EUNSUPPORTED;
   }
+  p->xinc_ready = true;
   return PFD_OK;
 }
 int pfd_xinc_mark(pfd_raster *h, const void *seed_dev, size_t elem) {

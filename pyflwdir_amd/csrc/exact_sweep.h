@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) k_xtrunk_scatter_inc(Op op, const u32 *__
 // an update request (pfd_set_block_update(h, 2)) can be served: the kept sweep is this operation's, into this buffer
 static inline bool xinc_applies(pfd_raster *h, const void *out_dev, size_t tag) {
   const ExactPlan *p = (const ExactPlan *)h->xplan;
-  return h->block_update == 2 && h->xplan_state == 1 && p && p->inc_valid && p->inc_tag == tag && p->inc_out == out_dev;
+  return h->block_update == 2 && h->xplan_state == 1 && p && p->xinc_ready && p->inc_valid && p->inc_tag == tag && p->inc_out == out_dev;
 }
 template <class Op>
 static int run_exact_up_inc(pfd_raster *h, const Op &op) {

@@ -1598,9 +1598,20 @@ static int down_block_run(pfd_raster *h, const Op &op0, T *out_dev, const T *see
   return PFD_OK;
 }
 
+// pfd_set_block_update modes 1 / 2 keep POINTERS into the result buffer between calls: with a host `out` that buffer is
+// OutArg's temporary, freed on return (and usually handed out again at the same address) — refused, not guessed
+static int block_update_needs_device(pfd_raster *h, int memspace, const char *what) {
+  if (h->block_update == 0 || memspace == PFD_DEVICE) return PFD_OK;
+  pfd_xinc_drop(h);
+  pfd_set_error("%s: pfd_set_block_update(%d) needs payload and result in DEVICE memory (memspace PFD_DEVICE)", what,
+                h->block_update);
+  return PFD_EINVAL;
+}
+
 template <class T>
 static int accuflux_block_t(pfd_raster *h, const void *data, bool by_row, T nodata, int has_nodata, int direction,
                             const void *seed_host, int verify, void *out, int memspace, void *brows_host, int64_t *n_bad) {
+  if (!verify) PFDCHK(block_update_needs_device(h, memspace, "pfd_accuflux_block"));
   InArg d, sd;
   if (by_row)
     PFDCHK(d.bind(data, (size_t)h->nrow * sizeof(T), PFD_HOST, h->stream));
@@ -1669,6 +1680,7 @@ extern "C" int pfd_strahler_block(pfd_raster *h, const uint8_t *mask, const uint
     pfd_set_error("pfd_strahler_block: bad arguments");
     return PFD_EINVAL;
   }
+  if (!verify) PFDCHK(block_update_needs_device(h, memspace, "pfd_strahler_block"));
   InArg m, sd;
   PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
   PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol, h->block_seed_space, h->stream));

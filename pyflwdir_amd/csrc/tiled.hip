@@ -1445,7 +1445,7 @@ int TiledRun::level4_down(i64 *launches) {
     // final synchronisation; a miss redoes the pass with more rounds.
     int batch = 5 + extra_rounds;
     for (u32 span = 1; span < (ntr + ntc) / (SG * HG) + 2; span <<= 1) ++batch;  // ~log2 of a path in hypertiles
-    if (const char *e = getenv("PFD_TEST_ROUNDS4")) batch = atoi(e) + extra_rounds;  // (tests: force a miss)
+    if (const char *e = pfd_knob("PFD_TEST_ROUNDS4")) batch = atoi(e) + extra_rounds;  // (tests: force a miss)
     bool done4 = false;
     PFDCHK(pfd_doubling_rounds(h, T4, J4, cap4, batch, false, &done4, &rounds4, launches, h->ctrl + T_NHYPER, true));
     J4fin = J4[0];

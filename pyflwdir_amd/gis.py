@@ -19,7 +19,7 @@ AREA_FACTORS = {"m2": 1.0, "ha": 1e4, "km2": 1e6, "cell": 1}  # reference gis_ut
 IDENTITY = Affine(1.0, 0.0, 0.0, 0.0, -1.0, 0.0)  # N->S orientation, reference gis_utils.py:13
 
 __all__ = ["AREA_FACTORS", "IDENTITY", "affine_to_coords", "cellarea", "area_grid", "area_rows",
-           "xy", "rowcol", "idxs_to_coords", "coords_to_idxs"]
+           "reggrid_area", "reggrid_dx", "reggrid_dy", "xy", "rowcol", "idxs_to_coords", "coords_to_idxs"]
 
 
 def _unit_factor(unit):
@@ -70,6 +70,36 @@ def area_rows(transform, shape, latlon=False, unit="m2"):
     # (the reference multiplies the float64 column by a float32 matrix of ones before dividing: kept, it is exact)
     xres, yres = np.abs(np.mean(np.diff(lon))), np.abs(np.mean(np.diff(lat)))
     return cellarea(lat, xres, yres) * np.ones(lat.size, dtype=np.float32) / factor
+
+
+def _mean_step(axis):
+    return np.abs(np.mean(np.diff(axis)))
+
+
+def _per_row_grid(column, ncol, ones_dtype):
+    """A per-row quantity as a full grid (the reference's public reggrid_* helpers return grids: column times a matrix
+    of ones of the given dtype — kept as a product so that the result dtype follows numpy's promotion as it does there)."""
+    column = np.asarray(column)
+    return column[:, None] * np.ones((column.size, ncol), dtype=ones_dtype)
+
+
+def reggrid_area(lats, lons):
+    """Cell areas [m2] of a regular lat/lon grid with centres ``lats`` / ``lons`` (reference gis_utils.py:379-385:
+    float64 column times float32 ones).  The hot path uses ``area_rows`` and never builds this grid."""
+    lats, lons = np.asarray(lats), np.asarray(lons)
+    return _per_row_grid(cellarea(lats, _mean_step(lons), _mean_step(lats)), lons.size, np.float32)
+
+
+def reggrid_dx(lats, lons):
+    """Cell widths [m] of a regular lat/lon grid (reference gis_utils.py:363-368)."""
+    lats, lons = np.asarray(lats), np.asarray(lons)
+    return _per_row_grid(degree_metres_x(lats) * _mean_step(lons), lons.size, lats.dtype)
+
+
+def reggrid_dy(lats, lons):
+    """Cell heights [m] of a regular lat/lon grid (reference gis_utils.py:371-376)."""
+    lats, lons = np.asarray(lats), np.asarray(lons)
+    return _per_row_grid(degree_metres_y(lats) * _mean_step(lats), lons.size, lats.dtype)
 
 
 def degree_metres_y(lat):

@@ -27,6 +27,8 @@ def test_rank_environments():
     assert all(e["PFD_DIST_TRANSPORT"] == "host" for e in shared)  # ranks sharing a GPU: host transport
     kept = b.rank_environments(2, 1, 29555, base_env={"PFD_DIST_TRANSPORT": "rccl", "PFD_BENCH_GROUP": "torch"})
     assert all(e["PFD_DIST_TRANSPORT"] == "rccl" and e["PFD_BENCH_GROUP"] == "torch" for e in kept)
+    lb = b.rank_environments(2, 1, 29555, base_env={"LD_PRELOAD": "/x.so"}, loopback=True)  # --rccl-loopback rehearsal
+    assert all(e["PFD_DIST_TRANSPORT"] == "rccl" and e["LD_PRELOAD"] == b.LOOPBACK_SO + ":/x.so" for e in lb)
 
 
 def test_free_port_pair():

@@ -575,3 +575,36 @@ def test_block_updates_fold_only_below_changed_seeds(gpu_lib, oracle, kind, dtyp
         blk.close(close_handle=False)
     finally:
         h.close()
+
+
+@pytest.mark.gpu
+def test_block_update_modes_refuse_a_host_result(gpu_lib, oracle):
+    """pfd_set_block_update modes 1 / 2 keep pointers into `out` between calls: a HOST `out` is a temporary device buffer
+    that is gone on return — refused with a message, the default mode takes it, and a refused call leaves
+    nothing behind that a later device-resident update could mistake for a kept sweep."""
+    from pyflwdir_amd import _hip, dist
+
+    O = oracle
+    nrow, ncol, nb = 600, 500, 2
+    d8 = O.synth_d8(nrow, ncol, seed=5, tilt=100000, white=2, nodata_pct=5)
+    data = (np.random.default_rng(1).random(d8.shape) + 0.01).astype(np.float32)
+    a, e = dist.block_slice(nrow, nb, 1)
+    r0, r1 = dist.block_rows(nrow, nb)[1]
+    h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, halo=dist.halo_of(1, nb))
+    try:
+        seed = np.zeros(2 * ncol, np.float32)
+        out0 = np.empty((e - a, ncol), np.float32)
+        h.accuflux_block(data[a:e], _hip.PFD_F32, seed, out0, nodata_f=-9999.0, has_nodata=1)
+        for mode in (1, 2):
+            h.set_block_update(mode)
+            out = np.empty((e - a, ncol), np.float32)
+            with pytest.raises(Exception, match="DEVICE memory"):
+                h.accuflux_block(data[a:e], _hip.PFD_F32, seed, out, nodata_f=-9999.0, has_nodata=1)
+            with pytest.raises(Exception, match="DEVICE memory"):
+                h.strahler_block(None, np.zeros(2 * ncol, np.uint8), np.empty((e - a, ncol), np.uint8))
+        h.set_block_update(0)
+        out = np.empty((e - a, ncol), np.float32)
+        h.accuflux_block(data[a:e], _hip.PFD_F32, seed, out, nodata_f=-9999.0, has_nodata=1)
+        assert np.array_equal(out.view(np.uint32), out0.view(np.uint32))
+    finally:
+        h.close()

@@ -203,3 +203,22 @@ def test_bench_spread_rasters_are_valid_and_acyclic(oracle):
     s = bench.serpentine(64, 64)
     idxs_ds, idxs_pit, _ = oracle.from_array(s)
     assert idxs_pit.size == 1 and oracle.rank(idxs_ds)[0].max() == 4095  # one 4096-cell path per tile
+
+
+def test_reggrid_helpers_match_the_reference_expressions():
+    """reggrid_area / reggrid_dx / reggrid_dy (public in the reference's gis_utils.__all__): a per-row column times a
+    matrix of ones; area_grid on a lat/lon transform is reggrid_area / factor; dtypes follow numpy's promotion."""
+    from pyflwdir_amd._affine import get_affine
+
+    Affine = get_affine()
+    tr = Affine(0.25, 0.0, 5.0, 0.0, -0.25, 52.0)
+    shape = (9, 6)
+    lon, lat = gis.affine_to_coords(tr, shape)
+    a = gis.reggrid_area(lat, lon)
+    assert a.shape == shape and a.dtype == np.float64
+    assert np.array_equal(a / 1e6, gis.area_grid(tr, shape, latlon=True, unit="km2"))
+    assert np.array_equal(a[:, 0], gis.cellarea(lat, 0.25, 0.25)) and np.all(a == a[:, :1])
+    dx, dy = gis.reggrid_dx(lat, lon), gis.reggrid_dy(lat, lon)
+    assert dx.shape == shape and dy.shape == shape and dx.dtype == lat.dtype
+    assert np.array_equal(dx[:, 3], gis.degree_metres_x(lat) * 0.25) and np.array_equal(dy[:, 0], gis.degree_metres_y(lat) * 0.25)
+    assert {"reggrid_area", "reggrid_dx", "reggrid_dy"} <= set(gis.__all__)
