@@ -288,9 +288,42 @@ __global__ void __launch_bounds__(256) k_iface_check(const u32 *__restrict__ J, 
   if (e < n && !(J[e] & XDONE)) ctrl[T_XACTIVE] = 1;  // (rare: only while the batch was too short)
 }
 
-// solve the interface forest from the gathered records (on the handle's device/stream) and
-// leave the inflow of block `blk` in run.brow_inflow
-static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u32 blk) {
+// The interface forest by CHASING (the default): a path through the blocks meets a handful of interface cells, and only
+// the cells that carry flow (L > 0) start one — each walks its path (the successor of a node is one lookup in the
+// gathered records, no pointer array) and adds its L to the nodes this rank needs: the halo cells next to its own two
+// boundary rows.  One launch instead of build + fill + log2(2 N) doubling rounds + check + host look + inflow
+// (0.27 ms + two host round trips for 8 blocks of 90000 columns).  A path longer than `maxhops` (a river meandering
+// along a block edge; a cycle through several blocks) raises MISS_IFACE: the pass is redone with the doubling rounds.
+__device__ __forceinline__ u32 iface_next(const u32 *__restrict__ rec, u32 nblocks, u32 ncol, u32 node) {
+  const u32 col = node % ncol, bs = node / ncol, side = bs & 1u;
+  const int owner = (int)(bs >> 1) + (side ? 1 : -1);  // the block this halo cell belongs to
+  if (owner < 0 || owner >= (int)nblocks) return NONE32;
+  const u32 s = rec[(size_t)owner * 4 * ncol + (2 + (1 - side)) * ncol + col];  // where flow entering there leaves `owner`
+  if (s == NONE32) return NONE32;
+  return ((u32)owner * 2 + ((s & ENC_SIDE1) ? 1u : 0u)) * ncol + (s & ENC_COL);
+}
+__global__ void __launch_bounds__(256) k_iface_chase(const u32 *__restrict__ rec, u32 nblocks, u32 ncol, u32 blk, u32 maxhops,
+                                                     u32 *__restrict__ brow_inflow, u64 *__restrict__ ctrl) {
+  const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= nblocks * 2 * ncol) return;
+  const u32 bs0 = id / ncol;
+  const u32 L = rec[(size_t)(bs0 >> 1) * 4 * ncol + (bs0 & 1u) * ncol + id % ncol];  // flow leaving the block through this cell
+  if (!L) return;
+  // F of the bottom halo of block blk-1 enters the first own row, F of the top halo of block blk+1 the last
+  const u32 want0 = blk ? (blk - 1) * 2 + 1 : NONE32, want1 = (blk + 1) * 2;
+  u32 node = id;
+  for (u32 hop = 0; hop < maxhops; ++hop) {
+    const u32 bs = node / ncol;
+    if (bs == want0) atomicAdd(&brow_inflow[node % ncol], L);
+    else if (bs == want1 && blk + 1 < nblocks) atomicAdd(&brow_inflow[ncol + node % ncol], L);
+    node = iface_next(rec, nblocks, ncol, node);
+    if (node == NONE32) return;
+  }
+  atomicOr((unsigned long long *)&ctrl[T_MISS], (unsigned long long)MISS_IFACE);
+}
+
+// the same forest by doubling rounds (after a chase ran out of hops); synchronises to see whether the rounds sufficed
+static int interface_solve_doubling(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u32 blk) {
   pfd_raster *h = run.h;
   const u32 ncol = (u32)h->ncol;
   const u32 nn = nblocks * 2 * ncol;
@@ -332,6 +365,39 @@ static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u3
   KCHK();
   pfd_seg_end(h, launches + 1);
   if (!done) run.coarse_done = false;  // a cycle through several blocks
+  return PFD_OK;
+}
+
+// flow entering the own boundary rows from the gathered records (on the handle's device / stream), left in
+// run.brow_inflow (zero since the pass began: k_pass_clear).  No host round trip unless the doubling form is asked for.
+static int interface_solve(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u32 blk) {
+  if (run.iface_doubling) return interface_solve_doubling(run, allrec_dev, nblocks, blk);
+  pfd_raster *h = run.h;
+  const u32 ncol = (u32)h->ncol;
+  u32 maxhops = 4u * nblocks + 32u;
+  if (const char *e = pfd_knob("PFD_TEST_IFACE_HOPS")) maxhops = (u32)atoi(e);  // (tests: force the doubling form)
+  pfd_seg_begin(h, "interface_solve");
+  k_iface_chase<<<cdiv_u32(nblocks * 2 * ncol, 256), 256, 0, h->stream>>>(allrec_dev, nblocks, ncol, blk, maxhops, run.brow_inflow,
+                                                                         h->ctrl);
+  KCHK();
+  pfd_seg_end(h, 1);
+  return PFD_OK;
+}
+// after a pass's final synchronisation: did the chase run out of hops?  (then the pass is redone with doubling rounds)
+static inline bool iface_missed(const u64 *c0) { return (c0[T_MISS] & MISS_IFACE) != 0; }
+
+// interface solve + phase B of a block whose phase A has run and whose records everybody holds.  When the chase ran
+// out of hops the whole pass of THIS block is redone with the doubling rounds (phase A is deterministic: the records
+// the other blocks hold stay valid).
+static int finish_block(TiledRun &run, const u32 *allrec_dev, u32 nblocks, u32 blk, int *complete) {
+  if (nblocks > 1) PFDCHK(interface_solve(run, allrec_dev, nblocks, blk));
+  PFDCHK(run.phase_b(complete));
+  if (nblocks > 1 && (run.last_miss & MISS_IFACE) && !run.iface_doubling) {
+    run.iface_doubling = true;
+    PFDCHK(run.phase_a_checked());
+    PFDCHK(interface_solve(run, allrec_dev, nblocks, blk));
+    PFDCHK(run.phase_b(complete));
+  }
   return PFD_OK;
 }
 
@@ -390,15 +456,14 @@ extern "C" int pfd_upstream_area_cell_blocks(pfd_raster **hs, int nblocks, int32
   for (int b = 0; b < nblocks; ++b) {  // "all-gather" = every block gets all records; then phase B
     pfd_raster *h = hs[b];
     PFDCHK(pfd_check_handle_lazy(h));
+    DevBuf allrec;
     if (nblocks > 1) {
-      DevBuf allrec;
       PFDCHK(allrec.alloc(allrec_host.size() * sizeof(u32)));
       HIPCHK(hipMemcpyAsync(allrec.p, allrec_host.data(), allrec_host.size() * sizeof(u32), hipMemcpyHostToDevice,
                             h->stream));
-      PFDCHK(interface_solve(runs[b], allrec.as<u32>(), (u32)nblocks, (u32)b));
     }
     int complete = 0;
-    PFDCHK(runs[b].phase_b(&complete));
+    PFDCHK(finish_block(runs[b], allrec.as<u32>(), (u32)nblocks, (u32)b, &complete));
     all_complete &= complete;
     PFDCHK(o[b].finish(h->stream));
   }
@@ -444,18 +509,31 @@ extern "C" int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int mem
     pfd_set_error("pfd_upstream_area_cell_begin: the block is too large for the tiled engine");
     rc = PFD_EUNSUPPORTED;
   }
-  if (rc == PFD_OK) rc = p->run.phase_a_checked();
+  DevBuf rec;
+  if (rc == PFD_OK) rc = rec.alloc(recw * sizeof(u32));
+  // phase A, the record and its control words leave in ONE synchronisation; phase A is redone when it fell short
+  // (flat level 3 after an overflow of a hypertile's id range, more level-4 rounds)
+  for (int tries = 0; rc == PFD_OK; ++tries) {
+    rc = p->run.phase_a();
+    if (rc != PFD_OK) break;
+    k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(p->run.haloL, p->run.brow_sink, ncol, rec.as<u32>());
+    u64 c8[8];
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(record_host, rec.p, recw * sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(c8, h->ctrl + 8, sizeof(c8), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {
+      pfd_set_error("pfd_upstream_area_cell_begin: phase A or the download of the boundary record failed");
+      rc = PFD_EHIP;
+      break;
+    }
+    if (!p->run.phase_a_needs_redo(c8, tries)) break;
+  }
   if (rc != PFD_OK) {
+    (void)hipStreamSynchronize(h->stream);
     delete p;
     return rc;
   }
   h->pending = p;
-  DevBuf rec;
-  PFDCHK(rec.alloc(recw * sizeof(u32)));
-  k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(p->run.haloL, p->run.brow_sink, ncol, rec.as<u32>());
-  KCHK();
-  HIPCHK(hipMemcpyAsync(record_host, rec.p, recw * sizeof(u32), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
   return PFD_OK;
 }
 
@@ -469,8 +547,8 @@ extern "C" int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_
   }
   int rc = PFD_OK;
   const size_t recw = 4 * (size_t)h->ncol;
+  DevBuf allrec;
   if (nblocks > 1) {
-    DevBuf allrec;
     rc = allrec.alloc((size_t)nblocks * recw * sizeof(u32));
     if (rc == PFD_OK &&
         hipMemcpyAsync(allrec.p, all_records_host, (size_t)nblocks * recw * sizeof(u32), hipMemcpyHostToDevice,
@@ -478,9 +556,8 @@ extern "C" int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_
       pfd_set_error("pfd_upstream_area_cell_finish: upload of the boundary records failed");
       rc = PFD_EHIP;
     }
-    if (rc == PFD_OK) rc = interface_solve(p->run, allrec.as<u32>(), (u32)nblocks, (u32)block);
   }
-  if (rc == PFD_OK) rc = p->run.phase_b(complete);
+  if (rc == PFD_OK) rc = finish_block(p->run, allrec.as<u32>(), (u32)nblocks, (u32)block, complete);
   if (rc == PFD_OK) rc = p->out.finish(h->stream);
   delete p;
   h->pending = nullptr;
@@ -552,42 +629,70 @@ extern "C" int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_
   }
   // From here on every rank reaches every collective whatever happens locally: a local failure (set-up included)
   // sends a zero record and travels with the final agreement.
+  //
+  // One pass = phase A, all-gather, interface solve, phase B, agreement — issued on the stream WITHOUT a host round
+  // trip in between (round 5; before: one after phase A, one inside the interface solve, one after phase B, one for
+  // the agreement).  What a host look used to decide is decided on the device: a stage that fell short (a hypertile
+  // overflowed its id range, level 4 or the interface chase ran out of their budgets) raises a sticky bit, the pass
+  // runs on with whatever it has, and its verdict (2 fine / 1 redo / 0 failed) goes through the agreement all-reduce
+  // (min): on "redo" EVERY rank repeats the pass — the collectives stay aligned — with the remedy applied where the
+  // miss happened.  Misses are rare (none on the benchmark rasters); the price of one is a second pass.
   u32 *rec = comm->rec_dev, *allrec = comm->allrec_dev;
-  if (rc == PFD_OK)
-    rc = run.phase_a_checked();
-  if (world > 1) {
-    pfd_seg_begin(h, "allgather");
-    if (rc == PFD_OK) {
-      k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(run.haloL, run.brow_sink, ncol, rec);
-    } else {
-      (void)hipMemsetAsync(rec, 0, recw * sizeof(u32), h->stream);
+  int ok_all = 0, complete = 0;
+  for (int tries = 0;; ++tries) {
+    if (rc == PFD_OK) rc = run.phase_a();
+    if (world > 1) {
+      if (rc == PFD_OK) rc = run.stage_verdict_a();
+      pfd_seg_begin(h, "allgather");
+      if (rc == PFD_OK) {
+        k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(run.haloL, run.brow_sink, ncol, rec);
+      } else {
+        (void)hipMemsetAsync(rec, 0, recw * sizeof(u32), h->stream);
+      }
+      const ncclResult_t r1 = ncclAllGather(rec, allrec, recw, ncclUint32, comm->comm, h->stream);
+      pfd_seg_end(h, 2);
+      if (r1 != ncclSuccess && rc == PFD_OK) {
+        pfd_set_error("ncclAllGather failed: %s", ncclGetErrorString(r1));
+        rc = PFD_ECOMM;
+      }
+      if (rc == PFD_OK) rc = interface_solve(run, allrec, (u32)world, (u32)rank);
     }
-    const ncclResult_t r1 = ncclAllGather(rec, allrec, recw, ncclUint32, comm->comm, h->stream);
-    pfd_seg_end(h, 2);
-    if (r1 != ncclSuccess && rc == PFD_OK) {
-      pfd_set_error("ncclAllGather failed: %s", ncclGetErrorString(r1));
-      rc = PFD_ECOMM;
-    }
-    if (rc == PFD_OK) rc = interface_solve(run, allrec, (u32)world, (u32)rank);
-  }
-  int complete = 0;
-  if (rc == PFD_OK) rc = run.phase_b(&complete);
-  if (rc == PFD_OK) rc = o.finish(h->stream);
-  // every rank must agree on success: a cycle anywhere invalidates downstream blocks as well
-  int ok_local = (rc == PFD_OK && complete) ? 1 : 0, ok_all = ok_local;
-  if (world > 1) {
+    if (rc == PFD_OK) rc = run.phase_b_issue();
+    u64 c0[48] = {0};
+    int verdict = 0;
     const char *what = nullptr;
-    if (hipMemcpyAsync(flag, &ok_local, sizeof(int), hipMemcpyHostToDevice, h->stream) != hipSuccess) what = "upload of the agreement flag";
-    const ncclResult_t r2 = ncclAllReduce(flag, flag + 8, 1, ncclInt32, ncclMin, comm->comm, h->stream);
-    if (r2 != ncclSuccess) what = "ncclAllReduce";
-    if (hipMemcpyAsync(&ok_all, flag + 8, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-        hipStreamSynchronize(h->stream) != hipSuccess)
-      what = "download of the agreement flag";
+    if (world > 1) {
+      // every rank must agree: a cycle anywhere invalidates downstream blocks as well, a redo anywhere is a redo everywhere
+      if (rc == PFD_OK) rc = run.block_verdict(flag, true);
+      if (rc != PFD_OK && hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) what = "clearing the agreement flag";
+      const ncclResult_t r2 = ncclAllReduce(flag, flag + 8, 1, ncclInt32, ncclMin, comm->comm, h->stream);
+      if (r2 != ncclSuccess) what = "ncclAllReduce";
+      if (hipMemcpyAsync(&verdict, flag + 8, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess) what = "download of the agreement flag";
+    }
+    if (hipMemcpyAsync(c0, h->ctrl, sizeof(c0), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)  // the pass's ONE synchronisation
+      what = "download of the control words";
     if (what && rc == PFD_OK) {
       pfd_set_error("pfd_upstream_area_cell_dist: %s failed", what);
       rc = PFD_ECOMM;
     }
+    if (rc == PFD_OK) rc = run.phase_b_collect(c0, &complete);  // (adopts a deferred handle's counts; bad D8 codes surface here)
+    bool redo;
+    if (world > 1) {
+      redo = !what && verdict == 1 && tries < 3;  // (the same on every rank: the all-reduce's result and the try count)
+      ok_all = !what && verdict == 2;
+    } else {
+      redo = rc == PFD_OK && (run.overflowed || run.short_of_rounds) && tries < 3;
+      ok_all = rc == PFD_OK && complete;
+    }
+    if (!redo) break;
+    if (rc == PFD_OK) {  // the remedy, where the miss happened (a rank without a miss repeats its pass unchanged)
+      if (run.overflowed || (c0[T_MISS] & MISS_OVERFLOW)) run.force_flat = true;
+      else if (run.short_of_rounds || (c0[T_MISS] & MISS_ROUNDS4)) run.extra_rounds += 8;
+      if (c0[T_MISS] & MISS_IFACE) run.iface_doubling = true;
+    }
   }
+  if (rc == PFD_OK) rc = o.finish(h->stream);
   if (rc != PFD_OK) return rc;  // the local failure (its message is already set)
   if (!ok_all) {
     pfd_set_error("a row block failed or the raster holds cells that never reach a pit (cycles); the multi-GPU "

@@ -27,7 +27,10 @@
 #define ENC_COL 0x3FFFFFFFu
 
 // ctrl slots (u64): 8..10 live for a whole pass, 12..14 are reset at the start of every exit-graph solve
-enum { T_UNSAT = 8, T_SLIVE = 9, T_OVERFLOW = 10, T_XACTIVE = 12, T_NSUPER = 13, T_NHYPER = 14 };  // ctrl slots (u64)
+enum { T_UNSAT = 8, T_SLIVE = 9, T_OVERFLOW = 10, T_XACTIVE = 12, T_NSUPER = 13, T_NHYPER = 14, T_MISS = 15 };  // ctrl slots (u64)
+// T_MISS: sticky "an earlier stage of this pass fell short" bits of a pass that runs without host round trips between its
+// stages (row blocks, dist.hip): the stage's own word (T_OVERFLOW, T_XACTIVE) is reused by the next stage
+enum { MISS_OVERFLOW = 1, MISS_ROUNDS4 = 2, MISS_IFACE = 4 };
 
 // slot numbering: [supertile][tile within supertile][perimeter slot] so that the exits of one
 // 8x8-tile supertile are 16384 consecutive ids (the level-2 solve keeps them in LDS)
@@ -348,6 +351,19 @@ struct TiledRun {
   int phase_a_checked();
   int phase_a_check();
   int phase_b(int *complete);
+  // phase_b in two halves: everything up to the final tile pass issued on the stream; the verdict from the pass's
+  // control words (48 u64, copied by the caller behind whatever else it wants to see at the same synchronisation)
+  int phase_b_issue();
+  int phase_b_collect(const u64 *c0, int *complete);
+  // stream-ordered stage checks of a pass without host round trips: phase A's overflow / level-4 budget folded into
+  // ctrl[T_MISS]; the whole pass folded into one word (2 = fine, 1 = redo the pass, 0 = failed) for an agreement
+  int stage_verdict_a();
+  int block_verdict(int *flag_dev, bool host_ok);
+  bool iface_doubling = false;  // the interface forest by doubling rounds (after a chase ran out of hops)
+  u64 last_miss = 0;            // ctrl[T_MISS] of the pass phase_b_collect last looked at
+  // phase A's control words 8..15 (copied by the caller): does phase A have to run again (flat level 3 after an
+  // overflow, more level-4 rounds after a short budget)?  Adjusts the run's settings when it does.
+  bool phase_a_needs_redo(const u64 *c8, int tries);
 };
 
 int pfd_doubling_rounds(pfd_raster *h, u32 *T[3], u32 *J[2], u32 n, int first_batch, bool check, bool *done,

@@ -1294,6 +1294,59 @@ __global__ void __launch_bounds__(256) k_brow_scatter(const u32 *__restrict__ br
   if (v && e != NONE32 && !(e & ENC_SINK)) atomicAdd(&start[e], v);
 }
 
+// same, and the super-exit / hyper-exit start values of the second solve (k_brow_delta) in one launch
+__global__ void __launch_bounds__(256) k_brow_scatter_delta(const u32 *__restrict__ brow_first, const u32 *__restrict__ brow_inflow,
+                                                            u32 ncol, u32 *__restrict__ start, const u64 *__restrict__ xmask,
+                                                            const uint16_t *__restrict__ xcb, const uint16_t *__restrict__ R2L,
+                                                            const u32 *__restrict__ sxidL, u32 *__restrict__ T3,
+                                                            const u32 *__restrict__ R3, const u32 *__restrict__ hx_id,
+                                                            u32 *__restrict__ T4start) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * ncol) return;
+  const u32 v = brow_inflow[t], e = brow_first[t];
+  if (!v || e == NONE32 || (e & ENC_SINK)) return;
+  atomicAdd(&start[e], v);
+  const u32 b = e & ~(u32)(SSL - 1);
+  const u32 id = sxidL[b + R2L[b + xl_index(xmask, xcb, e)]];  // the super-exit the path leaves the supertile through
+  if (id == NONE32) return;
+  atomicAdd(&T3[id], v);
+  const u32 m = hx_id[R3[id]];  // ... and the hyper-exit it leaves the hypertile through
+  if (m != NONE32) atomicAdd(&T4start[m], v);
+}
+// level 4 starts again: T4 <- saved start values (+ what k_brow_scatter_delta added), xin3 <- 0, round mark <- 0
+__global__ void __launch_bounds__(256) k_l4_restart(const u32 *__restrict__ T4saved, u32 *__restrict__ T4, u32 n4, u32 *__restrict__ xin3,
+                                                    u32 n3, u64 *__restrict__ ctrl) {
+  const u32 i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (u32 i = i0; i < n4; i += stride) T4[i] = T4saved[i];
+  for (u32 i = i0; i < n3; i += stride) xin3[i] = 0;
+  if (i0 == 0) ctrl[T_XACTIVE] = 0;
+}
+// every clear a pass starts with, in one launch (eight memsets cost eight host calls and eight kernel boundaries):
+// control words (all 64, or 8..63 when the handle's counters 0..7 are live), the five boundary arrays of a row block
+// (brow_first / brow_sink = NONE, haloA / haloL / brow_inflow = 0) and the exit bitmasks
+__global__ void __launch_bounds__(256) k_pass_clear(u64 *__restrict__ ctrl, u32 ctrl_from, u32 *__restrict__ bnd, u32 nb,
+                                                    uint4 *__restrict__ xmask16, u32 n16) {
+  const u32 i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (i0 < 64u && i0 >= ctrl_from) ctrl[i0] = 0;
+  for (u32 i = i0; i < 5u * nb; i += stride) {
+    const u32 reg = i / nb;  // brow_first | haloA | haloL | brow_sink | brow_inflow
+    bnd[i] = (reg == 0u || reg == 3u) ? NONE32 : 0u;
+  }
+  for (u32 i = i0; i < n16; i += stride) xmask16[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+// stage checks of a pass without host round trips (see T_MISS)
+__global__ void k_stage_verdict_a(u64 *ctrl, u32 hmode, u32 rounds4) {
+  u64 m = 0;
+  if (ctrl[T_OVERFLOW]) m |= MISS_OVERFLOW;
+  if (hmode && rounds4 && ctrl[T_XACTIVE] >= (u64)rounds4) m |= MISS_ROUNDS4;
+  if (m) ctrl[T_MISS] |= m;
+}
+__global__ void k_block_verdict(const u64 *ctrl, u32 hmode, u32 rounds4, u32 host_ok, int *flag) {
+  const bool redo = ctrl[T_OVERFLOW] != 0 || ctrl[T_MISS] != 0 || (hmode && rounds4 && ctrl[T_XACTIVE] >= (u64)rounds4);
+  const bool fine = host_ok && ctrl[T_SLIVE] == 0 && ctrl[T_UNSAT] == 0 && ctrl[2] == 0;  // (ctrl[2]: bad D8 codes)
+  *flag = redo ? 1 : (fine ? 2 : 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------------
@@ -1347,7 +1400,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   sa.hcnt = hcntbuf.as<u32>(), sa.ntr = ntr, sa.ntc = ntc, sa.hcap = HCAP, sa.scap = SCAP;
   PFDCHK(soverbuf.alloc((size_t)nst));
   sa.sover = soverbuf.as<u8>();
-  PFDCHK(xmaskbuf.alloc(nslots / 64 * sizeof(u64) + 8));  // (+ the count of flagged supertiles: one memset clears both)
+  PFDCHK(xmaskbuf.alloc(nslots / 64 * sizeof(u64) + 8 + 16));  // (+ the count of flagged supertiles: one clear for both, in 16-byte stores)
   PFDCHK(xlbuf.alloc(2 * nslots * sizeof(uint16_t)));
   PFDCHK(scountbuf.alloc((size_t)nst * sizeof(u32)));
   PFDCHK(xcbbuf.alloc(nslots / 64 * sizeof(uint16_t)));
@@ -1463,34 +1516,18 @@ int TiledRun::level4_down(i64 *launches) {
 // not solved upwards again — the inflow of every boundary-row cell is added to the start value of the super-exit
 // its path leaves its supertile through (T3) and of the hyper-exit that path leaves its hypertile through (T4), by
 // O(1) lookups; then level 4 runs again and the totals come down as usual.
-__global__ void __launch_bounds__(256) k_brow_delta(const u32 *__restrict__ brow_first, const u32 *__restrict__ brow_inflow,
-                                                    u32 ncol, const u64 *__restrict__ xmask, const uint16_t *__restrict__ xcb,
-                                                    const uint16_t *__restrict__ R2L, const u32 *__restrict__ sxidL,
-                                                    u32 *__restrict__ T3, const u32 *__restrict__ R3,
-                                                    const u32 *__restrict__ hx_id, u32 *__restrict__ T4start) {
-  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 2 * ncol) return;
-  const u32 v = brow_inflow[t], e = brow_first[t];
-  if (!v || e == NONE32 || (e & ENC_SINK)) return;
-  const u32 b = e & ~(u32)(SSL - 1);
-  const u32 id = sxidL[b + R2L[b + xl_index(xmask, xcb, e)]];  // the super-exit the path leaves the supertile through
-  if (id == NONE32) return;
-  atomicAdd(&T3[id], v);
-  const u32 m = hx_id[R3[id]];  // ... and the hyper-exit it leaves the hypertile through
-  if (m != NONE32) atomicAdd(&T4start[m], v);
-}
 int TiledRun::resolve_with_inflow(i64 *launches) {
   edge_down_now = false;
   sa.edge_nstr = 0;
   sa.xT = xT;
   const size_t nb = 2 * (size_t)h->ncol;
   u32 *y = l4.as<u32>();
-  k_brow_delta<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, sa.xmask, sa.xcb, R2L, sxidL, Tc,
-                                                        R3, hx_id, y + 6 * n4cap);
-  HIPCHK(hipMemcpyAsync(y + n4cap, y + 6 * n4cap, n4cap * sizeof(u32), hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemsetAsync(xin3, 0, (size_t)nht * HCAP * sizeof(u32), h->stream));
-  HIPCHK(hipMemsetAsync(h->ctrl + T_XACTIVE, 0, sizeof(u64), h->stream));
-  *launches += 4;
+  // (k_brow_scatter + k_brow_delta in one launch; the copy of the level-4 start values and the two clears in another)
+  k_brow_scatter_delta<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, xT, sa.xmask, sa.xcb, R2L,
+                                                                sxidL, Tc, R3, hx_id, y + 6 * n4cap);
+  const u32 n3 = (u32)((size_t)nht * HCAP), n4 = (u32)n4cap;
+  k_l4_restart<<<std::min(cdiv_u32(std::max(n3, n4), 256), 2048u), 256, 0, h->stream>>>(y + 6 * n4cap, y + n4cap, n4, xin3, n3, h->ctrl);
+  *launches += 2;
   PFDCHK(level4_down(launches));
   k_super<true><<<nst, SNT, 0, h->stream>>>(sa);
   k_super_flagged<true><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);
@@ -1544,19 +1581,18 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
 int TiledRun::phase_a() {
   coarse_done = true;
   const size_t nb = 2 * (size_t)h->ncol;
-  // (a deferred handle has never run a kernel: its counters, C_BAD among them, still hold whatever the block held)
-  if (!h->normalised) HIPCHK(hipMemsetAsync(h->ctrl, 0, 8 * sizeof(u64), h->stream));
-  HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 56 * sizeof(u64), h->stream));
-  // (no slot array needs clearing: every tile writes its 256 slots, slots of tiles beyond the
-  //  raster edge are never read)
-  if (is_block) {  // brow_first / brow_sink = NONE, haloA / haloL = 0
-    HIPCHK(hipMemsetAsync(brow_first, 0xFF, nb * sizeof(u32), h->stream));
-    HIPCHK(hipMemsetAsync(haloA, 0, 2 * nb * sizeof(u32), h->stream));
-    HIPCHK(hipMemsetAsync(brow_sink, 0xFF, nb * sizeof(u32), h->stream));
+  // One launch clears what the pass starts from: the control words (a deferred handle has never run a kernel: its
+  // counters 0..7, C_BAD among them, still hold whatever the block held — cleared too), the boundary arrays of a row
+  // block (brow_first / brow_sink = NONE, haloA / haloL = 0, brow_inflow = 0: read by the final tile pass), the exit
+  // bitmasks (tiles beyond the raster edge of a partial supertile write none; 8 bytes per 64 slots + the flagged count).
+  // No slot array needs clearing: every tile writes its 256 slots, slots of tiles beyond the raster edge are never read.
+  {
+    const size_t xbytes = nslots / 64 * sizeof(u64) + 8;  // (xmaskbuf is rounded up to 16 bytes in init)
+    const u32 n16 = (u32)((xbytes + 15) / 16);
+    const u32 work = std::max<u32>(n16, is_block ? (u32)(5 * nb) : 0u);
+    k_pass_clear<<<std::max(1u, std::min(cdiv_u32(work, 256), 4096u)), 256, 0, h->stream>>>(
+        h->ctrl, h->normalised ? 8u : 0u, bnd.as<u32>(), is_block ? (u32)nb : 0u, (uint4 *)a.xmask, n16);
   }
-  if (is_block) HIPCHK(hipMemsetAsync(brow_inflow, 0, nb * sizeof(u32), h->stream));  // read by the final tile pass
-  // exit bitmasks: tiles beyond the raster edge of a partial supertile write none (8 bytes per 64 slots)
-  HIPCHK(hipMemsetAsync(a.xmask, 0, nslots / 64 * sizeof(u64) + 8, h->stream));
   // interior tiles: k_tile_local_fast; the frame around them (raster edge, halo and boundary rows): k_tile
   const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
   const bool have_i = gridi.x && gridi.y;
@@ -1619,6 +1655,23 @@ int TiledRun::phase_a() {
 // phase B: add the flow arriving from the other row blocks (brow_inflow, already on the device),
 // final tile pass, completeness check
 int TiledRun::phase_b(int *complete) {
+  PFDCHK(phase_b_issue());
+  u64 c0[48];
+  HIPCHK(hipMemcpyAsync(c0, h->ctrl, sizeof(c0), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return phase_b_collect(c0, complete);
+}
+int TiledRun::stage_verdict_a() {
+  k_stage_verdict_a<<<1, 1, 0, h->stream>>>(h->ctrl, (u32)sa.hmode, (u32)rounds4);
+  KCHK();
+  return PFD_OK;
+}
+int TiledRun::block_verdict(int *flag_dev, bool host_ok) {
+  k_block_verdict<<<1, 1, 0, h->stream>>>(h->ctrl, (u32)sa.hmode, (u32)rounds4, host_ok && coarse_done ? 1u : 0u, flag_dev);
+  KCHK();
+  return PFD_OK;
+}
+int TiledRun::phase_b_issue() {
   const size_t nb = 2 * (size_t)h->ncol;
   if (is_block) {
     // The flow entering from the other row blocks is one more set of start values on the same exit
@@ -1626,13 +1679,15 @@ int TiledRun::phase_b(int *complete) {
     // now with the full down-pass.  The first solve left totals in the edge supertile rows only (that
     // is all the halo sinks needed); every exit's total is written again.
     pfd_seg_begin(h, "block_inflow");
-    i64 launches = 1;
-    k_brow_scatter<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, xT);
-    KCHK();
-    if (sa.hmode && !pfd_knob("PFD_BLOCK_FULL_RESOLVE"))
+    i64 launches = 0;
+    if (sa.hmode && !pfd_knob("PFD_BLOCK_FULL_RESOLVE")) {
       PFDCHK(resolve_with_inflow(&launches));  // (structure of the first solve reused: values only)
-    else
+    } else {
+      k_brow_scatter<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, xT);
+      KCHK();
+      ++launches;
       PFDCHK(solve_exits(xT, &launches));
+    }
     pfd_seg_end(h, launches);
   }
   const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
@@ -1649,9 +1704,9 @@ int TiledRun::phase_b(int *complete) {
   k_tile<true><<<frame_tiles(ntr, ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi), 256, 0, h->stream>>>(a);
   KCHK();
   pfd_seg_end(h, 1);
-  u64 c0[48];
-  HIPCHK(hipMemcpyAsync(c0, h->ctrl, sizeof(c0), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}
+int TiledRun::phase_b_collect(const u64 *c0, int *complete) {
   const u64 *c = c0 + 8;
   if (a.ablate & 32) {
     std::vector<u64> rc(1024);
@@ -1678,6 +1733,7 @@ int TiledRun::phase_b(int *complete) {
   }
   // T_UNSAT: cells left unsaturated by a tile pass; T_SLIVE: supertile/hypertile solves that did not
   // saturate; T_OVERFLOW: a hypertile held more super-exits than fit in LDS (result invalid: redo flat)
+  last_miss = c[T_MISS - 8];
   *complete = coarse_done && c[T_SLIVE - 8] == 0 && c[T_UNSAT - 8] == 0;
   overflowed = c[T_OVERFLOW - 8] != 0;
   // level 4 ran a fixed number of rounds: saturated iff the last one moved no pointer
@@ -1695,19 +1751,25 @@ int TiledRun::phase_a_checked() {
   PFDCHK(phase_a());
   return phase_a_check();
 }
+bool TiledRun::phase_a_needs_redo(const u64 *c8, int tries) {
+  if (!sa.hmode || tries >= 3) return false;
+  if (c8[T_OVERFLOW - 8]) {
+    force_flat = true;
+    return true;
+  }
+  if (rounds4 > 0 && c8[T_XACTIVE - 8] >= (u64)rounds4 && tries < 2) {
+    extra_rounds += 8;  // (a cyclic exit graph never saturates: give up after two extensions)
+    return true;
+  }
+  return false;
+}
 // the check alone: callers that run phase A of several blocks concurrently issue all of them first
 int TiledRun::phase_a_check() {
   for (int tries = 0; sa.hmode && tries < 3; ++tries) {
     u64 c[8];
     HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (c[T_OVERFLOW - 8]) {
-      force_flat = true;
-    } else if (rounds4 > 0 && c[T_XACTIVE - 8] >= (u64)rounds4 && tries < 2) {
-      extra_rounds += 8;  // (a cyclic exit graph never saturates: give up after two extensions)
-    } else {
-      break;
-    }
+    if (!phase_a_needs_redo(c, tries)) break;
     PFDCHK(phase_a());
   }
   return PFD_OK;

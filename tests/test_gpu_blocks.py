@@ -608,3 +608,38 @@ def test_block_update_modes_refuse_a_host_result(gpu_lib, oracle):
         assert np.array_equal(out.view(np.uint32), out0.view(np.uint32))
     finally:
         h.close()
+
+
+def _zigzag(nrow, ncol, row):
+    """A river that crosses the edge between `row` and `row + 1` at EVERY step (SE, NE, SE, ...): the interface forest of
+    the row blocks holds one path of ncol - 1 hops; tributaries feed it from above and below."""
+    d8 = np.full((nrow, ncol), 247, np.uint8)
+    for c in range(ncol - 1):
+        if c % 2 == 0:
+            d8[row, c] = 2  # SE -> (row + 1, c + 1)
+        else:
+            d8[row + 1, c] = 128  # NE -> (row, c + 1)
+    d8[row + ((ncol - 1) % 2), ncol - 1] = 0  # the river's pit
+    d8[:row, ::2] = 4  # columns of S-flowing cells above the even crossings ...
+    d8[row + 2:, 1::2] = 64  # ... and of N-flowing cells below the odd ones
+    return d8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deferred", [False, True])
+def test_interface_paths_longer_than_the_chase(gpu_lib, oracle, monkeypatch, deferred):
+    """The interface forest of a block pass is chased (one launch, paths of a handful of hops); a path with more hops than
+    the chase allows — here a river zigzagging across a block edge 299 times — raises the miss bit and the pass is redone
+    with the doubling rounds; PFD_TEST_IFACE_HOPS=1 forces that on an ordinary raster.  Results as the oracle's."""
+    from pyflwdir_amd import dist
+
+    d8 = _zigzag(100, 300, 49)  # block_rows(100, 2) = [0, 50), [50, 100): the river runs on rows 49 / 50
+    exp = oracle.upstream_area_cell(d8)[0]
+    assert exp.max() > 5000
+    for nb in (2, 4):
+        got = dist.upstream_area_blocks(d8, nb, deferred=deferred)
+        assert np.array_equal(got, exp), nb
+    d8 = oracle.synth_d8(1300, 900, seed=4, tilt=1 << 26, white=2, nodata_pct=3)
+    exp = oracle.upstream_area_cell(d8)[0]
+    monkeypatch.setenv("PFD_TEST_IFACE_HOPS", "1")
+    assert np.array_equal(dist.upstream_area_blocks(d8, 5, deferred=deferred), exp)

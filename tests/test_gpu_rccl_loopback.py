@@ -48,6 +48,26 @@ def test_every_collective_through_the_rccl_branches(gpu_lib, shim, world):
         assert "ok (rccl)" in o[0] and "rccl_sendrecv" in o[0] and "rccl_allgather" in o[0], o[0]
 
 
+@pytest.mark.parametrize("knob", ["PFD_TEST_IFACE_HOPS", "PFD_TEST_ROUNDS4", "PFD_TEST_HCAP"])
+def test_a_stage_that_falls_short_is_redone_by_every_rank(gpu_lib, shim, knob):
+    """pfd_upstream_area_cell_dist runs a pass without host round trips; a stage that falls short (the interface chase out of
+    hops, level 4 out of rounds, a hypertile's id range overflowed — forced by the test knobs) raises a sticky bit on the
+    device, the verdict travels through the agreement all-reduce and EVERY rank repeats the pass with the remedy.  Three
+    ranks, results against the oracle (tools/dist_check.py)."""
+    world = 3
+    procs = []
+    for r in range(world):
+        e = dict(_clean_env(), RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29871",
+                 HSA_ENABLE_IPC_MODE_LEGACY="0", PFD_DIST_TRANSPORT="rccl", LD_PRELOAD=shim, PFD_LOOPBACK_TIMEOUT_S="180",
+                 PFD_ENABLE_KNOBS="1", DIST_CHECK_ONLY="upstream_area", DIST_CHECK_SHAPE="6400x4300")  # (3 x 3 hypertiles per block)
+        e[knob] = "100" if knob == "PFD_TEST_HCAP" else "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dist_check.py")], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert all("ok (rccl)" in o[0] for o in outs)
+
+
 def _line(args, env, timeout=1500):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
                          timeout=timeout, env=env)

@@ -19,10 +19,8 @@ from pyflwdir_amd.hostgroup import HostGroup  # noqa: E402
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 grp = HostGroup(rank, world)
-shape = (1700, 1300)
+shape = tuple(int(x) for x in os.environ.get("DIST_CHECK_SHAPE", "1700x1300").split("x"))
 d8 = O.synth_d8(shape[0], shape[1], seed=77, tilt=100000, white=2, nodata_pct=20)
-idxs_ds, idxs_pit, _ = O.from_array(d8)
-seq = O.idxs_seq(idxs_ds, idxs_pit)
 upa = O.upstream_area_cell(d8)[0]
 r0, r1 = pdist.block_rows(shape[0], world)[rank]
 a, e = pdist.block_slice(shape[0], world, rank)
@@ -30,6 +28,16 @@ dr = pdist.DistributedRaster(d8[a:e], r1 - r0, shape[1], rank, world, 0, transpo
                              group=grp)
 got = dr.upstream_area()
 assert np.array_equal(got, upa[r0:r1]), f"rank {rank}: upstream_area differs"
+if os.environ.get("DIST_CHECK_ONLY") == "upstream_area":  # (the forced-miss runs of tests/test_gpu_rccl_loopback.py)
+    got = dr.upstream_area()  # once more on the same handle: the remedies of the first pass must not linger wrongly
+    assert np.array_equal(got, upa[r0:r1]), f"rank {rank}: second upstream_area differs"
+    dr.close()
+    grp.barrier()
+    grp.close()
+    print(f"rank {rank} of {world}: ok ({dr.transport}); upstream_area only")
+    sys.exit(0)
+idxs_ds, idxs_pit, _ = O.from_array(d8)
+seq = O.idxs_seq(idxs_ds, idxs_pit)
 outl = np.argsort(upa.ravel())[-400:]
 ids = (np.arange(outl.size) + 3).astype(np.uint32)
 lab = dr.basins(outl, ids, shape[0])
