@@ -11,6 +11,14 @@
 // file-backed shared mapping (hipMemcpy device -> mapping -> device): nothing here needs hipIpc, so it also runs
 // where the dmabuf exporter is not available.
 //
+// Record / replay (measurement aid: what ONE rank of an N-rank job spends when its peers answer at once).  With
+// PFD_LOOPBACK_RECORD=<dir> rank 0 of a normal N-rank run writes the result of every collective it takes part in, in call
+// order, to <dir>/NNNNNN.bin.  With PFD_LOOPBACK_REPLAY=<dir> a SINGLE process creates a communicator of N ranks without
+// peers: at ncclCommInitRank the recorded results are loaded into device memory, and every ncclAllGather / ncclAllReduce
+// is served by ONE device-to-device copy enqueued on the caller's stream — no synchronisation, no host round trip, i.e.
+// an ideal transport.  The caller must issue the collectives of the recorded run (same program, same arguments); the
+// sequence restarts from PFD_LOOPBACK_REPLAY_LOOP (default 0) when it runs out, so a program may repeat its passes.
+//
 // Rendezvous: ncclGetUniqueId creates the backing file and writes its path into the 128-byte id; every rank maps it
 // in ncclCommInitRank.  All waits are bounded (PFD_LOOPBACK_TIMEOUT_S, default 120 s): a rank that never arrives
 // makes the others return ncclSystemError instead of hanging the box.
@@ -97,6 +105,12 @@ struct ncclComm {
   Shm *shm = nullptr;
   int rank = 0, world = 1, device = 0;
   char path[120] = {0};
+  // record (rank 0 of a real run) / replay (one process, no peers)
+  char rec_dir[200] = {0};
+  unsigned rec_next = 0;
+  bool replay = false;
+  std::vector<std::pair<void *, size_t>> replay_bufs;  // device copies of the recorded results, in call order
+  size_t replay_next = 0, replay_loop = 0;
 };
 
 namespace {
@@ -206,6 +220,7 @@ ncclResult_t run_p2p(std::vector<std::pair<ncclComm *, P2P>> &ops, std::vector<h
 }
 
 ncclResult_t enqueue_p2p(bool send, const void *buf, size_t count, ncclDataType_t t, int peer, ncclComm *c, hipStream_t st) {
+  if (c && c->replay) return ncclInvalidUsage;  // (replay serves the collectives of pfd_upstream_area_cell_dist only)
   if (!c || !c->shm || peer < 0 || peer >= c->world || peer == c->rank || type_size(t) == 0) return ncclInvalidArgument;
   P2P o{send, (char *)buf, count * type_size(t), 0, peer, 0};
   c->shm->stats[send ? 2 : 3].fetch_add(1);
@@ -218,6 +233,48 @@ ncclResult_t enqueue_p2p(bool send, const void *buf, size_t count, ncclDataType_
   std::vector<std::pair<ncclComm *, P2P>> one{{c, o}};
   std::vector<hipStream_t> sts{st};
   return run_p2p(one, sts);
+}
+
+void record_result(ncclComm *c, const void *dev, size_t bytes) {
+  if (!c->rec_dir[0] || c->rank != 0) return;
+  std::vector<char> host(bytes);
+  if (bytes && hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
+  char path[260];
+  snprintf(path, sizeof(path), "%s/%06u.bin", c->rec_dir, c->rec_next++);
+  if (FILE *f = fopen(path, "wb")) {
+    fwrite(host.data(), 1, bytes, f);
+    fclose(f);
+  }
+}
+bool replay_load(ncclComm *c, const char *dir) {
+  for (unsigned i = 0;; ++i) {
+    char path[260];
+    snprintf(path, sizeof(path), "%s/%06u.bin", dir, i);
+    FILE *f = fopen(path, "rb");
+    if (!f) break;
+    fseek(f, 0, SEEK_END);
+    const size_t bytes = (size_t)ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<char> host(bytes);
+    const size_t got = fread(host.data(), 1, bytes, f);
+    fclose(f);
+    void *dev = nullptr;
+    if (got != bytes || hipMalloc(&dev, bytes ? bytes : 4) != hipSuccess) return false;
+    if (bytes && hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+    c->replay_bufs.emplace_back(dev, bytes);
+  }
+  return !c->replay_bufs.empty();
+}
+ncclResult_t replay_serve(ncclComm *c, void *recvbuf, size_t bytes, hipStream_t st) {
+  if (c->replay_next >= c->replay_bufs.size()) c->replay_next = c->replay_loop;
+  if (c->replay_next >= c->replay_bufs.size()) return ncclInvalidUsage;
+  const auto &b = c->replay_bufs[c->replay_next++];
+  if (b.second != bytes) {
+    fprintf(stderr, "[rccl loopback] replay: call %zu was recorded with %zu bytes, asked for %zu\n", c->replay_next - 1, b.second, bytes);
+    return ncclInvalidUsage;
+  }
+  if (bytes && hipMemcpyAsync(recvbuf, b.first, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return ncclUnhandledCudaError;
+  return ncclSuccess;
 }
 
 }  // namespace
@@ -261,6 +318,18 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
   ncclComm *c = new ncclComm();
   c->rank = rank, c->world = nranks;
   (void)hipGetDevice(&c->device);
+  if (const char *dir = getenv("PFD_LOOPBACK_REPLAY")) {  // one process stands for rank `rank` of `nranks`: no peers, no mapping
+    c->replay = true;
+    if (const char *e = getenv("PFD_LOOPBACK_REPLAY_LOOP")) c->replay_loop = (size_t)atol(e);
+    if (!replay_load(c, dir)) {
+      delete c;
+      return ncclSystemError;
+    }
+    unlink(id.internal + sizeof(MAGIC));  // (the id's backing file is not needed)
+    *comm = c;
+    return ncclSuccess;
+  }
+  if (const char *dir = getenv("PFD_LOOPBACK_RECORD")) snprintf(c->rec_dir, sizeof(c->rec_dir), "%s", dir);
   snprintf(c->path, sizeof(c->path), "%s", id.internal + sizeof(MAGIC));
   const int fd = open(c->path, O_RDWR);
   if (fd < 0) {
@@ -295,6 +364,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
 ncclResult_t ncclCommDestroy(ncclComm_t c) {
   if (!c) return ncclSuccess;
   if (c->shm) munmap((void *)c->shm, sizeof(Shm));
+  for (auto &b : c->replay_bufs) (void)hipFree(b.first);
   delete c;
   return ncclSuccess;
 }
@@ -345,6 +415,7 @@ ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t t, int peer, ncclC
 }
 
 ncclResult_t ncclAllGather(const void *sendbuf, void *recvbuf, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t st) {
+  if (c && c->replay) return replay_serve(c, recvbuf, count * type_size(t) * (size_t)c->world, st);
   if (!c || !c->shm || type_size(t) == 0 || group_depth > 0) return ncclInvalidArgument;
   if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
   Shm *s = c->shm;
@@ -364,11 +435,13 @@ ncclResult_t ncclAllGather(const void *sendbuf, void *recvbuf, size_t count, ncc
     if (!ok) return ncclUnhandledCudaError;
     if (bytes == 0) break;
   }
+  record_result(c, recvbuf, bytes * (size_t)c->world);
   return ncclSuccess;
 }
 
 ncclResult_t ncclAllReduce(const void *sendbuf, void *recvbuf, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c,
                            hipStream_t st) {
+  if (c && c->replay) return replay_serve(c, recvbuf, count * type_size(t), st);
   if (!c || !c->shm || type_size(t) == 0 || group_depth > 0) return ncclInvalidArgument;
   const size_t bytes = count * type_size(t);
   if (bytes > COLL_CAP) return ncclInvalidArgument;  // (the library reduces a handful of counters)
@@ -383,6 +456,7 @@ ncclResult_t ncclAllReduce(const void *sendbuf, void *recvbuf, size_t count, ncc
   if (ok && bytes) ok = hipMemcpy(recvbuf, acc.data(), bytes, hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) s->aborted.store(1);
   if (!barrier(c)) return ncclSystemError;
+  if (ok) record_result(c, recvbuf, bytes);
   return ok ? ncclSuccess : ncclUnhandledCudaError;
 }
 
