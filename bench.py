@@ -149,6 +149,27 @@ def rccl_binding():
         return "rccl"
 
 
+def reserve_working_memory(device, gib):
+    """One arena for the library's working buffers before anything is timed (pfd_reserve): hipMalloc of multi-GiB blocks
+    returns in 0.2 ms or in seconds on this hardware, unpredictably — a benchmark (or a serving process) pays that once,
+    up front.  A failure is not fatal: the class cache and hipMalloc remain."""
+    if gib <= 0:
+        return
+    try:
+        _hip.reserve(int(gib * 2**30), device)
+    except Exception as exc:  # noqa: BLE001
+        print(f"bench.py: pfd_reserve({gib} GiB) failed ({exc}); running without an arena", file=sys.stderr)
+
+
+def rank_reserve_gib(whole_raster_gib, world):
+    """Arena of one rank of a `world`-rank job: its share of what the whole raster needs (+50 %: per-rank fixed costs),
+    divided again when several ranks share a GPU (test boxes); PFD_BENCH_RESERVE_GIB overrides the whole-raster figure."""
+    whole = float(os.environ.get("PFD_BENCH_RESERVE_GIB", whole_raster_gib))
+    share = whole if world == 1 else 1.5 * whole / world
+    ranks_per_gpu = max(1, -(-world // max(1, _hip.device_count())))
+    return min(share, 200.0 / ranks_per_gpu)
+
+
 def one_step(d8_buf, out_buf, nrow, ncol, device, profile=False):
     """One pass of the hot path.  With profile=True the library brackets every phase with HIP
     events on its own stream (6 events per pass) and the phase times are returned."""
@@ -171,12 +192,14 @@ def mean_segments(all_segs):
     return list(acc.values())
 
 
-def timed_steps(step, steps, warmup, device):
+def timed_steps(step, steps, warmup, device, after_warmup=None):
     """W untimed steps, then exactly K steps between two device synchronisations.  Every step ends
     with the library's own stream synchronisation, so the per-step wall times are exact too."""
     for _ in range(warmup):
         step(False)
     _hip.check(_hip.lib().pfd_device_synchronize(device))
+    if after_warmup is not None:
+        after_warmup()
     marks = [time.perf_counter()]
     timed = []
     for _ in range(steps):
@@ -274,8 +297,10 @@ def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, ch
         label = f"{nrow}x{ncol} synthetic D8 ({regime} regime, seed {synth['seed']}, tilt {synth['tilt']})"
     n = nrow * ncol
     out_buf = _hip.DeviceBuffer(n * 4, device)
+    alloc0 = {}
     total, per, timed = timed_steps(lambda prof: one_step(d8_buf, out_buf, nrow, ncol, device, profile=prof), steps,
-                                    warmup, device)
+                                    warmup, device, after_warmup=lambda: alloc0.update(_hip.alloc_stats()))
+    alloc1 = _hip.alloc_stats()
     ms_per_step = total / steps * 1e3
     segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
     out = dict(value=round(n * steps / total / 1e6, 2), ms_per_step=round(ms_per_step, 3),
@@ -285,6 +310,12 @@ def upa_line(nrow, ncol, regime, steps, warmup, device, cpu=True, cpu_rows=0, ch
                                 "pfd_upstream_area_cell: what FlwdirRaster.upstream_area calls, device-resident in and out); a step = "
                                 "decode + pit rule + validation + tile pass + exit-graph solve + final tile pass on a fresh handle",
                n_cells=n, n_valid=info["n_valid"], n_pits=info["n_pits"], parallelism="1 GPU")
+    # the allocator inside the timed region: working buffers come from the reserved arena / the class cache; a hipMalloc
+    # there can stall for seconds on this hardware (DESIGN.md "allocation"), so the line says how many there were
+    out["allocator"] = dict(hipmalloc_calls_timed=alloc1["hipmalloc_calls"] - alloc0.get("hipmalloc_calls", 0),
+                            arena_blocks_timed=alloc1["arena_blocks"] - alloc0.get("arena_blocks", 0),
+                            reserved_GiB=round(alloc1["reserved_bytes"] / 2**30, 1),
+                            step_max_over_median=round(max(per) / statistics.median(per), 3))
     if checks:
         # graph statistics (outside the timed region): longest flow path, in-degree histogram, and the pointer-
         # doubling rounds the tile passes needed (counted by one extra profiled pass)
@@ -522,6 +553,8 @@ def run_distributed(a, rank, world, local):
         tdist.init_process_group(backend="gloo")
         grp = hostgroup.TorchGroup()
     device = local % max(1, _hip.device_count())  # (one rank per GPU; the modulo only matters on test boxes)
+    # (ranks that share a GPU share its HBM: the arena is sized per rank)
+    reserve_working_memory(device, rank_reserve_gib(64.0, world))
     ncol = nrow_total = a.size
     r0, r1 = pdist.block_rows(nrow_total, world)[rank]
     own = r1 - r0
@@ -628,6 +661,7 @@ def run_distributed_op(a, rank, world, local):
         os.environ.setdefault(k, v)
     grp = hostgroup.HostGroup(rank, world)
     device = local % max(1, _hip.device_count())
+    reserve_working_memory(device, rank_reserve_gib(96.0, world))
     nrow_total, ncol = a.rows, a.cols
     r0, r1 = pdist.block_rows(nrow_total, world)[rank]
     own = r1 - r0
@@ -896,6 +930,7 @@ def main():
     if world > 1 or os.environ.get("PFD_BENCH_FORCE_DIST"):  # the env knob runs the RCCL path with 1 rank
         return run_distributed(a, rank, world, local)
     device = local
+    reserve_working_memory(device, rank_reserve_gib(64.0, 1))
     if a.ops:  # (tools/prof_pmc.sh: the operation lines alone, `steps` warm calls each)
         if a.ops == "c3":
             lines = op_lines(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", a.steps, device)

@@ -74,6 +74,15 @@ int pfd_device_synchronize(int device);
 /* the library caches freed HBM blocks for reuse; pfd_trim returns them to the driver
  * (device < 0: all devices) */
 int pfd_trim(int device);
+/* Reserve `bytes` of HBM on `device` as ONE arena that the library's working buffers (>= 1 MiB) are carved from before
+ * anything else is tried: after this call a steady state never calls hipMalloc, whose latency for multi-GiB blocks is
+ * unpredictable on this hardware (0.2 ms or seconds; DESIGN.md "allocation").  May be called more than once (more
+ * arenas); requests that do not fit fall back to the class cache / hipMalloc.  bytes == 0 releases the device's arenas
+ * that hold no live block.  Callers that time first calls (bench.py, a serving process) reserve before they start. */
+int pfd_reserve(int device, size_t bytes);
+/* allocator counters since the process started: [0] hipMalloc calls, [1] exact-class cache hits, [2] near-fit cache hits,
+ * [3] blocks carved from reserved arenas, [4] idle cached bytes, [5] reserved bytes, [6] of them free, [7] live blocks */
+int pfd_alloc_stats(int64_t out[8]);
 
 /* ---- raster handle -------------------------------------------------------------------
  * pfd_raster_create: replaces core_d8.from_array (reference pyflwdir/core_d8.py:42-67) as the

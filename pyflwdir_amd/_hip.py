@@ -40,6 +40,7 @@ SYMBOLS = [
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
     "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic", "pfd_set_block_update",
+    "pfd_reserve", "pfd_alloc_stats",
 ]
 
 _lib = None
@@ -133,6 +134,8 @@ def lib() -> C.CDLL:
         L.pfd_memcpy_d2h.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         L.pfd_device_synchronize.argtypes = [C.c_int]
         L.pfd_trim.argtypes = [C.c_int]
+        L.pfd_reserve.argtypes = [C.c_int, C.c_size_t]
+        L.pfd_alloc_stats.argtypes = [C.POINTER(C.c_int64)]
         L.pfd_device_count.argtypes = [C.POINTER(C.c_int)]
         L.pfd_synth_d8.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                    C.c_int64, C.c_int64, C.c_void_p]
@@ -163,6 +166,21 @@ def ptr(a):
     if isinstance(a, DeviceBuffer):
         return C.c_void_p(a.addr)
     return C.c_void_p(int(a))
+
+
+def reserve(nbytes: int, device: int = 0):
+    """Reserve ``nbytes`` of HBM as one arena for the library's working buffers (``pfd_reserve``): afterwards a steady
+    state never calls hipMalloc, whose latency for multi-GiB blocks is unpredictable (0.2 ms or seconds).  ``nbytes=0``
+    releases the arenas that hold no live block."""
+    check(lib().pfd_reserve(int(device), C.c_size_t(int(nbytes))))
+
+
+def alloc_stats() -> dict:
+    """Allocator counters since the process started (``pfd_alloc_stats``)."""
+    a = (C.c_int64 * 8)()
+    check(lib().pfd_alloc_stats(a))
+    keys = ("hipmalloc_calls", "cache_hits", "near_fit_hits", "arena_blocks", "idle_bytes", "reserved_bytes", "reserved_free", "live_blocks")
+    return {k: int(v) for k, v in zip(keys, a)}
 
 
 class DeviceBuffer:

@@ -43,11 +43,25 @@ extern "C" int pfd_device_count(int *count) {
 // caching device allocator
 // ---------------------------------------------------------------------------------------------
 namespace {
+// A reserved arena (pfd_reserve): ONE hipMalloc, carved into blocks of any size class by a first-fit free list with
+// coalescing.  Measured on MI355X (tools/alloc_probe_big.py): hipMalloc of a block of tens of GiB returns in 0.2 ms
+// or in 0.5 - 7 s, unpredictably (memory released shortly before, by this or another process, seems to be scrubbed
+// first) — every stall the round-4 records show (a "cached" sweep of 591 ms, first calls of 1.2 - 3.2 s) was a
+// hipMalloc of a size class the cache had not seen.  With an arena a steady state never calls hipMalloc at all.
+struct Arena {
+  int device = 0;
+  char *base = nullptr;
+  size_t bytes = 0;
+  std::map<size_t, size_t> free_at;  // offset -> length of the free chunks (address order: neighbours coalesce)
+};
 struct DevCache {
   std::mutex mu;
   std::unordered_map<void *, std::pair<int, size_t>> live;       // ptr -> (device, class bytes)
   std::map<std::pair<int, size_t>, std::vector<void *>> idle;    // (device, class bytes) -> blocks
   size_t idle_bytes = 0;
+  std::vector<Arena> arenas;
+  std::unordered_map<void *, int> live_arena;                    // ptr -> arena index (blocks carved from an arena)
+  size_t arena_hits = 0, malloc_calls = 0, idle_hits = 0, near_hits = 0;
 };
 DevCache &cache() {
   static DevCache c;
@@ -104,6 +118,42 @@ int pfd_dmalloc(void **p, size_t bytes) {
 #else
 int pfd_dmalloc(void **p, size_t bytes) { return pfd_dmalloc_raw(p, bytes); }
 #endif
+#define ARENA_MIN (1u << 20)  // smaller blocks stay with hipMalloc + the class cache (they are cheap and many)
+// carve `cls` bytes from an arena of the device: best fit over the free chunks (a handful)
+static void *arena_take(DevCache &c, int dev, size_t cls) {
+  for (size_t ai = 0; ai < c.arenas.size(); ++ai) {
+    Arena &a = c.arenas[ai];
+    if (a.device != dev) continue;
+    auto best = a.free_at.end();
+    for (auto it = a.free_at.begin(); it != a.free_at.end(); ++it)
+      if (it->second >= cls && (best == a.free_at.end() || it->second < best->second)) best = it;
+    if (best == a.free_at.end()) continue;
+    const size_t off = best->first, len = best->second;
+    a.free_at.erase(best);
+    if (len > cls) a.free_at[off + cls] = len - cls;
+    void *p = a.base + off;
+    c.live_arena[p] = (int)ai;
+    return p;
+  }
+  return nullptr;
+}
+static void arena_give(DevCache &c, int ai, void *p, size_t cls) {
+  Arena &a = c.arenas[ai];
+  size_t off = (size_t)((char *)p - a.base), len = cls;
+  auto nx = a.free_at.lower_bound(off);
+  if (nx != a.free_at.begin()) {
+    auto pv = std::prev(nx);
+    if (pv->first + pv->second == off) {
+      off = pv->first, len += pv->second;
+      a.free_at.erase(pv);
+    }
+  }
+  if (nx != a.free_at.end() && off + len == nx->first) {
+    len += nx->second;
+    a.free_at.erase(nx);
+  }
+  a.free_at[off] = len;
+}
 static int pfd_dmalloc_raw(void **p, size_t bytes) {
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
@@ -117,8 +167,30 @@ static int pfd_dmalloc_raw(void **p, size_t bytes) {
       it->second.pop_back();
       c.idle_bytes -= cls;
       c.live[*p] = {dev, cls};
+      ++c.idle_hits;
       return PFD_OK;
     }
+    if (cls >= ARENA_MIN) {
+      if (void *q = arena_take(c, dev, cls)) {
+        *p = q;
+        c.live[q] = {dev, cls};
+        ++c.arena_hits;
+        return PFD_OK;
+      }
+      // no exact class idle: an idle block up to an eighth larger serves as well (row blocks of one raster differ by a
+      // few MiB per array — every miss here is a hipMalloc that may stall for seconds)
+      auto nb = c.idle.lower_bound({dev, cls});
+      for (; nb != c.idle.end() && nb->first.first == dev && nb->first.second <= cls + cls / 8; ++nb) {
+        if (nb->second.empty()) continue;
+        *p = nb->second.back();
+        nb->second.pop_back();
+        c.idle_bytes -= nb->first.second;
+        c.live[*p] = {dev, nb->first.second};
+        ++c.near_hits;
+        return PFD_OK;
+      }
+    }
+    ++c.malloc_calls;
   }
   hipError_t e = hipMalloc(p, cls);
   if (e != hipSuccess) {  // give the cached blocks back and retry once
@@ -157,6 +229,13 @@ void pfd_dfree(void *p) {
   }
   const auto key = it->second;
   c.live.erase(it);
+  auto ar = c.live_arena.find(p);
+  if (ar != c.live_arena.end()) {  // carved from an arena: back into its free list (any class can have it next)
+    const int ai = ar->second;
+    c.live_arena.erase(ar);
+    arena_give(c, ai, p, key.second);
+    return;
+  }
   if (c.idle_bytes + key.second > idle_cap()) {
     (void)hipFree(p);
     return;
@@ -177,6 +256,109 @@ extern "C" int pfd_trim(int device) {
     kv.second.clear();
   }
   return PFD_OK;
+}
+
+extern "C" int pfd_reserve(int device, size_t bytes) {
+  if (device < 0) {
+    pfd_set_error("pfd_reserve: bad device %d", device);
+    return PFD_EINVAL;
+  }
+  DevCache &c = cache();
+  if (bytes == 0) {  // release the arenas of the device that hold no live block
+    std::lock_guard<std::mutex> g(c.mu);
+    for (Arena &a : c.arenas) {
+      if (a.device != device || !a.base) continue;
+      if (a.free_at.size() == 1 && a.free_at.begin()->second == a.bytes) {
+        (void)hipSetDevice(device);
+        (void)hipFree(a.base);
+        a.base = nullptr, a.bytes = 0;
+        a.free_at.clear();
+      }
+    }
+    return PFD_OK;
+  }
+  int prev = 0;
+  HIPCHK(hipGetDevice(&prev));
+  HIPCHK(hipSetDevice(device));
+  const size_t sz = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+  void *base = nullptr;
+  hipError_t e = hipMalloc(&base, sz);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    pfd_trim(device);
+    e = hipMalloc(&base, sz);
+  }
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    pfd_set_error("pfd_reserve(%zu bytes) failed: %s", sz, hipGetErrorString(e));
+    return PFD_ENOMEM;
+  }
+  std::lock_guard<std::mutex> g(c.mu);
+  Arena a;
+  a.device = device, a.base = (char *)base, a.bytes = sz;
+  a.free_at[0] = sz;
+  c.arenas.push_back(std::move(a));
+  return PFD_OK;
+}
+extern "C" int pfd_alloc_stats(int64_t out[8]) {
+  if (!out) {
+    pfd_set_error("pfd_alloc_stats: NULL argument");
+    return PFD_EINVAL;
+  }
+  DevCache &c = cache();
+  std::lock_guard<std::mutex> g(c.mu);
+  size_t reserved = 0, reserved_free = 0;
+  for (const Arena &a : c.arenas) {
+    reserved += a.bytes;
+    for (const auto &kv : a.free_at) reserved_free += kv.second;
+  }
+  out[0] = (int64_t)c.malloc_calls, out[1] = (int64_t)c.idle_hits, out[2] = (int64_t)c.near_hits, out[3] = (int64_t)c.arena_hits;
+  out[4] = (int64_t)c.idle_bytes, out[5] = (int64_t)reserved, out[6] = (int64_t)reserved_free, out[7] = (int64_t)c.live.size();
+  return PFD_OK;
+}
+
+// Pinned staging for the small host <-> device transfers of the split-phase row-block protocol: a pageable copy out of a
+// host array HIP has not seen costs 10 - 50 ms the first time (measured: tools/alloc_probe.py), whatever its size.
+namespace {
+struct PinnedPool {
+  std::mutex mu;
+  std::vector<std::pair<void *, size_t>> idle;
+};
+PinnedPool &pinned() {
+  static PinnedPool p;
+  return p;
+}
+}  // namespace
+void *pfd_pinned_take(size_t bytes, size_t *cap) {
+  PinnedPool &pp = pinned();
+  {
+    std::lock_guard<std::mutex> g(pp.mu);
+    for (size_t i = 0; i < pp.idle.size(); ++i)
+      if (pp.idle[i].second >= bytes) {
+        auto b = pp.idle[i];
+        pp.idle.erase(pp.idle.begin() + (long)i);
+        *cap = b.second;
+        return b.first;
+      }
+  }
+  void *q = nullptr;
+  const size_t sz = std::max<size_t>((bytes + 4095) & ~(size_t)4095, 1u << 16);
+  if (hipHostMalloc(&q, sz, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  *cap = sz;
+  return q;
+}
+void pfd_pinned_give(void *p, size_t cap) {
+  if (!p) return;
+  PinnedPool &pp = pinned();
+  std::lock_guard<std::mutex> g(pp.mu);
+  if (pp.idle.size() >= 8) {
+    (void)hipHostFree(p);
+    return;
+  }
+  pp.idle.emplace_back(p, cap);
 }
 
 // hipStreamCreate/Destroy cost ~1 ms each: streams are pooled per device and reused

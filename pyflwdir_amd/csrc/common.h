@@ -176,6 +176,8 @@ struct pfd_raster {
 // again.  Every API call synchronises its stream before it returns, hence a block is idle
 // when it is released.  pfd_trim() returns the cache to the driver.
 int pfd_dmalloc(void **p, size_t bytes);
+void *pfd_pinned_take(size_t bytes, size_t *cap);  // pinned host staging from a small process-wide pool (api.hip); null: none
+void pfd_pinned_give(void *p, size_t cap);
 const char *pfd_knob(const char *name);  // test-only switch: getenv(name) if PFD_ENABLE_KNOBS=1, else null (api.hip)
 void pfd_dfree(void *p);
 

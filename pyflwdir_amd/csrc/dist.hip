@@ -302,24 +302,44 @@ __device__ __forceinline__ u32 iface_next(const u32 *__restrict__ rec, u32 nbloc
   if (s == NONE32) return NONE32;
   return ((u32)owner * 2 + ((s & ENC_SIDE1) ? 1u : 0u)) * ncol + (s & ENC_COL);
 }
+// one atomic per DISTINCT target among the lanes of a wave: neighbouring boundary cells drain into the same river, so
+// after a hop or two most lanes of a wave walk the same path, and the river's cell would take one same-address atomic
+// per source (they serialise at ~12 ns: 0.19 ms on the block at the bottom of the benchmark raster).  All 64 lanes call.
+__device__ __forceinline__ void wave_combined_add(u32 *__restrict__ base, u32 idx, u32 v, bool active) {
+  u64 todo = __ballot(active);
+  const u32 lane = threadIdx.x & 63u;
+  while (todo) {  // (wave-uniform)
+    const int leader = __ffsll((long long)todo) - 1;
+    const u32 lidx = __shfl(idx, leader);
+    const bool mine = active && idx == lidx;
+    u32 x = mine ? v : 0u;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) x += __shfl_xor(x, off);
+    if ((int)lane == leader) atomicAdd(&base[lidx], x);
+    todo &= ~__ballot(mine);
+  }
+}
 __global__ void __launch_bounds__(256) k_iface_chase(const u32 *__restrict__ rec, u32 nblocks, u32 ncol, u32 blk, u32 maxhops,
                                                      u32 *__restrict__ brow_inflow, u64 *__restrict__ ctrl) {
   const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= nblocks * 2 * ncol) return;
-  const u32 bs0 = id / ncol;
-  const u32 L = rec[(size_t)(bs0 >> 1) * 4 * ncol + (bs0 & 1u) * ncol + id % ncol];  // flow leaving the block through this cell
-  if (!L) return;
+  const bool inside = id < nblocks * 2 * ncol;
+  const u32 bs0 = inside ? id / ncol : 0u;
+  // flow leaving the block through this cell
+  const u32 L = inside ? rec[(size_t)(bs0 >> 1) * 4 * ncol + (bs0 & 1u) * ncol + id % ncol] : 0u;
   // F of the bottom halo of block blk-1 enters the first own row, F of the top halo of block blk+1 the last
-  const u32 want0 = blk ? (blk - 1) * 2 + 1 : NONE32, want1 = (blk + 1) * 2;
+  const u32 want0 = blk ? (blk - 1) * 2 + 1 : NONE32, want1 = blk + 1 < nblocks ? (blk + 1) * 2 : NONE32;
   u32 node = id;
-  for (u32 hop = 0; hop < maxhops; ++hop) {
-    const u32 bs = node / ncol;
-    if (bs == want0) atomicAdd(&brow_inflow[node % ncol], L);
-    else if (bs == want1 && blk + 1 < nblocks) atomicAdd(&brow_inflow[ncol + node % ncol], L);
-    node = iface_next(rec, nblocks, ncol, node);
-    if (node == NONE32) return;
+  bool live = L != 0u;  // (lanes stay in the loop until the whole wave is done: the combine needs all of them)
+  for (u32 hop = 0; hop < maxhops && __ballot(live); ++hop) {
+    const u32 bs = live ? node / ncol : NONE32 - 1u;
+    const bool hit = live && (bs == want0 || bs == want1);
+    wave_combined_add(brow_inflow, (bs == want1 ? ncol : 0u) + node % ncol, L, hit);
+    if (live) {
+      node = iface_next(rec, nblocks, ncol, node);
+      live = node != NONE32;
+    }
   }
-  atomicOr((unsigned long long *)&ctrl[T_MISS], (unsigned long long)MISS_IFACE);
+  if (live) atomicOr((unsigned long long *)&ctrl[T_MISS], (unsigned long long)MISS_IFACE);
 }
 
 // the same forest by doubling rounds (after a chase ran out of hops); synchronises to see whether the rounds sufficed
@@ -511,6 +531,10 @@ extern "C" int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int mem
   }
   DevBuf rec;
   if (rc == PFD_OK) rc = rec.alloc(recw * sizeof(u32));
+  // (the record goes through pinned staging: a pageable copy into a host array HIP has not seen costs 10 - 50 ms)
+  size_t pcap = 0;
+  void *pin = rc == PFD_OK ? pfd_pinned_take(recw * sizeof(u32), &pcap) : nullptr;
+  void *land = pin ? pin : (void *)record_host;
   // phase A, the record and its control words leave in ONE synchronisation; phase A is redone when it fell short
   // (flat level 3 after an overflow of a hypertile's id range, more level-4 rounds)
   for (int tries = 0; rc == PFD_OK; ++tries) {
@@ -519,7 +543,7 @@ extern "C" int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int mem
     k_pack_record<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(p->run.haloL, p->run.brow_sink, ncol, rec.as<u32>());
     u64 c8[8];
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(record_host, rec.p, recw * sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(land, rec.p, recw * sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipMemcpyAsync(c8, h->ctrl + 8, sizeof(c8), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess) {
       pfd_set_error("pfd_upstream_area_cell_begin: phase A or the download of the boundary record failed");
@@ -530,9 +554,12 @@ extern "C" int pfd_upstream_area_cell_begin(pfd_raster *h, int32_t *out, int mem
   }
   if (rc != PFD_OK) {
     (void)hipStreamSynchronize(h->stream);
+    pfd_pinned_give(pin, pcap);
     delete p;
     return rc;
   }
+  if (pin) memcpy(record_host, pin, recw * sizeof(u32));
+  pfd_pinned_give(pin, pcap);
   h->pending = p;
   return PFD_OK;
 }
@@ -548,16 +575,24 @@ extern "C" int pfd_upstream_area_cell_finish(pfd_raster *h, const uint32_t *all_
   int rc = PFD_OK;
   const size_t recw = 4 * (size_t)h->ncol;
   DevBuf allrec;
+  size_t pcap = 0;
+  void *pin = nullptr;
   if (nblocks > 1) {
-    rc = allrec.alloc((size_t)nblocks * recw * sizeof(u32));
-    if (rc == PFD_OK &&
-        hipMemcpyAsync(allrec.p, all_records_host, (size_t)nblocks * recw * sizeof(u32), hipMemcpyHostToDevice,
-                       h->stream) != hipSuccess) {
+    const size_t nbytes = (size_t)nblocks * recw * sizeof(u32);
+    rc = allrec.alloc(nbytes);
+    const void *src = all_records_host;
+    if (rc == PFD_OK && (pin = pfd_pinned_take(nbytes, &pcap)) != nullptr) {  // (pinned staging: see _begin)
+      memcpy(pin, all_records_host, nbytes);
+      src = pin;
+    }
+    if (rc == PFD_OK && hipMemcpyAsync(allrec.p, src, nbytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
       pfd_set_error("pfd_upstream_area_cell_finish: upload of the boundary records failed");
       rc = PFD_EHIP;
     }
   }
   if (rc == PFD_OK) rc = finish_block(p->run, allrec.as<u32>(), (u32)nblocks, (u32)block, complete);
+  if (rc != PFD_OK) (void)hipStreamSynchronize(h->stream);  // (nothing may still read the staging when it is handed back)
+  pfd_pinned_give(pin, pcap);
   if (rc == PFD_OK) rc = p->out.finish(h->stream);
   delete p;
   h->pending = nullptr;

@@ -6,6 +6,9 @@ import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyflwdir_amd import _hip
+if os.environ.get("PFD_TOOL_RESERVE_GIB"):  # one arena for the working buffers (pfd_reserve): no hipMalloc while timing
+    from pyflwdir_amd import _hip as _h0
+    _h0.reserve(int(float(os.environ["PFD_TOOL_RESERVE_GIB"]) * 2**30))
 L = _hip.lib()
 nrow = int(sys.argv[1]); ncol = int(sys.argv[2]) if len(sys.argv) > 2 else nrow
 nd = int(sys.argv[3]) if len(sys.argv) > 3 else 0

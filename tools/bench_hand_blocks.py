@@ -7,6 +7,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyflwdir_amd import _hip, dist
+if os.environ.get("PFD_TOOL_RESERVE_GIB"):  # one arena for the working buffers (pfd_reserve): no hipMalloc while timing
+    from pyflwdir_amd import _hip as _h0
+    _h0.reserve(int(float(os.environ["PFD_TOOL_RESERVE_GIB"]) * 2**30))
 L = _hip.lib()
 nrow, ncol, nb = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 nd = int(sys.argv[4]) if len(sys.argv) > 4 else 30

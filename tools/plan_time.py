@@ -6,6 +6,9 @@ Prints the `exact_plan` segment (HIP events) and the wall time of the first floa
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyflwdir_amd import _hip
+if os.environ.get("PFD_TOOL_RESERVE_GIB"):  # one arena for the working buffers (pfd_reserve): no hipMalloc while timing
+    from pyflwdir_amd import _hip as _h0
+    _h0.reserve(int(float(os.environ["PFD_TOOL_RESERVE_GIB"]) * 2**30))
 L = _hip.lib()
 nrow, ncol = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
