@@ -28,7 +28,10 @@ for r in range(reps + 1):  # (the first handle warms the allocator and is not re
     h.accuflux(w, _hip.PFD_F32, nodata_f=-9999.0, out=out, memspace=_hip.PFD_DEVICE)
     sync(); t1 = time.perf_counter()
     seg = {s["name"]: s["ms"] for s in h.last_timing()}
+    if r == 0:
+        first = round(1e3 * (t1 - t0), 2)  # this process's very first call: the allocator's (or the arena's) cold path
     if r:
         plan.append(round(seg.get("exact_plan", float("nan")), 2)); wall.append(round(1e3 * (t1 - t0), 2))
     h.close()
-print(f"{nrow}x{ncol} nodata_pct={nd} tilt={tilt}: exact_plan {plan} ms; first accuflux (plan + sweep) {wall} ms")
+print(f"{nrow}x{ncol} nodata_pct={nd} tilt={tilt}: exact_plan {plan} ms; first accuflux (plan + sweep) {wall} ms; the process's "
+      f"first handle {first} ms = {first / min(wall):.2f} x the warm-allocator first call; allocator {_hip.alloc_stats()}")
