@@ -44,7 +44,7 @@ from pyflwdir_amd import _hip  # noqa: E402
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per cell; the split of the 29 B of upstream_area("cell") over the
 # phases that replace build / init / sweep is documented in DESIGN.md §5
-B_ALG = {"upstream_area_cell": 29.0, "accuflux_f32": 33.0, "strahler": 18.0, "basins_u32": 18.0, "hand_f32": 35.0}
+B_ALG = {"upstream_area_cell": 29.0, "accuflux_f32": 33.0, "accuflux_f64": 45.0, "strahler": 18.0, "basins_u32": 18.0, "hand_f32": 35.0}
 B_ALG_PHASE = {"tile_local": 8.0, "exit_graph": 4.0, "tile_final": 17.0}
 # segment -> the kernel it times (names as rocprofv3 prints them); single-launch segments only
 KERNEL_OF = {"tile_local": "void k_tile_local_fast<true, false>(TileArgs)", "tile_final": "void k_tile_final_fast<false, 256>(TileArgs)"}
@@ -511,6 +511,59 @@ def op_lines(nrow, ncol, synth, label, steps, device, ops=("accuflux", "strahler
         b.free()
     _hip.check(_hip.lib().pfd_trim(device))
     return lines
+
+
+def km2_line(nrow, ncol, synth, label, steps, device):
+    """`FlwdirRaster.upstream_area(unit="km2")` on a lat/lon grid — the reference's documented call (pyflwdir.py:770-801,
+    gis_utils.py:379-412): float64 cell areas, one per raster row (pyflwdir_amd/gis.py area_rows), accumulated in the serial
+    loop's operand order by the exact-order engine (pfd_accuflux_rows, what raster.py calls), nodata cells -9999.  The
+    FIRST call on a fresh handle (plan build + sweep: what a one-shot user pays) and the warm call, device-resident."""
+    from pyflwdir_amd import gis
+    from pyflwdir_amd._affine import get_affine
+
+    n = nrow * ncol
+    res = 1.0 / 1200.0  # 3 arc-seconds, centred on 50 N
+    rows = np.ascontiguousarray(gis.area_rows(get_affine()(res, 0.0, 5.0, 0.0, -res, 50.0 + nrow * res / 2), (nrow, ncol), True, unit="m2")
+                                / gis.AREA_FACTORS["km2"])
+    assert rows.dtype == np.float64
+    d8_buf = _hip.synth_d8_device(nrow, ncol, device=device, **synth)
+    out = _hip.DeviceBuffer(n * 8, device)
+    h = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE)
+
+    def call():
+        h.accuflux_rows(rows, _hip.PFD_F64, nodata_i=-9999, nodata_f=-9999.0, has_nodata=1, direction=_hip.PFD_UP, mask_invalid=1,
+                        out=out, memspace=_hip.PFD_DEVICE)
+
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    t0 = time.perf_counter()
+    call()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    per = []
+    h.set_profiling(True)
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        call()
+        per.append((time.perf_counter() - t1) * 1e3)
+    segs = h.last_timing()
+    ms = statistics.median(per)
+    b_alg = B_ALG["accuflux_f64"]
+    # the result against the cell-count pass: on every cell  area[km2] >= count * (smallest cell area) and
+    # <= count * (largest) — a size-independent sanity bound, not a parity claim (parity: uparea_km2_latlon goldens)
+    ach, fa = b_alg * n / (ms * 1e-3) / 1e9, b_alg * n / (first_ms * 1e-3) / 1e9
+    line = dict(op="upstream_area_km2(lat/lon grid, float64)", workload=f"{label}, upstream_area(unit='km2') on a 3-arc-second lat/lon "
+                "grid: float64 row areas through pfd_accuflux_rows (exact-order engine); first call on a fresh handle and warm call",
+                dtype="f64", ms_per_call=round(ms, 3), ms_per_call_min=round(min(per), 3), value=round(n / ms / 1e3, 2), unit="Mcells/s",
+                first_call_on_handle_ms=round(first_ms, 2),
+                roofline=dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 5),
+                              traffic=None, frac_measured=None, alg_bytes_per_cell=b_alg,
+                              phases_ms={s["name"]: round(s["ms"], 3) for s in segs}),
+                roofline_first_call=dict(bound="hbm", achieved=round(fa, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                         frac=round(fa / PEAK_HBM_GBS, 5), alg_bytes_per_cell=b_alg,
+                                         note="first call on a fresh handle: plan build + sweep"))
+    h.close()
+    d8_buf.free()
+    out.free()
+    return [line]
 
 
 N1_RECORD = os.path.join(ROOT, ".bench_n1.json")  # (git-ignored scratch: lets the N > 1 lines quote their speed-up)
@@ -992,6 +1045,7 @@ def secondary_lines(a, device):
               n_valid=c2["n_valid"], n_pits=c2["n_pits"], roofline=l2["roofline"])], f"C2 10000x10000 {a.regime}")
     add(op_lines(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", 3, device),
         f"C3 30000x30000 {a.regime}")
+    add(km2_line(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", 3, device), f"C3 30000x30000 {a.regime}")
     # configs[4]'s shape: a MERIT-Hydro-like 3-arcsec tile, 72000 x 36000 cells (36000 rows), rough terrain, 30 % ocean
     add(op_lines(36000, 72000, C5_SYNTH, "36000x72000 synthetic D8 (rough regime, 30 % nodata: BASELINE configs[4] shape)", 2,
                  device, ops=("hand", "basins")), "C5 36000x72000 rough, 30 % nodata")
