@@ -463,24 +463,96 @@ __global__ void __launch_bounds__(256) k_plan_chain_lens(const u32 *__restrict__
   cpos_in[c] = l;  // (exclusive scan in place -> first position of the chain)
 }
 
-// position of every trunk cell: chain base + distance from the chain head; w = slots the cell needs
-// (one cell per thread: eight cells per thread with the lookups batched level by level measured 8.4 against 7.5 ms —
-//  fewer threads in flight hide less of the three dependent gathers)
+// position of every trunk cell: chain base + distance from the chain head; w = slots the cell needs.
+// One workgroup per 64 x 64 TILE (round 5; a strip of 256 cells of a raster row before): the records land in chain
+// order, and a chain crosses a tile in a run of ~64 consecutive positions — 1 KB of 16-byte records that the L2 merges
+// before they leave — where a row strip meets every chain once and pays a sector per record (the same observation as
+// k_xtrunk_unscatter's: 7.5 -> see DESIGN 4.5).  The position also goes into ptmp[x] (the plan's cslot array, coalesced):
+// k_plan_cslot turns it into the slot once the slots are known, so that nobody stores into raster order from chain order.
 __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict__ hinfo, const u32 *__restrict__ hops,
                                                       const u32 *__restrict__ tailnum, const u32 *__restrict__ tidx_at,
-                                                      const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos, u32 n,
-                                                      uint4 *__restrict__ urec) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= n) return;
-  const u32 info = hinfo[x];  // (never 0 for a trunk cell, 0 elsewhere)
-  if (!info) return;
-  const u32 tn = tailnum[x];
-  if (!tn) return;
-  const u32 c = tidx_at[tn - 1];  // (chain ids since k_plan_chain_lens)
-  const u32 p = cpos[c] + clen_pos[c] - 1 - hops[x];
-  // one 16-byte record per position — cell, chain, hinfo — so that k_plan_expand, which runs in position order, finds
-  // everything in one coalesced load instead of five dependent gathers per cell
-  urec[p] = make_uint4(x, c, info, 0u);
+                                                      const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos, u32 nrow,
+                                                      u32 ncol, uint4 *__restrict__ urec, u32 *__restrict__ ptmp) {
+  const u32 tid = threadIdx.x;
+  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  u32 inf[4][4], tn[4][4], hp[4][4], x0s[4];
+  bool any[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // all loads of the four quads first
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 gr = r0 + (l0 >> 6), gc = c0 + (l0 & 63);
+    x0s[j] = gr * ncol + gc;
+    any[j] = false;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) inf[j][b] = tn[j][b] = hp[j][b] = 0;
+    if (gr >= nrow || gc >= ncol) continue;
+    if (gc + 3 < ncol) {
+      uint2 i4;
+      __builtin_memcpy(&i4, hinfo + x0s[j], 8);
+      inf[j][0] = i4.x & 0xFFFFu, inf[j][1] = i4.x >> 16, inf[j][2] = i4.y & 0xFFFFu, inf[j][3] = i4.y >> 16;
+    } else {
+      for (u32 b = 0; b < 4u && gc + b < ncol; ++b) inf[j][b] = hinfo[x0s[j] + b];
+    }
+    any[j] = (inf[j][0] | inf[j][1] | inf[j][2] | inf[j][3]) != 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!any[j]) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (inf[j][b]) tn[j][b] = tailnum[x0s[j] + b], hp[j][b] = hops[x0s[j] + b];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (!any[j]) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (!inf[j][b] || !tn[j][b]) continue;
+      const u32 x = x0s[j] + (u32)b;
+      const u32 c = tidx_at[tn[j][b] - 1];  // (chain ids since k_plan_chain_lens)
+      const u32 p = cpos[c] + clen_pos[c] - 1 - hp[j][b];
+      // one 16-byte record per position — cell, chain, hinfo — so that k_plan_expand, which runs in position order, finds
+      // everything in one coalesced load instead of five dependent gathers per cell
+      urec[p] = make_uint4(x, c, inf[j][b], 0u);
+      ptmp[x] = p;
+    }
+  }
+}
+// cslot[x]: position -> slot (spos[p], written by k_plan_expand in position order), and the number of post slots into
+// the trunk mark; tile-shaped like the scatter (the gather from chain order hits the runs the tile holds)
+__global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__ hinfo, const u32 *__restrict__ tailnum,
+                                                    const u32 *__restrict__ spos, u32 nrow, u32 ncol, u32 *__restrict__ cslot,
+                                                    u8 *__restrict__ lh) {
+  const u32 tid = threadIdx.x;
+  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 l0 = 4u * tid + 1024u * j;
+    const u32 gr = r0 + (l0 >> 6), gc = c0 + (l0 & 63);
+    if (gr >= nrow || gc >= ncol) continue;
+    const u32 x0 = gr * ncol + gc;
+    u32 inf[4] = {0, 0, 0, 0};
+    if (gc + 3 < ncol) {
+      uint2 i4;
+      __builtin_memcpy(&i4, hinfo + x0, 8);
+      inf[0] = i4.x & 0xFFFFu, inf[1] = i4.x >> 16, inf[2] = i4.y & 0xFFFFu, inf[3] = i4.y >> 16;
+    } else {
+      for (u32 b = 0; b < 4u && gc + b < ncol; ++b) inf[b] = hinfo[x0 + b];
+    }
+    if (!(inf[0] | inf[1] | inf[2] | inf[3])) continue;
+    u32 pp[4], tn[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) tn[b] = inf[b] ? tailnum[x0 + b] : 0u, pp[b] = inf[b] ? cslot[x0 + b] : 0u;
+    u32 sl[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sl[b] = (inf[b] && tn[b]) ? spos[pp[b]] : 0u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (!inf[b] || !tn[b]) continue;
+      cslot[x0 + b] = sl[b];  // (the sweeps find a trunk cell's value in chain order through it: no scatter pass per round)
+      if ((inf[b] >> 12) & 7u) lh[x0 + b] = (u8)(XL_TRUNK + ((inf[b] >> 12) & 7u));  // (up-sweeps: the value sits behind the post slots)
+    }
+  }
 }
 struct XRecSlots {  // slots a position needs: 1 + its post slots (0 for a position nobody wrote)
   __device__ u32 operator()(const uint4 &r) const { return r.z ? 1u + ((r.z >> 12) & 7u) : 0u; }
@@ -516,20 +588,21 @@ __global__ void __launch_bounds__(256) k_plan_chains(const u32 *__restrict__ cpo
   clen[c] = (S[p + l] - u0) | ((((u32)hinfo[t] >> 12) & 7u) << 29);
   adj[c] = cstart_pad[c] - u0;
 }
-__global__ void __launch_bounds__(256) k_plan_expand(const uint4 *__restrict__ urec, const u32 *__restrict__ S,
+// (S is read at the thread's own position only: the padded slot of the position replaces it in place — k_plan_cslot
+//  carries it to the cell in raster order)
+__global__ void __launch_bounds__(256) k_plan_expand(const uint4 *__restrict__ urec, u32 *__restrict__ S,
                                                      const u32 *__restrict__ adj, Geo g, u32 npos, u32 *__restrict__ scell,
-                                                     uint16_t *__restrict__ sinfo, u32 *__restrict__ spost,
-                                                     u32 *__restrict__ cslot, u8 *__restrict__ lh) {
+                                                     uint16_t *__restrict__ sinfo, u32 *__restrict__ spost) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npos) return;
   const uint4 rec = urec[p];
   const u32 x = rec.x;
   const u32 info = rec.z;
+  if (!info) return;  // (a position nobody wrote: cannot happen on a consistent forest)
   u32 s = S[p] + adj[rec.y];
+  S[p] = s;
   scell[s] = x;
   sinfo[s] = (uint16_t)info;
-  cslot[x] = s;  // (the sweeps find a trunk cell's value in chain order through it: no scatter pass per round)
-  if ((info >> 12) & 7u) lh[x] = (u8)(XL_TRUNK + ((info >> 12) & 7u));  // (up-sweeps: the value sits behind the post slots)
   const u32 hs = (info >> 8) & 0xFu;
   if (hs < 8 && (info >> 12)) {
     const i64 hoff = (i64)d8_dr((int)hs) * (i64)g.ncol + d8_dc((int)hs);
@@ -958,8 +1031,10 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if ((rc = ucell.alloc((npos + 1) * sizeof(uint4))) != PFD_OK) return fail(rc);
   if ((rc = w.alloc((npos + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemsetAsync(ucell.p, 0, (npos + 1) * sizeof(uint4), h->stream) != hipSuccess) return fail(PFD_EHIP);
-  k_plan_scatter<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at,
-                                                          cpos.as<u32>(), clenp.as<u32>(), n, ucell.as<uint4>());
+  if ((rc = pfd_dmalloc((void **)&p->cslot, ((size_t)n + 64) * sizeof(u32))) != PFD_OK) return fail(rc);
+  k_plan_scatter<<<dim3(ntc, ntr), 256, 0, h->stream>>>(hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at,
+                                                        cpos.as<u32>(), clenp.as<u32>(), (u32)h->nrow, (u32)h->ncol,
+                                                        ucell.as<uint4>(), p->cslot);
   XDBG(h, "k_plan_scatter");
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   // slot of a position = exclusive scan of the slots the positions before it need (in place)
@@ -997,7 +1072,6 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   const size_t nwords = nsl / 32 + 4;
   if ((rc = pfd_dmalloc((void **)&p->scell, nsl * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->sinfo, nsl * sizeof(uint16_t) + 16)) != PFD_OK) return fail(rc);
-  if ((rc = pfd_dmalloc((void **)&p->cslot, ((size_t)n + 64) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->spost, nwords * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->cstart, std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->clen, std::max<size_t>(nchain, 1) * sizeof(u32))) != PFD_OK) return fail(rc);
@@ -1012,8 +1086,11 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
                                                                 (u32)nchain, p->cstart, p->clen, adj.as<u32>());
   XDBG(h, "k_plan_chains");
     k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<uint4>(), w.as<u32>(), adj.as<u32>(), h->geo, (u32)npos,
-                                                              p->scell, p->sinfo, p->spost, p->cslot, p->lh);
+                                                              p->scell, p->sinfo, p->spost);
   XDBG(h, "k_plan_expand");
+    k_plan_cslot<<<dim3(ntc, ntr), 256, 0, h->stream>>>(hinfo.as<uint16_t>(), tailnum.as<u32>(), w.as<u32>(), (u32)h->nrow,
+                                                        (u32)h->ncol, p->cslot, p->lh);
+  XDBG(h, "k_plan_cslot");
   xdigest(h, "ucell", ucell.p, (size_t)npos * 16);
   xdigest(h, "scell", p->scell, (size_t)p->nslot * 4);
   xdigest(h, "sinfo", p->sinfo, (size_t)p->nslot * 2);
