@@ -507,8 +507,12 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict
     if (!any[j]) continue;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if (!inf[j][b] || !tn[j][b]) continue;
+      if (!inf[j][b]) continue;
       const u32 x = x0s[j] + (u32)b;
+      if (!tn[j][b]) {  // (a trunk cell whose heavy path has no end: cannot happen on an acyclic forest)
+        ptmp[x] = NONE32;
+        continue;
+      }
       const u32 c = tidx_at[tn[j][b] - 1];  // (chain ids since k_plan_chain_lens)
       const u32 p = cpos[c] + clen_pos[c] - 1 - hp[j][b];
       // one 16-byte record per position — cell, chain, hinfo — so that k_plan_expand, which runs in position order, finds
@@ -520,8 +524,7 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict
 }
 // cslot[x]: position -> slot (spos[p], written by k_plan_expand in position order), and the number of post slots into
 // the trunk mark; tile-shaped like the scatter (the gather from chain order hits the runs the tile holds)
-__global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__ hinfo, const u32 *__restrict__ tailnum,
-                                                    const u32 *__restrict__ spos, u32 nrow, u32 ncol, u32 *__restrict__ cslot,
+__global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__ hinfo, const u32 *__restrict__ spos, u32 nrow, u32 ncol, u32 *__restrict__ cslot,
                                                     u8 *__restrict__ lh) {
   const u32 tid = threadIdx.x;
   const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
@@ -540,15 +543,18 @@ __global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__
       for (u32 b = 0; b < 4u && gc + b < ncol; ++b) inf[b] = hinfo[x0 + b];
     }
     if (!(inf[0] | inf[1] | inf[2] | inf[3])) continue;
-    u32 pp[4], tn[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) tn[b] = inf[b] ? tailnum[x0 + b] : 0u, pp[b] = inf[b] ? cslot[x0 + b] : 0u;
+    u32 pp[4];
+    if (gc + 3 < ncol) {
+      __builtin_memcpy(pp, cslot + x0, 16);  // (positions of the trunk cells of the quad; whatever the others hold)
+    } else {
+      for (u32 b = 0; b < 4u; ++b) pp[b] = gc + b < ncol ? cslot[x0 + b] : NONE32;
+    }
     u32 sl[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) sl[b] = (inf[b] && tn[b]) ? spos[pp[b]] : 0u;
+    for (int b = 0; b < 4; ++b) sl[b] = (inf[b] && pp[b] != NONE32) ? spos[pp[b]] : 0u;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if (!inf[b] || !tn[b]) continue;
+      if (!inf[b] || pp[b] == NONE32) continue;
       cslot[x0 + b] = sl[b];  // (the sweeps find a trunk cell's value in chain order through it: no scatter pass per round)
       if ((inf[b] >> 12) & 7u) lh[x0 + b] = (u8)(XL_TRUNK + ((inf[b] >> 12) & 7u));  // (up-sweeps: the value sits behind the post slots)
     }
@@ -1088,7 +1094,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
     k_plan_expand<<<cdiv_u32(npos, 256), 256, 0, h->stream>>>(ucell.as<uint4>(), w.as<u32>(), adj.as<u32>(), h->geo, (u32)npos,
                                                               p->scell, p->sinfo, p->spost);
   XDBG(h, "k_plan_expand");
-    k_plan_cslot<<<dim3(ntc, ntr), 256, 0, h->stream>>>(hinfo.as<uint16_t>(), tailnum.as<u32>(), w.as<u32>(), (u32)h->nrow,
+    k_plan_cslot<<<dim3(ntc, ntr), 256, 0, h->stream>>>(hinfo.as<uint16_t>(), w.as<u32>(), (u32)h->nrow,
                                                         (u32)h->ncol, p->cslot, p->lh);
   XDBG(h, "k_plan_cslot");
   xdigest(h, "ucell", ucell.p, (size_t)npos * 16);

@@ -51,6 +51,10 @@ struct PathArgs {
   // rounds leave in every exit's pointer the LAST exit of its chain, whose target entry holds the pit
   u32 *eend;        // [nslots]
   u32 *out2;        // [n]
+  // a pass over some tile rows only, into a window of rows (row blocks of basins: the boundary rows first, the rest when
+  // the labels of the halo cells are known): tile row = blockIdx.y + tr_off; `out` holds the rows [out_row0, out_row0 + out_nrows)
+  u32 tr_off = 0, out_row0 = 0, out_nrows = 0xFFFFFFFFu;
+  const u32 *halo32 = nullptr;  // label mode with ids32: labels of the halo cells of a row block ([2 * ncol], tag -> label)
 };
 
 template <int MODE, bool FINAL, bool TAIL = false>
@@ -59,7 +63,7 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2^k-th ancestor | PDONE once saturated
   __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
   const u32 tid = threadIdx.x;
-  const u32 tc = blockIdx.x, tr = blockIdx.y;
+  const u32 tc = blockIdx.x, tr = blockIdx.y + a.tr_off;
   const u32 sbase = sslot_base(tr, tc, a.nstc);
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   {
@@ -232,14 +236,19 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
           val = V[root];  // outlet at the end of the in-tile path (the cell's own seed, or what the exit reaches)
           // (32-bit labels straight from the table: saves the pass that maps numbers to labels — 8 bytes per cell)
           if (a.ids32) {  // (unconditional load from a clamped index, then the select: 16 loads in flight, not 16 round trips)
-            const u32 id = a.ids32[val ? val - 1u : 0u];
-            val = val ? id : 0u;
+            const bool tag = a.halo32 != nullptr && (val & 0x80000000u) != 0u;  // (BTAG: the path leaves through a halo cell)
+            const u32 id = a.ids32[(val && !tag) ? val - 1u : 0u];
+            u32 hl = 0;
+            if (a.halo32) hl = a.halo32[tag ? ((val >> 30) & 1u) * a.ncol + (val & 0x3FFFFFFFu) : 0u];
+            val = tag ? hl : (val ? id : 0u);
           }
         }
         o4[b] = val;
       }
       if (a.out == nullptr) continue;  // (statistics only: pfd_graph_stats)
-      u32 *dst = a.out + (size_t)gr * a.ncol + (size_t)gc0;
+      const i64 orow = gr - (i64)a.out_row0;
+      if (orow < 0 || orow >= (i64)a.out_nrows) continue;  // (rows outside the window: another pass writes them)
+      u32 *dst = a.out + (size_t)orow * a.ncol + (size_t)gc0;
       if (gc0 + 3 < (i64)a.ncol && (((size_t)dst) & 15) == 0) {
         *(uint4 *)dst = make_uint4(o4[0], o4[1], o4[2], o4[3]);
       } else {
@@ -495,8 +504,77 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
 // Reference: basins.basins + core.fillnodata_upstream (pyflwdir/basins.py:12-18, core.py:120-146).
 // ---------------------------------------------------------------------------------------------
 #define BTAG 0x80000000u
+__global__ void __launch_bounds__(256) k_zero_seed_tiles(const u8 *__restrict__ tflag, u32 nrow, u32 ncol, u32 ntc, u32 *__restrict__ seed);
+// The label query in two halves (round 5): start() = local tile pass + exit rounds; final_rows() = the final tile pass
+// over some tile rows into a window of rows.  A row block runs the final pass on the two tile rows that hold its
+// boundary rows first (their numbers / tags make the record that leaves the GPU) and on everything only when the labels
+// of its halo cells have come back — so the block's labels are written ONCE, by the tile pass itself (before: the
+// numbers of every cell, then a pass of their own that mapped numbers and tags to labels: 8 bytes per cell more, and
+// a 4-byte-per-cell memset of the seeds that the tile flags make unnecessary).
+struct LabelRun {
+  DevBuf buf, wdone, seed, tflag;
+  PathArgs a{};
+  u32 ntr = 0, ntc = 0;
+  bool done = false;
+  int start(pfd_raster *h) {  // seed / tflag are filled by the caller
+    ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
+    const u32 nstc = cdiv_u32(ntc, SG);
+    const size_t nslots = (size_t)cdiv_u32(ntr, SG) * nstc * SSL;
+    if (nslots >= 0x3FFFFFFFull || ntr > 65535u) {
+      pfd_set_error("the block is too large for the tiled label query");
+      return PFD_EUNSUPPORTED;
+    }
+    PFDCHK(buf.alloc(5 * nslots * sizeof(u32)));
+    u32 *b = buf.as<u32>();
+    u32 *xtgt = b + 2 * nslots, *elink = b + 3 * nslots, *eval = b + 4 * nslots;
+    u64 *WJ = buf.as<u64>();
+    HIPCHK(hipMemsetAsync(h->ctrl + 8, 0, 8 * sizeof(u64), h->stream));
+    HIPCHK(hipMemsetAsync(xtgt, 0xFF, nslots * sizeof(u32), h->stream));  // slots of tiles that do not exist
+    a = PathArgs{h->ncode, (u32)h->nrow, (u32)h->ncol, ntr, ntc, nstc, xtgt, elink, eval, nullptr, seed.as<u32>(), nullptr,
+                 tflag.as<u8>(), nullptr, h->ctrl, nullptr, nullptr};
+    k_path<MODE_LABEL, false><<<dim3(ntc, ntr), 256, 0, h->stream>>>(a);
+    const u32 sgrid = cdiv_u32(nslots, 256);
+    k_xinit<MODE_LABEL><<<sgrid, 256, 0, h->stream>>>(xtgt, elink, eval, WJ, (u32)nslots, h->ctrl);
+    KCHK();
+    PFDCHK(wdone.alloc(nslots / 64 + 64));
+    HIPCHK(hipMemsetAsync(wdone.p, 0, nslots / 64 + 64, h->stream));
+    done = false;
+    int batch = 2;
+    for (u32 span = 1; span < ntr + ntc; span <<= 1) ++batch;
+    for (int rounds = 0; rounds < 40 && !done;) {
+      for (int r = 0; r + 1 < batch; ++r, ++rounds) k_xround<MODE_LABEL, false><<<sgrid, 256, 0, h->stream>>>(WJ, (u32)nslots, h->ctrl, wdone.as<u8>());
+      HIPCHK(hipMemsetAsync(h->ctrl + P_XACTIVE, 0, sizeof(u64), h->stream));
+      k_xround<MODE_LABEL, true><<<sgrid, 256, 0, h->stream>>>(WJ, (u32)nslots, h->ctrl, wdone.as<u8>());
+      ++rounds;
+      KCHK();
+      u64 active = 0;
+      HIPCHK(hipMemcpyAsync(&active, h->ctrl + P_XACTIVE, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      done = active == 0;
+      batch = 2;
+    }
+    a.xres = WJ;
+    return PFD_OK;
+  }
+  // final tile pass over the tile rows [tr0, tr0 + ntrs) into `out` = the rows [row0, row0 + nrows) of the block
+  int final_rows(pfd_raster *h, u32 tr0, u32 ntrs, u32 *out, u32 row0, u32 nrows, const u32 *ids32, const u32 *halo32) {
+    PathArgs f = a;
+    f.tr_off = tr0, f.out = out, f.out_row0 = row0, f.out_nrows = nrows, f.ids32 = ids32, f.halo32 = halo32;
+    k_path<MODE_LABEL, true><<<dim3(ntc, ntrs), 256, 0, h->stream>>>(f);
+    KCHK();
+    return PFD_OK;
+  }
+  int unsaturated(pfd_raster *h, bool *bad) {  // (synchronises)
+    u64 c[6];
+    HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *bad = !done || c[P_UNSAT - 8] != 0;
+    return PFD_OK;
+  }
+};
 struct BasinsPending {
-  DevBuf num, ids;
+  DevBuf num, ids, brows;  // num: only for labels that are not 32 bits wide; brows: the numbers of the two boundary tile rows
+  LabelRun run;
   OutArg out;
   u32 k = 0;
   int id_size = 0;
@@ -518,11 +596,19 @@ __global__ void k_seed_halo(const u8 *__restrict__ ncode, u32 ncol, u32 halo_top
   const size_t cell = (size_t)(side ? nrow - 1 : 0) * ncol + col;
   if (ncode[cell] == D8_HALO) seed[cell] = BTAG | (side << 30) | col;
 }
+// sparse seeding of a row block (see k_flag_seed_tiles): the tiles that hold an outlet (indices relative to the own rows)
+__global__ void k_flag_seed_tiles_block(const i64 *__restrict__ idx, u32 k, u32 row_off, u32 ncol, u32 ntc, u8 *__restrict__ tflag) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k) return;
+  const u32 x = (u32)idx[t], r = x / ncol + row_off, c = x % ncol;
+  tflag[(size_t)(r >> 6) * ntc + (c >> 6)] = 1;
+}
 template <class L>
 __device__ __forceinline__ u64 label_bits(const L *ids, u32 num) { return num ? (u64)ids[num - 1] : 0ull; }
+// (num_first / num_last: the numbers of the first / last OWN row, wherever the caller keeps them)
 template <class L>
-__global__ void k_basin_record(const u8 *__restrict__ ncode, const u32 *__restrict__ num, const L *__restrict__ ids,
-                               u32 ncol, u32 halo_top, u32 own_rows, u32 *__restrict__ rec) {
+__global__ void k_basin_record(const u8 *__restrict__ ncode, const u32 *__restrict__ num_first, const u32 *__restrict__ num_last,
+                               const L *__restrict__ ids, u32 ncol, u32 halo_top, u32 own_rows, u32 *__restrict__ rec) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * ncol) return;
   const u32 side = t / ncol, col = t % ncol;
@@ -530,7 +616,7 @@ __global__ void k_basin_record(const u8 *__restrict__ ncode, const u32 *__restri
   u32 kind = 0;
   u64 val = 0;
   if (ncode[cell] != D8_MV) {
-    const u32 v = num[cell];
+    const u32 v = side ? num_last[col] : num_first[col];
     if (v & BTAG) {
       kind = 1;
       val = v & ~BTAG;
@@ -595,16 +681,19 @@ extern "C" int pfd_basins_begin(pfd_raster *h, const int64_t *outlets, const voi
   h->pending_basins = p;
   p->k = ku;
   p->id_size = id_size;
+  LabelRun &run = p->run;
+  const u32 ntr = cdiv_u32((u64)h->nrow, TS), ntc = cdiv_u32((u64)h->ncol, TS);
   InArg di;
-  DevBuf seed;
   int rc = di.bind(ku ? uidx.data() : nullptr, (size_t)ku * sizeof(i64), PFD_HOST, h->stream);
   if (rc == PFD_OK) rc = p->ids.alloc(std::max<size_t>((size_t)ku * id_size, 8));
   if (rc == PFD_OK && ku &&
       hipMemcpyAsync(p->ids.p, uids.data(), (size_t)ku * id_size, hipMemcpyHostToDevice, h->stream) != hipSuccess)
     rc = PFD_EHIP;
   if (rc == PFD_OK) rc = p->out.bind(out, (size_t)n_own * id_size, memspace);
-  if (rc == PFD_OK) rc = seed.alloc((size_t)n * sizeof(u32) + 64);
-  if (rc == PFD_OK) rc = p->num.alloc((size_t)n * sizeof(u32));
+  if (rc == PFD_OK) rc = run.seed.alloc((size_t)n * sizeof(u32) + 64);  // (+ slack: quads are loaded 16 bytes at a time)
+  if (rc == PFD_OK) rc = run.tflag.alloc((size_t)ntr * ntc);
+  if (rc == PFD_OK && id_size != 4) rc = p->num.alloc((size_t)n * sizeof(u32));  // (32-bit labels are written by the tile pass itself)
+  if (rc == PFD_OK) rc = p->brows.alloc(2 * (size_t)TS * ncol * sizeof(u32));
   if (rc != PFD_OK) {
     pfd_free_pending_basins(h);
     return rc;
@@ -615,8 +704,10 @@ extern "C" int pfd_basins_begin(pfd_raster *h, const int64_t *outlets, const voi
     return code;
   };
   if (h->acyclic == 0) {  // (see pfd_basins_tiled: the label query must not hide a cycle)
+    DevBuf rk;
+    if ((rc = rk.alloc((size_t)n * sizeof(u32))) != PFD_OK) return fail(rc);
     int ok_rank = 0;
-    if ((rc = run_paths<MODE_RANK>(h, nullptr, p->num.as<u32>(), &ok_rank, nullptr)) != PFD_OK) return fail(rc);
+    if ((rc = run_paths<MODE_RANK>(h, nullptr, rk.as<u32>(), &ok_rank, nullptr)) != PFD_OK) return fail(rc);
     h->acyclic = ok_rank ? 1 : -1;
   }
   if (h->acyclic < 0) {
@@ -624,26 +715,39 @@ extern "C" int pfd_basins_begin(pfd_raster *h, const int64_t *outlets, const voi
                   "valid flow direction raster (FlwdirRaster.isvalid)");
     return fail(PFD_EUNSUPPORTED);
   }
-  if (hipMemsetAsync(seed.p, 0, (size_t)n * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
-  if (ku) k_seed_block<<<cdiv_u32(ku, 256), 256, 0, h->stream>>>((const i64 *)di.dev, ku, (u32)h->halo_top, ncol, seed.as<u32>());
+  // seeds: the outlets' numbers and the halo cells' tags, in the tiles that hold one — the other tiles never read theirs
+  u8 *tflag = run.tflag.as<u8>();
+  if (hipMemsetAsync(tflag, 0, (size_t)ntr * ntc, h->stream) != hipSuccess) return fail(PFD_EHIP);
+  if (ku) k_flag_seed_tiles_block<<<cdiv_u32(ku, 256), 256, 0, h->stream>>>((const i64 *)di.dev, ku, (u32)h->halo_top, ncol, ntc, tflag);
+  if (h->halo_top && hipMemsetAsync(tflag, 1, ntc, h->stream) != hipSuccess) return fail(PFD_EHIP);
+  if (h->halo_bot && hipMemsetAsync(tflag + (size_t)(ntr - 1) * ntc, 1, ntc, h->stream) != hipSuccess) return fail(PFD_EHIP);
+  k_zero_seed_tiles<<<dim3(ntc, ntr), 256, 0, h->stream>>>(tflag, (u32)h->nrow, ncol, ntc, run.seed.as<u32>());
+  if (ku) k_seed_block<<<cdiv_u32(ku, 256), 256, 0, h->stream>>>((const i64 *)di.dev, ku, (u32)h->halo_top, ncol, run.seed.as<u32>());
   k_seed_halo<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(h->ncode, ncol, (u32)h->halo_top, (u32)h->halo_bot,
-                                                              (u32)h->nrow, seed.as<u32>());
-  int complete = 0;
+                                                              (u32)h->nrow, run.seed.as<u32>());
+  if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   pfd_seg_begin(h, "tile_labels");
-  if ((rc = run_paths<MODE_LABEL>(h, seed.as<u32>(), p->num.as<u32>(), &complete, nullptr)) != PFD_OK) return fail(rc);
-  pfd_seg_end(h, 2);
-  if (!complete) {
+  if ((rc = run.start(h)) != PFD_OK) return fail(rc);
+  // the numbers of the two boundary rows: the final pass on the tile rows that hold them, into a window of TS rows each
+  const u32 rf = (u32)h->halo_top, rl = (u32)(h->halo_top + h->own_rows - 1);
+  const u32 trf = rf / TS, trl = rl / TS;
+  u32 *bw = p->brows.as<u32>();
+  if ((rc = run.final_rows(h, trf, 1, bw, trf * TS, TS, nullptr, nullptr)) != PFD_OK) return fail(rc);
+  if ((rc = run.final_rows(h, trl, 1, bw + (size_t)TS * ncol, trl * TS, TS, nullptr, nullptr)) != PFD_OK) return fail(rc);
+  pfd_seg_end(h, 4);
+  if (!run.done) {
     pfd_set_error("pfd_basins_begin: the label query did not converge (cycles)");
     return fail(PFD_EUNSUPPORTED);
   }
   DevBuf rec;
   if ((rc = rec.alloc(6 * (size_t)ncol * sizeof(u32))) != PFD_OK) return fail(rc);
   const u32 g = cdiv_u32(2 * ncol, 256);
+  const u32 *nf = bw + (size_t)(rf - trf * TS) * ncol, *nl = bw + (size_t)TS * ncol + (size_t)(rl - trl * TS) * ncol;
   switch (id_size) {
-    case 1: k_basin_record<u8><<<g, 256, 0, h->stream>>>(h->ncode, p->num.as<u32>(), p->ids.as<u8>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
-    case 2: k_basin_record<uint16_t><<<g, 256, 0, h->stream>>>(h->ncode, p->num.as<u32>(), p->ids.as<uint16_t>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
-    case 4: k_basin_record<u32><<<g, 256, 0, h->stream>>>(h->ncode, p->num.as<u32>(), p->ids.as<u32>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
-    default: k_basin_record<u64><<<g, 256, 0, h->stream>>>(h->ncode, p->num.as<u32>(), p->ids.as<u64>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
+    case 1: k_basin_record<u8><<<g, 256, 0, h->stream>>>(h->ncode, nf, nl, p->ids.as<u8>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
+    case 2: k_basin_record<uint16_t><<<g, 256, 0, h->stream>>>(h->ncode, nf, nl, p->ids.as<uint16_t>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
+    case 4: k_basin_record<u32><<<g, 256, 0, h->stream>>>(h->ncode, nf, nl, p->ids.as<u32>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
+    default: k_basin_record<u64><<<g, 256, 0, h->stream>>>(h->ncode, nf, nl, p->ids.as<u64>(), ncol, (u32)h->halo_top, (u32)h->own_rows, rec.as<u32>()); break;
   }
   if (hipMemcpyAsync(record_host, rec.p, 6 * (size_t)ncol * sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess)
@@ -720,22 +824,43 @@ extern "C" int pfd_basins_finish(pfd_raster *h, const uint32_t *all_records_host
     if (nb < 0 || nb >= nblocks) continue;
     for (u32 c = 0; c < ncol; ++c) halo[(size_t)side * ncol + c] = lab[(size_t)(nb * 2 + (1 - (i64)side)) * ncol + c];
   }
-  InArg hl;
-  int rc = hl.bind(halo.data(), halo.size() * sizeof(u64), PFD_HOST, h->stream);
-  if (rc == PFD_OK) {
-    const u32 n_own = (u32)(h->own_rows * h->ncol);
-    const u32 *num = p->num.as<u32>() + (size_t)h->halo_top * ncol;
-    const u32 g = cdiv_u32(n_own, 256);
-    pfd_seg_begin(h, "labels_out");
-    switch (p->id_size) {
-      case 1: k_labels_out_block<u8><<<g, 256, 0, h->stream>>>(num, p->ids.as<u8>(), (const u64 *)hl.dev, ncol, n_own, (u8 *)p->out.dev); break;
-      case 2: k_labels_out_block<uint16_t><<<g, 256, 0, h->stream>>>(num, p->ids.as<uint16_t>(), (const u64 *)hl.dev, ncol, n_own, (uint16_t *)p->out.dev); break;
-      case 4: k_labels_out_block<u32><<<g, 256, 0, h->stream>>>(num, p->ids.as<u32>(), (const u64 *)hl.dev, ncol, n_own, (u32 *)p->out.dev); break;
-      default: k_labels_out_block<u64><<<g, 256, 0, h->stream>>>(num, p->ids.as<u64>(), (const u64 *)hl.dev, ncol, n_own, (u64 *)p->out.dev); break;
-    }
+  // the final tile pass, now that every path end has a label: 32-bit labels are written by the pass itself (numbers and
+  // tags through the two tables), other widths through the numbers of every cell and one mapping pass
+  int rc = PFD_OK;
+  const u32 ntr = p->run.ntr;
+  bool bad = false;
+  if (p->id_size == 4) {
+    std::vector<u32> halo32(halo.size());
+    for (size_t i = 0; i < halo.size(); ++i) halo32[i] = (u32)halo[i];
+    InArg hl;
+    rc = hl.bind(halo32.data(), halo32.size() * sizeof(u32), PFD_HOST, h->stream);
+    pfd_seg_begin(h, "tile_labels_final");
+    if (rc == PFD_OK)
+      rc = p->run.final_rows(h, 0, ntr, (u32 *)p->out.dev, (u32)h->halo_top, (u32)h->own_rows, p->ids.as<u32>(), (const u32 *)hl.dev);
     pfd_seg_end(h, 1);
-    if (hipGetLastError() != hipSuccess) rc = PFD_EHIP;
+    if (rc == PFD_OK) rc = p->run.unsaturated(h, &bad);  // (synchronises: hl is released on return)
+  } else {
+    InArg hl;
+    rc = hl.bind(halo.data(), halo.size() * sizeof(u64), PFD_HOST, h->stream);
+    pfd_seg_begin(h, "tile_labels_final");
+    if (rc == PFD_OK) rc = p->run.final_rows(h, 0, ntr, p->num.as<u32>(), 0, (u32)h->nrow, nullptr, nullptr);
+    pfd_seg_end(h, 1);
+    if (rc == PFD_OK) {
+      const u32 n_own = (u32)(h->own_rows * h->ncol);
+      const u32 *num = p->num.as<u32>() + (size_t)h->halo_top * ncol;
+      const u32 g = cdiv_u32(n_own, 256);
+      pfd_seg_begin(h, "labels_out");
+      switch (p->id_size) {
+        case 1: k_labels_out_block<u8><<<g, 256, 0, h->stream>>>(num, p->ids.as<u8>(), (const u64 *)hl.dev, ncol, n_own, (u8 *)p->out.dev); break;
+        case 2: k_labels_out_block<uint16_t><<<g, 256, 0, h->stream>>>(num, p->ids.as<uint16_t>(), (const u64 *)hl.dev, ncol, n_own, (uint16_t *)p->out.dev); break;
+        default: k_labels_out_block<u64><<<g, 256, 0, h->stream>>>(num, p->ids.as<u64>(), (const u64 *)hl.dev, ncol, n_own, (u64 *)p->out.dev); break;
+      }
+      pfd_seg_end(h, 1);
+      if (hipGetLastError() != hipSuccess) rc = PFD_EHIP;
+    }
+    if (rc == PFD_OK) rc = p->run.unsaturated(h, &bad);
   }
+  if (rc == PFD_OK && bad) *complete = 0;
   if (rc == PFD_OK) rc = p->out.finish(h->stream);
   else (void)hipStreamSynchronize(h->stream);
   pfd_free_pending_basins(h);

@@ -1419,7 +1419,11 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
       HandSeeded<double> op{{h->ncode, h->geo, (const u8 *)dr.dev, (const double *)el.dev, (double *)o.dev}, (const double *)sd.dev, rf, rl};
       PFDCHK(run_down(h, op, "sweep_hand_block"));
     }
-    PFDCHK(hand_block_collect(h, st, (const double *)o.dev, false));  // one scan: the unknown cells (own rows: never halo cells)
+    if (h->halo_top || h->halo_bot) {
+      PFDCHK(hand_block_collect(h, st, (const double *)o.dev, false));  // one scan: the unknown cells (own rows: never halo cells)
+    } else {  // a block without halo rows (one rank): no height can be unknown — the scan of 9 bytes per cell is skipped
+      st->unknown = 0, st->m = 0, st->valid = true;
+    }
   }
   const size_t ncol = (size_t)h->ncol, own0 = (size_t)h->halo_top * ncol, own1 = own0 + (size_t)h->own_rows * ncol;
   if (n_unknown) *n_unknown = (int64_t)st->unknown;  // (the listed cells are own cells: halo cells are never listed)

@@ -633,6 +633,9 @@ class DistributedRaster:
 
     def _allgather(self, data: bytes):
         """One-shot all-gather of a boundary record: RCCL (through the device) when the communicator exists."""
+        if self.world == 1:  # (nobody to exchange with: the record is its own gather)
+            self.exchanges.append(("rccl_allgather" if self.comm is not None else "host_allgather", 0))
+            return [bytes(data)]
         if self.comm is not None:
             self.exchanges.append(("rccl_allgather", len(data)))
             return self.comm.allgather_host(self.handle, data)
