@@ -21,6 +21,14 @@
 
 #include "exact.h"
 
+// An operation may WATCH what the down tile pass stores (k_xtile_down writes every cell of the raster exactly once):
+// members watch_cnt / watch_list / watch_cap and a predicate watched(code, value).  Row-block HAND lists the cells whose
+// height is still unknown that way — two scans of 9 bytes per cell (count, then collect) were a fifth of a block's sweep.
+template <class Op, class = void>
+struct XWatch : std::false_type {};
+template <class Op>
+struct XWatch<Op, std::void_t<decltype(std::declval<const Op &>().watch_cnt)>> : std::true_type {};
+
 struct XTileArgs {
   u32 nrow, ncol, ntc;
   const u8 *lh, *kids, *ncode;
@@ -1131,6 +1139,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     }
     __syncthreads();
   }
+  u32 wmask = 0;  // (XWatch) bit 4 j + b: the value stored for that cell is one the operation watches
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const u32 l0 = 4u * tid + 1024u * j;
@@ -1143,6 +1152,8 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     for (int b = 0; b < 4; ++b) {
       v[b] = val[(lr + 1) * XHW + lc + b + 1];
       if (((c4 >> (8 * b)) & 0xFFu) == D8_MV && gc + b < (i64)a.ncol) v[b] = op.dnodata((u32)(gr * (i64)a.ncol + gc + b));
+      if constexpr (XWatch<Op>::value)
+        wmask |= (gc + b < (i64)a.ncol && op.watched((c4 >> (8 * b)) & 0xFFu, v[b])) ? 1u << (4 * j + b) : 0u;
     }
     if (gc + 3 < (i64)a.ncol) {
       op.dstore4((u32)(gr * (i64)a.ncol + gc), v);
@@ -1150,6 +1161,38 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
         if (gc + b < (i64)a.ncol) op.store((u32)(gr * (i64)a.ncol + gc + b), v[b]);
+    }
+  }
+  if constexpr (XWatch<Op>::value) {
+    if (op.watch_cnt) {  // (uniform) the watched cells of the tile join the list: ONE global atomic per tile that holds any
+      __shared__ u32 s_wt[4], s_wbase;
+      const u32 lane = tid & 63u, wave = tid >> 6;
+      const u32 c = (u32)__popc(wmask);
+      u32 incl = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        const u32 y = (u32)__shfl_up((int)incl, o);
+        if (lane >= (u32)o) incl += y;
+      }
+      if (lane == 63u) s_wt[wave] = incl;
+      __syncthreads();
+      if (tid == 0) {
+        const u32 tot = s_wt[0] + s_wt[1] + s_wt[2] + s_wt[3];
+        s_wbase = tot ? (u32)atomicAdd(op.watch_cnt, (unsigned long long)tot) : 0u;  // (the count is exact beyond the capacity too)
+      }
+      __syncthreads();
+      if (c) {
+        u32 pos = s_wbase + incl - c;
+        for (u32 w = 0; w < wave; ++w) pos += s_wt[w];
+        u32 m = wmask;
+        while (m) {
+          const u32 bit = (u32)__ffs((int)m) - 1u;
+          m &= m - 1u;
+          const u32 l0 = 4u * tid + 1024u * (bit >> 2);
+          const u32 cell = (u32)((r0 + (l0 >> 6)) * (i64)a.ncol + c0 + (l0 & 63) + (bit & 3u));
+          if (pos < op.watch_cap) op.watch_list[pos] = cell;
+          ++pos;
+        }
+      }
     }
   }
 }

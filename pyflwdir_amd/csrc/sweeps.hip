@@ -721,6 +721,12 @@ struct Hand {
   const u8 *drain;
   const E *elev;
   double *out;
+  // (exact_sweep.h XWatch) row blocks: the cells whose height is still unknown — their path ends in a halo cell whose
+  // height has not arrived yet (-inf) — are counted and listed by the tile pass that stores them; null: nobody watches
+  unsigned long long *watch_cnt = nullptr;
+  u32 *watch_list = nullptr;
+  u32 watch_cap = 0;
+  __device__ __forceinline__ bool watched(u32 code, double v) const { return code != D8_HALO && v == -HUGE_VAL; }
   __device__ __forceinline__ double top(u32 p) const { return out[p]; }
   __device__ __forceinline__ double apply(u32 x, u32 code, bool root, double pv) const {
     if (drain[x] == 1) return 0.0;
@@ -1285,6 +1291,54 @@ __global__ void __launch_bounds__(256) k_hb_relax(const u8 *__restrict__ ncode, 
   if (*changed == 0u) *changed = 1u;
 }
 
+// the same relaxation to its fixpoint in ONE launch, for a list one workgroup can sweep (the lists of the later exchanges
+// hold a few thousand cells): rounds are separated by a workgroup barrier instead of a kernel boundary (a launch is ~6.5 us
+// here, 64 of them were 0.42 ms of every exchange of a block), and the loop ends when a round moved nothing — no host look
+template <class E>
+__global__ void __launch_bounds__(1024) k_hb_relax_wg(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ drain,
+                                                      const E *__restrict__ elev, const u32 *__restrict__ list, u32 m,
+                                                      double *__restrict__ out) {
+  // a thread keeps its (at most 8) cells in registers: a round is ONE load per unresolved cell — the downstream cell's
+  // height, all of a thread's loads in flight together — and a barrier
+  u32 xs[8], ps[8];
+  double dz[8];
+  u32 open = 0, isdrain = 0;  // bit k: cell k is still unknown / is a drain cell (height 0 whatever arrives)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const u32 i = threadIdx.x + 1024u * (u32)k;
+    xs[k] = ps[k] = 0u;
+    dz[k] = 0.0;
+    if (i < m) {
+      const u32 x = list[i];
+      const u32 p = d8_down(g, x, (u32)ncode[x]);
+      xs[k] = x, ps[k] = p;
+      if (p != x && __hip_atomic_load(&out[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == -HUGE_VAL) {
+        open |= 1u << k;
+        const E d = elev[x] - elev[p];
+        dz[k] = (double)d;
+        isdrain |= drain[x] == 1 ? 1u << k : 0u;
+      }
+    }
+  }
+  for (u32 round = 0; round < (1u << 22); ++round) {
+    double pv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      pv[k] = (open >> k) & 1u ? __hip_atomic_load(&out[ps[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -HUGE_VAL;
+    int moved = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (((open >> k) & 1u) && pv[k] != -HUGE_VAL) {
+        __hip_atomic_store(&out[xs[k]], (isdrain >> k) & 1u ? 0.0 : pv[k] + dz[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        open &= ~(1u << k);
+        moved = 1;
+      }
+    }
+    if (!__syncthreads_or(moved)) break;
+  }
+}
+#define HB_WG_MAX 8192u  // cells one workgroup relaxes (8 per thread, in registers)
+
 __global__ void __launch_bounds__(256) k_hb_count(const u8 *__restrict__ ncode, const double *__restrict__ out, u32 n,
                                                   unsigned long long *__restrict__ cnt) {
   unsigned long long c = 0;
@@ -1339,6 +1393,11 @@ static int hand_block_update(pfd_raster *h, HandBlockState *st, const u8 *drain,
   k_hb_seed<<<cdiv_u32(2 * ncol, 256), 256, 0, h->stream>>>(h->ncode, ncol, (u32)h->nrow, rf, rl, seed_dev, out);
   KCHK();
   if (st->m == 0) return PFD_OK;
+  if (st->m <= HB_WG_MAX && !pfd_knob("PFD_HAND_RELAX_LAUNCHES")) {
+    k_hb_relax_wg<E><<<1, 1024, 0, h->stream>>>(h->ncode, h->geo, drain, elev, st->list[st->cur].as<u32>(), st->m, out);
+    KCHK();
+    return hand_block_collect(h, st, out, true);  // drop what is known now
+  }
   DevBuf fl;
   const int BATCH = 64;
   PFDCHK(fl.alloc(BATCH * sizeof(u32)));
@@ -1396,6 +1455,7 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
     pfd_seg_end(h, 3);
   } else {
     (void)incremental;
+    bool counted = false;
     pfd_seg_begin(h, "init");
     k_fill<double><<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>((double *)o.dev, h->geo.n, -9999.0);
     KCHK();
@@ -1405,12 +1465,37 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
       k_hb_seed<<<cdiv_u32(2 * (u64)h->ncol, 256), 256, 0, h->stream>>>(h->ncode, (u32)h->ncol, (u32)h->nrow, rf, rl,
                                                                       (const double *)sd.dev, (double *)o.dev);
       KCHK();
+      // (the tile pass that stores the heights counts and lists the cells that are still unknown: no scan afterwards)
+      const bool watch = (h->halo_top || h->halo_bot) && !pfd_knob("PFD_HAND_SCAN_UNKNOWN");
+      DevBuf ctr;
+      const u32 wcap = std::max<u32>(h->geo.n / 16u, 1024u);
+      if (watch) {
+        PFDCHK(ctr.alloc(sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(ctr.p, 0, sizeof(unsigned long long), h->stream));
+        if (st->cap < wcap) {
+          st->cap = wcap;
+          PFDCHK(st->list[0].alloc((size_t)wcap * sizeof(u32)));
+          PFDCHK(st->list[1].alloc((size_t)wcap * sizeof(u32)));
+        }
+        st->cur = 0;
+      }
       if (elev_dtype == PFD_F32) {
         Hand<float> op{h->ncode, h->geo, (const u8 *)dr.dev, (const float *)el.dev, (double *)o.dev};
+        if (watch) op.watch_cnt = ctr.as<unsigned long long>(), op.watch_list = st->list[0].as<u32>(), op.watch_cap = st->cap;
         PFDCHK(run_exact_down(h, op, "exact_hand_block"));
       } else {
         Hand<double> op{h->ncode, h->geo, (const u8 *)dr.dev, (const double *)el.dev, (double *)o.dev};
+        if (watch) op.watch_cnt = ctr.as<unsigned long long>(), op.watch_list = st->list[0].as<u32>(), op.watch_cap = st->cap;
         PFDCHK(run_exact_down(h, op, "exact_hand_block"));
+      }
+      if (watch) {
+        unsigned long long m = 0;
+        HIPCHK(hipMemcpyAsync(&m, ctr.p, sizeof(m), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        st->unknown = m;
+        st->valid = m <= (unsigned long long)wcap;
+        st->m = st->valid ? (u32)m : 0u;
+        counted = true;
       }
     } else if (elev_dtype == PFD_F32) {
       HandSeeded<float> op{{h->ncode, h->geo, (const u8 *)dr.dev, (const float *)el.dev, (double *)o.dev}, (const double *)sd.dev, rf, rl};
@@ -1419,7 +1504,9 @@ extern "C" int pfd_hand_block(pfd_raster *h, const uint8_t *drain, int elev_dtyp
       HandSeeded<double> op{{h->ncode, h->geo, (const u8 *)dr.dev, (const double *)el.dev, (double *)o.dev}, (const double *)sd.dev, rf, rl};
       PFDCHK(run_down(h, op, "sweep_hand_block"));
     }
-    if (h->halo_top || h->halo_bot) {
+    if (counted) {
+      // (the tile pass listed them)
+    } else if (h->halo_top || h->halo_bot) {
       PFDCHK(hand_block_collect(h, st, (const double *)o.dev, false));  // one scan: the unknown cells (own rows: never halo cells)
     } else {  // a block without halo rows (one rank): no height can be unknown — the scan of 9 bytes per cell is skipped
       st->unknown = 0, st->m = 0, st->valid = true;
