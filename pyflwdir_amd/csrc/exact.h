@@ -51,6 +51,12 @@ struct ExactPlan {
   uint16_t *tord = nullptr;  // [ntiles * 4096] leaf cells of the tile, ordered by step: local index | downstream slot << 12 | pit << 15
   uint16_t *toff = nullptr;  // [ntiles * XOFF] start of step s in tord; entries past the last step = total
   u32 *cslot = nullptr;   // [n] slot of a trunk cell (its real slot; post slots follow it); undefined elsewhere
+  // The trunk cells of every 64 x 64 tile as a dense list (round 5): {slot, local index | post slots << 12}.  The passes
+  // that visit the trunk cells in raster order (k_xtrunk_demit, k_xtrunk_unscatter) read 8 contiguous bytes per trunk
+  // cell instead of the marks of every cell plus 4 scattered bytes of cslot per trunk cell — a quarter of the cells, one
+  // or two per 64-byte sector along a river.
+  uint2 *tlist = nullptr;  // [ntrunk]
+  u32 *tl_off = nullptr;   // [ntiles + 1] first entry of the tile
   u32 *scell = nullptr;   // [nslot]
   uint16_t *sinfo = nullptr;  // [nslot]
   u32 *spost = nullptr;   // [nslot / 32 + 4] bit s = slot s is a post slot (what the serial fold needs of sinfo)

@@ -472,9 +472,12 @@ __global__ void __launch_bounds__(256) k_plan_chain_lens(const u32 *__restrict__
 __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict__ hinfo, const u32 *__restrict__ hops,
                                                       const u32 *__restrict__ tailnum, const u32 *__restrict__ tidx_at,
                                                       const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos, u32 nrow,
-                                                      u32 ncol, uint4 *__restrict__ urec, u32 *__restrict__ ptmp) {
+                                                      u32 ncol, uint4 *__restrict__ urec, u32 *__restrict__ ptmp,
+                                                      u32 *__restrict__ tl_cnt) {
+  __shared__ u32 s_tc[4];
   const u32 tid = threadIdx.x;
   const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  u32 mine = 0;  // trunk cells with a position among the thread's 16 cells (-> tl_cnt[tile])
   u32 inf[4][4], tn[4][4], hp[4][4], x0s[4];
   bool any[4];
 #pragma unroll
@@ -519,15 +522,24 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict
       // everything in one coalesced load instead of five dependent gathers per cell
       urec[p] = make_uint4(x, c, inf[j][b], 0u);
       ptmp[x] = p;
+      ++mine;
     }
   }
+  for (int o = 32; o > 0; o >>= 1) mine += (u32)__shfl_down((int)mine, o);
+  if ((tid & 63u) == 0u) s_tc[tid >> 6] = mine;
+  __syncthreads();
+  if (tid == 0) tl_cnt[blockIdx.y * gridDim.x + blockIdx.x] = s_tc[0] + s_tc[1] + s_tc[2] + s_tc[3];
 }
 // cslot[x]: position -> slot (spos[p], written by k_plan_expand in position order), and the number of post slots into
 // the trunk mark; tile-shaped like the scatter (the gather from chain order hits the runs the tile holds)
 __global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__ hinfo, const u32 *__restrict__ spos, u32 nrow, u32 ncol, u32 *__restrict__ cslot,
-                                                    u8 *__restrict__ lh) {
+                                                    u8 *__restrict__ lh, const u32 *__restrict__ tl_off, uint2 *__restrict__ tlist) {
+  __shared__ u32 s_tw[4];
   const u32 tid = threadIdx.x;
   const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  u32 esl[16], eps[16], emask = 0;  // slot / post slots of the thread's cells that join the list (static indices only)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) esl[k] = eps[k] = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const u32 l0 = 4u * tid + 1024u * j;
@@ -557,6 +569,27 @@ __global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__
       if (!inf[b] || pp[b] == NONE32) continue;
       cslot[x0 + b] = sl[b];  // (the sweeps find a trunk cell's value in chain order through it: no scatter pass per round)
       if ((inf[b] >> 12) & 7u) lh[x0 + b] = (u8)(XL_TRUNK + ((inf[b] >> 12) & 7u));  // (up-sweeps: the value sits behind the post slots)
+      esl[4 * j + b] = sl[b], eps[4 * j + b] = (inf[b] >> 12) & 7u;
+      emask |= 1u << (4 * j + b);
+    }
+  }
+  const u32 ne = (u32)__popc(emask);
+  // the tile's dense list: exclusive prefix of the threads' counts (the order inside a tile does not matter)
+  const u32 lane = tid & 63u, wave = tid >> 6;
+  u32 incl = ne;
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 y = (u32)__shfl_up((int)incl, o);
+    if (lane >= (u32)o) incl += y;
+  }
+  if (lane == 63u) s_tw[wave] = incl;
+  __syncthreads();
+  u32 pos = tl_off[blockIdx.y * gridDim.x + blockIdx.x] + incl - ne;
+  for (u32 w = 0; w < wave; ++w) pos += s_tw[w];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if ((emask >> k) & 1u) {
+      const u32 local = 4u * tid + 1024u * (u32)(k >> 2) + (u32)(k & 3);
+      tlist[pos++] = make_uint2(esl[k], local | (eps[k] << 12));
     }
   }
 }
@@ -835,6 +868,8 @@ void pfd_free_xplan(pfd_raster *h) {
     pfd_dfree(p->tord);
     pfd_dfree(p->toff);
     pfd_dfree(p->cslot);
+    pfd_dfree(p->tlist);
+    pfd_dfree(p->tl_off);
     pfd_dfree(p->scell);
     pfd_dfree(p->sinfo);
     pfd_dfree(p->spost);
@@ -1038,9 +1073,18 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if ((rc = w.alloc((npos + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemsetAsync(ucell.p, 0, (npos + 1) * sizeof(uint4), h->stream) != hipSuccess) return fail(PFD_EHIP);
   if ((rc = pfd_dmalloc((void **)&p->cslot, ((size_t)n + 64) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = pfd_dmalloc((void **)&p->tl_off, (ntiles + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+  if (hipMemsetAsync(p->tl_off + ntiles, 0, sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
   k_plan_scatter<<<dim3(ntc, ntr), 256, 0, h->stream>>>(hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at,
                                                         cpos.as<u32>(), clenp.as<u32>(), (u32)h->nrow, (u32)h->ncol,
-                                                        ucell.as<uint4>(), p->cslot);
+                                                        ucell.as<uint4>(), p->cslot, p->tl_off);
+  // first list entry of every tile (exclusive scan of the tiles' trunk counts, in place)
+  if (rocprim::exclusive_scan(nullptr, tmp_bytes, p->tl_off, p->tl_off, 0u, ntiles + 1, rocprim::plus<u32>(), h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  if ((rc = tmp.alloc(std::max<size_t>(tmp_bytes, 16))) != PFD_OK) return fail(rc);
+  if (rocprim::exclusive_scan(tmp.p, tmp_bytes, p->tl_off, p->tl_off, 0u, ntiles + 1, rocprim::plus<u32>(), h->stream) != hipSuccess)
+    return fail(PFD_EHIP);
+  if ((rc = pfd_dmalloc((void **)&p->tlist, (npos + 1) * sizeof(uint2))) != PFD_OK) return fail(rc);
   XDBG(h, "k_plan_scatter");
   if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   // slot of a position = exclusive scan of the slots the positions before it need (in place)
@@ -1095,7 +1139,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
                                                               p->scell, p->sinfo, p->spost);
   XDBG(h, "k_plan_expand");
     k_plan_cslot<<<dim3(ntc, ntr), 256, 0, h->stream>>>(hinfo.as<uint16_t>(), w.as<u32>(), (u32)h->nrow,
-                                                        (u32)h->ncol, p->cslot, p->lh);
+                                                        (u32)h->ncol, p->cslot, p->lh, p->tl_off, p->tlist);
   XDBG(h, "k_plan_cslot");
   xdigest(h, "ucell", ucell.p, (size_t)npos * 16);
   xdigest(h, "scell", p->scell, (size_t)p->nslot * 4);
@@ -1138,7 +1182,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
     }
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return fail(PFD_EHIP);
-  p->bytes = 6 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)p->nslot / 8 + (size_t)nchain * 8;
+  p->bytes = 6 * ((size_t)n + 64) + ntiles * (XTC + XOFF) * sizeof(uint16_t) + (size_t)p->nslot * 6 + (size_t)p->nslot / 8 + (size_t)nchain * 8 + (size_t)npos * 8 + ntiles * 4;
   h->bytes_held += p->bytes;
   h->xplan_state = 1;
   pfd_seg_end(h, 14);

@@ -37,6 +37,9 @@ struct XTileArgs {
   // them up from there and writes every cell of the raster once; no scatter pass per round
   const u32 *cslot;
   const void *R;
+  // the trunk cells of a tile as a dense list (ExactPlan::tlist): what the raster-order passes over the trunk walk
+  const uint2 *tlist = nullptr;
+  const u32 *tl_off = nullptr;
 };
 
 // ---- leaves, up ---------------------------------------------------------------------------------
@@ -486,6 +489,34 @@ __global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, co
   }
 }
 
+// The same pass over the tile's dense trunk list (round 5): 8 contiguous bytes per trunk cell — slot, local index, post
+// slots — instead of the marks of all 4096 cells and a 16-byte quad of cslot wherever a quad holds a trunk cell (along a
+// river that is one useful word per 64-byte sector).
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_unscatter_list(Op op, XTileArgs a, const typename Op::V *__restrict__ R,
+                                                               u32 s_limit = 0xFFFFFFFFu) {
+  const u32 tile = blockIdx.y * a.ntc + blockIdx.x;
+  const u32 b = a.tl_off[tile], e = a.tl_off[tile + 1];
+  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  for (u32 i0 = b; i0 < e; i0 += 1024u) {  // four entries per thread in flight
+    uint2 en[4];
+    typename Op::V v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 i = i0 + threadIdx.x + 256u * (u32)k;
+      en[k] = a.tlist[i < e ? i : b];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = R[en[k].x + ((en[k].y >> 12) & 7u)];  // (the value sits behind the cell's post slots)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 i = i0 + threadIdx.x + 256u * (u32)k;
+      const u32 l = en[k].y & 0xFFFu;
+      if (i < e && en[k].x < s_limit) op.store((r0 + (l >> 6)) * a.ncol + c0 + (l & 63u), v[k]);
+    }
+  }
+}
+
 // ---- incremental re-sweep of a row block (ExactPlan::schain ...): the same steps for the dirty chains only ----
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_pre_inc(Op op, const u32 *__restrict__ scell, const uint16_t *__restrict__ sinfo,
@@ -507,6 +538,11 @@ __global__ void __launch_bounds__(256) k_xtrunk_scatter_inc(Op op, const u32 *__
   const u32 info = sinfo[s];
   if (info & XS_POST) return;  // (padding slots are post slots)
   op.store(scell[s], R[s + ((info >> 12) & 7u)]);
+}
+// (A/B knob: PFD_XLIST_OFF=1 walks the marks of every cell as rounds 3-4 did)
+static inline bool xlist_on() {
+  static const bool on = pfd_knob("PFD_XLIST_OFF") == nullptr;
+  return on;
 }
 // an update request (pfd_set_block_update(h, 2)) can be served: the kept sweep is this operation's, into this buffer
 static inline bool xinc_applies(pfd_raster *h, const void *out_dev, size_t tag) {
@@ -605,7 +641,11 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
       a.cslot = p->cslot;
       HIPCHK(hipEventRecord(h->ev_fork, h->stream));
       HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-      k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream2>>>(op, a, R, s_split);
+      a.tlist = p->tlist, a.tl_off = p->tl_off;
+      if (xlist_on())
+        k_xtrunk_unscatter_list<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream2>>>(op, a, R, s_split);
+      else
+        k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream2>>>(op, a, R, s_split);
       HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       ++launches;
     }
@@ -624,7 +664,11 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
     ++launches;
   } else if (p->nslot) {
     a.cslot = p->cslot;
-    k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, R);
+    a.tlist = p->tlist, a.tl_off = p->tl_off;
+    if (xlist_on())
+      k_xtrunk_unscatter_list<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, R);
+    else
+      k_xtrunk_unscatter<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, R);
     XDBG(h, "unscatter");
     ++launches;
   }
@@ -682,6 +726,36 @@ __global__ void __launch_bounds__(256) k_xtrunk_demit(Op op, XTileArgs a, typena
         const u32 sl = a.cslot[x0 + b];
         if (!LIMIT || sl < s_limit) E[sl] = e;
       }
+    }
+  }
+}
+
+// ... and over the tile's dense trunk list (see k_xtrunk_unscatter_list)
+template <class Op, bool LIMIT = false>
+__global__ void __launch_bounds__(256) k_xtrunk_demit_list(Op op, XTileArgs a, typename Op::DElem *__restrict__ E,
+                                                           u32 s_limit = 0xFFFFFFFFu) {
+  const u32 tile = blockIdx.y * a.ntc + blockIdx.x;
+  const u32 b = a.tl_off[tile], e = a.tl_off[tile + 1];
+  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  for (u32 i0 = b; i0 < e; i0 += 512u) {  // two entries per thread in flight
+    uint2 en[2];
+    u32 x[2], cd[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const u32 i = i0 + threadIdx.x + 256u * (u32)k;
+      en[k] = a.tlist[i < e ? i : b];
+      const u32 l = en[k].y & 0xFFFu;
+      x[k] = (r0 + (l >> 6)) * a.ncol + c0 + (l & 63u);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) cd[k] = a.ncode[x[k]];
+    typename Op::DElem el[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) el[k] = op.dpre(x[k], cd[k]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const u32 i = i0 + threadIdx.x + 256u * (u32)k;
+      if (i < e && (!LIMIT || en[k].x < s_limit)) E[en[k].x] = el[k];
     }
   }
 }
@@ -1032,6 +1106,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
       V vq[4][4];
       uint4 cs4[4];
       u32 tmask[4], hmask[4];  // trunk cells / halo cells of the quad
+      const bool by_list = a.tlist != nullptr;  // (uniform) the trunk values come in through the tile's dense list below
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32 l0 = 4u * tid + 1024u * j;
@@ -1045,7 +1120,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
           hmask[j] |= mk == XL_HALO ? 1u << b : 0u;
         }
         cs4[j] = make_uint4(0u, 0u, 0u, 0u);
-        if (tmask[j]) __builtin_memcpy(&cs4[j], a.cslot + g0, 16);  // (slot numbers of the quad's trunk cells)
+        if (tmask[j] && !by_list) __builtin_memcpy(&cs4[j], a.cslot + g0, 16);  // (slot numbers of the quad's trunk cells)
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1053,7 +1128,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
         const u32 g0 = (u32)((r0 + (l0 >> 6)) * (i64)a.ncol + c0 + (l0 & 63));
 #pragma unroll
         for (int b = 0; b < 4; ++b) vq[j][b] = V();
-        if (tmask[j]) {  // trunk values from chain order: four loads, the marks select
+        if (tmask[j] && !by_list) {  // trunk values from chain order: four loads, the marks select
           const u32 cs[4] = {cs4[j].x, cs4[j].y, cs4[j].z, cs4[j].w};
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
@@ -1090,9 +1165,31 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
           } else {
             De[l0 + b] = e;
           }
-          val[(lr + 1) * XHW + lc + b + 1] = v;
+          if (!(by_list && ((tmask[j] >> b) & 1u))) val[(lr + 1) * XHW + lc + b + 1] = v;  // (a trunk cell's word: the list loop's)
         }
         if (Op::DTILE_FLAG && fl) atomicOr(&F[l0 >> 5], fl << (l0 & 31u));
+      }
+      if (by_list) {
+        // the values of the tile's trunk cells, final in chain order: 8 contiguous bytes of the list per trunk cell instead
+        // of a 16-byte quad of cslot wherever a quad holds one (one useful word per sector along a river)
+        const u32 lb = a.tl_off[tile], le = a.tl_off[tile + 1];
+        for (u32 i0 = lb; i0 < le; i0 += 1024u) {
+          uint2 en[4];
+          V rv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const u32 i = i0 + tid + 256u * (u32)k;
+            en[k] = a.tlist[i < le ? i : lb];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rv[k] = Rv[en[k].x];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const u32 i = i0 + tid + 256u * (u32)k;
+            const u32 l = en[k].y & 0xFFFu;
+            if (i < le) val[((l >> 6) + 1u) * XHW + (l & 63u) + 1u] = rv[k];
+          }
+        }
       }
     } else {
       general_init(mycodes);
@@ -1208,6 +1305,8 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
   PFDCHK(E.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(Elem) + 64));
   PFDCHK(R.alloc(std::max<size_t>((size_t)p->nslot, 1) * sizeof(V) + 64));
   XTileArgs a{(u32)h->nrow, (u32)h->ncol, p->ntc, p->lh, p->kids, h->ncode, p->tord, p->toff, p->cslot, R.p};
+  a.tlist = p->tlist, a.tl_off = p->tl_off;
+  if (!xlist_on()) a.tlist = nullptr, a.tl_off = nullptr;
   // The rounds start with the main stems and their largest tributaries (the last two rounds of the layout): a few
   // thousand long chains, folded serially — 0.7 ms each for HAND at 30000 x 30000 with most of the chip idle.  Their
   // operands are gathered in chain order first (a few per cent of the slots); the raster-order gather of everything
@@ -1218,13 +1317,19 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
     const u32 s_split = (u32)p->b_slot[bsplit];
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    k_xtrunk_demit<Op, true><<<dim3(p->ntc, p->ntr), 256, 0, h->stream2>>>(op, a, E.as<Elem>(), s_split);
+    if (xlist_on())
+      k_xtrunk_demit_list<Op, true><<<dim3(p->ntc, p->ntr), 256, 0, h->stream2>>>(op, a, E.as<Elem>(), s_split);
+    else
+      k_xtrunk_demit<Op, true><<<dim3(p->ntc, p->ntr), 256, 0, h->stream2>>>(op, a, E.as<Elem>(), s_split);
     HIPCHK(hipEventRecord(h->ev_join, h->stream2));
     k_xtrunk_dpre<Op><<<cdiv_u32((u32)p->nslot - s_split, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, h->ncode, s_split,
                                                                                   (u32)p->nslot, E.as<Elem>());
     launches += 2;
   } else if (p->nslot) {  // what the folds read from memory, for every trunk cell at once (the rounds only fold)
-    k_xtrunk_demit<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, E.as<Elem>());
+    if (xlist_on())
+      k_xtrunk_demit_list<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, E.as<Elem>());
+    else
+      k_xtrunk_demit<Op><<<dim3(p->ntc, p->ntr), 256, 0, h->stream>>>(op, a, E.as<Elem>());
     ++launches;
   }
   bool joined = bsplit < 0;
