@@ -252,7 +252,9 @@ int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int
  *   counters    in: two local counts; out: [0], [1] their sums over the ranks (one ncclAllReduce), [2] 1 if a
  *               received row differs (bitwise) from the halo values it replaces, [3] the sum of [2] over the ranks
  * No row travels through the host: one stream synchronisation and a 32-byte read-back per exchange.  Every rank
- * must call it (collective).  The block sweeps read `halo_seed_host` from the DEVICE after pfd_set_block_io(h,
+ * must call it (collective).  A rank on which something fails locally (a handle whose halo rows do not fit its rank, a
+ * HIP call) still takes part in the send / recv group and in the all-reduce — nobody is left waiting — adds 1 to
+ * counters[1] (callers use [1] as "ranks that failed") and returns its own error afterwards.  The block sweeps read `halo_seed_host` from the DEVICE after pfd_set_block_io(h,
  * PFD_DEVICE). */
 int pfd_comm_exchange_rows(pfd_comm *comm, pfd_raster *h, const void *result_dev, int elem_bytes, void *seed_dev,
                            int64_t counters[4]);
@@ -415,6 +417,9 @@ int pfd_verify_hand(pfd_raster *h, const uint8_t *drain, int elev_dtype, const v
 /* sum of n int32 values in HBM (two's complement, 64 bit): the checksum multi-block runs compare with a
  * single-GPU run of the same raster */
 int pfd_checksum_i32(int device, const int32_t *dev_ptr, int64_t n, int64_t *sum);
+/* number of NaN / +-inf values of a DEVICE array (dtype PFD_F32 or PFD_F64): callers with device-resident elevations check
+ * them with it before the row-block HAND (pfd_hand_block), whose "-inf = height not known yet" a non-finite difference imitates */
+int pfd_count_nonfinite(int device, int dtype, const void *dev_ptr, int64_t n, int64_t *count);
 
 /* ---- synthetic rasters (bench / tests; device twin of oracle/pfd_oracle.c orc_synth_*) ---- */
 /* writes rows [row0, row0+nrows) of the nrow x ncol synthetic raster to device memory */

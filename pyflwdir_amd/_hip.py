@@ -40,7 +40,7 @@ SYMBOLS = [
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
     "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic", "pfd_set_block_update",
-    "pfd_reserve", "pfd_alloc_stats",
+    "pfd_reserve", "pfd_alloc_stats", "pfd_count_nonfinite",
 ]
 
 _lib = None
@@ -654,6 +654,13 @@ class Communicator:
         if self._c:
             lib().pfd_comm_destroy(self._c)
             self._c = C.c_void_p()
+
+
+def count_nonfinite(buf, n: int, dtype_code: int, device: int = 0) -> int:
+    """NaN / +-inf values among the first n float32 / float64 values of a device buffer."""
+    out = C.c_int64(0)
+    check(lib().pfd_count_nonfinite(device, int(dtype_code), ptr(buf), int(n), C.byref(out)))
+    return int(out.value)
 
 
 def checksum_i32(buf, n: int, device: int = 0) -> int:

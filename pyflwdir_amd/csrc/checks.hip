@@ -274,6 +274,34 @@ extern "C" int pfd_checksum_i32(int device, const int32_t *dev_ptr, int64_t n, i
   return PFD_OK;
 }
 
+// number of NaN / +-inf values in a device array of float32 (dtype PFD_F32) or float64: what a caller with
+// device-resident elevations asks before the row-block HAND, whose "-inf = not known yet" marker a non-finite
+// elevation difference could imitate (host inputs are checked with numpy)
+template <class T>
+__global__ void __launch_bounds__(256) k_count_nonfinite(const T *__restrict__ v, u64 n, unsigned long long *res) {
+  unsigned long long c = 0;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) c += isfinite(v[i]) ? 0u : 1u;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(res, c);
+}
+extern "C" int pfd_count_nonfinite(int device, int dtype, const void *dev_ptr, int64_t n, int64_t *count) {
+  if (!dev_ptr || n < 0 || !count || (dtype != PFD_F32 && dtype != PFD_F64)) {
+    pfd_set_error("pfd_count_nonfinite: bad arguments (dtype code %d)", dtype);
+    return PFD_EINVAL;
+  }
+  HIPCHK(hipSetDevice(device));
+  unsigned long long *acc = nullptr, host = 0;
+  HIPCHK(hipMalloc((void **)&acc, 8));
+  HIPCHK(hipMemset(acc, 0, 8));
+  if (n && dtype == PFD_F32) k_count_nonfinite<float><<<4096, 256>>>((const float *)dev_ptr, (u64)n, acc);
+  if (n && dtype == PFD_F64) k_count_nonfinite<double><<<4096, 256>>>((const double *)dev_ptr, (u64)n, acc);
+  hipError_t e = hipMemcpy(&host, acc, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(acc);
+  HIPCHK(e);
+  *count = (int64_t)host;
+  return PFD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // core.snap, downstream direction, cell units (reference pyflwdir/core.py:440-480 with core._trace
 // :316-366; Flwdir.snap flwdir.py:404-463): per start cell the first cell on its downstream path (the start

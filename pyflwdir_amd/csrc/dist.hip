@@ -158,24 +158,35 @@ extern "C" int pfd_comm_exchange_rows(pfd_comm *c, pfd_raster *h, const void *re
   }
   HIPCHK(hipSetDevice(h->device));
   const int rank = c->rank, world = c->world;
+  // A rank that returned before the collectives would leave its neighbours waiting in RCCL for ever: whatever can fail
+  // locally (a handle whose halo rows do not fit the rank, a HIP call) is remembered, the rank still takes part in the
+  // send / recv group and in the all-reduce — with rows of zeros when its own are unusable — and its failure is added to
+  // counters[1], which every caller sums as "ranks that failed"; the local error is returned afterwards.
+  int lrc = PFD_OK;
   if (h->halo_top != (rank > 0) || h->halo_bot != (rank + 1 < world)) {
     pfd_set_error("pfd_comm_exchange_rows: rank %d of %d must hold %d top / %d bottom halo rows", rank, world, rank > 0,
                   rank + 1 < world);
-    return PFD_EINVAL;
+    lrc = PFD_EINVAL;
   }
   const size_t rowb = (size_t)h->ncol * (size_t)elem_bytes;
-  // (an allocation failure here leaves the other ranks in the collective: the buffers are a few hundred KB and are
-  //  kept with the communicator, so this can only happen in the very first exchange)
-  PFDCHK(comm_reserve(c, 2 * rowb));
+  // (an allocation failure here does leave the other ranks in the collective: the buffers are a few hundred KB, kept with
+  //  the communicator, so this can only happen in the very first exchange)
+  PFDCHK(comm_reserve(c, 4 * rowb));
   hipStream_t st = h->stream;
   const char *res = (const char *)result_dev;
+  char *rtop = (char *)c->xbuf, *rbot = (char *)c->xbuf + rowb, *zeros = (char *)c->xbuf + 2 * rowb;
   const char *first = res + (size_t)h->halo_top * rowb, *last = res + (size_t)(h->halo_top + h->own_rows - 1) * rowb;
-  char *rtop = (char *)c->xbuf, *rbot = (char *)c->xbuf + rowb;
-  long long in[4] = {(long long)counters[0], (long long)counters[1], 0, 0};
-  HIPCHK(hipMemcpyAsync(c->cnt_dev, in, sizeof(in), hipMemcpyHostToDevice, st));
+  if (lrc != PFD_OK) {  // (rows of zeros stand in for rows this rank cannot name)
+    if (hipMemsetAsync(zeros, 0, 2 * rowb, st) != hipSuccess) (void)hipGetLastError();
+    first = zeros, last = zeros + rowb;
+  }
+  long long in[4] = {(long long)counters[0], (long long)counters[1] + (lrc != PFD_OK ? 1 : 0), 0, 0};
+  if (hipMemcpyAsync(c->cnt_dev, in, sizeof(in), hipMemcpyHostToDevice, st) != hipSuccess && lrc == PFD_OK) {
+    pfd_set_error("pfd_comm_exchange_rows: upload of the counters failed");
+    lrc = PFD_EHIP;
+  }
   if (world > 1) {
-    NCCLCHK(ncclGroupStart());
-    ncclResult_t r = ncclSuccess;
+    ncclResult_t r = ncclGroupStart();
     if (rank > 0) {
       if (r == ncclSuccess) r = ncclSend(first, rowb, ncclUint8, rank - 1, c->comm, st);
       if (r == ncclSuccess) r = ncclRecv(rtop, rowb, ncclUint8, rank - 1, c->comm, st);
@@ -185,9 +196,9 @@ extern "C" int pfd_comm_exchange_rows(pfd_comm *c, pfd_raster *h, const void *re
       if (r == ncclSuccess) r = ncclRecv(rbot, rowb, ncclUint8, rank + 1, c->comm, st);
     }
     const ncclResult_t r2 = ncclGroupEnd();
-    if (r != ncclSuccess || r2 != ncclSuccess) {
+    if ((r != ncclSuccess || r2 != ncclSuccess) && lrc == PFD_OK) {
       pfd_set_error("pfd_comm_exchange_rows: ncclSend/ncclRecv failed: %s", ncclGetErrorString(r != ncclSuccess ? r : r2));
-      return PFD_ECOMM;
+      lrc = PFD_ECOMM;
     }
     auto update = [&](const char *recv, char *seed) {
       if (elem_bytes == 1)
@@ -195,18 +206,31 @@ extern "C" int pfd_comm_exchange_rows(pfd_comm *c, pfd_raster *h, const void *re
       else
         k_seed_update<u32><<<cdiv_u32(rowb / 4, 256), 256, 0, st>>>((const u32 *)recv, (u32 *)seed, rowb / 4, c->cnt_dev + 2);
     };
-    if (rank > 0) update(rtop, (char *)seed_dev);
-    if (rank + 1 < world) update(rbot, (char *)seed_dev + rowb);
-    KCHK();
+    if (lrc == PFD_OK) {
+      if (rank > 0) update(rtop, (char *)seed_dev);
+      if (rank + 1 < world) update(rbot, (char *)seed_dev + rowb);
+      if (hipGetLastError() != hipSuccess) {
+        pfd_set_error("pfd_comm_exchange_rows: the seed update failed");
+        lrc = PFD_EHIP;
+      }
+    }
   }
   k_cnt_pack<<<1, 1, 0, st>>>(c->cnt_dev);
-  NCCLCHK(ncclAllReduce(c->cnt_dev, c->cnt_dev + 4, 4, ncclInt64, ncclSum, c->comm, st));
+  const ncclResult_t r3 = ncclAllReduce(c->cnt_dev, c->cnt_dev + 4, 4, ncclInt64, ncclSum, c->comm, st);
+  if (r3 != ncclSuccess && lrc == PFD_OK) {
+    pfd_set_error("pfd_comm_exchange_rows: ncclAllReduce failed: %s", ncclGetErrorString(r3));
+    lrc = PFD_ECOMM;
+  }
   long long out[4] = {0, 0, 0, 0}, mine = 0;
-  HIPCHK(hipMemcpyAsync(out, c->cnt_dev + 4, sizeof(out), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(&mine, c->cnt_dev + 2, sizeof(mine), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  if ((hipMemcpyAsync(out, c->cnt_dev + 4, sizeof(out), hipMemcpyDeviceToHost, st) != hipSuccess ||
+       hipMemcpyAsync(&mine, c->cnt_dev + 2, sizeof(mine), hipMemcpyDeviceToHost, st) != hipSuccess ||
+       hipStreamSynchronize(st) != hipSuccess) &&
+      lrc == PFD_OK) {
+    pfd_set_error("pfd_comm_exchange_rows: download of the counters failed");
+    lrc = PFD_EHIP;
+  }
   counters[0] = out[0], counters[1] = out[1], counters[2] = mine, counters[3] = out[3];
-  return PFD_OK;
+  return lrc;
 }
 
 extern "C" int pfd_comm_allgather_host(pfd_comm *c, pfd_raster *h, const void *in_host, size_t nbytes, void *out_host) {

@@ -539,6 +539,14 @@ __global__ void __launch_bounds__(256) k_xtrunk_scatter_inc(Op op, const u32 *__
   if (info & XS_POST) return;  // (padding slots are post slots)
   op.store(scell[s], R[s + ((info >> 12) & 7u)]);
 }
+// A sweep that forks work onto the handle's second stream frees its element / value buffers on return: on an error path
+// between fork and join the second stream may still read them — whoever leaves the function waits for it first.
+struct XStream2Guard {
+  pfd_raster *h;
+  ~XStream2Guard() {
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+  }
+};
 // (A/B knob: PFD_XLIST_OFF=1 walks the marks of every cell as rounds 3-4 did)
 static inline bool xlist_on() {
   static const bool on = pfd_knob("PFD_XLIST_OFF") == nullptr;
@@ -632,6 +640,7 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
   // slots — are scattered in chain order when they are done.
   int bsplit = xplan_tail_split(p);
   if (bsplit >= 0 && pfd_aux_stream(h) != PFD_OK) bsplit = -1;
+  XStream2Guard guard2{h};  // (declared after E / R: runs before they are released)
   const u32 s_split = bsplit >= 0 ? (u32)p->b_slot[bsplit] : 0xFFFFFFFFu;
   for (int b = 0; b < 32; ++b) {
     const u32 s0 = (u32)p->b_slot[b], s1 = (u32)p->b_slot[b + 1];
@@ -1313,6 +1322,7 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
   // else (k_xtrunk_demit: bandwidth) runs BESIDE those two rounds on the handle's second stream.
   int bsplit = xplan_tail_split(p);
   if (bsplit >= 0 && pfd_aux_stream(h) != PFD_OK) bsplit = -1;
+  XStream2Guard guard2{h};  // (declared after E / R: runs before they are released)
   if (bsplit >= 0) {
     const u32 s_split = (u32)p->b_slot[bsplit];
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));

@@ -588,12 +588,24 @@ class DistributedRaster:
         self._device_io = isinstance(drain_block, _hip.DeviceBuffer)
         if self._device_io:
             drain, elevtn, code = drain_block, elevtn_block, elev_code
+            # (the finite-elevation rule of _hand_inputs, on the device; checked once per buffer — every rank raises alike
+            #  only if every rank's rows are bad, so the verdict travels with the block set-up agreement below)
+            key = (elevtn.addr, elevtn.nbytes)
+            if getattr(self, "_finite_checked", None) != key:
+                nbad = _hip.count_nonfinite(elevtn, (h.nrow + sum(h.halo)) * ncol, code, h.device)
+                self._finite_checked = key if nbad == 0 else None
+                if nbad:
+                    self._nonfinite = NotImplementedError("hand over row blocks needs finite elevations (-inf marks heights that "
+                                                          "are not known yet); mask or fill inf / NaN cells first")
         else:
             drain, elevtn, code = _hand_inputs(drain_block, elevtn_block)
         seed = np.full(2 * ncol, -np.inf)
         unknown_before, it = None, 0
         blk, err = None, None
         try:
+            if getattr(self, "_nonfinite", None) is not None:
+                exc, self._nonfinite = self._nonfinite, None
+                raise exc
             blk = _HandBlock(h, drain, elevtn, code, out=out)
         except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
             err = exc

@@ -706,9 +706,15 @@ class FlwdirRaster(object):
         above a cycle untouched).  One tiled rank query on the whole raster tells; a raster even beyond that query's slot
         ids (max_rank -2: more than ~4e9 perimeter slots or 65535 tile rows) is left to the iteration bound of the
         fixpoint (``max_iter``: a cycle through a block edge never settles and raises there)."""
-        if self._h.graph_stats()["max_rank"] == -1:
+        max_rank = self._h.graph_stats()["max_rank"]
+        if max_rank == -1:
             raise NotImplementedError(f"{what}: the raster holds a cycle and is too large for one ordering "
                                       "(beyond 2**32 - 2 cells the operation runs in row blocks, which need an acyclic raster)")
+        if max_rank == -2 and what == "stream_order":
+            # (sums on a cycle grow until max_iter raises; a Strahler order on a cycle can SETTLE on values the reference
+            #  never assigns — without the rank query there is no telling, so the order is refused rather than guessed)
+            raise NotImplementedError("stream_order: the raster is too large for the cycle check that the row-block "
+                                      "Strahler order needs (more than 65535 tile rows or ~4e9 perimeter slots)")
 
     def hand(self, drain, elevtn):
         """Height above the nearest drain (float64); reference pyflwdir/pyflwdir.py:1485-1511."""
