@@ -21,10 +21,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEP_KERNELS = ("k_tile", "k_exit_lists", "k_boundary_records", "k_super", "k_link3", "k_link4", "k_hyper", "k_sx_totals", "k_push4", "k_coarse_round",
-                "k_check_saturated", "fillBuffer")
+                "k_check_saturated", "fillBuffer", "k_pass_clear", "k_l4_restart")
 # kernels of one warm call, by a substring of their (templated) names; calls per bench.py --ops run = steps + 1
 OPS = {"accuflux_f32_up": ("AccuUp<float",), "strahler": ("Strahler",), "hand_f32": ("Hand<float",),
-       "basins_u32": ("k_path<1", "k_xround<1", "k_xinit<1", "k_labels_out", "k_seed")}
+       "basins_u32": ("k_path<1", "k_xround<1", "k_xinit<1", "k_labels_out", "k_seed", "k_flag_seed", "k_zero_seed")}
 OP_SHAPE = {"c3": (30000, 30000), "c5": (36000, 72000)}
 
 

@@ -6,6 +6,7 @@ cd $R
 O=gpurun_out/$T
 mkdir -p $O
 clean() { find gpurun_out -name '*_results.db' -delete; }
+export PFD_TOOL_RESERVE_GIB=${PFD_TOOL_RESERVE_GIB:-120}   # (tools/*.py: one arena for the working buffers; bench.py reserves its own)
 bash tools/prof_calib.sh ${T}_calib > $O/calib.txt 2>&1; cp gpurun_out/${T}_calib/calib.csv $O/pmc_calibration_widths.csv  # (first: the FETCH_SIZE factor the folds below use)
 python bench.py > $O/bench_default_before_pmc.json 2> $O/bench_default.err
 bash tools/prof_pmc.sh 90000 ${T}_pmc > $O/pmc90k.txt 2>&1; cp gpurun_out/${T}_pmc/pmc_fetch_write.csv $O/pmc_fetch_write_90000.csv; clean
@@ -24,6 +25,8 @@ SQ_SIZE=10000 bash tools/prof_sq.sh "k_tile|k_super" > $O/sq_counters.csv 2>&1; 
 bash tools/run_ops.sh ${T}_ops > /dev/null 2>&1; cp gpurun_out/${T}_ops/*.txt $O/
 python tools/bench_blocks.py 11250 8 90000 > $O/blocks8_c4.txt 2>&1
 PFD_BLOCK_PHASES=1 python tools/bench_blocks_isolated.py 11250 8 90000 > $O/blocks8_isolated.txt 2>&1
+bash tools/run_rank_replay.sh ${T} > /dev/null 2>&1; cp gpurun_out/${T}_rank_replay.txt $O/rank_replay.txt
+python bench.py --gpus 8 --rccl-loopback --steps 5 --warmup 1 > $O/bench_gpus8_loopback.json 2> $O/bench_gpus8_loopback.err
 for op in hand basins accuflux strahler; do for g in 1 4; do python bench.py --gpus $g --op $op --steps 2 --warmup 1 > $O/op_${op}_n$g.json 2>/dev/null; done; done
 python tools/bench_blocks.py 10000 4 > $O/blocks4.txt 2>&1
 python tools/bench_hand_blocks.py 36000 72000 4 > $O/hand_blocks_c5.txt 2>&1
