@@ -246,7 +246,7 @@ int pfd_upstream_area_cell_dist(pfd_raster *h, pfd_comm *comm, int32_t *out, int
  * Strahler, stream_distance: pyflwdir_amd/dist.py DistributedRaster), device to device over RCCL — SURVEY 8e's
  * "ncclSend/ncclRecv pairs in one ncclGroup": rank k sends the first OWN row of `result_dev` to rank k-1 and the
  * last OWN row to rank k+1 and receives their boundary rows as its new halo values.
- *   result_dev  the block's result on the device (own + halo rows, elem_bytes per cell)
+ *   result_dev  the block's result on the device (own + halo rows, elem_bytes per cell: 1, 4, 8 or 16)
  *   seed_dev    DEVICE, 2 * ncol elements: the halo values of the next sweep (top halo row, bottom halo row), updated
  *               in place; sides without a neighbour keep their content
  *   counters    in: two local counts; out: [0], [1] their sums over the ranks (one ncclAllReduce), [2] 1 if a
@@ -323,6 +323,15 @@ int pfd_strahler_block(pfd_raster *h, const uint8_t *mask, const uint8_t *halo_s
 int pfd_stream_distance_block(pfd_raster *h, const uint8_t *mask, int real_length, const float *step_lengths,
                               const void *halo_seed_host, int verify, void *out, int memspace, void *boundary_rows_host,
                               int64_t *n_bad);
+/* dem.floodplains (reference pyflwdir/dem.py:333-379) of a row block, like pfd_stream_distance_block: the halo cells the
+ * block drains into hold the neighbouring block's floodplain STATE, 16 bytes per cell {float z, float h, int32 flag, int32
+ * pad} (z / h: elevation and height threshold of the stream cell that started the floodplain; flag 1 floodplain, 0 not,
+ * -1 nodata); `state` (own + halo rows of the block's device raster) is the result, `halo_seed_host` / boundary rows hold
+ * 2 * ncol such records.  `is_stream` / `stream_h` as in pfd_floodplains.  Iterated by pyflwdir_amd/dist.py
+ * floodplains_blocks until no boundary row changes: floodplains on rasters beyond 2^32 - 2 cells. */
+int pfd_floodplains_block(pfd_raster *h, int elev_dtype, const void *elevtn, const uint8_t *is_stream, const float *stream_h,
+                          const void *halo_seed_host, int verify, void *state, int memspace, void *boundary_rows_host,
+                          int64_t *n_bad);
 
 /* basins (reference pyflwdir/basins.py:12-18, core.py:120-146) on a raster row-tiled over several GPUs /
  * processes, split-phase like pfd_upstream_area_cell_begin/_finish (Multi-GPU): `outlets` are k

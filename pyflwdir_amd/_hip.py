@@ -40,7 +40,7 @@ SYMBOLS = [
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
     "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic", "pfd_set_block_update",
-    "pfd_reserve", "pfd_alloc_stats", "pfd_count_nonfinite",
+    "pfd_reserve", "pfd_alloc_stats", "pfd_count_nonfinite", "pfd_floodplains_block",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
         L.pfd_trim.argtypes = [C.c_int]
         L.pfd_reserve.argtypes = [C.c_int, C.c_size_t]
         L.pfd_alloc_stats.argtypes = [C.POINTER(C.c_int64)]
+        L.pfd_count_nonfinite.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pfd_device_count.argtypes = [C.POINTER(C.c_int)]
         L.pfd_synth_d8.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                    C.c_int64, C.c_int64, C.c_void_p]
@@ -166,6 +167,11 @@ def ptr(a):
     if isinstance(a, DeviceBuffer):
         return C.c_void_p(a.addr)
     return C.c_void_p(int(a))
+
+
+# state record of the row-block floodplains (csrc/sweeps.hip FloodV): elevation / height threshold of the stream cell that
+# started the floodplain, flag (1 floodplain, 0 not, -1 nodata), padding
+FLOOD_STATE = np.dtype([("z", np.float32), ("h", np.float32), ("flag", np.int32), ("pad", np.int32)])
 
 
 def reserve(nbytes: int, device: int = 0):
@@ -456,6 +462,20 @@ class RasterHandle:
         bad = C.c_int64(0)
         check(lib().pfd_stream_distance_block(self._h, ptr(mask), int(real), ptr(step_lengths), ptr(halo_seed),
                                               1 if verify else 0, ptr(out), memspace, ptr(brows), C.byref(bad)))
+        return brows, int(bad.value)
+
+    def floodplains_block(self, elevtn, elev_code, is_stream, stream_h, halo_seed, state, verify=False, memspace=PFD_HOST):
+        """dem.floodplains of a row block whose halo cells hold the floodplain state ``halo_seed`` (2 * ncol records of
+        FLOOD_STATE, host, or a DeviceBuffer after set_block_io); ``state`` covers the block's device raster.  Returns
+        (boundary rows [2, ncol] of FLOOD_STATE, own cells failing their local equation — verify only)."""
+        brows = None
+        if not isinstance(halo_seed, DeviceBuffer):
+            halo_seed = np.ascontiguousarray(halo_seed, dtype=FLOOD_STATE)
+            assert halo_seed.size == 2 * self.ncol
+            brows = np.empty((2, self.ncol), FLOOD_STATE)
+        bad = C.c_int64(0)
+        check(lib().pfd_floodplains_block(self._h, int(elev_code), ptr(elevtn), ptr(is_stream), ptr(stream_h), ptr(halo_seed),
+                                          1 if verify else 0, ptr(state), memspace, ptr(brows), C.byref(bad)))
         return brows, int(bad.value)
 
     def strahler_block(self, mask, halo_seed, out, verify=False, memspace=PFD_HOST):

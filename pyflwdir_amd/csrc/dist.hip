@@ -152,7 +152,7 @@ static int comm_reserve(pfd_comm *c, size_t bytes) {
 
 extern "C" int pfd_comm_exchange_rows(pfd_comm *c, pfd_raster *h, const void *result_dev, int elem_bytes, void *seed_dev,
                                       int64_t counters[4]) {
-  if (!c || !c->comm || !h || !result_dev || !seed_dev || !counters || (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8)) {
+  if (!c || !c->comm || !h || !result_dev || !seed_dev || !counters || (elem_bytes != 1 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16)) {
     pfd_set_error("pfd_comm_exchange_rows: bad arguments");
     return PFD_EINVAL;
   }

@@ -1545,6 +1545,11 @@ __device__ __forceinline__ u64 bits_of(float v) { return (u64)__float_as_uint(v)
 __device__ __forceinline__ u64 bits_of(i64 v) { return (u64)v; }
 __device__ __forceinline__ u64 bits_of(i32 v) { return (u64)(u32)v; }
 __device__ __forceinline__ u64 bits_of(u8 v) { return (u64)v; }
+template <class T>
+__device__ __forceinline__ bool bits_equal(const T &a, const T &b) { return bits_of(a) == bits_of(b); }
+__device__ __forceinline__ bool bits_equal(const FloodV &a, const FloodV &b) {  // (the padding word carries nothing)
+  return __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.h) == __float_as_uint(b.h) && a.flag == b.flag;
+}
 // local equations of every own cell against the values in place (halo rows = the neighbours' final rows): the
 // all-cell check of a result that was computed in blocks, and the fixpoint the iteration ends in
 template <class Op, class T>
@@ -1645,7 +1650,7 @@ __global__ void __launch_bounds__(256) k_verify_down(Op op, const u8 *__restrict
     if (code != D8_MV) {
       const bool root = !d8_is_dir(code);
       const T v = (T)op.apply(x, code, root, root ? T() : out[d8_down(g, x, code)]);
-      b = bits_of(v) != bits_of(out[x]);
+      b = !bits_equal(v, out[x]);
     }
   }
   const u64 m = __ballot(b);
@@ -2241,4 +2246,46 @@ extern "C" int pfd_floodplains(pfd_raster *h, int elev_dtype, const void *elevtn
   k_flood_out<<<grid, 256, 0, h->stream>>>(st.as<FloodV>(), h->geo.n, (int8_t *)o.dev);
   KCHK();
   return o.finish(h->stream);  // (synchronises: `st` may be released afterwards)
+}
+
+// dem.floodplains of a ROW BLOCK (reference pyflwdir/dem.py:333-379), the down- to upstream twin of pfd_hand_block /
+// pfd_stream_distance_block: a halo cell the block drains into holds the neighbouring block's STATE — (z, h, flag) of the
+// floodplain that cell is in, 16 bytes — as `halo_seed_host` gives it; the caller exchanges the boundary rows of the
+// state and sweeps again until no row changes (pyflwdir_amd/dist.py floodplains_blocks).  `state` covers the block's
+// device raster (own + halo rows, FloodV = {float z, float h, int32 flag, int32 pad} per cell) and IS the result: flag
+// = 1 floodplain, 0 not, -1 nodata.  Lifts the 2^32-cell limit of pfd_floodplains for rasters cut into row blocks.
+extern "C" int pfd_floodplains_block(pfd_raster *h, int elev_dtype, const void *elevtn, const uint8_t *is_stream,
+                                     const float *stream_h, const void *halo_seed_host, int verify, void *state,
+                                     int memspace, void *boundary_rows_host, int64_t *n_bad) {
+  PFDCHK(up_block_prepare(h, "pfd_floodplains_block"));
+  if (!elevtn || !is_stream || !stream_h || !state || !halo_seed_host || (elev_dtype != PFD_F32 && elev_dtype != PFD_F64)) {
+    pfd_set_error("pfd_floodplains_block: bad arguments (elevation dtype code %d)", elev_dtype);
+    return PFD_EINVAL;
+  }
+  PFDCHK(ensure_sweep_structure(h, true));
+  InArg el, sm, hh, sd;
+  PFDCHK(el.bind(elevtn, (size_t)h->n * (elev_dtype == PFD_F32 ? 4 : 8), memspace, h->stream));
+  PFDCHK(sm.bind(is_stream, (size_t)h->n, memspace, h->stream));
+  PFDCHK(hh.bind(stream_h, (size_t)h->n * sizeof(float), memspace, h->stream));
+  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol * sizeof(FloodV), h->block_seed_space, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(state, (size_t)h->n * sizeof(FloodV), memspace));
+  if (verify && memspace == PFD_HOST)
+    HIPCHK(hipMemcpyAsync(o.dev, state, (size_t)h->n * sizeof(FloodV), hipMemcpyHostToDevice, h->stream));
+  if (!verify) {
+    pfd_seg_begin(h, "init");
+    k_flood_init<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo.n, (FloodV *)o.dev);
+    KCHK();
+    pfd_seg_end(h, 1);
+  }
+  if (elev_dtype == PFD_F32) {
+    Flood<float> op{h->ncode, h->geo, (const u8 *)sm.dev, (const float *)hh.dev, (const float *)el.dev, (FloodV *)o.dev};
+    PFDCHK(down_block_run(h, op, (FloodV *)o.dev, (const FloodV *)sd.dev, verify, (FloodV *)boundary_rows_host, n_bad,
+                          "sweep_floodplains_block"));
+  } else {
+    Flood<double> op{h->ncode, h->geo, (const u8 *)sm.dev, (const float *)hh.dev, (const double *)el.dev, (FloodV *)o.dev};
+    PFDCHK(down_block_run(h, op, (FloodV *)o.dev, (const FloodV *)sd.dev, verify, (FloodV *)boundary_rows_host, n_bad,
+                          "sweep_floodplains_block"));
+  }
+  return verify ? PFD_OK : o.finish(h->stream);
 }

@@ -348,6 +348,75 @@ def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verif
             blk.close()
 
 
+class _FloodBlock:
+    """Device-resident state of one row block of dem.floodplains between the exchanges: elevation, stream flags, height
+    thresholds and the floodplain state (16 bytes per cell) stay in HBM; only the two boundary rows of the state travel."""
+
+    def __init__(self, handle, elevtn_rows, elev_code, is_stream_rows, stream_h_rows):
+        self.h, self.code = handle, elev_code
+        ncol, dev = handle.ncol, handle.device
+        self.nrows_dev = handle.nrow + sum(handle.halo)
+        up = lambda a: _hip.DeviceBuffer(a.nbytes, dev).upload(np.ascontiguousarray(a))  # noqa: E731
+        self.elev, self.stream, self.hs = up(elevtn_rows), up(is_stream_rows), up(stream_h_rows)
+        self.state = _hip.DeviceBuffer(self.nrows_dev * ncol * _hip.FLOOD_STATE.itemsize, dev)
+        self.swept_with, self.brows = None, None
+
+    def _call(self, seed, verify):
+        return self.h.floodplains_block(self.elev, self.code, self.stream, self.hs, seed, self.state, verify=verify,
+                                        memspace=_hip.PFD_DEVICE)
+
+    def sweep(self, seed):
+        bits = seed.view(np.uint8)
+        if self.swept_with is not None and np.array_equal(self.swept_with, bits):
+            return False
+        self.swept_with = bits.copy()
+        self.brows, _ = self._call(seed, False)
+        return True
+
+    def verify(self, seed):
+        return self._call(seed, True)[1]
+
+    def result(self):
+        ncol, sz = self.h.ncol, _hip.FLOOD_STATE.itemsize
+        st = self.state.download(_hip.FLOOD_STATE, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol * sz)
+        return st["flag"].astype(np.int8)
+
+    def close(self, close_handle=True):
+        for b in (self.elev, self.stream, self.hs, self.state):
+            b.free()
+        if close_handle:
+            self.h.close()
+
+
+def floodplains_blocks(d8: np.ndarray, nblocks: int, elevtn, is_stream, stream_h, devices=None, verify=False,
+                       max_iter=MAX_ROUNDS):
+    """``dem.floodplains`` (reference pyflwdir/dem.py:333-379) of a host raster computed as ``nblocks`` row blocks held by
+    this one process — what ``FlwdirRaster.floodplains`` runs beyond 2**32 - 2 cells.  ``is_stream`` (uint8: upstream area
+    >= upa_min) and ``stream_h`` (float32: uparea ** b on the stream cells, evaluated by the caller in the reference's
+    dtype) as ``pfd_floodplains`` takes them.  A cell joins the floodplain of its DOWNSTREAM cell, so a block needs the
+    state (z, h, flag) of the cells it drains into across its edges: the halo rows hold the neighbours' boundary rows
+    of the state, exchanged until no row changes.  Returns (int8 flags, rounds, bad cells or None)."""
+    d8 = np.ascontiguousarray(d8, dtype=np.uint8)
+    nrow, ncol = d8.shape
+    elevtn = np.ascontiguousarray(elevtn).reshape(nrow, ncol)
+    if elevtn.dtype not in _ELEV_CODE:
+        raise NotImplementedError(f"elevation dtype {elevtn.dtype} is not supported on the HIP path")
+    is_stream = np.ascontiguousarray(is_stream, dtype=np.uint8).reshape(nrow, ncol)
+    stream_h = np.ascontiguousarray(stream_h, dtype=np.float32).reshape(nrow, ncol)
+    devices = devices or [0] * nblocks
+    blocks = []
+    try:
+        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
+            a, e = block_slice(nrow, nblocks, b)
+            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
+            blocks.append(_FloodBlock(h, elevtn[a:e], _ELEV_CODE[elevtn.dtype], is_stream[a:e], stream_h[a:e]))
+        it, bad = _up_blocks_run(blocks, ncol, _hip.FLOOD_STATE, max_iter=max_iter, verify=verify)
+        return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
+    finally:
+        for blk in blocks:
+            blk.close()
+
+
 class _HandBlock:
     """Device-resident state of one row block's HAND between the exchanges: drain, elevation and the heights stay in
     HBM; only the two boundary rows and the number of unknown cells travel."""

@@ -770,6 +770,14 @@ class FlwdirRaster(object):
             code, elevtn = _hip.PFD_F64, elevtn.astype(np.float64, copy=False)
         else:
             raise NotImplementedError(f"elevation dtype {elevtn.dtype} is not supported on the HIP path")
+        nb = self._row_blocks_needed()
+        if nb > 1:  # beyond 32-bit cell indices: row blocks that exchange the floodplain state of their boundary rows
+            from . import dist
+
+            self._refuse_cycles_in_blocks("floodplains")
+            out = dist.floodplains_blocks(self._d8, nb, elevtn, is_stream, hs)[0]
+            # (cells that reach no pit are off the reference's sequence and keep -1; on an acyclic raster: nodata only)
+            return out.reshape(self.shape)
         return self._h.floodplains(np.ascontiguousarray(elevtn), code, is_stream, hs).reshape(self.shape)
 
     # -- shortcuts ------------------------------------------------------------------------------
