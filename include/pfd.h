@@ -332,6 +332,18 @@ int pfd_stream_distance_block(pfd_raster *h, const uint8_t *mask, int real_lengt
 int pfd_floodplains_block(pfd_raster *h, int elev_dtype, const void *elevtn, const uint8_t *is_stream, const float *stream_h,
                           const void *halo_seed_host, int verify, void *state, int memspace, void *boundary_rows_host,
                           int64_t *n_bad);
+/* Classic stream order (reference pyflwdir/streams.py:191-225 with core.main_upstream, core.py:191-219) over row blocks.
+ * pfd_trib_info_block: one byte per cell of the block's device raster — low 4 bits the slot (0-7; 15 none) of the cell's
+ * main upstream cell (largest `uparea` > upa_min, first in ascending index), bit 4 set when more than one upstream cell
+ * lies inside `mask` (nullable) — from the upstream masks that include the halo cells.  The byte of a HALO cell is
+ * incomplete (its upstream cells lie beyond the block): the caller replaces the halo rows of `tinfo` with the
+ * neighbouring blocks' boundary rows, then pfd_stream_order_classic_block sweeps down- to upstream with the halo cells
+ * the block drains into holding the neighbour's orders (`halo_seed_host`: 2 * ncol uint8), like
+ * pfd_stream_distance_block; iterated until no boundary row changes (pyflwdir_amd/dist.py classic_blocks). */
+int pfd_trib_info_block(pfd_raster *h, int dtype, const void *uparea, double upa_min, const uint8_t *mask, uint8_t *tinfo,
+                        int memspace);
+int pfd_stream_order_classic_block(pfd_raster *h, const uint8_t *tinfo, const uint8_t *mask, const uint8_t *halo_seed_host,
+                                   int verify, uint8_t *out, int memspace, uint8_t *boundary_rows_host, int64_t *n_bad);
 
 /* basins (reference pyflwdir/basins.py:12-18, core.py:120-146) on a raster row-tiled over several GPUs /
  * processes, split-phase like pfd_upstream_area_cell_begin/_finish (Multi-GPU): `outlets` are k

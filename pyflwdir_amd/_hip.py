@@ -40,7 +40,8 @@ SYMBOLS = [
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
     "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic", "pfd_set_block_update",
-    "pfd_reserve", "pfd_alloc_stats", "pfd_count_nonfinite", "pfd_floodplains_block",
+    "pfd_reserve", "pfd_alloc_stats", "pfd_count_nonfinite", "pfd_floodplains_block", "pfd_trib_info_block",
+    "pfd_stream_order_classic_block",
 ]
 
 _lib = None
@@ -462,6 +463,27 @@ class RasterHandle:
         bad = C.c_int64(0)
         check(lib().pfd_stream_distance_block(self._h, ptr(mask), int(real), ptr(step_lengths), ptr(halo_seed),
                                               1 if verify else 0, ptr(out), memspace, ptr(brows), C.byref(bad)))
+        return brows, int(bad.value)
+
+    def trib_info_block(self, uparea, dtype_code, mask=None, upa_min=0.0, out=None, memspace=PFD_HOST):
+        """One byte per cell of the block's device raster: slot of the main upstream cell | (more than one upstream cell
+        inside the mask) << 4 (include/pfd.h pfd_trib_info_block); the halo rows are the caller's to fill in."""
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, np.uint8)
+        check(lib().pfd_trib_info_block(self._h, int(dtype_code), ptr(uparea), float(upa_min), ptr(mask), ptr(out), memspace))
+        return out
+
+    def stream_order_classic_block(self, tinfo, mask, halo_seed, out, verify=False, memspace=PFD_HOST):
+        """Classic stream order of a row block whose halo cells hold ``halo_seed`` (2 * ncol uint8).  Returns (boundary
+        rows [2, ncol], own cells failing their local equation — verify only)."""
+        brows = None
+        if not isinstance(halo_seed, DeviceBuffer):
+            halo_seed = np.ascontiguousarray(halo_seed, dtype=np.uint8)
+            assert halo_seed.size == 2 * self.ncol
+            brows = np.empty((2, self.ncol), np.uint8)
+        bad = C.c_int64(0)
+        check(lib().pfd_stream_order_classic_block(self._h, ptr(tinfo), ptr(mask), ptr(halo_seed), 1 if verify else 0, ptr(out),
+                                                   memspace, ptr(brows), C.byref(bad)))
         return brows, int(bad.value)
 
     def floodplains_block(self, elevtn, elev_code, is_stream, stream_h, halo_seed, state, verify=False, memspace=PFD_HOST):

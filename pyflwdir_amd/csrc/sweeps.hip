@@ -1627,14 +1627,14 @@ static int up_block_prepare(pfd_raster *h, const char *what) {
   return ensure_sweep_structure(h, true);  // (the exact-order plan of the block, or its level structure)
 }
 // ---- down-sweeps of a row block (accuflux direction "down"): the halo cells a block drains into hold given values ----
-template <class Op>
+template <class Op, class T = typename Op::V>
 struct HaloSeeded : Op {  // level engine: a halo cell is a root of the block's ordering; its value is its seed
-  const typename Op::V *seed;
+  const T *seed;  // (T: the stored type of the result, which the operation's V may be wider than)
   u32 row_last;
   __device__ __forceinline__ typename Op::V apply(u32 x, u32 code, bool root, typename Op::V pv) const {
     if (code == D8_HALO) {
       const u32 r = geo_row(this->g, x);
-      return seed[(r > row_last ? this->g.ncol : 0u) + (x - r * this->g.ncol)];
+      return (typename Op::V)seed[(r > row_last ? this->g.ncol : 0u) + (x - r * this->g.ncol)];
     }
     return Op::apply(x, code, root, pv);
   }
@@ -1682,7 +1682,7 @@ static int down_block_run(pfd_raster *h, const Op &op0, T *out_dev, const T *see
   } else if (h->xplan_state == 1) {
     PFDCHK(run_exact_down(h, op0, "exact_down_block"));  // (halo cells: given values, loaded and written back unchanged)
   } else {
-    HaloSeeded<Op> op{op0, seed_dev, (u32)(h->halo_top + h->own_rows - 1)};
+    HaloSeeded<Op, T> op{op0, seed_dev, (u32)(h->halo_top + h->own_rows - 1)};
     PFDCHK(run_down(h, op, name));
     PFDCHK(seed_rows());  // (the level engine stored the seeds of the VALID halo cells only)
   }
@@ -2125,6 +2125,116 @@ extern "C" int pfd_stream_order_classic(pfd_raster *h, int idx_dtype, const void
   pfd_seg_end(h, 2);
   Classic op{h->ncode, h->geo, flag.as<u8>(), (const u8 *)m.dev, (u8 *)o.dev};
   PFDCHK(sweep_down(h, op, "sweep_classic_order", "exact_classic_order"));
+  return o.finish(h->stream);  // (synchronises: `flag` may be released afterwards)
+}
+
+// ---------------------------------------------------------------------------------------------
+// classic stream order over ROW BLOCKS (reference pyflwdir/streams.py:191-225 + core.main_upstream core.py:191-219):
+// what a cell needs to know of its DOWNSTREAM cell p is one byte — which of p's neighbours is p's main upstream cell
+// (slot 0-7, 15: none) and whether p has more than one upstream cell inside the mask (bit 4) — no index array at all:
+// a cell that drains into p through direction k is p's neighbour (k + 4) & 7.  pfd_trib_info_block computes that byte
+// for every cell of the block's device raster from the upstream masks that include the halo cells (the block's plan /
+// level structure); the byte of a HALO cell is incomplete (its own upstream cells lie beyond the block) and is
+// replaced by the neighbouring block's boundary row before pfd_stream_order_classic_block reads it
+// (pyflwdir_amd/dist.py classic_blocks: one exchange of one byte per boundary cell, then the seeded down-sweeps).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_trib_info(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ kids,
+                                                   const T *__restrict__ uparea, T upa_min, const u8 *__restrict__ mask,
+                                                   u8 *__restrict__ tinfo) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.n) return;
+  u32 slot = 15u, nup = 0;
+  if (ncode[x] != D8_MV) {
+    const u32 m = kids[x];
+    T best = upa_min;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // ascending index: the first maximum wins (core.py:216, strict >)
+      const int k = PFD_SLOT_ASC[q];
+      if (m & (1u << k)) {
+        const u32 nb = nb_of(g, x, k);
+        const T a = uparea[nb];
+        if (a > best) best = a, slot = (u32)k;
+        nup += (mask == nullptr || mask[nb]) ? 1u : 0u;
+      }
+    }
+  }
+  tinfo[x] = (u8)(slot | (nup > 1u ? 0x10u : 0u));
+}
+__global__ void __launch_bounds__(256) k_trib_flag_info(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ tinfo,
+                                                        u8 *__restrict__ flag) {
+  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.n) return;
+  u8 f = 0;
+  const u32 code = ncode[x];
+  if (d8_is_dir(code)) {
+    const u32 t = tinfo[d8_down(g, x, code)];
+    f = ((t & 0x10u) && (t & 0xFu) != (((u32)d8_slot(code) + 4u) & 7u)) ? 1 : 0;
+  }
+  flag[x] = f;
+}
+extern "C" int pfd_trib_info_block(pfd_raster *h, int dtype, const void *uparea, double upa_min, const uint8_t *mask,
+                                   uint8_t *tinfo, int memspace) {
+  PFDCHK(up_block_prepare(h, "pfd_trib_info_block"));
+  const size_t ps = payload_bytes(dtype);
+  if (!uparea || !tinfo || !ps) {
+    pfd_set_error("pfd_trib_info_block: bad arguments (dtype %d)", dtype);
+    return PFD_EINVAL;
+  }
+  PFDCHK(ensure_sweep_structure(h, true));
+  const u8 *kids = nullptr;  // per cell: the neighbours draining into it, halo cells included
+  if (h->xplan_state == 1) {
+    kids = ((ExactPlan *)h->xplan)->kids;
+  } else {
+    PFDCHK(pfd_ensure_seq_aux(h));
+    kids = h->cell_kids;
+  }
+  InArg a, m;
+  PFDCHK(a.bind(uparea, (size_t)h->n * ps, memspace, h->stream));
+  PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(tinfo, (size_t)h->n, memspace));
+  const u32 grid = cdiv_u32((u64)h->n, 256);
+  pfd_seg_begin(h, "trib_info");
+  switch (dtype) {
+    case PFD_I32: k_trib_info<i32><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, kids, (const i32 *)a.dev, (i32)upa_min, (const u8 *)m.dev, (u8 *)o.dev); break;
+    case PFD_I64: k_trib_info<i64><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, kids, (const i64 *)a.dev, (i64)upa_min, (const u8 *)m.dev, (u8 *)o.dev); break;
+    case PFD_F32: k_trib_info<float><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, kids, (const float *)a.dev, (float)upa_min, (const u8 *)m.dev, (u8 *)o.dev); break;
+    default: k_trib_info<double><<<grid, 256, 0, h->stream>>>(h->ncode, h->geo, kids, (const double *)a.dev, upa_min, (const u8 *)m.dev, (u8 *)o.dev); break;
+  }
+  KCHK();
+  pfd_seg_end(h, 1);
+  return o.finish(h->stream);
+}
+extern "C" int pfd_stream_order_classic_block(pfd_raster *h, const uint8_t *tinfo, const uint8_t *mask,
+                                              const uint8_t *halo_seed_host, int verify, uint8_t *out, int memspace,
+                                              uint8_t *boundary_rows_host, int64_t *n_bad) {
+  PFDCHK(up_block_prepare(h, "pfd_stream_order_classic_block"));
+  if (!tinfo || !out || !halo_seed_host) {
+    pfd_set_error("pfd_stream_order_classic_block: bad arguments");
+    return PFD_EINVAL;
+  }
+  PFDCHK(ensure_sweep_structure(h, true));
+  InArg ti, m, sd;
+  PFDCHK(ti.bind(tinfo, (size_t)h->n, memspace, h->stream));
+  PFDCHK(m.bind(mask, (size_t)h->n, memspace, h->stream));
+  PFDCHK(sd.bind(halo_seed_host, 2 * (size_t)h->ncol, h->block_seed_space, h->stream));
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)h->n, memspace));
+  if (verify && memspace == PFD_HOST) HIPCHK(hipMemcpyAsync(o.dev, out, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  DevBuf flag;
+  PFDCHK(flag.alloc((size_t)h->n));
+  pfd_seg_begin(h, "init");
+  if (!verify && h->xplan_state != 1) HIPCHK(hipMemsetAsync(o.dev, 0, (size_t)h->n, h->stream));
+  k_trib_flag_info<<<cdiv_u32((u64)h->n, 256), 256, 0, h->stream>>>(h->ncode, h->geo, (const u8 *)ti.dev, flag.as<u8>());
+  KCHK();
+  pfd_seg_end(h, 2);
+  Classic op{h->ncode, h->geo, flag.as<u8>(), (const u8 *)m.dev, (u8 *)o.dev};
+  PFDCHK(down_block_run(h, op, (u8 *)o.dev, (const u8 *)sd.dev, verify, boundary_rows_host, n_bad, "sweep_classic_block"));
+  if (verify) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PFD_OK;
+  }
   return o.finish(h->stream);  // (synchronises: `flag` may be released afterwards)
 }
 

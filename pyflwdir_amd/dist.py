@@ -348,6 +348,90 @@ def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verif
             blk.close()
 
 
+class _ClassicBlock:
+    """Device-resident state of one row block of the classic stream order between the exchanges: the per-cell byte of
+    pfd_trib_info_block (halo rows from the neighbours), the mask and the orders stay in HBM."""
+
+    def __init__(self, handle, tinfo_rows, mask_rows):
+        self.h = handle
+        ncol, dev = handle.ncol, handle.device
+        self.nrows_dev = handle.nrow + sum(handle.halo)
+        self.tinfo = _hip.DeviceBuffer(tinfo_rows.nbytes, dev).upload(np.ascontiguousarray(tinfo_rows))
+        self.mask = None if mask_rows is None else _hip.DeviceBuffer(mask_rows.nbytes, dev).upload(np.ascontiguousarray(mask_rows))
+        self.out = _hip.DeviceBuffer(self.nrows_dev * ncol, dev)
+        self.swept_with, self.brows = None, None
+
+    def _call(self, seed, verify):
+        return self.h.stream_order_classic_block(self.tinfo, self.mask, seed, self.out, verify=verify, memspace=_hip.PFD_DEVICE)
+
+    def sweep(self, seed):
+        bits = seed.view(np.uint8)
+        if self.swept_with is not None and np.array_equal(self.swept_with, bits):
+            return False
+        self.swept_with = bits.copy()
+        self.brows, _ = self._call(seed, False)
+        return True
+
+    def verify(self, seed):
+        return self._call(seed, True)[1]
+
+    def result(self):
+        ncol = self.h.ncol
+        return self.out.download(np.uint8, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol)
+
+    def close(self, close_handle=True):
+        for b in (self.tinfo, self.mask, self.out):
+            if b is not None:
+                b.free()
+        if close_handle:
+            self.h.close()
+
+
+def classic_blocks(d8: np.ndarray, nblocks: int, uparea, mask=None, upa_min=0.0, devices=None, verify=False,
+                   max_iter=MAX_ROUNDS):
+    """Classic stream order (reference pyflwdir/streams.py:191-225: the order grows by one at every confluence where the
+    cell is NOT its downstream cell's main upstream cell, core.py:191-219) of a host raster computed as ``nblocks`` row
+    blocks held by this one process — what ``FlwdirRaster.stream_order(type="classic")`` runs beyond 2**32 - 2 cells.
+    ``uparea``: the raster that ranks the upstream cells (the reference's default: the upstream cell count).  No index
+    array is built: a block computes one byte per cell (main upstream SLOT, several-upstream-cells flag), the blocks
+    swap the bytes of their boundary rows once, then sweep down- to upstream with their halo cells holding the
+    neighbours' orders until no boundary row changes.  Returns (uint8 orders, rounds, bad cells or None)."""
+    d8 = np.ascontiguousarray(d8, dtype=np.uint8)
+    nrow, ncol = d8.shape
+    uparea = np.ascontiguousarray(uparea).reshape(nrow, ncol)
+    if uparea.dtype not in _hip._PAYLOAD_CODE:
+        raise NotImplementedError(f"uparea dtype {uparea.dtype} is not supported by the row-block stream order")
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(nrow, ncol)
+    devices = devices or [0] * nblocks
+    handles, blocks = [], []
+    try:
+        infos = []
+        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
+            a, e = block_slice(nrow, nblocks, b)
+            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
+            handles.append(h)
+            infos.append(h.trib_info_block(uparea[a:e], _hip._PAYLOAD_CODE[uparea.dtype], None if mask is None else mask[a:e],
+                                           upa_min).reshape(e - a, ncol))
+        for b in range(nblocks):  # a halo cell's byte is its owner's: the neighbouring block's boundary row
+            top, bot = halo_of(b, nblocks)
+            if top:
+                infos[b][0] = infos[b - 1][-1 - halo_of(b - 1, nblocks)[1]]
+            if bot:
+                infos[b][-1] = infos[b + 1][halo_of(b + 1, nblocks)[0]]
+        for b in range(nblocks):
+            a, e = block_slice(nrow, nblocks, b)
+            blocks.append(_ClassicBlock(handles[b], infos[b], None if mask is None else mask[a:e]))
+        handles = []  # (the blocks own them now)
+        it, bad = _up_blocks_run(blocks, ncol, np.uint8, max_iter=max_iter, verify=verify)
+        return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
+    finally:
+        for h in handles:
+            h.close()
+        for blk in blocks:
+            blk.close()
+
+
 class _FloodBlock:
     """Device-resident state of one row block of dem.floodplains between the exchanges: elevation, stream flags, height
     thresholds and the floodplain state (16 bytes per cell) stay in HBM; only the two boundary rows of the state travel."""

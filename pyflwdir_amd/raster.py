@@ -606,7 +606,14 @@ class FlwdirRaster(object):
                     self._cached.update(strord=strord)
         elif type.lower() == "classic":  # reference pyflwdir/flwdir.py:540-543, streams.py:191-225
             m = None if mask is None else np.ascontiguousarray(mask != 0).view(np.uint8)
-            strord = self._h.stream_order_classic(np.ascontiguousarray(self.idxs_us_main), m)
+            nb = self._row_blocks_needed()
+            if nb > 1:  # beyond 32-bit cell indices: row blocks, one byte per cell instead of the index array
+                from . import dist
+
+                self._refuse_cycles_in_blocks("stream_order")
+                strord = dist.classic_blocks(self._d8, nb, self.upstream_area(), m)[0].ravel()
+            else:
+                strord = self._h.stream_order_classic(np.ascontiguousarray(self.idxs_us_main), m)
         else:
             # the reference falls through to an UnboundLocalError here; be explicit instead
             raise ValueError(f'Unknown stream order type: {type}, select from ["strahler", "classic"].')

@@ -643,3 +643,35 @@ def test_interface_paths_longer_than_the_chase(gpu_lib, oracle, monkeypatch, def
     exp = oracle.upstream_area_cell(d8)[0]
     monkeypatch.setenv("PFD_TEST_IFACE_HOPS", "1")
     assert np.array_equal(dist.upstream_area_blocks(d8, 5, deferred=deferred), exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("masked", [False, True])
+def test_classic_stream_order_over_row_blocks(gpu_lib, oracle, monkeypatch, masked):
+    """FlwdirRaster.stream_order(type="classic") beyond 32-bit cell indices (threshold lowered): one byte per cell about
+    the downstream cell's main upstream cell instead of the index array, swapped once between neighbouring blocks, then
+    seeded down-sweeps — the same orders as on one handle (whose classic order is pinned on the reference's goldens),
+    every own cell's local equation checked."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd import dist
+
+    O = oracle
+    shape = (1400, 900)
+    d8 = O.synth_d8(shape[0], shape[1], seed=23, tilt=100000, white=2, nodata_pct=12)
+    mask = None
+    if masked:
+        mask = (np.random.default_rng(2).random(shape) < 0.8)
+    whole = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    exp = whole.stream_order(type="classic", mask=mask)
+    assert exp.max() >= 5
+    blocked = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    monkeypatch.setenv("PFD_TEST_BIG_CELLS", "300000")  # 1.26 Mcells -> 5 row blocks
+    assert blocked._row_blocks_needed() == 5
+    got = blocked.stream_order(type="classic", mask=mask)
+    assert got.dtype == exp.dtype and np.array_equal(got, exp)
+    monkeypatch.delenv("PFD_TEST_BIG_CELLS")
+    upa = whole.upstream_area()
+    m8 = None if mask is None else mask.astype(np.uint8)
+    for nb in (2, 7):
+        res, rounds, bad = dist.classic_blocks(d8, nb, upa, m8, verify=True)
+        assert bad == 0 and rounds >= 1 and np.array_equal(res, exp), nb
