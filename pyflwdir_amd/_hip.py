@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
         L.pfd_reserve.argtypes = [C.c_int, C.c_size_t]
         L.pfd_alloc_stats.argtypes = [C.POINTER(C.c_int64)]
         L.pfd_count_nonfinite.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.pfd_trib_info_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_device_count.argtypes = [C.POINTER(C.c_int)]
         L.pfd_synth_d8.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                    C.c_int64, C.c_int64, C.c_void_p]
@@ -469,7 +470,7 @@ class RasterHandle:
         """One byte per cell of the block's device raster: slot of the main upstream cell | (more than one upstream cell
         inside the mask) << 4 (include/pfd.h pfd_trib_info_block); the halo rows are the caller's to fill in."""
         if memspace == PFD_HOST:
-            out = np.empty(self.n, np.uint8)
+            out = np.empty((self.nrow + sum(self.halo)) * self.ncol, np.uint8)
         check(lib().pfd_trib_info_block(self._h, int(dtype_code), ptr(uparea), float(upa_min), ptr(mask), ptr(out), memspace))
         return out
 
