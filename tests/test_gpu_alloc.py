@@ -55,3 +55,30 @@ def test_reserved_arena_serves_the_working_buffers(gpu_lib):
     assert r["reserved"] == 768 << 20 and r["arena_blocks_first"] > 5  # the >= 1 MiB buffers came out of the arena
     assert r["hipmalloc_big_later"] == 0  # second and third handle: cache + arena only
     assert r["reserved_after_release"] == 0  # every arena block was given back, the arena released
+
+
+CHILD_SMALL = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import oracle as O
+import pyflwdir_amd as pyflwdir
+from pyflwdir_amd import _hip
+_hip.reserve(8 << 20)  # far too small for the working buffers of this raster: they overflow into the class cache / hipMalloc
+d8 = O.synth_d8(2500, 2600, seed=9, tilt=1 << 26, white=2, nodata_pct=2)
+flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+ok = bool(np.array_equal(flw.upstream_area(), O.upstream_area_cell(d8)[0]))
+so = flw.stream_order()
+s = _hip.alloc_stats()
+del flw
+print(json.dumps(dict(ok=ok, somax=int(so.max()), hipmalloc=s["hipmalloc_calls"], arena_blocks=s["arena_blocks"], reserved=s["reserved_bytes"])))
+''' % ROOT
+
+
+def test_an_arena_that_is_too_small_overflows_into_the_cache(gpu_lib):
+    """Requests that do not fit the reserved arena fall back to the class cache / hipMalloc: results unchanged."""
+    out = subprocess.run([sys.executable, "-c", CHILD_SMALL], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["ok"] and r["somax"] >= 4 and r["reserved"] == 8 << 20
+    assert r["hipmalloc"] > 5  # the GB-class buffers did not come out of the 8 MiB arena
