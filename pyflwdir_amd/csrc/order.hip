@@ -354,19 +354,20 @@ extern "C" int pfd_idxs_pit(pfd_raster *h, int idx_dtype, void *out, int memspac
 // ---------------------------------------------------------------------------------------------
 // add_pits (reference pyflwdir/flwdir.py:261-279)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_add_pits(u8 *__restrict__ ncode, const i64 *__restrict__ idxs, u32 k, u32 n, u64 *ctrl) {
+// (64-bit cell indices: also for rasters beyond 2^32 - 2 cells, which only the tiled engine sweeps)
+__global__ void k_add_pits(u8 *__restrict__ ncode, const i64 *__restrict__ idxs, u32 k, i64 n, u64 *ctrl) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k) return;
   const i64 i = idxs[t];
-  if (i < 0 || i >= (i64)n || ncode[i] == D8_MV) {
+  if (i < 0 || i >= n || ncode[i] == D8_MV) {
     atomicAdd((unsigned long long *)&ctrl[C_BAD], 1ull);
     return;
   }
   ncode[i] = 0;
 }
-__global__ void __launch_bounds__(256) k_count_pits(const u8 *__restrict__ ncode, u32 n, u64 *ctrl) {
+__global__ void __launch_bounds__(256) k_count_pits(const u8 *__restrict__ ncode, i64 n, u64 *ctrl) {
   u32 cnt = 0;
-  for (u32 i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) cnt += ncode[i] == 0;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) cnt += ncode[i] == 0;
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd((unsigned long long *)&ctrl[C_NPITS], (unsigned long long)cnt);
 }
@@ -378,17 +379,21 @@ extern "C" int pfd_add_pits(pfd_raster *h, const int64_t *idxs, int64_t k) {
     return PFD_EINVAL;
   }
   if (k == 0) return PFD_OK;
-  PFDCHK(pfd_require_whole(h, "add_pits"));
+  if (h->halo_top || h->halo_bot) PFDCHK(pfd_require_whole(h, "add_pits"));  // (row blocks: edit the whole raster)
+  if (k > 0x7FFFFFFFll) {
+    pfd_set_error("pfd_add_pits: too many indices (%lld)", (long long)k);
+    return PFD_EINVAL;
+  }
   InArg in;
   HIPCHK(hipMemsetAsync(h->ctrl, 0, 64 * sizeof(u64), h->stream));
   if (h->gen) {
     PFDCHK(pfd_gen_add_pits(h, idxs, k));
   } else {
     PFDCHK(in.bind(idxs, (size_t)k * sizeof(i64), PFD_HOST, h->stream));
-    k_add_pits<<<cdiv_u32((u64)k, 256), 256, 0, h->stream>>>(h->ncode, (const i64 *)in.dev, (u32)k, h->geo.n, h->ctrl);
+    k_add_pits<<<cdiv_u32((u64)k, 256), 256, 0, h->stream>>>(h->ncode, (const i64 *)in.dev, (u32)k, h->n, h->ctrl);
     KCHK();
   }
-  k_count_pits<<<1024, 256, 0, h->stream>>>(h->ncode, h->geo.n, h->ctrl);
+  k_count_pits<<<1024, 256, 0, h->stream>>>(h->ncode, h->n, h->ctrl);
   KCHK();
   u64 c[3];
   HIPCHK(hipMemcpyAsync(c, h->ctrl, sizeof(c), hipMemcpyDeviceToHost, h->stream));

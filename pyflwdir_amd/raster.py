@@ -20,6 +20,7 @@ There is no CPU fallback: without the HIP library or a device the methods raise.
 """
 from __future__ import annotations
 
+import os
 import pickle
 
 import numpy as np
@@ -333,14 +334,33 @@ class FlwdirRaster(object):
     def idxs_ds(self):
         """Linear indices of the downstream cell (GPU decode, reference core_d8.from_array)."""
         if self._idxs_ds is None:
-            self._idxs_ds = self._h.idxs_ds(self._idx_dtype)
+            if self._row_blocks_needed() > 1:  # int64 rung of the reference's ladder (pyflwdir.py:105-127), slice by slice
+                ncol = self.shape[1]
+
+                def one(h, a, e):
+                    ds = h.idxs_ds(np.int64)
+                    return np.where(ds < 0, ds, ds + a * ncol)
+                self._idxs_ds = self._sliced(one, np.int64, -1).astype(self._idx_dtype, copy=False)
+            else:
+                self._idxs_ds = self._h.idxs_ds(self._idx_dtype)
         return self._idxs_ds
 
     @property
     def idxs_pit(self):
         """Linear indices of pits/outlets, ascending."""
         if self._pit is None:
-            self._pit = self._h.idxs_pit(self._idx_dtype)
+            if self._row_blocks_needed() > 1:
+                ncol, parts = self.shape[1], []
+                for r0, r1, a, e, h in self._row_slices():
+                    if h is None:
+                        continue
+                    p = h.idxs_pit(np.int64) + a * ncol
+                    parts.append(p[(p >= r0 * ncol) & (p < r1 * ncol)])
+                self._pit = (np.concatenate(parts) if parts else np.empty(0, np.int64)).astype(self._idx_dtype, copy=False)
+                if self._pit.size == 0:
+                    raise ValueError("Invalid FlwdirRaster: no pits found")
+            else:
+                self._pit = self._h.idxs_pit(self._idx_dtype)
         return self._pit
 
     @property
@@ -388,6 +408,8 @@ class FlwdirRaster(object):
 
     @property
     def n_upstream(self):
+        if self._row_blocks_needed() > 1:
+            return self._sliced(lambda h, a, e: h.upstream_count(), np.int8, -9).reshape(self.shape)
         return self._h.upstream_count().reshape(self.shape)
 
     @property
@@ -582,6 +604,11 @@ class FlwdirRaster(object):
         data = np.asarray(data)
         flat = self._check_data(data, "data")
         view, code, nd_i, nd_f, has_nd = _payload_args(flat, mv)
+        if self._row_blocks_needed() > 1:
+            ncol = self.shape[1]
+            out = self._sliced(lambda h, a, e: h.upstream_sum(np.ascontiguousarray(view[a * ncol:e * ncol]), code, nodata_i=nd_i,
+                                                              nodata_f=nd_f, has_nodata=has_nd), view.dtype, 0)
+            return out.view(flat.dtype).reshape(data.shape)
         out = self._h.upstream_sum(view, code, nodata_i=nd_i, nodata_f=nd_f, has_nodata=has_nd)
         return out.view(flat.dtype).reshape(data.shape)
 
@@ -651,7 +678,15 @@ class FlwdirRaster(object):
             if uparea.dtype.kind not in "iubf":
                 raise NotImplementedError(f"uparea dtype {uparea.dtype} is not supported on the HIP path")
             uparea = uparea.astype(np.float64 if uparea.dtype.kind == "f" else np.int64)
-        idxs_us_main = self._h.main_upstream(np.ascontiguousarray(uparea), _PAYLOAD[uparea.dtype], self._idx_dtype)
+        if self._row_blocks_needed() > 1:
+            ncol = self.shape[1]
+
+            def one(h, a, e):
+                mu = h.main_upstream(np.ascontiguousarray(uparea[a * ncol:e * ncol]), _PAYLOAD[uparea.dtype], np.int64)
+                return np.where(mu < 0, mu, mu + a * ncol)
+            idxs_us_main = self._sliced(one, np.int64, -1).astype(self._idx_dtype, copy=False)
+        else:
+            idxs_us_main = self._h.main_upstream(np.ascontiguousarray(uparea), _PAYLOAD[uparea.dtype], self._idx_dtype)
         if self.cache:
             self._cached.update(idxs_us_main=idxs_us_main)
         return idxs_us_main
@@ -689,6 +724,44 @@ class FlwdirRaster(object):
 
             return dist.basins_blocks(self._d8, nb, idxs64, ids).reshape(self.shape)
         return self._h.basins(idxs64, ids).reshape(self.shape)
+
+    def _row_slices(self):
+        """For rasters beyond 32-bit cell indices: (r0, r1, a, e, handle) over row chunks — a PLAIN handle on the rows
+        [a, e) = the chunk [r0, r1) plus one context row on every inner side.  What a cell-local export (downstream index,
+        pit test, upstream count / sum, main upstream cell) says about a cell of the chunk depends on its 8 neighbours
+        only, and those see the same codes as in the whole raster; the context rows' own answers are dropped.  (Cells of a
+        context row that point out of the slice become pits THERE — never in the chunk.)"""
+        nrow, ncol = self.shape
+        per = max(1, min(nrow, (1 << 30) // max(1, ncol)))
+        if os.environ.get("PFD_ENABLE_KNOBS") == "1" and os.environ.get("PFD_TEST_BIG_CELLS"):
+            per = max(1, int(os.environ["PFD_TEST_BIG_CELLS"]) // max(1, ncol))
+        for r0 in range(0, nrow, per):
+            r1 = min(nrow, r0 + per)
+            a, e = max(0, r0 - 1), min(nrow, r1 + 1)
+            try:
+                h = _hip.RasterHandle(self._d8[a:e], e - a, ncol, device=self.device)
+            except ValueError as exc:  # a slice without any pit (its own rows hold none either)
+                if "no pits" not in str(exc):
+                    raise
+                h = None
+            try:
+                yield r0, r1, a, e, h
+            finally:
+                if h is not None:
+                    h.close()
+
+    def _sliced(self, fn, dtype, fill):
+        """Assemble a per-cell export of a raster beyond 32-bit cell indices from the row slices: ``fn(handle, a, e)`` ->
+        flat array over the slice's rows; the chunk's own rows are copied out."""
+        nrow, ncol = self.shape
+        out = np.empty(self.size, dtype)
+        for r0, r1, a, e, h in self._row_slices():
+            dst = out[r0 * ncol:r1 * ncol]
+            if h is None:
+                dst[:] = fill
+                continue
+            dst[:] = np.asarray(fn(h, a, e)).reshape(e - a, ncol)[r0 - a:r1 - a].ravel()
+        return out
 
     def _row_blocks_needed(self):
         """1, or the number of row blocks a raster beyond 2**32 - 2 cells is cut into for the operations whose engines

@@ -675,3 +675,39 @@ def test_classic_stream_order_over_row_blocks(gpu_lib, oracle, monkeypatch, mask
     for nb in (2, 7):
         res, rounds, bad = dist.classic_blocks(d8, nb, upa, m8, verify=True)
         assert bad == 0 and rounds >= 1 and np.array_equal(res, exp), nb
+
+
+@pytest.mark.gpu
+def test_front_end_exports_in_row_slices(gpu_lib, oracle, monkeypatch):
+    """Beyond 32-bit cell indices the front end assembles its cell-local exports — idxs_ds, idxs_pit (needed to CONSTRUCT
+    the object), n_upstream, main_upstream, upstream_sum — from plain handles on row slices with one context row per inner
+    side (threshold lowered here); add_pits edits the whole raster with 64-bit indices.  Everything equal to the
+    one-handle object's, which the goldens pin."""
+    import pyflwdir_amd as pyflwdir
+
+    O = oracle
+    shape = (1300, 700)
+    d8 = O.synth_d8(shape[0], shape[1], seed=31, tilt=100000, white=2, nodata_pct=10)
+    whole = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    data = (np.random.default_rng(4).random(shape) * 3).astype(np.float32)
+    exp = dict(ds=whole.idxs_ds.copy(), pit=whole.idxs_pit.copy(), nup=whole.n_upstream.copy(), mu=whole.main_upstream().copy(),
+               us=whole.upstream_sum(data).copy(), outlet=whole.idxs_outlet.copy())
+    monkeypatch.setenv("PFD_TEST_BIG_CELLS", "200000")  # 0.91 Mcells: 5 row blocks, slices of 285 rows
+    sliced = pyflwdir.from_array(d8, ftype="d8", cache=False)  # (the constructor reads idxs_pit)
+    assert sliced._row_blocks_needed() == 5
+    assert np.array_equal(sliced.idxs_pit, exp["pit"]) and np.array_equal(sliced.idxs_outlet, exp["outlet"])
+    assert np.array_equal(sliced.idxs_ds, exp["ds"])
+    assert np.array_equal(sliced.n_upstream, exp["nup"])
+    assert np.array_equal(sliced.main_upstream(), exp["mu"])
+    assert np.array_equal(sliced.upstream_sum(data).view(np.uint32), exp["us"].view(np.uint32))
+    # add_pits, then the pit list and an accumulation through the row blocks
+    new = np.argsort(whole.upstream_area().ravel())[-3:]
+    sliced.add_pits(idxs=new)
+    monkeypatch.delenv("PFD_TEST_BIG_CELLS")
+    whole.add_pits(idxs=new)
+    monkeypatch.setenv("PFD_TEST_BIG_CELLS", "200000")
+    assert np.array_equal(sliced.idxs_pit, whole.idxs_pit)
+    got = sliced.stream_order(type="classic")
+    monkeypatch.delenv("PFD_TEST_BIG_CELLS")
+    assert np.array_equal(got, whole.stream_order(type="classic"))
+    assert np.array_equal(sliced.upstream_area(), whole.upstream_area())
