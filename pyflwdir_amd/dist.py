@@ -728,37 +728,35 @@ class DistributedRaster:
             raise NotImplementedError("a row block failed or the raster holds a cycle through several row blocks")
         return res.reshape(self.handle.nrow, ncol) if memspace == _hip.PFD_HOST else res
 
-    def hand(self, drain_block, elevtn_block, max_iter=None, elev_code=None, out=None):
+    def hand(self, drain_block, elevtn_block, max_iter=None, elev_code=None, out=None, check_finite=True):
         """Collective ``hand(drain, elevtn)`` (reference pyflwdir/dem.py:299-330): every rank passes the rows of its
         block INCLUDING its halo rows (like the D8 codes); returns (float64 heights of the rank's own rows,
         iterations).  Bit-identical to the whole raster: see :func:`hand_blocks`.  Per iteration the two boundary
         rows travel — device to device between neighbours with the RCCL transport, through one all-gather of the host
         group otherwise — plus one agreement on the number of unknown cells.  Device-resident inputs
         (``_hip.DeviceBuffer`` + ``elev_code``) are used in place and the result stays on the device (a DeviceBuffer
-        covering own + halo rows, owned by the caller; ``out``: use this device buffer for it)."""
+        covering own + halo rows, owned by the caller; ``out``: use this device buffer for it).  Device-resident
+        elevations are checked for NaN / inf on the device (one read of the array, like numpy's check of host inputs)
+        unless ``check_finite=False`` — for a caller that repeats the call on a buffer it has checked."""
         h = self.handle
         ncol = h.ncol
         self._device_io = isinstance(drain_block, _hip.DeviceBuffer)
         if self._device_io:
             drain, elevtn, code = drain_block, elevtn_block, elev_code
-            # (the finite-elevation rule of _hand_inputs, on the device; checked once per buffer — every rank raises alike
-            #  only if every rank's rows are bad, so the verdict travels with the block set-up agreement below)
-            key = (elevtn.addr, elevtn.nbytes)
-            if getattr(self, "_finite_checked", None) != key:
-                nbad = _hip.count_nonfinite(elevtn, (h.nrow + sum(h.halo)) * ncol, code, h.device)
-                self._finite_checked = key if nbad == 0 else None
-                if nbad:
-                    self._nonfinite = NotImplementedError("hand over row blocks needs finite elevations (-inf marks heights that "
-                                                          "are not known yet); mask or fill inf / NaN cells first")
+            nonfinite = None
+            if check_finite and _hip.count_nonfinite(elevtn, (h.nrow + sum(h.halo)) * ncol, code, h.device):
+                # (raised below, inside the block set-up: the failure travels with the agreement)
+                nonfinite = NotImplementedError("hand over row blocks needs finite elevations (-inf marks heights that "
+                                                "are not known yet); mask or fill inf / NaN cells first")
         else:
             drain, elevtn, code = _hand_inputs(drain_block, elevtn_block)
+            nonfinite = None
         seed = np.full(2 * ncol, -np.inf)
         unknown_before, it = None, 0
         blk, err = None, None
         try:
-            if getattr(self, "_nonfinite", None) is not None:
-                exc, self._nonfinite = self._nonfinite, None
-                raise exc
+            if nonfinite is not None:
+                raise nonfinite
             blk = _HandBlock(h, drain, elevtn, code, out=out)
         except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
             err = exc

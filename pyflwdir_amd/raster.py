@@ -69,10 +69,15 @@ def d8_isvalid(flwdir) -> bool:
     """True if ``flwdir`` is a 2-D uint8 raster of D8 values; reference pyflwdir/core_d8.py:105-122."""
     if not (isinstance(flwdir, np.ndarray) and flwdir.dtype == np.uint8 and flwdir.ndim == 2):
         return False
-    present = np.zeros(256, dtype=bool)
-    present[np.unique(flwdir)] = True
-    present[D8_ALL] = False
-    return not present.any()
+    # (one pass through a 256-entry table, chunk by chunk: np.unique sorts the raster — 47 s for 4.4e9 cells)
+    bad = np.ones(256, dtype=bool)
+    bad[D8_ALL] = False
+    flat = flwdir.reshape(-1)
+    step = 1 << 26
+    for i in range(0, flat.size, step):
+        if bad[flat[i:i + step]].any():
+            return False
+    return True
 
 
 def ldd_isvalid(flwdir) -> bool:

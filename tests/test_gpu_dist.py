@@ -146,3 +146,34 @@ def test_bench_op_lines_one_and_two_ranks(gpu_lib, op):
         assert two["config"]["iterations"] >= 2 and two["config"]["exchanges_per_step"] == two["config"]["iterations"]
     if op in ("accuflux", "strahler"):  # (the seeded up-sweeps: at least one exchange that changed a halo value, then one that did not)
         assert two["config"]["iterations"] >= 1 and two["config"]["exchanges_per_step"] >= 2
+
+
+def test_device_resident_hand_inputs_get_the_finite_check(gpu_lib, oracle):
+    """DistributedRaster.hand with DEVICE buffers: a NaN / inf elevation is refused with the message of the host path
+    (it would imitate the "-inf = not known yet" marker of the row-block protocol) — pfd_count_nonfinite; ADVICE r04."""
+    from pyflwdir_amd import _hip
+    from pyflwdir_amd import dist as pdist
+    from pyflwdir_amd.hostgroup import HostGroup
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29777"
+    shape = (300, 260)
+    d8 = oracle.synth_d8(shape[0], shape[1], seed=3, tilt=100000, white=2, nodata_pct=5)
+    elev = oracle.synth_elev_f32(shape[0], shape[1], seed=3, tilt=100000, white=2, nodata_pct=5)
+    grp = HostGroup(0, 1)
+    dr = pdist.DistributedRaster(d8, shape[0], shape[1], 0, 1, 0, transport="host", group=grp)
+    try:
+        drain = _hip.DeviceBuffer(d8.size).upload(np.zeros(shape, np.uint8))
+        good = _hip.DeviceBuffer(elev.nbytes).upload(elev)
+        res, it = dr.hand(drain, good, elev_code=_hip.PFD_F32)
+        assert it >= 1
+        res.free()
+        elev[100, 100] = np.inf
+        bad = _hip.DeviceBuffer(elev.nbytes).upload(elev)
+        with pytest.raises(NotImplementedError, match="finite elevations"):
+            dr.hand(drain, bad, elev_code=_hip.PFD_F32)
+        for b in (drain, good, bad):
+            b.free()
+    finally:
+        dr.close()
+        grp.close()
