@@ -237,6 +237,7 @@ class RasterHandle:
         self.nrow, self.ncol, self.n = int(nrow), int(ncol), int(nrow) * int(ncol)
         self.device = device
         self.halo = (int(halo[0]), int(halo[1]))
+        self.is_general = False
         if isinstance(d8, np.ndarray):
             d8 = np.ascontiguousarray(d8, dtype=np.uint8)
             assert d8.size == (self.nrow + sum(self.halo)) * self.ncol
@@ -256,7 +257,7 @@ class RasterHandle:
         self = cls.__new__(cls)
         self._h = C.c_void_p()
         self.nrow, self.ncol, self.n = int(nrow), int(ncol), int(nrow) * int(ncol)
-        self.device, self.halo, self._d8_ref = device, (0, 0), None
+        self.device, self.halo, self._d8_ref, self.is_general = device, (0, 0), None, True
         idxs_ds = np.ascontiguousarray(idxs_ds).ravel()
         assert idxs_ds.size == self.n
         check(lib().pfd_raster_create_general(ptr(idxs_ds), IDX_CODE[idxs_ds.dtype], self.nrow, self.ncol, PFD_HOST, device,
@@ -338,7 +339,15 @@ class RasterHandle:
     def order_cells(self):
         check(lib().pfd_order_cells(self._h))
 
+    def wide_cells(self) -> bool:
+        """The handle's cells need 64-bit indices (csrc/order64.hip: rank and idxs_seq without the level engine)."""
+        return self.n > 4294967294 or (os.environ.get("PFD_ENABLE_KNOBS") == "1" and bool(os.environ.get("PFD_TEST_ORDER64")))
+
     def idxs_seq(self, dtype) -> np.ndarray:
+        if self.wide_cells() and not self.is_general:
+            out = np.empty(self.info(counts=True)["n_valid"], np.int64)  # (acyclic, or the call raises)
+            check(lib().pfd_idxs_seq(self._h, PFD_I64, ptr(out), PFD_HOST))
+            return out.astype(dtype, copy=False)
         self.order_cells()
         out = np.empty(self.info()["n_seq"], dtype)
         check(lib().pfd_idxs_seq(self._h, IDX_CODE[np.dtype(dtype)], ptr(out), PFD_HOST))

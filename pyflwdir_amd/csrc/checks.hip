@@ -308,18 +308,19 @@ extern "C" int pfd_count_nonfinite(int device, int dtype, const void *dev_ptr, i
 // itself included) where `mask` is set, or the pit the path ends in; dist = hops walked.  One thread per start
 // cell; this is a bounded walk over k cells (k = number of outlets a user passes), not a raster sweep.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_snap_down(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ mask,
+__global__ void __launch_bounds__(64) k_snap_down(const u8 *__restrict__ ncode, u64 ncol, const u8 *__restrict__ mask,
                                                   const i64 *__restrict__ idx0, u32 k, i64 max_hops,
                                                   i64 *__restrict__ out, float *__restrict__ dist) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k) return;
-  u32 x = (u32)idx0[t];
+  u64 x = (u64)idx0[t];  // (64-bit cell indices: a walk over k cells serves a raster of any size)
   i64 d = 0;
   while (!mask[x]) {
     const u32 c = ncode[x];
     if (!d8_is_dir(c)) break;  // pit (or nodata: `idx1 == mv`)
     if (max_hops >= 0 && d + 1 > max_hops) break;
-    x = d8_down(g, x, c);
+    const int s = d8_slot(c);
+    x = (u64)((i64)x + (i64)d8_dr(s) * (i64)ncol + d8_dc(s));
     ++d;
   }
   out[t] = (i64)x;
@@ -333,30 +334,31 @@ __global__ void __launch_bounds__(64) k_snap_down(const u8 *__restrict__ ncode, 
 // with `dist` a Python float: float64 here, rounded to float32 when stored (core.snap: dists float32).  A step's
 // length depends on (row + row of the next cell, kind of step) only: `steps` = [2*nrow - 1][3] float64, evaluated
 // by the host in the reference's expression order (gis_utils.distance, gis_utils.py:452-486).
-__global__ void __launch_bounds__(64) k_snap(const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ mask,
+__global__ void __launch_bounds__(64) k_snap(const u8 *__restrict__ ncode, u64 n, u64 ncol, const u8 *__restrict__ mask,
                                              const i64 *__restrict__ nxt_up, const double *__restrict__ steps,
                                              const i64 *__restrict__ idx0, u32 k, double max_length, int has_max,
                                              i64 *__restrict__ out, float *__restrict__ dist) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k) return;
-  u32 x = (u32)idx0[t];
+  u64 x = (u64)idx0[t];
   double d = 0.0;
-  for (u32 guard = 0; guard <= g.n; ++guard) {  // (a cycle in a caller's idxs_us_main must not hang the GPU)
+  for (u64 guard = 0; guard <= n; ++guard) {  // (a cycle in a caller's idxs_us_main must not hang the GPU)
     if (mask && mask[x]) break;
-    u32 y;
+    u64 y;
     if (nxt_up) {
       const i64 v = nxt_up[x];
-      if (v < 0 || v == (i64)x || v >= (i64)g.n) break;
-      y = (u32)v;
+      if (v < 0 || v == (i64)x || v >= (i64)n) break;
+      y = (u64)v;
     } else {
       const u32 c = ncode[x];
       if (!d8_is_dir(c)) break;  // pit (or nodata: `idx1 == mv`)
-      y = d8_down(g, x, c);
+      const int s = d8_slot(c);
+      y = (u64)((i64)x + (i64)d8_dr(s) * (i64)ncol + d8_dc(s));
     }
     double step = 1.0;
     if (steps) {
-      const u32 r0 = geo_row(g, x), r1 = geo_row(g, y);
-      const u32 c0 = x - r0 * g.ncol, c1 = y - r1 * g.ncol;
+      const u64 r0 = x / ncol, r1 = y / ncol;
+      const u64 c0 = x - r0 * ncol, c1 = y - r1 * ncol;
       const int kind = r0 == r1 ? 1 : (c0 == c1 ? 0 : 2);  // vertical, horizontal, diagonal
       step = steps[(size_t)(r0 + r1) * 3 + kind];
     }
@@ -372,7 +374,7 @@ extern "C" int pfd_snap(pfd_raster *h, const int64_t *idxs, int64_t k, const uin
                         float *dist_out) {
   PFDCHK(pfd_check_handle(h));
   PFDCHK(pfd_reject_general(h, "snap"));
-  PFDCHK(pfd_require_whole(h, "snap"));
+  PFDCHK(pfd_require_unblocked(h, "snap"));  // (64-bit cell indices: any raster size)
   if (k < 0 || (k > 0 && (!idxs || !idxs_out || !dist_out))) {
     pfd_set_error("pfd_snap: bad arguments");
     return PFD_EINVAL;
@@ -391,7 +393,7 @@ extern "C" int pfd_snap(pfd_raster *h, const int64_t *idxs, int64_t k, const uin
   DevBuf o, d;
   PFDCHK(o.alloc((size_t)k * sizeof(i64)));
   PFDCHK(d.alloc((size_t)k * sizeof(float)));
-  k_snap<<<cdiv_u32((u64)k, 64), 64, 0, h->stream>>>(h->ncode, h->geo, (const u8 *)dm.dev, (const i64 *)du.dev,
+  k_snap<<<cdiv_u32((u64)k, 64), 64, 0, h->stream>>>(h->ncode, (u64)h->n, (u64)h->ncol, (const u8 *)dm.dev, (const i64 *)du.dev,
                                                     (const double *)ds.dev, (const i64 *)di.dev, (u32)k, max_length,
                                                     has_max_length, o.as<i64>(), d.as<float>());
   KCHK();
@@ -405,7 +407,7 @@ extern "C" int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k
                                    int64_t max_hops, int64_t *idxs_out, float *dist_out) {
   PFDCHK(pfd_check_handle(h));
   PFDCHK(pfd_reject_general(h, "snap"));
-  PFDCHK(pfd_require_whole(h, "snap"));
+  PFDCHK(pfd_require_unblocked(h, "snap"));
   if (k < 0 || (k > 0 && (!idxs || !idxs_out || !dist_out)) || !mask) {
     pfd_set_error("pfd_snap_downstream: bad arguments");
     return PFD_EINVAL;
@@ -422,7 +424,7 @@ extern "C" int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k
   DevBuf o, d;
   PFDCHK(o.alloc((size_t)k * sizeof(i64)));
   PFDCHK(d.alloc((size_t)k * sizeof(float)));
-  k_snap_down<<<cdiv_u32((u64)k, 64), 64, 0, h->stream>>>(h->ncode, h->geo, (const u8 *)dm.dev, (const i64 *)di.dev, (u32)k,
+  k_snap_down<<<cdiv_u32((u64)k, 64), 64, 0, h->stream>>>(h->ncode, (u64)h->ncol, (const u8 *)dm.dev, (const i64 *)di.dev, (u32)k,
                                                          max_hops, o.as<i64>(), d.as<float>());
   KCHK();
   HIPCHK(hipMemcpyAsync(idxs_out, o.p, (size_t)k * sizeof(i64), hipMemcpyDeviceToHost, h->stream));

@@ -258,11 +258,15 @@ int pfd_order_cells_impl(pfd_raster *h, bool allow_block = false);              
 int pfd_ensure_pits(pfd_raster *h);                             // order.hip
 int pfd_exact_seq_dev(pfd_raster *h, DevBuf &oseq);              // order.hip: core.idxs_seq order in HBM
 int pfd_basins_dev(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev);  // sweeps.hip
-int pfd_require_whole(pfd_raster *h, const char *what);          // order.hip
+int pfd_require_whole(pfd_raster *h, const char *what);          // order.hip: no row block, 32-bit cell indices
+int pfd_require_unblocked(pfd_raster *h, const char *what);      // order.hip: no row block
 void pfd_free_pending(pfd_raster *h);                            // dist.hip
 void pfd_free_pending_basins(pfd_raster *h);                     // paths.hip
 void pfd_free_hand_block(pfd_raster *h);                         // sweeps.hip
 int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
+bool pfd_wide_cells(const pfd_raster *h);                       // order64.hip: 64-bit cell indices (beyond 2^32 - 2 cells)
+int pfd_rank_wide(pfd_raster *h, i32 *out, int memspace);        // order64.hip
+int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace);  // order64.hip
 int pfd_aux_stream(pfd_raster *h);                                // api.hip: h->stream2 / ev_fork / ev_join exist afterwards
 void pfd_free_xplan(pfd_raster *h);                             // exact.hip
 void pfd_xinc_drop(pfd_raster *h);                               // exact.hip: releases a kept block sweep

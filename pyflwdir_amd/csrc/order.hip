@@ -321,12 +321,16 @@ int pfd_adopt_counts(pfd_raster *h, const u64 *c) {
   return PFD_OK;
 }
 
-int pfd_require_whole(pfd_raster *h, const char *what) {
+int pfd_require_unblocked(pfd_raster *h, const char *what) {
   if (h->halo_top || h->halo_bot) {
     pfd_set_error("%s is not available on a row-block handle (row blocks run pfd_upstream_area_cell_blocks / _begin / "
                   "_finish / _dist, pfd_basins_begin / _finish and the pfd_*_block sweeps)", what);
     return PFD_EUNSUPPORTED;
   }
+  return PFD_OK;
+}
+int pfd_require_whole(pfd_raster *h, const char *what) {
+  PFDCHK(pfd_require_unblocked(h, what));
   if (h->n > 4294967294ll) {
     pfd_set_error("%s needs 32-bit cell indices and is not available for a raster of %lld cells (only "
                   "upstream_area(unit=\"cell\") runs on rasters this large)", what, (long long)h->n);
@@ -640,6 +644,7 @@ extern "C" int pfd_rank(pfd_raster *h, int32_t *out, int memspace) {
     return PFD_EINVAL;
   }
   if (h->gen) return pfd_gen_rank(h, out, memspace);
+  if (pfd_wide_cells(h)) return pfd_rank_wide(h, out, memspace);
   PFDCHK(pfd_order_cells_impl(h));
   OutArg o;
   PFDCHK(o.bind(out, (size_t)h->n * sizeof(i32), memspace));
@@ -792,6 +797,7 @@ int pfd_exact_seq_dev(pfd_raster *h, DevBuf &oseq) {
 extern "C" int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   PFDCHK(pfd_check_handle(h));
   if (h->gen) return pfd_gen_idxs_seq(h, idx_dtype, out, memspace);
+  if (pfd_wide_cells(h)) return pfd_idxs_seq_wide(h, idx_dtype, out, memspace);
   DevBuf oseq;
   PFDCHK(pfd_exact_seq_dev(h, oseq));
   return pfd_export_u32(h, oseq.as<u32>(), h->n_seq, idx_dtype, out, memspace);

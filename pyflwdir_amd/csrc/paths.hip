@@ -871,6 +871,10 @@ extern "C" int pfd_basins_finish(pfd_raster *h, const uint32_t *all_records_host
 int pfd_path_rank(pfd_raster *h, const u8 *codes, u32 *out_dev, int *complete) {
   return run_paths<MODE_RANK>(h, nullptr, out_dev, complete, nullptr, codes);
 }
+// ranks of the handle's own raster + the largest of them (order64.hip: any raster size)
+int pfd_path_rank_max(pfd_raster *h, u32 *out_dev, int *complete, u32 *maxrank) {
+  return run_paths<MODE_RANK>(h, nullptr, out_dev, complete, maxrank);
+}
 // hops to the end of the path AND the end itself (linear index + 1 of the pit; 0 on cells that are no path cells) in one query
 int pfd_path_rank_tails(pfd_raster *h, const u8 *codes, u32 *hops_dev, u32 *tails_dev, int *complete) {
   return run_paths<MODE_RANK>(h, nullptr, hops_dev, complete, nullptr, codes, nullptr, nullptr, tails_dev);

@@ -380,8 +380,13 @@ class FlwdirRaster(object):
     @property
     def nnodes(self):
         if self._nnodes is None:
-            self._h.order_cells()
-            self._nnodes = self._h.info()["n_seq"]
+            if self._wide():  # (64-bit cell indices: no level structure; an acyclic raster orders every valid cell)
+                if not self.isvalid:
+                    raise NotImplementedError("nnodes: the raster holds a cycle and is too large for the level ordering")
+                self._nnodes = self._h.info(counts=True)["n_valid"]
+            else:
+                self._h.order_cells()
+                self._nnodes = self._h.info()["n_seq"]
         return self._nnodes
 
     @property
@@ -409,6 +414,12 @@ class FlwdirRaster(object):
     def isvalid(self):
         """True if no valid cell is part of (or drains to) a loop."""
         self._cached.pop("rank", None)
+        if self._wide():  # (the 64-bit rank refuses a cyclic raster instead of marking its cells: ask the rank query itself)
+            max_rank = self._h.graph_stats()["max_rank"]
+            if max_rank == -2:
+                raise NotImplementedError("isvalid: the raster is beyond the tiled rank query (more than 65535 tile rows or "
+                                          "~4e9 perimeter slots)")
+            return max_rank >= 0
         return bool(np.all(self.rank != -1))
 
     @property
@@ -447,7 +458,8 @@ class FlwdirRaster(object):
     def order_cells(self, method="sort"):
         """Order cells from down- to upstream; reference pyflwdir/flwdir.py:231-250 (default "sort" like the
         reference).  "walk" reproduces the reference's breadth-first order exactly on the GPU; "sort" is the
-        reference's own numpy expression over the GPU-computed ranks."""
+        reference's own numpy expression over the GPU-computed ranks.  Beyond 2**32 - 2 cells (int64 indices,
+        pyflwdir.py:105-127) ranks and the breadth-first order come from csrc/order64.hip, for valid (acyclic) rasters."""
         if method == "walk":
             if self._d8 is None:  # general graph: an installed "sort" order must not pose as the breadth-first one
                 self._h.clear_idxs_seq()
@@ -768,6 +780,10 @@ class FlwdirRaster(object):
             dst[:] = np.asarray(fn(h, a, e)).reshape(e - a, ncol)[r0 - a:r1 - a].ravel()
         return out
 
+    def _wide(self):
+        """The raster's cells need 64-bit indices: rank and idxs_seq come from csrc/order64.hip."""
+        return self._d8 is not None and self._h.wide_cells()
+
     def _row_blocks_needed(self):
         """1, or the number of row blocks a raster beyond 2**32 - 2 cells is cut into for the operations whose engines
         address cells with 32 bits (the reference's index ladder reaches int64, pyflwdir.py:105-127): basins, hand,
@@ -833,8 +849,56 @@ class FlwdirRaster(object):
         if unit != "cell":
             rows = np.ascontiguousarray(gis.area_rows(self.transform, self.shape, self.latlon, unit="m2")
                                         / gis.AREA_FACTORS[unit])
-        ucat_map, ucat_are = self._h.ucat_area(idx64, self._idx_dtype, rows)
+        if self._row_blocks_needed() > 1:
+            ucat_map, ucat_are = self._ucat_area_wide(idx64, rows)
+        else:
+            ucat_map, ucat_are = self._h.ucat_area(idx64, self._idx_dtype, rows)
         return ucat_map.reshape(self.shape), ucat_are.reshape(idxs_out.shape)
+
+    def _ucat_area_wide(self, idx64, rows):
+        """subgrid.ucat_area (pyflwdir/subgrid.py:51-93) beyond 2**32 - 2 cells, composed from the operations that run
+        there: the map is the label query of ``basins`` with label i + 1 on outlet i (the same fill from down- to upstream;
+        a repeated outlet keeps the last label in both), the areas are the reference's own accumulation — every outlet
+        starts with the area of its cell, then the cells of the sequence add theirs in sequence order (floats: the order
+        is part of the result; ``np.add.at`` is that loop) — over the 64-bit breadth-first order of csrc/order64.hip."""
+        k, ncol = idx64.size, self.shape[1]
+        sel = np.flatnonzero(idx64 >= 0)
+        if np.any(idx64[sel] >= self.size):
+            raise IndexError("idxs outside domain")
+        ids = (sel + 1).astype(np.uint32)
+        if sel.size:
+            ucat_map = self.basins(idxs=idx64[sel], ids=ids).ravel().astype(self._idx_dtype)
+            ucat_map[idx64[sel]] = ids  # (an outlet on a nodata cell keeps its label, subgrid.py:81-85)
+        else:
+            ucat_map = np.zeros(self.size, self._idx_dtype)
+        if rows is None:  # cells: integer counts, any order
+            ucat_are = np.full(k, -9999, np.int32)
+            counts = np.zeros(k + 1, np.int64)
+            step = 1 << 28
+            for i in range(0, ucat_map.size, step):
+                counts += np.bincount(ucat_map[i:i + step], minlength=k + 1)
+            owner = np.zeros(k, bool)
+            owner[sel] = ucat_map[idx64[sel]] == ids
+            ucat_are[sel] = 1
+            ucat_are[owner] = counts[1:][owner].astype(np.int32)
+            return ucat_map, ucat_are
+        ucat_are = np.full(k, -9999, rows.dtype)  # (float64 on lat/lon grids, float32 on projected ones: FlwdirRaster.area)
+        ucat_are[sel] = rows[idx64[sel] // ncol]
+        acc = np.zeros(k + 1, rows.dtype)
+        acc[1:] = np.where(idx64 >= 0, ucat_are, 0)
+        is_outlet = np.zeros(self.size, bool)
+        is_outlet[idx64[sel]] = True
+        seq = self.idxs_seq
+        step = 1 << 27
+        for i in range(0, seq.size, step):
+            part = seq[i:i + step]
+            w = rows[part // ncol]
+            w[is_outlet[part]] = 0.0  # (the reference skips cells that hold a label already: x + 0.0 is x)
+            np.add.at(acc, ucat_map[part], w)
+        owner = np.zeros(k, bool)
+        owner[sel] = ucat_map[idx64[sel]] == ids
+        ucat_are[owner] = acc[1:][owner]
+        return ucat_map, ucat_are
 
     def floodplains(self, elevtn, uparea=None, upa_min=1000, b=0.3):
         """Floodplain boundaries from a HAND threshold that scales with upstream area, h ~ A**b (Nardi et al

@@ -711,3 +711,46 @@ def test_front_end_exports_in_row_slices(gpu_lib, oracle, monkeypatch):
     monkeypatch.delenv("PFD_TEST_BIG_CELLS")
     assert np.array_equal(got, whole.stream_order(type="classic"))
     assert np.array_equal(sliced.upstream_area(), whole.upstream_area())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("latlon", [False, True])
+def test_front_end_order_ucat_snap_beyond_32_bit_indices(gpu_lib, oracle, monkeypatch, latlon):
+    """The last operations that needed 32-bit cell indices: rank / idxs_seq / order_cells through csrc/order64.hip,
+    ucat_area composed from the label query and the 64-bit sequence (float64 areas added in sequence order: bit for bit),
+    snap with 64-bit walks — thresholds lowered, everything equal to the one-handle object's (which the goldens pin)."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd._affine import Affine
+
+    shape = (900, 1100)
+    d8 = oracle.synth_d8(shape[0], shape[1], seed=37, tilt=100000, white=2, nodata_pct=9)
+    tf = Affine(0.01, 0, 4.0, 0, -0.01, 52.0) if latlon else Affine(30.0, 0, 0, 0, -30.0, 0)
+    whole = pyflwdir.from_array(d8, ftype="d8", transform=tf, latlon=latlon, cache=False)
+    upa = whole.upstream_area()
+    rng = np.random.default_rng(6)
+    valid = np.flatnonzero(d8.ravel() != 247)
+    outs = np.concatenate([np.argsort(upa.ravel())[-40:], rng.choice(valid, 60), np.flatnonzero(d8.ravel() == 247)[:2]])
+    outs = np.concatenate([outs, outs[:5]]).astype(whole.idxs_ds.dtype)  # repeated outlets: the last label wins
+    outs[7] = -1  # the reference's missing value
+    outs = outs[: outs.size // 4 * 4].reshape(4, -1)
+    exp = dict(rank=whole.rank.copy(), seq=whole.idxs_seq.copy(), n=whole.nnodes)
+    for unit in ("cell", "km2"):
+        exp[unit] = whole.ucat_area(outs, unit=unit)
+    pts = rng.choice(valid, 200)
+    streams = upa > 50
+    exp["snap_down"] = whole.snap(idxs=pts, mask=streams, unit="m")
+    exp["snap_up"] = whole.snap(idxs=pts[:50], mask=upa < 3, direction="up", max_length=40)
+    monkeypatch.setenv("PFD_TEST_BIG_CELLS", "250000")
+    monkeypatch.setenv("PFD_TEST_ORDER64", "1")
+    big = pyflwdir.from_array(d8, ftype="d8", transform=tf, latlon=latlon, cache=False)
+    assert big._row_blocks_needed() == 4 and big._wide()
+    assert big.isvalid and big.nnodes == exp["n"]
+    assert np.array_equal(big.rank, exp["rank"]) and np.array_equal(big.idxs_seq, exp["seq"])
+    for unit in ("cell", "km2"):
+        m, a = big.ucat_area(outs, unit=unit)
+        assert m.dtype == exp[unit][0].dtype and np.array_equal(m, exp[unit][0]), unit
+        assert a.dtype == exp[unit][1].dtype and a.shape == outs.shape, unit
+        assert a.tobytes() == exp[unit][1].tobytes(), unit
+    for key, got in (("snap_down", big.snap(idxs=pts, mask=streams, unit="m")),
+                     ("snap_up", big.snap(idxs=pts[:50], mask=upa < 3, direction="up", max_length=40))):
+        assert np.array_equal(got[0], exp[key][0]) and np.array_equal(got[1], exp[key][1]), key

@@ -1,0 +1,89 @@
+"""rank and the exact core.idxs_seq order with 64-bit cell indices (csrc/order64.hip) — the int64 rung of the reference's
+index ladder (pyflwdir/pyflwdir.py:105-127), for rasters beyond 2**32 - 2 cells.  The form needs no level engine, so it
+runs on ANY raster; PFD_TEST_ORDER64 (with PFD_ENABLE_KNOBS=1) makes the small golden cases take it, against the
+reference's own outputs bit for bit (core.idxs_seq, pyflwdir/core.py:87-117; core.rank, core.py:17-47), and a seeded raster
+against the 32-bit form and the oracle.  The at-size run is tools/big_frontend_probe.py (profiles/r05_big_frontend.txt)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import case_names
+from golden_util import Case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def wide(gpu_lib):
+    os.environ["PFD_TEST_ORDER64"] = "1"  # (conftest.py enables the knobs)
+    try:
+        yield
+    finally:
+        for k in ("PFD_TEST_ORDER64", "PFD_TEST_ORDER64_SMALL"):
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("small", [None, "48"])
+@pytest.mark.parametrize("name", case_names())
+def test_golden_cases_through_the_64_bit_form(name, small, manifest, wide):
+    """Both level forms: one workgroup per level (default up to 16384 cells) and count / scan / scatter (threshold 48)."""
+    import pyflwdir_amd as pyflwdir
+
+    case = Case(name, manifest)
+    st = case.entry["stats"]
+    if small:
+        os.environ["PFD_TEST_ORDER64_SMALL"] = small
+    flw = pyflwdir.from_array(case.d8, ftype="d8", cache=False)
+    assert flw._wide()
+    if st["n_loop_cells"]:
+        # the reference marks the cells of a cycle with rank -1 and leaves them out of the sequence; with 64-bit indices
+        # only valid rasters are ordered, and the refusal says so
+        assert not flw.isvalid
+        with pytest.raises(NotImplementedError, match="never reach a pit"):
+            flw.rank
+        with pytest.raises(NotImplementedError, match="never reach a pit"):
+            flw.idxs_seq
+        return
+    assert flw.isvalid
+    case.check("rank", flw.rank.ravel())
+    case.check("idxs_seq_int32", flw.idxs_seq)
+    if "idxs_seq_int64" in case.digests:
+        case.check("idxs_seq_int64", flw._h.idxs_seq(np.int64))
+    assert flw.nnodes == st["n_seq"]
+    # "sort" is the reference's numpy expression over the 64-bit form's ranks: rank-monotone, the property the
+    # reference tests (tests/test_core.py:82)
+    flw.order_cells(method="sort")
+    assert flw.idxs_seq.size == st["n_seq"] and np.all(np.diff(flw.rank.ravel()[flw.idxs_seq]) >= 0)
+
+
+@pytest.mark.parametrize("shape,small", [((700, 900), None), ((1500, 1100), "1000"), ((129, 4097), "0")])
+def test_seeded_raster_against_the_32_bit_form_and_the_oracle(shape, small, gpu_lib, oracle, wide):
+    from pyflwdir_amd import _hip
+
+    d8 = oracle.synth_d8(shape[0], shape[1], seed=11, tilt=3000, white=3, nodata_pct=7)
+    if small is not None:
+        os.environ["PFD_TEST_ORDER64_SMALL"] = small
+    h = _hip.RasterHandle(d8, shape[0], shape[1])
+    seq64 = h.idxs_seq(np.int64)
+    rank64 = h.rank()
+    os.environ.pop("PFD_TEST_ORDER64")
+    h2 = _hip.RasterHandle(d8, shape[0], shape[1])
+    assert not h2.wide_cells()
+    np.testing.assert_array_equal(seq64, h2.idxs_seq(np.int64))
+    np.testing.assert_array_equal(rank64, h2.rank())
+    idxs_ds, idxs_pit, _ = oracle.from_array(d8, dtype=np.int64)
+    np.testing.assert_array_equal(seq64, oracle.idxs_seq(idxs_ds, idxs_pit))
+    h.close()
+    h2.close()
+
+
+def test_int64_is_the_only_index_dtype_of_the_c_entry(gpu_lib, oracle, wide):
+    from pyflwdir_amd import _hip
+
+    d8 = oracle.synth_d8(200, 300, seed=1)
+    h = _hip.RasterHandle(d8, 200, 300)
+    out = np.empty(d8.size, np.int32)
+    rc = _hip.lib().pfd_idxs_seq(h._h, _hip.PFD_I32, _hip.ptr(out), _hip.PFD_HOST)
+    assert rc == -1 and b"int64" in _hip.lib().pfd_last_error()  # PFD_EINVAL
+    h.close()
