@@ -149,7 +149,9 @@ int pfd_upstream_count(pfd_raster *h, const uint8_t *mask, int8_t *out, int mems
 int pfd_order_cells(pfd_raster *h);
 /* core.idxs_seq (reference pyflwdir/core.py:87-117): the exact breadth-first order of the
  * reference (pits ascending, then each dequeued cell's upstream cells ascending); out has
- * n_seq entries. */
+ * n_seq entries.  A raster beyond 2^32 - 2 cells (the int64 rung of pyflwdir.py:105-127) takes idx_dtype PFD_I64
+ * only and must be acyclic (PFD_EUNSUPPORTED otherwise): n_valid entries, built without the level structure from the
+ * tiled rank query and a level-by-level expansion with 64-bit queue entries (csrc/order64.hip). */
 int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace);
 /* General idxs_ds graphs only: install the cell sequence the sweeps follow.  Flwdir.order_cells("sort")
  * (reference pyflwdir/flwdir.py:231-245; the only ordering of NEXTXY rasters, pyflwdir.py:292-297) sorts the
@@ -160,7 +162,8 @@ int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace);
  * pfd_add_pits forgets it as well (it describes the graph before the edit). */
 int pfd_set_idxs_seq(pfd_raster *h, int idx_dtype, const void *seq, int64_t n_seq);
 /* core.rank (reference pyflwdir/core.py:17-47): int32 distance to the pit, -1 for cells that
- * do not drain to a pit, -9999 on nodata. */
+ * do not drain to a pit, -9999 on nodata.  Beyond 2^32 - 2 cells: the tiled rank query, acyclic rasters only
+ * (a raster with cells that never reach a pit is refused with PFD_EUNSUPPORTED instead of marked). */
 int pfd_rank(pfd_raster *h, int32_t *out, int memspace);
 
 /* ---- sweeps ---------------------------------------------------------------------------- */
@@ -384,7 +387,8 @@ int pfd_floodplains(pfd_raster *h, int elev_dtype, const void *elevtn, const uin
 /* core.snap in downstream direction, cell units (reference pyflwdir/core.py:440-480, Flwdir.snap
  * flwdir.py:404-463; used by basins(streams=...) / add_pits(streams=...), flwdir.py:805-811): per start cell
  * (k HOST indices) the first cell downstream, itself included, where mask != 0, or the pit its path ends in;
- * dist_out = cells walked (float32 like the reference); max_hops < 0: unlimited. */
+ * dist_out = cells walked (float32 like the reference); max_hops < 0: unlimited.  64-bit cell indices: both snap
+ * entries serve whole rasters of any size. */
 int pfd_snap_downstream(pfd_raster *h, const int64_t *idxs, int64_t k, const uint8_t *mask, int memspace,
                         int64_t max_hops, int64_t *idxs_out, float *dist_out);
 /* The general form of core.snap (reference pyflwdir/core.py:440-480, core._trace :308-366, Flwdir.snap

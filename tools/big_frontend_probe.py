@@ -43,3 +43,10 @@ if step("from_array", make):
     step("add_pits + idxs_pit", lambda: (flw.add_pits(idxs=np.array([int(np.argmax(upa)) - 5 * size])), flw.idxs_pit.size)[1])
     step("upstream_area after add_pits", lambda: int(flw.upstream_area().max()))
     step("floodplains", lambda: np.bincount(flw.floodplains(np.zeros(flw.shape, np.float32), uparea=upa.astype(np.float32), upa_min=1e5).ravel() + 1).tolist())
+    # the operations that needed 32-bit cell indices until the end of round 5: csrc/order64.hip, 64-bit snap walks, ucat_area
+    step("rank", lambda: (flw.rank.dtype, int(flw.rank.max())))
+    step("idxs_seq (walk)", lambda: (flw.idxs_seq.dtype, int(flw.idxs_seq.size), int(flw.idxs_seq[0])))
+    top = np.argsort(upa.ravel()[:: 4097])[-500:].astype(np.int64) * 4097
+    step("ucat_area cell, 500 outlets", lambda: [int(v) for v in np.sort(flw.ucat_area(top, unit="cell")[1])[-2:]])
+    step("ucat_area km2, 500 outlets", lambda: [float(v) for v in np.sort(flw.ucat_area(top, unit="km2")[1])[-2:]])
+    step("snap down, 1000 points", lambda: float(flw.snap(idxs=np.arange(1000, dtype=np.int64) * 4000003 + 7, mask=upa > 1000)[1].max()))
