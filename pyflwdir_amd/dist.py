@@ -154,7 +154,62 @@ def hand_blocks(d8: np.ndarray, nblocks: int, drain, elevtn, devices=None, max_i
             blk.close()
 
 
-class _UpBlock:
+def relevant_halo(d8_rows: np.ndarray, halo, down: bool) -> np.ndarray:
+    """Which of a row block's 2 * ncol halo cells its result depends on.  A down-sweep (a cell takes its value from the
+    cell it drains into) reads the halo cells an own boundary cell drains INTO; an up-sweep those that drain into an own
+    boundary cell.  The neighbour's other boundary values change from round to round of the fixpoint iteration without
+    meaning anything to this block: a block whose RELEVANT halo values are those of its last sweep is not swept again
+    (flow crossing the blocks one way: the downstream blocks of a down-sweep sweep once or twice instead of every round).
+    ``d8_rows``: the block's device rows (halo rows included), raw D8 codes."""
+    ncol = d8_rows.shape[1]
+    rel = np.zeros(2 * ncol, bool)
+
+    def flows(src, dst, codes):  # (source columns, target columns) of the cells of row `src` that drain into row `dst`
+        cs, cd = [], []
+        for j, code in enumerate(codes):  # codes[j] points at column c + j - 1
+            c = np.flatnonzero(src == code)
+            d = c + (j - 1)
+            ok = (d >= 0) & (d < ncol)
+            c, d = c[ok], d[ok]
+            ok = dst[d] != 247  # (flow into nodata ends where it is: the cell is a pit of its own row)
+            cs.append(c[ok])
+            cd.append(d[ok])
+        return np.concatenate(cs), np.concatenate(cd)
+
+    if halo[0]:
+        own, hal = d8_rows[1], d8_rows[0]
+        rel[:ncol][flows(own, hal, (32, 64, 128))[1] if down else flows(hal, own, (8, 4, 2))[0]] = True  # NW N NE / SW S SE
+    if halo[1]:
+        own, hal = d8_rows[-2], d8_rows[-1]
+        rel[ncol:][flows(own, hal, (8, 4, 2))[1] if down else flows(hal, own, (32, 64, 128))[0]] = True
+    return rel
+
+
+class _SeedGate:
+    """``sweep(seed)``: sweep with these halo values unless the ones that matter are those of the last sweep."""
+
+    relevant = None  # bool [2 * ncol] (relevant_halo), or None: every halo value counts
+    calls = 0        # sweeps that ran
+
+    def _seed_bits(self, seed):
+        part = seed if self.relevant is None else np.ascontiguousarray(seed[self.relevant])
+        return part.view(np.uint8)
+
+    def sweep(self, seed):
+        """False if the relevant halo values are the ones of the last sweep (nothing can have changed)."""
+        bits = self._seed_bits(seed)
+        if self.swept_with is not None and np.array_equal(self.swept_with, bits):
+            return False
+        self.swept_with = bits.copy()
+        self.brows, _ = self._call(seed, False)
+        self.calls += 1
+        return True
+
+
+LAST_SWEEPS = []  # sweeps per block of the last fixpoint iteration of this process (diagnostics, tools/bench_down_blocks.py)
+
+
+class _UpBlock(_SeedGate):
     """Device-resident state of one row block of an up-sweep (accuflux, Strahler) between the exchanges: payload and
     result stay in HBM; only the two boundary rows travel."""
 
@@ -200,15 +255,6 @@ class _UpBlock:
             return self.h.stream_distance_block(self.mask, self.payload, seed, self.out, verify=verify, memspace=_hip.PFD_DEVICE)
         return self.h.strahler_block(self.mask, seed, self.out, verify=verify, memspace=_hip.PFD_DEVICE)
 
-    def sweep(self, seed):
-        """Sweep with these halo values; False if they are the ones of the last sweep (nothing can have changed)."""
-        bits = seed.view(np.uint8)
-        if self.swept_with is not None and np.array_equal(self.swept_with, bits):
-            return False
-        self.swept_with = bits.copy()
-        self.brows, _ = self._call(seed, False)
-        return True
-
     def sweep_dev(self, seed_buf):
         """Sweep with the halo values in the DEVICE buffer ``seed_buf`` (the handle reads device seeds:
         ``set_block_io(PFD_DEVICE)``); the boundary rows stay in ``self.out`` for the RCCL exchange."""
@@ -247,22 +293,44 @@ def _up_blocks_run(blocks, ncol, dtype, max_iter=MAX_ROUNDS, verify=False):
     """Exchange boundary rows and sweep until no halo value changes: the fixpoint is the whole raster's result (the
     graph is acyclic; a value is final after as many exchanges as its longest upstream path crosses block edges).
     Returns the number of rounds in which some block swept.  A cycle through the block edges never settles (its sums
-    grow with every round): the iteration is bounded by ``max_iter`` and raises."""
+    grow with every round): the iteration is bounded by ``max_iter`` and raises.
+
+    Order of the sweeps: a block whose relevant halo values (relevant_halo) all come from blocks that are FINAL is swept
+    once and is final itself — flow that crosses the blocks one way costs every block one sweep, in the order of the
+    flow, instead of one per block it has downstream.  Blocks that wait for each other (a path that leaves a block and
+    comes back) iterate as before: every one of them whose relevant halo values changed sweeps, until none does."""
     nb = len(blocks)
     seeds = [np.zeros(2 * ncol, dtype) for _ in range(nb)]
+
+    def deps(b):  # the neighbouring blocks whose boundary rows block b's result depends on
+        rel = blocks[b].relevant
+        up = b > 0 and (rel is None or bool(rel[:ncol].any()))
+        dn = b + 1 < nb and (rel is None or bool(rel[ncol:].any()))
+        return ([b - 1] if up else []) + ([b + 1] if dn else [])
+
+    dep = [deps(b) for b in range(nb)]
+    final = [False] * nb
     it = 0
-    while True:
-        swept = [blk.sweep(seeds[b]) for b, blk in enumerate(blocks)]
-        if not any(swept):
-            break
-        it += 1
-        if max_iter is not None and it > max_iter:
-            raise _not_settled(max_iter)
+    while not all(final):
+        ready = [b for b in range(nb) if not final[b] and all(final[d] for d in dep[b])]
+        if ready:
+            swept = [blocks[b].sweep(seeds[b]) for b in ready]
+            for b in ready:
+                final[b] = True
+        else:  # mutual dependence among the blocks that are left
+            swept = [blocks[b].sweep(seeds[b]) for b in range(nb) if not final[b]]
+            if not any(swept):
+                break
+        if any(swept):
+            it += 1
+            if max_iter is not None and it > max_iter:
+                raise _not_settled(max_iter)
         for b in range(nb):  # halo rows = the neighbours' boundary rows
-            if b > 0:
+            if b > 0 and blocks[b - 1].brows is not None:
                 seeds[b][:ncol] = blocks[b - 1].brows[1]
-            if b + 1 < nb:
+            if b + 1 < nb and blocks[b + 1].brows is not None:
                 seeds[b][ncol:] = blocks[b + 1].brows[0]
+    LAST_SWEEPS[:] = [blk.calls for blk in blocks]
     bad = sum(blk.verify(seeds[b]) for b, blk in enumerate(blocks)) if verify else None
     return it, bad
 
@@ -292,6 +360,7 @@ def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0),
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
             blocks.append(_UpBlock(h, "accuflux", dtype, payload=data[a:e], by_row=by_row, nodata=nodata_args,
                                    direction=_hip.PFD_UP if direction == "up" else _hip.PFD_DOWN))
+            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=direction != "up")
         it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -318,6 +387,7 @@ def stream_distance_blocks(d8: np.ndarray, nblocks: int, mask=None, step_lengths
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
             rows = None if tab is None else tab[2 * a:2 * a + 2 * (e - a) - 1]  # (row sums 2a .. 2(e-1): the block's steps)
             blocks.append(_UpBlock(h, "distance", dtype, payload=rows, mask=None if mask is None else mask[a:e]))
+            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=True)
         it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -341,6 +411,7 @@ def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verif
             a, e = block_slice(nrow, nblocks, b)
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
             blocks.append(_UpBlock(h, "strahler", np.uint8, mask=None if mask is None else mask[a:e]))
+            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=False)
         it, bad = _up_blocks_run(blocks, ncol, np.uint8, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -348,7 +419,7 @@ def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verif
             blk.close()
 
 
-class _ClassicBlock:
+class _ClassicBlock(_SeedGate):
     """Device-resident state of one row block of the classic stream order between the exchanges: the per-cell byte of
     pfd_trib_info_block (halo rows from the neighbours), the mask and the orders stay in HBM."""
 
@@ -363,14 +434,6 @@ class _ClassicBlock:
 
     def _call(self, seed, verify):
         return self.h.stream_order_classic_block(self.tinfo, self.mask, seed, self.out, verify=verify, memspace=_hip.PFD_DEVICE)
-
-    def sweep(self, seed):
-        bits = seed.view(np.uint8)
-        if self.swept_with is not None and np.array_equal(self.swept_with, bits):
-            return False
-        self.swept_with = bits.copy()
-        self.brows, _ = self._call(seed, False)
-        return True
 
     def verify(self, seed):
         return self._call(seed, True)[1]
@@ -422,6 +485,7 @@ def classic_blocks(d8: np.ndarray, nblocks: int, uparea, mask=None, upa_min=0.0,
         for b in range(nblocks):
             a, e = block_slice(nrow, nblocks, b)
             blocks.append(_ClassicBlock(handles[b], infos[b], None if mask is None else mask[a:e]))
+            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=True)
         handles = []  # (the blocks own them now)
         it, bad = _up_blocks_run(blocks, ncol, np.uint8, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
@@ -432,7 +496,7 @@ def classic_blocks(d8: np.ndarray, nblocks: int, uparea, mask=None, upa_min=0.0,
             blk.close()
 
 
-class _FloodBlock:
+class _FloodBlock(_SeedGate):
     """Device-resident state of one row block of dem.floodplains between the exchanges: elevation, stream flags, height
     thresholds and the floodplain state (16 bytes per cell) stay in HBM; only the two boundary rows of the state travel."""
 
@@ -448,14 +512,6 @@ class _FloodBlock:
     def _call(self, seed, verify):
         return self.h.floodplains_block(self.elev, self.code, self.stream, self.hs, seed, self.state, verify=verify,
                                         memspace=_hip.PFD_DEVICE)
-
-    def sweep(self, seed):
-        bits = seed.view(np.uint8)
-        if self.swept_with is not None and np.array_equal(self.swept_with, bits):
-            return False
-        self.swept_with = bits.copy()
-        self.brows, _ = self._call(seed, False)
-        return True
 
     def verify(self, seed):
         return self._call(seed, True)[1]
@@ -494,6 +550,7 @@ def floodplains_blocks(d8: np.ndarray, nblocks: int, elevtn, is_stream, stream_h
             a, e = block_slice(nrow, nblocks, b)
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
             blocks.append(_FloodBlock(h, elevtn[a:e], _ELEV_CODE[elevtn.dtype], is_stream[a:e], stream_h[a:e]))
+            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=True)
         it, bad = _up_blocks_run(blocks, ncol, _hip.FLOOD_STATE, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -648,6 +705,9 @@ class DistributedRaster:
         # collectives below and raises afterwards: nobody is left waiting
         err = None
         self.handle = None
+        self._edge = None  # host callers: the first / last two device rows of the raw codes (relevant_halo)
+        if isinstance(d8_block, np.ndarray) and d8_block.size >= 2 * ncol:
+            self._edge = np.asarray(d8_block, np.uint8).reshape(-1, ncol)[[0, 1, -2, -1]].copy()
         try:
             self.handle = _hip.RasterHandle(d8_block, own_rows, ncol, device=device, memspace=memspace,
                                             halo=halo_of(rank, world), deferred=deferred)
@@ -897,6 +957,10 @@ class DistributedRaster:
         blk, err, it = None, None, 0
         try:
             blk = make_block()
+            if getattr(self, "_edge", None) is not None and isinstance(blk, _UpBlock):  # (host transport: a rank sweeps again only when a halo value it depends on changed;
+                #  the RCCL loop counts every changed halo value on the device)
+                down = blk.kind == "distance" or (blk.kind == "accuflux" and blk.direction == _hip.PFD_DOWN)
+                blk.relevant = relevant_halo(self._edge, self.handle.halo, down)
         except Exception as exc:  # noqa: BLE001 - the failure travels with the agreement: nobody is left waiting
             err = exc
         if self.comm is not None:

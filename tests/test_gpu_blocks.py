@@ -754,3 +754,36 @@ def test_front_end_order_ucat_snap_beyond_32_bit_indices(gpu_lib, oracle, monkey
     for key, got in (("snap_down", big.snap(idxs=pts, mask=streams, unit="m")),
                      ("snap_up", big.snap(idxs=pts[:50], mask=upa < 3, direction="up", max_length=40))):
         assert np.array_equal(got[0], exp[key][0]) and np.array_equal(got[1], exp[key][1]), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["accuflux_down", "distance", "classic", "strahler"])
+def test_blocks_sweep_only_when_a_relevant_halo_value_changed(gpu_lib, oracle, monkeypatch, op):
+    """The fixpoint iteration over row blocks compares only the halo values a block's result depends on
+    (dist.relevant_halo): same results as with every halo value counted, in fewer sweeps — flow that crosses the blocks
+    one way lets the downstream blocks of a down-sweep settle at once."""
+    from pyflwdir_amd import dist
+
+    shape, nb = (1400, 600), 5
+    d8 = oracle.synth_d8(shape[0], shape[1], seed=5, tilt=400, white=2, nodata_pct=6)  # (a strong tilt: flow mostly one way)
+    data = (np.random.default_rng(3).random(shape) * 4).astype(np.float32)
+    upa = oracle.upstream_area_cell(d8)[0].reshape(shape)
+
+    def run():
+        if op == "accuflux_down":
+            return dist.accuflux_blocks(d8, nb, data, (-9999, -9999.0, 1), verify=True, direction="down")
+        if op == "distance":
+            return dist.stream_distance_blocks(d8, nb, verify=True)
+        if op == "classic":
+            return dist.classic_blocks(d8, nb, upa, verify=True)
+        return dist.strahler_blocks(d8, nb, verify=True)
+
+    got, rounds, bad = run()
+    gated = list(dist.LAST_SWEEPS)
+    monkeypatch.setattr(dist, "relevant_halo", lambda rows, halo, down: None)
+    exp, rounds_all, bad_all = run()
+    every = list(dist.LAST_SWEEPS)
+    assert bad == 0 and bad_all == 0 and got.tobytes() == exp.tobytes()
+    assert all(g <= e for g, e in zip(gated, every)) and sum(gated) <= sum(every), (gated, every)
+    if op != "strahler":  # (the down-sweeps of this tilted raster: at least one block is spared a sweep)
+        assert sum(gated) < sum(every), (gated, every)

@@ -222,3 +222,28 @@ def test_reggrid_helpers_match_the_reference_expressions():
     assert dx.shape == shape and dy.shape == shape and dx.dtype == lat.dtype
     assert np.array_equal(dx[:, 3], gis.degree_metres_x(lat) * 0.25) and np.array_equal(dy[:, 0], gis.degree_metres_y(lat) * 0.25)
     assert {"reggrid_area", "reggrid_dx", "reggrid_dy"} <= set(gis.__all__)
+
+
+def test_relevant_halo_cells_of_a_row_block():
+    """dist.relevant_halo: a down-sweep depends on the halo cells its boundary cells drain into, an up-sweep on the halo
+    cells that drain into a boundary cell; flow into nodata ends where it is."""
+    from pyflwdir_amd.dist import relevant_halo
+
+    MV = 247
+    rows = np.array([[4, 2, MV, 8, 1, 64],      # top halo row:   S  SE  nodata  SW  E  N
+                     [64, MV, 128, 32, 16, 4],  # own first row:  N  nodata  NE  NW  W  S
+                     [4, 8, 2, 1, 64, 4],       # own last row:   S  SW  SE  E  N  S
+                     [64, MV, 32, 128, 1, MV]],  # bottom halo row: N nodata NW NE E nodata
+                    dtype=np.uint8)
+    ncol = rows.shape[1]
+    down = relevant_halo(rows, (1, 1), True)
+    # own first row: col 0 N -> halo col 0; col 2 NE -> halo col 3; col 3 NW -> halo col 2 is nodata: ends there
+    assert down[:ncol].tolist() == [True, False, False, True, False, False]
+    # own last row: col 0 S -> 0; col 1 SW -> 0; col 2 SE -> 3; col 5 S -> nodata
+    assert down[ncol:].tolist() == [True, False, False, True, False, False]
+    up = relevant_halo(rows, (1, 1), False)
+    # top halo: col 0 S -> own 0 valid; col 1 SE -> own 2 valid; col 3 SW -> own 2 valid
+    assert up[:ncol].tolist() == [True, True, False, True, False, False]
+    # bottom halo: col 0 N -> own 0; col 2 NW -> own 1; col 3 NE -> own 4
+    assert up[ncol:].tolist() == [True, False, True, True, False, False]
+    assert not relevant_halo(rows[1:], (0, 1), True)[:ncol].any()  # (no top halo row: nothing to depend on)
