@@ -199,6 +199,7 @@ static int pfd_dmalloc_raw(void **p, size_t bytes) {
     e = hipMalloc(p, cls);
   }
   if (e != hipSuccess) {
+    (void)hipGetLastError();  // (the failure is reported here; left sticky, the next launch check of ANY call would report it again)
     *p = nullptr;
     pfd_set_error("hipMalloc(%zu bytes) failed: %s", cls, hipGetErrorString(e));
     return PFD_ENOMEM;
@@ -300,6 +301,7 @@ extern "C" int pfd_reserve(int device, size_t bytes) {
   }
   (void)hipSetDevice(prev);
   if (e != hipSuccess) {
+    (void)hipGetLastError();  // (see pfd_dmalloc)
     pfd_set_error("pfd_reserve(%zu bytes) failed: %s", sz, hipGetErrorString(e));
     return PFD_ENOMEM;
   }
@@ -438,6 +440,7 @@ extern "C" int pfd_malloc(int device, size_t bytes, void **ptr) {
     e = hipMalloc(ptr, bytes ? bytes : 16);
   }
   if (e != hipSuccess) {
+    (void)hipGetLastError();  // (see pfd_dmalloc)
     *ptr = nullptr;
     pfd_set_error("pfd_malloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     return PFD_ENOMEM;

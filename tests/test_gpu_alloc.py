@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -82,3 +83,23 @@ def test_an_arena_that_is_too_small_overflows_into_the_cache(gpu_lib):
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["ok"] and r["somax"] >= 4 and r["reserved"] == 8 << 20
     assert r["hipmalloc"] > 5  # the GB-class buffers did not come out of the 8 MiB arena
+
+
+def test_a_failed_allocation_does_not_fail_the_next_call(gpu_lib, oracle):
+    """hipMalloc leaves its error sticky: reported where it happened (PFD_ENOMEM) and cleared, or the first launch check
+    of the NEXT call — any call, any handle — reports "out of memory" again (seen at 90000 x 90000: `rank` failed right
+    behind a `floodplains` that had run out of memory, and worked on the next try)."""
+    import ctypes as C
+
+    from pyflwdir_amd import _hip
+
+    d8 = oracle.synth_d8(300, 200, seed=2)
+    h = _hip.RasterHandle(d8, 300, 200)
+    exp = h.rank()
+    p = C.c_void_p()
+    rc = _hip.lib().pfd_malloc(0, C.c_size_t(1 << 50), C.byref(p))  # 1 PiB
+    assert rc == -4 and b"out of memory" in _hip.lib().pfd_last_error().lower()  # PFD_ENOMEM
+    rc = _hip.lib().pfd_reserve(0, C.c_size_t(1 << 50))
+    assert rc == -4
+    np.testing.assert_array_equal(h.rank(), exp)  # (launch checks in front of its first kernel)
+    h.close()
