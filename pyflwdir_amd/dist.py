@@ -124,10 +124,14 @@ def hand_blocks(d8: np.ndarray, nblocks: int, drain, elevtn, devices=None, max_i
     drain, elevtn = drain.reshape(nrow, ncol), elevtn.reshape(nrow, ncol)
     devices = devices or [0] * nblocks
     rows = block_rows(nrow, nblocks)
+    stream = _stream_blocks(d8.size, 1 + elevtn.dtype.itemsize + 8 + 28, devices)
     blocks = []
     try:
         for b, (r0, r1) in enumerate(rows):
             a, e = block_slice(nrow, nblocks, b)
+            if stream:
+                blocks.append(_StreamedHandBlock(d8[a:e], r1 - r0, ncol, devices[b], halo_of(b, nblocks), drain[a:e], elevtn[a:e], code))
+                continue
             h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
             blocks.append(_HandBlock(h, drain[a:e], elevtn[a:e], code))
         seeds = [np.full(2 * ncol, -np.inf) for _ in range(nblocks)]
@@ -204,6 +208,70 @@ class _SeedGate:
         self.brows, _ = self._call(seed, False)
         self.calls += 1
         return True
+
+
+HBM_BUDGET = 200 << 30  # bytes of an MI355X's 288 GB that the row blocks of ONE call may hold at the same time
+
+
+def _stream_blocks(cells: int, bytes_per_cell: int, devices) -> bool:
+    """Do the row blocks of a call go through the device one at a time?  Resident blocks keep payloads, results and
+    their sweep plans (~26 bytes per cell) in HBM between the exchanges; when that does not fit one GPU — floodplains of
+    8.1 Gcells: ~85 bytes per cell — a block is built, swept and released per sweep instead, its result waiting on the
+    host (the flow-order schedule of _up_blocks_run keeps the sweeps few).  Blocks spread over several devices are
+    held.  (PFD_TEST_STREAM_BLOCKS with PFD_ENABLE_KNOBS=1 forces either.)"""
+    import os
+
+    if os.environ.get("PFD_ENABLE_KNOBS") == "1" and os.environ.get("PFD_TEST_STREAM_BLOCKS"):
+        return os.environ["PFD_TEST_STREAM_BLOCKS"] == "1"
+    return len(set(devices)) == 1 and cells * bytes_per_cell > HBM_BUDGET
+
+
+class _StreamedBlock(_SeedGate):
+    """A row block that is on the device only while it sweeps (``make()`` builds it from the host arrays)."""
+
+    def __init__(self, make):
+        self.make, self.host = make, None
+        self.swept_with, self.brows = None, None
+
+    def _call(self, seed, verify):
+        if verify:
+            raise NotImplementedError("verify=True needs the blocks resident: these are streamed through the device "
+                                      "(their state exceeds HBM_BUDGET)")
+        blk = self.make()
+        try:
+            if hasattr(blk, "incremental"):
+                blk.incremental = False  # (nothing is kept between the sweeps)
+            out = blk._call(seed, False)
+            self.host = blk.result()
+            return out
+        finally:
+            blk.close()
+
+    def verify(self, seed):
+        return self._call(seed, True)[1]
+
+    def result(self):
+        return self.host
+
+    def close(self, close_handle=True):
+        pass
+
+
+def _blocks_of(nblocks, make, relevant, stream):
+    """The blocks of a call: ``make(b)`` now, or a streamed stand-in; ``relevant(b)`` = its relevant_halo mask."""
+    import functools
+
+    blocks = []
+    try:
+        for b in range(nblocks):
+            blk = _StreamedBlock(functools.partial(make, b)) if stream else make(b)
+            blocks.append(blk)
+            blk.relevant = relevant(b)
+    except Exception:
+        for blk in blocks:
+            blk.close()
+        raise
+    return blocks
 
 
 LAST_SWEEPS = []  # sweeps per block of the last fixpoint iteration of this process (diagnostics, tools/bench_down_blocks.py)
@@ -353,14 +421,18 @@ def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0),
         raise NotImplementedError(f"payload dtype {dtype} is not supported by the row-block accuflux")
     data = data.reshape(nrow) if by_row else data.reshape(nrow, ncol)
     devices = devices or [0] * nblocks
-    blocks = []
+    rows = block_rows(nrow, nblocks)
+    dirc = _hip.PFD_UP if direction == "up" else _hip.PFD_DOWN
+
+    def make(b):
+        a, e = block_slice(nrow, nblocks, b)
+        h = _hip.RasterHandle(d8[a:e], rows[b][1] - rows[b][0], ncol, device=devices[b], halo=halo_of(b, nblocks))
+        return _UpBlock(h, "accuflux", dtype, payload=data[a:e], by_row=by_row, nodata=nodata_args, direction=dirc)
+
+    blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks),
+                                                               down=direction != "up"),
+                        _stream_blocks(d8.size, (1 if by_row else 2) * dtype.itemsize + 28, devices))
     try:
-        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
-            a, e = block_slice(nrow, nblocks, b)
-            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
-            blocks.append(_UpBlock(h, "accuflux", dtype, payload=data[a:e], by_row=by_row, nodata=nodata_args,
-                                   direction=_hip.PFD_UP if direction == "up" else _hip.PFD_DOWN))
-            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=direction != "up")
         it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -380,14 +452,17 @@ def stream_distance_blocks(d8: np.ndarray, nblocks: int, mask=None, step_lengths
     tab = None if step_lengths is None else np.ascontiguousarray(step_lengths, dtype=np.float32).reshape(2 * nrow - 1, 3)
     dtype = np.int32 if tab is None else np.float32
     devices = devices or [0] * nblocks
-    blocks = []
+    brows = block_rows(nrow, nblocks)
+
+    def make(b):
+        a, e = block_slice(nrow, nblocks, b)
+        h = _hip.RasterHandle(d8[a:e], brows[b][1] - brows[b][0], ncol, device=devices[b], halo=halo_of(b, nblocks))
+        rows = None if tab is None else tab[2 * a:2 * a + 2 * (e - a) - 1]  # (row sums 2a .. 2(e-1): the block's steps)
+        return _UpBlock(h, "distance", dtype, payload=rows, mask=None if mask is None else mask[a:e])
+
+    blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks), down=True),
+                        _stream_blocks(d8.size, 4 + (mask is not None) + 28, devices))
     try:
-        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
-            a, e = block_slice(nrow, nblocks, b)
-            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
-            rows = None if tab is None else tab[2 * a:2 * a + 2 * (e - a) - 1]  # (row sums 2a .. 2(e-1): the block's steps)
-            blocks.append(_UpBlock(h, "distance", dtype, payload=rows, mask=None if mask is None else mask[a:e]))
-            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=True)
         it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -405,13 +480,16 @@ def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verif
     if mask is not None:
         mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(nrow, ncol)
     devices = devices or [0] * nblocks
-    blocks = []
+    brows = block_rows(nrow, nblocks)
+
+    def make(b):
+        a, e = block_slice(nrow, nblocks, b)
+        h = _hip.RasterHandle(d8[a:e], brows[b][1] - brows[b][0], ncol, device=devices[b], halo=halo_of(b, nblocks))
+        return _UpBlock(h, "strahler", np.uint8, mask=None if mask is None else mask[a:e])
+
+    blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks), down=False),
+                        _stream_blocks(d8.size, 1 + (mask is not None) + 28, devices))
     try:
-        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
-            a, e = block_slice(nrow, nblocks, b)
-            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
-            blocks.append(_UpBlock(h, "strahler", np.uint8, mask=None if mask is None else mask[a:e]))
-            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=False)
         it, bad = _up_blocks_run(blocks, ncol, np.uint8, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -467,30 +545,44 @@ def classic_blocks(d8: np.ndarray, nblocks: int, uparea, mask=None, upa_min=0.0,
     if mask is not None:
         mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(nrow, ncol)
     devices = devices or [0] * nblocks
-    handles, blocks = [], []
+    brows = block_rows(nrow, nblocks)
+    stream = _stream_blocks(d8.size, 3 + uparea.dtype.itemsize + 28, devices)
+
+    def handle(b):
+        a, e = block_slice(nrow, nblocks, b)
+        return _hip.RasterHandle(d8[a:e], brows[b][1] - brows[b][0], ncol, device=devices[b], halo=halo_of(b, nblocks))
+
+    handles, blocks = {}, []
     try:
         infos = []
-        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
+        for b in range(nblocks):
             a, e = block_slice(nrow, nblocks, b)
-            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
-            handles.append(h)
-            infos.append(h.trib_info_block(uparea[a:e], _hip._PAYLOAD_CODE[uparea.dtype], None if mask is None else mask[a:e],
-                                           upa_min).reshape(e - a, ncol))
+            h = handle(b)
+            try:
+                infos.append(h.trib_info_block(uparea[a:e], _hip._PAYLOAD_CODE[uparea.dtype], None if mask is None else mask[a:e],
+                                               upa_min).reshape(e - a, ncol))
+            finally:
+                if stream:
+                    h.close()
+                else:
+                    handles[b] = h  # (kept: the block below owns it)
         for b in range(nblocks):  # a halo cell's byte is its owner's: the neighbouring block's boundary row
             top, bot = halo_of(b, nblocks)
             if top:
                 infos[b][0] = infos[b - 1][-1 - halo_of(b - 1, nblocks)[1]]
             if bot:
                 infos[b][-1] = infos[b + 1][halo_of(b + 1, nblocks)[0]]
-        for b in range(nblocks):
+
+        def make(b):
             a, e = block_slice(nrow, nblocks, b)
-            blocks.append(_ClassicBlock(handles[b], infos[b], None if mask is None else mask[a:e]))
-            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=True)
-        handles = []  # (the blocks own them now)
+            return _ClassicBlock(handles.pop(b) if b in handles else handle(b), infos[b], None if mask is None else mask[a:e])
+
+        blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks),
+                                                                   down=True), stream)
         it, bad = _up_blocks_run(blocks, ncol, np.uint8, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
-        for h in handles:
+        for h in handles.values():
             h.close()
         for blk in blocks:
             blk.close()
@@ -544,13 +636,16 @@ def floodplains_blocks(d8: np.ndarray, nblocks: int, elevtn, is_stream, stream_h
     is_stream = np.ascontiguousarray(is_stream, dtype=np.uint8).reshape(nrow, ncol)
     stream_h = np.ascontiguousarray(stream_h, dtype=np.float32).reshape(nrow, ncol)
     devices = devices or [0] * nblocks
-    blocks = []
+    brows = block_rows(nrow, nblocks)
+
+    def make(b):
+        a, e = block_slice(nrow, nblocks, b)
+        h = _hip.RasterHandle(d8[a:e], brows[b][1] - brows[b][0], ncol, device=devices[b], halo=halo_of(b, nblocks))
+        return _FloodBlock(h, elevtn[a:e], _ELEV_CODE[elevtn.dtype], is_stream[a:e], stream_h[a:e])
+
+    blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks), down=True),
+                        _stream_blocks(d8.size, elevtn.dtype.itemsize + 5 + 2 * _hip.FLOOD_STATE.itemsize + 28, devices))
     try:
-        for b, (r0, r1) in enumerate(block_rows(nrow, nblocks)):
-            a, e = block_slice(nrow, nblocks, b)
-            h = _hip.RasterHandle(d8[a:e], r1 - r0, ncol, device=devices[b], halo=halo_of(b, nblocks))
-            blocks.append(_FloodBlock(h, elevtn[a:e], _ELEV_CODE[elevtn.dtype], is_stream[a:e], stream_h[a:e]))
-            blocks[-1].relevant = relevant_halo(d8[a:e], halo_of(b, nblocks), down=True)
         it, bad = _up_blocks_run(blocks, ncol, _hip.FLOOD_STATE, max_iter=max_iter, verify=verify)
         return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
     finally:
@@ -607,6 +702,37 @@ class _HandBlock:
             b.free()
         if close_handle:
             self.h.close()
+
+
+class _StreamedHandBlock:
+    """A row block of HAND that is on the device only while it sweeps (_stream_blocks): the heights wait on the host,
+    own and halo rows; a later sweep sends them back and relaxes the cells that are still unknown (pfd_hand_block with
+    host memory rebuilds its list of unknown cells by one scan)."""
+
+    def __init__(self, d8_rows, own_rows, ncol, device, halo, drain_rows, elevtn_rows, code):
+        self.args = (d8_rows, own_rows, ncol, device, halo)
+        self.drain, self.elev, self.code = np.ascontiguousarray(drain_rows), np.ascontiguousarray(elevtn_rows), code
+        self.own_rows, self.ncol, self.top = own_rows, ncol, halo[0]
+        self.out, self.swept_with, self.brows, self.unknown = None, None, None, None
+
+    def sweep(self, seed):
+        if self.swept_with is not None and np.array_equal(self.swept_with.view(np.uint64), seed.view(np.uint64)):
+            return
+        update = self.swept_with is not None
+        self.swept_with = seed.copy()
+        d8_rows, own_rows, ncol, device, halo = self.args
+        h = _hip.RasterHandle(d8_rows, own_rows, ncol, device=device, halo=halo)
+        try:
+            self.out, self.brows, self.unknown = h.hand_block(self.drain, self.elev, self.code, seed, out=self.out,
+                                                              memspace=_hip.PFD_HOST, update=update)
+        finally:
+            h.close()
+
+    def result(self):
+        return self.out.reshape(-1, self.ncol)[self.top:self.top + self.own_rows]
+
+    def close(self, close_handle=True):
+        pass
 
 
 def exchange_unique_id(rank: int, world: int, group=None) -> bytes:

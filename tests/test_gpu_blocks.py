@@ -787,3 +787,48 @@ def test_blocks_sweep_only_when_a_relevant_halo_value_changed(gpu_lib, oracle, m
     assert all(g <= e for g, e in zip(gated, every)) and sum(gated) <= sum(every), (gated, every)
     if op != "strahler":  # (the down-sweeps of this tilted raster: at least one block is spared a sweep)
         assert sum(gated) < sum(every), (gated, every)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["accuflux_up", "accuflux_down", "distance", "strahler", "classic", "floodplains", "hand"])
+def test_streamed_row_blocks_equal_resident_ones(gpu_lib, oracle, monkeypatch, op):
+    """Row blocks whose state would not fit one GPU go through the device one at a time (dist._stream_blocks: a block is
+    built, swept and released per sweep, its result waits on the host).  Forced here; bit for bit the resident result —
+    which the other tests of this file pin against the oracle."""
+    from pyflwdir_amd import dist
+
+    shape, nb = (900, 500), 4
+    d8 = oracle.synth_d8(shape[0], shape[1], seed=8, tilt=100000, white=2, nodata_pct=8)
+    upa = oracle.upstream_area_cell(d8)[0].reshape(shape)
+    data = (np.random.default_rng(5).random(shape) * 2).astype(np.float32)
+    elev = oracle.synth_elev_f32(shape[0], shape[1], seed=8, tilt=100000, white=2, nodata_pct=8)
+
+    def run():
+        if op.startswith("accuflux"):
+            return dist.accuflux_blocks(d8, nb, data, (-9999, -9999.0, 1), direction=op.split("_")[1])[0]
+        if op == "distance":
+            return dist.stream_distance_blocks(d8, nb)[0]
+        if op == "strahler":
+            return dist.strahler_blocks(d8, nb)[0]
+        if op == "classic":
+            return dist.classic_blocks(d8, nb, upa)[0]
+        if op == "floodplains":
+            stream = (upa > 200).astype(np.uint8)
+            hs = np.where(stream, upa.astype(np.float32) ** np.float32(0.3), 0).astype(np.float32)
+            return dist.floodplains_blocks(d8, nb, elev, stream, hs)[0]
+        return dist.hand_blocks(d8, nb, upa > 100, elev)[0]
+
+    monkeypatch.setenv("PFD_TEST_STREAM_BLOCKS", "0")
+    held = run()
+    monkeypatch.setenv("PFD_TEST_STREAM_BLOCKS", "1")
+    streamed = run()
+    assert streamed.dtype == held.dtype and streamed.shape == held.shape and streamed.tobytes() == held.tobytes()
+    if op != "hand":
+        with pytest.raises(NotImplementedError, match="resident"):
+            {"accuflux_up": lambda: dist.accuflux_blocks(d8, nb, data, (-9999, -9999.0, 1), verify=True),
+             "accuflux_down": lambda: dist.accuflux_blocks(d8, nb, data, (-9999, -9999.0, 1), verify=True, direction="down"),
+             "distance": lambda: dist.stream_distance_blocks(d8, nb, verify=True),
+             "strahler": lambda: dist.strahler_blocks(d8, nb, verify=True),
+             "classic": lambda: dist.classic_blocks(d8, nb, upa, verify=True),
+             "floodplains": lambda: dist.floodplains_blocks(d8, nb, elev, (upa > 200).astype(np.uint8),
+                                                            np.zeros(shape, np.float32), verify=True)}[op]()
