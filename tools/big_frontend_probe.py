@@ -50,3 +50,5 @@ if step("from_array", make):
     step("ucat_area cell, 500 outlets", lambda: [int(v) for v in np.sort(flw.ucat_area(top, unit="cell")[1])[-2:]])
     step("ucat_area km2, 500 outlets", lambda: [float(v) for v in np.sort(flw.ucat_area(top, unit="km2")[1])[-2:]])
     step("snap down, 1000 points", lambda: float(flw.snap(idxs=np.arange(1000, dtype=np.int64) * 4000003 + 7, mask=upa > 1000)[1].max()))
+    step("stream_distance (cells)", lambda: int(flw.stream_distance(unit="cell").max()))
+    step("hand", lambda: float(np.nanmax(flw.hand(upa > 1000, np.zeros(flw.shape, np.float32)))))
