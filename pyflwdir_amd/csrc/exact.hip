@@ -463,6 +463,13 @@ __global__ void __launch_bounds__(256) k_plan_chain_lens(const u32 *__restrict__
   cpos_in[c] = l;  // (exclusive scan in place -> first position of the chain)
 }
 
+// the LAST position of a chain, where its end cell finds it: k_plan_scatter's cells look their chain up through their end
+// cell (tailnum) — with this array the position is one gather beside the chain id instead of two behind it
+__global__ void __launch_bounds__(256) k_plan_pend(const u32 *__restrict__ ctail, const u32 *__restrict__ cpos,
+                                                   const u32 *__restrict__ clen_pos, u32 nchain, u32 *__restrict__ pend_at) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nchain) pend_at[ctail[c]] = cpos[c] + clen_pos[c] - 1u;
+}
 // position of every trunk cell: chain base + distance from the chain head; w = slots the cell needs.
 // One workgroup per 64 x 64 TILE (round 5; a strip of 256 cells of a raster row before): the records land in chain
 // order, and a chain crosses a tile in a run of ~64 consecutive positions — 1 KB of 16-byte records that the L2 merges
@@ -471,7 +478,7 @@ __global__ void __launch_bounds__(256) k_plan_chain_lens(const u32 *__restrict__
 // k_plan_cslot turns it into the slot once the slots are known, so that nobody stores into raster order from chain order.
 __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict__ hinfo, const u32 *__restrict__ hops,
                                                       const u32 *__restrict__ tailnum, const u32 *__restrict__ tidx_at,
-                                                      const u32 *__restrict__ cpos, const u32 *__restrict__ clen_pos, u32 nrow,
+                                                      const u32 *__restrict__ pend_at, u32 nrow,
                                                       u32 ncol, uint4 *__restrict__ urec, u32 *__restrict__ ptmp,
                                                       u32 *__restrict__ tl_cnt) {
   __shared__ u32 s_tc[4];
@@ -517,7 +524,7 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict
         continue;
       }
       const u32 c = tidx_at[tn[j][b] - 1];  // (chain ids since k_plan_chain_lens)
-      const u32 p = cpos[c] + clen_pos[c] - 1 - hp[j][b];
+      const u32 p = pend_at[tn[j][b] - 1] - hp[j][b];
       // one 16-byte record per position — cell, chain, hinfo — so that k_plan_expand, which runs in position order, finds
       // everything in one coalesced load instead of five dependent gathers per cell
       urec[p] = make_uint4(x, c, inf[j][b], 0u);
@@ -1075,8 +1082,12 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if ((rc = pfd_dmalloc((void **)&p->cslot, ((size_t)n + 64) * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pfd_dmalloc((void **)&p->tl_off, (ntiles + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemsetAsync(p->tl_off + ntiles, 0, sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
+  DevBuf pend;  // (written at the chain ends only, like tidx_at)
+  if ((rc = pend.alloc((size_t)n * sizeof(u32) + 64)) != PFD_OK) return fail(rc);
+  if (nchain)
+    k_plan_pend<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(ctail.as<u32>(), cpos.as<u32>(), clenp.as<u32>(), nt32, pend.as<u32>());
   k_plan_scatter<<<dim3(ntc, ntr), 256, 0, h->stream>>>(hinfo.as<uint16_t>(), hops.as<u32>(), tailnum.as<u32>(), tidx_at,
-                                                        cpos.as<u32>(), clenp.as<u32>(), (u32)h->nrow, (u32)h->ncol,
+                                                        pend.as<u32>(), (u32)h->nrow, (u32)h->ncol,
                                                         ucell.as<uint4>(), p->cslot, p->tl_off);
   // first list entry of every tile (exclusive scan of the tiles' trunk counts, in place)
   if (rocprim::exclusive_scan(nullptr, tmp_bytes, p->tl_off, p->tl_off, 0u, ntiles + 1, rocprim::plus<u32>(), h->stream) != hipSuccess)
