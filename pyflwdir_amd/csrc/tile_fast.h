@@ -34,6 +34,9 @@
 #ifndef FX_COMBINE
 #define FX_COMBINE true
 #endif
+#ifndef FY_LEAVES
+#define FY_LEAVES 0  // (1: the experiment of k_tile_final_fast with the in-tile leaves retired before the rounds)
+#endif
 #ifndef FXP
 #define FXP 4  // count words per perimeter slot (replicas picked by lane: a wave's atomics on one word are serialised)
 #endif
@@ -424,12 +427,56 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 6 : 8) k_tile_final_fast(TileA
     for (int i = 0; i < 5; ++i) inf += ((m >> xk[i]) & 1u) ? xc[i] : 0u;
   }
   __syncthreads();
+  if (FY_LEAVES && !WEIGHTS) {
+    // EXPERIMENT (off by default, same-box A/B + SQ counters in profiles/r05_ab_tile_leaves.txt): the
+    // doubling without the in-tile leaves — cells no cell of the tile drains into, a third of them.  A leaf's count is
+    // final from the start (1) and what its ancestors get from it reaches the parent ONCE; the forest of the other cells,
+    // with the leaves absorbed, has the same counts.  Leaves are found by a mark: bit 31 of a cell's count word (never
+    // set by a count) is raised by every cell that drains into it, and by the entry that receives flow from outside.
+    // A retired leaf points at its lane's sink like a saturated cell: no instruction less, fewer LDS conflicts.
+#pragma unroll
+    for (int i = 0; i < QF * 4; ++i)
+      if (pc[i] < FY_SINK0) ((u8 *)A)[pc[i] + 3u] = 0x80u;
+    int plr = 0, plc = 0;
+    pslot_inv((int)ptid, &plr, &plc);
+    const u32 eoff = 4u * PHYS((u32)(plr * TS + plc));
+    if (inf) ((u8 *)A)[eoff + 3u] = 0x80u;
+    __syncthreads();
+    u32 leafm = 0;
+#pragma unroll
+    for (int j = 0; j < QF; ++j) {
+      const u32 l0 = 4u * tid + QSTR * j;
+      uint4 a4 = *(const uint4 *)&A[l0];
+      const u32 m4[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (!(m4[b] >> 31) && pc[4 * j + b] < FY_SINK0) leafm |= 1u << (4 * j + b);
+      a4.x &= 0x7FFFFFFFu, a4.y &= 0x7FFFFFFFu, a4.z &= 0x7FFFFFFFu, a4.w &= 0x7FFFFFFFu;
+      *(uint4 *)&A[l0] = a4;
+    }
+    __syncthreads();
+    if (inf) atomicAdd(&A[eoff >> 2], inf);  // (an entry with inflow is marked: never a leaf; leaves that drain into it push beside this)
+#pragma unroll
+    for (int i = 0; i < QF * 4; ++i)
+      if ((leafm >> i) & 1u) atomicAdd((u32 *)((u8 *)A + pc[i]), 1u);  // (a leaf's count is its own cell: 1)
+#pragma unroll
+    for (int j = 0; j < QF; ++j) {
+      if (!((leafm >> (4 * j)) & 15u)) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if ((leafm >> (4 * j + b)) & 1u) pc[4 * j + b] = sink;
+      *(uint2 *)&P[4u * tid + QSTR * j] = make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
+      lv[j] = !(pc[4 * j + 0] & pc[4 * j + 1] & pc[4 * j + 2] & pc[4 * j + 3] & FY_SINK0);
+    }
+    __syncthreads();
+  } else {
   if (inf) {  // (one slot per perimeter cell: no two threads share a word)
     int plr, plc;
     pslot_inv((int)ptid, &plr, &plc);
     A[PHYS((u32)(plr * TS + plc))] += inf;
   }
   __syncthreads();
+  }
 
   // ---- doubling: A[J(z)] += A(z); J(z) <- J(J(z)).  A saturated cell adds to its lane's sink word --------------
   // One round reads (own counts, the pointers of the ancestors), waits for everybody's reads, then writes.  Two
