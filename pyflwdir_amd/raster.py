@@ -344,7 +344,9 @@ class FlwdirRaster(object):
 
                 def one(h, a, e):
                     ds = h.idxs_ds(np.int64)
-                    return np.where(ds < 0, ds, ds + a * ncol)
+                    if a:  # (in place: the arrays are 8 GB a slice)
+                        np.add(ds, a * ncol, out=ds, where=ds >= 0)
+                    return ds
                 self._idxs_ds = self._sliced(one, np.int64, -1).astype(self._idx_dtype, copy=False)
             else:
                 self._idxs_ds = self._h.idxs_ds(self._idx_dtype)
@@ -700,7 +702,9 @@ class FlwdirRaster(object):
 
             def one(h, a, e):
                 mu = h.main_upstream(np.ascontiguousarray(uparea[a * ncol:e * ncol]), _PAYLOAD[uparea.dtype], np.int64)
-                return np.where(mu < 0, mu, mu + a * ncol)
+                if a:
+                    np.add(mu, a * ncol, out=mu, where=mu >= 0)
+                return mu
             idxs_us_main = self._sliced(one, np.int64, -1).astype(self._idx_dtype, copy=False)
         else:
             idxs_us_main = self._h.main_upstream(np.ascontiguousarray(uparea), _PAYLOAD[uparea.dtype], self._idx_dtype)
