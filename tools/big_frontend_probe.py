@@ -38,7 +38,7 @@ if step("from_array", make):
     step("stream_order classic", lambda: int(flw.stream_order(type="classic").max()))
     step("n_upstream", lambda: np.bincount(flw.n_upstream.ravel()[:10_000_000] + 9)[:3].tolist())
     step("idxs_ds dtype", lambda: (flw.idxs_ds.dtype, int(flw.idxs_ds[-1])))
-    step("main_upstream", lambda: (flw.main_upstream(upa).dtype, int(flw.idxs_us_main.max())))
+    step("main_upstream", lambda: (lambda mu: (mu.dtype, int(mu.max())))(flw.main_upstream(upa)))
     step("upstream_sum", lambda: float(flw.upstream_sum(np.ones(flw.shape, np.float32)).max()))
     step("add_pits + idxs_pit", lambda: (flw.add_pits(idxs=np.array([int(np.argmax(upa)) - 5 * size])), flw.idxs_pit.size)[1])
     step("upstream_area after add_pits", lambda: int(flw.upstream_area().max()))
