@@ -104,6 +104,28 @@ __device__ __forceinline__ u32 d8_down(const Geo &g, u32 i, u32 code) {
   return (u32)((i64)i + (i64)d8_dr(k) * (i64)g.ncol + d8_dc(k));
 }
 
+// XCD-aware order of the tiles of a 2-D grid (one workgroup per 64 x 64 tile).  The hardware hands consecutive workgroup ids
+// to the 8 XCDs of an MI355X in turn, each with its own L2.  With the identity map the left / right neighbours of a tile run
+// on other XCDs, and every 128-byte line of a 1-byte-per-cell raster (two tiles wide) and every halo ring is fetched from
+// HBM by two or three of them: measured on the count's tile passes at 90000^2, FETCH_SIZE 13.3 -> 4.1 GB (local) and
+// 16.6 -> 7.0 GB (final) raw with this map (profiles/r05_xcd_order.txt).  Workgroup id L takes tile
+// (L mod 8) * (n / 8) + L div 8 of the row-major sequence: every XCD sweeps one contiguous band of tile rows.
+#ifndef PFD_XCD_ORDER
+#define PFD_XCD_ORDER 1
+#endif
+#ifdef __HIPCC__
+__device__ __forceinline__ void pfd_tile_of_block(u32 *bx, u32 *by) {
+  *bx = blockIdx.x, *by = blockIdx.y;
+  if (PFD_XCD_ORDER) {
+    const u32 gx = gridDim.x, n = gx * gridDim.y, L = blockIdx.y * gx + blockIdx.x;
+    const u32 q = n >> 3, r = n & 7u, k = L & 7u;
+    const u32 t = k * q + min(k, r) + (L >> 3);
+    *by = t / gx;
+    *bx = t - *by * gx;
+  }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // profiling segments (HIP events on the handle's stream)
 // ---------------------------------------------------------------------------------------------

@@ -42,7 +42,9 @@ __global__ void __launch_bounds__(256) k_plan_tile(const u8 *__restrict__ ncode,
   __shared__ u32 s_add[XOFF];      // entries appended by step s (a counter per step: one barrier per step)
   __shared__ uint16_t off[XOFF];
   const u32 tid = threadIdx.x;
-  const u32 tc = blockIdx.x, tr = blockIdx.y;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tc = bx_, tr = by_;
   const i64 r0 = (i64)tr * XT, c0 = (i64)tc * XT;
   {
     u32 v[5];
@@ -194,7 +196,9 @@ __global__ void __launch_bounds__(256) k_plan_heavy_tile(const u8 *__restrict__ 
   __shared__ u8 sL[HPW * HPW];
   __shared__ u8 sK[HRW * HRW], sH[HRW * HRW];
   const u32 tid = threadIdx.x;
-  const i64 r0 = (i64)blockIdx.y * XT, c0 = (i64)blockIdx.x * XT;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const i64 r0 = (i64)by_ * XT, c0 = (i64)bx_ * XT;
   // (all loads of the staging first, from clamped addresses: one round trip, not one per loop iteration)
   constexpr int NU = (HPW * HPW + 255) / 256, NK = (HRW * HRW + 255) / 256;
   u32 ua[NU], la[NU], ka[NK];
@@ -483,7 +487,9 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict
                                                       u32 *__restrict__ tl_cnt) {
   __shared__ u32 s_tc[4];
   const u32 tid = threadIdx.x;
-  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 r0 = by_ * XT, c0 = bx_ * XT;
   u32 mine = 0;  // trunk cells with a position among the thread's 16 cells (-> tl_cnt[tile])
   u32 inf[4][4], tn[4][4], hp[4][4], x0s[4];
   bool any[4];
@@ -535,7 +541,7 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict
   for (int o = 32; o > 0; o >>= 1) mine += (u32)__shfl_down((int)mine, o);
   if ((tid & 63u) == 0u) s_tc[tid >> 6] = mine;
   __syncthreads();
-  if (tid == 0) tl_cnt[blockIdx.y * gridDim.x + blockIdx.x] = s_tc[0] + s_tc[1] + s_tc[2] + s_tc[3];
+  if (tid == 0) tl_cnt[by_ * gridDim.x + bx_] = s_tc[0] + s_tc[1] + s_tc[2] + s_tc[3];
 }
 // cslot[x]: position -> slot (spos[p], written by k_plan_expand in position order), and the number of post slots into
 // the trunk mark; tile-shaped like the scatter (the gather from chain order hits the runs the tile holds)
@@ -543,7 +549,9 @@ __global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__
                                                     u8 *__restrict__ lh, const u32 *__restrict__ tl_off, uint2 *__restrict__ tlist) {
   __shared__ u32 s_tw[4];
   const u32 tid = threadIdx.x;
-  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 r0 = by_ * XT, c0 = bx_ * XT;
   u32 esl[16], eps[16], emask = 0;  // slot / post slots of the thread's cells that join the list (static indices only)
 #pragma unroll
   for (int k = 0; k < 16; ++k) esl[k] = eps[k] = 0;
@@ -590,7 +598,7 @@ __global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__
   }
   if (lane == 63u) s_tw[wave] = incl;
   __syncthreads();
-  u32 pos = tl_off[blockIdx.y * gridDim.x + blockIdx.x] + incl - ne;
+  u32 pos = tl_off[by_ * gridDim.x + bx_] + incl - ne;
   for (u32 w = 0; w < wave; ++w) pos += s_tw[w];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {

@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(256) k_xtile_up(Op op, XTileArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t ord[XTC];
   __shared__ uint16_t off[XOFF];
   const u32 tid = threadIdx.x;
-  const u32 tc = blockIdx.x, tr = blockIdx.y;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tc = bx_, tr = by_;
   const size_t tile = (size_t)tr * a.ntc + tc;
   const u32 r0 = tr * XT, c0 = tc * XT;
   if (tid < XOFF) off[tid] = a.toff[tile * XOFF + tid];
@@ -433,7 +435,9 @@ template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, const typename Op::V *__restrict__ R,
                                                           u32 s_limit = 0xFFFFFFFFu) {  // only the cells of slots below s_limit
   const u32 tid = threadIdx.x;
-  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 r0 = by_ * XT, c0 = bx_ * XT;
   u32 l4s[4], x0s[4];
   uint4 c4s[4];
   bool full[4];
@@ -495,9 +499,11 @@ __global__ void __launch_bounds__(256) k_xtrunk_unscatter(Op op, XTileArgs a, co
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_unscatter_list(Op op, XTileArgs a, const typename Op::V *__restrict__ R,
                                                                u32 s_limit = 0xFFFFFFFFu) {
-  const u32 tile = blockIdx.y * a.ntc + blockIdx.x;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tile = by_ * a.ntc + bx_;
   const u32 b = a.tl_off[tile], e = a.tl_off[tile + 1];
-  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  const u32 r0 = by_ * XT, c0 = bx_ * XT;
   for (u32 i0 = b; i0 < e; i0 += 1024u) {  // four entries per thread in flight
     uint2 en[4];
     typename Op::V v[4];
@@ -710,7 +716,9 @@ template <class Op, bool LIMIT = false>
 __global__ void __launch_bounds__(256) k_xtrunk_demit(Op op, XTileArgs a, typename Op::DElem *__restrict__ E,
                                                       u32 s_limit = 0xFFFFFFFFu) {  // LIMIT: only the slots below s_limit
   const u32 tid = threadIdx.x;
-  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 r0 = by_ * XT, c0 = bx_ * XT;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const u32 l0 = 4u * tid + 1024u * j;
@@ -743,9 +751,11 @@ __global__ void __launch_bounds__(256) k_xtrunk_demit(Op op, XTileArgs a, typena
 template <class Op, bool LIMIT = false>
 __global__ void __launch_bounds__(256) k_xtrunk_demit_list(Op op, XTileArgs a, typename Op::DElem *__restrict__ E,
                                                            u32 s_limit = 0xFFFFFFFFu) {
-  const u32 tile = blockIdx.y * a.ntc + blockIdx.x;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tile = by_ * a.ntc + bx_;
   const u32 b = a.tl_off[tile], e = a.tl_off[tile + 1];
-  const u32 r0 = blockIdx.y * XT, c0 = blockIdx.x * XT;
+  const u32 r0 = by_ * XT, c0 = bx_ * XT;
   for (u32 i0 = b; i0 < e; i0 += 512u) {  // two entries per thread in flight
     uint2 en[2];
     u32 x[2], cd[2];
@@ -1018,7 +1028,9 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   __shared__ u32 F[XTC / 32];  // one flag bit per cell, for operations whose element needs one (HAND: drain)
   __shared__ uint16_t off[XOFF];
   const u32 tid = threadIdx.x;
-  const u32 tc = blockIdx.x, tr = blockIdx.y;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tc = bx_, tr = by_;
   const size_t tile = (size_t)tr * a.ntc + tc;
   const i64 r0 = (i64)tr * XT, c0 = (i64)tc * XT;
   if (tid < XOFF) off[tid] = a.toff[tile * XOFF + tid];

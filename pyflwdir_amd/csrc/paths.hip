@@ -63,7 +63,9 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];  // 2^k-th ancestor | PDONE once saturated
   __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
   const u32 tid = threadIdx.x;
-  const u32 tc = blockIdx.x, tr = blockIdx.y + a.tr_off;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tc = bx_, tr = by_ + a.tr_off;
   const u32 sbase = sslot_base(tr, tc, a.nstc);
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   {
@@ -968,7 +970,9 @@ __global__ void k_flag_seed_tiles(const i64 *__restrict__ idx, u32 k, u32 ncol, 
 }
 __global__ void __launch_bounds__(256) k_zero_seed_tiles(const u8 *__restrict__ tflag, u32 nrow, u32 ncol, u32 ntc,
                                                          u32 *__restrict__ seed) {
-  const u32 tc = blockIdx.x, tr = blockIdx.y;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tc = bx_, tr = by_;
   if (!tflag[(size_t)tr * ntc + tc]) return;
   for (u32 i = threadIdx.x; i < TS * TS / 4; i += 256u) {  // quads of the tile
     const u32 r = tr * TS + (i >> 4), c = tc * TS + 4u * (i & 15u);

@@ -133,7 +133,9 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
   __shared__ u64 s_cnt[4];
   const u32 tid = threadIdx.x;
-  const u32 tc = blockIdx.x + a.tc_lo, tr = blockIdx.y + a.tr_lo;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tc = bx_ + a.tc_lo, tr = by_ + a.tr_lo;
   const u32 sbase = sslot_base(tr, tc, a.nstc);
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   bool mvq = false;  // RAW: one of the staged bytes is nodata (zero-byte test of v ^ 247 x 4)
@@ -359,7 +361,9 @@ __global__ void __launch_bounds__(NT, NT == 256 ? 6 : 8) k_tile_final_fast(TileA
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS + 64];   // A byte offset of an ancestor / of a sink word
   __shared__ __attribute__((aligned(16))) u32 s_flag[2][8];
   const u32 tid = threadIdx.x;
-  const u32 tc = blockIdx.x + a.tc_lo, tr = blockIdx.y + a.tr_lo;
+  u32 bx_, by_;
+  pfd_tile_of_block(&bx_, &by_);
+  const u32 tc = bx_ + a.tc_lo, tr = by_ + a.tr_lo;
   const u32 sbase = sslot_base(tr, tc, a.nstc);
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   const u32 lcq = 4u * (tid & 15u);
