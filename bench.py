@@ -569,6 +569,58 @@ def km2_line(nrow, ncol, synth, label, steps, device):
 N1_RECORD = os.path.join(ROOT, ".bench_n1.json")  # (git-ignored scratch: lets the N > 1 lines quote their speed-up)
 
 
+def api_lines(nrow, ncol, synth, device, reps=3):
+    """What a drop-in numpy caller sees (SURVEY 8d "report H2D/D2H separately"): host uint8 raster ->
+    ``from_array`` -> ``upstream_area()`` -> host int32 raster through ``FlwdirRaster``, wall clock, with the upload, the
+    device work and the download told apart (``pfd_transfer_stats``: the library's own clocks around its staging copies;
+    compute = wall - h2d - d2h).  The process's default arena is whatever the front end reserved (bench.py's own arena
+    exists already at this point, so the first-call figure here is NOT a cold process: tests/test_gpu_frontend.py
+    measures that)."""
+    import pyflwdir_amd as pyflwdir
+
+    n = nrow * ncol
+    buf = _hip.synth_d8_device(nrow, ncol, device=device, **synth)
+    d8 = buf.download(np.uint8, (nrow, ncol))
+    buf.free()
+    rows = []
+    for _ in range(reps + 1):  # (the first repetition is reported apart: first pageable copies, fresh result pages)
+        _hip.transfer_stats(reset=True)
+        t0 = time.perf_counter()
+        flw = pyflwdir.from_array(d8, ftype="d8")
+        t1 = time.perf_counter()
+        tr_a = _hip.transfer_stats(reset=True)
+        upa = flw.upstream_area()
+        t2 = time.perf_counter()
+        tr_b = _hip.transfer_stats(reset=True)
+        ok = bool(upa.dtype == np.int32 and upa.shape == (nrow, ncol))
+        rows.append(dict(from_array_ms=(t1 - t0) * 1e3, upstream_area_ms=(t2 - t1) * 1e3, h2d_ms=tr_a["h2d_ms"] + tr_b["h2d_ms"],
+                         h2d_bytes=tr_a["h2d_bytes"] + tr_b["h2d_bytes"], d2h_ms=tr_a["d2h_ms"] + tr_b["d2h_ms"],
+                         d2h_bytes=tr_a["d2h_bytes"] + tr_b["d2h_bytes"], prefault_ms=tr_b["prefault_ms"],
+                         upa_d2h_ms=tr_b["d2h_ms"], upa_d2h_bytes=tr_b["d2h_bytes"], ok=ok, upa_max=int(upa.max())))
+        del upa, flw
+    first, warm = rows[0], rows[1:]
+
+    def med(k):
+        return statistics.median(r[k] for r in warm)
+
+    total_ms = med("from_array_ms") + med("upstream_area_ms")
+    line = dict(op="FlwdirRaster: from_array + upstream_area() (host numpy in, host numpy out)",
+                workload=f"{nrow}x{ncol} synthetic D8, uint8 host array -> int32 host array", dtype="int32",
+                value=round(n / total_ms / 1e3, 2), unit="Mcells/s", ms_per_call=round(total_ms, 3),
+                from_array_ms=round(med("from_array_ms"), 3), upstream_area_ms=round(med("upstream_area_ms"), 3),
+                h2d_ms=round(med("h2d_ms"), 3), d2h_ms=round(med("d2h_ms"), 3),
+                compute_ms=round(total_ms - med("h2d_ms") - med("d2h_ms"), 3),
+                h2d_GBps=round(med("h2d_bytes") / max(med("h2d_ms"), 1e-9) / 1e6, 2),
+                d2h_GBps=round(med("d2h_bytes") / max(med("d2h_ms"), 1e-9) / 1e6, 2),
+                upstream_area_d2h_GBps=round(med("upa_d2h_bytes") / max(med("upa_d2h_ms"), 1e-9) / 1e6, 2),
+                prefault_ms=round(med("prefault_ms"), 3),
+                first_call=dict(from_array_ms=round(first["from_array_ms"], 3), upstream_area_ms=round(first["upstream_area_ms"], 3),
+                                h2d_ms=round(first["h2d_ms"], 3), d2h_ms=round(first["d2h_ms"], 3)),
+                ok=all(r["ok"] for r in rows) and len({r["upa_max"] for r in rows}) == 1,
+                pinned_pcie_GBps_measured=57.0)  # (tools/probes/pcie_probe.cpp on the test box: pinned D2H 56.8, H2D 57.2 GB/s)
+    return [line]
+
+
 def save_n1_record(a, out):
     try:
         with open(N1_RECORD, "w") as f:
@@ -643,10 +695,21 @@ def run_distributed(a, rank, world, local):
     _hip.check(_hip.lib().pfd_device_synchronize(device))
     grp.barrier()
     t0 = time.perf_counter()
-    timed = [step(profile=True) for _ in range(a.steps)]
+    timed, marks = [], [t0]
+    for _ in range(a.steps):
+        timed.append(step(profile=True))
+        marks.append(time.perf_counter())  # (a step ends with the pass's own stream synchronisation and agreement)
     _hip.check(_hip.lib().pfd_device_synchronize(device))
     grp.barrier()
     dt = grp.allreduce(time.perf_counter() - t0, "max")
+    # every rank's own step times, so that a first hardware run explains itself: a collective step
+    # costs what its slowest rank costs — per rank median / max and max over median, and per step the maximum over the ranks
+    per = [(b - a_) * 1e3 for a_, b in zip(marks[:-1], marks[1:])]
+    all_per = [json.loads(x.decode()) for x in grp.allgather(json.dumps([round(v, 3) for v in per]).encode())]
+    rank_steps = dict(per_rank_median_ms=[round(statistics.median(p), 3) for p in all_per],
+                      per_rank_max_ms=[round(max(p), 3) for p in all_per],
+                      step_max_over_median=[round(max(p) / statistics.median(p), 3) for p in all_per],
+                      per_step_max_over_ranks_ms=[round(max(p[i] for p in all_per), 3) for i in range(len(per))])
     segs, info = mean_segments([t[0] for t in timed]), timed[-1][1]
     # checksum of the whole result (the sum over the ranks must equal the 1-GPU run's
     # invariants.result_checksum: SURVEY §8d C4 check iii) and the pit-sum invariant (river regime: every
@@ -682,7 +745,7 @@ def run_distributed(a, rank, world, local):
                                launcher="self-spawned" if os.environ.get("PFD_BENCH_SPAWNED") else "external",
                                retried_with_host_transport=bool(os.environ.get("PFD_BENCH_RETRY")),
                                devices_visible=_hip.device_count()),
-                   roofline=roof,
+                   roofline=roof, rank_steps=rank_steps,
                    invariants=dict(result_checksum=csum,
                                    last_row_pit_sum_equals_n_valid=bool(pit_sum == n_valid) if a.regime == "river" else None))
         n1 = load_n1_record(a)
@@ -827,6 +890,9 @@ def run_distributed_op(a, rank, world, local):
                                rccl_binding=rccl_binding() if dr.comm is not None else None,
                                exchanges_per_step=n_ex, exchange_kinds=kinds, exchange_bytes_per_rank_per_step=ex_bytes,
                                iterations=iters[0], devices_visible=_hip.device_count(),
+                               # (hand: the timed steps skip the non-finite scan of the unchanged elevation buffer — the
+                               #  first, untimed call did it; the default API call pays it every time)
+                               check_finite=False if a.op == "hand" else None,
                                launcher="self-spawned" if os.environ.get("PFD_BENCH_SPAWNED") else "external"),
                    roofline=dict(bound="hbm", achieved=round(per_gpu, 2), peak=PEAK_HBM_GBS, unit="GB/s",
                                  frac=round(per_gpu / PEAK_HBM_GBS, 5), alg_bytes_per_cell=b_alg, per_gpu=True, traffic=None),
@@ -1027,9 +1093,12 @@ def compact_row(line, tag):
         row["frac_first_call"] = line["roofline_first_call"]["frac"]
     if "invariants" in line:
         row["ok"] = bool(all(v for v in line["invariants"].values() if isinstance(v, bool)))
-    for k in ("n_pits", "max_rank", "tile_doubling_rounds"):
+    for k in ("n_pits", "max_rank", "tile_doubling_rounds", "from_array_ms", "upstream_area_ms", "h2d_ms", "d2h_ms", "compute_ms",
+              "h2d_GBps", "d2h_GBps", "upstream_area_d2h_GBps", "first_call"):
         if k in line:
             row[k] = line[k]
+    if "ok" in line and "ok" not in row:
+        row["ok"] = line["ok"]
     return row
 
 
@@ -1049,6 +1118,9 @@ def secondary_lines(a, device):
     add(op_lines(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", 3, device),
         f"C3 30000x30000 {a.regime}")
     add(km2_line(30000, 30000, REGIMES[a.regime], f"30000x30000 synthetic D8 ({a.regime} regime)", 3, device), f"C3 30000x30000 {a.regime}")
+    # the path a numpy caller of the drop-in takes (host raster in, host raster out), upload / device / download apart
+    add(api_lines(10000, 10000, REGIMES[a.regime], device), f"API C2 10000x10000 {a.regime}")
+    add(api_lines(30000, 30000, REGIMES[a.regime], device), f"API C3 30000x30000 {a.regime}")
     # configs[4]'s shape: a MERIT-Hydro-like 3-arcsec tile, 72000 x 36000 cells (36000 rows), rough terrain, 30 % ocean
     add(op_lines(36000, 72000, C5_SYNTH, "36000x72000 synthetic D8 (rough regime, 30 % nodata: BASELINE configs[4] shape)", 2,
                  device, ops=("hand", "basins")), "C5 36000x72000 rough, 30 % nodata")

@@ -83,6 +83,17 @@ int pfd_reserve(int device, size_t bytes);
 /* allocator counters since the process started: [0] hipMalloc calls, [1] exact-class cache hits, [2] near-fit cache hits,
  * [3] blocks carved from reserved arenas, [4] idle cached bytes, [5] reserved bytes, [6] of them free, [7] live blocks */
 int pfd_alloc_stats(int64_t out[8]);
+/* free and total HBM of `device` in bytes (hipMemGetInfo): out[0] free, out[1] total.  The Python front end sizes its
+ * default arena with it (pyflwdir_amd/_hip.py ensure_reserved). */
+int pfd_mem_info(int device, int64_t out[2]);
+/* Host <-> device traffic of the calling thread's API calls since the last call with reset != 0 (§8d "report H2D/D2H
+ * separately"): out[0] bytes uploaded from PFD_HOST arguments, out[1] ms spent in those uploads (wall clock of the
+ * staging calls), out[2] bytes downloaded into PFD_HOST results, out[3] ms of the downloads (from the moment the stream
+ * is idle, i.e. compute excluded), out[4] ms the host spent pre-faulting result pages (runs beside the kernels),
+ * out[5] number of host results.  A result buffer of >= 64 MiB is touched by a few host threads while the kernels run
+ * (first-touch page faults bound a copy into fresh pages at ~15 GB/s on this host; into touched pages it runs at
+ * ~50 GB/s), one byte per page, read and written back unchanged. */
+int pfd_transfer_stats(double out[6], int reset);
 
 /* ---- raster handle -------------------------------------------------------------------
  * pfd_raster_create: replaces core_d8.from_array (reference pyflwdir/core_d8.py:42-67) as the

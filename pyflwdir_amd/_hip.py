@@ -40,7 +40,7 @@ SYMBOLS = [
     "pfd_accuflux_rows", "pfd_basins", "pfd_hand", "pfd_main_upstream", "pfd_stream_order_classic", "pfd_stream_distance", "pfd_set_profiling", "pfd_last_timing", "pfd_synth_d8", "pfd_synth_elev_f32",
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
     "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic", "pfd_set_block_update",
-    "pfd_reserve", "pfd_alloc_stats", "pfd_count_nonfinite", "pfd_floodplains_block", "pfd_trib_info_block",
+    "pfd_reserve", "pfd_alloc_stats", "pfd_mem_info", "pfd_transfer_stats", "pfd_count_nonfinite", "pfd_floodplains_block", "pfd_trib_info_block",
     "pfd_stream_order_classic_block",
 ]
 
@@ -137,6 +137,8 @@ def lib() -> C.CDLL:
         L.pfd_trim.argtypes = [C.c_int]
         L.pfd_reserve.argtypes = [C.c_int, C.c_size_t]
         L.pfd_alloc_stats.argtypes = [C.POINTER(C.c_int64)]
+        L.pfd_mem_info.argtypes = [C.c_int, C.POINTER(C.c_int64)]
+        L.pfd_transfer_stats.argtypes = [C.POINTER(C.c_double), C.c_int]
         L.pfd_count_nonfinite.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.pfd_trib_info_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_device_count.argtypes = [C.POINTER(C.c_int)]
@@ -176,11 +178,68 @@ def ptr(a):
 FLOOD_STATE = np.dtype([("z", np.float32), ("h", np.float32), ("flag", np.int32), ("pad", np.int32)])
 
 
+_explicit_reserve = False  # the caller sized an arena itself: the default one stands down
+_auto_reserved = {}        # device -> bytes of the default arenas of this process
+AUTO_RESERVE_MIN = 64 << 20
+AUTO_RESERVE_BYTES_PER_CELL = 48
+
+
 def reserve(nbytes: int, device: int = 0):
     """Reserve ``nbytes`` of HBM as one arena for the library's working buffers (``pfd_reserve``): afterwards a steady
     state never calls hipMalloc, whose latency for multi-GiB blocks is unpredictable (0.2 ms or seconds).  ``nbytes=0``
-    releases the arenas that hold no live block."""
+    releases the arenas that hold no live block.  A process that calls this sizes its arenas itself: the default arena
+    of ``ensure_reserved`` is not added."""
+    global _explicit_reserve
     check(lib().pfd_reserve(int(device), C.c_size_t(int(nbytes))))
+    if nbytes:
+        _explicit_reserve = True
+    else:
+        _auto_reserved.pop(int(device), None)
+
+
+def mem_info(device: int = 0) -> dict:
+    """Free and total HBM of ``device`` in bytes (``pfd_mem_info``)."""
+    a = (C.c_int64 * 2)()
+    check(lib().pfd_mem_info(int(device), a))
+    return dict(free=int(a[0]), total=int(a[1]))
+
+
+def ensure_reserved(n_cells: int, device: int = 0):
+    """The default arena: the first handle of a process reserves
+    ``min(0.5 x free HBM, 48 B x n_cells)`` — what the working buffers of the operations on a raster of ``n_cells`` need —
+    so that the path a ``FlwdirRaster`` user takes is the path ``bench.py`` times; a later, larger raster adds the
+    difference.  ``PFD_RESERVE_GIB`` overrides the size (``0``: no default arena); an explicit ``reserve()`` switches this
+    off; arenas stay below half of the device's HBM in total and are released by ``reserve(0)``.  Failure to reserve is
+    not an error: the class cache and hipMalloc remain."""
+    if _explicit_reserve:
+        return
+    env = os.environ.get("PFD_RESERVE_GIB")
+    have = _auto_reserved.get(int(device), 0)
+    try:
+        if env is not None:
+            want = int(float(env) * 2**30)
+            if want <= 0 or have:
+                return
+        else:
+            want = AUTO_RESERVE_BYTES_PER_CELL * int(n_cells)
+            if want - have < AUTO_RESERVE_MIN:
+                return
+            mi = mem_info(device)
+            want = min(want - have, mi["free"] // 2, max(0, mi["total"] // 2 - have))
+            if want < AUTO_RESERVE_MIN:
+                return
+        check(lib().pfd_reserve(int(device), C.c_size_t(int(want))))
+        _auto_reserved[int(device)] = have + int(want)
+    except (RuntimeError, MemoryError, ValueError):
+        pass
+
+
+def transfer_stats(reset: bool = True) -> dict:
+    """Host <-> device traffic of this thread's API calls since the last reset (``pfd_transfer_stats``)."""
+    a = (C.c_double * 6)()
+    check(lib().pfd_transfer_stats(a, 1 if reset else 0))
+    keys = ("h2d_bytes", "h2d_ms", "d2h_bytes", "d2h_ms", "prefault_ms", "host_results")
+    return {k: float(v) for k, v in zip(keys, a)}
 
 
 def alloc_stats() -> dict:
@@ -242,6 +301,7 @@ class RasterHandle:
             d8 = np.ascontiguousarray(d8, dtype=np.uint8)
             assert d8.size == (self.nrow + sum(self.halo)) * self.ncol
         self._d8_ref = d8 if deferred else None  # keep a referenced device buffer alive
+        ensure_reserved((self.nrow + sum(self.halo)) * self.ncol, device)
         if deferred:
             check(lib().pfd_raster_create_deferred(ptr(d8), self.nrow, self.ncol, self.halo[0], self.halo[1],
                                                    memspace, device, C.byref(self._h)))
@@ -260,6 +320,7 @@ class RasterHandle:
         self.device, self.halo, self._d8_ref, self.is_general = device, (0, 0), None, True
         idxs_ds = np.ascontiguousarray(idxs_ds).ravel()
         assert idxs_ds.size == self.n
+        ensure_reserved(self.n, device)
         check(lib().pfd_raster_create_general(ptr(idxs_ds), IDX_CODE[idxs_ds.dtype], self.nrow, self.ncol, PFD_HOST, device,
                                               C.byref(self._h)))
         return self

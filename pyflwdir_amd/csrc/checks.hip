@@ -263,13 +263,13 @@ extern "C" int pfd_checksum_i32(int device, const int32_t *dev_ptr, int64_t n, i
     return PFD_EINVAL;
   }
   HIPCHK(hipSetDevice(device));
-  unsigned long long *acc = nullptr, host = 0;
-  HIPCHK(hipMalloc((void **)&acc, 8));
-  HIPCHK(hipMemset(acc, 0, 8));
-  if (n) k_checksum_i32<<<4096, 256>>>(dev_ptr, (u64)n, acc);
-  hipError_t e = hipMemcpy(&host, acc, 8, hipMemcpyDeviceToHost);
-  (void)hipFree(acc);
-  HIPCHK(e);
+  unsigned long long host = 0;
+  DevBuf acc;  // (the caching allocator: a raw hipMalloc here was a driver call per checksum; released on every way out)
+  PFDCHK(acc.alloc(8));
+  HIPCHK(hipMemsetAsync(acc.p, 0, 8, nullptr));
+  if (n) k_checksum_i32<<<4096, 256>>>(dev_ptr, (u64)n, acc.as<unsigned long long>());
+  KCHK();
+  HIPCHK(hipMemcpy(&host, acc.p, 8, hipMemcpyDeviceToHost));
   *sum = (int64_t)host;
   return PFD_OK;
 }
@@ -290,14 +290,16 @@ extern "C" int pfd_count_nonfinite(int device, int dtype, const void *dev_ptr, i
     return PFD_EINVAL;
   }
   HIPCHK(hipSetDevice(device));
-  unsigned long long *acc = nullptr, host = 0;
-  HIPCHK(hipMalloc((void **)&acc, 8));
-  HIPCHK(hipMemset(acc, 0, 8));
-  if (n && dtype == PFD_F32) k_count_nonfinite<float><<<4096, 256>>>((const float *)dev_ptr, (u64)n, acc);
-  if (n && dtype == PFD_F64) k_count_nonfinite<double><<<4096, 256>>>((const double *)dev_ptr, (u64)n, acc);
-  hipError_t e = hipMemcpy(&host, acc, 8, hipMemcpyDeviceToHost);
-  (void)hipFree(acc);
-  HIPCHK(e);
+  unsigned long long host = 0;
+  DevBuf acc;  // (caching allocator, released on every way out; the scan is ordered behind the caller's work by the
+               //  null stream, which waits for nothing here: the handles' streams are non-blocking, so the caller must
+               //  have synchronised whatever produced dev_ptr — every API call of this library does before it returns)
+  PFDCHK(acc.alloc(8));
+  HIPCHK(hipMemsetAsync(acc.p, 0, 8, nullptr));
+  if (n && dtype == PFD_F32) k_count_nonfinite<float><<<4096, 256>>>((const float *)dev_ptr, (u64)n, acc.as<unsigned long long>());
+  if (n && dtype == PFD_F64) k_count_nonfinite<double><<<4096, 256>>>((const double *)dev_ptr, (u64)n, acc.as<unsigned long long>());
+  KCHK();
+  HIPCHK(hipMemcpy(&host, acc.p, 8, hipMemcpyDeviceToHost));
   *count = (int64_t)host;
   return PFD_OK;
 }

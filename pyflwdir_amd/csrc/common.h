@@ -224,6 +224,17 @@ struct DevBuf {
   DevBuf &operator=(const DevBuf &) = delete;
 };
 
+// Host <-> device traffic of the calling thread's API calls (pfd_transfer_stats, api.hip).
+struct PfdTransfer {
+  double h2d_bytes = 0, h2d_ms = 0, d2h_bytes = 0, d2h_ms = 0, prefault_ms = 0, host_results = 0;
+};
+PfdTransfer &pfd_transfer();
+double pfd_now_ms();
+// Pre-faulting of a host result buffer while the kernels run (api.hip): a copy into fresh pages is bound by first-touch
+// page faults (~15 GB/s on the test host, 50 GB/s into touched pages; tools/probes/pcie_probe.cpp, thp_probe.cpp).
+void *pfd_prefault_begin(void *dst, size_t bytes);  // null: nothing started (small buffer)
+double pfd_prefault_join(void *state);              // ms the touching took (0 for null)
+
 // An input that may live on the host (staged through a temp buffer) or on the device (used as is).
 struct InArg {
   DevBuf tmp;
@@ -238,17 +249,24 @@ struct InArg {
       return PFD_OK;
     }
     PFDCHK(tmp.alloc(bytes));
+    const double t0 = pfd_now_ms();
     HIPCHK(hipMemcpyAsync(tmp.p, src, bytes, hipMemcpyHostToDevice, s));
+    if (bytes >= (1u << 20)) HIPCHK(hipStreamSynchronize(s));  // (a pageable upload has all but finished when the call returns)
+    PfdTransfer &t = pfd_transfer();
+    t.h2d_bytes += (double)bytes, t.h2d_ms += pfd_now_ms() - t0;
     dev = tmp.p;
     return PFD_OK;
   }
 };
-// An output that is produced in HBM and, for host callers, copied back at the end.
+// An output that is produced in HBM and, for host callers, copied back at the end.  The pages of a large host result are
+// touched by a few host threads while the kernels run (pfd_prefault_begin).
 struct OutArg {
   DevBuf tmp;
   void *dev = nullptr;
   void *host = nullptr;
   size_t bytes = 0;
+  void *prefault = nullptr;
+  ~OutArg() { (void)pfd_prefault_join(prefault); }
   int bind(void *dst, size_t nbytes, int memspace) {
     bytes = nbytes;
     if (memspace == PFD_DEVICE) {
@@ -258,10 +276,21 @@ struct OutArg {
     host = dst;
     PFDCHK(tmp.alloc(nbytes));
     dev = tmp.p;
+    prefault = pfd_prefault_begin(dst, nbytes);
     return PFD_OK;
   }
   int finish(hipStream_t s) {
-    if (host) HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+    if (host) {
+      HIPCHK(hipStreamSynchronize(s));  // (the kernels are done: what follows is the download alone)
+      PfdTransfer &t = pfd_transfer();
+      t.prefault_ms += pfd_prefault_join(prefault);
+      prefault = nullptr;
+      const double t0 = pfd_now_ms();
+      HIPCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      t.d2h_bytes += (double)bytes, t.d2h_ms += pfd_now_ms() - t0, t.host_results += 1;
+      return PFD_OK;
+    }
     HIPCHK(hipStreamSynchronize(s));
     return PFD_OK;
   }

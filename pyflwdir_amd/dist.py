@@ -213,6 +213,17 @@ class _SeedGate:
 HBM_BUDGET = 200 << 30  # bytes of an MI355X's 288 GB that the row blocks of ONE call may hold at the same time
 
 
+def hbm_budget(device: int = 0) -> int:
+    """What the row blocks of one call may hold on ``device``: 70 % of its HBM (200 GiB of an MI355X's 288 GB — the
+    module constant, kept for callers that read it — and the same share of a smaller part), never more than what is
+    free right now less a working margin of an eighth of the device."""
+    try:
+        mi = _hip.mem_info(device)
+    except Exception:  # noqa: BLE001 - (no device query: the MI355X figure)
+        return HBM_BUDGET
+    return max(1 << 30, min(int(0.7 * mi["total"]), mi["free"] + _hip.alloc_stats()["reserved_free"] - mi["total"] // 8))
+
+
 def _stream_blocks(cells: int, bytes_per_cell: int, devices) -> bool:
     """Do the row blocks of a call go through the device one at a time?  Resident blocks keep payloads, results and
     their sweep plans (~26 bytes per cell) in HBM between the exchanges; when that does not fit one GPU — floodplains of
@@ -223,7 +234,7 @@ def _stream_blocks(cells: int, bytes_per_cell: int, devices) -> bool:
 
     if os.environ.get("PFD_ENABLE_KNOBS") == "1" and os.environ.get("PFD_TEST_STREAM_BLOCKS"):
         return os.environ["PFD_TEST_STREAM_BLOCKS"] == "1"
-    return len(set(devices)) == 1 and cells * bytes_per_cell > HBM_BUDGET
+    return len(set(devices)) == 1 and cells * bytes_per_cell > hbm_budget(list(devices)[0] if devices else 0)
 
 
 class _StreamedBlock(_SeedGate):

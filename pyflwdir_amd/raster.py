@@ -56,6 +56,9 @@ _PAYLOAD = {np.dtype(np.int32): _hip.PFD_I32, np.dtype(np.int64): _hip.PFD_I64,
             np.dtype(np.float32): _hip.PFD_F32, np.dtype(np.float64): _hip.PFD_F64}
 
 
+_INFER_ON_DEVICE_MIN = 1 << 24  # cells from which ftype="infer" asks the device whether a uint8 raster is D8
+
+
 def _get_idxs_dtype(n):
     """Smallest index dtype for ``n`` cells; reference pyflwdir/pyflwdir.py:105-127."""
     if n < 2147483647:
@@ -171,6 +174,16 @@ def from_array(data, ftype="infer", check_ftype=True, mask=None, transform=gis.I
     Same signature and checks as the reference's ``from_array`` (pyflwdir/pyflwdir.py:130-205).
     ``ftype="d8"`` and ``"ldd"`` (or ``"infer"`` on either) run on the GPU path."""
     if ftype == "infer":
+        if (isinstance(data, np.ndarray) and data.dtype == np.uint8 and data.ndim == 2 and mask is None
+                and data.size >= _INFER_ON_DEVICE_MIN):
+            # large uint8 rasters: "is it D8" is answered by the device pass that builds the graph anyway
+            try:
+                flw = FlwdirRaster._from_d8(np.ascontiguousarray(data), transform=transform, latlon=latlon, **kwargs)
+                flw.ftype = "d8"
+                return flw
+            except ValueError as exc:
+                if "not D8 codes" not in str(exc):
+                    raise
         ftype = _infer_ftype(data)
         check_ftype = False
     if ftype not in FTYPES:
@@ -194,6 +207,17 @@ def from_array(data, ftype="infer", check_ftype=True, mask=None, transform=gis.I
     data = np.asarray(data)
     if data.ndim != 2:
         raise ValueError("The FlwdirRaster should be 2 dimensional")
+    if ftype == "d8" and check_ftype and mask is None and data.dtype == np.uint8 and data.size >= _INFER_ON_DEVICE_MIN:
+        # (small rasters keep the host check: argument errors before any device call)  The alphabet check of core_d8.isvalid rides the device's first pass over the raster (k_normalise counts the
+        # bytes that are no D8 value) instead of a host pass of its own: 3 s of numpy at 8.1 Gcells
+        try:
+            flw = FlwdirRaster._from_d8(np.ascontiguousarray(data), transform=transform, latlon=latlon, **kwargs)
+        except ValueError as exc:
+            if "not D8 codes" in str(exc):
+                raise ValueError(f'The flow direction data with type "{ftype}" is invalid.') from None
+            raise
+        flw.ftype = ftype
+        return flw
     if check_ftype and not (d8_isvalid(data) if ftype == "d8" else ldd_isvalid(data)):
         raise ValueError(f'The flow direction data with type "{ftype}" is invalid.')
     if ftype == "ldd":  # same graph, other labels (core_ldd.from_array, reference pyflwdir/core_ldd.py:41-66)

@@ -27,6 +27,14 @@ def shim():
     return SHIM
 
 
+def _free_port():
+    """A port nobody listens on right now (bench.py's own helper: two suites on one box cannot collide on a fixed number)."""
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    import bench
+
+    return bench.free_port()
+
+
 def _clean_env():
     return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "PFD_DIST_TRANSPORT")}
 
@@ -37,8 +45,9 @@ def test_every_collective_through_the_rccl_branches(gpu_lib, shim, world):
     accuflux / stream_distance / Strahler (pfd_comm_exchange_rows) of `world` row blocks, all against the oracle on the
     whole raster; no boundary row may travel through the host group."""
     procs = []
+    port = _free_port()
     for r in range(world):
-        e = dict(_clean_env(), RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + world),
+        e = dict(_clean_env(), RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                  HSA_ENABLE_IPC_MODE_LEGACY="0", PFD_DIST_TRANSPORT="rccl", LD_PRELOAD=shim, PFD_LOOPBACK_TIMEOUT_S="180")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "dist_check.py")], env=e,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -56,8 +65,9 @@ def test_a_stage_that_falls_short_is_redone_by_every_rank(gpu_lib, shim, knob):
     ranks, results against the oracle (tools/dist_check.py)."""
     world = 3
     procs = []
+    port = _free_port()
     for r in range(world):
-        e = dict(_clean_env(), RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29871",
+        e = dict(_clean_env(), RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                  HSA_ENABLE_IPC_MODE_LEGACY="0", PFD_DIST_TRANSPORT="rccl", LD_PRELOAD=shim, PFD_LOOPBACK_TIMEOUT_S="180",
                  PFD_ENABLE_KNOBS="1", DIST_CHECK_ONLY="upstream_area", DIST_CHECK_SHAPE="6400x4300")  # (3 x 3 hypertiles per block)
         e[knob] = "100" if knob == "PFD_TEST_HCAP" else "1"
