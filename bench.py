@@ -560,10 +560,51 @@ def km2_line(nrow, ncol, synth, label, steps, device):
                 roofline_first_call=dict(bound="hbm", achieved=round(fa, 2), peak=PEAK_HBM_GBS, unit="GB/s",
                                          frac=round(fa / PEAK_HBM_GBS, 5), alg_bytes_per_cell=b_alg,
                                          note="first call on a fresh handle: plan build + sweep"))
+    # the opt-in tolerance mode (raster.py upstream_area(unit, exact=False); csrc/wide.h): the same areas in 64-bit fixed
+    # point on the tiled engine — order-free, no plan.  First call on a fresh DEFERRED handle (decode + validation inside),
+    # warm call, and the largest relative distance to the exact result on the first / last 1500 rows (the main stems end
+    # in the last rows: the largest sums of the raster)
+    lines = [line]
+    band = min(1500, nrow)
+    ex_top, ex_bot = out.download(np.float64, (band, ncol)), out.download(np.float64, (band, ncol), (nrow - band) * ncol * 8)
+    hf = _hip.RasterHandle(d8_buf, nrow, ncol, device=device, memspace=_hip.PFD_DEVICE, deferred=True)
+    _hip.check(_hip.lib().pfd_device_synchronize(device))
+    t0 = time.perf_counter()
+    got, quantum = hf.upstream_area_rows_fixed(rows, out=out, memspace=_hip.PFD_DEVICE)
+    first_f = (time.perf_counter() - t0) * 1e3
+    if got is not None:
+        perf = []
+        hf.set_profiling(True)
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            hf.upstream_area_rows_fixed(rows, out=out, memspace=_hip.PFD_DEVICE)
+            perf.append((time.perf_counter() - t1) * 1e3)
+        segs_f = hf.last_timing()
+        msf = statistics.median(perf)
+        rel = 0.0
+        for ex, off in ((ex_top, 0), (ex_bot, (nrow - band) * ncol * 8)):
+            g = out.download(np.float64, (band, ncol), off)
+            v = ex != -9999.0
+            assert np.array_equal(g[~v], ex[~v])
+            rel = max(rel, float(np.max(np.abs(g[v] - ex[v]) / ex[v], initial=0.0)))
+        achf, faf = b_alg * n / (msf * 1e-3) / 1e9, b_alg * n / (first_f * 1e-3) / 1e9
+        lines.append(dict(op="upstream_area_km2(lat/lon grid, float64), exact=False", workload=f"{label}, the opt-in tolerance mode: row areas "
+                          "in 64-bit fixed point accumulated as integers on the LDS-tiled engine (pfd_upstream_area_rows_fixed): "
+                          "order-free, no plan; first call on a fresh deferred handle and warm call", dtype="u64 fixed point -> f64",
+                          ms_per_call=round(msf, 3), ms_per_call_min=round(min(perf), 3), value=round(n / msf / 1e3, 2), unit="Mcells/s",
+                          first_call_on_handle_ms=round(first_f, 2), quantum_km2=quantum,
+                          max_rel_diff_to_exact_sampled=rel, within_1e_9=bool(rel <= 1e-9),
+                          roofline=dict(bound="hbm", achieved=round(achf, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                        frac=round(achf / PEAK_HBM_GBS, 5), traffic=None, frac_measured=None,
+                                        alg_bytes_per_cell=b_alg, phases_ms={s_["name"]: round(s_["ms"], 3) for s_ in segs_f}),
+                          roofline_first_call=dict(bound="hbm", achieved=round(faf, 2), peak=PEAK_HBM_GBS, unit="GB/s",
+                                                   frac=round(faf / PEAK_HBM_GBS, 5), alg_bytes_per_cell=b_alg,
+                                                   note="first call on a fresh deferred handle: no plan to build")))
+    hf.close()
     h.close()
     d8_buf.free()
     out.free()
-    return [line]
+    return lines
 
 
 N1_RECORD = os.path.join(ROOT, ".bench_n1.json")  # (git-ignored scratch: lets the N > 1 lines quote their speed-up)
@@ -1088,6 +1129,9 @@ def compact_row(line, tag):
                frac=roof.get("frac"), frac_measured=roof.get("frac_measured"), B_cell_model=roof.get("alg_bytes_per_cell"))
     if roof.get("traffic") and line.get("value") and ms:
         row["B_cell_measured"] = round(roof["traffic"] / (line["value"] * 1e3 * ms), 2)
+    if "quantum_km2" in line:  # the opt-in tolerance mode of upstream_area(unit): told apart from the exact row
+        row["mode"] = "exact=False: 64-bit fixed point, order-free"
+        row["max_rel_diff_to_exact"] = line["max_rel_diff_to_exact_sampled"]
     if "first_call_on_handle_ms" in line:
         row["first_call_ms"] = line["first_call_on_handle_ms"]
         row["frac_first_call"] = line["roofline_first_call"]["frac"]

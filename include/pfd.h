@@ -199,6 +199,19 @@ int pfd_accuflux(pfd_raster *h, int dtype, const void *data, int64_t nodata_i, d
  * gis_utils.area_grid, gis_utils.py:388-402 — so no n-element input has to exist or travel). */
 int pfd_accuflux_rows(pfd_raster *h, int dtype, const void *row_values, int64_t nodata_i, double nodata_f,
                       int has_nodata, int direction, int mask_invalid, void *out, int memspace);
+/* OPT-IN, tolerance mode of FlwdirRaster.upstream_area(unit != "cell") on lat/lon grids (reference
+ * pyflwdir/pyflwdir.py:770-801: a float64 accumulation of cell areas): `row_values` is a HOST pointer to nrow float64
+ * areas, `out` receives n float64 sums, -9999 on nodata cells.  The areas are quantised to 64-bit fixed point (the
+ * largest power-of-two scale that keeps the raster's total below 2^64; *quantum, if given, receives one unit of it) and
+ * accumulated as integers on the LDS-tiled engine of pfd_upstream_area_cell (a cell gets the integer part of its row's
+ * scaled area plus its Bresenham share of the fraction, so that any run of consecutive cells of a row is off by less than
+ * one quantum): the result does not depend on any execution order, every value is the exact sum of the quantised areas,
+ * |error| < upstream cells x quantum in the worst case (relative: <= n_cells / 2^63 x mean / min area, 1.3e-10 at
+ * 30000^2, reached at cells with a handful of upstream cells) plus one float64 rounding — NOT bit-identical to the reference's
+ * serial float64 sum (pfd_accuflux_rows is).  *used = 0: not taken (cycles, row block, general graph, a value that is not
+ * finite and positive, a supertile the 64-bit LDS form cannot hold); `out` is then undefined, call pfd_accuflux_rows. */
+int pfd_upstream_area_rows_fixed(pfd_raster *h, const double *row_values, double *out, int memspace, int *used,
+                                 double *quantum);
 /* streams.strahler_order (reference pyflwdir/streams.py:228-269); mask uint8 or NULL. */
 int pfd_strahler(pfd_raster *h, const uint8_t *mask, uint8_t *out, int memspace);
 /* basins.basins + core.fillnodata_upstream (reference pyflwdir/basins.py:12-18,

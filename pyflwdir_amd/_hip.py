@@ -41,7 +41,7 @@ SYMBOLS = [
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
     "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic", "pfd_set_block_update",
     "pfd_reserve", "pfd_alloc_stats", "pfd_mem_info", "pfd_transfer_stats", "pfd_count_nonfinite", "pfd_floodplains_block", "pfd_trib_info_block",
-    "pfd_stream_order_classic_block",
+    "pfd_stream_order_classic_block", "pfd_upstream_area_rows_fixed",
 ]
 
 _lib = None
@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
                                    C.c_int, C.c_void_p, C.c_int]
         L.pfd_accuflux_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p, C.c_int]
+        L.pfd_upstream_area_rows_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                                   C.POINTER(C.c_double)]
         L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -464,6 +466,18 @@ class RasterHandle:
         check(lib().pfd_accuflux_rows(self._h, dtype_code, ptr(row_values), int(nodata_i), float(nodata_f),
                                       int(has_nodata), direction, int(mask_invalid), ptr(out), memspace))
         return out
+
+    def upstream_area_rows_fixed(self, row_values, out=None, memspace=PFD_HOST):
+        """Order-free upstream sums of one float64 value per row in 64-bit fixed point (pfd_upstream_area_rows_fixed).
+        Returns (out, quantum), or (None, 0.0) when the library did not take the call (the caller runs accuflux_rows)."""
+        row_values = np.ascontiguousarray(row_values, dtype=np.float64)
+        assert row_values.size == self.nrow
+        if memspace == PFD_HOST:
+            out = np.empty(self.n, np.float64)
+        used, quantum = C.c_int(0), C.c_double(0.0)
+        check(lib().pfd_upstream_area_rows_fixed(self._h, ptr(row_values), ptr(out), memspace, C.byref(used),
+                                                 C.byref(quantum)))
+        return (out, quantum.value) if used.value else (None, 0.0)
 
     def strahler(self, mask=None, out=None, memspace=PFD_HOST):
         if memspace == PFD_HOST:

@@ -1800,3 +1800,5 @@ int pfd_upstream_area_cell_tiled(pfd_raster *h, i32 *out_dev, int *complete, con
   if (*complete && !run.is_block) h->acyclic = 1;  // every valid cell was finalised: no cycles
   return PFD_OK;
 }
+
+#include "wide.h"

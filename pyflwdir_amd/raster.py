@@ -559,10 +559,19 @@ class FlwdirRaster(object):
         return gis.idxs_to_coords(idxs, self.transform, self.shape, **kwargs)
 
     # -- the hot path -------------------------------------------------------------------------
-    def upstream_area(self, unit="cell"):
+    def upstream_area(self, unit="cell", exact=True):
         """Upstream area map; reference pyflwdir/pyflwdir.py:770-801.  ``unit="cell"`` returns the
         int32 upstream cell count; other units accumulate the cell-area grid (float64 for
-        lat/lon grids, float32 for projected ones).  -9999 on nodata cells."""
+        lat/lon grids, float32 for projected ones).  -9999 on nodata cells.
+
+        ``exact`` (not in the reference; default True = bit-identical to its serial sums).  ``exact=False`` is an
+        opt-in tolerance mode for the float64 sums of lat/lon grids only: the row areas are quantised to 64-bit fixed
+        point and accumulated as integers on the tiled engine of ``unit="cell"`` (csrc/wide.h) — independent of any
+        execution order, within n_cells / 2**63 relative of the real-number sum (1.3e-10 at 30000 x 30000), and several
+        times faster on a fresh raster because it needs no ordering plan.  It is never offered for float32 sums
+        (projected grids): a sequential float32 sum drifts from the real-number sum by more than the 1e-6 this path
+        promises, so only the exact order reproduces it.  Whatever the fast form cannot take (cycles, rasters beyond
+        2**32 - 2 cells) is answered by the exact form."""
         unit = str(unit).lower()
         if unit not in gis.AREA_FACTORS:
             fstr = '", "'.join(gis.AREA_FACTORS.keys())
@@ -574,6 +583,11 @@ class FlwdirRaster(object):
         rows = np.ascontiguousarray(gis.area_rows(self.transform, self.shape, self.latlon, unit="m2")
                                     / gis.AREA_FACTORS[unit])
         nb = self._row_blocks_needed()
+        if not exact and nb == 1 and rows.dtype == np.float64:
+            out, quantum = self._h.upstream_area_rows_fixed(rows)
+            if out is not None:
+                self._last_quantum = quantum  # (one unit of the fixed-point scale, in the unit asked for)
+                return out.reshape(self.shape)
         if nb > 1:  # beyond 32-bit cell indices: seeded row blocks (pyflwdir_amd/dist.py), bit-identical
             from . import dist
 
