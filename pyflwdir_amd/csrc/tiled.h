@@ -328,6 +328,10 @@ struct TiledRun {
   u32 nst = 0, nstc = 0, nsuper = 0, nht = 0, nhtc = 0, nhyper = 0;
   DevBuf sbbuf, l3, l4, hcntbuf, tcntbuf, iface_buf, stampbuf, soverbuf, rcntbuf, xmaskbuf, xlbuf, scountbuf, flaggedbuf, xcbbuf;
   bool fused_norm = false;  // this run's first tile pass normalises a deferred handle
+#ifndef PFD_PATCH_DEFAULT
+#define PFD_PATCH_DEFAULT 0
+#endif
+  bool use_patch = PFD_PATCH_DEFAULT != 0;  // local pass of the interior tiles: k_tile_local_patch (tile_patch.h) instead of k_tile_local_fast
   int rounds4 = 0, extra_rounds = 0;  // level-4 rounds issued without a host check / added after a miss
   bool short_of_rounds = false;
   u32 *xT = nullptr, *xrec = nullptr, *xtot = nullptr, *sxidL = nullptr, *sx_slot = nullptr,

@@ -540,6 +540,7 @@ __global__ void __launch_bounds__(256) k_tile(TileArgs a) {
 #define FY_NT 256  // threads of the final pass of an interior tile (tile_fast.h; 512 = 8 waves per tile was measured: 20.5 vs 17.6 ms — tiles in flight per CU count, not waves)
 #endif
 #include "tile_fast.h"
+#include "tile_patch.h"
 
 // per-tile counts of a raw pass -> the counters k_normalise would have left in ctrl
 __global__ void __launch_bounds__(1024) k_tile_counts(const u64 *__restrict__ tcnt, u32 ntiles, u64 *ctrl) {
@@ -1416,6 +1417,7 @@ int TiledRun::init(pfd_raster *hh, i32 *out_dev) {
   if (const char *e = pfd_knob("PFD_TEST_HCAP")) sa.hcap = (u32)std::min(atoi(e), HCAP);
   if (const char *e = pfd_knob("PFD_TEST_SCAP")) sa.scap = (u32)std::min<u32>((u32)atoi(e), SCAP);
   if (const char *e = pfd_knob("PFD_SUPER_ABLATE")) sa.ablate = atoi(e);
+  if (const char *e = pfd_knob("PFD_TILE_PATCH")) use_patch = atoi(e) != 0;
   a.stamps = nullptr;
 #ifdef PFD_DEVTOOLS
   if (const char *e = getenv("PFD_TILE_ABLATE")) a.ablate = atoi(e);
@@ -1604,6 +1606,7 @@ int TiledRun::phase_a() {
     a.tcnt = tcntbuf.as<u64>();
     if (have_i) {
       if (a.weights) k_tile_local_fast<true, true><<<gridi, 256, 0, h->stream>>>(a);
+      else if (use_patch) k_tile_local_patch<true><<<gridi, 256, 0, h->stream>>>(a);
       else k_tile_local_fast<true, false><<<gridi, 256, 0, h->stream>>>(a);
       pfd_seg_end(h, 1);
       pfd_seg_begin(h, "tile_local_frame");
@@ -1619,6 +1622,7 @@ int TiledRun::phase_a() {
   } else {
     if (have_i) {
       if (a.weights) k_tile_local_fast<false, true><<<gridi, 256, 0, h->stream>>>(a);
+      else if (use_patch) k_tile_local_patch<false><<<gridi, 256, 0, h->stream>>>(a);
       else k_tile_local_fast<false, false><<<gridi, 256, 0, h->stream>>>(a);
       pfd_seg_end(h, 1);
       pfd_seg_begin(h, "tile_local_frame");
