@@ -161,8 +161,9 @@ int pfd_order_cells(pfd_raster *h);
 /* core.idxs_seq (reference pyflwdir/core.py:87-117): the exact breadth-first order of the
  * reference (pits ascending, then each dequeued cell's upstream cells ascending); out has
  * n_seq entries.  A raster beyond 2^32 - 2 cells (the int64 rung of pyflwdir.py:105-127) takes idx_dtype PFD_I64
- * only and must be acyclic (PFD_EUNSUPPORTED otherwise): n_valid entries, built without the level structure from the
- * tiled rank query and a level-by-level expansion with 64-bit queue entries (csrc/order64.hip). */
+ * only: built without the level structure from the tiled rank query and a level-by-level expansion with 64-bit queue
+ * entries (csrc/order64.hip); `out` must hold n_valid entries, n_seq of them are written (pfd_raster_info afterwards) —
+ * cells that never reach a pit are left out, found by a walk from the pits with one host look per level. */
 int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace);
 /* General idxs_ds graphs only: install the cell sequence the sweeps follow.  Flwdir.order_cells("sort")
  * (reference pyflwdir/flwdir.py:231-245; the only ordering of NEXTXY rasters, pyflwdir.py:292-297) sorts the
@@ -173,8 +174,8 @@ int pfd_idxs_seq(pfd_raster *h, int idx_dtype, void *out, int memspace);
  * pfd_add_pits forgets it as well (it describes the graph before the edit). */
 int pfd_set_idxs_seq(pfd_raster *h, int idx_dtype, const void *seq, int64_t n_seq);
 /* core.rank (reference pyflwdir/core.py:17-47): int32 distance to the pit, -1 for cells that
- * do not drain to a pit, -9999 on nodata.  Beyond 2^32 - 2 cells: the tiled rank query, acyclic rasters only
- * (a raster with cells that never reach a pit is refused with PFD_EUNSUPPORTED instead of marked). */
+ * do not drain to a pit, -9999 on nodata.  Beyond 2^32 - 2 cells: the tiled rank query; a raster with cells that never
+ * reach a pit is walked from its pits instead (slower: a host look per level), so that those cells read -1. */
 int pfd_rank(pfd_raster *h, int32_t *out, int memspace);
 
 /* ---- sweeps ---------------------------------------------------------------------------- */

@@ -408,9 +408,9 @@ class RasterHandle:
 
     def idxs_seq(self, dtype) -> np.ndarray:
         if self.wide_cells() and not self.is_general:
-            out = np.empty(self.info(counts=True)["n_valid"], np.int64)  # (acyclic, or the call raises)
-            check(lib().pfd_idxs_seq(self._h, PFD_I64, ptr(out), PFD_HOST))
-            return out.astype(dtype, copy=False)
+            out = np.empty(self.info(counts=True)["n_valid"], np.int64)  # (room for every valid cell; cells that never
+            check(lib().pfd_idxs_seq(self._h, PFD_I64, ptr(out), PFD_HOST))  # reach a pit are left out: n_seq entries)
+            return out[: self.info()["n_seq"]].astype(dtype, copy=False)
         self.order_cells()
         out = np.empty(self.info()["n_seq"], dtype)
         check(lib().pfd_idxs_seq(self._h, IDX_CODE[np.dtype(dtype)], ptr(out), PFD_HOST))

@@ -776,7 +776,7 @@ extern "C" int pfd_raster_info(pfd_raster *h, int64_t info[8]) {
   info[1] = h->ncol;
   info[2] = h->n_valid;
   info[3] = h->n_pits;
-  info[4] = h->ordered ? h->n_seq : -1;
+  info[4] = (h->ordered || (pfd_wide_cells(h) && h->n_seq >= 0)) ? h->n_seq : -1;  // (64-bit forms: set by rank / idxs_seq, order64.hip)
   info[5] = h->ordered ? h->n_levels : -1;
   info[6] = h->device;
   info[7] = (int64_t)h->bytes_held;

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_rank_hist(u32 *__restrict__ v, u64 n, u
   }
 }
 
-__global__ void __launch_bounds__(1024) k_scan_u64_1block(u64 *__restrict__ v, u64 m) {  // in place, exclusive
+__global__ void __launch_bounds__(1024) k_scan_u64_1block(u64 *__restrict__ v, u64 m, u64 *__restrict__ total_out = nullptr) {  // in place, exclusive
   __shared__ u64 wsum[16];
   __shared__ u64 carry;
   if (threadIdx.x == 0) carry = 0;
@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(1024) k_scan_u64_1block(u64 *__restrict__ v, u
     if (threadIdx.x == 0) carry += total;
     __syncthreads();
   }
+  if (total_out && threadIdx.x == 0) *total_out = carry;
 }
 
 // ---- level 0: the pits in ascending index order ------------------------------------------------------------------
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(1024) k_wseq_small(const u8 *__restrict__ ncod
 }
 
 // ranks of every cell (u32, 0xFFFFFFFF on nodata) through the tiled path query
-int wide_ranks(pfd_raster *h, DevBuf &keys, u32 *maxrank, const char *what) {
+int wide_ranks(pfd_raster *h, DevBuf &keys, u32 *maxrank, const char *what, bool *cyclic) {
   PFDCHK(pfd_reject_general(h, what));
   if (h->halo_top || h->halo_bot) {
     pfd_set_error("%s is not available on a row-block handle", what);
@@ -214,13 +215,61 @@ int wide_ranks(pfd_raster *h, DevBuf &keys, u32 *maxrank, const char *what) {
   pfd_seg_begin(h, "tile_rank");
   PFDCHK(pfd_path_rank_max(h, keys.as<u32>(), &complete, maxrank));
   pfd_seg_end(h, 2);
-  if (!complete) {
-    // (the reference marks cells that never reach a pit with rank -1 and leaves them out of idxs_seq; beyond 2^32 - 2
-    //  cells only the tiled query is left to find them, and it stops at "there are some")
-    pfd_set_error("%s: the raster of %lld cells holds cells that never reach a pit (cycles), or is beyond the slot ids of the "
-                  "tiled rank query; with 64-bit cell indices only valid (acyclic) rasters are ordered", what, (long long)h->n);
-    return PFD_EUNSUPPORTED;
+  *cyclic = !complete;  // (cells that never reach a pit, or a raster beyond the slot ids of the tiled query: wide_bfs)
+  return PFD_OK;
+}
+
+// ranks of a queue level -> the rank raster
+__global__ void __launch_bounds__(256) k_wrank_init(const u8 *__restrict__ ncode, u64 n, i32 *__restrict__ rank) {
+  for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) rank[i] = ncode[i] == D8_MV ? -9999 : -1;
+}
+__global__ void __launch_bounds__(256) k_wrank_level(const u64 *__restrict__ q, u64 begin, u64 end, i32 *__restrict__ rank, i32 level) {
+  for (u64 j = begin + (u64)blockIdx.x * 256u + threadIdx.x; j < end; j += (u64)gridDim.x * 256u) rank[q[j]] = level;
+}
+
+// The reference's own walk for rasters the rank query cannot finish: cells on or upstream of a cycle never reach a pit,
+// core.rank marks them -1 and core.idxs_seq leaves them out (pyflwdir/core.py:17-47, :87-117) — which is what a
+// breadth-first expansion FROM THE PITS does by construction.  Level sizes are not known up front here (no rank
+// histogram), so the host reads one number per level: 4 launches + a synchronisation per level, ~6 s for 10^5 levels —
+// the price of a raster that is both cyclic and beyond 32-bit cell indices.  `rank_dev` (optional): -9999 / -1 / level.
+int wide_bfs(pfd_raster *h, i32 *rank_dev, DevBuf &q, u64 *nseq) {
+  const u64 n = (u64)h->n;
+  const Shape g{(u64)h->nrow, (u64)h->ncol};
+  const u64 cap = (u64)std::max<i64>(h->n_valid, 1);
+  PFDCHK(q.alloc((size_t)cap * sizeof(u64)));
+  const u64 npc = (n + PITC - 1) / PITC;
+  DevBuf sums;
+  PFDCHK(sums.alloc((size_t)(std::max<u64>((cap + W_CHUNK - 1) / W_CHUNK, npc) + 2) * sizeof(u64)));
+  pfd_seg_begin(h, "idxs_seq_walk_from_pits");
+  if (rank_dev) k_wrank_init<<<4096, 256, 0, h->stream>>>(h->ncode, n, rank_dev);
+  k_pit_count64<<<(u32)npc, 256, 0, h->stream>>>(h->ncode, n, sums.as<u64>());
+  k_scan_u64_1block<<<1, 1024, 0, h->stream>>>(sums.as<u64>(), npc);
+  k_pit_scatter64<<<(u32)npc, 256, 0, h->stream>>>(h->ncode, n, sums.as<u64>(), q.as<u64>());
+  KCHK();
+  i64 launches = 4;
+  u64 begin = 0, end = (u64)h->n_pits;
+  for (i32 level = 0; end > begin; ++level) {
+    const u64 m = end - begin, nchunk = (m + W_CHUNK - 1) / W_CHUNK;
+    if (rank_dev) k_wrank_level<<<(u32)std::min<u64>((m + 255) / 256, 4096), 256, 0, h->stream>>>(q.as<u64>(), begin, end, rank_dev, level);
+    k_wseq_count<<<(u32)nchunk, 256, 0, h->stream>>>(h->ncode, g, q.as<u64>(), begin, end, sums.as<u64>());
+    k_scan_u64_1block<<<1, 1024, 0, h->stream>>>(sums.as<u64>(), nchunk, sums.as<u64>() + nchunk);
+    u64 total = 0;
+    HIPCHK(hipMemcpyAsync(&total, sums.as<u64>() + nchunk, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    launches += 3;
+    if (end + total > cap) {
+      pfd_set_error("idxs_seq: the walk from the pits found more cells than the raster has valid ones");
+      return PFD_EHIP;
+    }
+    if (total) {
+      k_wseq_scatter<<<(u32)nchunk, 256, 0, h->stream>>>(h->ncode, g, q.as<u64>(), begin, end, sums.as<u64>());
+      ++launches;
+    }
+    begin = end, end += total;
   }
+  KCHK();
+  pfd_seg_end(h, launches);
+  *nseq = end;
   return PFD_OK;
 }
 
@@ -230,10 +279,19 @@ int wide_ranks(pfd_raster *h, DevBuf &keys, u32 *maxrank, const char *what) {
 int pfd_rank_wide(pfd_raster *h, i32 *out, int memspace) {
   DevBuf keys;
   u32 maxrank = 0;
+  bool cyclic = false;
   pfd_seg_clear(h);
-  PFDCHK(wide_ranks(h, keys, &maxrank, "rank"));
-  k_rank_hist<<<4096, 256, 0, h->stream>>>(keys.as<u32>(), (u64)h->n, 0u, nullptr, true);
-  KCHK();
+  PFDCHK(wide_ranks(h, keys, &maxrank, "rank", &cyclic));
+  if (cyclic) {  // cells that never reach a pit: the walk from the pits marks them -1 like the reference
+    DevBuf q;
+    u64 nseq = 0;
+    PFDCHK(wide_bfs(h, keys.as<i32>(), q, &nseq));
+    h->n_seq = (i64)nseq;
+  } else {
+    k_rank_hist<<<4096, 256, 0, h->stream>>>(keys.as<u32>(), (u64)h->n, 0u, nullptr, true);
+    KCHK();
+    h->n_seq = h->n_valid;
+  }
   HIPCHK(hipMemcpyAsync(out, keys.p, (size_t)h->n * sizeof(i32), memspace == PFD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                         h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -250,9 +308,11 @@ int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   u32 maxrank = 0;
   const u64 n = (u64)h->n;
   std::vector<unsigned long long> cnt;
+  bool cyclic = false;
   {
     DevBuf keys, hist;
-    PFDCHK(wide_ranks(h, keys, &maxrank, "idxs_seq"));
+    PFDCHK(wide_ranks(h, keys, &maxrank, "idxs_seq", &cyclic));
+    if (cyclic) maxrank = 0;
     const u32 nlev = maxrank + 1u;
     PFDCHK(hist.alloc((size_t)nlev * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(hist.p, 0, (size_t)nlev * sizeof(unsigned long long), h->stream));
@@ -262,6 +322,18 @@ int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace) {
     HIPCHK(hipMemcpyAsync(cnt.data(), hist.p, (size_t)nlev * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }  // (the ranks are released: the queue below is twice their size)
+  if (cyclic) {  // the reference's sequence leaves the cells that never reach a pit out: n_seq < n_valid entries (h->n_seq)
+    DevBuf q;
+    u64 nseq = 0;
+    PFDCHK(wide_bfs(h, nullptr, q, &nseq));
+    h->n_seq = (i64)nseq;
+    if (nseq)
+      HIPCHK(hipMemcpyAsync(out, q.p, (size_t)nseq * sizeof(u64), memspace == PFD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                            h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return PFD_OK;
+  }
+  h->n_seq = h->n_valid;
   const u32 nlev = maxrank + 1u;
   std::vector<u64> off(nlev + 1, 0);
   for (u32 l = 0; l < nlev; ++l) off[l + 1] = off[l] + cnt[l];

@@ -406,10 +406,10 @@ class FlwdirRaster(object):
     @property
     def nnodes(self):
         if self._nnodes is None:
-            if self._wide():  # (64-bit cell indices: no level structure; an acyclic raster orders every valid cell)
-                if not self.isvalid:
-                    raise NotImplementedError("nnodes: the raster holds a cycle and is too large for the level ordering")
-                self._nnodes = self._h.info(counts=True)["n_valid"]
+            if self._wide():  # (64-bit cell indices: no level structure; an acyclic raster orders every valid cell,
+                # a cyclic one the cells its rank raster does not mark -1)
+                self._nnodes = (self._h.info(counts=True)["n_valid"] if self.isvalid
+                                else int(np.count_nonzero(self._h.rank() >= 0)))
             else:
                 self._h.order_cells()
                 self._nnodes = self._h.info()["n_seq"]
@@ -440,7 +440,7 @@ class FlwdirRaster(object):
     def isvalid(self):
         """True if no valid cell is part of (or drains to) a loop."""
         self._cached.pop("rank", None)
-        if self._wide():  # (the 64-bit rank refuses a cyclic raster instead of marking its cells: ask the rank query itself)
+        if self._wide():  # (ask the tiled rank query itself: no 32 GB rank raster on the host for a yes / no)
             max_rank = self._h.graph_stats()["max_rank"]
             if max_rank == -2:
                 raise NotImplementedError("isvalid: the raster is beyond the tiled rank query (more than 65535 tile rows or "
@@ -485,7 +485,8 @@ class FlwdirRaster(object):
         """Order cells from down- to upstream; reference pyflwdir/flwdir.py:231-250 (default "sort" like the
         reference).  "walk" reproduces the reference's breadth-first order exactly on the GPU; "sort" is the
         reference's own numpy expression over the GPU-computed ranks.  Beyond 2**32 - 2 cells (int64 indices,
-        pyflwdir.py:105-127) ranks and the breadth-first order come from csrc/order64.hip, for valid (acyclic) rasters."""
+        pyflwdir.py:105-127) ranks and the breadth-first order come from csrc/order64.hip (cells that never reach a pit:
+        rank -1, left out of the sequence — a walk from the pits, like the reference's)."""
         if method == "walk":
             if self._d8 is None:  # general graph: an installed "sort" order must not pose as the breadth-first one
                 self._h.clear_idxs_seq()

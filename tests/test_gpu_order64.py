@@ -37,13 +37,14 @@ def test_golden_cases_through_the_64_bit_form(name, small, manifest, wide):
     flw = pyflwdir.from_array(case.d8, ftype="d8", cache=False)
     assert flw._wide()
     if st["n_loop_cells"]:
-        # the reference marks the cells of a cycle with rank -1 and leaves them out of the sequence; with 64-bit indices
-        # only valid rasters are ordered, and the refusal says so
+        # the reference marks the cells of a cycle (and everything draining to it) with rank -1 and leaves them out of the
+        # sequence (core.py:17-47, :87-117); the 64-bit form walks from the pits like it does
         assert not flw.isvalid
-        with pytest.raises(NotImplementedError, match="never reach a pit"):
-            flw.rank
-        with pytest.raises(NotImplementedError, match="never reach a pit"):
-            flw.idxs_seq
+        case.check("rank", flw.rank.ravel())
+        assert int(np.count_nonzero(flw.rank == -1)) == st["n_loop_cells"]
+        case.check("idxs_seq_int32", flw.idxs_seq)
+        assert flw.idxs_seq.size == st["n_seq"] == st["n_valid"] - st["n_loop_cells"]
+        assert flw.nnodes == st["n_seq"]
         return
     assert flw.isvalid
     case.check("rank", flw.rank.ravel())
@@ -87,3 +88,106 @@ def test_int64_is_the_only_index_dtype_of_the_c_entry(gpu_lib, oracle, wide):
     rc = _hip.lib().pfd_idxs_seq(h._h, _hip.PFD_I32, _hip.ptr(out), _hip.PFD_HOST)
     assert rc == -1 and b"int64" in _hip.lib().pfd_last_error()  # PFD_EINVAL
     h.close()
+
+
+def _monotone_windows(seq, rank, nwin=48, wlen=1 << 21):
+    """rank[seq] non-decreasing inside windows spread over the sequence, and from window to window (tests/test_core.py:82;
+    the full gather of 4.4e9 random reads takes a minute on the host: sampled)."""
+    ok, prev = True, -1
+    for w in range(nwin):
+        i = (seq.size - wlen) * w // max(1, nwin - 1) if seq.size > wlen else 0
+        r = rank[seq[i:i + wlen]]
+        ok = ok and int(r[0]) >= prev and bool(np.all(np.diff(r) >= 0))
+        prev = int(r[-1])
+    return ok
+
+
+def test_true_size_beyond_2_32_cells(gpu_lib):
+    """66000 x 66000 = 4.356e9 cells (> 2**32 - 2: the int64 rung of pyflwdir.py:105-127) through the front end at TRUE size —
+    no lowered threshold: rank and the exact idxs_seq order by the properties that define them (core.py:17-47, :87-117,
+    tests/test_core.py:66-82), the classic stream order over row blocks by its local properties (streams.py:191-225), and the
+    same raster with a cycle injected: the cells that never reach a pit read -1 and are left out of the sequence."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd import _hip
+
+    size = 66000
+    _hip.reserve(120 << 30)
+    buf = _hip.synth_d8_device(size, size, seed=0)
+    d8 = buf.download(np.uint8, (size, size))
+    buf.free()
+    n = d8.size
+    assert n > 2**32 - 2
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    assert flw._wide() and flw.idxs_pit.dtype == np.int64
+    rank = flw.rank.ravel()
+    assert rank.dtype == np.int32 and int(rank.min()) == 0  # (no nodata, no cycle)
+    pits = flw.idxs_pit
+    assert np.all(rank[pits] == 0) and int(np.count_nonzero(rank[: 1 << 28] == 0)) == int(np.count_nonzero(pits < (1 << 28)))
+    # rank is the distance to the pit: one more than the downstream cell's, on sampled row windows
+    dr = np.array([0, 1, 1, 1, 0, -1, -1, -1])
+    dc = np.array([1, 1, 0, -1, -1, -1, 0, 1])
+    r2 = rank.reshape(size, size)
+    for r0 in (0, 31000, size - 1001):
+        blk, rk = d8[r0:r0 + 1001], r2[r0:r0 + 1001]
+        for k in range(8):
+            rr, cc = np.nonzero(blk[1:-1, 1:-1] == (1 << k))
+            assert np.all(rk[rr + 1 + dr[k], cc + 1 + dc[k]] + 1 == rk[rr + 1, cc + 1])
+    seq = flw.idxs_seq
+    assert seq.dtype == np.int64 and seq.size == n
+    assert np.array_equal(seq[: pits.size], pits)  # pits first, ascending
+    assert _monotone_windows(seq, rank)
+    # every cell exactly once: the sums of the indices and of their squares (mod 2^64) are those of 0 .. n - 1
+    s1 = s2 = 0
+    for i in range(0, n, 1 << 28):
+        part = seq[i:i + (1 << 28)].view(np.uint64)
+        s1 = (s1 + int(part.sum(dtype=np.uint64))) & (2**64 - 1)
+        s2 = (s2 + int((part * part).sum(dtype=np.uint64))) & (2**64 - 1)
+    assert s1 == (n * (n - 1) // 2) & (2**64 - 1) and s2 == ((n - 1) * n * (2 * n - 1) // 6) & (2**64 - 1)
+    # the upstream cells of a dequeued cell are contiguous and ascending at the queue's own positions (a prefix)
+    j = pits.size
+    for i in range(20000):
+        r, c = divmod(int(seq[i]), size)
+        ch = sorted((r + dr[k]) * size + c + dc[k] for k in range(8)
+                    if 0 <= r + dr[k] < size and 0 <= c + dc[k] < size and d8[r + dr[k], c + dc[k]] == (1 << ((k + 4) & 7)))
+        assert seq[j:j + len(ch)].tolist() == ch
+        j += len(ch)
+    del seq
+    # classic ("Hack") stream order over row blocks (the raster is beyond one handle's 32-bit cell indices; reference
+    # streams.py:191-225): a pit has order 1; a cell has its downstream cell's order, or one more — only where that cell has
+    # more than one upstream cell
+    so = flw.stream_order(type="classic")
+    assert so.dtype == np.uint8 and so.shape == (size, size)
+    assert np.all(so.ravel()[pits] == 1)
+    nup = flw.n_upstream
+    for r0 in (0, 40000, size - 1001):
+        blk, o, nu = d8[r0:r0 + 1001], so[r0:r0 + 1001], nup[r0:r0 + 1001]
+        for k in range(8):
+            rr, cc = np.nonzero(blk[1:-1, 1:-1] == (1 << k))
+            od, ou = o[rr + 1 + dr[k], cc + 1 + dc[k]].astype(int), o[rr + 1, cc + 1].astype(int)
+            nd = nu[rr + 1 + dr[k], cc + 1 + dc[k]]
+            assert np.all((ou == od) | (ou == od + 1)) and np.all(nd[ou > od] > 1) and np.all(ou[nd == 1] == od[nd == 1])
+    del so, nup
+    # ---- the same raster with a cycle: two neighbouring headwater-side cells made to drain into each other ----------
+    r, c = 5, 40000
+    d8[r, c], d8[r, c + 1] = 1, 16  # E and W
+    loop = {r * size + c, r * size + c + 1}
+    todo = list(loop)
+    while todo:  # everything that drains to the cycle (a handful of cells this close to the raster's upper edge)
+        x = todo.pop()
+        rr, cc = divmod(x, size)
+        for k in range(8):
+            a, b = rr + dr[k], cc + dc[k]
+            if 0 <= a < size and 0 <= b < size and d8[a, b] == (1 << ((k + 4) & 7)) and a * size + b not in loop:
+                loop.add(a * size + b)
+                todo.append(a * size + b)
+    assert len(loop) < 10**6
+    flw2 = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    assert not flw2.isvalid
+    rank2 = flw2.rank.ravel()
+    li = np.fromiter(loop, np.int64)
+    assert np.all(rank2[li] == -1) and int(np.count_nonzero(rank2 == -1)) == li.size
+    rank[li] = -1
+    assert np.array_equal(rank2, rank)  # everybody else keeps its distance to its pit
+    seq2 = flw2.idxs_seq
+    assert seq2.size == n - li.size and _monotone_windows(seq2, rank2)
+    assert int(rank2[seq2[:: 4099]].min()) >= 0 and flw2.nnodes == seq2.size
