@@ -5,7 +5,7 @@
 // boundary-row bookkeeping.  That is all but a one-tile frame of a raster (99.7 % of the tiles at 90000 x 90000),
 // so these kernels ARE the tile passes; k_tile (tiled.hip) keeps the general form for the frame.
 //
-// Both passes sit on the VALU (SQ counters, profiles/r02y_sq_counters_tile.csv: 123 and 89 VALU instructions per
+// Both passes sit on the VALU (SQ counters, profiles/archive/r02y_sq_counters_tile.csv: 123 and 89 VALU instructions per
 // cell in round 2, LDS and HBM far from their limits), so everything here is about instructions per cell:
 //  * decode by byte permute: the step of a direction code c = 1 << k inside the tile (dr * 64 + dc) and inside the
 //    staged codes (dr * 72 + dc) are 8-entry byte tables looked up with v_perm_b32 (selector k); "the step stays in
