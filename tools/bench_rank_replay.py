@@ -36,6 +36,10 @@ def rank_main(a):
 
     rank, world = a.rank, a.gpus
     nrow = ncol = a.size
+    if a.stage == "replay" and a.reserve_gib > 0:
+        # one arena for the working buffers, like bench.py's ranks (pfd_reserve): the 13.7 / 6.0 ms steps of
+        # profiles/r05f_rank_replay.txt were hipMalloc calls of a process that had none
+        _hip.reserve(int(a.reserve_gib * 2**30))
     r0, r1 = pdist.block_rows(nrow, world)[rank]
     own = r1 - r0
     top, bot = pdist.halo_of(rank, world)
@@ -72,17 +76,21 @@ def rank_main(a):
     for _ in range(a.warmup):
         step()
     ts = []
+    m0 = _hip.alloc_stats()["hipmalloc_calls"]
     for _ in range(a.steps):
         sync()
         t0 = time.perf_counter()
         step()
         sync()
         ts.append(1e3 * (time.perf_counter() - t0))
+    mallocs = _hip.alloc_stats()["hipmalloc_calls"] - m0
     segs = step(profile=True)
     comm.close()
     ts = np.array(ts)
+    slow = [(int(i), round(float(ts[i]), 3)) for i in np.argsort(ts)[-3:][::-1]]
     print(json.dumps(dict(stage="replay", rank=rank, ms_median=round(float(np.median(ts)), 3), ms_min=round(float(ts.min()), 3),
-                          ms_max=round(float(ts.max()), 3), ms_mean=round(float(ts.mean()), 3),
+                          ms_max=round(float(ts.max()), 3), ms_mean=round(float(ts.mean()), 3), ms_p99=round(float(np.percentile(ts, 99)), 3),
+                          slowest_steps=slow, hipmalloc_calls_timed=int(mallocs), reserved_GiB=a.reserve_gib,
                           segments={s["name"]: round(s["ms"], 3) for s in segs}, checksum=int(_hip.checksum_i32(out, own * ncol)))))
 
 
@@ -94,6 +102,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n1-ms", type=float, default=0.0, help="ms per step of the N = 1 run on this box (bench.py), for the estimate")
     ap.add_argument("--checksum", type=int, default=None, help="result checksum of the N = 1 run")
+    ap.add_argument("--reserve-gib", type=float, default=24.0, help="arena of a replayed rank (0: none, the round-5 state)")
     ap.add_argument("--stage", default=None)
     ap.add_argument("--rank", type=int, default=0)
     a = ap.parse_args()
@@ -104,7 +113,7 @@ def main():
     base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PFD_DIST_TRANSPORT")}
     base.update(LD_PRELOAD=SHIM, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29911")
     common = [sys.executable, os.path.abspath(__file__), "--size", str(a.size), "--gpus", str(a.gpus), "--steps", str(a.steps),
-              "--warmup", str(a.warmup)]
+              "--warmup", str(a.warmup), "--reserve-gib", str(a.reserve_gib)]
     with tempfile.TemporaryDirectory(prefix="pfd_replay_") as d:
         procs = [subprocess.Popen(common + ["--stage", "record", "--rank", str(r)],
                                   env=dict(base, RANK=str(r), WORLD_SIZE=str(a.gpus), PFD_LOOPBACK_RECORD=d),
@@ -126,9 +135,11 @@ def main():
                 raise SystemExit(f"replay of rank {r} failed:\n{out.stderr[-1500:]}")
             rows.append(json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]))
             print(f"rank {r} of {a.gpus} alone on the GPU, ideal transport: median {rows[-1]['ms_median']:.3f} ms "
-                  f"(min {rows[-1]['ms_min']:.3f}, max {rows[-1]['ms_max']:.3f}) per pass; segments {rows[-1]['segments']}")
+                  f"(min {rows[-1]['ms_min']:.3f}, p99 {rows[-1]['ms_p99']:.3f}, max {rows[-1]['ms_max']:.3f}; slowest steps "
+                  f"{rows[-1]['slowest_steps']}; hipMalloc calls while timing {rows[-1]['hipmalloc_calls_timed']}) per pass; "
+                  f"segments {rows[-1]['segments']}")
     worst = max(r["ms_median"] for r in rows)
-    summary = dict(size=a.size, ranks=a.gpus, steps=a.steps, slowest_rank_ms=worst, mean_rank_ms=round(sum(r["ms_median"] for r in rows) / len(rows), 3),
+    summary = dict(size=a.size, ranks=a.gpus, steps=a.steps, reserved_GiB_per_rank=a.reserve_gib, slowest_rank_ms=worst, mean_rank_ms=round(sum(r["ms_median"] for r in rows) / len(rows), 3),
                    max_over_median=round(max(r["ms_max"] / r["ms_median"] for r in rows), 2),
                    checksum=sum(r["checksum"] for r in rows), checksum_equals_record=sum(r["checksum"] for r in rows) == rec["checksum"])
     if a.n1_ms:

@@ -7,5 +7,5 @@ python bench.py --size $SIZE --steps 20 --warmup 3 --no-cpu-baseline --no-second
 MS=$(python -c "import json;print(json.load(open('gpurun_out/${TAG}_n1.json'))['ms_per_step'])")
 CS=$(python -c "import json;print(json.load(open('gpurun_out/${TAG}_n1.json'))['invariants']['result_checksum'])")
 echo "N = 1: $MS ms per step, checksum $CS" > $O
-python tools/bench_rank_replay.py --size $SIZE --gpus $RANKS --steps 20 --n1-ms $MS --checksum $CS >> $O 2>&1
+python tools/bench_rank_replay.py --size $SIZE --gpus $RANKS --steps ${STEPS:-100} --reserve-gib ${RESERVE_GIB:-24} --n1-ms $MS --checksum $CS >> $O 2>&1
 cat $O
