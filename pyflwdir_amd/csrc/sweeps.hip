@@ -367,7 +367,10 @@ __device__ __forceinline__ void load_window5_of(const D &d, const Geo &g, u32 x,
   }
 }
 
-template <class T, class D = CellData<T>>
+// MASKINV (exact-order engine only): the tile pass, which writes every cell of the raster, leaves `nodata` on the raster's
+// nodata cells instead of their payload — FlwdirRaster.upstream_area's `uparea[~mask] = -9999` (pyflwdir.py:800) without a
+// pass of its own over the result (k_mask_invalid: 0.95 ms of 17 at 30000^2 for float64)
+template <class T, class D = CellData<T>, bool MASKINV = false>
 struct AccuUp {
   typedef T V;
   const u8 *ncode;
@@ -424,7 +427,7 @@ struct AccuUp {
     const bool ok = !has_nodata || (acc != nodata && a != nodata);
     return ok ? sum : acc;
   }
-  __device__ __forceinline__ T tile_init(u32 x, bool) const { return data.at(x); }
+  __device__ __forceinline__ T tile_init(u32 x, bool nd) const { return (MASKINV && nd) ? nodata : data.at(x); }
   __device__ __forceinline__ T tile_combine(u32 l, u32 kids, const T *val) const {
     T acc = val[l];
 #pragma unroll
@@ -435,8 +438,14 @@ struct AccuUp {
     return acc;
   }
   __device__ __forceinline__ void tile_store(u32 x, T v) const { out[x] = v; }
-  static constexpr bool NEEDS_NODATA = false;
-  __device__ __forceinline__ void tile_init4(u32 x0, u32, T (&v)[4]) const { data.load4(x0, v); }
+  static constexpr bool NEEDS_NODATA = MASKINV;
+  __device__ __forceinline__ void tile_init4(u32 x0, u32 nd, T (&v)[4]) const {
+    data.load4(x0, v);
+    if (MASKINV) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[b] = (nd & (1u << b)) ? nodata : v[b];
+    }
+  }
   __device__ __forceinline__ void tile_store4(u32 x0, const T (&v)[4]) const { __builtin_memcpy(out + x0, v, 4 * sizeof(T)); }
   // own payload + the light upstream cells that precede the heavy one (slot hs) in the serial loop's order
   __device__ __forceinline__ T pre_real(u32 x, u32 kids, u32 hs) const {
@@ -1049,7 +1058,12 @@ static int accuflux_t(pfd_raster *h, const void *data, bool by_row, T nodata, in
     }
     pfd_seg_end(h, 1);
   }
-  if (direction == PFD_UP && by_row) {
+  if (direction == PFD_UP && by_row && mask_invalid && h->xplan_state == 1) {
+    // upstream_area in area units: the tile pass of the exact-order engine masks the nodata cells itself
+    AccuUp<T, RowData<T>, true> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
+    PFDCHK(run_exact_up(h, op, "exact_accuflux_up"));
+    return o.finish(h->stream);
+  } else if (direction == PFD_UP && by_row) {
     AccuUp<T, RowData<T>> op{h->ncode, h->geo, RowData<T>{(const T *)d.dev, h->geo}, (T *)o.dev, nodata, has_nodata};
     PFDCHK(sweep_up(h, op, "sweep_accuflux_up", "exact_accuflux_up"));
   } else if (direction == PFD_UP) {
