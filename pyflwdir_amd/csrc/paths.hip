@@ -133,23 +133,24 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
     // labels travel with the ROOT (read at the end), so the loop moves pointers only: every value a pointer ever holds
     // is an ancestor of its cell, whoever advanced it when — no barrier between reads and writes, and two jumps per
     // round (4 rounds instead of 6 on a river raster)
+    // (the four gathers of a quad go out together, unconditionally: a load under a per-cell branch is waited for on the
+    //  spot — 8 serialised LDS round trips per quad and round; a cell that has arrived re-reads its root's word, which
+    //  names the root)
     for (int round = 0; round < MAXROUNDS_TILE; ++round) {
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         if (!(live & (0xFu << (4 * j)))) continue;
+        u32 q[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[b] = P[pc[4 * j + b] & 0xFFFu];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q[b] = P[q[b] & 0xFFFu];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          if (live & (1u << (4 * j + b))) {
-            u32 q = P[pc[4 * j + b]];
-            if (!(q & PDONE)) q = P[q];
-            pc[4 * j + b] = q;
-          }
+          pc[4 * j + b] = q[b];
+          if (q[b] & PDONE) live &= ~(1u << (4 * j + b));
         }
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if ((live & (1u << (4 * j + b))) && (pc[4 * j + b] & PDONE)) live &= ~(1u << (4 * j + b));
-        *(uint2 *)&P[4u * tid + 1024u * j] =
-            make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
+        *(uint2 *)&P[4u * tid + 1024u * j] = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
       }
       if (!vote(round)) break;
     }
@@ -158,12 +159,12 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
       u32 q[QPT * 4], dv[QPT * 4];
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
+        if (!(live & (0xFu << (4 * j)))) continue;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (live & (1u << (4 * j + b))) {
-            q[4 * j + b] = P[pc[4 * j + b]];
-            dv[4 * j + b] = V[pc[4 * j + b]];
-          }
+        for (int b = 0; b < 4; ++b) {  // (unconditional inside a live quad; a cell that has arrived is not updated below)
+          const u32 t = pc[4 * j + b] & 0xFFFu;
+          q[4 * j + b] = P[t];
+          dv[4 * j + b] = V[t];
         }
       }
       __syncthreads();  // every read of this round precedes every write of this round
@@ -174,11 +175,10 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
           uint4 v4 = *(const uint4 *)&V[l0];
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            if (live & (1u << (4 * j + b))) {
-              ((u32 *)&v4)[b] += dv[4 * j + b];
-              pc[4 * j + b] = q[4 * j + b];
-              if (q[4 * j + b] & PDONE) live &= ~(1u << (4 * j + b));
-            }
+            const bool lv = (live >> (4 * j + b)) & 1u;
+            ((u32 *)&v4)[b] += lv ? dv[4 * j + b] : 0u;
+            pc[4 * j + b] = lv ? q[4 * j + b] : pc[4 * j + b];
+            if (lv && (q[4 * j + b] & PDONE)) live &= ~(1u << (4 * j + b));
           }
           *(uint4 *)&V[l0] = v4;
           *(uint2 *)&P[l0] = make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
@@ -221,21 +221,25 @@ __global__ void __launch_bounds__(256) k_path(PathArgs a) {
       const i64 gr = r0 + lr, gc0 = c0 + lc0;
       if (gr >= (i64)a.nrow || gc0 >= (i64)a.ncol) continue;
       const u32 c4 = *(const u32 *)&CODE(lr, lc0);
-      u32 o4[4];
+      u32 o4[4], vr[4];
+      const uint4 own4 = *(const uint4 *)&V[l0];  // (rank: the cells' own hops to their roots)
+      const u32 own[4] = {own4.x, own4.y, own4.z, own4.w};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) vr[b] = V[pc[4 * j + b] & 0xFFFu];  // (the pointer registers ARE P[l]: no re-read; all four gathers in flight)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const u32 c = (c4 >> (8 * b)) & 0xFFu;
         const u32 l = l0 + b;
-        const u32 root = P[l] & 0xFFFu;
+        const u32 root = pc[4 * j + b] & 0xFFFu;
         u32 val;
         if (MODE == MODE_RANK) {
           val = KEY_INVALID;
           if (c != D8_MV) {
-            val = V[l] + (root != l ? V[root] : 0u);  // hops to the root + the root's hops from there on
+            val = own[b] + (root != l ? vr[b] : 0u);  // hops to the root + the root's hops from there on
             mx = max(mx, val);
           }
         } else {
-          val = V[root];  // outlet at the end of the in-tile path (the cell's own seed, or what the exit reaches)
+          val = vr[b];  // outlet at the end of the in-tile path (the cell's own seed, or what the exit reaches)
           // (32-bit labels straight from the table: saves the pass that maps numbers to labels — 8 bytes per cell)
           if (a.ids32) {  // (unconditional load from a clamped index, then the select: 16 loads in flight, not 16 round trips)
             const bool tag = a.halo32 != nullptr && (val & 0x80000000u) != 0u;  // (BTAG: the path leaves through a halo cell)
@@ -421,6 +425,19 @@ __global__ void __launch_bounds__(256) k_xround(u64 *__restrict__ WJ, u32 nslots
         w = wj;
         q = s | XDONE;
       }
+      // a second jump in the same round (the composed word is a true statement again): half the launches and half the
+      // passes over the slots' own words for the same gathers
+      if (!(q & XDONE)) {
+        const u64 oth2 = wj_load(WJ + q);
+        const u32 wj2 = (u32)oth2;
+        q = (u32)(oth2 >> 32);
+        if (MODE == MODE_RANK) {
+          w += wj2;
+        } else if (wj2) {
+          w = wj2;
+          q = s | XDONE;
+        }
+      }
       wj_store(WJ + s, (u64)w | ((u64)q << 32));
       moving = !(q & XDONE);
     }
@@ -462,7 +479,7 @@ static int run_paths(pfd_raster *h, const u32 *seed_dev, u32 *out_dev, int *comp
   HIPCHK(hipMemsetAsync(wdone.p, 0, nslots / 64 + 64, h->stream));
   bool done = false;
   int batch = 2;
-  for (u32 span = 1; span < ntr + ntc; span <<= 1) ++batch;
+  for (u32 span = 1; span < ntr + ntc; span <<= 2) ++batch;  // (two jumps per round: a round covers a factor of 4)
   for (int rounds = 0; rounds < 40 && !done;) {
     for (int r = 0; r + 1 < batch; ++r, ++rounds) {
       k_xround<MODE, false><<<sgrid, 256, 0, h->stream>>>(WJ, (u32)nslots, h->ctrl, wdone.as<u8>());
