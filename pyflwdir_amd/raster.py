@@ -571,8 +571,8 @@ class FlwdirRaster(object):
         execution order, within n_cells / 2**63 relative of the real-number sum (1.3e-10 at 30000 x 30000), and several
         times faster on a fresh raster because it needs no ordering plan.  It is never offered for float32 sums
         (projected grids): a sequential float32 sum drifts from the real-number sum by more than the 1e-6 this path
-        promises, so only the exact order reproduces it.  Whatever the fast form cannot take (cycles, rasters beyond
-        2**32 - 2 cells) is answered by the exact form."""
+        promises, so only the exact order reproduces it.  Whatever the fast form cannot take (cycles, general graphs) is
+        answered by the exact form."""
         unit = str(unit).lower()
         if unit not in gis.AREA_FACTORS:
             fstr = '", "'.join(gis.AREA_FACTORS.keys())
@@ -584,7 +584,9 @@ class FlwdirRaster(object):
         rows = np.ascontiguousarray(gis.area_rows(self.transform, self.shape, self.latlon, unit="m2")
                                     / gis.AREA_FACTORS[unit])
         nb = self._row_blocks_needed()
-        if not exact and nb == 1 and rows.dtype == np.float64:
+        if not exact and rows.dtype == np.float64 and self._d8 is not None:
+            # (one handle whatever the size: the tiled engine addresses tiles and slots, not cells — also beyond 2**32 - 2
+            #  cells, where the exact form runs in seeded row blocks)
             out, quantum = self._h.upstream_area_rows_fixed(rows)
             if out is not None:
                 self._last_quantum = quantum  # (one unit of the fixed-point scale, in the unit asked for)

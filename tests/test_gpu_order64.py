@@ -4,6 +4,7 @@ runs on ANY raster; PFD_TEST_ORDER64 (with PFD_ENABLE_KNOBS=1) makes the small g
 reference's own outputs bit for bit (core.idxs_seq, pyflwdir/core.py:87-117; core.rank, core.py:17-47), and a seeded raster
 against the 32-bit form and the oracle.  The at-size run is tools/big_frontend_probe.py (profiles/r05_big_frontend.txt)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -117,8 +118,26 @@ def test_true_size_beyond_2_32_cells(gpu_lib):
     buf.free()
     n = d8.size
     assert n > 2**32 - 2
-    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    from pyflwdir_amd._affine import Affine
+
+    res = 1.0 / 1200.0  # a 3-arc-second lat/lon grid from 60 N down to 5 N
+    flw = pyflwdir.from_array(d8, ftype="d8", transform=Affine(res, 0.0, 5.0, 0.0, -res, 60.0), latlon=True, cache=False)
     assert flw._wide() and flw.idxs_pit.dtype == np.int64
+    # upstream_area in km2, order-free in fixed point (csrc/wide.h) on ONE handle of 4.36e9 cells, against the exact form in
+    # seeded row blocks on sampled rows: within the stated n_cells / 2**63 x (mean / min area) relative, and the local
+    # equation area(x) = own + sum of the upstream cells' areas to the same tolerance
+    t0 = time.perf_counter()
+    fx = flw.upstream_area("km2", exact=False)
+    t_fixed = time.perf_counter() - t0
+    assert fx.dtype == np.float64 and fx.shape == (size, size) and float(fx.min()) > 0.0
+    t0 = time.perf_counter()
+    ex = flw.upstream_area("km2")
+    t_exact = time.perf_counter() - t0
+    print(f"66000^2 upstream_area('km2'): fixed point {t_fixed:.2f} s, exact (row blocks) {t_exact:.2f} s")
+    for r0 in (0, 33000, size - 2000):
+        a, b = fx[r0:r0 + 2000], ex[r0:r0 + 2000]
+        assert float(np.max(np.abs(a - b) / b)) <= 2e-9
+    del ex, fx
     rank = flw.rank.ravel()
     assert rank.dtype == np.int32 and int(rank.min()) == 0  # (no nodata, no cycle)
     pits = flw.idxs_pit
