@@ -243,14 +243,22 @@ __global__ void __launch_bounds__(256) k_plan_heavy_tile(const u8 *__restrict__ 
     u32 hs = 8;
     if (xl_trunk(sL[lr * HPW + lc])) {
       const u32 m = sK[idx];
+      // (the eight neighbours' marks and areas first, unconditionally — they lie inside the staged area —, then the
+      //  selection in registers: under `if (m & bit)` every one of the 16 LDS loads was waited for on the spot)
+      u32 nl[8], nu[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u32 j = (u32)((int)lr + d8_dr(k)) * HPW + (u32)((int)lc + d8_dc(k));
+        nl[k] = sL[j];
+        nu[k] = sU[j];
+      }
       u32 best = 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int k = PFD_SLOT_ASC[q];
-        if (m & (1u << k)) {
-          const u32 j = (u32)((int)lr + d8_dr(k)) * HPW + (u32)((int)lc + d8_dc(k));
-          if (xl_trunk(sL[j]) && sU[j] > best) best = sU[j], hs = (u32)k;
-        }
+        const int k = (q == 0) ? 5 : (q == 1) ? 6 : (q == 2) ? 7 : (q == 3) ? 4 : (q == 4) ? 0 : (q == 5) ? 3 : (q == 6) ? 2 : 1;  // PFD_SLOT_ASC
+        const bool take = (m & (1u << k)) && xl_trunk(nl[k]) && nu[k] > best;
+        best = take ? nu[k] : best;
+        hs = take ? (u32)k : hs;
       }
     }
     sH[idx] = (u8)hs;
@@ -511,12 +519,38 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict
     }
     any[j] = (inf[j][0] | inf[j][1] | inf[j][2] | inf[j][3]) != 0u;
   }
+  // (NOTES item 1 once more: a load under a per-cell branch is waited for on the spot — 2 x 16 serialised round trips per
+  //  thread here, then 2 x 16 dependent ones.  A quad that holds a trunk cell loads its four tail numbers and hops as two
+  //  16-byte vectors; the chain id / chain end of a cell come from a clamped index, all of a quad's in flight, the mark selects)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (!any[j]) continue;
+    if (c0 + (4u * tid & 63u) + 3u < ncol) {
+      uint4 t4, h4;
+      __builtin_memcpy(&t4, tailnum + x0s[j], 16);
+      __builtin_memcpy(&h4, hops + x0s[j], 16);
+      tn[j][0] = t4.x, tn[j][1] = t4.y, tn[j][2] = t4.z, tn[j][3] = t4.w;
+      hp[j][0] = h4.x, hp[j][1] = h4.y, hp[j][2] = h4.z, hp[j][3] = h4.w;
+    } else {
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-      if (inf[j][b]) tn[j][b] = tailnum[x0s[j] + b], hp[j][b] = hops[x0s[j] + b];
+      for (int b = 0; b < 4; ++b)
+        if (inf[j][b]) tn[j][b] = tailnum[x0s[j] + b], hp[j][b] = hops[x0s[j] + b];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) tn[j][b] = inf[j][b] ? tn[j][b] : 0u;
+  }
+  u32 cid[4][4], pe[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cid[j][b] = pe[j][b] = 0;
+    if (!any[j]) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const u32 t = tn[j][b] ? tn[j][b] - 1u : 0u;  // (clamped: the loads are unconditional inside the quad)
+      cid[j][b] = tidx_at[t];
+      pe[j][b] = pend_at[t];
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -529,8 +563,8 @@ __global__ void __launch_bounds__(256) k_plan_scatter(const uint16_t *__restrict
         ptmp[x] = NONE32;
         continue;
       }
-      const u32 c = tidx_at[tn[j][b] - 1];  // (chain ids since k_plan_chain_lens)
-      const u32 p = pend_at[tn[j][b] - 1] - hp[j][b];
+      const u32 c = cid[j][b];  // (chain ids since k_plan_chain_lens)
+      const u32 p = pe[j][b] - hp[j][b];
       // one 16-byte record per position — cell, chain, hinfo — so that k_plan_expand, which runs in position order, finds
       // everything in one coalesced load instead of five dependent gathers per cell
       urec[p] = make_uint4(x, c, inf[j][b], 0u);
@@ -578,7 +612,11 @@ __global__ void __launch_bounds__(256) k_plan_cslot(const uint16_t *__restrict__
     }
     u32 sl[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) sl[b] = (inf[b] && pp[b] != NONE32) ? spos[pp[b]] : 0u;
+    for (int b = 0; b < 4; ++b) {  // (unconditional gathers from clamped positions, the select afterwards)
+      const bool ok = inf[b] && pp[b] != NONE32;
+      const u32 v = spos[ok ? pp[b] : 0u];
+      sl[b] = ok ? v : 0u;
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       if (!inf[b] || pp[b] == NONE32) continue;
