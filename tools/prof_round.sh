@@ -35,6 +35,8 @@ python tools/bench_up_blocks.py 30000 30000 4 > $O/up_blocks_30k.txt 2>&1
 PFD_UP_FULL=1 python tools/bench_up_blocks.py 30000 30000 4 > $O/up_blocks_30k_full_sweeps.txt 2>&1
 python tools/bench_up_blocks.py 36000 72000 4 30 100000 > $O/up_blocks_c5.txt 2>&1
 (python tools/plan_time.py 30000 30000 3; python tools/plan_time.py 36000 72000 2 30 100000; python tools/xplan_info.py) > $O/plan_time.txt 2>&1
+python tools/wide_probe.py 10000 30000 > $O/wide_probe.txt 2>&1
+PROF_CMD="python tools/wide_probe.py 30000" bash tools/prof_cmd.sh 80 > $O/wide_kernels_30k.txt 2>&1
 for r in rough meander; do python bench.py --regime $r --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_90000_$r.json 2>/dev/null; done
 rm -rf gpurun_out/${T}_calib gpurun_out/${T}_pmc gpurun_out/${T}_pmc10k gpurun_out/${T}_pmc_c3 gpurun_out/${T}_pmc_c5 gpurun_out/${T}_bench90k gpurun_out/${T}_bench10k gpurun_out/${T}_benchc3 gpurun_out/sq1 gpurun_out/sq2 gpurun_out/${T}_ops
 du -sh gpurun_out
