@@ -13,7 +13,7 @@
 //     |result - sum| < (row runs in the upstream set) * 2^-s  <=  N_up(x) * 2^-s,   2^-s <= (sum of all areas) / 2^63
 // i.e. relative <= n_cells / 2^63 * mean / min area: 1.3e-10 at 30000^2, 6e-10 at 2^32 cells, reached at cells with a
 // handful of upstream cells (one quantum against one cell's area); a large basin is off by far less (measured:
-// see profiles/r06_wide_probe.txt) plus one float64 rounding of the final value.  The reference's own serial float64 sum carries up to N * 2^-53
+// see profiles/r06f_wide_probe.txt) plus one float64 rounding of the final value.  The reference's own serial float64 sum carries up to N * 2^-53
 // relative error (1e-7 worst case at 9e8 terms, ~3e-12 typical) — the two agree far inside the north star's 1e-6.
 //
 // The pass reuses everything of the count pass that does not depend on the values:
@@ -24,7 +24,7 @@
 //   3. k_wsuper_up     — no doubling: an exit's root inside its supertile is known, its sum goes there;
 //   4. k_wlink3 / k_wround x R / k_wsx_totals — the super-exits as ONE flat forest in global memory (u64 values);
 //   5. k_wsuper_down   — the value-carrying doubling of a supertile's exits in LDS (u64: 80 KB, one per CU);
-//   6. k_wtile_final   — the value-carrying doubling of a tile (u64: 41 KB, three per CU), float64 result.
+//   6. k_wtile_final   — the value-carrying doubling of a tile (u64: 41 KB, three per CU, 512 threads), float64 result.
 // Anything the u64 forms cannot hold (a supertile with more than SCAP exits, a raster with cycles, row blocks) is
 // reported as "not taken" and the front end runs the exact form.
 #pragma once
@@ -61,6 +61,7 @@ __global__ void __launch_bounds__(256) k_wtile_local(WideArgs a) {
   __shared__ __attribute__((aligned(16))) u64 A[PSL * 4];  // 4 replicas per perimeter slot, picked by lane
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];
   __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
   const u32 tid = threadIdx.x;
   u32 tc, tr;
   pfd_tile_of_block(&tc, &tr);
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(256) k_wtile_local(WideArgs a) {
         *(uint2 *)&P[4u * tid + 1024u * j] = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
       }
     }
-    if (!__syncthreads_or((int)live)) break;
+    if (!fx_vote(s_flag, round, tid, live != 0u)) break;
   }
   // every valid cell adds the weight of its row to the counter of its exit (cells of a quad share their row and
   // mostly their exit: combined in registers first)
@@ -333,19 +334,24 @@ __global__ void __launch_bounds__(NT) k_wsuper_down(SuperArgs s, const u64 *__re
 }
 
 // final pass of a tile: the doubling with 64-bit values, entries start with their own weight + the inflow they pull
-__global__ void __launch_bounds__(256) k_wtile_final(WideArgs a) {
-  // (32 KB + 8 KB = a quarter of a CU's LDS: four tiles in flight; no sink words — a saturated cell issues no atomic)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_wtile_final(WideArgs a) {
+  constexpr int QF = TCELLS / 4 / NT;  // quads per thread (4 with 256 threads, 2 with 512)
+  constexpr u32 QSTR = 4u * NT;        // cells between a thread's quads
+  // (32 KB + 8 KB + the vote's flags: three tiles per CU — a fourth would need the image to be EXACTLY a quarter of the LDS,
+  //  and any vote costs a few bytes; no sink words — a saturated cell issues no atomic)
   __shared__ __attribute__((aligned(16))) u64 A[TCELLS];
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];
+  __shared__ __attribute__((aligned(16))) u32 s_flag[2][8];
   const u32 tid = threadIdx.x;
   u32 tc, tr;
   pfd_tile_of_block(&tc, &tr);
   const u32 sbase = sslot_base(tr, tc, a.nstc);
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
-  u32 cq[QPT];
+  u32 cq[QF];
 #pragma unroll
-  for (int j = 0; j < QPT; ++j) {  // own quads straight from HBM (clamped address, masked afterwards)
-    const u32 l0 = 4u * tid + 1024u * j;
+  for (int j = 0; j < QF; ++j) {  // own quads straight from HBM (clamped address, masked afterwards)
+    const u32 l0 = 4u * tid + QSTR * j;
     const i64 gr = r0 + (l0 >> 6), gc0 = c0 + (l0 & 63);
     const i64 crr = gr >= (i64)a.nrow ? (i64)a.nrow - 1 : gr;
     const i64 ccs = gc0 >= (i64)a.ncol ? (i64)a.ncol - 1 : gc0;
@@ -368,11 +374,11 @@ __global__ void __launch_bounds__(256) k_wtile_final(WideArgs a) {
     }
   }
   const u32 qs = (tid >> 3) & 3u;
-  u32 pc[QPT * 4];
+  u32 pc[QF * 4];
   u32 live = 0;
 #pragma unroll
-  for (int j = 0; j < QPT; ++j) {
-    const u32 l0 = 4u * tid + 1024u * j;
+  for (int j = 0; j < QF; ++j) {
+    const u32 l0 = 4u * tid + QSTR * j;
     const int lr = l0 >> 6, lc0 = l0 & 63;
     const u32 grow = min((u32)(r0 + lr), a.nrow - 1u);
     const u64 wr = a.wrow[grow];
@@ -391,21 +397,21 @@ __global__ void __launch_bounds__(256) k_wtile_final(WideArgs a) {
   if (inf) A[PHYS((u32)(plr * TS + plc))] += inf;  // (one slot per perimeter cell: no two threads share a word)
   __syncthreads();
   for (int round = 0; round < MAXROUNDS_TILE; ++round) {
-    u64 av[QPT * 4];
-    u32 q[QPT * 4];
+    u64 av[QF * 4];
+    u32 q[QF * 4];
 #pragma unroll
-    for (int j = 0; j < QPT; ++j) {
+    for (int j = 0; j < QF; ++j) {
       if (live & (1u << j)) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          av[4 * j + b] = A[4u * tid + 1024u * j + (u32)b];
+          av[4 * j + b] = A[4u * tid + QSTR * j + (u32)b];
           q[4 * j + b] = *(const uint16_t *)((const u8 *)P + (pc[4 * j + b] & 0x1FFEu));
         }
       }
     }
     __syncthreads();  // every read of this round precedes every write of this round
 #pragma unroll
-    for (int j = 0; j < QPT; ++j) {
+    for (int j = 0; j < QF; ++j) {
       if (live & (1u << j)) {
         // the four cells of a quad are neighbours in a row and, after a few rounds, mostly share their target: combined
         // in registers (same-address LDS atomics are served one lane after the other); a saturated cell has delivered
@@ -427,16 +433,16 @@ __global__ void __launch_bounds__(256) k_wtile_final(WideArgs a) {
           pc[4 * j + b] = q[4 * j + b];
         }
         if (pc[4 * j + 0] & pc[4 * j + 1] & pc[4 * j + 2] & pc[4 * j + 3] & PDONE) live &= ~(1u << j);
-        *(uint2 *)&P[4u * tid + 1024u * j] =
+        *(uint2 *)&P[4u * tid + QSTR * j] =
             make_uint2(pc[4 * j + 0] | (pc[4 * j + 1] << 16), pc[4 * j + 2] | (pc[4 * j + 3] << 16));
       }
     }
-    if (!__syncthreads_or((int)live)) break;
+    if (!fx_vote_n<NT / 64>(s_flag, round, tid, live != 0u)) break;  // (one barrier; __syncthreads_or is three)
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < QPT; ++j) {
-    const u32 l0 = 4u * tid + 1024u * j;
+  for (int j = 0; j < QF; ++j) {
+    const u32 l0 = 4u * tid + QSTR * j;
     const i64 gr = r0 + (l0 >> 6), gc0 = c0 + (l0 & 63);
     if (gr >= (i64)a.nrow || gc0 >= (i64)a.ncol) continue;
     double o4[4];
@@ -543,7 +549,11 @@ int pfd_upstream_area_wide_tiled(pfd_raster *h, const u64 *wrow_dev, const u32 *
   KCHK();
   pfd_seg_end(h, launches + 1);
   pfd_seg_begin(h, "wide_tile_final");
-  k_wtile_final<<<grid, 256, 0, h->stream>>>(wa);
+  // (512 threads: the 40 KB image fixes four tiles per CU either way, and eight waves per tile overlap more of the LDS
+  //  round trips than four — profiles/r06_wide_probe.txt; PFD_WIDE_NT=256 is the other form)
+  const char *nt = pfd_knob("PFD_WIDE_NT");
+  if (nt && atoi(nt) == 256) k_wtile_final<256><<<grid, 256, 0, h->stream>>>(wa);
+  else k_wtile_final<512><<<grid, 512, 0, h->stream>>>(wa);
   KCHK();
   pfd_seg_end(h, 1);
   *complete = 1;
