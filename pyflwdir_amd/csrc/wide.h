@@ -550,7 +550,7 @@ int pfd_upstream_area_wide_tiled(pfd_raster *h, const u64 *wrow_dev, const u32 *
   pfd_seg_end(h, launches + 1);
   pfd_seg_begin(h, "wide_tile_final");
   // (512 threads: the 40 KB image fixes four tiles per CU either way, and eight waves per tile overlap more of the LDS
-  //  round trips than four — profiles/r06_wide_probe.txt; PFD_WIDE_NT=256 is the other form)
+  //  round trips than four — profiles/r06f_wide_probe.txt; PFD_WIDE_NT=256 is the other form)
   const char *nt = pfd_knob("PFD_WIDE_NT");
   if (nt && atoi(nt) == 256) k_wtile_final<256><<<grid, 256, 0, h->stream>>>(wa);
   else k_wtile_final<512><<<grid, 512, 0, h->stream>>>(wa);
