@@ -31,7 +31,9 @@ def main():
     from pyflwdir_amd import _hip
 
     size = 66000
-    _hip.reserve(120 << 30)
+    free = _hip.mem_info()["free"]
+    assert free > (150 << 30), f"only {free >> 30} GiB of HBM free: this run needs ~150"
+    _hip.reserve(min(120 << 30, int(0.55 * free)))
     buf = _hip.synth_d8_device(size, size, seed=0)
     d8 = buf.download(np.uint8, (size, size))
     buf.free()
