@@ -1010,6 +1010,11 @@ __global__ void __launch_bounds__(256) k_xtrunk_dscatter(Op op, const u32 *__res
 // apply() would read from memory: gathered up front, quad by quad).  Writes every own cell once.
 // (LDS per workgroup decides how many tiles a CU overlaps, and the step loop is latency: keep it small.)
 #define XHW (XT + 2)
+#ifndef XORD_REGS
+#define XORD_REGS 0  // k_xtile_down, 1: the leaf list in registers instead of a 16 KB LDS copy with precomputed ring indices —
+                     // measured twice (round 4: per-lane range tests; round 6: uniform slices behind scalar branches,
+                     // profiles/r06_ab_ord_regs.txt) and slower both times although a tile more fits per CU: off
+#endif
 // cells whose final value is in place before the tile kernel runs: trunk cells, and the halo cells of a row block
 __device__ __forceinline__ bool xl_given(u32 m) { return xl_trunk(m) || m == XL_HALO; }
 template <class Op>
@@ -1024,7 +1029,9 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
   __shared__ __attribute__((aligned(16))) Elem De[INPL ? 4 : XTC];
   // per leaf, in step order: own cell (12 bits) | ring index of its downstream cell << 12 (13 bits) | pit << 25
   // (looked up once per leaf here instead of once per step through the cell's code)
+#if !XORD_REGS
   __shared__ __attribute__((aligned(16))) u32 ord[XTC];
+#endif
   __shared__ u32 F[XTC / 32];  // one flag bit per cell, for operations whose element needs one (HAND: drain)
   __shared__ uint16_t off[XOFF];
   const u32 tid = threadIdx.x;
@@ -1219,6 +1226,51 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     general_init(mycodes);
   }
   const u32 total = off[XOFF - 1];
+#if XORD_REGS
+  // The leaf list stays in REGISTERS: list position p belongs to thread p mod 256, so a thread holds positions tid + 256 m,
+  // m = 0 .. 15, as sixteen u16 entries in eight registers — loaded once, coalesced — and the positions of a step
+  // [off[s], off[s + 1]) lie in the slices m = off[s] >> 8 .. (off[s + 1] - 1) >> 8: a range that is UNIFORM over the
+  // workgroup, so the sixteen copies of the step body sit behind scalar branches (round 4 walked all sixteen with a per-lane
+  // range test and lost 3 %).  16 KB of LDS less: HAND runs four tiles per CU instead of three, float32 down-sweeps six
+  // instead of four.  The ring index of a leaf's downstream cell is recomputed from its 3-bit direction per use.
+  // RESULT (same box, 30000^2 / C5 shape): accuflux down 9.6 -> 10.4 / 21.9 -> 23.4 ms, HAND 15.4 -> 15.4 / 34.0 -> 34.9 ms.
+  u32 en[8];
+#pragma unroll
+  for (int m = 0; m < 16; m += 2) {
+    const u32 e0 = a.tord[tile * XTC + tid + 256u * (u32)m], e1 = a.tord[tile * XTC + tid + 256u * (u32)(m + 1)];  // (zeros past `total`)
+    en[m >> 1] = e0 | (e1 << 16);
+  }
+  __syncthreads();
+  int last = 0;
+  for (int s = 1; s < XOFF - 1; ++s) last = off[s] < total ? s : last;
+  for (int s = last; s >= 0; --s) {
+    const u32 b = (u32)__builtin_amdgcn_readfirstlane((int)off[s]), e = (u32)__builtin_amdgcn_readfirstlane((int)off[s + 1]);
+    if (e > b) {
+      const u32 mlo = b >> 8, mhi = (e - 1u) >> 8;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        if ((u32)m < mlo || (u32)m > mhi) continue;  // (scalar: the whole workgroup skips the slice)
+        const u32 j = tid + 256u * (u32)m;
+        if (j >= b && j < e) {
+          const u32 w = (en[m >> 1] >> (16 * (m & 1))) & 0xFFFFu;
+          const u32 x = w & 0xFFFu, root = w >> 15;
+          const int k = (int)((w >> 12) & 7u);
+          const int dr = root ? 0 : (int)((0x101A9u >> (2 * k)) & 3u) - 1, dc = root ? 0 : (int)((0x1901Au >> (2 * k)) & 3u) - 1;
+          const u32 own = ((x >> 6) + 1) * XHW + (x & 63u) + 1;
+          const V pv = val[(u32)((int)own + dr * (int)XHW + dc)];
+          Elem el;
+          if (INPL)
+            __builtin_memcpy(&el, &val[own], sizeof(Elem));
+          else
+            el = De[x];
+          const bool f = Op::DTILE_FLAG ? ((F[x >> 5] >> (x & 31u)) & 1u) != 0 : false;
+          val[own] = root ? op.dtroot(el, f) : op.dtfold(el, f, pv);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#else
   {
     uint2 o4[4];
 #pragma unroll
@@ -1257,6 +1309,7 @@ __global__ void __launch_bounds__(256) k_xtile_down(Op op, XTileArgs a) {
     }
     __syncthreads();
   }
+#endif
   u32 wmask = 0;  // (XWatch) bit 4 j + b: the value stored for that cell is one the operation watches
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
