@@ -345,6 +345,8 @@ struct TiledRun {
   int solve_exits(const u32 *start, i64 *launches, bool cleared = false, bool edge_down = false);
   bool edge_down_now = false;
   int level3_flat(i64 *launches);
+  int level3_flat_nosync(i64 *launches);
+  bool flat_nosync = false;  // this solve ran level 3 as one flat forest without host round trips (few hypertiles)
   int level3_hyper(i64 *launches);
   int level4_down(i64 *launches);
   int resolve_with_inflow(i64 *launches);

@@ -957,6 +957,30 @@ __global__ void __launch_bounds__(256) k_sx_totals(SuperArgs s, u32 nsuper, cons
   if (k < nsuper) s.xtot[s.sx_slot[k]] = T3final[k];
 }
 
+// The same two for a whole raster of few hypertiles (TiledRun::level3_flat_nosync): the number of super-exits stays on the
+// device (ctrl[T_NSUPER]), a bounded grid strides over it, and the first round's buffer is cleared on the way — no host look
+__global__ void __launch_bounds__(256) k_link3_flat(SuperArgs s, u32 cap, u32 *__restrict__ J3, u32 *__restrict__ Tnext) {
+  const u32 n = min(cap, (u32)s.ctrl[T_NSUPER]);
+  for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    Tnext[k] = 0;
+    const u32 tgt = s.sx_n1[k];
+    const u32 xe = (s.xrec[tgt] >> 8) & 0xFFu;
+    u32 j = k | XDONE, pos = NONE32;
+    if (xe != XR_NONE) {
+      const u32 n1 = (tgt & ~255u) | xe, b1 = n1 & ~(u32)(SSL - 1);
+      pos = b1 + xl_index(s.xmask, s.xcb, n1);
+      const u32 id = s.sxidL[b1 + s.R2L[pos]];
+      if (id != NONE32) j = id;
+    }
+    s.sx_n1[k] = pos;
+    J3[k] = j;
+  }
+}
+__global__ void __launch_bounds__(256) k_sx_totals_flat(SuperArgs s, u32 cap, const u32 *__restrict__ T3final) {
+  const u32 n = min(cap, (u32)s.ctrl[T_NSUPER]);
+  for (u32 k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) s.xtot[s.sx_slot[k]] = T3final[k];
+}
+
 // ---------------------------------------------------------------------------------------------
 // level 3: one 1024-thread workgroup per hypertile (4x4 supertiles = 2048 x 2048 cells) keeps the
 // <= HCAP super-exits of the hypertile in LDS; same doubling restricted to the hops that stay
@@ -1465,6 +1489,31 @@ int TiledRun::level3_flat(i64 *launches) {
   return PFD_OK;
 }
 
+// The flat level 3 WITHOUT host round trips, for a whole raster of at most FLAT_MAX_HT hypertiles (10000^2: 25): the two
+// hypertile solves of such a raster are 25 single-workgroup kernels on 256 CUs — 2 x 50 us of a 0.80 ms pass, plus the
+// level-4 launches behind them — where one flat forest of its ~3e5 super-exits takes ~10 rounds of ~5 us.  Same machinery as
+// level 4: device-side count, bounded grids, a fixed round budget whose shortfall shows at the pass's only synchronisation
+// (rounds4 / short_of_rounds: the pass is redone with more rounds).
+#define FLAT_MAX_HT 64u
+int TiledRun::level3_flat_nosync(i64 *launches) {
+  const u32 cap3 = (u32)std::min<size_t>(n3cap, 0x7FFFFFFF);
+  const u32 g3 = std::min(cdiv_u32(cap3, 256), 4096u);
+  k_link3_flat<<<g3, 256, 0, h->stream>>>(sa, cap3, Jc, Tn);
+  // (a river that runs along a supertile edge crosses it again and again: its chain of super-exits is several times the
+  //  raster's width in supertiles — 9 rounds fell short at 10000^2, and a miss costs a whole pass)
+  int batch = 7 + extra_rounds;
+  for (u32 span = 1; span < (ntr + ntc) / SG + 2; span <<= 1) ++batch;  // ~log2 of a path in supertiles
+  if (const char *e = pfd_knob("PFD_TEST_ROUNDS4")) batch = atoi(e) + extra_rounds;  // (tests: force a miss)
+  bool done3 = false;
+  u32 *T[3] = {Tc, Tn, xin3}, *J[2] = {Jc, Jn};
+  PFDCHK(pfd_doubling_rounds(h, T, J, cap3, batch, false, &done3, &rounds4, launches, h->ctrl + T_NSUPER, true));
+  Tc = T[0], Tn = T[1], xin3 = T[2], Jc = J[0], Jn = J[1];
+  k_sx_totals_flat<<<g3, 256, 0, h->stream>>>(sa, cap3, Tc);
+  *launches += 2;
+  KCHK();
+  return PFD_OK;
+}
+
 // level 3 per hypertile in LDS + level 4 (global doubling over the hyper-exits only)
 int TiledRun::level3_hyper(i64 *launches) {
   const u32 n3 = nht * HCAP;
@@ -1556,11 +1605,18 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   sa.T3 = Tc;
   // level 3 runs per hypertile in LDS when the raster spans several hypertiles, else flat
   sa.hmode = (nht > 1 && !force_flat && !pfd_knob("PFD_FLAT_L3")) ? 1 : 0;
+  // a whole raster of few hypertiles: one flat forest, no host look (level3_flat_nosync); PFD_FLAT_L3=0 keeps the hypertiles
+  const char *hs = pfd_knob("PFD_HYPER_SMALL");
+  flat_nosync = !is_block && sa.hmode && nht <= FLAT_MAX_HT && !(hs && atoi(hs) != 0);
+  if (flat_nosync) sa.hmode = 0;
+  xin3 = l3.as<u32>() + 5 * n3cap;  // (undo a rotation of level3_flat_nosync)
   k_super<false><<<nst, SNT, 0, h->stream>>>(sa);
   k_super_flagged<false><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);  // (normally none)
   KCHK();
   *launches += 2;
-  if (!sa.hmode) {  // the flat level-3 rounds are sized by the number of super-exits
+  if (flat_nosync) {
+    PFDCHK(level3_flat_nosync(launches));
+  } else if (!sa.hmode) {  // the flat level-3 rounds are sized by the number of super-exits
     u64 c[8];
     HIPCHK(hipMemcpyAsync(c, h->ctrl + 8, sizeof(c), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1568,7 +1624,8 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   }
   // (hyper mode runs on without a host round trip; T_OVERFLOW — a hypertile with more super-exits
   //  than fit in LDS — is looked at when the pass is checked, and the pass is redone flat)
-  if (sa.hmode)
+  if (flat_nosync) {
+  } else if (sa.hmode)
     PFDCHK(level3_hyper(launches));
   else if (nsuper)
     PFDCHK(level3_flat(launches));
@@ -1741,7 +1798,7 @@ int TiledRun::phase_b_collect(const u64 *c0, int *complete) {
   *complete = coarse_done && c[T_SLIVE - 8] == 0 && c[T_UNSAT - 8] == 0;
   overflowed = c[T_OVERFLOW - 8] != 0;
   // level 4 ran a fixed number of rounds: saturated iff the last one moved no pointer
-  short_of_rounds = sa.hmode && rounds4 > 0 && c[T_XACTIVE - 8] >= (u64)rounds4;
+  short_of_rounds = (sa.hmode || flat_nosync) && rounds4 > 0 && c[T_XACTIVE - 8] >= (u64)rounds4;
 #ifdef PFD_DEVTOOLS
   if (getenv("PFD_DEBUG_ROUNDS")) fprintf(stderr, "[level4] rounds issued %d, last active %llu\n", rounds4, (unsigned long long)c[T_XACTIVE - 8]);
 #endif

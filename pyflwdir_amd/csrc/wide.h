@@ -496,6 +496,12 @@ int pfd_upstream_area_wide_tiled(pfd_raster *h, const u64 *wrow_dev, const u32 *
   if (nflag) return PFD_OK;  // a supertile with more exits than the u64 LDS form holds (contrived rasters)
   const SuperArgs &sa = run.sa;
   const size_t nslots = run.nslots;
+  if (run.flat_nosync) {  // (the count of super-exits stayed on the device)
+    u64 ns = 0;
+    HIPCHK(hipMemcpyAsync(&ns, h->ctrl + T_NSUPER, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    run.nsuper = (u32)ns;
+  }
   const u32 n3 = sa.hmode ? (u32)((size_t)run.nht * HCAP) : run.nsuper;
   DevBuf slots64, l3w;
   PFDCHK(slots64.alloc(2 * nslots * sizeof(u64)));

@@ -118,12 +118,15 @@ def test_invalid_rasters(gpu_lib):
 
 def test_hypertile_overflow_fallback(gpu_lib, oracle, monkeypatch):
     """A hypertile with more super-exits than fit in LDS makes the pass fall back to the flat
-    level-3 id range (forced here by lowering the capacity); single handle and row blocks."""
+    level-3 id range (forced here by lowering the capacity); single handle and row blocks.  (A WHOLE raster of at most 64
+    hypertiles takes the flat forest without host round trips since round 6: PFD_HYPER_SMALL keeps the hypertile solves
+    for this one, so that their overflow path stays under test at a size the oracle answers.)"""
     import pyflwdir_amd as pyflwdir
     from pyflwdir_amd import dist
 
     d8 = oracle.synth_d8(2300, 2600, seed=8, tilt=100000, white=2, nodata_pct=10)  # 2 x 2 hypertiles
     exp, _, _ = oracle.upstream_area_cell(d8)
+    monkeypatch.setenv("PFD_HYPER_SMALL", "1")
     monkeypatch.setenv("PFD_TEST_HCAP", "100")
     flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
     assert np.array_equal(flw.upstream_area(), exp)
@@ -149,18 +152,42 @@ def test_supertile_dense_capacity_fallback(gpu_lib, oracle, monkeypatch, scap):
     assert np.array_equal(dist.upstream_area_blocks(d8, 3), exp)
 
 
-def test_level4_round_budget_miss(gpu_lib, oracle, monkeypatch):
-    """Level 4 of the exit graph issues a fixed number of doubling rounds without asking the host;
-    too few (forced here) must be noticed at the end of the pass and repaired by a longer re-run."""
+@pytest.mark.parametrize("hyper_small", [None, "1"])
+def test_level4_round_budget_miss(gpu_lib, oracle, monkeypatch, hyper_small):
+    """Level 4 of the exit graph — and the flat level-3 forest a whole raster of few hypertiles takes instead (round 6) —
+    issues a fixed number of doubling rounds without asking the host; too few (forced here) must be noticed at the end of
+    the pass and repaired by a longer re-run.  Both forms of the single handle, and row blocks."""
     import pyflwdir_amd as pyflwdir
     from pyflwdir_amd import dist
 
     d8 = oracle.synth_d8(4200, 4300, seed=9, tilt=1 << 26, white=2, nodata_pct=0)  # 3 x 3 hypertiles, long rivers
     exp, _, _ = oracle.upstream_area_cell(d8)
+    if hyper_small:
+        monkeypatch.setenv("PFD_HYPER_SMALL", hyper_small)
+    flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
+    assert np.array_equal(flw.upstream_area(), exp)  # (no knob: the budget suffices)
     monkeypatch.setenv("PFD_TEST_ROUNDS4", "1")
     flw = pyflwdir.from_array(d8, ftype="d8", cache=False)
     assert np.array_equal(flw.upstream_area(), exp)
     assert np.array_equal(dist.upstream_area_blocks(d8, 2), exp)
+
+
+@pytest.mark.parametrize("hyper_small", [None, "1"])
+def test_both_level3_forms_of_a_small_raster(gpu_lib, oracle, monkeypatch, hyper_small):
+    """10 x 11 hypertiles' worth of nothing special: the flat forest (default up to 64 hypertiles) and the hypertile solves
+    (PFD_HYPER_SMALL) give the oracle's counts on a river and on a rough raster with nodata, eager and deferred."""
+    from pyflwdir_amd import _hip
+
+    if hyper_small:
+        monkeypatch.setenv("PFD_HYPER_SMALL", hyper_small)
+    for shape, kw in (((6200, 7100), dict(seed=3, tilt=1 << 26, white=2, nodata_pct=0)),
+                      ((5000, 9000), dict(seed=4, tilt=100000, white=6, nodata_pct=30))):
+        d8 = oracle.synth_d8(shape[0], shape[1], **kw)
+        exp, _, _ = oracle.upstream_area_cell(d8)
+        for deferred in (False, True):
+            h = _hip.RasterHandle(d8, shape[0], shape[1], deferred=deferred)
+            assert np.array_equal(h.upstream_area_cell().reshape(shape), exp)
+            h.close()
 
 
 @pytest.mark.parametrize("engine", ["exact", "levels"])
