@@ -882,9 +882,9 @@ __global__ void k_export_idxs_ds(const u8 *__restrict__ ncode, Geo g, IDX *__res
 }
 
 template <class IDX>
-__global__ void k_export_u32(const u32 *__restrict__ src, u32 m, IDX *__restrict__ out) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) out[i] = (IDX)src[i];
+__global__ void k_export_u32(const u32 *__restrict__ src, u64 m, IDX *__restrict__ out) {
+  // (grid-stride: a launch of more than 2^32 threads per dimension does not run whole — m may exceed that)
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) out[i] = (IDX)src[i];
 }
 
 static size_t idx_size(int idx_dtype) {
@@ -930,13 +930,13 @@ int pfd_export_u32(pfd_raster *h, const u32 *src, i64 m, int idx_dtype, void *ou
   OutArg o;
   PFDCHK(o.bind(out, (size_t)m * es, memspace));
   if (m > 0) {
-    const u32 grid = cdiv_u32((u64)m, 256);
+    const u32 grid = (u32)std::min<u64>(cdiv_u32((u64)m, 256), 1u << 22);
     if (idx_dtype == PFD_I32)
-      k_export_u32<i32><<<grid, 256, 0, h->stream>>>(src, (u32)m, (i32 *)o.dev);
+      k_export_u32<i32><<<grid, 256, 0, h->stream>>>(src, (u64)m, (i32 *)o.dev);
     else if (idx_dtype == PFD_U32)
-      k_export_u32<u32><<<grid, 256, 0, h->stream>>>(src, (u32)m, (u32 *)o.dev);
+      k_export_u32<u32><<<grid, 256, 0, h->stream>>>(src, (u64)m, (u32 *)o.dev);
     else
-      k_export_u32<i64><<<grid, 256, 0, h->stream>>>(src, (u32)m, (i64 *)o.dev);
+      k_export_u32<i64><<<grid, 256, 0, h->stream>>>(src, (u64)m, (i64 *)o.dev);
     KCHK();
   }
   return o.finish(h->stream);

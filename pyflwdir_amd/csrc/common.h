@@ -318,6 +318,7 @@ int pfd_order_cells_by_rank(pfd_raster *h, int *ok);            // paths.hip
 bool pfd_wide_cells(const pfd_raster *h);                       // order64.hip: 64-bit cell indices (beyond 2^32 - 2 cells)
 int pfd_rank_wide(pfd_raster *h, i32 *out, int memspace);        // order64.hip
 int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace);  // order64.hip
+int pfd_wide_seq_dev(pfd_raster *h, struct DevBuf &q, u64 *nseq);  // order64.hip: the 64-bit sequence on the device
 int pfd_aux_stream(pfd_raster *h);                                // api.hip: h->stream2 / ev_fork / ev_join exist afterwards
 void pfd_free_xplan(pfd_raster *h);                             // exact.hip
 void pfd_xinc_drop(pfd_raster *h);                               // exact.hip: releases a kept block sweep

@@ -298,13 +298,9 @@ int pfd_rank_wide(pfd_raster *h, i32 *out, int memspace) {
   return PFD_OK;
 }
 
-// core.idxs_seq with 64-bit cell indices: n_valid entries (the raster is acyclic, or the call has failed)
-int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace) {
-  if (idx_dtype != PFD_I64) {
-    pfd_set_error("idxs_seq of a raster of %lld cells needs the int64 index dtype (PFD_I64)", (long long)h->n);
-    return PFD_EINVAL;
-  }
-  pfd_seg_clear(h);
+// core.idxs_seq with 64-bit cell indices, on the device: q holds *nseq queue entries (h->n_seq is set; a raster with
+// cycles: the cells that reach a pit only, like the reference's sequence)
+int pfd_wide_seq_dev(pfd_raster *h, DevBuf &q, u64 *nseq_out) {
   u32 maxrank = 0;
   const u64 n = (u64)h->n;
   std::vector<unsigned long long> cnt;
@@ -323,14 +319,10 @@ int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace) {
     HIPCHK(hipStreamSynchronize(h->stream));
   }  // (the ranks are released: the queue below is twice their size)
   if (cyclic) {  // the reference's sequence leaves the cells that never reach a pit out: n_seq < n_valid entries (h->n_seq)
-    DevBuf q;
     u64 nseq = 0;
     PFDCHK(wide_bfs(h, nullptr, q, &nseq));
     h->n_seq = (i64)nseq;
-    if (nseq)
-      HIPCHK(hipMemcpyAsync(out, q.p, (size_t)nseq * sizeof(u64), memspace == PFD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                            h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    *nseq_out = nseq;
     return PFD_OK;
   }
   h->n_seq = h->n_valid;
@@ -344,7 +336,7 @@ int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   }
   const u64 nseq = off[nlev];
   const Shape g{(u64)h->nrow, (u64)h->ncol};
-  DevBuf q, sums;
+  DevBuf sums;
   PFDCHK(q.alloc(std::max<size_t>((size_t)nseq, 1) * sizeof(u64)));
   u64 maxlev = 0;
   for (u32 l = 0; l < nlev; ++l) maxlev = std::max<u64>(maxlev, cnt[l]);
@@ -375,6 +367,20 @@ int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace) {
   }
   KCHK();
   pfd_seg_end(h, launches);
+  *nseq_out = nseq;
+  return PFD_OK;
+}
+
+// core.idxs_seq with 64-bit cell indices: h->n_seq entries (n_valid on an acyclic raster)
+int pfd_idxs_seq_wide(pfd_raster *h, int idx_dtype, void *out, int memspace) {
+  if (idx_dtype != PFD_I64) {
+    pfd_set_error("idxs_seq of a raster of %lld cells needs the int64 index dtype (PFD_I64)", (long long)h->n);
+    return PFD_EINVAL;
+  }
+  pfd_seg_clear(h);
+  DevBuf q;
+  u64 nseq = 0;
+  PFDCHK(pfd_wide_seq_dev(h, q, &nseq));
   if (nseq)
     HIPCHK(hipMemcpyAsync(out, q.p, (size_t)nseq * sizeof(u64), memspace == PFD_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                           h->stream));

@@ -982,7 +982,8 @@ __global__ void k_seed_numbers(const i64 *__restrict__ idx, u32 k, u32 *__restri
 __global__ void k_flag_seed_tiles(const i64 *__restrict__ idx, u32 k, u32 ncol, u32 ntc, u8 *__restrict__ tflag) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= k) return;
-  const u32 x = (u32)idx[t], r = x / ncol, c = x - r * ncol;
+  const u64 x = (u64)idx[t];
+  const u32 r = (u32)(x / ncol), c = (u32)(x - (u64)r * ncol);
   tflag[(size_t)(r >> 6) * ntc + (c >> 6)] = 1;
 }
 __global__ void __launch_bounds__(256) k_zero_seed_tiles(const u8 *__restrict__ tflag, u32 nrow, u32 ncol, u32 ntc,
@@ -1000,17 +1001,18 @@ __global__ void __launch_bounds__(256) k_zero_seed_tiles(const u8 *__restrict__ 
   }
 }
 template <class L>
-__global__ void k_labels_out(const u32 *__restrict__ num, const L *__restrict__ ids, u32 n, L *__restrict__ out) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u32 v = num[i];
-  out[i] = v ? ids[v - 1] : (L)0;
+__global__ void k_labels_out(const u32 *__restrict__ num, const L *__restrict__ ids, u64 n, L *__restrict__ out) {
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {  // (n may exceed 2^32)
+    const u32 v = num[i];
+    out[i] = v ? ids[v - 1] : (L)0;
+  }
 }
 
 int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k, int id_size, void *out_dev, int *ok) {
   *ok = 0;
-  if (h->n > 4294967294ll || h->halo_top || h->halo_bot) return PFD_OK;
-  const u32 n = h->geo.n;
+  if (h->halo_top || h->halo_bot) return PFD_OK;
+  const size_t n = (size_t)h->n;  // (any size: the query addresses tiles and slots, the labels are 32-bit VALUES)
+  const bool wide = pfd_wide_cells(h);
   DevBuf seed, num;
   PFDCHK(seed.alloc((size_t)n * sizeof(u32) + 64));  // + slack: quads are loaded 16 bytes at a time
   const bool direct = id_size == 4;  // 32-bit labels: the final tile pass writes them itself
@@ -1021,10 +1023,11 @@ int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32
   // be acyclic; the rank query answers that once per handle.
   if (h->acyclic == 0) {
     DevBuf rk;
-    PFDCHK(rk.alloc((size_t)n * sizeof(u32)));
+    if (!wide) PFDCHK(rk.alloc((size_t)n * sizeof(u32)));  // (beyond 2^32 cells: the form without the output array)
     int ok_rank = 0;
+    u32 mr = 0;
     pfd_seg_begin(h, "tile_rank_check");
-    PFDCHK(run_paths<MODE_RANK>(h, nullptr, rk.as<u32>(), &ok_rank, nullptr));
+    PFDCHK(run_paths<MODE_RANK>(h, nullptr, wide ? nullptr : rk.as<u32>(), &ok_rank, wide ? &mr : nullptr));
     pfd_seg_end(h, 2);
     h->acyclic = ok_rank ? 1 : -1;
   }
@@ -1049,7 +1052,7 @@ int pfd_basins_tiled(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32
     *ok = 1;
     return PFD_OK;
   }
-  const u32 grid = cdiv_u32(n, 256);
+  const u32 grid = (u32)std::min<u64>(cdiv_u32((u64)n, 256), 1u << 22);
   switch (id_size) {
     case 1: k_labels_out<u8><<<grid, 256, 0, h->stream>>>(num.as<u32>(), (const u8 *)ids_dev, n, (u8 *)out_dev); break;
     case 2: k_labels_out<uint16_t><<<grid, 256, 0, h->stream>>>(num.as<u32>(), (const uint16_t *)ids_dev, n, (uint16_t *)out_dev); break;

@@ -20,9 +20,11 @@ __global__ void k_mark_cells(const i64 *__restrict__ idx, u32 k, u8 *__restrict_
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < k) flag[idx[t]] = 1;
 }
-__global__ void __launch_bounds__(256) k_ucat_count(const u32 *__restrict__ lab, const u8 *__restrict__ is_out, u32 n,
+__global__ void __launch_bounds__(256) k_ucat_count(const u32 *__restrict__ lab, const u8 *__restrict__ is_out, u64 n,
                                                     u32 *__restrict__ cnt) {
-  const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+  // (grid-stride in whole workgroups: n may exceed the 2^32 threads one launch dimension runs)
+  for (u64 x0 = (u64)blockIdx.x * blockDim.x; x0 < n; x0 += (u64)gridDim.x * blockDim.x) {
+  const u64 x = x0 + threadIdx.x;
   u32 u = 0;
   if (x < n) {
     u = lab[x];
@@ -38,6 +40,7 @@ __global__ void __launch_bounds__(256) k_ucat_count(const u32 *__restrict__ lab,
     const u64 later = lane == 63u ? 0ull : (heads >> (lane + 1u));
     const u32 len = later ? (u32)__ffsll((long long)later) : 64u - lane;
     atomicAdd(&cnt[u - 1], len);
+  }
   }
 }
 __global__ void __launch_bounds__(256) k_ucat_keys(const u32 *__restrict__ oseq, u32 nseq, const u32 *__restrict__ lab,
@@ -97,18 +100,100 @@ static int ucat_float(pfd_raster *h, const u32 *lab, const u8 *is_out, u32 k, co
   return PFD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// beyond 2^32 - 2 cells: the same sum over the 64-bit sequence (order64.hip), in pieces of the sequence — per piece the
+// (label, area) pairs of its cells are stably sorted by label, then ONE WAVE per label adds the label's values of the
+// piece to the label's running sum, one after the other: lane 0's chain of adds is the reference's loop, the other
+// lanes only fetch (64 consecutive values per load, the next 64 in flight while the chain runs)
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_ucat_pairs64(const u64 *__restrict__ q, u64 m, const u32 *__restrict__ lab,
+                                                      const u8 *__restrict__ is_out, const T *__restrict__ rows, u64 ncol,
+                                                      u32 *__restrict__ keys, T *__restrict__ vals) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const u64 x = q[j];
+  const u32 u = lab[x];
+  keys[j] = (u && !is_out[x]) ? u : 0u;
+  vals[j] = rows[x / ncol];
+}
+template <class T>
+__global__ void __launch_bounds__(64) k_ucat_sum_wave(const T *__restrict__ vals, const u32 *__restrict__ first,
+                                                      const u32 *__restrict__ last, u32 k, T *__restrict__ are) {
+  const u32 u = blockIdx.x, lane = threadIdx.x;
+  const u32 b = first[u], e = last[u];
+  if (b >= e) return;
+  T acc = are[u];
+  T v = b + lane < e ? vals[b + lane] : (T)0;
+  for (u32 j = b; j < e; j += 64u) {
+    const T cur = v;
+    const u32 nx = j + 64u + lane;
+    v = nx < e ? vals[nx] : (T)0;  // (in flight while the chain below runs)
+    const u32 cnt = min(64u, e - j);
+    if (cnt == 64u) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) acc = acc + __shfl(cur, i);
+    } else {
+      for (u32 i = 0; i < cnt; ++i) acc = acc + __shfl(cur, (int)i);
+    }
+  }
+  if (lane == 0) are[u] = acc;
+}
+
+template <class T>
+static int ucat_float_wide(pfd_raster *h, const u32 *lab, const u8 *is_out, u32 k, const T *rows_dev, T *are_dev) {
+  DevBuf q;
+  u64 nseq = 0;
+  PFDCHK(pfd_wide_seq_dev(h, q, &nseq));
+  if (!nseq) return PFD_OK;
+  u64 piece = 1ull << 28;
+  if (const char *e = pfd_knob("PFD_UCAT_PIECE")) piece = std::max<u64>(64, (u64)atoll(e));  // (tests: several pieces of a small raster)
+  piece = std::min(piece, nseq);
+  DevBuf keys, keys2, vals, vals2, bounds, tmp;
+  PFDCHK(keys.alloc((size_t)piece * sizeof(u32)));
+  PFDCHK(keys2.alloc((size_t)piece * sizeof(u32)));
+  PFDCHK(vals.alloc((size_t)piece * sizeof(T)));
+  PFDCHK(vals2.alloc((size_t)piece * sizeof(T)));
+  PFDCHK(bounds.alloc(2 * (size_t)k * sizeof(u32)));
+  int bits = 1;
+  while ((1ull << bits) <= (u64)k) ++bits;
+  size_t tb = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, keys.as<u32>(), keys2.as<u32>(), vals.as<T>(), vals2.as<T>(), (size_t)piece, 0u,
+                                   (unsigned)bits, h->stream));
+  PFDCHK(tmp.alloc(std::max<size_t>(tb, 16)));
+  pfd_seg_begin(h, "ucat_sums");
+  i64 launches = 0;
+  for (u64 p0 = 0; p0 < nseq; p0 += piece) {
+    const u64 m = std::min(piece, nseq - p0);
+    k_ucat_pairs64<T><<<cdiv_u32(m, 256), 256, 0, h->stream>>>(q.as<u64>() + p0, m, lab, is_out, rows_dev, (u64)h->ncol, keys.as<u32>(),
+                                                              vals.as<T>());
+    size_t tb2 = tb;
+    HIPCHK(rocprim::radix_sort_pairs(tmp.p, tb2, keys.as<u32>(), keys2.as<u32>(), vals.as<T>(), vals2.as<T>(), (size_t)m, 0u,
+                                     (unsigned)bits, h->stream));
+    HIPCHK(hipMemsetAsync(bounds.p, 0, 2 * (size_t)k * sizeof(u32), h->stream));  // first = last = 0: empty segment
+    k_seg_bounds<<<cdiv_u32(m, 256), 256, 0, h->stream>>>(keys2.as<u32>(), (u32)m, bounds.as<u32>(), bounds.as<u32>() + k);
+    k_ucat_sum_wave<T><<<k, 64, 0, h->stream>>>(vals2.as<T>(), bounds.as<u32>(), bounds.as<u32>() + k, k, are_dev);
+    launches += 5;
+  }
+  KCHK();
+  pfd_seg_end(h, launches);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return PFD_OK;
+}
+
 extern "C" int pfd_ucat_area(pfd_raster *h, const int64_t *idxs_out, int64_t k, int map_dtype, void *map_out, int memspace,
                              int area_dtype, const void *area_rows, void *area_out) {
   PFDCHK(pfd_check_handle(h));
   PFDCHK(pfd_reject_general(h, "ucat_area"));
-  PFDCHK(pfd_require_whole(h, "ucat_area"));
+  PFDCHK(pfd_require_unblocked(h, "ucat_area"));
+  const bool wide = pfd_wide_cells(h);  // (64-bit cell indices: the label query runs at any size, the float sums walk order64.hip's sequence)
   if (!idxs_out || k < 0 || k >= 0xFFFFFFFFll || !map_out || !area_out ||
       (area_dtype != PFD_I32 && area_dtype != PFD_F32 && area_dtype != PFD_F64) || (area_dtype != PFD_I32 && !area_rows)) {
     pfd_set_error("pfd_ucat_area: bad arguments");
     return PFD_EINVAL;
   }
   pfd_seg_clear(h);
-  const u32 n = h->geo.n;
+  const u64 n = (u64)h->n;
   // outlets: a missing value (< 0) is skipped; of a repeated cell the LAST entry owns the label
   // (`ucatch_map[idx0] = i + 1` in a loop over i); every valid entry starts with its own cell's area
   std::vector<i64> uidx, all_valid;
@@ -178,12 +263,16 @@ extern "C" int pfd_ucat_area(pfd_raster *h, const int64_t *idxs_out, int64_t k, 
     HIPCHK(hipMemcpyAsync(are_dev.p, are.data(), (size_t)k * esz, hipMemcpyHostToDevice, h->stream));
     if (area_dtype == PFD_I32) {
       // (int32 adds commute: the counts are added to the start values, wrapping like the reference's int32)
-      k_ucat_count<<<cdiv_u32(n, 256), 256, 0, h->stream>>>(lab.as<u32>(), is_out.as<u8>(), n, are_dev.as<u32>());
+      k_ucat_count<<<(u32)std::min<u64>(cdiv_u32(n, 256), 1u << 22), 256, 0, h->stream>>>(lab.as<u32>(), is_out.as<u8>(), n, are_dev.as<u32>());
       KCHK();
     } else {
       InArg rows;
       PFDCHK(rows.bind(area_rows, (size_t)h->nrow * esz, PFD_HOST, h->stream));
-      if (area_dtype == PFD_F32)
+      if (wide && area_dtype == PFD_F32)
+        PFDCHK(ucat_float_wide<float>(h, lab.as<u32>(), is_out.as<u8>(), (u32)k, (const float *)rows.dev, are_dev.as<float>()));
+      else if (wide)
+        PFDCHK(ucat_float_wide<double>(h, lab.as<u32>(), is_out.as<u8>(), (u32)k, (const double *)rows.dev, are_dev.as<double>()));
+      else if (area_dtype == PFD_F32)
         PFDCHK(ucat_float<float>(h, lab.as<u32>(), is_out.as<u8>(), (u32)k, (const float *)rows.dev, are_dev.as<float>()));
       else
         PFDCHK(ucat_float<double>(h, lab.as<u32>(), is_out.as<u8>(), (u32)k, (const double *)rows.dev, are_dev.as<double>()));

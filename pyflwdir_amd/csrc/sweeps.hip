@@ -1161,6 +1161,11 @@ int pfd_basins_dev(pfd_raster *h, const i64 *idx_dev, const void *ids_dev, u32 k
   int tiled_ok = 0;
   if (!pfd_knob("PFD_BASINS_LEVELS")) PFDCHK(pfd_basins_tiled(h, idx_dev, ids_dev, ku, id_size, out_dev, &tiled_ok));
   if (!tiled_ok) {
+    if (pfd_wide_cells(h)) {  // (the level engine addresses cells with 32 bits; the caller has the row-block protocol)
+      pfd_set_error("basins / ucat_area of a raster with cycles need the level engine's 32-bit cell order and are not available "
+                    "for a raster of %lld cells on one handle (pfd_basins_begin / _finish run it in row blocks)", (long long)h->n);
+      return PFD_EUNSUPPORTED;
+    }
     PFDCHK(pfd_order_cells_impl(h));
     int rc;
     switch (id_size) {

@@ -108,6 +108,13 @@ constexpr NbrTab make_nbr_tab() {
 }
 static __device__ __constant__ const NbrTab NBR_TAB = make_nbr_tab();
 
+// Weight of the cell in column c of a row with quantised area base + f / 2^32: base + floor((c + 1) f) - floor(c f)
+// (Bresenham along the row).  Rounding every cell of a row the same way would give a run of k cells the error
+// k * (rounding of the row); sharing the fraction out keeps the error of ANY run of consecutive cells of a row
+// below one quantum — and the upstream set of a cell is made of such runs.
+__device__ __forceinline__ u64 w_cell(u64 base, u32 f, u32 c) { return base + (u64)(__umulhi(c + 1u, f) - __umulhi(c, f)); }
+
+
 template <int NW>
 __device__ __forceinline__ bool fx_vote_n(u32 (*s_flag)[8], int round, u32 tid, bool live) {
   const bool any = __ballot(live) != 0ull;
@@ -125,9 +132,11 @@ __device__ __forceinline__ bool fx_vote_n(u32 (*s_flag)[8], int round, u32 tid, 
 // ---------------------------------------------------------------------------------------------------------------
 // local pass of an interior tile
 // ---------------------------------------------------------------------------------------------------------------
-template <bool RAW, bool WEIGHTS>
+// WIDE (wide.h, the fixed-point upstream area): beside the count, the 64-bit weights of the cells per exit (a.xT64)
+template <bool RAW, bool WEIGHTS, bool WIDE = false>
 __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   __shared__ __attribute__((aligned(16))) u32 A[PSL * FXP];      // FXP count words per perimeter slot
+  __shared__ __attribute__((aligned(16))) u64 A64[WIDE ? PSL * 4 : 2];  // WIDE: 4 sum words per perimeter slot
   __shared__ __attribute__((aligned(16))) uint16_t P[FX_PN];     // byte offset into P of an ancestor / of a root word
   __shared__ __attribute__((aligned(16))) u8 code[HW * CP];
   __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
@@ -153,6 +162,10 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   }
   *(uint4 *)&A[FXP * tid] = make_uint4(0u, 0u, 0u, 0u);
   if (FXP == 8) *(uint4 *)&A[FXP * tid + 4] = make_uint4(0u, 0u, 0u, 0u);
+  if (WIDE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A64[tid + 256u * k] = 0;
+  }
   P[TCELLS + tid] = (uint16_t)(FX_SLOT0 + 2u * tid);  // a root word points at itself
   if (tid == 0) P[TCELLS + PSL] = (uint16_t)FX_NOBODY;
   // a tile without a nodata byte in its staging area (most tiles of a land raster) has no "flow into nodata ends
@@ -315,6 +328,22 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       if (w[s]) atomicAdd((u32 *)((u8 *)A + (x[s] << (FXP == 8 ? 4 : 3)) + rep), w[s]);  // word slot * FXP + replica
+    if (WIDE) {  // the same walk with the cells' 64-bit weights (a quad shares its row: one pair of row words)
+      const u32 lr = (tid >> 4) + 16u * j;
+      const u64 wr = a.wrow[(u32)(r0 + lr)];
+      const u32 wf = a.wfrac[(u32)(r0 + lr)];
+      u64 v[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = x[s] < 2u * PSL ? w_cell(wr, wf, (u32)c0 + lcq + (sh[s] >> 3)) : 0ull;
+      const bool e10 = x[1] == x[0], e20 = x[2] == x[0], e21 = x[2] == x[1], e30 = x[3] == x[0], e31 = x[3] == x[1], e32 = x[3] == x[2];
+      v[0] += (e10 ? v[1] : 0ull) + (e20 ? v[2] : 0ull) + (e30 ? v[3] : 0ull);
+      v[1] = e10 ? 0ull : v[1] + ((!e20 && e21) ? v[2] : 0ull) + ((!e30 && e31) ? v[3] : 0ull);
+      v[2] = (e20 || e21) ? 0ull : v[2] + ((!e30 && !e31 && e32) ? v[3] : 0ull);
+      v[3] = (e30 || e31 || e32) ? 0ull : v[3];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        if (v[s]) atomicAdd((unsigned long long *)&A64[(x[s] >> 1) * 4u + (tid & 3u)], (unsigned long long)v[s]);
+    }
   }
   __syncthreads();
 
@@ -344,6 +373,7 @@ __global__ void __launch_bounds__(256) k_tile_local_fast(TileArgs a) {
   }
   a.xT[sbase + tid] = xt;
   a.xrec[sbase + tid] = xr_pack(xt12 & 0xFFu, xt12 >> 8, link, inmask);
+  if (WIDE) a.xT64[sbase + tid] = (tid < NPERIM && xt12 != XR_NONE) ? A64[4u * tid] + A64[4u * tid + 1] + A64[4u * tid + 2] + A64[4u * tid + 3] : 0ull;
   const u64 xm = __ballot(xt12 != XR_NONE);  // (a wave = 64 consecutive slots)
   if ((tid & 63u) == 0u) a.xmask[(sbase + tid) >> 6] = xm;
 }

@@ -163,6 +163,11 @@ struct TileArgs {
   u64 *stamps;     // DEVTOOLS: [1024][8] cycle stamps, spread over 1024 rows against same-address atomics
   int ablate;      // profiling knob (env PFD_TILE_ABLATE): bit0 skip doubling, bit4 cycle stamps; bit5 (set by
                    // pfd_set_profiling(h, 2)) counts the doubling rounds per tile into ctrl[48..51]
+  // the fixed-point upstream area (wide.h): when xT64 is set, the local pass of the INTERIOR tiles also sums the 64-bit
+  // weights of its cells per exit (k_tile_local_fast<.., WIDE>) — the roots are in its registers anyway
+  const u64 *wrow = nullptr;   // [nrow] integer part of a cell's quantised area
+  const u32 *wfrac = nullptr;  // [nrow] the fraction the columns of the row share out (w_cell)
+  u64 *xT64 = nullptr;         // [nslots] 64-bit tile-local sum of the exit on the slot
 };
 
 // ---- device helpers shared by the tile kernels (tiled.hip, paths.hip) ---------------------------

@@ -1663,6 +1663,7 @@ int TiledRun::phase_a() {
     a.tcnt = tcntbuf.as<u64>();
     if (have_i) {
       if (a.weights) k_tile_local_fast<true, true><<<gridi, 256, 0, h->stream>>>(a);
+      else if (a.xT64) k_tile_local_fast<true, false, true><<<gridi, 256, 0, h->stream>>>(a);
       else if (use_patch) k_tile_local_patch<true><<<gridi, 256, 0, h->stream>>>(a);
       else k_tile_local_fast<true, false><<<gridi, 256, 0, h->stream>>>(a);
       pfd_seg_end(h, 1);
@@ -1679,6 +1680,7 @@ int TiledRun::phase_a() {
   } else {
     if (have_i) {
       if (a.weights) k_tile_local_fast<false, true><<<gridi, 256, 0, h->stream>>>(a);
+      else if (a.xT64) k_tile_local_fast<false, false, true><<<gridi, 256, 0, h->stream>>>(a);
       else if (use_patch) k_tile_local_patch<false><<<gridi, 256, 0, h->stream>>>(a);
       else k_tile_local_fast<false, false><<<gridi, 256, 0, h->stream>>>(a);
       pfd_seg_end(h, 1);

@@ -39,13 +39,8 @@ struct WideArgs {
   const u64 *xtot;   // [nslots] (final) total of the exit on the slot
   double *out;
   double inv;        // 2^-s
+  u32 tr_lo = 0, tr_hi = 0, tc_lo = 0, tc_hi = 0;  // the interior rectangle of the count pass (k_wtile_local<true>: the frame around it)
 };
-
-// Weight of the cell in column c of a row with quantised area base + f / 2^32: base + floor((c + 1) f) - floor(c f)
-// (Bresenham along the row).  Rounding every cell of a row the same way would give a run of k cells the error
-// k * (rounding of the row); sharing the fraction out keeps the error of ANY run of consecutive cells of a row
-// below one quantum — and the upstream set of a cell is made of such runs.
-__device__ __forceinline__ u64 w_cell(u64 base, u32 f, u32 c) { return base + (u64)(__umulhi(c + 1u, f) - __umulhi(c, f)); }
 
 // the branch-free initial pointer of the cell in register slot s of quad (lr, lc0) — tile_body's general form
 __device__ __forceinline__ u32 w_init_ptr(u32 c, u32 l, int lr, int lc) {
@@ -57,6 +52,9 @@ __device__ __forceinline__ u32 w_init_ptr(u32 c, u32 l, int lr, int lc) {
   return go ? PHYS((u32)(nr * TS + nc)) << 1 : ((l << 1) | PDONE);
 }
 
+// FRAME: only the tiles of the frame around the interior rectangle (1-D grid) — the interior tiles' sums came out of the
+// count pass's own local kernel (k_tile_local_fast<.., WIDE>)
+template <bool FRAME>
 __global__ void __launch_bounds__(256) k_wtile_local(WideArgs a) {
   __shared__ __attribute__((aligned(16))) u64 A[PSL * 4];  // 4 replicas per perimeter slot, picked by lane
   __shared__ __attribute__((aligned(16))) uint16_t P[TCELLS];
@@ -64,7 +62,8 @@ __global__ void __launch_bounds__(256) k_wtile_local(WideArgs a) {
   __shared__ __attribute__((aligned(16))) u32 s_flag[2][4];
   const u32 tid = threadIdx.x;
   u32 tc, tr;
-  pfd_tile_of_block(&tc, &tr);
+  if (FRAME) frame_tile(blockIdx.x, a.ntr, a.ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi, &tr, &tc);
+  else pfd_tile_of_block(&tc, &tr);
   const u32 sbase = sslot_base(tr, tc, a.nstc);
   const i64 r0 = (i64)tr * TS, c0 = (i64)tc * TS;
   {
@@ -470,6 +469,14 @@ int pfd_upstream_area_wide_tiled(pfd_raster *h, const u64 *wrow_dev, const u32 *
   TiledRun run;
   PFDCHK(run.init(h, nullptr));
   if (!run.supported) return PFD_OK;
+  // the interior tiles' sums per exit come out of the count pass's own local kernel (TileArgs::xT64)
+  const size_t nslots = run.nslots;
+  DevBuf slots64, l3w;
+  PFDCHK(slots64.alloc(2 * nslots * sizeof(u64)));
+  u64 *xT64 = slots64.as<u64>(), *xtot64 = xT64 + nslots;
+  const char *uf = pfd_knob("PFD_WIDE_UNFUSED");  // (test knob: the separate local pass over every tile)
+  const bool fused = !(uf && atoi(uf) != 0) && !run.a.weights;
+  if (fused) run.a.wrow = wrow_dev, run.a.wfrac = wfrac_dev, run.a.xT64 = xT64;
   // ---- structure: the count pass without its final tile pass ----
   int ok = 0;
   for (int tries = 0; tries < 4; ++tries) {
@@ -495,7 +502,6 @@ int pfd_upstream_area_wide_tiled(pfd_raster *h, const u64 *wrow_dev, const u32 *
   HIPCHK(hipStreamSynchronize(h->stream));
   if (nflag) return PFD_OK;  // a supertile with more exits than the u64 LDS form holds (contrived rasters)
   const SuperArgs &sa = run.sa;
-  const size_t nslots = run.nslots;
   if (run.flat_nosync) {  // (the count of super-exits stayed on the device)
     u64 ns = 0;
     HIPCHK(hipMemcpyAsync(&ns, h->ctrl + T_NSUPER, sizeof(u64), hipMemcpyDeviceToHost, h->stream));
@@ -503,16 +509,18 @@ int pfd_upstream_area_wide_tiled(pfd_raster *h, const u64 *wrow_dev, const u32 *
     run.nsuper = (u32)ns;
   }
   const u32 n3 = sa.hmode ? (u32)((size_t)run.nht * HCAP) : run.nsuper;
-  DevBuf slots64, l3w;
-  PFDCHK(slots64.alloc(2 * nslots * sizeof(u64)));
   PFDCHK(l3w.alloc((size_t)std::max(n3, 1u) * (3 * sizeof(u64) + 2 * sizeof(u32))));
-  u64 *xT64 = slots64.as<u64>(), *xtot64 = xT64 + nslots;
   u64 *T[3] = {l3w.as<u64>(), l3w.as<u64>() + n3, l3w.as<u64>() + 2 * (size_t)n3};
   u32 *J[2] = {(u32 *)(l3w.as<u64>() + 3 * (size_t)n3), (u32 *)(l3w.as<u64>() + 3 * (size_t)n3) + n3};
   WideArgs wa{h->ncode, (u32)h->nrow, (u32)h->ncol, run.ntr, run.ntc, run.nstc, wrow_dev, wfrac_dev, run.xrec, xT64, xtot64, out_dev, inv};
   const dim3 grid(run.ntc, run.ntr);
   pfd_seg_begin(h, "wide_tile_local");
-  k_wtile_local<<<grid, 256, 0, h->stream>>>(wa);
+  if (fused) {
+    wa.tr_lo = run.a.tr_lo, wa.tr_hi = run.a.tr_hi, wa.tc_lo = run.a.tc_lo, wa.tc_hi = run.a.tc_hi;
+    k_wtile_local<true><<<frame_tiles(run.ntr, run.ntc, wa.tr_lo, wa.tr_hi, wa.tc_lo, wa.tc_hi), 256, 0, h->stream>>>(wa);
+  } else {
+    k_wtile_local<false><<<grid, 256, 0, h->stream>>>(wa);
+  }
   KCHK();
   pfd_seg_end(h, 1);
   pfd_seg_begin(h, "wide_exit_graph");

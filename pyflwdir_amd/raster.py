@@ -774,7 +774,15 @@ class FlwdirRaster(object):
         if np.any(idxs64 < 0) or np.any(idxs64 >= self.size):
             raise IndexError("idxs outside domain")
         nb = self._row_blocks_needed()
-        if nb > 1:  # beyond 32-bit cell indices: the row-block protocol of the multi-GPU path, blocks held by this process
+        if nb > 1:
+            # beyond 32-bit cell indices: the tiled label query addresses tiles and slots and runs on the whole raster
+            # (csrc/paths.hip pfd_basins_tiled); a raster with cycles needs the level engine's 32-bit order — then the
+            # row-block protocol of the multi-GPU path, blocks held by this process
+            if self._wide():
+                try:
+                    return self._h.basins(idxs64, ids).reshape(self.shape)
+                except NotImplementedError:
+                    pass
             from . import dist
 
             return dist.basins_blocks(self._d8, nb, idxs64, ids).reshape(self.shape)
@@ -906,7 +914,16 @@ class FlwdirRaster(object):
             rows = np.ascontiguousarray(gis.area_rows(self.transform, self.shape, self.latlon, unit="m2")
                                         / gis.AREA_FACTORS[unit])
         if self._row_blocks_needed() > 1:
-            ucat_map, ucat_are = self._ucat_area_wide(idx64, rows)
+            # the library's own form first (label query on the whole raster; float areas summed over the 64-bit sequence
+            # on the device, csrc/subgrid.hip ucat_float_wide); a raster with cycles: composed on the host
+            ucat_map = None
+            if self._wide():
+                try:
+                    ucat_map, ucat_are = self._h.ucat_area(idx64, self._idx_dtype, rows)
+                except NotImplementedError:
+                    pass
+            if ucat_map is None:
+                ucat_map, ucat_are = self._ucat_area_wide(idx64, rows)
         else:
             ucat_map, ucat_are = self._h.ucat_area(idx64, self._idx_dtype, rows)
         return ucat_map.reshape(self.shape), ucat_are.reshape(idxs_out.shape)

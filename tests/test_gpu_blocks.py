@@ -746,11 +746,33 @@ def test_front_end_order_ucat_snap_beyond_32_bit_indices(gpu_lib, oracle, monkey
     assert big._row_blocks_needed() == 4 and big._wide()
     assert big.isvalid and big.nnodes == exp["n"]
     assert np.array_equal(big.rank, exp["rank"]) and np.array_equal(big.idxs_seq, exp["seq"])
-    for unit in ("cell", "km2"):
-        m, a = big.ucat_area(outs, unit=unit)
-        assert m.dtype == exp[unit][0].dtype and np.array_equal(m, exp[unit][0]), unit
-        assert a.dtype == exp[unit][1].dtype and a.shape == outs.shape, unit
-        assert a.tobytes() == exp[unit][1].tobytes(), unit
+    # ucat_area runs in the library on the whole raster (round 6: the tiled label query at any size + the float sums over
+    # the 64-bit sequence in pieces, csrc/subgrid.hip ucat_float_wide) — pieces of 7001 and of 64 entries, and one piece
+    big._h.set_profiling(True)
+    for piece in ("7001", "64", None):
+        if piece:
+            monkeypatch.setenv("PFD_UCAT_PIECE", piece)
+        else:
+            monkeypatch.delenv("PFD_UCAT_PIECE")
+        for unit in ("cell", "km2"):
+            m, a = big.ucat_area(outs, unit=unit)
+            names = [s["name"] for s in big._h.last_timing()]
+            assert "tile_labels" in names and ("ucat_sums" in names) == (unit == "km2"), names
+            assert m.dtype == exp[unit][0].dtype and np.array_equal(m, exp[unit][0]), unit
+            assert a.dtype == exp[unit][1].dtype and a.shape == outs.shape, unit
+            assert a.tobytes() == exp[unit][1].tobytes(), unit
+    # the composed form (what a raster with cycles falls back to) stays pinned too
+    idx64 = np.where(outs.ravel() == big._mv, -1, outs.ravel().astype(np.int64))
+    from pyflwdir_amd import gis
+    rows = np.ascontiguousarray(gis.area_rows(big.transform, big.shape, big.latlon, unit="m2") / gis.AREA_FACTORS["km2"])
+    m, a = big._ucat_area_wide(idx64, rows)
+    assert np.array_equal(m.reshape(shape), exp["km2"][0]) and a.tobytes() == exp["km2"][1].tobytes()
+    # basins: one label query on the whole raster (any id width)
+    for dt in (np.uint32, np.uint8, np.int64):
+        ids = (np.arange(40) + 3).astype(dt)
+        got = big.basins(idxs=np.argsort(upa.ravel())[-40:], ids=ids)
+        assert "tile_labels" in [s["name"] for s in big._h.last_timing()]
+        assert got.dtype == dt and np.array_equal(got, whole.basins(idxs=np.argsort(upa.ravel())[-40:], ids=ids))
     for key, got in (("snap_down", big.snap(idxs=pts, mask=streams, unit="m")),
                      ("snap_up", big.snap(idxs=pts[:50], mask=upa < 3, direction="up", max_length=40))):
         assert np.array_equal(got[0], exp[key][0]) and np.array_equal(got[1], exp[key][1]), key

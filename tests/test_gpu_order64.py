@@ -59,6 +59,35 @@ def test_golden_cases_through_the_64_bit_form(name, small, manifest, wide):
     assert flw.idxs_seq.size == st["n_seq"] and np.all(np.diff(flw.rank.ravel()[flw.idxs_seq]) >= 0)
 
 
+def test_basins_and_ucat_area_of_a_cyclic_raster_beyond_32_bits(manifest, wide, monkeypatch):
+    """The one-handle label query is only taken on acyclic rasters (an outlet downstream of a cycle would hide it), and so
+    is the row-block protocol (pfd_basins_begin): with cycles AND 64-bit cells the library answers PFD_EUNSUPPORTED, the
+    front end passes it on — a stated limit (the 32-bit object answers through the level engine)."""
+    import pyflwdir_amd as pyflwdir
+    from pyflwdir_amd._affine import Affine
+
+    case = Case("synth_loops_96x80", manifest)
+    tf = Affine(0.01, 0, 4.0, 0, -0.01, 52.0)
+    monkeypatch.delenv("PFD_TEST_ORDER64")
+    whole = pyflwdir.from_array(case.d8, ftype="d8", transform=tf, latlon=True, cache=False)
+    valid = np.flatnonzero(case.d8.ravel() != 247)
+    outs = np.random.default_rng(1).choice(valid, 24, replace=False).astype(whole.idxs_ds.dtype)
+    exp_b = whole.basins(idxs=outs)
+    exp_u = {u: whole.ucat_area(outs, unit=u) for u in ("cell", "km2")}
+    monkeypatch.setenv("PFD_TEST_ORDER64", "1")
+    monkeypatch.setenv("PFD_TEST_BIG_CELLS", "2000")
+    big = pyflwdir.from_array(case.d8, ftype="d8", transform=tf, latlon=True, cache=False)
+    assert big._wide() and big._row_blocks_needed() > 1
+    with pytest.raises(NotImplementedError):
+        big._h.basins(outs.astype(np.int64), np.arange(1, 25, dtype=np.uint32))
+    assert exp_b.shape == case.shape and exp_u["km2"][1].dtype == np.float64
+    with pytest.raises(NotImplementedError, match="cycles"):
+        big.basins(idxs=outs)
+    for u in ("cell", "km2"):
+        with pytest.raises(NotImplementedError, match="cycles"):
+            big.ucat_area(outs, unit=u)
+
+
 @pytest.mark.parametrize("shape,small", [((700, 900), None), ((1500, 1100), "1000"), ((129, 4097), "0")])
 def test_seeded_raster_against_the_32_bit_form_and_the_oracle(shape, small, gpu_lib, oracle, wide):
     from pyflwdir_amd import _hip

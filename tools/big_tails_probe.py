@@ -45,3 +45,25 @@ for r0 in (1, size // 2 + 17, size - 1001):  # the main upstream cell drains int
 print(f"  main_upstream {t_mu:.1f} s  dtype {mu.dtype}  sampled main upstream cells drain into their cell: {ok}", flush=True)
 del mu
 t0 = time.perf_counter(); nu = flw.n_upstream; print(f"  n_upstream {time.perf_counter() - t0:.1f} s  histogram of 1e7 cells {np.bincount(nu.ravel()[:10_000_000] + 9)[9:14].tolist()}", flush=True)
+del nu
+# basins and ucat_area on ONE handle (round 6: the tiled label query runs at any size; the float sums of ucat_area walk the 64-bit
+# sequence on the device in pieces, csrc/subgrid.hip) — on a lat/lon grid (float64 areas) against the host-composed form
+from pyflwdir_amd._affine import Affine
+from pyflwdir_amd import gis
+res = 1.0 / 1200.0
+flw = pyflwdir.from_array(d8, ftype="d8", transform=Affine(res, 0.0, 5.0, 0.0, -res, 80.0), latlon=True, cache=False)
+top = np.argsort(upa.ravel()[:: 4097])[-500:].astype(np.int64) * 4097
+del upa
+t0 = time.perf_counter(); bas = flw.basins(idxs=top); t_b = time.perf_counter() - t0
+print(f"  basins, 500 outlets {t_b:.1f} s  dtype {bas.dtype}  labelled cells {int(np.count_nonzero(bas[::7]))} of {bas[::7].size} sampled", flush=True)
+t0 = time.perf_counter(); m_c, a_c = flw.ucat_area(top, unit="cell"); t_c = time.perf_counter() - t0
+ok_c = bool(np.array_equal(m_c[::5], bas[::5]))
+print(f"  ucat_area cell, 500 outlets {t_c:.1f} s  map dtype {m_c.dtype}  equals basins (sampled): {ok_c}  largest {np.sort(a_c)[-2:].tolist()}", flush=True)
+del m_c, bas
+t0 = time.perf_counter(); m_k, a_k = flw.ucat_area(top, unit="km2"); t_k = time.perf_counter() - t0
+print(f"  ucat_area km2, 500 outlets {t_k:.1f} s  area dtype {a_k.dtype}  largest {np.sort(a_k)[-2:].tolist()}", flush=True)
+del m_k
+if os.environ.get("PFD_PROBE_COMPOSED", "1") == "1":
+    rows = np.ascontiguousarray(gis.area_rows(flw.transform, flw.shape, flw.latlon, unit="m2") / gis.AREA_FACTORS["km2"])
+    t0 = time.perf_counter(); m2, a2 = flw._ucat_area_wide(top.copy(), rows); t2 = time.perf_counter() - t0
+    print(f"  the host-composed form (row-block basins + np.add.at over the sequence): {t2:.1f} s  areas bit-identical: {a2.tobytes() == a_k.tobytes()}", flush=True)
