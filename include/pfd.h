@@ -360,6 +360,10 @@ int pfd_stream_distance_block(pfd_raster *h, const uint8_t *mask, int real_lengt
 int pfd_floodplains_block(pfd_raster *h, int elev_dtype, const void *elevtn, const uint8_t *is_stream, const float *stream_h,
                           const void *halo_seed_host, int verify, void *state, int memspace, void *boundary_rows_host,
                           int64_t *n_bad);
+/* The int8 result of dem.floodplains (1 floodplain, 0 not, -1 off the sequence; dem.py:333-379) for the block's OWN rows,
+ * from the DEVICE-resident `state` of pfd_floodplains_block: own_rows * ncol bytes into `out` (host or device) — a caller
+ * that assembles the raster on the host moves 1 byte per cell instead of the 16-byte state records. */
+int pfd_floodplains_block_flags(pfd_raster *h, const void *state_dev, int8_t *out, int memspace);
 /* Classic stream order (reference pyflwdir/streams.py:191-225 with core.main_upstream, core.py:191-219) over row blocks.
  * pfd_trib_info_block: one byte per cell of the block's device raster — low 4 bits the slot (0-7; 15 none) of the cell's
  * main upstream cell (largest `uparea` > upa_min, first in ascending index), bit 4 set when more than one upstream cell

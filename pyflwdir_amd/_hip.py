@@ -41,7 +41,7 @@ SYMBOLS = [
     "pfd_synth_weights_f32", "pfd_graph_stats", "pfd_verify_upstream_area_cell", "pfd_verify_basins", "pfd_verify_hand", "pfd_hand_block", "pfd_accuflux_block", "pfd_strahler_block", "pfd_stream_distance_block", "pfd_checksum_i32", "pfd_basins_begin", "pfd_basins_finish", "pfd_fill_depressions", "pfd_ucat_area", "pfd_floodplains", "pfd_snap_downstream", "pfd_snap", "pfd_raster_create_general", "pfd_set_idxs_seq", "pfd_upstream_sum",
     "pfd_comm_exchange_rows", "pfd_comm_allgather_host", "pfd_set_block_io", "pfd_synth_mosaic", "pfd_calib_traffic", "pfd_set_block_update",
     "pfd_reserve", "pfd_alloc_stats", "pfd_mem_info", "pfd_transfer_stats", "pfd_count_nonfinite", "pfd_floodplains_block", "pfd_trib_info_block",
-    "pfd_stream_order_classic_block", "pfd_upstream_area_rows_fixed",
+    "pfd_stream_order_classic_block", "pfd_upstream_area_rows_fixed", "pfd_floodplains_block_flags",
 ]
 
 _lib = None
@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
                                    C.c_int, C.c_void_p, C.c_int]
         L.pfd_upstream_area_rows_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                                    C.POINTER(C.c_double)]
+        L.pfd_floodplains_block_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_strahler.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.pfd_basins.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.pfd_hand.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -584,6 +585,15 @@ class RasterHandle:
         check(lib().pfd_floodplains_block(self._h, int(elev_code), ptr(elevtn), ptr(is_stream), ptr(stream_h), ptr(halo_seed),
                                           1 if verify else 0, ptr(state), memspace, ptr(brows), C.byref(bad)))
         return brows, int(bad.value)
+
+    def floodplains_block_flags(self, state: "DeviceBuffer", out=None) -> np.ndarray:
+        """int8 flags of the block's own rows from its device-resident floodplain state (pfd_floodplains_block_flags);
+        ``out``: a C-contiguous int8 array of own_rows * ncol cells to fill (e.g. the block's rows of the whole result)."""
+        if out is None:
+            out = np.empty((self.nrow, self.ncol), np.int8)
+        assert out.dtype == np.int8 and out.flags.c_contiguous and out.size == self.nrow * self.ncol
+        check(lib().pfd_floodplains_block_flags(self._h, ptr(state), ptr(out), PFD_HOST))
+        return out
 
     def strahler_block(self, mask, halo_seed, out, verify=False, memspace=PFD_HOST):
         """Strahler order of a row block whose halo cells hold ``halo_seed`` (2 * ncol uint8, host).  Returns

@@ -2377,6 +2377,22 @@ extern "C" int pfd_floodplains(pfd_raster *h, int elev_dtype, const void *elevtn
   return o.finish(h->stream);  // (synchronises: `st` may be released afterwards)
 }
 
+// the int8 flags of a row block's OWN rows from its device-resident state (pfd_floodplains_block): what a caller that
+// assembles the raster on the host downloads — 1 byte per cell instead of the 16-byte records
+extern "C" int pfd_floodplains_block_flags(pfd_raster *h, const void *state_dev, int8_t *out, int memspace) {
+  PFDCHK(pfd_check_handle(h));
+  if (!state_dev || !out) {
+    pfd_set_error("pfd_floodplains_block_flags: NULL state or out");
+    return PFD_EINVAL;
+  }
+  const u32 n_own = (u32)((size_t)h->own_rows * h->ncol);
+  OutArg o;
+  PFDCHK(o.bind(out, (size_t)n_own, memspace));
+  if (n_own) k_flood_out<<<cdiv_u32(n_own, 256), 256, 0, h->stream>>>((const FloodV *)state_dev + (size_t)h->halo_top * h->ncol, n_own, (int8_t *)o.dev);
+  KCHK();
+  return o.finish(h->stream);
+}
+
 // dem.floodplains of a ROW BLOCK (reference pyflwdir/dem.py:333-379), the down- to upstream twin of pfd_hand_block /
 // pfd_stream_distance_block: a halo cell the block drains into holds the neighbouring block's STATE — (z, h, flag) of the
 // floodplain that cell is in, 16 bytes — as `halo_seed_host` gives it; the caller exchanges the boundary rows of the

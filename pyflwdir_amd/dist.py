@@ -243,6 +243,7 @@ class _StreamedBlock(_SeedGate):
     def __init__(self, make):
         self.make, self.host = make, None
         self.swept_with, self.brows = None, None
+        self.into = None  # (optional: the block's rows of the caller's result array — result(out=) of the block fills them)
 
     def _call(self, seed, verify):
         if verify:
@@ -253,7 +254,7 @@ class _StreamedBlock(_SeedGate):
             if hasattr(blk, "incremental"):
                 blk.incremental = False  # (nothing is kept between the sweeps)
             out = blk._call(seed, False)
-            self.host = blk.result()
+            self.host = blk.result() if self.into is None else blk.result(self.into)
             return out
         finally:
             blk.close()
@@ -603,13 +604,24 @@ class _FloodBlock(_SeedGate):
     """Device-resident state of one row block of dem.floodplains between the exchanges: elevation, stream flags, height
     thresholds and the floodplain state (16 bytes per cell) stay in HBM; only the two boundary rows of the state travel."""
 
-    def __init__(self, handle, elevtn_rows, elev_code, is_stream_rows, stream_h_rows):
+    def __init__(self, handle, elevtn_rows, elev_code, is_stream_rows, stream_h_rows, pool=None):
         self.h, self.code = handle, elev_code
         ncol, dev = handle.ncol, handle.device
         self.nrows_dev = handle.nrow + sum(handle.halo)
-        up = lambda a: _hip.DeviceBuffer(a.nbytes, dev).upload(np.ascontiguousarray(a))  # noqa: E731
-        self.elev, self.stream, self.hs = up(elevtn_rows), up(is_stream_rows), up(stream_h_rows)
-        self.state = _hip.DeviceBuffer(self.nrows_dev * ncol * _hip.FLOOD_STATE.itemsize, dev)
+        # ``pool`` (streamed blocks: {"rows": the most device rows any block has}): the four buffers are allocated once
+        # for the largest block and serve every block of the call — a hipMalloc of tens of GB takes longer than filling it
+        self.pool = pool
+
+        def buf(name, bytes_per_cell):
+            if pool is None:
+                return _hip.DeviceBuffer(self.nrows_dev * ncol * bytes_per_cell, dev)
+            if name not in pool:
+                pool[name] = _hip.DeviceBuffer(max(pool["rows"], self.nrows_dev) * ncol * bytes_per_cell, dev)
+            return pool[name]
+
+        up = lambda name, a: buf(name, a.dtype.itemsize).upload(np.ascontiguousarray(a))  # noqa: E731
+        self.elev, self.stream, self.hs = up("elev", elevtn_rows), up("stream", is_stream_rows), up("hs", stream_h_rows)
+        self.state = buf("state", _hip.FLOOD_STATE.itemsize)
         self.swept_with, self.brows = None, None
 
     def _call(self, seed, verify):
@@ -619,14 +631,15 @@ class _FloodBlock(_SeedGate):
     def verify(self, seed):
         return self._call(seed, True)[1]
 
-    def result(self):
-        ncol, sz = self.h.ncol, _hip.FLOOD_STATE.itemsize
-        st = self.state.download(_hip.FLOOD_STATE, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol * sz)
-        return st["flag"].astype(np.int8)
+    def result(self, out=None):
+        """int8 flags of the own rows (``out``: the block's rows of the whole result, filled in place) — extracted from the
+        16-byte state records on the device (pfd_floodplains_block_flags): 1 byte per cell crosses PCIe."""
+        return self.h.floodplains_block_flags(self.state, out)
 
     def close(self, close_handle=True):
-        for b in (self.elev, self.stream, self.hs, self.state):
-            b.free()
+        if self.pool is None:
+            for b in (self.elev, self.stream, self.hs, self.state):
+                b.free()
         if close_handle:
             self.h.close()
 
@@ -649,19 +662,32 @@ def floodplains_blocks(d8: np.ndarray, nblocks: int, elevtn, is_stream, stream_h
     devices = devices or [0] * nblocks
     brows = block_rows(nrow, nblocks)
 
+    stream = _stream_blocks(d8.size, elevtn.dtype.itemsize + 5 + 2 * _hip.FLOOD_STATE.itemsize + 28, devices)
+    pool = {"rows": max(e - a for a, e in (block_slice(nrow, nblocks, b) for b in range(nblocks)))} if stream else None
+
     def make(b):
         a, e = block_slice(nrow, nblocks, b)
         h = _hip.RasterHandle(d8[a:e], brows[b][1] - brows[b][0], ncol, device=devices[b], halo=halo_of(b, nblocks))
-        return _FloodBlock(h, elevtn[a:e], _ELEV_CODE[elevtn.dtype], is_stream[a:e], stream_h[a:e])
+        return _FloodBlock(h, elevtn[a:e], _ELEV_CODE[elevtn.dtype], is_stream[a:e], stream_h[a:e], pool=pool)
 
     blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks), down=True),
-                        _stream_blocks(d8.size, elevtn.dtype.itemsize + 5 + 2 * _hip.FLOOD_STATE.itemsize + 28, devices))
+                        stream)
     try:
+        out = np.empty((nrow, ncol), np.int8)  # (every block writes its own rows: no concatenation of 8 GB at 8.1 Gcells)
+        for b, blk in enumerate(blocks):
+            if isinstance(blk, _StreamedBlock):
+                blk.into = out[brows[b][0]:brows[b][1]]
         it, bad = _up_blocks_run(blocks, ncol, _hip.FLOOD_STATE, max_iter=max_iter, verify=verify)
-        return np.concatenate([blk.result() for blk in blocks], axis=0), it, bad
+        for b, blk in enumerate(blocks):
+            if not isinstance(blk, _StreamedBlock):
+                blk.result(out[brows[b][0]:brows[b][1]])
+        return out, it, bad
     finally:
         for blk in blocks:
             blk.close()
+        for b in (pool or {}).values():
+            if isinstance(b, _hip.DeviceBuffer):
+                b.free()
 
 
 class _HandBlock:
