@@ -53,3 +53,19 @@ for k, v in T.items():
     print(f"  {k}: {v:.1f} s in {N[k]} calls")
 print(f"  allocator: {_hip.alloc_stats()}")
 print(f"  front end outside dist.floodplains_blocks: {total - T['dist.floodplains_blocks (all)']:.1f} s")
+
+# HAND through the same streamed row blocks (dist.hand_blocks)
+if os.environ.get("PFD_PROBE_HAND", "1") == "1":
+    T.clear(); N.clear()
+    timed(dist, "hand_blocks", "dist.hand_blocks (all)")
+    timed(dist, "_hand_inputs", "  _hand_inputs (dtype + finite checks)")
+    timed(dist._StreamedHandBlock, "sweep", "  streamed block: handle + uploads + sweep + download")
+    timed(_hip.RasterHandle, "hand_block", "    RasterHandle.hand_block")
+    drain = upa > 1000
+    t0 = time.perf_counter()
+    hand = flw.hand(drain, elev)
+    total = time.perf_counter() - t0
+    print(f"{size}x{size}: hand {total:.1f} s  max {float(np.nanmax(hand[::97])):.1f} (sampled rows)")
+    for k, v in T.items():
+        print(f"  {k}: {v:.1f} s in {N[k]} calls")
+    print(f"  front end outside dist.hand_blocks: {total - T['dist.hand_blocks (all)']:.1f} s")
