@@ -404,7 +404,11 @@ int pfd_fill_depressions(int dtype, const void *elevtn, int64_t nrow, int64_t nc
  * catchment map and area.  `idxs_out`: k outlet cells (HOST; < 0 = missing).  map_out: n labels of map_dtype
  * (PFD_I32/U32/I64; label i+1 for outlet i, 0 elsewhere).  area_dtype PFD_I32: cell counts (area_rows NULL);
  * PFD_F32/PFD_F64: `area_rows` = nrow HOST values, the area of a cell of that row; area_out: k HOST values of
- * area_dtype (-9999 for missing outlets), float sums accumulated in the reference's (idxs_seq) order. */
+ * area_dtype (-9999 for missing outlets), float sums accumulated in the reference's (idxs_seq) order.
+ * Any raster size (round 6): beyond 2^32 - 2 cells the label query runs on the whole raster (tiles and slots, 32-bit
+ * values) and the float sums walk the 64-bit sequence (csrc/order64.hip) in sorted pieces, bit-identical to the
+ * reference's loop; a raster of that size WITH cycles returns PFD_EUNSUPPORTED (its label query needs the level
+ * engine's 32-bit order) — as does pfd_basins, which otherwise runs at any size too. */
 int pfd_ucat_area(pfd_raster *h, const int64_t *idxs_out, int64_t k, int map_dtype, void *map_out, int memspace,
                   int area_dtype, const void *area_rows, void *area_out);
 /* dem.floodplains (reference pyflwdir/dem.py:333-379; FlwdirRaster.floodplains pyflwdir.py:1513-1545):
