@@ -107,6 +107,53 @@ def main():
             nd = nu[rr + 1 + dr[k], cc + 1 + dc[k]]
             assert np.all((ou == od) | (ou == od + 1)) and np.all(nd[ou > od] > 1) and np.all(ou[nd == 1] == od[nd == 1])
     del so, nup
+    # ---- basins and ucat_area on ONE handle (round 6: the tiled label query at any size; the float64 sums of ucat_area over
+    # the 64-bit sequence on the device) by what defines them (basins.py:12-18, subgrid.py:51-93): an outlet carries its own
+    # label, every other cell its downstream cell's; a catchment's cell count is the number of cells with its label, its
+    # area the sum of their row areas (the device adds them in sequence order, a row-count dot product in another:
+    # equal to 1e-12 relative)
+    from pyflwdir_amd import gis
+
+    upa_s = flw.upstream_area()[::, ::4097]  # (a strided sample to pick outlets from)
+    cols = np.arange(0, size, 4097)
+    flat = np.argsort(upa_s.ravel())[-300:]
+    outs = (flat // cols.size).astype(np.int64) * size + cols[flat % cols.size]
+    del upa_s
+    t0 = time.perf_counter()
+    bas = flw.basins(idxs=outs)
+    t_b = time.perf_counter() - t0
+    assert bas.dtype == np.uint32 and np.array_equal(bas.ravel()[outs], np.arange(1, outs.size + 1, dtype=np.uint32))
+    is_out = np.zeros(n, bool)
+    is_out[outs] = True
+    is_out = is_out.reshape(size, size)
+    for r0 in (0, 20000, size - 1001):
+        blk, lb, io = d8[r0:r0 + 1001], bas[r0:r0 + 1001], is_out[r0:r0 + 1001]
+        for k in range(8):
+            rr, cc = np.nonzero((blk[1:-1, 1:-1] == (1 << k)) & ~io[1:-1, 1:-1])
+            assert np.array_equal(lb[rr + 1, cc + 1], lb[rr + 1 + dr[k], cc + 1 + dc[k]])
+        assert np.all(lb[(blk == 0) & ~io] == 0)  # a pit that is no outlet: label 0
+    del is_out
+    t0 = time.perf_counter()
+    m_c, a_c = flw.ucat_area(outs, unit="cell")
+    t_c = time.perf_counter() - t0
+    assert m_c.dtype == np.int64 and a_c.dtype == np.int32
+    t0 = time.perf_counter()
+    m_k, a_k = flw.ucat_area(outs, unit="km2")
+    t_k = time.perf_counter() - t0
+    assert a_k.dtype == np.float64
+    rows = gis.area_rows(flw.transform, flw.shape, flw.latlon, unit="m2") / gis.AREA_FACTORS["km2"]
+    big3 = np.argsort(a_c)[-3:]
+    per_row = np.zeros((3, size), np.int64)
+    for r0 in range(0, size, 4096):
+        assert np.array_equal(m_c[r0:r0 + 4096], bas[r0:r0 + 4096]) and np.array_equal(m_k[r0:r0 + 4096], bas[r0:r0 + 4096])
+        for j, i in enumerate(big3):
+            per_row[j, r0:r0 + 4096] = np.count_nonzero(bas[r0:r0 + 4096] == i + 1, axis=1)
+    for j, i in enumerate(big3):
+        assert int(per_row[j].sum()) == int(a_c[i])
+        ref = float(np.dot(per_row[j].astype(np.float64), rows))
+        assert abs(float(a_k[i]) - ref) <= 1e-9 * ref
+    print(f"66000^2, 300 outlets on one handle: basins {t_b:.2f} s, ucat_area cell {t_c:.2f} s, km2 {t_k:.2f} s")
+    del bas, m_c, m_k
     # ---- the same raster with a cycle: two neighbouring headwater-side cells made to drain into each other ----------
     r, c = 5, 40000
     d8[r, c], d8[r, c + 1] = 1, 16  # E and W
