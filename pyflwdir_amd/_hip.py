@@ -269,8 +269,11 @@ class DeviceBuffer:
         check(lib().pfd_memcpy_h2d(self.device, C.c_void_p(self.addr), ptr(arr), C.c_size_t(arr.nbytes)))
         return self
 
-    def download(self, dtype, shape, offset_bytes: int = 0) -> np.ndarray:
-        out = np.empty(shape, dtype)
+    def download(self, dtype, shape, offset_bytes: int = 0, out=None) -> np.ndarray:
+        """``out``: a C-contiguous array of that dtype and size to fill (e.g. a block's rows of the whole result)."""
+        if out is None:
+            out = np.empty(shape, dtype)
+        assert out.dtype == np.dtype(dtype) and out.flags.c_contiguous and out.size == int(np.prod(shape))
         assert out.nbytes + offset_bytes <= self.nbytes
         check(lib().pfd_memcpy_d2h(self.device, ptr(out), C.c_void_p(self.addr + offset_bytes), C.c_size_t(out.nbytes)))
         return out

@@ -579,6 +579,9 @@ extern "C" int pfd_memcpy_h2d(int device, void *dst_dev, const void *src_host, s
 }
 extern "C" int pfd_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes) {
   PFDCHK(select_device(device));
+  // a large download into fresh pages is bound by the copy's own first-touch faults (15-20 GB/s): a few host threads touch
+  // the pages first (pfd_prefault_begin: nothing for small buffers), then the copy runs at the PCIe rate
+  (void)pfd_prefault_join(pfd_prefault_begin(dst_host, bytes));
   HIPCHK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
   return PFD_OK;
 }

@@ -325,6 +325,24 @@ def _blocks_of(nblocks, make, relevant, stream):
     return blocks
 
 
+def _result_array(blocks, rows, ncol, dtype):
+    """The whole result of a call, allocated up front: streamed blocks fill their rows when they sweep (``into``), resident
+    ones when ``_collect`` asks — no per-block host arrays, no concatenation (at 8.1 Gcells those were 32-65 GB allocated,
+    copied and freed again: seconds of page faults and munmap)."""
+    out = np.empty((rows[-1][1], ncol), dtype)
+    for b, blk in enumerate(blocks):
+        if isinstance(blk, _StreamedBlock):
+            blk.into = out[rows[b][0]:rows[b][1]]
+    return out
+
+
+def _collect(blocks, rows, out):
+    for b, blk in enumerate(blocks):
+        if not isinstance(blk, _StreamedBlock):
+            blk.result(out[rows[b][0]:rows[b][1]])
+    return out
+
+
 LAST_SWEEPS = []  # sweeps per block of the last fixpoint iteration of this process (diagnostics, tools/bench_down_blocks.py)
 
 
@@ -383,11 +401,11 @@ class _UpBlock(_SeedGate):
         """Own cells whose value is not the one their upstream cells (halo values included) give."""
         return self._call(seed, True)[1]
 
-    def result(self):
+    def result(self, out=None):
         if self.out_given:
             return self.out
         ncol, sz = self.h.ncol, self.dtype.itemsize
-        return self.out.download(self.dtype, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol * sz)
+        return self.out.download(self.dtype, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol * sz, out=out)
 
     def close(self, close_handle=True):
         for b in (self.payload, self.mask, None if self.out_given else self.out):
@@ -484,8 +502,9 @@ def accuflux_blocks(d8: np.ndarray, nblocks: int, data, nodata_args=(0, 0.0, 0),
                                                                down=direction != "up"),
                         _stream_blocks(d8.size, (1 if by_row else 2) * dtype.itemsize + 28, devices))
     try:
+        out = _result_array(blocks, rows, ncol, dtype)
         it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
-        return _concat_rows([blk.result() for blk in blocks]), it, bad
+        return _collect(blocks, rows, out), it, bad
     finally:
         for blk in blocks:
             blk.close()
@@ -514,8 +533,9 @@ def stream_distance_blocks(d8: np.ndarray, nblocks: int, mask=None, step_lengths
     blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks), down=True),
                         _stream_blocks(d8.size, 4 + (mask is not None) + 28, devices))
     try:
+        out = _result_array(blocks, brows, ncol, dtype)
         it, bad = _up_blocks_run(blocks, ncol, dtype, max_iter=max_iter, verify=verify)
-        return _concat_rows([blk.result() for blk in blocks]), it, bad
+        return _collect(blocks, brows, out), it, bad
     finally:
         for blk in blocks:
             blk.close()
@@ -541,8 +561,9 @@ def strahler_blocks(d8: np.ndarray, nblocks: int, mask=None, devices=None, verif
     blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks), down=False),
                         _stream_blocks(d8.size, 1 + (mask is not None) + 28, devices))
     try:
+        out = _result_array(blocks, brows, ncol, np.uint8)
         it, bad = _up_blocks_run(blocks, ncol, np.uint8, max_iter=max_iter, verify=verify)
-        return _concat_rows([blk.result() for blk in blocks]), it, bad
+        return _collect(blocks, brows, out), it, bad
     finally:
         for blk in blocks:
             blk.close()
@@ -567,9 +588,9 @@ class _ClassicBlock(_SeedGate):
     def verify(self, seed):
         return self._call(seed, True)[1]
 
-    def result(self):
+    def result(self, out=None):
         ncol = self.h.ncol
-        return self.out.download(np.uint8, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol)
+        return self.out.download(np.uint8, (self.h.nrow, ncol), offset_bytes=self.h.halo[0] * ncol, out=out)
 
     def close(self, close_handle=True):
         for b in (self.tinfo, self.mask, self.out):
@@ -630,8 +651,9 @@ def classic_blocks(d8: np.ndarray, nblocks: int, uparea, mask=None, upa_min=0.0,
 
         blocks = _blocks_of(nblocks, make, lambda b: relevant_halo(d8[slice(*block_slice(nrow, nblocks, b))], halo_of(b, nblocks),
                                                                    down=True), stream)
+        out = _result_array(blocks, brows, ncol, np.uint8)
         it, bad = _up_blocks_run(blocks, ncol, np.uint8, max_iter=max_iter, verify=verify)
-        return _concat_rows([blk.result() for blk in blocks]), it, bad
+        return _collect(blocks, brows, out), it, bad
     finally:
         for h in handles.values():
             h.close()

@@ -244,6 +244,28 @@ def from_dem(data, nodata=-9999.0, max_depth=-1.0, transform=gis.IDENTITY, latlo
     return from_array(d8, ftype="d8", check_ftype=False, transform=transform, latlon=latlon)
 
 
+
+def _fill_where(out, codes, code, value, rows_per=None):
+    """``out[codes == code] = value`` for rasters of billions of cells: row pieces on host threads (one numpy pass over
+    8.1 Gcells — the comparison, its 8 GB mask, the masked store — took 5 s of ``upstream_area("km2")``)."""
+    nrow = out.shape[0]
+    rows_per = rows_per or max(1, (1 << 25) // max(1, out.shape[1]))
+
+    def piece(r0):
+        o, c = out[r0:r0 + rows_per], codes[r0:r0 + rows_per]
+        m = c == code
+        if m.any():
+            o[m] = value
+
+    starts = range(0, nrow, rows_per)
+    if len(starts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(min(16, len(starts), os.cpu_count() or 1)) as ex:
+            list(ex.map(piece, starts))
+    elif nrow:
+        piece(0)
+
 _FLOOD_PIECE = 1 << 25  # cells per host-thread piece of floodplains' input preparation
 
 class FlwdirRaster(object):
@@ -594,7 +616,7 @@ class FlwdirRaster(object):
 
             self._refuse_cycles_in_blocks("upstream_area")
             out = dist.accuflux_blocks(self._d8, nb, rows, (-9999, -9999.0, 1), by_row=True)[0]
-            out[self._d8 == D8_MV] = -9999
+            _fill_where(out, self._d8, D8_MV, -9999)
             return out
         out = self._h.accuflux_rows(rows, _PAYLOAD[rows.dtype], nodata_i=-9999, nodata_f=-9999.0, has_nodata=1,
                                     direction=_hip.PFD_UP, mask_invalid=1)
