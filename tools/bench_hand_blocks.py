@@ -71,8 +71,53 @@ for it in range(2, 65):
         per.append(sweep(b, True))
         prev[b] = seeds[b].copy()
     times.append(per)
+# The same protocol as an RCCL rank runs it (DistributedRaster._hand_rccl): halo seeds in a DEVICE buffer
+# (pfd_set_block_io(PFD_DEVICE)), nothing but the count of unknown cells crosses PCIe inside a pass; the boundary rows move
+# between the blocks' buffers OUTSIDE the timed calls (on hardware: ncclSend / ncclRecv of 2 x ncol float64 per neighbour).
+dev_times = None
+if os.environ.get("PFD_TOOL_DEVICE_IO", "1") == "1":
+    sbuf = [_hip.DeviceBuffer(2 * ncol * 8).upload(np.full(2 * ncol, -np.inf)) for _ in range(nb)]
+    for hb in hs:
+        hb.set_block_io(_hip.PFD_DEVICE)
+    def sweep_dev(b, update):
+        a, e = dist.block_slice(nrow, nb, b)
+        t0 = time.perf_counter()
+        _, _, nunk[b] = hs[b].hand_block(drain.addr + a * ncol, elev.addr + a * ncol * 4, _hip.PFD_F32, sbuf[b], out=outs[b],
+                                         memspace=_hip.PFD_DEVICE, update=update)
+        sync()
+        return round((time.perf_counter() - t0) * 1e3, 2)
+    def own_row(b, last):
+        top = dist.halo_of(b, nb)[0]
+        r = top + (rows[b][1] - rows[b][0] - 1 if last else 0)
+        return outs[b].download(np.float64, (ncol,), offset_bytes=r * ncol * 8)
+    dev_times = [[sweep_dev(b, False) for b in range(nb)]]
+    seen = [np.full(2 * ncol, -np.inf) for _ in range(nb)]
+    for it_dev in range(2, 65):
+        if sum(nunk) == 0:
+            it_dev -= 1
+            break
+        per = []
+        first_last = [(own_row(b, False), own_row(b, True)) for b in range(nb)]
+        for b in range(nb):
+            sd = seen[b].copy()
+            if b > 0: sd[:ncol] = first_last[b - 1][1]
+            if b + 1 < nb: sd[ncol:] = first_last[b + 1][0]
+            if np.array_equal(sd.view(np.uint64), seen[b].view(np.uint64)):
+                continue
+            seen[b] = sd
+            sbuf[b].upload(sd)
+            per.append(sweep_dev(b, True))
+        dev_times.append(per)
+    for hb in hs:
+        hb.set_block_io(_hip.PFD_HOST)
 print(f"{nrow}x{ncol}, {nb} row blocks, drain = upa > {thr}: whole raster on one handle {t_whole*1e3:.1f} ms (warm);")
 print(f"  first call per block (builds the block's plan / level structure + full sweep) {t_cold} ms")
 print(f"  exchanges {it}; full sweep per block (structure cached) {times[0]} ms; later passes (unknown cells only) {times[1:]}")
 print(f"  per-GPU critical path, warm ~ max full sweep {max(times[0]):.1f} ms + sum of later maxima {sum(max(t) for t in times[1:] if t):.1f} ms"
       f"; cold ~ {max(t_cold):.1f} ms + the same")
+if dev_times:
+    later = sum(max(t) for t in dev_times[1:] if t)
+    print(f"  with the halo seeds on the device (what an RCCL rank runs; the rows move between the passes, untimed): exchanges {it_dev}; "
+          f"full sweep {dev_times[0]} ms; later passes {dev_times[1:]}")
+    print(f"  per-GPU critical path, device seeds ~ {max(dev_times[0]):.1f} + {later:.1f} ms = {max(dev_times[0]) + later:.1f} ms: "
+          f"{t_whole * 1e3 / (max(dev_times[0]) + later):.2f}x of the one-handle call on {nb} GPUs before the cost of the exchanges themselves")
