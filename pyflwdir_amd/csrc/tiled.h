@@ -113,6 +113,7 @@ struct SuperArgs {
   u8 *sover;        // [nst] set by k_exit_lists: the supertile holds more exits than the dense form keeps in LDS
   u32 scap;         // that capacity (SCAP; lowered by tests via PFD_TEST_SCAP)
   int ablate;       // DEVTOOLS experiments (PFD_SUPER_ABLATE): 1 skip the rounds, 2 skip the outputs, 4 no start-value gather
+  u32 st0 = 0;      // first supertile of the launch (k_exit_lists / k_boundary_records / k_super over a band of supertile rows)
 };
 
 // level-3 (hypertile = 4x4 supertiles) solve arguments; node ids k = ht*HCAP + i, i < hcnt[ht]
@@ -348,6 +349,15 @@ struct TiledRun {
   size_t n3cap = 0, n4cap = 0;
   u32 *J4fin = nullptr;
   int solve_exits(const u32 *start, i64 *launches, bool cleared = false, bool edge_down = false);
+  // phase A with the supertile-local part of the exit graph (exit lists, boundary records, first supertile solve) of a BAND
+  // of supertile rows running on the handle's second stream beside the local tile pass of the next band (PFD_BANDS)
+  int phase_a_bands(int bands);
+  bool setup_only = false, up_done = false;  // solve_exits: set up the solve and return / the first supertile solve has run
+  hipEvent_t band_ev[16] = {};
+  ~TiledRun() {
+    for (hipEvent_t e : band_ev)
+      if (e) (void)hipEventDestroy(e);
+  }
   bool edge_down_now = false;
   int level3_flat(i64 *launches);
   int level3_flat_nosync(i64 *launches);

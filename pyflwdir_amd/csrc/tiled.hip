@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
   __shared__ u32 cbase[SSL / 64];
   __shared__ u32 wsum[4];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const u32 st = blockIdx.x >> 4, part = blockIdx.x & 15u;  // 16 workgroups per supertile, 1024 slots (4 tiles) each
+  const u32 st = (blockIdx.x >> 4) + s.st0, part = blockIdx.x & 15u;  // 16 workgroups per supertile, 1024 slots (4 tiles) each
   const u32 base = st << SSHIFT;
   const u32 i0 = (part << 10) + 4u * tid;  // own slots i0 .. i0 + 3
   // (unconditional: slots of tiles beyond the raster edge are allocated, never written and have no mask bit)
@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(256) k_exit_lists(SuperArgs s) {
 // those super-exits itself, so every boundary cell gets one record (sb) naming its sources and the list index of the
 // exit its in-tile path reaches.  One thread per boundary cell, after k_exit_lists (xcb).
 __global__ void __launch_bounds__(256) k_boundary_records(SuperArgs s) {
-  const u32 st = blockIdx.x >> 3, t = ((blockIdx.x & 7u) << 8) + threadIdx.x;
+  const u32 st = (blockIdx.x >> 3) + s.st0, t = ((blockIdx.x & 7u) << 8) + threadIdx.x;
   u32 v = 0;
   if (t < 4u * SC - 4u) {
     u32 R, C;
@@ -909,8 +909,8 @@ __device__ __forceinline__ void super_solve(const SuperArgs &s, const u32 st) {
 
 template <bool FINAL>
 __global__ void __launch_bounds__(SNT, SNT == 512u ? 6 : 8) k_super(SuperArgs s) {
-  if (s.sover[blockIdx.x]) return;  // (more exits than SCAP: k_super_flagged takes it)
-  super_solve<FINAL, SCAP, SNT>(s, blockIdx.x);
+  if (s.sover[blockIdx.x + s.st0]) return;  // (more exits than SCAP: k_super_flagged takes it)
+  super_solve<FINAL, SCAP, SNT>(s, blockIdx.x + s.st0);
 }
 // the supertiles k_exit_lists flagged (contrived rasters only: normally none, and a grid of this 96 KB kernel over all
 // supertiles costs 60-90 us just to find that out): a small fixed grid walks their list
@@ -1610,7 +1610,9 @@ int TiledRun::solve_exits(const u32 *start, i64 *launches, bool cleared, bool ed
   flat_nosync = !is_block && sa.hmode && nht <= FLAT_MAX_HT && !(hs && atoi(hs) != 0);
   if (flat_nosync) sa.hmode = 0;
   xin3 = l3.as<u32>() + 5 * n3cap;  // (undo a rotation of level3_flat_nosync)
-  k_super<false><<<nst, SNT, 0, h->stream>>>(sa);
+  if (setup_only) return PFD_OK;  // (phase_a in bands: the caller launches the first solve band by band)
+  if (!up_done) k_super<false><<<nst, SNT, 0, h->stream>>>(sa);
+  up_done = false;
   k_super_flagged<false><<<std::min<u32>(nst, SFLAG_GRID), 1024, 0, h->stream>>>(sa);  // (normally none)
   KCHK();
   *launches += 2;
@@ -1656,6 +1658,10 @@ int TiledRun::phase_a() {
   const dim3 gridi(a.tc_hi - a.tc_lo, a.tr_hi - a.tr_lo);
   const bool have_i = gridi.x && gridi.y;
   const u32 gridf = frame_tiles(ntr, ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi);
+  if (const char *e = pfd_knob("PFD_BANDS")) {
+    const int bands = atoi(e);
+    if (bands > 1 && !is_block && have_i && !a.weights && !a.xT64 && !use_patch) return phase_a_bands(std::min(bands, 16));
+  }
   pfd_seg_begin(h, "tile_local");
   if (!h->normalised) {  // deferred handle: decode + validate + count inside the tile pass
     if (!tcntbuf.p) PFDCHK(tcntbuf.alloc((size_t)ntr * ntc * sizeof(u64)));
@@ -1711,6 +1717,64 @@ int TiledRun::phase_a() {
     launches += 3;
     KCHK();
   }
+  pfd_seg_end(h, launches);
+  return PFD_OK;
+}
+
+int TiledRun::phase_a_bands(int bands) {
+  PFDCHK(pfd_aux_stream(h));
+  const bool raw = !h->normalised;
+  const u32 gridf = frame_tiles(ntr, ntc, a.tr_lo, a.tr_hi, a.tc_lo, a.tc_hi);
+  pfd_seg_begin(h, "tile_local_frame");
+  if (raw) {
+    if (!tcntbuf.p) PFDCHK(tcntbuf.alloc((size_t)ntr * ntc * sizeof(u64)));
+    a.raw = h->raw;
+    a.tcnt = tcntbuf.as<u64>();
+    k_tile<false, true, true><<<gridf, 256, 0, h->stream>>>(a);
+    fused_norm = true;
+  } else {
+    k_tile<false, false, true><<<gridf, 256, 0, h->stream>>>(a);
+  }
+  KCHK();
+  pfd_seg_end(h, 1);
+  i64 launches = 0;
+  setup_only = true;
+  PFDCHK(solve_exits(xT, &launches, true, false));  // (pointers and modes of the solve: the first supertile solve reads them)
+  setup_only = false;
+  pfd_seg_begin(h, "tile_local");
+  const u32 nstr = cdiv_u32(ntr, SG);
+  const u32 nb_ = std::min<u32>((u32)bands, nstr);
+  i64 nl = 0;
+  for (u32 b = 0; b < nb_; ++b) {
+    const u32 sr0 = (u32)((u64)nstr * b / nb_), sr1 = (u32)((u64)nstr * (b + 1) / nb_);
+    const u32 lo = std::max(a.tr_lo, sr0 * SG), hi = std::min(a.tr_hi, sr1 * SG);
+    if (hi > lo) {
+      TileArgs ab = a;
+      ab.tr_lo = lo, ab.tr_hi = hi;
+      const dim3 g(a.tc_hi - a.tc_lo, hi - lo);
+      if (raw) k_tile_local_fast<true, false><<<g, 256, 0, h->stream>>>(ab);
+      else k_tile_local_fast<false, false><<<g, 256, 0, h->stream>>>(ab);
+      ++nl;
+    }
+    if (!band_ev[b]) HIPCHK(hipEventCreateWithFlags(&band_ev[b], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(band_ev[b], h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream2, band_ev[b], 0));
+    SuperArgs sb_ = sa;
+    sb_.st0 = sr0 * nstc;
+    const u32 nsb = (sr1 - sr0) * nstc;
+    k_exit_lists<<<nsb * 16, 256, 0, h->stream2>>>(sb_);
+    k_boundary_records<<<nsb * (SBN / 256), 256, 0, h->stream2>>>(sb_);
+    k_super<false><<<nsb, SNT, 0, h->stream2>>>(sb_);
+    launches += 3;
+  }
+  KCHK();
+  HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+  HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  pfd_seg_end(h, nl);
+  if (raw) k_tile_counts<<<std::min<u32>(cdiv_u32((u64)ntr * ntc, 4096), 256u), 1024, 0, h->stream>>>(a.tcnt, ntr * ntc, h->ctrl);
+  pfd_seg_begin(h, "exit_graph");
+  up_done = true;
+  PFDCHK(solve_exits(xT, &launches, true, false));
   pfd_seg_end(h, launches);
   return PFD_OK;
 }
