@@ -124,7 +124,9 @@ def test_true_size_beyond_2_32_cells(gpu_lib):
     """66000 x 66000 = 4.356e9 cells (> 2**32 - 2: the int64 rung of pyflwdir.py:105-127) through the front end at TRUE size —
     no lowered threshold: the order-free fixed-point `upstream_area("km2")` on one handle against the exact row-block form,
     rank and the exact idxs_seq order by the properties that define them (core.py:17-47, :87-117, tests/test_core.py:66-82),
-    the classic stream order over row blocks by its local properties (streams.py:191-225), and the same raster with a cycle
+    the classic stream order over row blocks by its local properties (streams.py:191-225), basins and ucat_area on one handle
+    (labels follow the downstream cell; counts and float64 areas against a row-count dot product), floodplains over streamed
+    row blocks by its local equations (dem.py:333-379), and the same raster with a cycle
     injected: the cells that never reach a pit read -1 and are left out of the sequence.  The body is
     tests/true_size_child.py, in a child process (it holds a 120 GiB arena)."""
     import subprocess

@@ -154,6 +154,39 @@ def main():
         assert abs(float(a_k[i]) - ref) <= 1e-9 * ref
     print(f"66000^2, 300 outlets on one handle: basins {t_b:.2f} s, ucat_area cell {t_c:.2f} s, km2 {t_k:.2f} s")
     del bas, m_c, m_k
+    # ---- floodplains over streamed row blocks (dem.py:333-379) by its local equations: a stream cell (upstream area >= upa_min)
+    # is floodplain; any other cell is floodplain only if its downstream cell is, and — where the downstream cell is a stream
+    # cell, whose (z0, h0) are its own elevation and uparea ** b — exactly when elevtn - z0 <= h0 in float32
+    # (any elevation serves the local equations; the synthetic surface's float32 values are all tilt at this size — a periodic
+    #  pattern with steps of the order of the height thresholds instead: some cells beside every stream are floodplain, most not)
+    base = ((np.arange(4094, dtype=np.int64)[:, None] * 7 + np.arange(size, dtype=np.int64)[None, :] * 13) % 23).astype(np.float32)
+    elev = np.empty((size, size), np.float32)
+    for r0 in range(0, size, 4094):  # (4094 = 23 * 178: the pattern continues across the pieces)
+        elev[r0:r0 + 4094] = base[: min(4094, size - r0)]
+    del base
+    upa = flw.upstream_area().astype(np.float32)
+    upa_min, bexp = 3000.0, 0.3
+    t0 = time.perf_counter()
+    fld = flw.floodplains(elev, uparea=upa, upa_min=upa_min, b=bexp)
+    t_f = time.perf_counter() - t0
+    assert fld.dtype == np.int8 and fld.shape == (size, size) and int(fld.min()) >= 0  # (no nodata, no cycle: nothing off the sequence)
+    nflood = 0
+    for r0 in (0, 25000, size - 1001):
+        blk, f, u, z = d8[r0:r0 + 1001], fld[r0:r0 + 1001], upa[r0:r0 + 1001], elev[r0:r0 + 1001]
+        assert np.all(f[u >= upa_min] == 1)
+        for k in range(8):
+            rr, cc = np.nonzero((blk[1:-1, 1:-1] == (1 << k)) & (u[1:-1, 1:-1] < upa_min))
+            rd, cd = rr + 1 + dr[k], cc + 1 + dc[k]
+            fd, fu = f[rd, cd], f[rr + 1, cc + 1]
+            assert np.all(fu <= fd)  # floodplain only below a floodplain cell
+            st = u[rd, cd] >= upa_min  # the downstream cell starts a floodplain itself
+            h0 = (u[rd, cd][st] ** bexp).astype(np.float32)
+            dh = z[rr + 1, cc + 1][st] - z[rd, cd][st]
+            assert np.array_equal(fu[st] == 1, dh <= h0)
+            nflood += int(fu.sum())
+    assert nflood > 1000
+    print(f"66000^2 floodplains over streamed row blocks: {t_f:.2f} s ({nflood} floodplain cells off the streams in the sampled windows)")
+    del elev, upa, fld
     # ---- the same raster with a cycle: two neighbouring headwater-side cells made to drain into each other ----------
     r, c = 5, 40000
     d8[r, c], d8[r, c + 1] = 1, 16  # E and W
