@@ -247,3 +247,36 @@ def test_relevant_halo_cells_of_a_row_block():
     # bottom halo: col 0 N -> own 0; col 2 NW -> own 1; col 3 NE -> own 4
     assert up[ncol:].tolist() == [True, False, True, True, False, False]
     assert not relevant_halo(rows[1:], (0, 1), True)[:ncol].any()  # (no top halo row: nothing to depend on)
+
+
+def test_host_thread_helpers_of_the_wide_front_end(monkeypatch):
+    """The host-side pieces that assemble results of billions of cells (round 6): the same bytes as the one-piece numpy
+    expressions they replace — concatenation of row blocks, the finite check, the nodata fill — also across piece edges."""
+    from pyflwdir_amd import dist, raster
+
+    rng = np.random.default_rng(5)
+    parts = [rng.random((r, 3001)) for r in (700, 1, 1299, 350)]  # (> 2**28 bytes would take the threaded form: forced below)
+    exp = np.concatenate(parts, axis=0)
+    assert np.array_equal(dist._concat_rows(parts), exp)
+    big = [np.broadcast_to(rng.random((1, 1 << 16)), (1100, 1 << 16)) for _ in range(4)]  # 4 x 577 MB views, no memory behind them
+    got = dist._concat_rows(big)
+    assert got.shape == (4400, 1 << 16) and all(np.array_equal(got[1100 * i], big[i][0]) and np.array_equal(got[1100 * i + 1099], big[i][0])
+                                                for i in range(4))
+    del got
+    a = rng.random(70_000_001).astype(np.float32)
+    assert dist._all_finite(a) and dist._all_finite(a.reshape(1, -1))
+    for bad in (np.inf, -np.inf, np.nan):
+        a[-1] = bad
+        assert not dist._all_finite(a)
+    a[-1] = 0
+    a[(1 << 25) - 1] = np.nan  # (the last element of the first piece)
+    assert not dist._all_finite(a)
+    codes = rng.choice(np.array([1, 2, 4, 247, 0], np.uint8), size=(1000, 777))
+    out = rng.random((1000, 777))
+    exp = out.copy()
+    exp[codes == 247] = -9999
+    raster._fill_where(out, codes, 247, -9999, rows_per=37)  # (28 pieces on the host threads)
+    assert np.array_equal(out, exp)
+    out2 = exp.copy()
+    raster._fill_where(out2, codes, 255, -1.0)  # (nothing to fill, one piece)
+    assert np.array_equal(out2, exp)
