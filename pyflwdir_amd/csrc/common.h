@@ -124,6 +124,17 @@ __device__ __forceinline__ void pfd_tile_of_block(u32 *bx, u32 *by) {
     *bx = t - *by * gx;
   }
 }
+// the same for a 1-D grid over a chain-order array: XCD k takes one contiguous range of blocks.  Since the chains are laid
+// out tile by tile (k_plan_tail_list<true>), blocks that follow each other touch the same tiles of the raster — with the
+// identity map their scattered sectors would be fetched by eight different L2s.
+__device__ __forceinline__ u32 pfd_block_1d() {
+  u32 L = blockIdx.x;
+  if (PFD_XCD_ORDER) {
+    const u32 n = gridDim.x, q = n >> 3, r = n & 7u, k = L & 7u;
+    L = k * q + min(k, r) + (L >> 3);
+  }
+  return L;
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------

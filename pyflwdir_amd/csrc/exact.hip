@@ -329,24 +329,51 @@ __device__ __forceinline__ void tl_load(const u8 *__restrict__ hcode, u32 n, u32
       if (x0 + 4u * i + b >= n) z[i] &= ~(0x80u << (8 * b));  // (cells past the raster)
   }
 }
-__global__ void __launch_bounds__(256) k_plan_count_ends(const u8 *__restrict__ hcode, u32 n, u32 *__restrict__ bcount) {
+// TILED = one workgroup per 64 x 64 tile (16 cells of a tile row per thread, the list in tile-major order: the chains of a
+// tile — and with them their slots in every chain-order array — lie together, see k_plan_tail order in DESIGN 4.5);
+// !TILED = 4096 cells of the raster in linear order per workgroup (the list in raster order, PFD_TAILS_RASTER).
+template <bool TILED>
+__device__ __forceinline__ u32 tl_load_any(const u8 *__restrict__ hcode, u32 n, u32 nrow, u32 ncol, u32 ntc, u32 (&z)[4]) {
+  if (!TILED) {
+    const u32 x0 = blockIdx.x * TLG + 16u * threadIdx.x;
+    tl_load(hcode, n, x0, z);
+    return x0;
+  }
+  const u32 ty = blockIdx.x / ntc, tx = blockIdx.x - ty * ntc;
+  const u32 gr = ty * XT + (threadIdx.x >> 2), gc = tx * XT + 16u * (threadIdx.x & 3u);
+  const u32 x0 = gr * ncol + gc;  // (< n whenever the thread has a cell)
+  uint4 v = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+  const bool in = gr < nrow && gc < ncol;
+  if (in) __builtin_memcpy(&v, hcode + x0, 16);  // (unaligned; hcode carries 64 bytes of slack behind its n cells)
+  const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    z[i] = zero_bytes(w[i]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (!in || gc + 4u * i + b >= ncol) z[i] &= ~(0x80u << (8 * b));  // (cells of the next row / past the raster)
+  }
+  return x0;
+}
+template <bool TILED>
+__global__ void __launch_bounds__(256) k_plan_count_ends(const u8 *__restrict__ hcode, u32 n, u32 nrow, u32 ncol, u32 ntc,
+                                                         u32 *__restrict__ bcount) {
   __shared__ u32 wcnt[4];
-  const u32 x0 = blockIdx.x * TLG + 16u * threadIdx.x;
   u32 z[4];
-  tl_load(hcode, n, x0, z);
+  tl_load_any<TILED>(hcode, n, nrow, ncol, ntc, z);
   u32 c = (u32)__popc(z[0]) + (u32)__popc(z[1]) + (u32)__popc(z[2]) + (u32)__popc(z[3]);
   for (int o = 32; o > 0; o >>= 1) c += (u32)__shfl_down((int)c, o);
   if ((threadIdx.x & 63u) == 0u) wcnt[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) bcount[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
-__global__ void __launch_bounds__(256) k_plan_tail_list(const u8 *__restrict__ hcode, u32 n, const u32 *__restrict__ boff,
-                                                        u32 *__restrict__ tails) {
+template <bool TILED>
+__global__ void __launch_bounds__(256) k_plan_tail_list(const u8 *__restrict__ hcode, u32 n, u32 nrow, u32 ncol, u32 ntc,
+                                                        const u32 *__restrict__ boff, u32 *__restrict__ tails) {
   __shared__ u32 wcnt[4];
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const u32 x0 = blockIdx.x * TLG + 16u * threadIdx.x;
   u32 z[4];
-  tl_load(hcode, n, x0, z);
+  const u32 x0 = tl_load_any<TILED>(hcode, n, nrow, ncol, ntc, z);
   const u32 c = (u32)__popc(z[0]) + (u32)__popc(z[1]) + (u32)__popc(z[2]) + (u32)__popc(z[3]);
   u32 incl = c;  // inclusive prefix over the wave's lanes
   for (int o = 1; o < 64; o <<= 1) {
@@ -413,7 +440,7 @@ __global__ void __launch_bounds__(256) k_plan_len(const uint16_t *__restrict__ h
 __global__ void __launch_bounds__(256) k_plan_tails(const u8 *__restrict__ ncode, Geo g, const u32 *__restrict__ tails,
                                                     u32 nt, const u32 *__restrict__ tailnum,
                                                     const u32 *__restrict__ tidx_at, u32 *__restrict__ D,
-                                                    u32 *__restrict__ P) {
+                                                    u32 *__restrict__ P, u32 *__restrict__ par) {
   const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nt) return;
   const u32 x = tails[j];
@@ -425,6 +452,7 @@ __global__ void __launch_bounds__(256) k_plan_tails(const u8 *__restrict__ ncode
   }
   D[j] = d;
   P[j] = p;
+  par[j] = p;
 }
 __global__ void __launch_bounds__(256) k_plan_depth_round(u32 nt, const u32 *__restrict__ Di, const u32 *__restrict__ Pi,
                                                           u32 *__restrict__ Do, u32 *__restrict__ Po) {
@@ -439,16 +467,63 @@ __global__ void __launch_bounds__(256) k_plan_depth_round(u32 nt, const u32 *__r
   Po[j] = p;
 }
 
+// ---- rounds of the chains (round 6) ----------------------------------------------------------------------------------
+// Any labelling with label(chain) < label(chain it joins) is a valid order of the rounds.  "As late as possible" — 31 minus
+// the light links below the chain — puts all main stems into the last round, which is what the few LONG chains need (each
+// is folded serially by one wave: they must run side by side, not one round after the other).  But it spreads the ~3e7
+// short headwater chains of a raster over all 13 rounds by how deep in the tree they happen to sit, and every round is a
+// launch of its own: a 64 x 64 tile's chains are then gathered in 8 - 13 different launches and every launch fetches
+// nearly all lines of the tile's payload for a few hundred slots.  So: a chain of >= XPIN cells keeps the late label
+// (PINNED, bit 7 set so that an atomicMax below 128 never moves it); every other chain takes the EARLIEST round its
+// tributaries allow, 1 + max(label of the chains joining it), starting at the first round in use.  A pinned tributary's
+// label is below its parent's late label, so by induction no label exceeds the late one: the order stays valid and the
+// number of rounds the same.  Pass k pushes the labels of the chains whose label is k (final by then: everything below
+// pushed in an earlier pass; a push from a label that rises later is only a lower bound pushed too early).
+#define XPIN 512u
+#define XLAB_PIN 0x80u
+__global__ void __launch_bounds__(256) k_plan_maxdepth(u32 nt, const u32 *__restrict__ depth, u32 *__restrict__ maxd) {
+  __shared__ u32 s_m;
+  if (threadIdx.x == 0) s_m = 0;
+  __syncthreads();
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 d = j < nt ? min(depth[j], 31u) : 0u;
+  for (int o = 32; o > 0; o >>= 1) d = max(d, (u32)__shfl_down((int)d, o));
+  if ((threadIdx.x & 63u) == 0u && d) atomicMax(&s_m, d);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_m) atomicMax(maxd, s_m);
+}
+__global__ void __launch_bounds__(256) k_plan_label_init(u32 nt, const u32 *__restrict__ depth, const u32 *__restrict__ len_of,
+                                                         const u32 *__restrict__ maxd, u32 *__restrict__ lab) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nt) return;
+  lab[j] = len_of[j] >= XPIN ? (XLAB_PIN | (31u - min(depth[j], 31u))) : 31u - *maxd;
+}
+__global__ void __launch_bounds__(256) k_plan_label_pins(u32 nt, const u32 *__restrict__ par, u32 *__restrict__ lab) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nt) return;
+  const u32 l = lab[j];
+  if (!(l & XLAB_PIN)) return;
+  const u32 p = par[j];
+  if (p != NONE32) atomicMax(&lab[p], (l & 31u) + 1u);  // (a pinned parent holds >= 128: unchanged)
+}
+__global__ void __launch_bounds__(256) k_plan_label_pass(u32 nt, u32 k, const u32 *__restrict__ par, u32 *__restrict__ lab) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nt) return;
+  if (lab[j] != k) return;
+  const u32 p = par[j];
+  if (p != NONE32) atomicMax(&lab[p], k + 1u);
+}
+
 // chains in layout order = the chain ends sorted by round (stable: raster order inside a round);
 // the sort carries the list numbers j, rank_of[j] = chain id
-__global__ void __launch_bounds__(256) k_plan_keys(u32 nt, const u32 *__restrict__ depth, u32 *__restrict__ keys,
+__global__ void __launch_bounds__(256) k_plan_keys(u32 nt, const u32 *__restrict__ depth, const u32 *__restrict__ lab, u32 *__restrict__ keys,
                                                    u32 *__restrict__ iota, u32 *__restrict__ hist) {
   __shared__ u32 s_h[32];
   if (threadIdx.x < 32) s_h[threadIdx.x] = 0;
   __syncthreads();
   const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < nt) {
-    const u32 k = 31u - min(depth[j], 31u);
+    const u32 k = lab ? (lab[j] & 31u) : 31u - min(depth[j], 31u);
     keys[j] = k;
     iota[j] = j;
     atomicAdd(&s_h[k], 1u);
@@ -1000,12 +1075,17 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if ((rc = tidxbuf.alloc((size_t)n * sizeof(u32) + 64)) != PFD_OK) return fail(rc);  // (written at the chain ends only)
   if ((rc = hinfo.alloc((size_t)n * sizeof(uint16_t) + 64)) != PFD_OK) return fail(rc);
   DevBuf bcount;
-  const u32 gridT = cdiv_u32(n, TLG);  // (the chain-end count / list kernels: 4096 cells per workgroup)
+  // (the chain-end count / list kernels: a 64 x 64 tile per workgroup, or 4096 cells in linear order)
+  const bool tails_tiled = !pfd_knob("PFD_TAILS_RASTER");
+  const u32 gridT = tails_tiled ? (u32)ntiles : cdiv_u32(n, TLG);
   if ((rc = bcount.alloc(((size_t)gridT + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemsetAsync(bcount.as<u32>() + gridT, 0, sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
   k_plan_heavy_tile<<<dim3(ntc, ntr), 256, 0, h->stream>>>(h->ncode, (u32)h->nrow, (u32)h->ncol, p->lh, p->kids, upa.as<u32>(),
                                                            hinfo.as<uint16_t>(), hcode.as<u8>());
-  k_plan_count_ends<<<gridT, 256, 0, h->stream>>>(hcode.as<u8>(), n, bcount.as<u32>());
+  if (tails_tiled)
+    k_plan_count_ends<true><<<gridT, 256, 0, h->stream>>>(hcode.as<u8>(), n, (u32)h->nrow, (u32)h->ncol, ntc, bcount.as<u32>());
+  else
+    k_plan_count_ends<false><<<gridT, 256, 0, h->stream>>>(hcode.as<u8>(), n, (u32)h->nrow, (u32)h->ncol, ntc, bcount.as<u32>());
   XDBG(h, "k_plan_heavy");
   xdigest(h, "hcode", hcode.p, (size_t)n);
   xdigest(h, "hinfo", hinfo.p, (size_t)n * 2);
@@ -1019,7 +1099,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   xdigest(h, "tailnum", tailnum.p, (size_t)n * 4);
   // the chain ends (pits of the heavy forest), in raster order (selection by scan: no same-address atomics).  The list
   // lives in the upstream-area buffer, which is no longer needed.
-  DevBuf dA, dB, pA, pB, tmp, cnt, len_of, rank_of;
+  DevBuf dA, dB, pA, pB, tmp, cnt, len_of, rank_of, parb, labb;
   u32 *tails = upa.as<u32>();
   if ((rc = cnt.alloc(64 * sizeof(u32))) != PFD_OK) return fail(rc);
   size_t tmp_bytes = 0;
@@ -1031,7 +1111,10 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
     if (rocprim::exclusive_scan(tmp.p, tmp_bytes, bcount.as<u32>(), bcount.as<u32>(), 0u, (size_t)gridT + 1, rocprim::plus<u32>(),
                                 h->stream) != hipSuccess)
       return fail(PFD_EHIP);
-    k_plan_tail_list<<<gridT, 256, 0, h->stream>>>(hcode.as<u8>(), n, bcount.as<u32>(), tails);
+    if (tails_tiled)
+      k_plan_tail_list<true><<<gridT, 256, 0, h->stream>>>(hcode.as<u8>(), n, (u32)h->nrow, (u32)h->ncol, ntc, bcount.as<u32>(), tails);
+    else
+      k_plan_tail_list<false><<<gridT, 256, 0, h->stream>>>(hcode.as<u8>(), n, (u32)h->nrow, (u32)h->ncol, ntc, bcount.as<u32>(), tails);
     if (hipGetLastError() != hipSuccess) return fail(PFD_EHIP);
   }
   hcode.alloc(0);
@@ -1049,9 +1132,11 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if ((rc = dB.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pA.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
   if ((rc = pB.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
+  if ((rc = parb.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
   u32 *Dc = dA.as<u32>(), *Dn = dB.as<u32>(), *Pc = pA.as<u32>(), *Pn = pB.as<u32>();
   if (nchain) {
-    k_plan_tails<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(h->ncode, h->geo, tails, nt32, tailnum.as<u32>(), tidx_at, Dc, Pc);
+    k_plan_tails<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(h->ncode, h->geo, tails, nt32, tailnum.as<u32>(), tidx_at, Dc, Pc,
+                                                               parb.as<u32>());
   XDBG(h, "k_plan_tails");
     for (int r = 0; r < 6; ++r) {
       k_plan_depth_round<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(nt32, Dc, Pc, Dn, Pn);
@@ -1069,6 +1154,25 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   xdigest(h, "tails", tails, (size_t)nchain * 4);
   xdigest(h, "depth", depth, (size_t)nchain * 4);
   xdigest(h, "len_of", len_of.p, (size_t)nchain * 4);
+  // labels = rounds of the chains (see k_plan_label_pass): built, measured (profiles/r06_ab_rounds_early.txt) and OFF —
+  // PFD_ROUNDS_EARLY turns them on; by default every chain keeps "as late as possible"
+  const u32 *lab = nullptr;
+  if (nchain && pfd_knob("PFD_ROUNDS_EARLY")) {
+    if ((rc = labb.alloc((nc1 + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
+    u32 *L = labb.as<u32>(), *maxd = L + nc1;
+    if (hipMemsetAsync(maxd, 0, sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
+    const u32 gc = cdiv_u32(nchain, 256);
+    k_plan_maxdepth<<<gc, 256, 0, h->stream>>>(nt32, depth, maxd);
+    k_plan_label_init<<<gc, 256, 0, h->stream>>>(nt32, depth, len_of.as<u32>(), maxd, L);
+    k_plan_label_pins<<<gc, 256, 0, h->stream>>>(nt32, parb.as<u32>(), L);
+    u32 md = 0;
+    if (hipMemcpyAsync(&md, maxd, sizeof(u32), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+      return fail(PFD_EHIP);
+    for (u32 k = 31u - md; k < 31u; ++k) k_plan_label_pass<<<gc, 256, 0, h->stream>>>(nt32, k, parb.as<u32>(), L);
+    XDBG(h, "k_plan_label_pass");
+    lab = L;
+  }
   // chains in layout order: stable sort of the chain ends by round; chain id = rank in that order
   DevBuf ucell, w, cpos, clenp, ctail, cpad, pick, keys, keys2, iota, cj, adj;
   if ((rc = keys.alloc(nc1 * sizeof(u32))) != PFD_OK) return fail(rc);
@@ -1082,7 +1186,7 @@ int pfd_ensure_xplan(pfd_raster *h, bool allow_block) {
   if ((rc = cpad.alloc((nchain + 1) * sizeof(u32))) != PFD_OK) return fail(rc);
   if (hipMemsetAsync(cnt.p, 0, 64 * sizeof(u32), h->stream) != hipSuccess) return fail(PFD_EHIP);
   if (nchain) {
-    k_plan_keys<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(nt32, depth, keys.as<u32>(), iota.as<u32>(), cnt.as<u32>());
+    k_plan_keys<<<cdiv_u32(nchain, 256), 256, 0, h->stream>>>(nt32, depth, lab, keys.as<u32>(), iota.as<u32>(), cnt.as<u32>());
   XDBG(h, "k_plan_keys");
     if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<u32>(), keys2.as<u32>(), iota.as<u32>(), cj.as<u32>(),
                                   (size_t)nchain, 0u, 5u, h->stream) != hipSuccess)

@@ -160,7 +160,7 @@ template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_pre(Op op, const u32 *__restrict__ scell,
                                                     const uint16_t *__restrict__ sinfo, u32 s0, u32 s1,
                                                     typename Op::Elem *__restrict__ E) {
-  const u32 s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 s = s0 + pfd_block_1d() * blockDim.x + threadIdx.x;
   if (s >= s1) return;
   const u32 info = sinfo[s];
   const u32 x = scell[s];
@@ -187,37 +187,17 @@ __device__ __forceinline__ u32 xpost_bits(const u32 *__restrict__ spost, u32 s) 
   return (u32)((((u64)w1 << 32) | (u64)w0) >> (s & 31u));
 }
 
-// The first `nlong` workgroups take one LONG chain each (ids in longc): the wave streams the chain through LDS,
-// 64 groups of 4 slots per block (the next block's loads are in flight during the fold), lane 0 folds the block
-// from LDS and the wave stores the results.  A lane of its own would run at one HBM round trip per 48 slots.
-template <class Op>
-__global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
-                                                    u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
-                                                    const u32 *__restrict__ spost,
-                                                    const typename Op::Elem *__restrict__ E,
-                                                    typename Op::V *__restrict__ R, const u32 *__restrict__ scell,
-                                                    u8 *__restrict__ dirty = nullptr, const u32 *__restrict__ dchain = nullptr) {
+// the fold of ONE long chain by one wave (lane = 0..63), see k_xtrunk_scan; sE / sR / sB: 64 entries each; sync: the
+// workgroup barrier where the wave is the workgroup, a wave-level fence where other waves of the workgroup are elsewhere
+template <class Op, class Sync, class Finish>
+__device__ __forceinline__ void xscan_long(const Op &op, u32 cc, u32 lane, const u32 *__restrict__ cstart,
+                                           const u32 *__restrict__ clen, const u32 *__restrict__ spost,
+                                           const typename Op::Elem *__restrict__ E, typename Op::V *__restrict__ R,
+                                           XVec4<typename Op::Elem> *sE, XVec4<typename Op::V> *sR, u32 *sB, Sync sync,
+                                           Finish finish) {
   typedef typename Op::Elem Elem;
   typedef typename Op::V V;
-  constexpr int G = XBlk<Elem>::G;
-  // (dirty != nullptr: an incremental re-sweep of a row block — only the chains marked there are folded again)
-  // The END of a chain is the only trunk cell a later round reads from the raster (as a light upstream cell): whoever
-  // folds the chain stores it — its value follows its post slots, so it is the value of the chain's last slot — and,
-  // in a re-sweep, marks the chain that end drains into (always a chain of a later round).
-  auto finish = [&](u32 c, u32 s0, u32 cl, V endv) {
-    op.store(scell[s0 + (cl & XC_LEN) - 1u - (cl >> 29)], endv);
-    if (dchain) {
-      const u32 d = dchain[c];
-      if (d != 0xFFFFFFFFu) dirty[d] = 1;
-    }
-  };
-  if (blockIdx.x < nlong) {
-    __shared__ XVec4<Elem> sE[64];
-    __shared__ XVec4<V> sR[64];
-    __shared__ u32 sB[64];
-    const u32 lane = threadIdx.x;
-    const u32 cc = longc[blockIdx.x];
-    if (dirty && !dirty[cc]) return;
+  {
     const u32 s0 = cstart[cc];
     const u32 ng = ((clen[cc] & XC_LEN) + 3u) >> 2;
     const XVec4<Elem> *E4 = (const XVec4<Elem> *)E + (s0 >> 2);
@@ -235,7 +215,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
       sE[lane] = cur;
       sB[lane] = cb;
       gload(g0 + 64u + lane, cur, cb);
-      __syncthreads();
+      sync();
       const u32 cnt = ng - g0 < 64u ? ng - g0 : 64u;
       // exact fold of the groups [q0, cnt) of the block by lane 0, from the running value tt
       auto exact = [&](u32 q0, V tt) {
@@ -306,7 +286,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
                   (int)op.special(tt, e.v[3]);
           }
         } else {
-        __syncthreads();
+        sync();
         if (lane >= q0 && lane < cnt) {
           const XVec4<Elem> e = sE[lane];
           const XVec4<V> r = sR[lane];
@@ -317,18 +297,60 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
         }
         }
         if (__any((int)bad)) {
-          __syncthreads();
+          sync();
           if (lane == 0) tt = exact(0, t);
         }
         t = tt;
       }
-      __syncthreads();
+      sync();
       if (g0 + lane < ng) R4[g0 + lane] = sR[lane];
       if (lane == 0 && g0 + 64u >= ng) {  // the block that holds the chain's last slot
         const u32 last = (clen[cc] & XC_LEN) - 1u;
         finish(cc, s0, clen[cc], sR[(last >> 2) - g0].v[last & 3u]);
       }
     }
+  }
+}
+struct XSyncWG {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+struct XSyncWave {  // one wave works alone on its LDS words: program order + a compiler / LDS fence
+  __device__ __forceinline__ void operator()() const {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+// The first `nlong` workgroups take one LONG chain each (ids in longc): the wave streams the chain through LDS,
+// 64 groups of 4 slots per block (the next block's loads are in flight during the fold), lane 0 folds the block
+// from LDS and the wave stores the results.  A lane of its own would run at one HBM round trip per 48 slots.
+template <class Op>
+__global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
+                                                    u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
+                                                    const u32 *__restrict__ spost,
+                                                    const typename Op::Elem *__restrict__ E,
+                                                    typename Op::V *__restrict__ R, const u32 *__restrict__ scell,
+                                                    u8 *__restrict__ dirty = nullptr, const u32 *__restrict__ dchain = nullptr) {
+  typedef typename Op::Elem Elem;
+  typedef typename Op::V V;
+  constexpr int G = XBlk<Elem>::G;
+  // (dirty != nullptr: an incremental re-sweep of a row block — only the chains marked there are folded again)
+  // The END of a chain is the only trunk cell a later round reads from the raster (as a light upstream cell): whoever
+  // folds the chain stores it — its value follows its post slots, so it is the value of the chain's last slot — and,
+  // in a re-sweep, marks the chain that end drains into (always a chain of a later round).
+  auto finish = [&](u32 c, u32 s0, u32 cl, V endv) {
+    op.store(scell[s0 + (cl & XC_LEN) - 1u - (cl >> 29)], endv);
+    if (dchain) {
+      const u32 d = dchain[c];
+      if (d != 0xFFFFFFFFu) dirty[d] = 1;
+    }
+  };
+  if (blockIdx.x < nlong) {
+    __shared__ XVec4<Elem> sE[64];
+    __shared__ XVec4<V> sR[64];
+    __shared__ u32 sB[64];
+    const u32 cc = longc[blockIdx.x];
+    if (dirty && !dirty[cc]) return;
+    xscan_long(op, cc, threadIdx.x, cstart, clen, spost, E, R, sE, sR, sB, XSyncWG(), finish);
     return;
   }
   const u32 c = c0 + (blockIdx.x - nlong) * blockDim.x + threadIdx.x;
@@ -351,7 +373,7 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
     bits = xpost_bits(spost, s0 + 4u * (g0 < ng ? g0 : 0u));
   };
   auto fold = [&](u32 g0, const XVec4<Elem>(&e)[G], u32 bits) {
-    if (Op::FAST) {
+    if (Op::FAST_SHORT) {
       // speculative block: fold without the operation's special cases (accuflux: the nodata rule) and
       // check afterwards that no operand of the block was special — one dependent instruction per slot
       // instead of six.  A block with a special operand in ANY lane of the wave is redone exactly.
@@ -413,11 +435,195 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
   if (m) finish(c, s0, clen[c], R[s0 + m - 1u]);  // (the lane reads back what it stored itself)
 }
 
+// ---- gather + fold of the SHORT chains in one kernel (round 6) --------------------------------------------------------
+// k_xtrunk_pre is bandwidth (scattered sectors), the lane-per-chain fold of k_xtrunk_scan is latency (a chain of 8 slots
+// costs its lane ~28 memory instructions, most of them clamped repeats, and a 16-byte access per lane and trip), and the
+// two ran one after the other with the elements making a round trip through HBM between them.  Here a workgroup takes
+// 256 consecutive chains — a contiguous run of slots, chains being laid out back to back — and moves that run through LDS
+// in chunks of XFuse::CAP slots: (1) every thread gathers the elements of the chunk's slots tid, tid + 256, ... (coalesced
+// slot arrays, the same hooks as k_xtrunk_pre) into LDS, the post flags as ballots; (2) the lane that owns a chain folds
+// the part of it that lies in the chunk from LDS, 4 slots per trip, running value in a register across chunks,
+// speculative form first (a group with a special operand is redone exactly, per lane); (3) the workgroup stores the
+// chunk's values with 16-byte accesses.  The gathers of one workgroup run under the folds of the others on its CU.
+// Chains of XLONG slots or more keep their own path (k_xtrunk_pre_long + the wave-per-chain part of k_xtrunk_scan): a
+// chunk never covers their slots — it ends where the next long chain of the workgroup starts.
+#ifndef XF_ABLATE
+#define XF_ABLATE 0  // timing experiments only: 1 = no fold, 2 = no gather (wrong results)
+#endif
+template <class Op>
+struct XFuse {
+  static constexpr u32 B = (u32)(sizeof(typename Op::Elem) + sizeof(typename Op::V));
+  static constexpr u32 CAP = B <= 8 ? 2048u : (B <= 16 ? 1024u : 512u);  // slots per chunk: <= 16 KB of elements + values
+};
+__device__ __forceinline__ u32 xwg_min(u32 v, u32 *s_red) {  // minimum over a 256-thread workgroup (s_red: 4 words, reusable after return)
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o));
+  __syncthreads();  // (the previous call's readers are done)
+  if ((threadIdx.x & 63u) == 0u) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+}
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_prescan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
+                                                        u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
+                                                        const u32 *__restrict__ spost, const u32 *__restrict__ scell,
+                                                        const uint16_t *__restrict__ sinfo,
+                                                        const typename Op::Elem *__restrict__ E,
+                                                        typename Op::V *__restrict__ R) {
+  typedef typename Op::Elem Elem;
+  typedef typename Op::V V;
+  constexpr u32 CAP = XFuse<Op>::CAP;
+  __shared__ XVec4<Elem> sE4[CAP / 4];
+  __shared__ XVec4<V> sR4[CAP / 4];
+  __shared__ u32 sP[CAP / 32];
+  __shared__ u32 sB[64];
+  __shared__ u32 s_red[4];
+  const u32 tid = threadIdx.x;
+  if (blockIdx.x < nlong) {  // a LONG chain of the round (its elements: k_xtrunk_pre_long): one wave, beside the others' chunks
+    if (tid >= 64u) return;
+    const u32 cc = longc[blockIdx.x];
+    auto finish = [&](u32, u32 s0, u32 cl, V endv) { op.store(scell[s0 + (cl & XC_LEN) - 1u - (cl >> 29)], endv); };
+    xscan_long(op, cc, tid, cstart, clen, spost, E, R, sE4, sR4, sB, XSyncWave(), finish);
+    return;
+  }
+  Elem *sE = reinterpret_cast<Elem *>(sE4);
+  const V *sR = reinterpret_cast<const V *>(sR4);
+  // (XCD-aware order of the short-chain workgroups only: the long ones come first in the grid)
+  u32 L = blockIdx.x - nlong;
+  if (PFD_XCD_ORDER) {
+    const u32 n = gridDim.x - nlong, q = n >> 3, r = n & 7u, k = L & 7u;
+    L = k * q + min(k, r) + (L >> 3);
+  }
+  const u32 c = c0 + L * 256u + tid;
+  const bool act = c < c1;
+  const u32 a = act ? cstart[c] : 0xFFFFFFFFu;
+  const u32 cl = act ? clen[c] : 0u;
+  u32 m = cl & XC_LEN;
+  const bool islong = m >= XLONG;
+  if (islong) m = 0;
+  const u32 endp = a + ((m + 3u) & ~3u);  // (padding belongs to the chain)
+  u32 cur = m ? a : 0xFFFFFFFFu;          // next slot of the own chain to fold; nothing left: NONE
+  // end of the last short chain of the workgroup (maximum = NOT of the minimum of the complements) and whether a
+  // long chain lies between them
+  const u32 lastend = ~xwg_min(m ? ~endp : 0xFFFFFFFFu, s_red);
+  const bool anylong = xwg_min(islong ? 0u : 1u, s_red) == 0u;
+  V t = V();
+  for (;;) {
+    const u32 g = xwg_min(cur, s_red);
+    if (g == 0xFFFFFFFFu) break;
+    // the chunk [g, e): up to CAP slots, not into a long chain, not beyond the chains of this workgroup
+    u32 e = min(g + CAP, lastend);
+    if (anylong) e = min(e, xwg_min((islong && a >= g) ? a : 0xFFFFFFFFu, s_red));
+    const u32 cnt = e - g;
+    // (1) gather, four slots per thread in flight
+    for (u32 i0 = 0; i0 < cnt; i0 += 1024u) {
+      u32 info[4], x[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 i = i0 + 256u * (u32)k + tid;
+        const u32 sl = g + (i < cnt ? i : cnt - 1u);
+        info[k] = sinfo[sl];
+        x[k] = scell[sl];
+      }
+      Elem ev[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#if XF_ABLATE == 2
+        ev[k] = Elem();
+#else
+        ev[k] = (info[k] & XS_POST) ? op.pre_post(x[k]) : op.pre_real(x[k], info[k] & 0xFFu, (info[k] >> 8) & 0xFu);
+#endif
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 i = i0 + 256u * (u32)k + tid;
+        const bool in = i < cnt;
+        const unsigned long long pb = __ballot((int)(in && (info[k] & XS_POST)));
+        if (in) sE[i] = ev[k];
+        if ((tid & 63u) == 0u && i0 + 256u * (u32)k < cnt) {
+          sP[i >> 5] = (u32)pb;  // (the wave's 64 slots: two words; words past the chunk are never read)
+          sP[(i >> 5) + 1u] = (u32)(pb >> 32);
+        }
+      }
+    }
+    __syncthreads();
+    // (2) fold
+#if XF_ABLATE == 1
+    if (cur != 0xFFFFFFFFu && cur < e) cur = endp <= e ? 0xFFFFFFFFu : e;
+#endif
+    if (cur != 0xFFFFFFFFu && cur < e) {
+      const u32 hi = min(endp, e) - g;
+      u32 q = cur - g;
+      XVec4<Elem> evn = sE4[q >> 2];
+      for (; q < hi; q += 4u) {
+        const XVec4<Elem> ev = evn;
+        if (q + 4u < hi) evn = sE4[(q + 4u) >> 2];  // (the next group is on its way during the fold)
+        const u32 bits = (sP[q >> 5] >> (q & 31u)) & 0xFu;
+        const bool head = g + q == a;
+        XVec4<V> r;
+        V tt = t;
+        bool bad = !Op::FAST_SHORT;
+        if (Op::FAST_SHORT) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const Elem xe = ev.v[j];
+            if (j == 0) {
+              bad |= !head && op.special(tt, xe);
+              const V f = op.fold_fast(tt, xe);
+              tt = head ? op.first(xe) : f;
+            } else {
+              bad |= op.special(tt, xe);
+              tt = op.fold_fast(tt, xe);
+            }
+            r.v[j] = tt;
+          }
+        }
+        if (bad) {
+          tt = t;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const V f = op.fold(tt, ev.v[j], ((bits >> j) & 1u) != 0);
+            tt = (j == 0 && head) ? op.first(ev.v[j]) : f;
+            r.v[j] = tt;
+          }
+        }
+        t = tt;
+        sR4[q >> 2] = r;
+      }
+      if (endp <= e) {  // the chain ends in this chunk: its END is the only trunk cell a later round reads from the raster
+        const u32 last = a + m - 1u;
+        op.store(scell[last - (cl >> 29)], sR[last - g]);
+        cur = 0xFFFFFFFFu;
+      } else {
+        cur = e;
+      }
+    }
+    __syncthreads();
+    // (3) store
+    XVec4<V> *R4 = reinterpret_cast<XVec4<V> *>(R) + (g >> 2);
+    for (u32 q = tid; q < (cnt >> 2); q += 256u) R4[q] = sR4[q];
+  }
+}
+// elements of the LONG chains of a round (blockIdx.x = the chain's number in longc, blockIdx.y = a piece of 1024 slots)
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_pre_long(Op op, const u32 *__restrict__ longc, const u32 *__restrict__ cstart,
+                                                         const u32 *__restrict__ clen, const u32 *__restrict__ scell,
+                                                         const uint16_t *__restrict__ sinfo,
+                                                         typename Op::Elem *__restrict__ E) {
+  const u32 cc = longc[blockIdx.x];
+  const u32 s0 = cstart[cc], n4 = ((clen[cc] & XC_LEN) + 3u) & ~3u;
+  const u32 i1 = min(n4, (blockIdx.y + 1u) * 1024u);
+  for (u32 i = blockIdx.y * 1024u + threadIdx.x; i < i1; i += 256u) {
+    const u32 s = s0 + i;
+    const u32 info = sinfo[s];
+    const u32 x = scell[s];
+    E[s] = (info & XS_POST) ? op.pre_post(x) : op.pre_real(x, info & 0xFFu, (info >> 8) & 0xFu);
+  }
+}
+
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_scatter(Op op, const u32 *__restrict__ scell,
                                                         const uint16_t *__restrict__ sinfo, u32 s0, u32 s1,
                                                         const typename Op::V *__restrict__ R) {
-  const u32 s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 s = s0 + pfd_block_1d() * blockDim.x + threadIdx.x;
   if (s >= s1) return;
   const u32 info = sinfo[s];
   if (info & XS_POST) return;
@@ -528,7 +734,7 @@ template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_pre_inc(Op op, const u32 *__restrict__ scell, const uint16_t *__restrict__ sinfo,
                                                         const u32 *__restrict__ schain, const u8 *__restrict__ dirty, u32 s0,
                                                         u32 s1, typename Op::Elem *__restrict__ E) {
-  const u32 s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 s = s0 + pfd_block_1d() * blockDim.x + threadIdx.x;
   if (s >= s1 || !dirty[schain[s]]) return;
   const u32 info = sinfo[s];
   const u32 x = scell[s];
@@ -648,6 +854,8 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
   if (bsplit >= 0 && pfd_aux_stream(h) != PFD_OK) bsplit = -1;
   XStream2Guard guard2{h};  // (declared after E / R: runs before they are released)
   const u32 s_split = bsplit >= 0 ? (u32)p->b_slot[bsplit] : 0xFFFFFFFFu;
+  // (a kept sweep needs the element array of every slot: the short chains' elements never leave LDS in the fused form)
+  const bool fused = Op::FUSE_UP && !keep && !pfd_knob("PFD_SCAN_UNFUSED");
   for (int b = 0; b < 32; ++b) {
     const u32 s0 = (u32)p->b_slot[b], s1 = (u32)p->b_slot[b + 1];
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
@@ -664,9 +872,25 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
       HIPCHK(hipEventRecord(h->ev_join, h->stream2));
       ++launches;
     }
+    const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
+    // (a round that is mostly long chains — the main stems' — keeps the two-kernel form: nothing to fuse there)
+    // and so do the rounds that run beside the raster-order pass on the second stream: the long chains' own gather
+    // kernel — a few thousand half-empty workgroups — waits behind that pass's workgroups (1.9 ms measured)
+    if (fused && (u64)nl * 16u <= (u64)(c1 - c0) && (bsplit < 0 || b < bsplit)) {
+      if (nl) {
+        k_xtrunk_pre_long<Op><<<dim3(nl, cdiv_u32(p->b_maxlen[b] + 3u, 1024u)), 256, 0, h->stream>>>(
+            op, p->longc + p->b_long[b], p->cstart, p->clen, p->scell, p->sinfo, E);
+        ++launches;
+      }
+      k_xtrunk_prescan<Op><<<nl + cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
+                                                                               p->longc + p->b_long[b], nl, p->spost, p->scell,
+                                                                               p->sinfo, E, R);
+      ++launches;
+      XDBG(h, "prescan");
+      continue;
+    }
     k_xtrunk_pre<Op><<<cdiv_u32(s1 - s0, 256), 256, 0, h->stream>>>(op, p->scell, p->sinfo, s0, s1, E);
     XDBG(h, "pre");
-    const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
     k_xtrunk_scan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
                                                                         p->longc + p->b_long[b], nl, p->spost, E, R, p->scell);
     XDBG(h, "scan");
@@ -702,7 +926,7 @@ template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_dpre(Op op, const u32 *__restrict__ scell,
                                                      const uint16_t *__restrict__ sinfo, const u8 *__restrict__ ncode,
                                                      u32 s0, u32 s1, typename Op::DElem *__restrict__ E) {
-  const u32 s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 s = s0 + pfd_block_1d() * blockDim.x + threadIdx.x;
   if (s >= s1) return;
   const u32 info = sinfo[s];
   const u32 x = scell[s];  // (a post slot names the light upstream cell: a valid cell as well)
@@ -779,30 +1003,20 @@ __global__ void __launch_bounds__(256) k_xtrunk_demit_list(Op op, XTileArgs a, t
   }
 }
 
-// the chain is walked from its last cell (slot `tail`, possibly followed by its post slots) upstream;
-// post slots are skipped.  The value of the tail comes from its downstream cell, which belongs to a chain
-// of a later round (final), or the tail is a pit.
-template <class Op>
-__global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
-                                                     u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
-                                                     const u32 *__restrict__ scell,
-                                                     const u32 *__restrict__ spost, const u8 *__restrict__ ncode, Geo g,
-                                                     const u8 *__restrict__ lh, const u32 *__restrict__ cslot,
-                                                     const typename Op::DElem *__restrict__ E,
-                                                     typename Op::V *R) {
+// the down-fold of ONE long chain by one wave (lane = 0..63), see k_xtrunk_dscan; sE / sR / sB: 64 entries each, sT: the
+// running value that enters a block; sync: XSyncWG where the wave is the workgroup, XSyncWave otherwise
+template <class Op, class Sync>
+__device__ __forceinline__ void xdscan_long(const Op &op, u32 cc, u32 lane, const u32 *__restrict__ cstart,
+                                            const u32 *__restrict__ clen, const u32 *__restrict__ scell,
+                                            const u32 *__restrict__ spost, const u8 *__restrict__ ncode, const Geo &g,
+                                            const u8 *__restrict__ lh, const u32 *__restrict__ cslot,
+                                            const typename Op::DElem *__restrict__ E, typename Op::V *R,
+                                            XVec4<typename Op::DElem> *sE, XVec4<typename Op::V> *sR, u32 *sB,
+                                            typename Op::V *sT, Sync sync) {
   typedef typename Op::DElem Elem;
   typedef typename Op::V V;
-  constexpr int G = XBlk<Elem>::G;
-  // the value of a chain's downstream cell: a trunk cell of a later round — final, in chain order — or (row blocks) a
-  // halo cell, whose value is given in the raster
   auto top_of = [&](u32 pc) -> V { return xl_trunk(lh[pc]) ? R[cslot[pc]] : op.top(pc); };
-  if (blockIdx.x < nlong) {  // a long chain: the whole wave (see k_xtrunk_scan), blocks of 64 groups from the top
-    __shared__ XVec4<Elem> sE[64];
-    __shared__ XVec4<V> sR[64];
-    __shared__ u32 sB[64];
-    __shared__ V sT;  // the running value that enters the block (lane 0 holds it)
-    const u32 lane = threadIdx.x;
-    const u32 cc = longc[blockIdx.x];
+  {
     const u32 s0 = cstart[cc], cl = clen[cc];
     const u32 m = cl & XC_LEN;
     const u32 tail = m - 1u - (cl >> 29);
@@ -839,8 +1053,8 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
       }
       sE[lane] = cur;
       gload(lo - 64 + (i32)lane, cur, cb);
-      if (lane == 0) sT = t;
-      __syncthreads();
+      if (lane == 0) *sT = t;
+      sync();
       const int lmin = lo < 0 ? -lo : 0;
       auto exact = [&](V tt) {
         for (int l = 63; l >= lmin; --l) {
@@ -874,26 +1088,53 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
             sR[l] = r;
           }
         }
-        __syncthreads();
+        sync();
         bool bad = false;
         if ((int)lane >= lmin) {
           const XVec4<Elem> e = sE[lane];
           const XVec4<V> r = sR[lane];
           const u32 skip = sB[lane];
-          const V prev = lane < 63u ? sR[lane + 1u].v[0] : sT;
+          const V prev = lane < 63u ? sR[lane + 1u].v[0] : *sT;
           bad = (int)(!(skip & 8u) && op.dspecial(e.v[3], prev)) | (int)(!(skip & 4u) && op.dspecial(e.v[2], r.v[3])) |
                 (int)(!(skip & 2u) && op.dspecial(e.v[1], r.v[2])) | (int)(!(skip & 1u) && op.dspecial(e.v[0], r.v[1]));
         }
         if (__any((int)bad)) {
-          __syncthreads();
+          sync();
           if (lane == 0) tt = exact(t);
         }
         t = tt;
       }
-      __syncthreads();
+      sync();
       const i32 gi = lo + (i32)lane;
       if (gi >= 0) R4[gi] = sR[lane];
     }
+  }
+}
+
+// the chain is walked from its last cell (slot `tail`, possibly followed by its post slots) upstream;
+// post slots are skipped.  The value of the tail comes from its downstream cell, which belongs to a chain
+// of a later round (final), or the tail is a pit.
+template <class Op>
+__global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
+                                                     u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
+                                                     const u32 *__restrict__ scell,
+                                                     const u32 *__restrict__ spost, const u8 *__restrict__ ncode, Geo g,
+                                                     const u8 *__restrict__ lh, const u32 *__restrict__ cslot,
+                                                     const typename Op::DElem *__restrict__ E,
+                                                     typename Op::V *R) {
+  typedef typename Op::DElem Elem;
+  typedef typename Op::V V;
+  constexpr int G = XBlk<Elem>::G;
+  // the value of a chain's downstream cell: a trunk cell of a later round — final, in chain order — or (row blocks) a
+  // halo cell, whose value is given in the raster
+  auto top_of = [&](u32 pc) -> V { return xl_trunk(lh[pc]) ? R[cslot[pc]] : op.top(pc); };
+  if (blockIdx.x < nlong) {  // a long chain: the whole wave (see k_xtrunk_scan), blocks of 64 groups from the top
+    __shared__ XVec4<Elem> sE[64];
+    __shared__ XVec4<V> sR[64];
+    __shared__ u32 sB[64];
+    __shared__ V sT;  // the running value that enters the block (lane 0 holds it)
+    xdscan_long(op, longc[blockIdx.x], threadIdx.x, cstart, clen, scell, spost, ncode, g, lh, cslot, E, R, sE, sR, sB, &sT,
+                XSyncWG());
     return;
   }
   const u32 c = c0 + (blockIdx.x - nlong) * blockDim.x + threadIdx.x;
@@ -992,11 +1233,136 @@ __global__ void __launch_bounds__(64) k_xtrunk_dscan(Op op, const u32 *__restric
   }
 }
 
+// ---- the down-fold of the SHORT chains through LDS (round 6) ----------------------------------------------------------
+// The lane-per-chain fold of k_xtrunk_dscan reads its chain with one 16-byte access per lane and trip, strided by the
+// chain lengths, clamped repeats included (a chain of 8 slots: ~28 memory instructions).  Here a workgroup takes 256
+// consecutive chains — one contiguous run of slots — and moves the run through LDS in chunks of XFuseD::CAP slots, from
+// its upper end down (a chain is folded from its last cell upstream): coalesced 16-byte loads of the elements and of the
+// post-flag words, the lane that owns a chain folds the part of it that lies in the chunk from LDS (running value in a
+// register across chunks), coalesced 16-byte stores of the values.  Long chains: one wave each, in the same launch.
+template <class Op>
+struct XFuseD {
+  static constexpr u32 B = (u32)(sizeof(typename Op::DElem) + sizeof(typename Op::V));
+  static constexpr u32 CAP = B <= 8 ? 2048u : (B <= 16 ? 1024u : 512u);
+};
+template <class Op>
+__global__ void __launch_bounds__(256) k_xtrunk_dscan_lds(Op op, const u32 *__restrict__ cstart, const u32 *__restrict__ clen,
+                                                          u32 c0, u32 c1, const u32 *__restrict__ longc, u32 nlong,
+                                                          const u32 *__restrict__ scell, const u32 *__restrict__ spost,
+                                                          const u8 *__restrict__ ncode, Geo g, const u8 *__restrict__ lh,
+                                                          const u32 *__restrict__ cslot,
+                                                          const typename Op::DElem *__restrict__ E, typename Op::V *R) {
+  typedef typename Op::DElem Elem;
+  typedef typename Op::V V;
+  constexpr u32 CAP = XFuseD<Op>::CAP;
+  __shared__ XVec4<Elem> sE4[CAP / 4];
+  __shared__ XVec4<V> sR4[CAP / 4];
+  __shared__ u32 sP[CAP / 32 + 2];
+  __shared__ u32 sB[64];
+  __shared__ V sT;
+  __shared__ u32 s_red[4];
+  const u32 tid = threadIdx.x;
+  if (blockIdx.x < nlong) {
+    if (tid >= 64u) return;
+    xdscan_long(op, longc[blockIdx.x], tid, cstart, clen, scell, spost, ncode, g, lh, cslot, E, R, sE4, sR4, sB, &sT, XSyncWave());
+    return;
+  }
+  u32 L = blockIdx.x - nlong;
+  if (PFD_XCD_ORDER) {
+    const u32 n = gridDim.x - nlong, q = n >> 3, r = n & 7u, k = L & 7u;
+    L = k * q + min(k, r) + (L >> 3);
+  }
+  const u32 c = c0 + L * 256u + tid;
+  const bool act = c < c1;
+  const u32 a = act ? cstart[c] : 0u;
+  const u32 cl = act ? clen[c] : 0u;
+  const u32 mfull = cl & XC_LEN;
+  const bool islong = mfull >= XLONG;
+  const u32 m = islong ? 0u : mfull;
+  const u32 pend = a + ((mfull + 3u) & ~3u);       // end of the chain's padded run (long ones too: what a chunk must not enter)
+  const u32 tail = m ? a + m - 1u - (cl >> 29) : 0u;  // SLOT of the chain's last cell
+  u32 cur = m ? pend : 0u;                        // the part [a, cur) is still to fold; 0: nothing left
+  V t = V();
+#if XF_ABLATE != 3
+  if (m)
+#else
+  if (m && a == 12345u)
+#endif
+  {  // the value of the last cell: from its downstream cell — a trunk cell of a later round, final — or a pit's own
+    const u32 x = scell[tail];
+    const u32 code = ncode[x];
+    const Elem e = E[tail];
+    if (d8_is_dir(code)) {
+      const u32 pc = d8_down(g, x, code);
+      t = op.dfold(e, xl_trunk(lh[pc]) ? R[cslot[pc]] : op.top(pc));
+    } else {
+      t = op.droot(e);
+    }
+  }
+  const u32 first = xwg_min(m ? a : 0xFFFFFFFFu, s_red);  // start of the first short chain of the workgroup
+  const bool anylong = xwg_min(islong ? 0u : 1u, s_red) == 0u;
+  for (;;) {
+    const u32 top = ~xwg_min(~cur, s_red);  // maximum
+    if (top == 0u) break;
+    // the chunk [lo, top): up to CAP slots, not into a long chain, not below the chains of this workgroup
+    u32 lo = max(top > CAP ? top - CAP : 0u, first);
+    if (anylong) lo = max(lo, ~xwg_min((islong && pend <= top) ? ~pend : 0xFFFFFFFFu, s_red));
+    const u32 cnt = top - lo, w0 = lo >> 5;
+    {
+      const XVec4<Elem> *E4 = reinterpret_cast<const XVec4<Elem> *>(E) + (lo >> 2);
+      for (u32 q = tid; q < (cnt >> 2); q += 256u) sE4[q] = E4[q];
+      if (tid <= ((top - 1u) >> 5) - w0) sP[tid] = spost[w0 + tid];
+    }
+    __syncthreads();
+#if XF_ABLATE == 4
+    if (cur > lo && cur <= top && cur != 0u) cur = max(a, lo) == a ? 0u : max(a, lo);
+#endif
+    if (cur > lo && cur <= top && cur != 0u) {
+      const u32 stop = max(a, lo);
+      for (u32 sg = cur - 4u;; sg -= 4u) {  // group of the slots sg .. sg + 3
+        const u32 q = sg - lo;
+        const XVec4<Elem> ev = sE4[q >> 2];
+        u32 skip = (sP[(sg >> 5) - w0] >> (sg & 31u)) & 0xFu;  // post slots; and the slots from the tail on keep the value
+        if (sg + 3u >= tail) skip |= sg >= tail ? 0xFu : (~((1u << (tail - sg)) - 1u) & 0xFu);
+        XVec4<V> r;
+        V tt = t;
+        bool bad = !Op::FAST;
+        if (Op::FAST) {
+#pragma unroll
+          for (int j = 3; j >= 0; --j) {
+            const bool sk = ((skip >> j) & 1u) != 0;
+            bad |= !sk && op.dspecial(ev.v[j], tt);
+            const V f = op.dfold_fast(ev.v[j], tt);
+            tt = sk ? tt : f;
+            r.v[j] = tt;
+          }
+        }
+        if (bad) {
+          tt = t;
+#pragma unroll
+          for (int j = 3; j >= 0; --j) {
+            const V f = op.dfold(ev.v[j], tt);
+            tt = ((skip >> j) & 1u) ? tt : f;
+            r.v[j] = tt;
+          }
+        }
+        t = tt;
+        sR4[q >> 2] = r;
+        if (sg == stop) break;
+      }
+      cur = stop == a ? 0u : stop;
+    }
+    __syncthreads();
+    XVec4<V> *R4 = reinterpret_cast<XVec4<V> *>(R) + (lo >> 2);
+    for (u32 q = tid; q < (cnt >> 2); q += 256u) R4[q] = sR4[q];
+  }
+}
+
 template <class Op>
 __global__ void __launch_bounds__(256) k_xtrunk_dscatter(Op op, const u32 *__restrict__ scell,
                                                          const uint16_t *__restrict__ sinfo, u32 s0, u32 s1,
                                                          const typename Op::V *__restrict__ R) {
-  const u32 s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 s = s0 + pfd_block_1d() * blockDim.x + threadIdx.x;
   if (s >= s1) return;
   const u32 info = sinfo[s];  // (three independent loads, then the decision)
   const u32 x = scell[s];
@@ -1408,6 +1774,8 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
     ++launches;
   }
   bool joined = bsplit < 0;
+  // (PFD_DSCAN_LDS=1: the LDS form for every operation — the tests run all of them through it)
+  const bool lds_scan = !pfd_knob("PFD_DSCAN_GLOBAL") && (Op::DSCAN_LDS || pfd_knob("PFD_DSCAN_LDS"));
   for (int b = 31; b >= 0; --b) {
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
     if (c1 == c0) continue;
@@ -1416,6 +1784,16 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
       joined = true;
     }
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
+    // the short chains through LDS (k_xtrunk_dscan_lds) where a round is mostly short chains and does not run beside the
+    // raster-order gather; PFD_DSCAN_GLOBAL: the lane-per-chain fold from global memory everywhere
+    if (lds_scan && (u64)nl * 16u <= (u64)(c1 - c0) && (bsplit < 0 || b < bsplit)) {
+      k_xtrunk_dscan_lds<Op><<<nl + cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
+                                                                                p->longc + p->b_long[b], nl, p->scell, p->spost,
+                                                                                h->ncode, h->geo, p->lh, p->cslot, E.as<Elem>(),
+                                                                                R.as<V>());
+      ++launches;
+      continue;
+    }
     k_xtrunk_dscan<Op><<<nl + cdiv_u32(c1 - c0, 64), 64, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
                                                                          p->longc + p->b_long[b], nl, p->scell, p->spost,
                                                                          h->ncode, h->geo, p->lh, p->cslot, E.as<Elem>(),

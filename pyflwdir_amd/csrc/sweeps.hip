@@ -477,6 +477,9 @@ struct AccuUp {
   // speculative form (exact_sweep.h): a plain add is the exact result whenever neither operand is the nodata value
   static constexpr bool FAST = true;
   static constexpr bool FAST_CONST = false;  // (fold_fast leaves the running value unchanged whatever the element)
+  // gather + fold of the short chains in one kernel (k_xtrunk_prescan): the gather is the bound, the fold hides under it
+  static constexpr bool FUSE_UP = true;
+  static constexpr bool FAST_SHORT = true;  // (the lane-per-chain fold of the short chains speculates too)
   __device__ __forceinline__ bool special(T t, T e) const { return has_nodata && ((t == nodata) | (e == nodata)); }
   __device__ __forceinline__ T fold_fast(T t, T e) const { return Num<T>::add(e, t); }
 };
@@ -511,6 +514,7 @@ struct AccuDown {
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
   static constexpr bool DTILE4 = true;  // (quad form, loads only: see Hand)
+  static constexpr bool DSCAN_LDS = false;
   struct DQuad {
     T d[4];
   };
@@ -691,6 +695,16 @@ struct Strahler {
   // inside the mask and its order exceeds that of the light cells); anything else redoes the block exactly
   static constexpr bool FAST = true;
   static constexpr bool FAST_CONST = true;   // (fold_fast leaves the running value unchanged whatever the element)
+  // the fused gather + fold LOSES here (7.95 -> 8.3 ms at 30000^2): the exact fold of the short chains is branchy VALU work
+  // — half of a bulk round's time with the gather switched off — and one lane per chain of a 256-thread workgroup does
+  // it while the other lanes wait at the chunk's barrier; the two-kernel form folds in 64-thread workgroups, 32 waves a CU
+  static constexpr bool FUSE_UP = false;
+  // short headwater chains meet streams of their own order all the time (special: the order rises) and a block is redone
+  // exactly when ANY lane of the wave met one: the short chains fold exactly right away
+#ifndef STRAHLER_FAST_SHORT
+#define STRAHLER_FAST_SHORT false
+#endif
+  static constexpr bool FAST_SHORT = STRAHLER_FAST_SHORT;
   __device__ __forceinline__ bool special(u32 t, u32 e) const {
     return !(e & 0x80000000u) && !((e & (1u << 10)) && t > (e & 0xFFu));
   }
@@ -764,6 +778,9 @@ struct Hand {
   // the same for a whole quad inside the raster, loads only — unconditional, so that k_xtile_down has the loads of all
   // its 16 cells in flight at once (a load inside a per-cell branch is waited for on the spot: 32 round trips)
   static constexpr bool DTILE4 = true;
+  // the short chains of a round folded through LDS (k_xtrunk_dscan_lds): the bulk rounds 3.60 -> 3.33 ms at 30000^2 here
+  // (16 bytes per slot; the lane-per-chain kernel holds 203 VGPRs: 2 waves per SIMD); no gain for the 4-byte sweeps
+  static constexpr bool DSCAN_LDS = true;
   struct DQuad {
     u32 d4;
     E ev[4], dn[4];
@@ -821,6 +838,7 @@ struct Flood {
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
   static constexpr bool DTILE4 = false;
+  static constexpr bool DSCAN_LDS = false;
   static constexpr bool FAST = false;
   static constexpr bool FAST_CONST = false;  // (fold_fast leaves the running value unchanged whatever the element)
   __device__ __forceinline__ FloodV top(u32 p) const { return state[p]; }
@@ -1923,6 +1941,7 @@ struct Classic {
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
   static constexpr bool DTILE4 = false;
+  static constexpr bool DSCAN_LDS = false;
   __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
   __device__ __forceinline__ u32 dtroot(DElem e, bool) const { return droot(e); }
   __device__ __forceinline__ u32 dtfold(DElem e, bool, u32 pv) const { return dfold(e, pv); }
@@ -1978,6 +1997,7 @@ struct Dist {
   typedef DElem DTile;
   static constexpr bool DTILE_FLAG = false;
   static constexpr bool DTILE4 = false;
+  static constexpr bool DSCAN_LDS = false;
   __device__ __forceinline__ DElem dtile(u32 x, u32 code, bool &) const { return dpre(x, code); }
   __device__ __forceinline__ T dtroot(DElem e, bool) const { return droot(e); }
   __device__ __forceinline__ T dtfold(DElem e, bool, T pv) const { return dfold(e, pv); }

@@ -190,16 +190,23 @@ def test_both_level3_forms_of_a_small_raster(gpu_lib, oracle, monkeypatch, hyper
             h.close()
 
 
-@pytest.mark.parametrize("engine", ["exact", "levels"])
+@pytest.mark.parametrize("engine", ["exact", "levels", "exact:PFD_SCAN_UNFUSED", "exact:PFD_TAILS_RASTER",
+                                    "exact:PFD_ROUNDS_EARLY", "exact:PFD_DSCAN_LDS", "exact:PFD_DSCAN_GLOBAL"])
 def test_exact_engine_accuflux(gpu_lib, oracle, monkeypatch, engine):
     """float / int accuflux through the exact-order engine (tile leaves + heavy-chain trunk, exact.hip) and,
     forced by PFD_EXACT_LEVELS=1, through the level engine: both bit-identical to the reference's serial
-    loop, with and without in-domain nodata, rasters spanning many tiles."""
+    loop, with and without in-domain nodata, rasters spanning many tiles.  The exact engine in its default form
+    (chain ends listed tile by tile, gather + fold of the short chains fused in k_xtrunk_prescan) and with each of the
+    round-6 choices switched the other way: the two-kernel gather / fold, the raster-ordered chain list, the "earliest
+    round" labels of the short chains, the down-fold of the short chains through LDS for every operation / for none."""
     import pyflwdir_amd as pyflwdir
 
     O = oracle
     if engine == "levels":
         monkeypatch.setenv("PFD_EXACT_LEVELS", "1")
+    if ":" in engine:
+        engine, knob = engine.split(":")
+        monkeypatch.setenv(knob, "1")
     for shape, seed, kw in [((1500, 2100), 3, dict(tilt=1 << 26, white=2, nodata_pct=0)),
                             ((1024, 1024), 4, dict(tilt=100000, white=2, nodata_pct=30)),
                             ((700, 900), 5, dict(tilt=3000, white=2, nodata_pct=3))]:
@@ -224,6 +231,11 @@ def test_exact_engine_accuflux(gpu_lib, oracle, monkeypatch, engine):
         assert np.array_equal(flw.accuflux(wl.reshape(shape)).ravel(), O.accuflux(idxs_ds, seq, wl))
         assert np.array_equal(flw.accuflux(w.reshape(shape), direction="down").ravel(),
                               O.accuflux(idxs_ds, seq, w, direction="down"))
+        assert np.array_equal(flw.stream_order().ravel(), O.strahler_order(idxs_ds, seq))
+        elev = O.synth_elev_f32(shape[0], shape[1], seed=seed, **kw)
+        drain = (np.arange(d8.size) % 97 == 0).reshape(shape)
+        assert np.array_equal(flw.hand(drain, elev).ravel(),
+                              O.height_above_nearest_drain(idxs_ds, seq, drain.ravel(), elev.ravel()))
 
 
 def test_basins_outlet_on_a_cycle(gpu_lib, oracle):
