@@ -503,28 +503,39 @@ StreamPool &streams() {
   return p;
 }
 }  // namespace
-static int acquire_stream(int device, hipStream_t *out) {
+// (low: a stream of the lowest priority — the handle's SECOND stream, whose bandwidth pass runs beside latency-bound rounds
+//  of the first: the rounds' few waves must not queue behind the pass's workgroups.  Pool key: device, or -1 - device)
+static int acquire_stream(int device, hipStream_t *out, bool low = false) {
   StreamPool &p = streams();
   {
     std::lock_guard<std::mutex> g(p.mu);
-    auto &v = p.idle[device];
+    auto &v = p.idle[low ? -1 - device : device];
     if (!v.empty()) {
       *out = v.back();
       v.pop_back();
       return PFD_OK;
     }
   }
+  if (low) {
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, least));
+    return PFD_OK;
+  }
   HIPCHK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
   return PFD_OK;
 }
-static void release_stream(int device, hipStream_t s) {
+static void release_stream(int device, hipStream_t s, bool low = false) {
   StreamPool &p = streams();
   std::lock_guard<std::mutex> g(p.mu);
-  p.idle[device].push_back(s);
+  p.idle[low ? -1 - device : device].push_back(s);
 }
 
 int pfd_aux_stream(pfd_raster *h) {
-  if (!h->stream2) PFDCHK(acquire_stream(h->device, &h->stream2));
+  if (!h->stream2) {
+    h->stream2_low = !pfd_knob("PFD_AUX_PRIORITY_SAME");
+    PFDCHK(acquire_stream(h->device, &h->stream2, h->stream2_low));
+  }
   if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   if (!h->ev_join) HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   return PFD_OK;
@@ -631,7 +642,7 @@ static void free_handle(pfd_raster *h) {
   pfd_dfree(h->ctrl);
   if (h->stream2) {
     (void)hipStreamSynchronize(h->stream2);
-    release_stream(h->device, h->stream2);
+    release_stream(h->device, h->stream2, h->stream2_low);
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);

@@ -155,6 +155,7 @@ struct pfd_raster {
   // a second stream + two events (pfd_aux_stream, created on first use): work that may run beside the latency-bound last
   // rounds of an exact-order up-sweep (run_exact_up)
   hipStream_t stream2 = nullptr;
+  bool stream2_low = false;  // (it came from the pool of lowest-priority streams)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   i64 nrow = 0, ncol = 0, n = 0;  // device raster incl. halo rows (row blocks of a multi-GPU job)
   i64 halo_top = 0, halo_bot = 0, own_rows = 0;  // owned rows = [halo_top, halo_top + own_rows)

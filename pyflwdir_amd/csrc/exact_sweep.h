@@ -453,7 +453,10 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
 template <class Op>
 struct XFuse {
   static constexpr u32 B = (u32)(sizeof(typename Op::Elem) + sizeof(typename Op::V));
-  static constexpr u32 CAP = B <= 8 ? 2048u : (B <= 16 ? 1024u : 512u);  // slots per chunk: <= 16 KB of elements + values
+#ifndef XF_CAP4
+#define XF_CAP4 2048u
+#endif
+  static constexpr u32 CAP = B <= 8 ? XF_CAP4 : (B <= 16 ? 1024u : 512u);  // slots per chunk: <= 16 KB of elements + values
 };
 __device__ __forceinline__ u32 xwg_min(u32 v, u32 *s_red) {  // minimum over a 256-thread workgroup (s_red: 4 words, reusable after return)
   for (int o = 32; o > 0; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o));
