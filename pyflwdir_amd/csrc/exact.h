@@ -91,6 +91,7 @@ struct ExactPlan {
 #define XTAIL_LONG 16384u
 // first of the (at most two) last rounds that are latency-bound and hold at most an eighth of the slots, or -1
 inline int xplan_tail_split(const ExactPlan *p) {
+  if (pfd_knob("PFD_TAIL_SPLIT_OFF")) return -1;
   int nb = 0, rounds[32];
   for (int b = 0; b < 32; ++b)
     if (p->b_chain[b + 1] > p->b_chain[b]) rounds[nb++] = b;

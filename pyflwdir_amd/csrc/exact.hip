@@ -470,8 +470,8 @@ __global__ void __launch_bounds__(256) k_plan_depth_round(u32 nt, const u32 *__r
 // ---- rounds of the chains (round 6) ----------------------------------------------------------------------------------
 // Any labelling with label(chain) < label(chain it joins) is a valid order of the rounds.  "As late as possible" — 31 minus
 // the light links below the chain — puts all main stems into the last round, which is what the few LONG chains need (each
-// is folded serially by one wave: they must run side by side, not one round after the other).  But it spreads the ~3e7
-// short headwater chains of a raster over all 13 rounds by how deep in the tree they happen to sit, and every round is a
+// is folded serially by one wave: they must run side by side, not one round after the other).  But it spreads the ~1.3e7
+// short headwater chains of a 30000 x 30000 raster over all 13 rounds by how deep in the tree they happen to sit, and every round is a
 // launch of its own: a 64 x 64 tile's chains are then gathered in 8 - 13 different launches and every launch fetches
 // nearly all lines of the tile's payload for a few hundred slots.  So: a chain of >= XPIN cells keeps the late label
 // (PINNED, bit 7 set so that an atomicMax below 128 never moves it); every other chain takes the EARLIEST round its

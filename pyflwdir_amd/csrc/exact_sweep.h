@@ -450,6 +450,12 @@ __global__ void __launch_bounds__(64) k_xtrunk_scan(Op op, const u32 *__restrict
 #ifndef XF_ABLATE
 #define XF_ABLATE 0  // timing experiments only: 1 = no fold, 2 = no gather (wrong results)
 #endif
+// chains a round must hold to take the workgroup-per-256-chains kernels (k_xtrunk_prescan, k_xtrunk_dscan_lds);
+// PFD_TEST_FUSE_MIN: the tests run rasters of a few million cells through them
+static u32 xfuse_min_chains() {
+  const char *e = pfd_knob("PFD_TEST_FUSE_MIN");
+  return e ? (u32)atoll(e) : (1u << 20);
+}
 template <class Op>
 struct XFuse {
   static constexpr u32 B = (u32)(sizeof(typename Op::Elem) + sizeof(typename Op::V));
@@ -859,6 +865,7 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
   const u32 s_split = bsplit >= 0 ? (u32)p->b_slot[bsplit] : 0xFFFFFFFFu;
   // (a kept sweep needs the element array of every slot: the short chains' elements never leave LDS in the fused form)
   const bool fused = Op::FUSE_UP && !keep && !pfd_knob("PFD_SCAN_UNFUSED");
+  const u32 fuse_min = xfuse_min_chains();
   for (int b = 0; b < 32; ++b) {
     const u32 s0 = (u32)p->b_slot[b], s1 = (u32)p->b_slot[b + 1];
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
@@ -879,7 +886,9 @@ static int run_exact_up(pfd_raster *h, const Op &op, const char *name, int keep 
     // (a round that is mostly long chains — the main stems' — keeps the two-kernel form: nothing to fuse there)
     // and so do the rounds that run beside the raster-order pass on the second stream: the long chains' own gather
     // kernel — a few thousand half-empty workgroups — waits behind that pass's workgroups (1.9 ms measured)
-    if (fused && (u64)nl * 16u <= (u64)(c1 - c0) && (bsplit < 0 || b < bsplit)) {
+    // and a round of fewer than 2^20 chains: 4096 workgroups are two generations of the chip's workgroup slots — below
+    // that the workgroup with the longest run of chunks is the round (10000^2: accuflux 1.79 -> 2.02 ms when every round fused)
+    if (fused && c1 - c0 >= fuse_min && (u64)nl * 16u <= (u64)(c1 - c0) && (bsplit < 0 || b < bsplit)) {
       if (nl) {
         k_xtrunk_pre_long<Op><<<dim3(nl, cdiv_u32(p->b_maxlen[b] + 3u, 1024u)), 256, 0, h->stream>>>(
             op, p->longc + p->b_long[b], p->cstart, p->clen, p->scell, p->sinfo, E);
@@ -1779,6 +1788,7 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
   bool joined = bsplit < 0;
   // (PFD_DSCAN_LDS=1: the LDS form for every operation — the tests run all of them through it)
   const bool lds_scan = !pfd_knob("PFD_DSCAN_GLOBAL") && (Op::DSCAN_LDS || pfd_knob("PFD_DSCAN_LDS"));
+  const u32 fuse_min = xfuse_min_chains();  // (small rounds keep the lane-per-chain kernel: HAND at 10000^2 2.24 -> 2.71 ms otherwise)
   for (int b = 31; b >= 0; --b) {
     const u32 c0 = (u32)p->b_chain[b], c1 = (u32)p->b_chain[b + 1];
     if (c1 == c0) continue;
@@ -1789,7 +1799,7 @@ static int run_exact_down(pfd_raster *h, const Op &op, const char *name) {
     const u32 nl = (u32)(p->b_long[b + 1] - p->b_long[b]);
     // the short chains through LDS (k_xtrunk_dscan_lds) where a round is mostly short chains and does not run beside the
     // raster-order gather; PFD_DSCAN_GLOBAL: the lane-per-chain fold from global memory everywhere
-    if (lds_scan && (u64)nl * 16u <= (u64)(c1 - c0) && (bsplit < 0 || b < bsplit)) {
+    if (lds_scan && c1 - c0 >= fuse_min && (u64)nl * 16u <= (u64)(c1 - c0) && (bsplit < 0 || b < bsplit)) {
       k_xtrunk_dscan_lds<Op><<<nl + cdiv_u32(c1 - c0, 256), 256, 0, h->stream>>>(op, p->cstart, p->clen, c0, c1,
                                                                                 p->longc + p->b_long[b], nl, p->scell, p->spost,
                                                                                 h->ncode, h->geo, p->lh, p->cslot, E.as<Elem>(),

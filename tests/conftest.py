@@ -13,6 +13,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 # the library's test-only switches (PFD_EXACT_LEVELS, PFD_TEST_HCAP, ... forcing a fallback engine or shrinking a
 # capacity) are inert unless this is set before the library is first used
 os.environ.setdefault("PFD_ENABLE_KNOBS", "1")
+# the kernels that take a workgroup per 256 chains of the exact-order engine (k_xtrunk_prescan, k_xtrunk_dscan_lds) are used
+# for rounds of >= 2^20 chains; the test rasters are far smaller, so the suite lowers the threshold and runs EVERYTHING
+# through them (test_gpu_large.py::test_exact_engine_accuflux and the 30000^2 test of test_gpu_fullsize.py run the production
+# threshold: there the rounds lie on both sides of it)
+os.environ.setdefault("PFD_TEST_FUSE_MIN", "1")
 
 
 def pytest_configure(config):

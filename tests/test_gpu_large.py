@@ -191,7 +191,7 @@ def test_both_level3_forms_of_a_small_raster(gpu_lib, oracle, monkeypatch, hyper
 
 
 @pytest.mark.parametrize("engine", ["exact", "levels", "exact:PFD_SCAN_UNFUSED", "exact:PFD_TAILS_RASTER",
-                                    "exact:PFD_ROUNDS_EARLY", "exact:PFD_DSCAN_LDS", "exact:PFD_DSCAN_GLOBAL"])
+                                    "exact:PFD_ROUNDS_EARLY", "exact:PFD_DSCAN_LDS", "exact:PFD_DSCAN_GLOBAL", "exact:PFD_TEST_FUSE_MIN=1048576"])
 def test_exact_engine_accuflux(gpu_lib, oracle, monkeypatch, engine):
     """float / int accuflux through the exact-order engine (tile leaves + heavy-chain trunk, exact.hip) and,
     forced by PFD_EXACT_LEVELS=1, through the level engine: both bit-identical to the reference's serial
@@ -206,7 +206,8 @@ def test_exact_engine_accuflux(gpu_lib, oracle, monkeypatch, engine):
         monkeypatch.setenv("PFD_EXACT_LEVELS", "1")
     if ":" in engine:
         engine, knob = engine.split(":")
-        monkeypatch.setenv(knob, "1")
+        knob, _, val = knob.partition("=")
+        monkeypatch.setenv(knob, val or "1")
     for shape, seed, kw in [((1500, 2100), 3, dict(tilt=1 << 26, white=2, nodata_pct=0)),
                             ((1024, 1024), 4, dict(tilt=100000, white=2, nodata_pct=30)),
                             ((700, 900), 5, dict(tilt=3000, white=2, nodata_pct=3))]:
