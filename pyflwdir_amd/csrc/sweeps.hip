@@ -672,8 +672,14 @@ struct Strahler {
     const u32 o = (u32)(v[0] & 0x7Fu) | ((u32)(v[1] & 0x7Fu) << 8) | ((u32)(v[2] & 0x7Fu) << 16) | ((u32)(v[3] & 0x7Fu) << 24);
     __builtin_memcpy(out + x0, &o, 4);
   }
-  // element: bits 0-7 max order of the light cells inside the mask, 8-9 min(their count of it, 3),
-  // 10 heavy cell inside the mask, 11 own cell inside the mask, 31 post slot (no-op)
+  // element (round 6: the fold as a three-way select).  With m / cnt = the highest order among the light upstream cells inside
+  // the mask and how many hold it, the order of a cell whose heavy upstream cell (inside the mask) has order t is
+  //   t > m: t     t == m: m + 1 (cnt >= 1; m else)     t < m: cnt >= 2 ? m + 1 : m
+  // — three values the gather can compute: bits 0-7 m, 8-15 the value for t == m, 16-23 the value for t < m.  A cell whose
+  // heavy upstream cell lies outside the mask, or that has none (the head of a chain), ignores t: m = 255 and bits 16-23
+  // hold its order (own cell inside the mask and no upstream cell in it: 1; outside: 0).  A post slot passes t through:
+  // the element 0 does that (t > 0: t; t == 0: bits 8-15 = 0).  The fold is two compares and two selects — no branch, a
+  // dependent chain of three instead of a dozen — and the exact fold IS the fast one for the short chains (FAST_SHORT).
   __device__ __forceinline__ u32 pre_real(u32 x, u32 kids, u32 hs) const {
     u32 m = 0, cnt = 0;
 #pragma unroll
@@ -684,37 +690,32 @@ struct Strahler {
     u32 hin = 0;
     if (hs < 8) hin = (mask == nullptr || mask[nb_of(g, x, (int)hs)]) ? 1u : 0u;
     const u32 own = (mask == nullptr || mask[x]) ? 1u : 0u;
-    return m | ((cnt > 3 ? 3u : cnt) << 8) | (hin << 10) | (own << 11);
+    const u32 lt = cnt == 0 ? own : (cnt >= 2 ? m + 1 : m);  // the order without the heavy cell / with a lower one
+    if (!hin) return 255u | (lt << 8) | (lt << 16);
+    const u32 eq = cnt >= 1 ? m + 1 : m;
+    return m | (eq << 8) | ((cnt == 0 ? m : lt) << 16);  // (cnt == 0: m = 0 and t < 0 never happens)
   }
-  __device__ __forceinline__ u32 pre_post(u32) const { return 0x80000000u; }
-  __device__ __forceinline__ u32 first(u32 e) const {
-    const u32 m = e & 0xFFu, cnt = (e >> 8) & 3u;
-    return cnt == 0 ? ((e >> 11) & 1u) : (cnt >= 2 ? m + 1 : m);
-  }
-  // speculative block fold: along a main stem nearly every slot leaves the order unchanged (the heavy cell is
-  // inside the mask and its order exceeds that of the light cells); anything else redoes the block exactly
+  __device__ __forceinline__ u32 pre_post(u32) const { return 0u; }
+  __device__ __forceinline__ u32 first(u32 e) const { return (e >> 16) & 0xFFu; }
+  // speculative block fold (the long chains): along a main stem nearly every slot leaves the order unchanged (the heavy
+  // cell's order exceeds that of the light cells); anything else redoes the block exactly
   static constexpr bool FAST = true;
   static constexpr bool FAST_CONST = true;   // (fold_fast leaves the running value unchanged whatever the element)
-  // the fused gather + fold LOSES here (7.95 -> 8.3 ms at 30000^2): the exact fold of the short chains is branchy VALU work
-  // — half of a bulk round's time with the gather switched off — and one lane per chain of a 256-thread workgroup does
-  // it while the other lanes wait at the chunk's barrier; the two-kernel form folds in 64-thread workgroups, 32 waves a CU
-  static constexpr bool FUSE_UP = false;
-  // short headwater chains meet streams of their own order all the time (special: the order rises) and a block is redone
-  // exactly when ANY lane of the wave met one: the short chains fold exactly right away
-#ifndef STRAHLER_FAST_SHORT
-#define STRAHLER_FAST_SHORT false
+#ifndef STRAHLER_FUSE_UP
+#define STRAHLER_FUSE_UP true
 #endif
-  static constexpr bool FAST_SHORT = STRAHLER_FAST_SHORT;
-  __device__ __forceinline__ bool special(u32 t, u32 e) const {
-    return !(e & 0x80000000u) && !((e & (1u << 10)) && t > (e & 0xFFu));
+  // the fused gather + fold (k_xtrunk_prescan) LOST with the old, branchy fold (7.95 -> 8.3 ms at 30000^2: one lane per chain
+  // doing a dozen dependent VALU steps per slot while its workgroup waits) and WINS with the select form: 7.65 -> 7.1 ms,
+  // C5 shape 16.3 -> 13.7 ms (profiles/r06_ab_strahler_fold.txt)
+  static constexpr bool FUSE_UP = STRAHLER_FUSE_UP;
+  static constexpr bool FAST_SHORT = false;  // the short chains fold exactly right away: nothing to speculate on
+  __device__ __forceinline__ u32 fold(u32 t, u32 e, bool) const {
+    const u32 m = e & 0xFFu;
+    const u32 le = t == m ? (e >> 8) & 0xFFu : (e >> 16) & 0xFFu;
+    return t > m ? t : le;
   }
+  __device__ __forceinline__ bool special(u32 t, u32 e) const { return fold(t, e, false) != t; }
   __device__ __forceinline__ u32 fold_fast(u32 t, u32) const { return t; }
-  __device__ __forceinline__ u32 fold(u32 t, u32 e, bool post) const {
-    if (post) return t;
-    u32 m = e & 0xFFu, cnt = (e >> 8) & 3u;
-    if (e & (1u << 10)) join(t & 0xFFu, m, cnt);
-    return cnt == 0 ? ((e >> 11) & 1u) : (cnt >= 2 ? m + 1 : m);
-  }
 };
 
 template <class L>
