@@ -40,7 +40,9 @@
 // 12-14 number of post slots that follow, 15 = this is a post slot (scell = the upstream cell it carries)
 #define XS_POST 0x8000u
 #define XC_LEN 0x1FFFFFFFu  // clen: length bits
+#ifndef XLONG
 #define XLONG 512u          // a chain of at least this many slots is folded by a whole wave (see k_xtrunk_scan)
+#endif
 
 __host__ __device__ inline bool xl_trunk(u32 m) { return (m & 0xF8u) == XL_TRUNK; }
 
