@@ -1325,9 +1325,13 @@ __global__ void __launch_bounds__(256) k_brow_scatter_delta(const u32 *__restric
                                                             const uint16_t *__restrict__ xcb, const uint16_t *__restrict__ R2L,
                                                             const u32 *__restrict__ sxidL, u32 *__restrict__ T3,
                                                             const u32 *__restrict__ R3, const u32 *__restrict__ hx_id,
-                                                            u32 *__restrict__ T4start) {
+                                                            u32 *__restrict__ T4start, const u64 *__restrict__ ctrl) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 2 * ncol) return;
+  // (a pass without host round trips runs on after a hypertile overflowed its id range — it is about to be redone flat —
+  //  and R3 / hx_id of that hypertile were never written: a lookup through them is an address from uninitialised memory.
+  //  Found by the suite under allocation poisoning, test_a_stage_that_falls_short_is_redone_by_every_rank[PFD_TEST_HCAP])
+  if (ctrl[T_OVERFLOW]) return;
   const u32 v = brow_inflow[t], e = brow_first[t];
   if (!v || e == NONE32 || (e & ENC_SINK)) return;
   atomicAdd(&start[e], v);
@@ -1575,7 +1579,7 @@ int TiledRun::resolve_with_inflow(i64 *launches) {
   u32 *y = l4.as<u32>();
   // (k_brow_scatter + k_brow_delta in one launch; the copy of the level-4 start values and the two clears in another)
   k_brow_scatter_delta<<<cdiv_u32(nb, 256), 256, 0, h->stream>>>(brow_first, brow_inflow, (u32)h->ncol, xT, sa.xmask, sa.xcb, R2L,
-                                                                sxidL, Tc, R3, hx_id, y + 6 * n4cap);
+                                                                sxidL, Tc, R3, hx_id, y + 6 * n4cap, h->ctrl);
   const u32 n3 = (u32)((size_t)nht * HCAP), n4 = (u32)n4cap;
   k_l4_restart<<<std::min(cdiv_u32(std::max(n3, n4), 256), 2048u), 256, 0, h->stream>>>(y + 6 * n4cap, y + n4cap, n4, xin3, n3, h->ctrl);
   *launches += 2;
